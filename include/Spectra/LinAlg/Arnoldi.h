@@ -1,0 +1,198 @@
+// The factorisation  A V = V H + f e'  held in GPU memory.
+//
+// Counterpart of the reference's Arnoldi<ArnoldiOpType> (LinAlg/Arnoldi.h:32-343): same life cycle —
+// init(), factorize_from(from_k, to_m, op_counter), compress, matrix_H(), f_norm(), subspace_dim() —
+// but V (n x m), f and the work vectors never leave HBM.  The class is a thin owner of a `mispec_fac`
+// handle (include/mispec.h); the arithmetic is in spectra_amd/csrc/{csr,krylov,small,fac}.hip.
+//
+// Operators.  If OpType exposes a device matrix (SparseSymMatProd / SparseGenMatProd do, through
+// mispec_matrix()), the factorisation binds it and each step is: all-gather (sharded runs only) ->
+// fused SpMV -> one or two passes over V.  Any other OpType is used through the reference's own
+// contract, perform_op(const Scalar* x_in, Scalar* y_out) on HOST pointers: x is copied out of HBM, the
+// user's code runs, y is copied back in (2 x 8n bytes over PCIe per step) — everything else stays on
+// the device.
+#ifndef MISPEC_SPECTRA_ARNOLDI_H
+#define MISPEC_SPECTRA_ARNOLDI_H
+
+#include <cstdint>
+#include <memory>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "../internal/Dense.h"
+#include "../internal/Device.h"
+
+namespace Spectra {
+
+namespace internal {
+template <typename T, typename = void>
+struct has_device_matrix : std::false_type
+{};
+template <typename T>
+struct has_device_matrix<T, std::void_t<decltype(std::declval<const T&>().mispec_matrix())>> : std::true_type
+{};
+template <typename T, typename = void>
+struct has_device_context : std::false_type
+{};
+template <typename T>
+struct has_device_context<T, std::void_t<decltype(std::declval<const T&>().mispec_context())>> : std::true_type
+{};
+// The context a host-pointer operator wants its Krylov basis on: its own, if it names one.
+template <typename T>
+typename std::enable_if<has_device_context<T>::value, CtxPtr>::type context_of(const T& op)
+{
+    return borrow_context(op.mispec_context());
+}
+template <typename T>
+typename std::enable_if<!has_device_context<T>::value, CtxPtr>::type context_of(const T&)
+{
+    return default_context();
+}
+}  // namespace internal
+
+template <typename OpType>
+class Arnoldi
+{
+public:
+    using Scalar = typename OpType::Scalar;
+
+protected:
+    static_assert(std::is_same<Scalar, double>::value, "the MI355X path computes in fp64: Scalar must be double");
+    using Matrix = DenseMatrix<Scalar>;
+    using Vector = DenseVector<Scalar>;
+
+    const OpType& m_op;
+    const Index m_n;  // dimension of A
+    const Index m_m;  // maximum dimension of the Krylov subspace
+    internal::CtxPtr m_ctx;
+    std::shared_ptr<mispec_fac> m_fac;
+
+    // perform_op of a user operator, called back from inside the library with pinned host buffers.
+    static int call_user_op(void* user, const double* x_in, double* y_out)
+    {
+        try
+        {
+            static_cast<const OpType*>(user)->perform_op(x_in, y_out);
+            return 0;
+        }
+        catch (...)
+        {
+            return 1;
+        }
+    }
+
+    template <typename T = OpType>
+    typename std::enable_if<internal::has_device_matrix<T>::value>::type bind(bool symmetric)
+    {
+        m_ctx = internal::borrow_context(m_op.mispec_context());
+        mispec_fac* raw = nullptr;
+        internal::check(mispec_fac_create(m_ctx.get(), m_op.mispec_matrix(), nullptr, nullptr, m_n, static_cast<int>(m_m),
+                                          symmetric ? 1 : 0, &raw));
+        m_fac = std::shared_ptr<mispec_fac>(raw, [](mispec_fac* p) { (void) mispec_fac_destroy(p); });
+    }
+    template <typename T = OpType>
+    typename std::enable_if<!internal::has_device_matrix<T>::value>::type bind(bool symmetric)
+    {
+        m_ctx = internal::context_of(m_op);
+        mispec_fac* raw = nullptr;
+        internal::check(mispec_fac_create(m_ctx.get(), nullptr, &Arnoldi::call_user_op, const_cast<OpType*>(&m_op), m_n,
+                                          static_cast<int>(m_m), symmetric ? 1 : 0, &raw));
+        m_fac = std::shared_ptr<mispec_fac>(raw, [](mispec_fac* p) { (void) mispec_fac_destroy(p); });
+    }
+
+    Arnoldi(const OpType& op, Index m, bool symmetric) : m_op(op), m_n(op.rows()), m_m(m) { bind(symmetric); }
+
+public:
+    // General (non-symmetric) factorisation: full Gram-Schmidt against V every step (Arnoldi.h:198-295).
+    Arnoldi(const OpType& op, Index m) : Arnoldi(op, m, false) {}
+    virtual ~Arnoldi() {}
+
+    // v <- A v0 / |A v0|, H(0,0), f  (Arnoldi.h:136-195).  v0 has n entries, host memory.
+    void init(const Scalar* v0, Index& op_counter)
+    {
+        std::int64_t cnt = op_counter;
+        internal::check(mispec_fac_init(m_fac.get(), v0, &cnt));
+        op_counter = static_cast<Index>(cnt);
+    }
+    // Same with v0 = SimpleRandom(seed) generated on the device (HermEigsBase.h:337-342 uses seed 0).
+    void init_random(unsigned long seed, Index& op_counter)
+    {
+        std::int64_t cnt = op_counter;
+        internal::check(mispec_fac_init_random(m_fac.get(), seed, &cnt));
+        op_counter = static_cast<Index>(cnt);
+    }
+
+    // Extend the k-step factorisation to to_m steps.
+    virtual void factorize_from(Index from_k, Index to_m, Index& op_counter)
+    {
+        std::int64_t cnt = op_counter;
+        internal::check(mispec_fac_factorize(m_fac.get(), static_cast<int>(from_k), static_cast<int>(to_m), &cnt));
+        op_counter = static_cast<Index>(cnt);
+    }
+
+    Index subspace_dim() const { return mispec_fac_subspace_dim(m_fac.get()); }
+    Scalar f_norm() const
+    {
+        double b = 0;
+        internal::check(mispec_fac_f_norm(m_fac.get(), &b));
+        return b;
+    }
+    Matrix matrix_H() const
+    {
+        Matrix H(m_m, m_m);
+        internal::check(mispec_fac_get_H(m_fac.get(), H.data()));
+        return H;
+    }
+    // Downloads: V is local_rows x m (the whole matrix on an unsharded run).
+    Matrix matrix_V() const
+    {
+        Matrix V(local_rows(), m_m);
+        internal::check(mispec_fac_get_V(m_fac.get(), static_cast<int>(m_m), V.data()));
+        return V;
+    }
+    Vector vector_f() const
+    {
+        Vector f(local_rows());
+        internal::check(mispec_fac_get_f(m_fac.get(), f.data()));
+        return f;
+    }
+    Index local_rows() const { return static_cast<Index>(mispec_fac_local_rows(m_fac.get())); }
+
+    // V[:, :k+1] <- V Q and the matching update of f (Arnoldi.h:320-340) after the caller compressed H on the host.
+    void compress_V(const Matrix& Q, const Matrix& H_compressed, Index new_k)
+    {
+        internal::check(mispec_fac_compress_V(m_fac.get(), Q.data(), H_compressed.data(), static_cast<int>(new_k)));
+    }
+
+    // X = V * Y, Y is m x ncols (HermEigsBase.h:467 / GenEigsBase.h:600); returned on the host.
+    Matrix ritz_vectors(const Matrix& Y) const
+    {
+        Matrix X(local_rows(), Y.cols());
+        if (Y.cols() > 0)
+            internal::check(mispec_fac_ritz_vectors(m_fac.get(), Y.data(), static_cast<int>(Y.cols()), X.data(), nullptr));
+        return X;
+    }
+
+    // Same product left in HBM only (valid until the next call); returns the device pointer, leading dimension in *ld.
+    const Scalar* ritz_vectors_device(const Matrix& Y, Index* ld = nullptr) const
+    {
+        const double* X = nullptr;
+        if (Y.cols() > 0)
+            internal::check(mispec_fac_ritz_vectors(m_fac.get(), Y.data(), static_cast<int>(Y.cols()), nullptr, &X));
+        if (ld)
+        {
+            std::int64_t l = 0;
+            (void) mispec_fac_V_dev(m_fac.get(), &l);
+            *ld = static_cast<Index>(l);
+        }
+        return X;
+    }
+
+    mispec_fac* handle() const { return m_fac.get(); }
+    mispec_ctx* context() const { return m_ctx.get(); }
+};
+
+}  // namespace Spectra
+
+#endif

@@ -1,0 +1,112 @@
+// Dense value types handed back by eigenvalues() / eigenvectors().
+//
+// The reference returns Eigen::Matrix / Eigen::Vector by value (HermEigsBase.h:417, :447).  Eigen 3.4.0
+// is the reference's only dependency and is NOT vendored with it; when <Eigen/Core> is on the include
+// path these aliases ARE the Eigen types, so user code written against Spectra compiles unchanged.
+// Without Eigen (this repository's own build and tests) a minimal column-major container with the
+// same element access (operator(), operator[], data(), rows(), cols(), size(), col()) stands in.
+#ifndef MISPEC_SPECTRA_DENSE_H
+#define MISPEC_SPECTRA_DENSE_H
+
+#include <cstddef>
+#include <vector>
+
+#if !defined(MISPEC_NO_EIGEN) && defined(__has_include)
+#if __has_include(<Eigen/Core>)
+#define MISPEC_HAVE_EIGEN 1
+#include <Eigen/Core>
+#include <Eigen/SparseCore>
+#endif
+#endif
+
+namespace Spectra {
+
+using Index = std::ptrdiff_t;  // Eigen::Index
+
+// Values of Eigen::Lower / Eigen::Upper / Eigen::ColMajor / Eigen::RowMajor, for the Uplo / Flags
+// template parameters of the matrix operators when Eigen itself is not there.
+constexpr int Lower = 1;
+constexpr int Upper = 2;
+constexpr int ColMajor = 0;
+constexpr int RowMajor = 1;
+
+namespace internal {
+
+template <typename T>
+class PlainVector
+{
+    std::vector<T> m_data;
+
+public:
+    PlainVector() {}
+    explicit PlainVector(Index n) : m_data(static_cast<std::size_t>(n)) {}
+    Index size() const { return static_cast<Index>(m_data.size()); }
+    Index rows() const { return size(); }
+    Index cols() const { return 1; }
+    void resize(Index n) { m_data.assign(static_cast<std::size_t>(n), T()); }
+    T& operator[](Index i) { return m_data[static_cast<std::size_t>(i)]; }
+    const T& operator[](Index i) const { return m_data[static_cast<std::size_t>(i)]; }
+    T& operator()(Index i) { return (*this)[i]; }
+    const T& operator()(Index i) const { return (*this)[i]; }
+    T* data() { return m_data.data(); }
+    const T* data() const { return m_data.data(); }
+    const T* begin() const { return m_data.data(); }
+    const T* end() const { return m_data.data() + m_data.size(); }
+};
+
+template <typename T>
+class PlainMatrix  // column-major
+{
+    Index m_rows = 0, m_cols = 0;
+    std::vector<T> m_data;
+
+public:
+    PlainMatrix() {}
+    PlainMatrix(Index r, Index c) : m_rows(r), m_cols(c), m_data(static_cast<std::size_t>(r) * static_cast<std::size_t>(c)) {}
+    Index rows() const { return m_rows; }
+    Index cols() const { return m_cols; }
+    Index size() const { return m_rows * m_cols; }
+    void resize(Index r, Index c)
+    {
+        m_rows = r;
+        m_cols = c;
+        m_data.assign(static_cast<std::size_t>(r) * static_cast<std::size_t>(c), T());
+    }
+    T& operator()(Index i, Index j) { return m_data[static_cast<std::size_t>(j) * m_rows + i]; }
+    const T& operator()(Index i, Index j) const { return m_data[static_cast<std::size_t>(j) * m_rows + i]; }
+    T* data() { return m_data.data(); }
+    const T* data() const { return m_data.data(); }
+    T* col(Index j) { return m_data.data() + static_cast<std::size_t>(j) * m_rows; }
+    const T* col(Index j) const { return m_data.data() + static_cast<std::size_t>(j) * m_rows; }
+};
+
+}  // namespace internal
+
+#ifdef MISPEC_HAVE_EIGEN
+template <typename T>
+using DenseVector = Eigen::Matrix<T, Eigen::Dynamic, 1>;
+template <typename T>
+using DenseMatrix = Eigen::Matrix<T, Eigen::Dynamic, Eigen::Dynamic>;
+#else
+template <typename T>
+using DenseVector = internal::PlainVector<T>;
+template <typename T>
+using DenseMatrix = internal::PlainMatrix<T>;
+#endif
+
+// A borrowed view of a compressed sparse matrix (what an Eigen::SparseMatrix in compressed mode holds):
+// outer[outer_size+1], inner[nnz], values[nnz]; row_major tells whether "outer" runs over rows (CSR)
+// or columns (CSC, Eigen's default).
+template <typename Scalar, typename StorageIndex = int>
+struct SparseView
+{
+    Index rows = 0, cols = 0;
+    const StorageIndex* outer = nullptr;
+    const StorageIndex* inner = nullptr;
+    const Scalar* values = nullptr;
+    bool row_major = false;
+};
+
+}  // namespace Spectra
+
+#endif

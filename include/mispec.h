@@ -1,0 +1,225 @@
+/* =============================================================================
+ *  mispec.h — C ABI of the MI355X-native implicitly-restarted Lanczos/Arnoldi
+ *  hot path (libmispec.so, built from spectra_amd/csrc/ for gfx950).
+ *
+ *  The reference (yixuan/spectra v1.2.0) is header-only C++ and defines NO FFI:
+ *  its plugin boundary is the duck-typed template concept
+ *      OpType::Scalar, rows(), cols(), perform_op(const Scalar*, Scalar*)
+ *  (include/Spectra/SymEigsSolver.h:43-51, MIGRATION.md:11-39).  This header is
+ *  the "thin C-ABI shim" BASELINE.json's north_star asks for: plain pointers and
+ *  sizes, no C++/torch types.  Each entry point names the reference routine it
+ *  replaces (paths relative to /root/reference/include/Spectra/).  The
+ *  Spectra-compatible C++ templates in include/Spectra/ are written on top of
+ *  exactly these functions; INTEGRATION.md shows the binding a Spectra
+ *  maintainer would add.
+ *
+ *  Conventions
+ *    - every function returns int: 0 = ok, <0 = error class (below); the
+ *      message is in mispec_last_error() (thread-local).
+ *    - dense matrices are column-major (like Eigen's default), fp64; sparse
+ *      indices are int32 (StorageIndex=int, SparseSymMatProd.h:30).
+ *    - "_host" pointers are host memory owned by the caller; "_dev" pointers are
+ *      device memory on the context's device.  Handles own everything behind them.
+ *    - a context is bound to one device and one HIP stream; handles are not
+ *      thread-safe (the reference's solver objects are not either).
+ * ============================================================================= */
+#ifndef MISPEC_H
+#define MISPEC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MISPEC_OK 0
+#define MISPEC_EINVAL (-1)   /* bad argument            -> std::invalid_argument (HermEigsBase.h:267-271, Arnoldi.h:148,209) */
+#define MISPEC_ELOGIC (-2)   /* call-order violation    -> std::logic_error      (UpperHessenbergQR.h:207) */
+#define MISPEC_ERUNTIME (-3) /* HIP/RCCL failure, failed small decomposition -> std::runtime_error (TridiagEigen.h:204) */
+
+typedef struct mispec_ctx mispec_ctx; /* device + stream (+ communicator when row-sharded) */
+typedef struct mispec_csr mispec_csr; /* device-resident CSR row shard: the A behind Sparse{Sym,Gen}MatProd */
+typedef struct mispec_fac mispec_fac; /* Lanczos/Arnoldi factorisation A V = V H + f e' (LinAlg/Arnoldi.h:32-62) */
+
+const char* mispec_last_error(void);
+/* "x.y.z (gfx950)" */
+const char* mispec_version(void);
+
+/* ---------------------------------------------------------------------------
+ * Context
+ * ------------------------------------------------------------------------- */
+/* hip_stream: a hipStream_t to launch on (e.g. torch.cuda.current_stream().cuda_stream), or NULL to create one. */
+int mispec_ctx_create(int device, void* hip_stream, mispec_ctx** out);
+int mispec_ctx_destroy(mispec_ctx* ctx);
+int mispec_ctx_sync(mispec_ctx* ctx);
+void* mispec_ctx_stream(mispec_ctx* ctx);
+
+/* Row sharding (the reference has no notion of it).  rank/world and two collectives over
+ * the ranks: an all-gather of equal-sized blocks of doubles (the Krylov vector before each SpMV) and an
+ * in-place sum all-reduce of a few doubles (alpha, |f|^2, V'f).  Both are enqueued on `hip_stream`. */
+typedef struct mispec_comm
+{
+    int rank, world;
+    int (*allgather)(void* user, const double* send_dev, double* recv_dev, int64_t count_per_rank, void* hip_stream);
+    int (*allreduce_sum)(void* user, double* buf_dev, int64_t count, void* hip_stream);
+    void* user;
+} mispec_comm;
+int mispec_ctx_set_comm(mispec_ctx* ctx, const mispec_comm* comm);
+/* Built-in communicator over RCCL (librccl.so.1 is dlopen'ed on first use).  unique_id is the 128-byte
+ * ncclUniqueId produced by mispec_rccl_unique_id() on rank 0 and broadcast by the launcher. */
+int mispec_rccl_unique_id(char out[128]);
+int mispec_ctx_set_comm_rccl(mispec_ctx* ctx, int rank, int world, const char unique_id[128]);
+/* Built-in in-process communicator for `world` host threads sharing one device (tests of the sharded
+ * path on a 1-GPU box).  Returns a group handle; each thread calls _attach with its own ctx and rank. */
+typedef struct mispec_loopback mispec_loopback;
+int mispec_loopback_create(int world, mispec_loopback** out);
+int mispec_loopback_attach(mispec_loopback* grp, mispec_ctx* ctx, int rank);
+int mispec_loopback_destroy(mispec_loopback* grp);
+/* Row range [begin,end) owned by `rank` when n rows are split over `world` ranks in equal blocks of
+ * mispec_shard_block(n, world) rows (the last ranks may be short or empty). Pure host arithmetic. */
+int64_t mispec_shard_block(int64_t n, int world);
+int mispec_shard_range(int64_t n, int world, int rank, int64_t* begin, int64_t* end);
+
+/* ---------------------------------------------------------------------------
+ * Sparse matrix ingest — replaces the Eigen::SparseMatrix held by
+ * SparseSymMatProd / SparseGenMatProd (MatOp/SparseSymMatProd.h:46-60).
+ * The matrix is COPIED to HBM once (the reference keeps an Eigen::Ref).
+ * With a sharded context only rows [begin,end) of mispec_shard_range are kept.
+ * ------------------------------------------------------------------------- */
+/* General CSR (SparseGenMatProd<double, RowMajor>).  rowptr[n_rows+1], colind/val[nnz], host memory. */
+int mispec_csr_upload(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const int32_t* rowptr_host,
+                      const int32_t* colind_host, const double* val_host, mispec_csr** out);
+/* General CSC (SparseGenMatProd<double, ColMajor>, the reference default): transposed to CSR on ingest. */
+int mispec_csr_from_csc(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const int32_t* colptr_host,
+                        const int32_t* rowind_host, const double* val_host, mispec_csr** out);
+/* Symmetric operator from ONE triangle of a compressed matrix: SparseSymMatProd<double, Uplo, Flags>
+ * (MatOp/SparseSymMatProd.h:83-88, selfadjointView<Uplo>).  Entries in the other triangle are ignored
+ * (test/SymEigs.cpp:27-28 relies on that); the triangle is mirrored into a full CSR on ingest.
+ * uplo: 'L' or 'U'.  row_major: 0 = CSC input (Eigen::ColMajor), 1 = CSR input (Eigen::RowMajor). */
+int mispec_csr_from_triangle(mispec_ctx* ctx, int64_t n, const int32_t* outer_host, const int32_t* inner_host,
+                             const double* val_host, char uplo, int row_major, mispec_csr** out);
+/* Synthetic benchmark matrices generated directly in HBM (SURVEY.md §8d "M-band"): row i holds columns
+ * i+off for off in {0} U {+-offsets[k]} inside [0,n); value = counter hash of (seed, min(i,j), max(i,j))
+ * (symmetric) or (seed, i, j) (non-symmetric) mapped to U(-0.5,0.5).  Bit-identical to oracle/synth_matrix.h. */
+int mispec_csr_synth_band(mispec_ctx* ctx, int64_t n, uint64_t seed, const int64_t* offsets, int noff, int symmetric,
+                          mispec_csr** out);
+int mispec_csr_destroy(mispec_csr* A);
+int64_t mispec_csr_rows(const mispec_csr* A);       /* global row count (rows() of the op) */
+int64_t mispec_csr_cols(const mispec_csr* A);       /* global column count */
+int64_t mispec_csr_local_rows(const mispec_csr* A); /* rows held by this shard */
+int64_t mispec_csr_local_nnz(const mispec_csr* A);
+/* A(i,j) of the stored (mirrored) matrix; 0 when absent.  Replaces operator()(i,j) (SparseSymMatProd.h:101-104).
+ * Only rows of this shard can be queried. */
+int mispec_csr_coeff(const mispec_csr* A, int64_t i, int64_t j, double* out);
+/* Download this shard as host CSR (rowptr[local_rows+1], colind/val[local_nnz]; any pointer may be NULL). */
+int mispec_csr_download(const mispec_csr* A, int32_t* rowptr_host, int32_t* colind_host, double* val_host);
+
+/* ---------------------------------------------------------------------------
+ * y = A x — replaces perform_op (MatOp/SparseSymMatProd.h:83-88, SparseGenMatProd.h:82-87).
+ * ------------------------------------------------------------------------- */
+/* Device path: x_dev has cols() doubles (the FULL vector, also when row-sharded), y_dev local_rows(). */
+int mispec_spmv(const mispec_csr* A, const double* x_dev, double* y_dev);
+/* Literal perform_op contract: host pointers, staged through HBM (H2D + kernel + D2H).  Unsharded only. */
+int mispec_spmv_host(const mispec_csr* A, const double* x_host, double* y_host);
+/* Y = A X for a column-major n x k block: operator* (SparseSymMatProd.h:93-96). Host pointers. */
+int mispec_spmm_host(const mispec_csr* A, const double* X_host, int64_t ldx, int k, double* Y_host, int64_t ldy);
+/* Duration (ms, HIP events on the context stream) of the last `reps` back-to-back SpMV launches. */
+int mispec_spmv_time(const mispec_csr* A, const double* x_dev, double* y_dev, int reps, float* ms_per_launch);
+
+/* ---------------------------------------------------------------------------
+ * Factorisation A V = V H + f e' kept in HBM — replaces LinAlg/Arnoldi.h + LinAlg/Lanczos.h.
+ * V is local_rows x ncv column-major, H is ncv x ncv (host copy is authoritative), f is local_rows.
+ * ------------------------------------------------------------------------- */
+/* User operator with the reference's host-pointer contract (slow path: D2H x, call, H2D y per step).
+ * Must return 0 on success. */
+typedef int (*mispec_op_fn)(void* user, const double* x_in_host, double* y_out_host);
+
+/* Exactly one of A / op must be given.  n = rows() of the operator.  symmetric=1: Lanczos (Lanczos.h),
+ * symmetric=0: Arnoldi (Arnoldi.h). */
+int mispec_fac_create(mispec_ctx* ctx, const mispec_csr* A, mispec_op_fn op, void* op_user, int64_t n, int ncv,
+                      int symmetric, mispec_fac** out);
+int mispec_fac_destroy(mispec_fac* fac);
+/* Arnoldi::init (Arnoldi.h:136-195).  v0_host: n doubles (the GLOBAL vector; each shard takes its rows).
+ * *nmatop is incremented once per operator application, like op_counter. */
+int mispec_fac_init(mispec_fac* fac, const double* v0_host, int64_t* nmatop);
+/* HermEigsBase::init() start vector (HermEigsBase.h:337-342): SimpleRandom(seed) generated on the
+ * device by LCG jump-ahead (Util/SimpleRandom.h:30-123), then Arnoldi::init. */
+int mispec_fac_init_random(mispec_fac* fac, uint64_t seed, int64_t* nmatop);
+/* Lanczos::factorize_from / Arnoldi::factorize_from (Lanczos.h:62-187, Arnoldi.h:198-295). */
+int mispec_fac_factorize(mispec_fac* fac, int from_k, int to_m, int64_t* nmatop);
+int mispec_fac_subspace_dim(const mispec_fac* fac);          /* subspace_dim() */
+int mispec_fac_f_norm(const mispec_fac* fac, double* beta);  /* f_norm() */
+int mispec_fac_get_H(const mispec_fac* fac, double* H_host); /* matrix_H(), ncv x ncv col-major */
+int mispec_fac_set_H(mispec_fac* fac, const double* H_host, int k); /* after a host-side compress_H */
+/* matrix_V().leftCols(ncols) / vector_f() of this shard to host (ld = local_rows). */
+int mispec_fac_get_V(const mispec_fac* fac, int ncols, double* V_host);
+int mispec_fac_get_f(const mispec_fac* fac, double* f_host);
+const double* mispec_fac_V_dev(const mispec_fac* fac, int64_t* ld); /* device-resident accessor */
+int64_t mispec_fac_local_rows(const mispec_fac* fac);
+
+/* Ritz pairs of the projected matrix on the device: TridiagEigen::compute (LinAlg/TridiagEigen.h:121-210)
+ * on H(0:ncv,0:ncv) in one workgroup (H and the eigenvector matrix live in LDS).
+ * evals_host[ncv], evecs_host[ncv*ncv] col-major (may be NULL). Symmetric factorisations only. */
+int mispec_fac_tridiag_eigen(mispec_fac* fac, double* evals_host, double* evecs_host);
+/* Implicit restart: for each shift mu (already ordered by the caller, HermEigsBase.h:118-121)
+ *   TridiagQR::compute(H, mu); Q <- Q*Qi (apply_YQ); H <- Qi' H Qi (matrix_QtHQ)   (HermEigsBase.h:124-147,
+ *   UpperHessenbergQR.h:515-598, :383-417, :627-693) — one workgroup, T and Q in LDS —
+ * then Arnoldi::compress_V(Q) (Arnoldi.h:320-340): V[:, :k+1] <- V Q, f <- f Q(m-1,k-1) + V[:,k] H(k,k-1).
+ * On return subspace_dim() == ncv - nshift and H (host copy) is the compressed H. */
+int mispec_fac_restart_sym(mispec_fac* fac, const double* shifts_host, int nshift);
+/* Host-side variant: the caller ran the shifted QR itself and hands over Q (ncv x ncv col-major) and the
+ * compressed H / new k (compress_H already applied): only compress_V runs on the device. */
+int mispec_fac_compress_V(mispec_fac* fac, const double* Q_host, const double* H_host, int new_k);
+/* X = V * Y  (HermEigsBase.h:467, GenEigsBase.h:600).  Y_host: ncv x ncols col-major.
+ * X_host (local_rows x ncols, may be NULL) and/or *X_dev (device buffer owned by fac, valid until the next call). */
+int mispec_fac_ritz_vectors(mispec_fac* fac, const double* Y_host, int ncols, double* X_host, const double** X_dev);
+/* max_j || A x_j - lambda_j x_j ||_2 / || x_j ||_2 over the ncols vectors of the last mispec_fac_ritz_vectors call,
+ * evaluated on the device (parity check at sizes the CPU oracle cannot reach). resid_host[ncols]. */
+int mispec_fac_residuals(mispec_fac* fac, const double* lambda_host, int ncols, double* resid_host);
+
+/* Profile of the factorisation so far: counts and accumulated HIP-event time (ms) per kernel family.
+ * Timing is only collected between mispec_fac_profile(fac, 1) and mispec_fac_profile(fac, 0). */
+typedef struct mispec_profile
+{
+    int64_t n_spmv, n_vtf, n_gemv, n_scale, n_compress, n_small, n_host_sync;
+    double ms_spmv, ms_vtf, ms_gemv, ms_scale, ms_compress, ms_small;
+    double spmv_bytes; /* algorithmic bytes per SpMV launch of this shard: 12*nnz + 4*(rows+1) + 8*cols + 8*rows */
+} mispec_profile;
+int mispec_fac_profile(mispec_fac* fac, int enable);
+int mispec_fac_get_profile(const mispec_fac* fac, mispec_profile* out);
+
+/* ---------------------------------------------------------------------------
+ * Stand-alone small dense kernels (unit-test entry points mirroring test/QR.cpp, test/Eigen.cpp):
+ * one workgroup, matrices in LDS.  All matrices n x n column-major host memory; outputs may be NULL.
+ * ------------------------------------------------------------------------- */
+int mispec_tridiag_qr(mispec_ctx* ctx, int n, const double* T_host, double shift, double* Q_host, double* QtHQ_host);
+int mispec_tridiag_eigen(mispec_ctx* ctx, int n, const double* T_host, double* evals_host, double* evecs_host);
+
+/* ---------------------------------------------------------------------------
+ * Solver-level facade: Spectra::SymEigsSolver<Spectra::SparseSymMatProd<double>> (include/Spectra/)
+ * instantiated inside the library, for bindings that cannot instantiate C++ templates (ctypes, cgo...).
+ * Argument meaning and defaults as HermEigsBase.h:257-272, :309-342, :366-390, :395-478.
+ * selection / sorting use the integer values of Spectra::SortRule (Util/SelectionRule.h:33-58).
+ * ------------------------------------------------------------------------- */
+typedef struct mispec_symeigs mispec_symeigs;
+int mispec_symeigs_create(mispec_ctx* ctx, const mispec_csr* A, int64_t nev, int64_t ncv, mispec_symeigs** out);
+int mispec_symeigs_create_op(mispec_ctx* ctx, mispec_op_fn op, void* op_user, int64_t n, int64_t nev, int64_t ncv,
+                             mispec_symeigs** out);
+int mispec_symeigs_destroy(mispec_symeigs* s);
+int mispec_symeigs_init(mispec_symeigs* s, const double* v0_host /* NULL = init() */);
+int mispec_symeigs_compute(mispec_symeigs* s, int selection, int64_t maxit, double tol, int sorting, int64_t* nconv);
+int mispec_symeigs_info(const mispec_symeigs* s);            /* Spectra::CompInfo as int */
+int64_t mispec_symeigs_num_iterations(const mispec_symeigs* s);
+int64_t mispec_symeigs_num_operations(const mispec_symeigs* s);
+int mispec_symeigs_eigenvalues(const mispec_symeigs* s, double* out_host, int64_t* count);
+/* out_host: local_rows x min(nvec, nconv) col-major (may be NULL to keep the result on the device only). */
+int mispec_symeigs_eigenvectors(mispec_symeigs* s, int64_t nvec, double* out_host, int64_t* ncols);
+/* Residuals ||A x - lambda x|| / ||x|| of the converged pairs, computed on the device. */
+int mispec_symeigs_residuals(mispec_symeigs* s, double* resid_host, int64_t* count);
+int mispec_symeigs_get_profile(const mispec_symeigs* s, mispec_profile* out);
+int mispec_symeigs_profile(mispec_symeigs* s, int enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MISPEC_H */

@@ -1,0 +1,357 @@
+"""TEST INFRASTRUCTURE — ctypes binding of the CPU oracle (oracle/liboracle.so).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this package.  The product (spectra_amd/, include/) never does.
+
+The oracle is an Eigen-free C++ restatement of yixuan/spectra v1.2.0's
+symmetric IRLM path; see oracle/spectra_oracle.hpp for the file:line map and
+the pinning status.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+# Util/SelectionRule.h:33-58 (same enumerator order)
+LargestMagn, LargestReal, LargestImag, LargestAlge, SmallestMagn, SmallestReal, SmallestImag, SmallestAlge, BothEnds = range(9)
+# Util/CompInfo.h:17-32
+Successful, NotComputed, NotConverging, NumericalIssue = range(4)
+
+
+def build(force=False):
+    """Compile oracle/liboracle.so with the committed Makefile (g++ -O2)."""
+    if force or not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
+        for f in ("oracle_capi.cpp", "spectra_oracle.hpp", "synth_matrix.h")
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        dp = C.POINTER(C.c_double)
+        ip = C.POINTER(C.c_int)
+        lp = C.POINTER(C.c_long)
+        vp = C.c_void_p
+        sig = {
+            "oracle_last_error": (C.c_char_p, []),
+            "oracle_simple_random": (None, [C.c_ulong, C.c_long, dp]),
+            "oracle_lcg_states": (None, [C.c_long, C.c_long, lp]),
+            "oracle_minstd_states": (None, [C.c_long, C.c_long, lp]),
+            "oracle_gen_sparse_data": (C.c_long, [C.c_int, C.c_double, ip, ip, dp]),
+            "oracle_synth_band_csr": (C.c_long, [C.c_long, C.c_ulonglong, lp, C.c_int, C.c_int, ip, ip, dp]),
+            "oracle_synth_value": (C.c_double, [C.c_ulonglong, C.c_ulonglong, C.c_ulonglong]),
+            "oracle_givens": (None, [C.c_double, C.c_double, dp, dp, dp]),
+            "oracle_eigen_make_givens": (None, [C.c_double, C.c_double, dp, dp]),
+            "oracle_tridiag_qr": (C.c_int, [C.c_long, dp, C.c_double, dp, dp, dp]),
+            "oracle_tridiag_eigen": (C.c_int, [C.c_long, dp, dp, dp]),
+            "oracle_argsort": (C.c_int, [C.c_int, dp, C.c_long, lp]),
+            "oracle_op_csc_sym": (vp, [C.c_long, ip, ip, dp, C.c_int]),
+            "oracle_op_csr": (vp, [C.c_long, C.c_long, ip, ip, dp]),
+            "oracle_op_csc": (vp, [C.c_long, C.c_long, ip, ip, dp]),
+            "oracle_op_dense_sym": (vp, [C.c_long, dp]),
+            "oracle_op_dense_gen": (vp, [C.c_long, dp]),
+            "oracle_op_diag": (vp, [C.c_long, dp]),
+            "oracle_op_free": (None, [vp]),
+            "oracle_op_rows": (C.c_long, [vp]),
+            "oracle_op_apply": (None, [vp, dp, dp]),
+            "oracle_op_time": (C.c_double, [vp, dp, dp, C.c_int]),
+            "oracle_fac_create": (vp, [vp, C.c_long, C.c_int]),
+            "oracle_fac_free": (None, [vp]),
+            "oracle_fac_init": (C.c_int, [vp, dp]),
+            "oracle_fac_factorize": (C.c_int, [vp, C.c_long, C.c_long]),
+            "oracle_fac_k": (C.c_long, [vp]),
+            "oracle_fac_nmatop": (C.c_long, [vp]),
+            "oracle_fac_beta": (C.c_double, [vp]),
+            "oracle_fac_get": (None, [vp, dp, dp, dp]),
+            "oracle_symeigs_create": (vp, [vp, C.c_long, C.c_long]),
+            "oracle_symeigs_free": (None, [vp]),
+            "oracle_symeigs_set_shift_invert": (None, [vp, C.c_double]),
+            "oracle_symeigs_init": (C.c_int, [vp, dp]),
+            "oracle_symeigs_compute": (C.c_long, [vp, C.c_int, C.c_long, C.c_double, C.c_int]),
+            "oracle_symeigs_info": (C.c_int, [vp]),
+            "oracle_symeigs_num_iterations": (C.c_long, [vp]),
+            "oracle_symeigs_num_operations": (C.c_long, [vp]),
+            "oracle_symeigs_eigenvalues": (C.c_long, [vp, dp]),
+            "oracle_symeigs_eigenvectors": (C.c_long, [vp, C.c_long, dp]),
+            "oracle_symeigs_time_steps": (C.c_double, [vp, C.c_long, C.c_long, lp]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def _lp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_long))
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _check(rc):
+    if rc == -1:
+        raise ValueError(lib().oracle_last_error().decode())  # std::invalid_argument
+    if rc == -2:
+        raise AssertionError(lib().oracle_last_error().decode())  # std::logic_error
+    if rc < 0:
+        raise RuntimeError(lib().oracle_last_error().decode())  # std::runtime_error
+
+
+# ---------------------------------------------------------------------------------
+def simple_random(n, seed=0):
+    out = np.empty(n)
+    lib().oracle_simple_random(seed, n, _dp(out))
+    return out
+
+
+def lcg_states(seed, count):
+    out = np.empty(count, dtype=np.int64)
+    lib().oracle_lcg_states(seed, count, _lp(out))
+    return out
+
+
+def minstd_states(seed, count):
+    out = np.empty(count, dtype=np.int64)
+    lib().oracle_minstd_states(seed, count, _lp(out))
+    return out
+
+
+def gen_sparse_data(n, prob):
+    """test/SymEigs.cpp:25-42 fixture as COO (rows, cols, vals) — NOT symmetric."""
+    cnt = lib().oracle_gen_sparse_data(n, prob, None, None, None)
+    r = np.empty(cnt, dtype=np.int32)
+    c = np.empty(cnt, dtype=np.int32)
+    v = np.empty(cnt)
+    lib().oracle_gen_sparse_data(n, prob, _ip(r), _ip(c), _dp(v))
+    return r, c, v
+
+
+BAND_OFFSETS = (1, 2, 3, 1000, 1001, 100000, 100001)  # SURVEY §8(d) M-band
+SYNTH_SEED = 20240607
+
+
+def synth_band_csr(n, offsets=BAND_OFFSETS, seed=SYNTH_SEED, symmetric=True):
+    offs = np.ascontiguousarray(offsets, dtype=np.int64)
+    cnt = lib().oracle_synth_band_csr(n, seed, _lp(offs), len(offs), int(symmetric), None, None, None)
+    rowptr = np.empty(n + 1, dtype=np.int32)
+    colind = np.empty(cnt, dtype=np.int32)
+    val = np.empty(cnt)
+    lib().oracle_synth_band_csr(n, seed, _lp(offs), len(offs), int(symmetric), _ip(rowptr), _ip(colind), _dp(val))
+    return rowptr, colind, val
+
+
+def givens(x, y):
+    r, c, s = C.c_double(), C.c_double(), C.c_double()
+    lib().oracle_givens(x, y, C.byref(r), C.byref(c), C.byref(s))
+    return r.value, c.value, s.value
+
+
+def eigen_make_givens(p, q):
+    c, s = C.c_double(), C.c_double()
+    lib().oracle_eigen_make_givens(p, q, C.byref(c), C.byref(s))
+    return c.value, s.value
+
+
+def tridiag_qr(T, shift):
+    """Returns (R, QtHQ, Q) as numpy (n, n) arrays."""
+    T = np.asfortranarray(T, dtype=np.float64)
+    n = T.shape[0]
+    R, D, Q = (np.empty((n, n), order="F") for _ in range(3))
+    _check(lib().oracle_tridiag_qr(n, _dp(T), shift, _dp(R), _dp(D), _dp(Q)))
+    return R, D, Q
+
+
+def tridiag_eigen(T):
+    T = np.asfortranarray(T, dtype=np.float64)
+    n = T.shape[0]
+    ev = np.empty(n)
+    U = np.empty((n, n), order="F")
+    _check(lib().oracle_tridiag_eigen(n, _dp(T), _dp(ev), _dp(U)))
+    return ev, U
+
+
+def argsort(rule, values):
+    v = _f64(values)
+    out = np.empty(len(v), dtype=np.int64)
+    _check(lib().oracle_argsort(rule, _dp(v), len(v), _lp(out)))
+    return out
+
+
+class Op:
+    """A matrix operator of the oracle (the reference's OpType concept)."""
+
+    def __init__(self, handle, n, keep=()):
+        self.h = handle
+        self.n = n
+        self._keep = keep
+
+    @classmethod
+    def csc_sym(cls, n, colptr, rowind, val, lower=True):
+        cp, ri, v = _i32(colptr), _i32(rowind), _f64(val)
+        return cls(lib().oracle_op_csc_sym(n, _ip(cp), _ip(ri), _dp(v), int(lower)), n)
+
+    @classmethod
+    def csr(cls, nr, nc, rowptr, colind, val):
+        rp, ci, v = _i32(rowptr), _i32(colind), _f64(val)
+        return cls(lib().oracle_op_csr(nr, nc, _ip(rp), _ip(ci), _dp(v)), nr)
+
+    @classmethod
+    def csc(cls, nr, nc, colptr, rowind, val):
+        cp, ri, v = _i32(colptr), _i32(rowind), _f64(val)
+        return cls(lib().oracle_op_csc(nr, nc, _ip(cp), _ip(ri), _dp(v)), nr)
+
+    @classmethod
+    def dense_sym(cls, A):
+        A = np.asfortranarray(A, dtype=np.float64)
+        return cls(lib().oracle_op_dense_sym(A.shape[0], _dp(A)), A.shape[0])
+
+    @classmethod
+    def dense_gen(cls, A):
+        A = np.asfortranarray(A, dtype=np.float64)
+        return cls(lib().oracle_op_dense_gen(A.shape[0], _dp(A)), A.shape[0])
+
+    @classmethod
+    def diag(cls, d):
+        d = _f64(d)
+        return cls(lib().oracle_op_diag(len(d), _dp(d)), len(d))
+
+    def rows(self):
+        return self.n
+
+    def cols(self):
+        return self.n
+
+    def perform_op(self, x):
+        x = _f64(x)
+        y = np.empty(self.n)
+        lib().oracle_op_apply(self.h, _dp(x), _dp(y))
+        return y
+
+    def time_op(self, x, reps):
+        x = _f64(x)
+        y = np.empty(self.n)
+        return lib().oracle_op_time(self.h, _dp(x), _dp(y), reps)
+
+    def __del__(self):
+        try:
+            lib().oracle_op_free(self.h)
+        except Exception:
+            pass
+
+
+class Factorization:
+    """LinAlg/Arnoldi.h + LinAlg/Lanczos.h (symmetric=True follows Lanczos::factorize_from)."""
+
+    def __init__(self, op, m, symmetric=True):
+        self.op, self.m, self.n = op, m, op.n
+        self.h = lib().oracle_fac_create(op.h, m, int(symmetric))
+
+    def init(self, v0):
+        v0 = _f64(v0)
+        _check(lib().oracle_fac_init(self.h, _dp(v0)))
+
+    def factorize_from(self, from_k, to_m):
+        _check(lib().oracle_fac_factorize(self.h, from_k, to_m))
+
+    def subspace_dim(self):
+        return lib().oracle_fac_k(self.h)
+
+    def num_operations(self):
+        return lib().oracle_fac_nmatop(self.h)
+
+    def f_norm(self):
+        return lib().oracle_fac_beta(self.h)
+
+    def matrices(self):
+        V = np.empty((self.n, self.m), order="F")
+        H = np.empty((self.m, self.m), order="F")
+        f = np.empty(self.n)
+        lib().oracle_fac_get(self.h, _dp(V), _dp(H), _dp(f))
+        return V, H, f
+
+    def __del__(self):
+        try:
+            lib().oracle_fac_free(self.h)
+        except Exception:
+            pass
+
+
+class SymEigsSolver:
+    """SymEigsSolver.h:133-160 (HermEigsBase.h) on the oracle; same method names as the reference."""
+
+    def __init__(self, op, nev, ncv, sigma=None):
+        self.op, self.nev, self.ncv, self.n = op, nev, min(ncv, op.n), op.n
+        self.h = lib().oracle_symeigs_create(op.h, nev, ncv)
+        if not self.h:
+            raise ValueError(lib().oracle_last_error().decode())
+        if sigma is not None:  # SymEigsShiftSolver.h:190-195 (the op must already be shift-inverted)
+            lib().oracle_symeigs_set_shift_invert(self.h, sigma)
+
+    def init(self, v0=None):
+        v0 = None if v0 is None else _f64(v0)
+        _check(lib().oracle_symeigs_init(self.h, _dp(v0)))
+
+    def compute(self, selection=LargestMagn, maxit=1000, tol=1e-10, sorting=LargestAlge):
+        rc = lib().oracle_symeigs_compute(self.h, selection, maxit, tol, sorting)
+        _check(rc)
+        return rc
+
+    def info(self):
+        return lib().oracle_symeigs_info(self.h)
+
+    def num_iterations(self):
+        return lib().oracle_symeigs_num_iterations(self.h)
+
+    def num_operations(self):
+        return lib().oracle_symeigs_num_operations(self.h)
+
+    def eigenvalues(self):
+        out = np.empty(self.nev)
+        cnt = lib().oracle_symeigs_eigenvalues(self.h, _dp(out))
+        return out[:cnt].copy()
+
+    def eigenvectors(self, nvec=None):
+        nvec = self.nev if nvec is None else nvec
+        out = np.zeros((self.n, max(nvec, 1)), order="F")
+        cnt = lib().oracle_symeigs_eigenvectors(self.h, nvec, _dp(out))
+        return out[:, :cnt].copy(order="F")
+
+    def __del__(self):
+        try:
+            lib().oracle_symeigs_free(self.h)
+        except Exception:
+            pass
+
+
+def time_lanczos_steps(op, ncv, nsteps):
+    """cpu_baseline helper: wall seconds of init() + nsteps Lanczos steps, and the perform_op count."""
+    nops = C.c_long()
+    t = lib().oracle_symeigs_time_steps(op.h, ncv, nsteps, C.byref(nops))
+    return t, nops.value

@@ -1,0 +1,340 @@
+// =============================================================================
+//  TEST INFRASTRUCTURE — C interface (ctypes-friendly) over spectra_oracle.hpp.
+//  Built by oracle/Makefile into oracle/liboracle.so.  See the header of
+//  spectra_oracle.hpp for scope and pinning status.
+// =============================================================================
+#include "spectra_oracle.hpp"
+#include "synth_matrix.h"
+
+#include <chrono>
+#include <cstring>
+#include <random>
+
+using namespace oracle;
+
+namespace {
+thread_local std::string g_err;
+template <typename F>
+int guarded(F&& f)
+{
+    try
+    {
+        f();
+        return 0;
+    }
+    catch (const std::invalid_argument& e)
+    {
+        g_err = e.what();
+        return -1;
+    }
+    catch (const std::logic_error& e)
+    {
+        g_err = e.what();
+        return -2;
+    }
+    catch (const std::exception& e)
+    {
+        g_err = e.what();
+        return -3;
+    }
+}
+}  // namespace
+
+extern "C" {
+
+const char* oracle_last_error() { return g_err.c_str(); }
+
+// ---- Util/SimpleRandom.h ----------------------------------------------------
+void oracle_simple_random(unsigned long seed, long n, double* out)
+{
+    SimpleRandom rng(seed);
+    rng.fill(out, n);
+}
+void oracle_lcg_states(long seed, long count, long* out)
+{
+    long x = seed;
+    for (long i = 0; i < count; i++)
+    {
+        x = lcg_next(x);
+        out[i] = x;
+    }
+}
+// the same LCG through libstdc++ (std::minstd_rand0), as a cross-check of lcg_next
+void oracle_minstd_states(long seed, long count, long* out)
+{
+    std::minstd_rand0 g(static_cast<unsigned long>(seed));
+    for (long i = 0; i < count; i++)
+        out[i] = static_cast<long>(g());
+}
+
+// ---- test/SymEigs.cpp:25-42 gen_sparse_data (libstdc++ RNG, bit-reproducible) --
+// COO triplets in insertion (row-major) order. Call with rows==NULL to count.
+long oracle_gen_sparse_data(int n, double prob, int* rows, int* cols, double* vals)
+{
+    std::default_random_engine gen;
+    gen.seed(0);
+    std::uniform_real_distribution<double> distr(0.0, 1.0);
+    long cnt = 0;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++)
+            if (distr(gen) < prob)
+            {
+                const double v = distr(gen) - 0.5;
+                if (rows)
+                {
+                    rows[cnt] = i;
+                    cols[cnt] = j;
+                    vals[cnt] = v;
+                }
+                cnt++;
+            }
+    return cnt;
+}
+
+// ---- synthetic benchmark matrices ------------------------------
+// Row i holds columns i+off for every signed offset in {0} U {+-offsets[k]} that lands in [0,n),
+// ascending.  rowptr may be NULL to just count.
+long oracle_synth_band_csr(long n, unsigned long long seed, const long* offsets, int noff, int symmetric,
+                           int* rowptr, int* colind, double* val)
+{
+    std::vector<long> offs;
+    offs.push_back(0);
+    for (int k = 0; k < noff; k++)
+    {
+        offs.push_back(offsets[k]);
+        offs.push_back(-offsets[k]);
+    }
+    std::sort(offs.begin(), offs.end());
+    offs.erase(std::unique(offs.begin(), offs.end()), offs.end());
+    long cnt = 0;
+    for (long i = 0; i < n; i++)
+    {
+        if (rowptr)
+            rowptr[i] = static_cast<int>(cnt);
+        for (long o : offs)
+        {
+            const long j = i + o;
+            if (j < 0 || j >= n)
+                continue;
+            if (rowptr)
+            {
+                colind[cnt] = static_cast<int>(j);
+                const uint64_t a = symmetric ? static_cast<uint64_t>(std::min(i, j)) : static_cast<uint64_t>(i);
+                const uint64_t b = symmetric ? static_cast<uint64_t>(std::max(i, j)) : static_cast<uint64_t>(j);
+                val[cnt] = synth_value(seed, a, b);
+            }
+            cnt++;
+        }
+    }
+    if (rowptr)
+        rowptr[n] = static_cast<int>(cnt);
+    return cnt;
+}
+double oracle_synth_value(unsigned long long seed, unsigned long long a, unsigned long long b)
+{
+    return synth_value(seed, a, b);
+}
+
+// ---- LinAlg/Givens.h ----------------------------------------------------------
+void oracle_givens(double x, double y, double* r, double* c, double* s) { givens_rotation(x, y, *r, *c, *s); }
+void oracle_eigen_make_givens(double p, double q, double* c, double* s) { eigen_make_givens(p, q, *c, *s); }
+
+// ---- LinAlg/UpperHessenbergQR.h TridiagQR --------------------------------------
+// T: n x n column-major. Outputs (each may be NULL): R, QtHQ, Q (= I * G1 * G2 ...), all n x n col-major.
+int oracle_tridiag_qr(long n, const double* T, double shift, double* R, double* QtHQ, double* Q)
+{
+    return guarded([&] {
+        Mat M(n, n);
+        std::memcpy(M.a.data(), T, sizeof(double) * n * n);
+        TridiagQR qr;
+        qr.compute(M, shift);
+        if (R)
+        {
+            Mat r = qr.matrix_R();
+            std::memcpy(R, r.a.data(), sizeof(double) * n * n);
+        }
+        if (QtHQ)
+        {
+            Mat d;
+            qr.matrix_QtHQ(d);
+            std::memcpy(QtHQ, d.a.data(), sizeof(double) * n * n);
+        }
+        if (Q)
+        {
+            Mat q(n, n);
+            q.set_identity();
+            qr.apply_YQ(q);
+            std::memcpy(Q, q.a.data(), sizeof(double) * n * n);
+        }
+    });
+}
+
+// ---- LinAlg/TridiagEigen.h ------------------------------------------------------
+int oracle_tridiag_eigen(long n, const double* T, double* evals, double* evecs)
+{
+    return guarded([&] {
+        Mat M(n, n);
+        std::memcpy(M.a.data(), T, sizeof(double) * n * n);
+        TridiagEigen te;
+        te.compute(M);
+        std::memcpy(evals, te.main_diag.data(), sizeof(double) * n);
+        if (evecs)
+            std::memcpy(evecs, te.evecs.a.data(), sizeof(double) * n * n);
+    });
+}
+
+// ---- Util/SelectionRule.h argsort --------------------------------------------------
+int oracle_argsort(int rule, const double* values, long len, long* out)
+{
+    return guarded([&] {
+        std::vector<Index> ind = argsort(static_cast<SortRule>(rule), values, len);
+        for (long i = 0; i < len; i++)
+            out[i] = ind[i];
+    });
+}
+
+// ---- operators ---------------------------------------------------------------------
+void* oracle_op_csc_sym(long n, const int* colptr, const int* rowind, const double* val, int lower)
+{
+    return new SparseSymCsc(n, colptr, rowind, val, lower != 0);
+}
+void* oracle_op_csr(long nr, long nc, const int* rowptr, const int* colind, const double* val)
+{
+    return new SparseCsr(nr, nc, rowptr, colind, val);
+}
+void* oracle_op_csc(long nr, long nc, const int* colptr, const int* rowind, const double* val)
+{
+    return new SparseCsc(nr, nc, colptr, rowind, val);
+}
+void* oracle_op_dense_sym(long n, const double* a) { return new DenseSym(n, a); }
+void* oracle_op_dense_gen(long n, const double* a) { return new DenseGen(n, a); }
+void* oracle_op_diag(long n, const double* d)
+{
+    std::vector<double> dv(d, d + n);
+    return new CallbackOp(n, [dv, n](const double* x, double* y) {
+        for (long i = 0; i < n; i++)
+            y[i] = x[i] * dv[i];
+    });
+}
+void oracle_op_free(void* op) { delete static_cast<Op*>(op); }
+long oracle_op_rows(void* op) { return static_cast<Op*>(op)->rows(); }
+void oracle_op_apply(void* op, const double* x, double* y) { static_cast<Op*>(op)->perform_op(x, y); }
+// mean seconds per perform_op over `reps` applications (cpu_baseline helper)
+double oracle_op_time(void* op, const double* x, double* y, int reps)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < reps; i++)
+        static_cast<Op*>(op)->perform_op(x, y);
+    const auto t1 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double>(t1 - t0).count() / reps;
+}
+
+// ---- LinAlg/Arnoldi.h + Lanczos.h ------------------------------------------------------
+struct FacHandle
+{
+    Factorization fac;
+    bool symmetric;
+    Index nmatop = 0;
+    FacHandle(const Op& op, Index m, bool sym) : fac(op, m), symmetric(sym) {}
+};
+void* oracle_fac_create(void* op, long m, int symmetric)
+{
+    return new FacHandle(*static_cast<Op*>(op), m, symmetric != 0);
+}
+void oracle_fac_free(void* h) { delete static_cast<FacHandle*>(h); }
+int oracle_fac_init(void* h, const double* v0)
+{
+    auto* F = static_cast<FacHandle*>(h);
+    return guarded([&] { F->fac.init(v0, F->nmatop); });
+}
+int oracle_fac_factorize(void* h, long from_k, long to_m)
+{
+    auto* F = static_cast<FacHandle*>(h);
+    return guarded([&] {
+        if (F->symmetric)
+            F->fac.factorize_from_lanczos(from_k, to_m, F->nmatop);
+        else
+            F->fac.factorize_from_arnoldi(from_k, to_m, F->nmatop);
+    });
+}
+long oracle_fac_k(void* h) { return static_cast<FacHandle*>(h)->fac.k; }
+long oracle_fac_nmatop(void* h) { return static_cast<FacHandle*>(h)->nmatop; }
+double oracle_fac_beta(void* h) { return static_cast<FacHandle*>(h)->fac.beta; }
+void oracle_fac_get(void* h, double* V, double* H, double* f)
+{
+    auto* F = static_cast<FacHandle*>(h);
+    if (V)
+        std::memcpy(V, F->fac.V.a.data(), sizeof(double) * F->fac.V.a.size());
+    if (H)
+        std::memcpy(H, F->fac.H.a.data(), sizeof(double) * F->fac.H.a.size());
+    if (f)
+        std::memcpy(f, F->fac.f.data(), sizeof(double) * F->fac.f.size());
+}
+
+// ---- HermEigsBase.h / SymEigsSolver.h / SymEigsShiftSolver.h -----------------------------
+void* oracle_symeigs_create(void* op, long nev, long ncv)
+{
+    SymEigs* s = nullptr;
+    int rc = guarded([&] { s = new SymEigs(*static_cast<Op*>(op), nev, ncv); });
+    return rc == 0 ? s : nullptr;
+}
+void oracle_symeigs_free(void* s) { delete static_cast<SymEigs*>(s); }
+void oracle_symeigs_set_shift_invert(void* s, double sigma)
+{
+    static_cast<SymEigs*>(s)->shift_invert = true;
+    static_cast<SymEigs*>(s)->sigma = sigma;
+}
+int oracle_symeigs_init(void* s, const double* v0)
+{
+    auto* S = static_cast<SymEigs*>(s);
+    return guarded([&] {
+        if (v0)
+            S->init(v0);
+        else
+            S->init();
+    });
+}
+// returns nconv (>= 0) or a negative error code
+long oracle_symeigs_compute(void* s, int selection, long maxit, double tol, int sorting)
+{
+    auto* S = static_cast<SymEigs*>(s);
+    long nconv = 0;
+    int rc = guarded(
+        [&] { nconv = S->compute(static_cast<SortRule>(selection), maxit, tol, static_cast<SortRule>(sorting)); });
+    return rc == 0 ? nconv : rc;
+}
+int oracle_symeigs_info(void* s) { return static_cast<int>(static_cast<SymEigs*>(s)->info); }
+long oracle_symeigs_num_iterations(void* s) { return static_cast<SymEigs*>(s)->niter; }
+long oracle_symeigs_num_operations(void* s) { return static_cast<SymEigs*>(s)->nmatop; }
+long oracle_symeigs_eigenvalues(void* s, double* out)
+{
+    std::vector<double> ev = static_cast<SymEigs*>(s)->eigenvalues();
+    std::memcpy(out, ev.data(), sizeof(double) * ev.size());
+    return static_cast<long>(ev.size());
+}
+long oracle_symeigs_eigenvectors(void* s, long nvec, double* out)
+{
+    Mat X = static_cast<SymEigs*>(s)->eigenvectors(nvec);
+    std::memcpy(out, X.a.data(), sizeof(double) * X.a.size());
+    return X.cols;
+}
+// Bounded timing sample for bench.py's cpu_baseline: init() + factorize_from(1, nsteps+1)
+// on the given op; returns wall seconds and the number of perform_op calls made.
+double oracle_symeigs_time_steps(void* op, long ncv, long nsteps, long* nops_out)
+{
+    Op& O = *static_cast<Op*>(op);
+    const Index n = O.rows();
+    std::vector<double> v0(n);
+    SimpleRandom rng(0);
+    rng.fill(v0.data(), n);
+    Factorization fac(O, ncv);
+    Index nops = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    fac.init(v0.data(), nops);
+    fac.factorize_from_lanczos(1, std::min<Index>(ncv, nsteps + 1), nops);
+    const auto t1 = std::chrono::steady_clock::now();
+    *nops_out = nops;
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+
+}  // extern "C"

@@ -1,0 +1,472 @@
+"""spectra_amd — MI355X-native implicitly-restarted Lanczos eigensolver (drop-in for the Spectra hot path).
+
+Python mirror of the reference's operator / solver interface for the path this repository implements
+(yixuan/spectra v1.2.0, include/Spectra/): `SparseSymMatProd`, `SparseGenMatProd`, `SymEigsSolver`,
+`SortRule`, `CompInfo` — same names, argument meaning and error behaviour — on top of the C ABI of
+`libmispec.so` (include/mispec.h, HIP kernels for gfx950).  The C++ users' entry point is the header-only
+API in include/Spectra/; this module exists for tests, the benchmark and Python callers.
+
+There is NO CPU fallback: constructing a `Context` without a visible HIP device raises.
+"""
+import ctypes as C
+import enum
+
+import numpy as np
+
+from . import _capi
+from ._capi import MispecError, Profile, build_library, check, lib
+
+__all__ = ["SortRule", "CompInfo", "Context", "SparseSymMatProd", "SparseGenMatProd", "SymEigsSolver", "Factorization",
+           "tridiag_qr", "tridiag_eigen", "MispecError", "build_library", "shard_range", "BAND_OFFSETS", "SYNTH_SEED"]
+
+BAND_OFFSETS = (1, 2, 3, 1000, 1001, 100000, 100001)  # SURVEY.md §8(d) "M-band": 15 nnz/row with the diagonal
+SYNTH_SEED = 20240607
+
+
+class SortRule(enum.IntEnum):
+    """Util/SelectionRule.h:33-58 (same order as the C++ enum)."""
+    LargestMagn = 0
+    LargestReal = 1
+    LargestImag = 2
+    LargestAlge = 3
+    SmallestMagn = 4
+    SmallestReal = 5
+    SmallestImag = 6
+    SmallestAlge = 7
+    BothEnds = 8
+
+
+class CompInfo(enum.IntEnum):
+    """Util/CompInfo.h:17-32."""
+    Successful = 0
+    NotComputed = 1
+    NotConverging = 2
+    NumericalIssue = 3
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32)) if a is not None else None
+
+
+def shard_range(n, world, rank):
+    """Rows [begin, end) owned by `rank` (equal even-sized blocks, see mispec_shard_range)."""
+    b, e = C.c_int64(), C.c_int64()
+    check(lib().mispec_shard_range(n, world, rank, C.byref(b), C.byref(e)))
+    return b.value, e.value
+
+
+class Context:
+    """One device + one HIP stream (+ the communicator of a row-sharded run)."""
+
+    def __init__(self, device=0, stream=None):
+        h = C.c_void_p()
+        check(lib().mispec_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
+        self.h = h
+        self.device = int(device)
+        self.rank, self.world = 0, 1
+        self._keep = []
+
+    def sync(self):
+        check(lib().mispec_ctx_sync(self.h))
+
+    @property
+    def stream(self):
+        return lib().mispec_ctx_stream(self.h)
+
+    def set_comm_rccl(self, rank, world, unique_id):
+        check(lib().mispec_ctx_set_comm_rccl(self.h, rank, world, unique_id))
+        self.rank, self.world = rank, world
+
+    def set_comm_callbacks(self, rank, world, allgather, allreduce_sum):
+        """allgather(send_ptr, recv_ptr, count_per_rank, stream) / allreduce_sum(buf_ptr, count, stream) -> 0 on success."""
+        ag = _capi.allgather_fn(lambda user, s, r, cnt, st: int(allgather(s, r, cnt, st) or 0))
+        ar = _capi.allreduce_fn(lambda user, b, cnt, st: int(allreduce_sum(b, cnt, st) or 0))
+        comm = _capi.Comm(rank, world, ag, ar, None)
+        self._keep += [ag, ar, comm]
+        check(lib().mispec_ctx_set_comm(self.h, C.byref(comm)))
+        self.rank, self.world = rank, world
+
+    @staticmethod
+    def rccl_unique_id():
+        buf = C.create_string_buffer(128)
+        check(lib().mispec_rccl_unique_id(buf))
+        return buf.raw
+
+    def __del__(self):
+        try:
+            lib().mispec_ctx_destroy(self.h)
+        except Exception:
+            pass
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+class _DeviceMatrix:
+    """A CSR row shard in HBM (mispec_csr)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self.h = handle
+
+    def rows(self):
+        return lib().mispec_csr_rows(self.h)
+
+    def cols(self):
+        return lib().mispec_csr_cols(self.h)
+
+    def local_rows(self):
+        return lib().mispec_csr_local_rows(self.h)
+
+    def nnz(self):
+        return lib().mispec_csr_local_nnz(self.h)
+
+    def perform_op(self, x_in, y_out=None):
+        """y_out = A * x_in with HOST arrays (the reference's perform_op contract)."""
+        x = _f64(x_in)
+        if x.shape != (self.cols(),):
+            raise ValueError("perform_op: x_in must have cols() entries")
+        y = np.empty(self.rows()) if y_out is None else y_out
+        check(lib().mispec_spmv_host(self.h, _dp(x), _dp(y)))
+        return y
+
+    def __matmul__(self, X):
+        """operator*: A @ X for a dense block (SparseSymMatProd.h:93-96)."""
+        X = np.asarray(X, dtype=np.float64)
+        if X.ndim == 1:
+            return self.perform_op(X)
+        Xf = np.asfortranarray(X)
+        Y = np.empty((self.rows(), X.shape[1]), order="F")
+        check(lib().mispec_spmm_host(self.h, _dp(Xf), Xf.shape[0], X.shape[1], _dp(Y), Y.shape[0]))
+        return Y
+
+    def __call__(self, i, j):
+        """operator()(i, j): coefficient of the (mirrored) operator."""
+        v = C.c_double()
+        check(lib().mispec_csr_coeff(self.h, int(i), int(j), C.byref(v)))
+        return v.value
+
+    def spmv_device(self, x_ptr, y_ptr):
+        """y = A x with raw DEVICE pointers (x: cols() doubles, y: local_rows())."""
+        check(lib().mispec_spmv(self.h, C.c_void_p(x_ptr), C.c_void_p(y_ptr)))
+
+    def spmv_time(self, x_ptr, y_ptr, reps):
+        ms = C.c_float()
+        check(lib().mispec_spmv_time(self.h, C.c_void_p(x_ptr), C.c_void_p(y_ptr), reps, C.byref(ms)))
+        return ms.value
+
+    def algorithmic_bytes(self):
+        return 12.0 * self.nnz() + 4.0 * (self.local_rows() + 1) + 8.0 * self.cols() + 8.0 * self.local_rows()
+
+    def to_host_csr(self):
+        nl, nnz = self.local_rows(), self.nnz()
+        rp = np.empty(nl + 1, dtype=np.int32)
+        ci = np.empty(nnz, dtype=np.int32)
+        v = np.empty(nnz)
+        check(lib().mispec_csr_download(self.h, _ip(rp), _ip(ci), _dp(v)))
+        return rp, ci, v
+
+    def __del__(self):
+        try:
+            lib().mispec_csr_destroy(self.h)
+        except Exception:
+            pass
+
+
+def _compressed(mat):
+    """(rows, cols, outer, inner, values, row_major) of a scipy.sparse CSR/CSC matrix."""
+    fmt = getattr(mat, "format", None)
+    if fmt not in ("csr", "csc"):
+        raise TypeError("expected a scipy.sparse csr_matrix or csc_matrix (compressed storage)")
+    m = mat.copy()
+    m.sum_duplicates()
+    m.sort_indices()
+    return m.shape[0], m.shape[1], _i32(m.indptr), _i32(m.indices), _f64(m.data), fmt == "csr"
+
+
+class SparseSymMatProd(_DeviceMatrix):
+    """MatOp/SparseSymMatProd.h: y = selfadjointView<Uplo>(A) * x; only the `uplo` triangle of A is read."""
+
+    def __init__(self, mat, uplo="L", ctx=None):
+        ctx = ctx or default_context()
+        n, nc, outer, inner, val, row_major = _compressed(mat)
+        if n != nc:
+            raise ValueError("SparseSymMatProd: matrix must be square")
+        h = C.c_void_p()
+        check(lib().mispec_csr_from_triangle(ctx.h, n, _ip(outer), _ip(inner), _dp(val), uplo.encode()[0:1], int(row_major),
+                                             C.byref(h)))
+        super().__init__(ctx, h)
+
+    @classmethod
+    def synth_band(cls, n, offsets=BAND_OFFSETS, seed=SYNTH_SEED, ctx=None):
+        """The synthetic symmetric benchmark matrix of SURVEY.md §8(d), generated directly in HBM."""
+        return _synth(cls, n, offsets, seed, True, ctx)
+
+
+class SparseGenMatProd(_DeviceMatrix):
+    """MatOp/SparseGenMatProd.h: y = A * x for a general sparse A (CSR or CSC input)."""
+
+    def __init__(self, mat, ctx=None):
+        ctx = ctx or default_context()
+        nr, nc, outer, inner, val, row_major = _compressed(mat)
+        h = C.c_void_p()
+        fn = lib().mispec_csr_upload if row_major else lib().mispec_csr_from_csc
+        check(fn(ctx.h, nr, nc, _ip(outer), _ip(inner), _dp(val), C.byref(h)))
+        super().__init__(ctx, h)
+
+    @classmethod
+    def synth_band(cls, n, offsets=BAND_OFFSETS, seed=SYNTH_SEED, ctx=None):
+        return _synth(cls, n, offsets, seed, False, ctx)
+
+
+def _synth(cls, n, offsets, seed, symmetric, ctx):
+    ctx = ctx or default_context()
+    offs = np.ascontiguousarray(offsets, dtype=np.int64)
+    h = C.c_void_p()
+    check(lib().mispec_csr_synth_band(ctx.h, n, seed, offs.ctypes.data_as(C.POINTER(C.c_int64)), len(offs), int(symmetric),
+                                      C.byref(h)))
+    obj = cls.__new__(cls)
+    _DeviceMatrix.__init__(obj, ctx, h)
+    return obj
+
+
+class _UserOp:
+    """Adapter for a Python operator with rows(), cols(), perform_op(x_in) -> y (host numpy arrays)."""
+
+    def __init__(self, op):
+        self.op = op
+        n = op.rows()
+
+        def tramp(user, x_ptr, y_ptr):
+            try:
+                x = np.ctypeslib.as_array(x_ptr, shape=(n,))
+                y = np.ctypeslib.as_array(y_ptr, shape=(n,))
+                y[:] = op.perform_op(x)
+                return 0
+            except Exception:  # noqa: BLE001 - reported through the return code
+                return 1
+
+        self.cb = _capi.op_fn(tramp)
+
+
+class SymEigsSolver:
+    """SymEigsSolver.h:133-160 / HermEigsBase.h: init(), compute(), info(), eigenvalues(), eigenvectors() ..."""
+
+    def __init__(self, op, nev, ncv, ctx=None):
+        self.op = op
+        h = C.c_void_p()
+        if isinstance(op, _DeviceMatrix):
+            self.ctx = op.ctx
+            check(lib().mispec_symeigs_create(self.ctx.h, op.h, int(nev), int(ncv), C.byref(h)))
+            self._user = None
+        else:  # any object with rows(), cols(), perform_op(x) -> y: the reference's OpType concept
+            self.ctx = ctx or default_context()
+            self._user = _UserOp(op)
+            check(lib().mispec_symeigs_create_op(self.ctx.h, self._user.cb, None, int(op.rows()), int(nev), int(ncv),
+                                                 C.byref(h)))
+        self.h = h
+        self.nev, self.ncv = int(nev), int(ncv)
+
+    def init(self, init_resid=None):
+        v0 = None if init_resid is None else _f64(init_resid)
+        if v0 is not None and v0.shape != (self.op.rows(),):
+            raise ValueError("init: the initial residual vector must have n entries")
+        check(lib().mispec_symeigs_init(self.h, _dp(v0)))
+
+    def compute(self, selection=SortRule.LargestMagn, maxit=1000, tol=1e-10, sorting=SortRule.LargestAlge):
+        nconv = C.c_int64()
+        check(lib().mispec_symeigs_compute(self.h, int(selection), int(maxit), float(tol), int(sorting), C.byref(nconv)))
+        return nconv.value
+
+    def info(self):
+        return CompInfo(lib().mispec_symeigs_info(self.h))
+
+    def num_iterations(self):
+        return lib().mispec_symeigs_num_iterations(self.h)
+
+    def num_operations(self):
+        return lib().mispec_symeigs_num_operations(self.h)
+
+    def eigenvalues(self):
+        out = np.empty(self.nev)
+        cnt = C.c_int64()
+        check(lib().mispec_symeigs_eigenvalues(self.h, _dp(out), C.byref(cnt)))
+        return out[:cnt.value].copy()
+
+    def local_rows(self):
+        return self.op.local_rows() if isinstance(self.op, _DeviceMatrix) else self.op.rows()
+
+    def eigenvectors(self, nvec=None, to_host=True):
+        """n x nconv (this shard's rows).  to_host=False leaves the result in HBM and returns the column count."""
+        nvec = self.nev if nvec is None else int(nvec)
+        cnt = C.c_int64()
+        if not to_host:
+            check(lib().mispec_symeigs_eigenvectors(self.h, nvec, None, C.byref(cnt)))
+            return cnt.value
+        out = np.zeros((self.local_rows(), max(min(nvec, self.nev), 1)), order="F")
+        check(lib().mispec_symeigs_eigenvectors(self.h, nvec, _dp(out), C.byref(cnt)))
+        return np.asfortranarray(out[:, :cnt.value])
+
+    def residuals(self):
+        """||A x - lambda x|| / ||x|| of the converged pairs, evaluated on the device."""
+        out = np.empty(self.nev)
+        cnt = C.c_int64()
+        check(lib().mispec_symeigs_residuals(self.h, _dp(out), C.byref(cnt)))
+        return out[:cnt.value].copy()
+
+    def profile(self, enable):
+        check(lib().mispec_symeigs_profile(self.h, int(bool(enable))))
+
+    def get_profile(self):
+        p = Profile()
+        check(lib().mispec_symeigs_get_profile(self.h, C.byref(p)))
+        return p.as_dict()
+
+    def __del__(self):
+        try:
+            lib().mispec_symeigs_destroy(self.h)
+        except Exception:
+            pass
+
+
+class Factorization:
+    """LinAlg/Arnoldi.h + LinAlg/Lanczos.h on the device (mispec_fac), for the L2 parity tests."""
+
+    def __init__(self, op, m, symmetric=True, ctx=None):
+        self.op = op
+        self.m = int(m)
+        h = C.c_void_p()
+        if isinstance(op, _DeviceMatrix):
+            self.ctx = op.ctx
+            self.n = op.rows()
+            check(lib().mispec_fac_create(self.ctx.h, op.h, _capi.op_fn(), None, self.n, self.m, int(symmetric), C.byref(h)))
+            self._user = None
+        else:
+            self.ctx = ctx or default_context()
+            self.n = op.rows()
+            self._user = _UserOp(op)
+            check(lib().mispec_fac_create(self.ctx.h, None, self._user.cb, None, self.n, self.m, int(symmetric), C.byref(h)))
+        self.h = h
+        self.nmatop = C.c_int64(0)
+
+    def init(self, v0):
+        v0 = _f64(v0)
+        check(lib().mispec_fac_init(self.h, _dp(v0), C.byref(self.nmatop)))
+
+    def init_random(self, seed=0):
+        check(lib().mispec_fac_init_random(self.h, seed, C.byref(self.nmatop)))
+
+    def factorize_from(self, from_k, to_m):
+        check(lib().mispec_fac_factorize(self.h, int(from_k), int(to_m), C.byref(self.nmatop)))
+
+    def subspace_dim(self):
+        return lib().mispec_fac_subspace_dim(self.h)
+
+    def num_operations(self):
+        return self.nmatop.value
+
+    def f_norm(self):
+        b = C.c_double()
+        check(lib().mispec_fac_f_norm(self.h, C.byref(b)))
+        return b.value
+
+    def local_rows(self):
+        return lib().mispec_fac_local_rows(self.h)
+
+    def matrix_H(self):
+        H = np.empty((self.m, self.m), order="F")
+        check(lib().mispec_fac_get_H(self.h, _dp(H)))
+        return H
+
+    def matrix_V(self, ncols=None):
+        ncols = self.m if ncols is None else ncols
+        V = np.empty((self.local_rows(), ncols), order="F")
+        check(lib().mispec_fac_get_V(self.h, ncols, _dp(V)))
+        return V
+
+    def vector_f(self):
+        f = np.empty(self.local_rows())
+        check(lib().mispec_fac_get_f(self.h, _dp(f)))
+        return f
+
+    def tridiag_eigen(self):
+        ev = np.empty(self.m)
+        U = np.empty((self.m, self.m), order="F")
+        check(lib().mispec_fac_tridiag_eigen(self.h, _dp(ev), _dp(U)))
+        return ev, U
+
+    def restart_sym(self, shifts):
+        s = _f64(shifts)
+        check(lib().mispec_fac_restart_sym(self.h, _dp(s), len(s)))
+
+    def compress_V(self, Q, H, new_k):
+        Q = np.asfortranarray(Q, dtype=np.float64)
+        H = np.asfortranarray(H, dtype=np.float64)
+        check(lib().mispec_fac_compress_V(self.h, _dp(Q), _dp(H), int(new_k)))
+
+    def ritz_vectors(self, Y):
+        Y = np.asfortranarray(Y, dtype=np.float64)
+        X = np.empty((self.local_rows(), Y.shape[1]), order="F")
+        check(lib().mispec_fac_ritz_vectors(self.h, _dp(Y), Y.shape[1], _dp(X), None))
+        return X
+
+    def residuals(self, lam):
+        lam = _f64(lam)
+        out = np.empty(len(lam))
+        check(lib().mispec_fac_residuals(self.h, _dp(lam), len(lam), _dp(out)))
+        return out
+
+    def profile(self, enable):
+        check(lib().mispec_fac_profile(self.h, int(bool(enable))))
+
+    def get_profile(self):
+        p = Profile()
+        check(lib().mispec_fac_get_profile(self.h, C.byref(p)))
+        return p.as_dict()
+
+    def __del__(self):
+        try:
+            lib().mispec_fac_destroy(self.h)
+        except Exception:
+            pass
+
+
+def tridiag_qr(T, shift, ctx=None):
+    """TridiagQR on the device (single-workgroup LDS kernel): returns (Q, Q'TQ), both (n, n)."""
+    ctx = ctx or default_context()
+    T = np.asfortranarray(T, dtype=np.float64)
+    n = T.shape[0]
+    Q = np.empty((n, n), order="F")
+    D = np.empty((n, n), order="F")
+    check(lib().mispec_tridiag_qr(ctx.h, n, _dp(T), float(shift), _dp(Q), _dp(D)))
+    return Q, D
+
+
+def tridiag_eigen(T, ctx=None):
+    """TridiagEigen on the device: returns (eigenvalues, eigenvectors)."""
+    ctx = ctx or default_context()
+    T = np.asfortranarray(T, dtype=np.float64)
+    n = T.shape[0]
+    ev = np.empty(n)
+    U = np.empty((n, n), order="F")
+    check(lib().mispec_tridiag_eigen(ctx.h, n, _dp(T), _dp(ev), _dp(U)))
+    return ev, U

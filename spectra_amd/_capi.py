@@ -1,0 +1,153 @@
+"""ctypes binding of libmispec.so (the C ABI declared in include/mispec.h).
+
+There is no CPU fallback anywhere in this package: if the shared library is missing, or no HIP
+device is visible when a context is created, an exception is raised.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libmispec.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+MISPEC_OK, MISPEC_EINVAL, MISPEC_ELOGIC, MISPEC_ERUNTIME = 0, -1, -2, -3
+
+
+class MispecError(RuntimeError):
+    """HIP / RCCL failure or a failed small decomposition (std::runtime_error in the C++ API)."""
+
+
+def build_library(force=False, verbose=False):
+    """Compile spectra_amd/libmispec.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j8"] + (["-B"] if force else [])
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or out.returncode != 0:
+        print(out.stdout)
+    if out.returncode != 0:
+        raise RuntimeError("building libmispec.so failed")
+    return LIB_PATH
+
+
+op_fn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))
+allgather_fn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+allreduce_fn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+
+class Comm(C.Structure):
+    _fields_ = [("rank", C.c_int), ("world", C.c_int), ("allgather", allgather_fn), ("allreduce_sum", allreduce_fn),
+                ("user", C.c_void_p)]
+
+
+class Profile(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("n_spmv", "n_vtf", "n_gemv", "n_scale", "n_compress", "n_small", "n_host_sync")] + \
+               [(n, C.c_double) for n in ("ms_spmv", "ms_vtf", "ms_gemv", "ms_scale", "ms_compress", "ms_small", "spmv_bytes")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lp = C.POINTER(C.c_int64)
+_vp = C.c_void_p
+_vpp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); must list every symbol include/mispec.h declares (tests check that)
+SIGNATURES = {
+    "mispec_last_error": (C.c_char_p, []),
+    "mispec_version": (C.c_char_p, []),
+    "mispec_ctx_create": (C.c_int, [C.c_int, _vp, _vpp]),
+    "mispec_ctx_destroy": (C.c_int, [_vp]),
+    "mispec_ctx_sync": (C.c_int, [_vp]),
+    "mispec_ctx_stream": (_vp, [_vp]),
+    "mispec_ctx_set_comm": (C.c_int, [_vp, C.POINTER(Comm)]),
+    "mispec_rccl_unique_id": (C.c_int, [C.c_char_p]),
+    "mispec_ctx_set_comm_rccl": (C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p]),
+    "mispec_loopback_create": (C.c_int, [C.c_int, _vpp]),
+    "mispec_loopback_attach": (C.c_int, [_vp, _vp, C.c_int]),
+    "mispec_loopback_destroy": (C.c_int, [_vp]),
+    "mispec_shard_block": (C.c_int64, [C.c_int64, C.c_int]),
+    "mispec_shard_range": (C.c_int, [C.c_int64, C.c_int, C.c_int, _lp, _lp]),
+    "mispec_csr_upload": (C.c_int, [_vp, C.c_int64, C.c_int64, _ip, _ip, _dp, _vpp]),
+    "mispec_csr_from_csc": (C.c_int, [_vp, C.c_int64, C.c_int64, _ip, _ip, _dp, _vpp]),
+    "mispec_csr_from_triangle": (C.c_int, [_vp, C.c_int64, _ip, _ip, _dp, C.c_char, C.c_int, _vpp]),
+    "mispec_csr_synth_band": (C.c_int, [_vp, C.c_int64, C.c_uint64, _lp, C.c_int, C.c_int, _vpp]),
+    "mispec_csr_destroy": (C.c_int, [_vp]),
+    "mispec_csr_rows": (C.c_int64, [_vp]),
+    "mispec_csr_cols": (C.c_int64, [_vp]),
+    "mispec_csr_local_rows": (C.c_int64, [_vp]),
+    "mispec_csr_local_nnz": (C.c_int64, [_vp]),
+    "mispec_csr_coeff": (C.c_int, [_vp, C.c_int64, C.c_int64, _dp]),
+    "mispec_csr_download": (C.c_int, [_vp, _ip, _ip, _dp]),
+    "mispec_spmv": (C.c_int, [_vp, _vp, _vp]),
+    "mispec_spmv_host": (C.c_int, [_vp, _dp, _dp]),
+    "mispec_spmm_host": (C.c_int, [_vp, _dp, C.c_int64, C.c_int, _dp, C.c_int64]),
+    "mispec_spmv_time": (C.c_int, [_vp, _vp, _vp, C.c_int, C.POINTER(C.c_float)]),
+    "mispec_fac_create": (C.c_int, [_vp, _vp, op_fn, _vp, C.c_int64, C.c_int, C.c_int, _vpp]),
+    "mispec_fac_destroy": (C.c_int, [_vp]),
+    "mispec_fac_init": (C.c_int, [_vp, _dp, _lp]),
+    "mispec_fac_init_random": (C.c_int, [_vp, C.c_uint64, _lp]),
+    "mispec_fac_factorize": (C.c_int, [_vp, C.c_int, C.c_int, _lp]),
+    "mispec_fac_subspace_dim": (C.c_int, [_vp]),
+    "mispec_fac_f_norm": (C.c_int, [_vp, _dp]),
+    "mispec_fac_get_H": (C.c_int, [_vp, _dp]),
+    "mispec_fac_set_H": (C.c_int, [_vp, _dp, C.c_int]),
+    "mispec_fac_get_V": (C.c_int, [_vp, C.c_int, _dp]),
+    "mispec_fac_get_f": (C.c_int, [_vp, _dp]),
+    "mispec_fac_V_dev": (_vp, [_vp, _lp]),
+    "mispec_fac_local_rows": (C.c_int64, [_vp]),
+    "mispec_fac_tridiag_eigen": (C.c_int, [_vp, _dp, _dp]),
+    "mispec_fac_restart_sym": (C.c_int, [_vp, _dp, C.c_int]),
+    "mispec_fac_compress_V": (C.c_int, [_vp, _dp, _dp, C.c_int]),
+    "mispec_fac_ritz_vectors": (C.c_int, [_vp, _dp, C.c_int, _dp, _vpp]),
+    "mispec_fac_residuals": (C.c_int, [_vp, _dp, C.c_int, _dp]),
+    "mispec_fac_profile": (C.c_int, [_vp, C.c_int]),
+    "mispec_fac_get_profile": (C.c_int, [_vp, C.POINTER(Profile)]),
+    "mispec_tridiag_qr": (C.c_int, [_vp, C.c_int, _dp, C.c_double, _dp, _dp]),
+    "mispec_tridiag_eigen": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
+    "mispec_symeigs_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vpp]),
+    "mispec_symeigs_create_op": (C.c_int, [_vp, op_fn, _vp, C.c_int64, C.c_int64, C.c_int64, _vpp]),
+    "mispec_symeigs_destroy": (C.c_int, [_vp]),
+    "mispec_symeigs_init": (C.c_int, [_vp, _dp]),
+    "mispec_symeigs_compute": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_double, C.c_int, _lp]),
+    "mispec_symeigs_info": (C.c_int, [_vp]),
+    "mispec_symeigs_num_iterations": (C.c_int64, [_vp]),
+    "mispec_symeigs_num_operations": (C.c_int64, [_vp]),
+    "mispec_symeigs_eigenvalues": (C.c_int, [_vp, _dp, _lp]),
+    "mispec_symeigs_eigenvectors": (C.c_int, [_vp, C.c_int64, _dp, _lp]),
+    "mispec_symeigs_residuals": (C.c_int, [_vp, _dp, _lp]),
+    "mispec_symeigs_get_profile": (C.c_int, [_vp, C.POINTER(Profile)]),
+    "mispec_symeigs_profile": (C.c_int, [_vp, C.c_int]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded libmispec.so; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "spectra_amd/libmispec.so is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  This package has no CPU fallback.")
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here = header and library out of sync
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    """Map C error classes to the exception types the reference API throws."""
+    if rc == MISPEC_OK:
+        return
+    msg = lib().mispec_last_error().decode(errors="replace")
+    if rc == MISPEC_EINVAL:
+        raise ValueError(msg)  # std::invalid_argument
+    if rc == MISPEC_ELOGIC:
+        raise AssertionError(msg)  # std::logic_error
+    raise MispecError(msg)

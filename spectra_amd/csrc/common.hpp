@@ -1,0 +1,147 @@
+// Shared host-side plumbing of libmispec.so: error propagation across the C ABI,
+// the context object, small RAII helpers.  gfx950 / ROCm only — no CUDA shims.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/mispec.h"
+
+namespace mispec {
+
+// Error carried through the library and turned into (code, thread-local message) at the C boundary.
+struct Error : std::runtime_error
+{
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+void set_last_error(const std::string& msg);
+
+#define MISPEC_HIP(expr)                                                                                   \
+    do                                                                                                     \
+    {                                                                                                      \
+        hipError_t _e = (expr);                                                                            \
+        if (_e != hipSuccess)                                                                              \
+            throw ::mispec::Error(MISPEC_ERUNTIME, std::string(#expr) + ": " + hipGetErrorString(_e) +     \
+                                                       " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
+    } while (0)
+
+#define MISPEC_REQUIRE(cond, msg)                       \
+    do                                                  \
+    {                                                   \
+        if (!(cond))                                    \
+            throw ::mispec::Error(MISPEC_EINVAL, msg);  \
+    } while (0)
+
+// Wrap the body of an extern "C" entry point.
+template <typename F>
+int guarded(F&& f) noexcept
+{
+    try
+    {
+        f();
+        return MISPEC_OK;
+    }
+    catch (const Error& e)
+    {
+        set_last_error(e.what());
+        return e.code;
+    }
+    catch (const std::invalid_argument& e)
+    {
+        set_last_error(e.what());
+        return MISPEC_EINVAL;
+    }
+    catch (const std::logic_error& e)
+    {
+        set_last_error(e.what());
+        return MISPEC_ELOGIC;
+    }
+    catch (const std::exception& e)
+    {
+        set_last_error(e.what());
+        return MISPEC_ERUNTIME;
+    }
+    catch (...)
+    {
+        set_last_error("unknown error");
+        return MISPEC_ERUNTIME;
+    }
+}
+
+// Device buffer owned by a handle.
+template <typename T>
+struct DevBuf
+{
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void alloc(size_t count)
+    {
+        release();
+        if (count)
+            MISPEC_HIP(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+        n = count;
+    }
+    void release()
+    {
+        if (p)
+            (void) hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+// Pinned host buffer (D2H targets of the per-step scalars).
+template <typename T>
+struct PinnedBuf
+{
+    T* p = nullptr;
+    size_t n = 0;
+    PinnedBuf() {}
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    ~PinnedBuf()
+    {
+        if (p)
+            (void) hipHostFree(p);
+    }
+    void alloc(size_t count)
+    {
+        if (p)
+            (void) hipHostFree(p);
+        p = nullptr;
+        MISPEC_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), count * sizeof(T), hipHostMallocDefault));
+        n = count;
+    }
+};
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+}  // namespace mispec
+
+// The context: one device, one stream, optional communicator for the row-sharded path.
+struct mispec_ctx
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cu = 256;
+    // communicator (world == 1: no collectives are ever called)
+    mispec_comm comm{0, 1, nullptr, nullptr, nullptr};
+    void* comm_owner = nullptr;                 // built-in communicator state to free with the ctx
+    void (*comm_owner_free)(void*) = nullptr;
+
+    void make_current() const { MISPEC_HIP(hipSetDevice(device)); }
+    int rank() const { return comm.rank; }
+    int world() const { return comm.world; }
+};

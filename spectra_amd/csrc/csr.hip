@@ -1,0 +1,566 @@
+// CSR ingest, synthetic matrix generation and the fp64 CSR SpMV kernel for gfx950.
+//
+// SpMV design ("CSR-stream", row-block per workgroup, LDS partial products):
+//   * a workgroup of 256 threads owns 256 consecutive rows, i.e. ONE contiguous run of
+//     val/col_ind (~3.8k entries at 15 nnz/row).  All 256 threads stream that run with
+//     16-byte loads (2 x double2 + 1 x int4 per thread per step), gather x[col] and park the
+//     products in LDS — the HBM side is perfectly coalesced whatever the row lengths are;
+//   * after one barrier, thread r adds up row r's products from LDS in storage order, which
+//     is exactly the order of the CPU row-dot (oracle SparseCsr / Eigen's row-major product),
+//     so the result is bit-identical to it (up to FMA contraction in the fused epilogue);
+//   * rows longer than the LDS chunk are handled by looping over chunks, each thread
+//     accumulating the part of its row inside the chunk;
+//   * blockIdx -> row-block map is XCD-aware: hardware sends block b to XCD b%8, so XCD k is
+//     given the k-th contiguous eighth of the rows and its private 4 MiB L2 sees one sliding
+//     window of x instead of eight interleaved ones.
+// Bound: HBM.  Algorithmic bytes per launch: 12*nnz + 4*(rows+1) + 8*cols + 8*rows.
+#include "csr.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+using namespace mispec;
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kCap = 4080;       // products per LDS chunk: (4080+4)*8 B + 32 B <= 32 KiB -> 5 workgroups / CU
+constexpr int kLoadIters = 4;    // 256 threads * 4 entries * 4 steps = 4096 >= kCap + 3
+
+__device__ __forceinline__ double wave_reduce_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Deterministic 256-thread sum; every thread returns the total.
+__device__ __forceinline__ double block_reduce_sum(double v, double* red)
+{
+    v = wave_reduce_sum(v);
+    if ((threadIdx.x & 63) == 0)
+        red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+template <bool EPI>
+__global__ __launch_bounds__(kThreads) void k_spmv_csr_stream(const int32_t* __restrict__ rowptr,
+                                                               const int32_t* __restrict__ colind,
+                                                               const double* __restrict__ val,
+                                                               const double* __restrict__ x, double* __restrict__ y,
+                                                               int64_t nrows, int nblocks, SpmvEpilogue epi)
+{
+    __shared__ __attribute__((aligned(16))) double prod[kCap + 4];
+    __shared__ double red[4];
+
+    // XCD-aware map: gridDim.x == 8 * per; block b runs on XCD b % 8 and takes the (b/8)-th
+    // row-block of that XCD's contiguous range.
+    const int per = (nblocks + 7) >> 3;
+    const int lb = (int(blockIdx.x) & 7) * per + (int(blockIdx.x) >> 3);
+    if (lb >= nblocks)
+        return;
+
+    const int tid = threadIdx.x;
+    const int64_t row0 = int64_t(lb) * kThreads;
+    const int nr = int(min(int64_t(kThreads), nrows - row0));
+    const int bs = rowptr[row0];
+    const int be = rowptr[row0 + nr];
+    int rs = 0, re = 0;
+    if (tid < nr)
+    {
+        rs = rowptr[row0 + tid];
+        re = rowptr[row0 + tid + 1];
+    }
+
+    double acc = 0.0;
+    for (int cs = bs; cs < be;)
+    {
+        const int a0 = cs & ~3;  // 32-byte aligned start for the vector loads
+        const int ce = min(be, a0 + kCap);
+
+        // phase 1: issue every streaming load of this chunk.  No branches: lanes past the end of
+        // the chunk re-read its last aligned group (one broadcast line), so the loads of all
+        // steps are in flight together and waits are counted, not drained.
+        const int last = (ce - 1) & ~3;
+        double2 va[kLoadIters][2];
+        int4 ci[kLoadIters];
+#pragma unroll
+        for (int it = 0; it < kLoadIters; it++)
+        {
+            const int base = min(a0 + tid * 4 + it * (kThreads * 4), last);
+            va[it][0] = *reinterpret_cast<const double2*>(val + base);
+            va[it][1] = *reinterpret_cast<const double2*>(val + base + 2);
+            ci[it] = *reinterpret_cast<const int4*>(colind + base);
+        }
+        // phase 2: gather x
+        double xg[kLoadIters][4];
+#pragma unroll
+        for (int it = 0; it < kLoadIters; it++)
+        {
+            xg[it][0] = x[ci[it].x];
+            xg[it][1] = x[ci[it].y];
+            xg[it][2] = x[ci[it].z];
+            xg[it][3] = x[ci[it].w];
+        }
+        // phase 3: products -> LDS
+#pragma unroll
+        for (int it = 0; it < kLoadIters; it++)
+        {
+            const int base = a0 + tid * 4 + it * (kThreads * 4);
+            if (base < ce)
+            {
+                double2 p0, p1;
+                p0.x = va[it][0].x * xg[it][0];
+                p0.y = va[it][0].y * xg[it][1];
+                p1.x = va[it][1].x * xg[it][2];
+                p1.y = va[it][1].y * xg[it][3];
+                *reinterpret_cast<double2*>(&prod[base - a0]) = p0;
+                *reinterpret_cast<double2*>(&prod[base - a0 + 2]) = p1;
+            }
+        }
+        __syncthreads();
+        // phase 4: thread r sums the part of row r that lies in [cs, ce), in storage order
+        const int lo = max(rs, cs), hi = min(re, ce);
+        for (int k = lo; k < hi; k++)
+            acc += prod[k - a0];
+        cs = ce;
+        if (cs < be)
+            __syncthreads();
+    }
+
+    if (EPI)
+    {
+        double contrib = 0.0;
+        if (tid < nr)
+        {
+            const int64_t row = row0 + tid;
+            double yv = acc;
+            if (epi.v_prev)
+                yv -= epi.h_prev * epi.v_prev[row];  // Lanczos.h:139
+            y[row] = yv;
+            contrib = epi.v_rows[row] * yv;  // Lanczos.h:142 partial <v, w>
+        }
+        const double total = block_reduce_sum(contrib, red);
+        if (tid == 0)
+            epi.partials[lb] = total;
+    }
+    else if (tid < nr)
+        y[row0 + tid] = acc;
+}
+
+// ---- synthetic band matrix, bit-identical to oracle/synth_matrix.h -------------
+__host__ __device__ inline uint64_t synth_mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__host__ __device__ inline double synth_value(uint64_t seed, uint64_t a, uint64_t b)
+{
+    const uint64_t k = synth_mix64(synth_mix64(seed ^ a) ^ (b * 0xD6E8FEB86659FD93ULL));
+    return double(k >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+}
+
+constexpr int kMaxOffsets = 72;
+struct BandSpec
+{
+    int64_t off[kMaxOffsets];  // sorted, unique, signed (contains 0)
+    int count;
+};
+
+// number of stored entries in rows [0, i)
+__host__ __device__ inline int64_t band_prefix(const BandSpec& s, int64_t n, int64_t i)
+{
+    int64_t total = 0;
+    for (int k = 0; k < s.count; k++)
+    {
+        const int64_t o = s.off[k];
+        const int64_t lo = o < 0 ? -o : 0;            // first row with a valid column
+        const int64_t hi = o > 0 ? n - o : n;         // one past the last such row
+        const int64_t top = i < hi ? i : hi;
+        if (top > lo)
+            total += top - lo;
+    }
+    return total;
+}
+
+__global__ void k_synth_band(BandSpec spec, int64_t n, int64_t row_begin, int64_t nloc, int64_t base_nnz, uint64_t seed,
+                             int symmetric, int32_t* __restrict__ rowptr, int32_t* __restrict__ colind,
+                             double* __restrict__ val)
+{
+    const int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (r > nloc)
+        return;
+    const int64_t i = row_begin + r;
+    int64_t p = band_prefix(spec, n, i) - base_nnz;
+    rowptr[r] = int32_t(p);
+    if (r == nloc)
+        return;
+    for (int k = 0; k < spec.count; k++)
+    {
+        const int64_t j = i + spec.off[k];
+        if (j < 0 || j >= n)
+            continue;
+        const uint64_t a = symmetric ? uint64_t(i < j ? i : j) : uint64_t(i);
+        const uint64_t b = symmetric ? uint64_t(i < j ? j : i) : uint64_t(j);
+        colind[p] = int32_t(j);
+        val[p] = synth_value(seed, a, b);
+        p++;
+    }
+}
+
+void alloc_entries(mispec_csr& A, int64_t nnz)
+{
+    MISPEC_REQUIRE(nnz < (int64_t(1) << 31) - 16, "matrix shard has too many non-zeros for int32 row pointers");
+    const size_t cap = size_t(round_up(nnz, 4) + 8);
+    A.colind.alloc(cap);
+    A.val.alloc(cap);
+    MISPEC_HIP(hipMemsetAsync(A.colind.p, 0, cap * sizeof(int32_t), A.ctx->stream));
+    MISPEC_HIP(hipMemsetAsync(A.val.p, 0, cap * sizeof(double), A.ctx->stream));
+    A.nnz = nnz;
+}
+
+// Upload host CSR rows [begin,end) of a global matrix.
+mispec_csr* upload_rows(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const int32_t* rowptr, const int32_t* colind,
+                        const double* val)
+{
+    MISPEC_REQUIRE(ctx && rowptr && n_rows >= 0 && n_cols >= 0, "csr upload: bad argument");
+    MISPEC_REQUIRE(n_cols < (int64_t(1) << 31), "csr upload: column count exceeds int32");
+    ctx->make_current();
+    auto* A = new mispec_csr();
+    try
+    {
+        A->ctx = ctx;
+        A->n_rows = n_rows;
+        A->n_cols = n_cols;
+        int64_t b, e;
+        if (mispec_shard_range(n_rows, ctx->world(), ctx->rank(), &b, &e) != MISPEC_OK)
+            throw Error(MISPEC_EINVAL, mispec_last_error());
+        A->row_begin = b;
+        A->row_end = e;
+        const int64_t nloc = e - b;
+        const int64_t p0 = rowptr[b], p1 = rowptr[e];
+        MISPEC_REQUIRE(p1 >= p0, "csr upload: row pointers must be non-decreasing");
+        alloc_entries(*A, p1 - p0);
+        std::vector<int32_t> rp(size_t(nloc) + 1);
+        for (int64_t i = 0; i <= nloc; i++)
+        {
+            MISPEC_REQUIRE(rowptr[b + i] >= rowptr[b + (i ? i - 1 : 0)], "csr upload: row pointers must be non-decreasing");
+            rp[size_t(i)] = int32_t(rowptr[b + i] - p0);
+        }
+        for (int64_t p = p0; p < p1; p++)
+            MISPEC_REQUIRE(colind[p] >= 0 && colind[p] < n_cols, "csr upload: column index out of range");
+        A->rowptr.alloc(size_t(nloc) + 1);
+        MISPEC_HIP(hipMemcpyAsync(A->rowptr.p, rp.data(), rp.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        if (p1 > p0)
+        {
+            MISPEC_HIP(hipMemcpyAsync(A->colind.p, colind + p0, size_t(p1 - p0) * sizeof(int32_t), hipMemcpyHostToDevice,
+                                      ctx->stream));
+            MISPEC_HIP(hipMemcpyAsync(A->val.p, val + p0, size_t(p1 - p0) * sizeof(double), hipMemcpyHostToDevice,
+                                      ctx->stream));
+        }
+        MISPEC_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    catch (...)
+    {
+        delete A;
+        throw;
+    }
+    return A;
+}
+
+}  // namespace
+
+namespace mispec {
+
+void launch_spmv(const mispec_csr& A, const double* x_dev, double* y_dev, const SpmvEpilogue* epi)
+{
+    const int64_t nloc = A.local_rows();
+    if (nloc == 0)
+        return;
+    const int nblocks = spmv_num_blocks(nloc);
+    const int per = (nblocks + 7) >> 3;
+    const dim3 grid(unsigned(per * 8)), block(kThreads);
+    if (epi)
+        hipLaunchKernelGGL(k_spmv_csr_stream<true>, grid, block, 0, A.ctx->stream, A.rowptr.p, A.colind.p, A.val.p, x_dev,
+                           y_dev, nloc, nblocks, *epi);
+    else
+        hipLaunchKernelGGL(k_spmv_csr_stream<false>, grid, block, 0, A.ctx->stream, A.rowptr.p, A.colind.p, A.val.p, x_dev,
+                           y_dev, nloc, nblocks, SpmvEpilogue{});
+    MISPEC_HIP(hipGetLastError());
+}
+
+}  // namespace mispec
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" int mispec_csr_upload(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const int32_t* rowptr_host,
+                                 const int32_t* colind_host, const double* val_host, mispec_csr** out)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(out, "mispec_csr_upload: out is NULL");
+        MISPEC_REQUIRE(n_rows == 0 || (colind_host && val_host) || rowptr_host[n_rows] == 0, "mispec_csr_upload: NULL arrays");
+        *out = upload_rows(ctx, n_rows, n_cols, rowptr_host, colind_host, val_host);
+    });
+}
+
+extern "C" int mispec_csr_from_csc(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const int32_t* colptr,
+                                   const int32_t* rowind, const double* val, mispec_csr** out)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(ctx && out && colptr, "mispec_csr_from_csc: NULL argument");
+        const int64_t nnz = colptr[n_cols];
+        std::vector<int32_t> rp(size_t(n_rows) + 1, 0), ci(static_cast<size_t>(nnz));
+        std::vector<double> v(static_cast<size_t>(nnz));
+        for (int64_t p = 0; p < nnz; p++)
+        {
+            MISPEC_REQUIRE(rowind[p] >= 0 && rowind[p] < n_rows, "mispec_csr_from_csc: row index out of range");
+            rp[size_t(rowind[p]) + 1]++;
+        }
+        for (int64_t i = 0; i < n_rows; i++)
+            rp[size_t(i) + 1] += rp[size_t(i)];
+        std::vector<int32_t> fill(rp.begin(), rp.end() - 1);
+        for (int64_t j = 0; j < n_cols; j++)  // column order => each row ends up sorted by column
+            for (int32_t p = colptr[j]; p < colptr[j + 1]; p++)
+            {
+                const int32_t q = fill[size_t(rowind[p])]++;
+                ci[size_t(q)] = int32_t(j);
+                v[size_t(q)] = val[p];
+            }
+        *out = upload_rows(ctx, n_rows, n_cols, rp.data(), ci.data(), v.data());
+    });
+}
+
+extern "C" int mispec_csr_from_triangle(mispec_ctx* ctx, int64_t n, const int32_t* outer, const int32_t* inner,
+                                        const double* val, char uplo, int row_major, mispec_csr** out)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(ctx && out && outer, "mispec_csr_from_triangle: NULL argument");
+        MISPEC_REQUIRE(uplo == 'L' || uplo == 'U' || uplo == 'l' || uplo == 'u', "mispec_csr_from_triangle: uplo must be 'L' or 'U'");
+        const bool lower = (uplo == 'L' || uplo == 'l');
+        // Walk the compressed input; (r, c) is the matrix position whatever the storage order.
+        // Keep the entry iff it lies in the requested triangle (selfadjointView<Uplo> ignores the rest).
+        auto for_each_kept = [&](auto&& fn) {
+            for (int64_t o = 0; o < n; o++)
+                for (int32_t p = outer[o]; p < outer[o + 1]; p++)
+                {
+                    const int64_t in = inner[p];
+                    MISPEC_REQUIRE(in >= 0 && in < n, "mispec_csr_from_triangle: index out of range");
+                    const int64_t r = row_major ? o : in, c = row_major ? in : o;
+                    if (lower ? (r >= c) : (r <= c))
+                        fn(r, c, val[p]);
+                }
+        };
+        std::vector<int32_t> rp(size_t(n) + 1, 0);
+        for_each_kept([&](int64_t r, int64_t c, double) {
+            rp[size_t(r) + 1]++;
+            if (r != c)
+                rp[size_t(c) + 1]++;
+        });
+        for (int64_t i = 0; i < n; i++)
+            rp[size_t(i) + 1] += rp[size_t(i)];
+        const int64_t nnz = rp[size_t(n)];
+        std::vector<int32_t> ci(static_cast<size_t>(nnz));
+        std::vector<double> v(static_cast<size_t>(nnz));
+        std::vector<int32_t> fill(rp.begin(), rp.end() - 1);
+        for_each_kept([&](int64_t r, int64_t c, double a) {
+            int32_t q = fill[size_t(r)]++;
+            ci[size_t(q)] = int32_t(c);
+            v[size_t(q)] = a;
+            if (r != c)
+            {
+                q = fill[size_t(c)]++;
+                ci[size_t(q)] = int32_t(r);
+                v[size_t(q)] = a;
+            }
+        });
+        // sort every row by column (the SpMV sums in storage order)
+        std::vector<int32_t> perm;
+        std::vector<int32_t> tc;
+        std::vector<double> tv;
+        for (int64_t i = 0; i < n; i++)
+        {
+            const int32_t s = rp[size_t(i)], e = rp[size_t(i) + 1];
+            if (e - s < 2 || std::is_sorted(ci.begin() + s, ci.begin() + e))
+                continue;
+            perm.resize(size_t(e - s));
+            std::iota(perm.begin(), perm.end(), 0);
+            std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) { return ci[size_t(s + a)] < ci[size_t(s + b)]; });
+            tc.assign(ci.begin() + s, ci.begin() + e);
+            tv.assign(v.begin() + s, v.begin() + e);
+            for (int32_t k = 0; k < e - s; k++)
+            {
+                ci[size_t(s + k)] = tc[size_t(perm[size_t(k)])];
+                v[size_t(s + k)] = tv[size_t(perm[size_t(k)])];
+            }
+        }
+        *out = upload_rows(ctx, n, n, rp.data(), ci.data(), v.data());
+    });
+}
+
+extern "C" int mispec_csr_synth_band(mispec_ctx* ctx, int64_t n, uint64_t seed, const int64_t* offsets, int noff,
+                                     int symmetric, mispec_csr** out)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(ctx && out && n > 0 && noff >= 0 && (noff == 0 || offsets), "mispec_csr_synth_band: bad argument");
+        MISPEC_REQUIRE(n < (int64_t(1) << 31), "mispec_csr_synth_band: n exceeds int32 column indices");
+        std::vector<int64_t> offs{0};
+        for (int k = 0; k < noff; k++)
+        {
+            offs.push_back(offsets[k]);
+            offs.push_back(-offsets[k]);
+        }
+        std::sort(offs.begin(), offs.end());
+        offs.erase(std::unique(offs.begin(), offs.end()), offs.end());
+        MISPEC_REQUIRE(int(offs.size()) <= kMaxOffsets, "mispec_csr_synth_band: too many offsets");
+        BandSpec spec;
+        spec.count = int(offs.size());
+        for (int k = 0; k < spec.count; k++)
+            spec.off[k] = offs[size_t(k)];
+
+        ctx->make_current();
+        auto* A = new mispec_csr();
+        try
+        {
+            A->ctx = ctx;
+            A->n_rows = A->n_cols = n;
+            int64_t b, e;
+            if (mispec_shard_range(n, ctx->world(), ctx->rank(), &b, &e) != MISPEC_OK)
+                throw Error(MISPEC_EINVAL, mispec_last_error());
+            A->row_begin = b;
+            A->row_end = e;
+            const int64_t nloc = e - b;
+            const int64_t base = band_prefix(spec, n, b);
+            alloc_entries(*A, band_prefix(spec, n, e) - base);
+            A->rowptr.alloc(size_t(nloc) + 1);
+            const int threads = 256;
+            const unsigned blocks = unsigned((nloc + 1 + threads - 1) / threads);
+            hipLaunchKernelGGL(k_synth_band, dim3(blocks), dim3(threads), 0, ctx->stream, spec, n, b, nloc, base, seed,
+                               symmetric, A->rowptr.p, A->colind.p, A->val.p);
+            MISPEC_HIP(hipGetLastError());
+            MISPEC_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        catch (...)
+        {
+            delete A;
+            throw;
+        }
+        *out = A;
+    });
+}
+
+extern "C" int mispec_csr_destroy(mispec_csr* A)
+{
+    return guarded([&] {
+        if (A)
+        {
+            A->ctx->make_current();
+            delete A;
+        }
+    });
+}
+extern "C" int64_t mispec_csr_rows(const mispec_csr* A) { return A ? A->n_rows : 0; }
+extern "C" int64_t mispec_csr_cols(const mispec_csr* A) { return A ? A->n_cols : 0; }
+extern "C" int64_t mispec_csr_local_rows(const mispec_csr* A) { return A ? A->local_rows() : 0; }
+extern "C" int64_t mispec_csr_local_nnz(const mispec_csr* A) { return A ? A->nnz : 0; }
+
+extern "C" int mispec_csr_coeff(const mispec_csr* A, int64_t i, int64_t j, double* out)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(A && out, "mispec_csr_coeff: NULL argument");
+        MISPEC_REQUIRE(i >= A->row_begin && i < A->row_end && j >= 0 && j < A->n_cols, "mispec_csr_coeff: index outside this shard");
+        A->ctx->make_current();
+        int32_t rp[2];
+        MISPEC_HIP(hipMemcpy(rp, A->rowptr.p + (i - A->row_begin), sizeof(rp), hipMemcpyDeviceToHost));
+        const int len = rp[1] - rp[0];
+        *out = 0.0;
+        if (len <= 0)
+            return;
+        std::vector<int32_t> ci(static_cast<size_t>(len));
+        std::vector<double> v(static_cast<size_t>(len));
+        MISPEC_HIP(hipMemcpy(ci.data(), A->colind.p + rp[0], size_t(len) * sizeof(int32_t), hipMemcpyDeviceToHost));
+        MISPEC_HIP(hipMemcpy(v.data(), A->val.p + rp[0], size_t(len) * sizeof(double), hipMemcpyDeviceToHost));
+        for (int k = 0; k < len; k++)
+            if (ci[size_t(k)] == j)
+                *out += v[size_t(k)];
+    });
+}
+
+extern "C" int mispec_csr_download(const mispec_csr* A, int32_t* rowptr_host, int32_t* colind_host, double* val_host)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(A, "mispec_csr_download: NULL argument");
+        A->ctx->make_current();
+        MISPEC_HIP(hipStreamSynchronize(A->ctx->stream));
+        if (rowptr_host)
+            MISPEC_HIP(hipMemcpy(rowptr_host, A->rowptr.p, size_t(A->local_rows() + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (colind_host && A->nnz)
+            MISPEC_HIP(hipMemcpy(colind_host, A->colind.p, size_t(A->nnz) * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (val_host && A->nnz)
+            MISPEC_HIP(hipMemcpy(val_host, A->val.p, size_t(A->nnz) * sizeof(double), hipMemcpyDeviceToHost));
+    });
+}
+
+extern "C" int mispec_spmv(const mispec_csr* A, const double* x_dev, double* y_dev)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(A && x_dev && y_dev, "mispec_spmv: NULL argument");
+        A->ctx->make_current();
+        launch_spmv(*A, x_dev, y_dev, nullptr);
+    });
+}
+
+extern "C" int mispec_spmv_host(const mispec_csr* A, const double* x_host, double* y_host)
+{
+    return mispec_spmm_host(A, x_host, A ? A->n_cols : 0, 1, y_host, A ? A->n_rows : 0);
+}
+
+extern "C" int mispec_spmm_host(const mispec_csr* A, const double* X_host, int64_t ldx, int k, double* Y_host, int64_t ldy)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(A && X_host && Y_host && k >= 0, "mispec_spmm_host: bad argument");
+        MISPEC_REQUIRE(A->ctx->world() == 1, "mispec_spmm_host: host-pointer products need an unsharded matrix");
+        MISPEC_REQUIRE(ldx >= A->n_cols && ldy >= A->n_rows, "mispec_spmm_host: leading dimension too small");
+        A->ctx->make_current();
+        hipStream_t s = A->ctx->stream;
+        if (A->stage_x.n < size_t(A->n_cols))
+            A->stage_x.alloc(size_t(A->n_cols));
+        if (A->stage_y.n < size_t(A->n_rows))
+            A->stage_y.alloc(size_t(A->n_rows));
+        for (int c = 0; c < k; c++)
+        {
+            MISPEC_HIP(hipMemcpyAsync(A->stage_x.p, X_host + int64_t(c) * ldx, size_t(A->n_cols) * sizeof(double),
+                                      hipMemcpyHostToDevice, s));
+            launch_spmv(*A, A->stage_x.p, A->stage_y.p, nullptr);
+            MISPEC_HIP(hipMemcpyAsync(Y_host + int64_t(c) * ldy, A->stage_y.p, size_t(A->n_rows) * sizeof(double),
+                                      hipMemcpyDeviceToHost, s));
+            MISPEC_HIP(hipStreamSynchronize(s));
+        }
+    });
+}
+
+extern "C" int mispec_spmv_time(const mispec_csr* A, const double* x_dev, double* y_dev, int reps, float* ms_per_launch)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(A && x_dev && y_dev && reps > 0 && ms_per_launch, "mispec_spmv_time: bad argument");
+        A->ctx->make_current();
+        hipEvent_t e0, e1;
+        MISPEC_HIP(hipEventCreate(&e0));
+        MISPEC_HIP(hipEventCreate(&e1));
+        MISPEC_HIP(hipEventRecord(e0, A->ctx->stream));
+        for (int i = 0; i < reps; i++)
+            launch_spmv(*A, x_dev, y_dev, nullptr);
+        MISPEC_HIP(hipEventRecord(e1, A->ctx->stream));
+        MISPEC_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        MISPEC_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void) hipEventDestroy(e0);
+        (void) hipEventDestroy(e1);
+        *ms_per_launch = ms / float(reps);
+    });
+}

@@ -1,0 +1,45 @@
+// Device-resident CSR row shard (the A behind SparseSymMatProd / SparseGenMatProd) and the SpMV launcher.
+#pragma once
+#include "common.hpp"
+
+struct mispec_csr
+{
+    mispec_ctx* ctx = nullptr;
+    int64_t n_rows = 0;     // global rows
+    int64_t n_cols = 0;     // global columns (length of x)
+    int64_t row_begin = 0;  // this shard holds rows [row_begin, row_end)
+    int64_t row_end = 0;
+    int64_t nnz = 0;        // local non-zeros
+    mispec::DevBuf<int32_t> rowptr;  // local_rows + 1, offsets into colind/val (start at 0)
+    mispec::DevBuf<int32_t> colind;  // nnz rounded up to 4, +8 slack, padded with column 0 / value 0
+    mispec::DevBuf<double> val;
+    // staging for the host-pointer paths (allocated on first use)
+    mutable mispec::DevBuf<double> stage_x, stage_y;
+
+    int64_t local_rows() const { return row_end - row_begin; }
+    // 12*nnz + 4*(rows+1) + 8*cols + 8*rows  
+    double algorithmic_bytes() const
+    {
+        return 12.0 * double(nnz) + 4.0 * double(local_rows() + 1) + 8.0 * double(n_cols) + 8.0 * double(local_rows());
+    }
+};
+
+namespace mispec {
+
+// Optional epilogue fused into the SpMV of a Lanczos step (Lanczos.h:131-142):
+//   w = A v - h_prev * v_prev ;  alpha_partials[block] = sum_rows v[row] * w[row]
+struct SpmvEpilogue
+{
+    const double* v_rows = nullptr;   // local rows of the input vector (the new basis column)
+    const double* v_prev = nullptr;   // previous basis column, or nullptr when restarting (Lanczos.h:138)
+    double h_prev = 0.0;              // H(i,i-1); used only when v_prev != nullptr
+    double* partials = nullptr;       // one double per block, deterministic second stage elsewhere
+};
+
+// Rows per SpMV workgroup (one thread per row in the reduction phase).
+constexpr int kSpmvRowsPerBlock = 256;
+inline int spmv_num_blocks(int64_t local_rows) { return int((local_rows + kSpmvRowsPerBlock - 1) / kSpmvRowsPerBlock); }
+
+void launch_spmv(const mispec_csr& A, const double* x_dev, double* y_dev, const SpmvEpilogue* epi);
+
+}  // namespace mispec

@@ -1,0 +1,946 @@
+// Device-resident Lanczos / Arnoldi factorisation  A V = V H + f e'  and the restart primitives.
+//
+// Replaces (yixuan/spectra v1.2.0, include/Spectra/): LinAlg/Arnoldi.h (init :136-195, expand_basis
+// :66-115, factorize_from :198-295, compress_V :320-340), LinAlg/Lanczos.h (factorize_from :62-187)
+// and the ArnoldiOp reductions (MatOp/internal/ArnoldiOp.h:137-161).  Control flow, thresholds and
+// the order of the updates are the reference's; what differs is where the data lives and how many
+// passes over V each step makes:
+//   * V (local_rows x ncv, column-major), f and w stay in HBM for the whole solve; per step the host
+//     sees ~70 doubles (alpha, beta, V'f) through one pinned D2H copy per decision;
+//   * SpMV, "w -= beta v_prev" and the alpha dot product are one kernel (csr.hip);
+//   * "f = w - alpha v", |f| and V'f are one pass over V; each re-orthogonalisation
+//     (f -= V c, |f|, V'f) is ONE pass over V instead of the reference's two (krylov.hip);
+//   * H is kept on the host (ncv x ncv, authoritative) — every rank of a row-sharded run holds the
+//     same H because all reductions end in an all-reduce.
+#include "csr.hpp"
+#include "krylov.hpp"
+#include "small.hpp"
+
+#include <cmath>
+#include <cstring>
+
+using namespace mispec;
+
+namespace {
+constexpr double kEps = 2.220446049250313e-16;           // TypeTraits<double>::epsilon()
+constexpr double kNear0 = 2.2250738585072014e-308 * 10;  // TypeTraits<double>::min() * 10 (Arnoldi.h:50)
+
+enum Family
+{
+    FAM_SPMV = 0,
+    FAM_VTF,
+    FAM_GEMV,
+    FAM_SCALE,
+    FAM_COMPRESS,
+    FAM_SMALL,
+    FAM_COUNT
+};
+}  // namespace
+
+struct mispec_fac
+{
+    mispec_ctx* ctx = nullptr;
+    const mispec_csr* A = nullptr;
+    mispec_op_fn op = nullptr;
+    void* op_user = nullptr;
+    int64_t n = 0;     // global dimension
+    int64_t nloc = 0;  // rows of this shard
+    int64_t row_begin = 0;
+    int64_t block = 0;  // all-gather block (rows per rank, padded)
+    int64_t ldv = 0;
+    int m = 0;
+    bool symmetric = true;
+    int k = 0;
+    double beta = 0.0;
+    std::vector<double> H;  // m x m column-major, host
+
+    DevBuf<double> V, f, w, tmp, xfull, X, partials, alpha_partials, red, Qdev, d_diag, d_subd, d_evals, d_evecs, d_Y, gmax;
+    DevBuf<int> d_info;
+    PinnedBuf<double> h_red, h_small, h_x, h_y;
+    int red_cur = 0;   // which half of `red` holds the latest reduced record
+    int x_cols = 0;    // columns currently held in X
+
+    // profile
+    bool prof = false;
+    int64_t counts[FAM_COUNT] = {0, 0, 0, 0, 0, 0};
+    int64_t n_sync = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[FAM_COUNT];
+    std::vector<hipEvent_t> ev_pool;
+    double ms_acc[FAM_COUNT] = {0, 0, 0, 0, 0, 0};
+
+    double& Hat(int i, int j) { return H[size_t(j) * m + i]; }
+    double* col(int j) { return V.p + int64_t(j) * ldv; }
+    double* red_buf(int which) { return red.p + which * kPartialLd; }
+    hipStream_t stream() const { return ctx->stream; }
+    bool sharded() const { return ctx->world() > 1; }
+
+    ~mispec_fac()
+    {
+        for (auto& fam : ev)
+            for (auto& pr : fam)
+            {
+                (void) hipEventDestroy(pr.first);
+                (void) hipEventDestroy(pr.second);
+            }
+        for (auto e : ev_pool)
+            (void) hipEventDestroy(e);
+    }
+};
+
+namespace {
+
+// RAII timing scope: records a HIP-event pair on the context stream around the enclosed launches.
+struct Timed
+{
+    mispec_fac& F;
+    int fam;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    Timed(mispec_fac& f, int family) : F(f), fam(family)
+    {
+        F.counts[fam]++;
+        if (!F.prof)
+            return;
+        e0 = take();
+        e1 = take();
+        (void) hipEventRecord(e0, F.stream());
+    }
+    hipEvent_t take()
+    {
+        if (!F.ev_pool.empty())
+        {
+            hipEvent_t e = F.ev_pool.back();
+            F.ev_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        MISPEC_HIP(hipEventCreate(&e));
+        return e;
+    }
+    ~Timed()
+    {
+        if (!F.prof || !e0)
+            return;
+        (void) hipEventRecord(e1, F.stream());
+        F.ev[fam].emplace_back(e0, e1);
+    }
+};
+
+void drain_profile(mispec_fac& F)
+{
+    MISPEC_HIP(hipStreamSynchronize(F.stream()));
+    for (int fam = 0; fam < FAM_COUNT; fam++)
+    {
+        for (auto& pr : F.ev[fam])
+        {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess)
+                F.ms_acc[fam] += double(ms);
+            F.ev_pool.push_back(pr.first);
+            F.ev_pool.push_back(pr.second);
+        }
+        F.ev[fam].clear();
+    }
+}
+
+void sync_stream(mispec_fac& F)
+{
+    MISPEC_HIP(hipStreamSynchronize(F.stream()));
+    F.n_sync++;
+}
+
+void comm_check(int rc, const char* what)
+{
+    if (rc != MISPEC_OK)
+        throw Error(MISPEC_ERUNTIME, std::string(what) + " failed: " + mispec_last_error());
+}
+
+void allreduce(mispec_fac& F, double* buf, int64_t count)
+{
+    if (F.sharded())
+        comm_check(F.ctx->comm.allreduce_sum(F.ctx->comm.user, buf, count, F.stream()), "all-reduce");
+}
+
+// max over ranks of a device scalar (sum-only communicator: every rank contributes into its own slot)
+void allreduce_max_scalar(mispec_fac& F, double* dev_scalar)
+{
+    if (!F.sharded())
+        return;
+    const int W = F.ctx->world();
+    MISPEC_HIP(hipMemsetAsync(F.gmax.p, 0, size_t(W) * sizeof(double), F.stream()));
+    MISPEC_HIP(hipMemcpyAsync(F.gmax.p + F.ctx->rank(), dev_scalar, sizeof(double), hipMemcpyDeviceToDevice, F.stream()));
+    allreduce(F, F.gmax.p, W);
+    std::vector<double> h(static_cast<size_t>(W));
+    MISPEC_HIP(hipMemcpyAsync(h.data(), F.gmax.p, size_t(W) * sizeof(double), hipMemcpyDeviceToHost, F.stream()));
+    sync_stream(F);
+    double mx = 0.0;
+    for (double v : h)
+        mx = std::max(mx, v);
+    MISPEC_HIP(hipMemcpyAsync(dev_scalar, &mx, sizeof(double), hipMemcpyHostToDevice, F.stream()));
+    sync_stream(F);
+}
+
+// y = Op(x).  x_loc / y_loc: this shard's rows (device).  With `lanczos_epi`, additionally
+// y -= h_prev * v_prev (when v_prev != nullptr) and alpha = <x, y> is left in red_buf(0)[kSlotAlpha]
+// (device) — Lanczos.h:131-142.
+void apply_op(mispec_fac& F, const double* x_loc, double* y_loc, bool lanczos_epi, const double* v_prev, double h_prev)
+{
+    double* alpha_dev = F.red_buf(0) + kSlotAlpha;
+    if (F.A)
+    {
+        const double* x = x_loc;
+        if (F.sharded())
+        {
+            // all-gather of the Krylov vector over xGMI; blocks are equal-sized and padded
+            comm_check(F.ctx->comm.allgather(F.ctx->comm.user, x_loc, F.xfull.p, F.block, F.stream()), "all-gather");
+            x = F.xfull.p;
+        }
+        Timed t(F, FAM_SPMV);
+        if (lanczos_epi)
+        {
+            SpmvEpilogue epi;
+            epi.v_rows = x_loc;
+            epi.v_prev = v_prev;
+            epi.h_prev = h_prev;
+            epi.partials = F.alpha_partials.p;
+            launch_spmv(*F.A, x, y_loc, &epi);
+        }
+        else
+            launch_spmv(*F.A, x, y_loc, nullptr);
+    }
+    else
+    {
+        // user operator with the reference's host-pointer contract (SymEigsSolver.h:43-51): staged through pinned memory
+        MISPEC_HIP(hipMemcpyAsync(F.h_x.p, x_loc, size_t(F.n) * sizeof(double), hipMemcpyDeviceToHost, F.stream()));
+        sync_stream(F);
+        const int rc = F.op(F.op_user, F.h_x.p, F.h_y.p);
+        if (rc != 0)
+            throw Error(MISPEC_ERUNTIME, "user perform_op callback reported failure");
+        MISPEC_HIP(hipMemcpyAsync(y_loc, F.h_y.p, size_t(F.n) * sizeof(double), hipMemcpyHostToDevice, F.stream()));
+        F.counts[FAM_SPMV]++;
+        if (lanczos_epi)
+            launch_lanczos_epilogue(*F.ctx, y_loc, x_loc, v_prev, h_prev, F.nloc, F.alpha_partials.p);
+    }
+    if (lanczos_epi)
+    {
+        const int64_t nparts = F.A ? spmv_num_blocks(F.nloc) : lanczos_epilogue_records(*F.ctx, F.nloc);
+        launch_reduce_sum(*F.ctx, F.alpha_partials.p, nparts, alpha_dev);
+        allreduce(F, alpha_dev, 1);
+    }
+}
+
+// Reduce the per-workgroup records of the last orth/axpby launch into red_buf(which) and bring the
+// record to the host (h_red).  One stream synchronisation.
+void reduce_to_host(mispec_fac& F, int nrec, int ncol, int which)
+{
+    double* red = F.red_buf(which);
+    if (!F.sharded())
+        launch_reduce_partials(*F.ctx, F.partials.p, nrec, ncol, red, true);
+    else
+    {
+        launch_reduce_partials(*F.ctx, F.partials.p, nrec, ncol, red, false);
+        allreduce(F, red, kSlotBeta2 + 1);  // slots [0, 64] are sums
+        launch_finish(*F.ctx, red, ncol);
+    }
+    MISPEC_HIP(hipMemcpyAsync(F.h_red.p, red, kPartialLd * sizeof(double), hipMemcpyDeviceToHost, F.stream()));
+    sync_stream(F);
+    F.red_cur = which;
+}
+
+OrthArgs orth_args(mispec_fac& F, int ncol)
+{
+    OrthArgs a;
+    a.V = F.V.p;
+    a.ldv = F.ldv;
+    a.ncol = ncol;
+    a.n = F.nloc;
+    a.partials = F.partials.p;
+    return a;
+}
+
+// c = V[:, :ncol]' x ; returns with h_red = {c, |x|^2, ...}
+void vtf(mispec_fac& F, const double* x, int ncol, int which)
+{
+    OrthArgs a = orth_args(F, ncol);
+    a.src = x;
+    int nrec;
+    {
+        Timed t(F, FAM_VTF);
+        nrec = launch_orth(*F.ctx, ORTH_VTF, a);
+    }
+    reduce_to_host(F, nrec, ncol, which);
+}
+
+// dst = src - V[:, :ncol] c (c = red_buf(F.red_cur)[0..ncol) on the device), then |dst| and V'dst
+// in the same pass.  Result record in the other half of `red`.
+void correct_vtf(mispec_fac& F, const double* src, double* dst, int ncol)
+{
+    OrthArgs a = orth_args(F, ncol);
+    a.src = src;
+    a.dst = dst;
+    a.c_in = F.red_buf(F.red_cur);
+    int nrec;
+    {
+        Timed t(F, FAM_GEMV);
+        nrec = launch_orth(*F.ctx, ORTH_CORRECT_VTF, a);
+    }
+    reduce_to_host(F, nrec, ncol, F.red_cur ^ 1);
+}
+
+double host_norm(const double* x, int n)
+{
+    double s = 0.0;
+    for (int i = 0; i < n; i++)
+        s += x[i] * x[i];
+    return std::sqrt(s);
+}
+
+// Arnoldi.h:66-115.  On return f is (numerically) orthogonal to V[:, :ncol] and F.beta = |f|.
+void expand_basis(mispec_fac& F, int ncol, int64_t seed, int64_t* nmatop)
+{
+    for (int iter = 0; iter < 5; iter++)
+    {
+        const uint64_t s = uint64_t(seed + 123 * iter);
+        if (iter == 0)
+        {
+            launch_simple_random(*F.ctx, F.tmp.p, F.row_begin, F.nloc, s);  // :76
+            apply_op(F, F.tmp.p, F.f.p, false, nullptr, 0.0);               // :79  f = A * rand
+            (*nmatop)++;
+        }
+        else
+            launch_simple_random(*F.ctx, F.f.p, F.row_begin, F.nloc, s);  // :84
+        vtf(F, F.f.p, ncol, 0);                                         // :87
+        correct_vtf(F, F.f.p, F.f.p, ncol);                             // :88-93 (f -= V Vf ; |f| ; V'f)
+        double fnorm = F.h_red.p[kSlotBeta];
+        double ortho_err = F.h_red.p[kSlotErr];
+        int count = 0;
+        while (count < 3 && ortho_err >= kEps * fnorm)  // :98-108
+        {
+            correct_vtf(F, F.f.p, F.f.p, ncol);
+            fnorm = F.h_red.p[kSlotBeta];
+            ortho_err = F.h_red.p[kSlotErr];
+            count++;
+        }
+        F.beta = fnorm;
+        if (ortho_err < kEps * fnorm)  // :112
+            return;
+    }
+}
+
+void zero_vector(mispec_fac& F, double* v)
+{
+    MISPEC_HIP(hipMemsetAsync(v, 0, size_t(F.ldv) * sizeof(double), F.stream()));
+}
+
+// Common start of Arnoldi::init once the start vector is in F.tmp (Arnoldi.h:145-195).
+void init_from_tmp(mispec_fac& F, int64_t* nmatop)
+{
+    std::fill(F.H.begin(), F.H.end(), 0.0);
+    MISPEC_HIP(hipMemsetAsync(F.V.p, 0, F.V.n * sizeof(double), F.stream()));
+    zero_vector(F, F.f.p);
+    zero_vector(F, F.w.p);
+
+    vtf(F, F.tmp.p, 0, 0);  // :146 v0norm
+    const double v0norm = F.h_red.p[kSlotBeta];
+    if (v0norm < kNear0)
+        throw Error(MISPEC_EINVAL, "initial residual vector cannot be zero");
+
+    double* v = F.col(0);
+    apply_op(F, F.tmp.p, v, false, nullptr, 0.0);  // :153  v = A v0
+    (*nmatop)++;
+    vtf(F, v, 0, 0);  // :157
+    const double vnorm = F.h_red.p[kSlotBeta];
+    {
+        Timed t(F, FAM_SCALE);
+        if (vnorm < kNear0)
+            launch_scale(*F.ctx, F.tmp.p, v, F.ldv, v0norm);  // :162-165 v0 is in the null space of A
+        else
+            launch_scale(*F.ctx, v, v, F.ldv, vnorm);  // :168
+    }
+    apply_op(F, v, F.w.p, true, nullptr, 0.0);  // :173-176  w = A v ; H(0,0) = <v, w>
+    (*nmatop)++;
+
+    OrthArgs a = orth_args(F, 1);  // f = w - v H(0,0)  (:177) ; the V'f by-product is not used here
+    a.src = F.w.p;
+    a.dst = F.f.p;
+    a.vi = v;
+    a.alpha_dev = F.red_buf(0) + kSlotAlpha;
+    int nrec;
+    {
+        Timed t(F, FAM_VTF);
+        nrec = launch_orth(*F.ctx, ORTH_RESID_VTF, a);
+    }
+    MISPEC_HIP(hipMemcpyAsync(F.h_red.p + kPartialLd, F.red_buf(0) + kSlotAlpha, sizeof(double), hipMemcpyDeviceToHost,
+                              F.stream()));
+    reduce_to_host(F, nrec, 1, 1);
+    const double alpha = F.h_red.p[kPartialLd];
+    if (F.sharded())
+    {
+        allreduce_max_scalar(F, F.red_buf(1) + kSlotMaxAbs);
+        MISPEC_HIP(hipMemcpyAsync(F.h_red.p + kSlotMaxAbs, F.red_buf(1) + kSlotMaxAbs, sizeof(double), hipMemcpyDeviceToHost,
+                                  F.stream()));
+        sync_stream(F);
+    }
+    F.Hat(0, 0) = alpha;
+    if (F.h_red.p[kSlotMaxAbs] < kEps * std::fabs(alpha))  // :183-187
+    {
+        zero_vector(F, F.f.p);
+        F.beta = 0.0;
+    }
+    else
+        F.beta = F.h_red.p[kSlotBeta];
+    F.k = 1;
+}
+
+void zero_H_outside(mispec_fac& F, int from_k)  // Lanczos.h:85-86 / Arnoldi.h:219-220
+{
+    const int m = F.m;
+    for (int j = from_k; j < m; j++)
+        for (int i = 0; i < m; i++)
+            F.Hat(i, j) = 0.0;
+    for (int j = 0; j < from_k; j++)
+        for (int i = from_k; i < m; i++)
+            F.Hat(i, j) = 0.0;
+}
+
+// Lanczos.h:62-187
+void factorize_lanczos(mispec_fac& F, int from_k, int to_m, int64_t* nmatop)
+{
+    const double beta_thresh = kEps * std::sqrt(double(F.n));
+    const double eps_sqrt = std::sqrt(kEps);
+    zero_H_outside(F, from_k);
+
+    for (int i = from_k; i <= to_m - 1; i++)
+    {
+        bool restart = (F.beta < kNear0);  // :99
+        double* v = F.col(i);
+        if (!restart)
+        {
+            {
+                Timed t(F, FAM_SCALE);
+                launch_scale(*F.ctx, F.f.p, v, F.ldv, F.beta);  // :106
+            }
+            if (F.beta < eps_sqrt)  // :107-113 (rare)
+            {
+                OrthArgs a = orth_args(F, 1);
+                a.V = F.col(i - 1);
+                a.src = v;
+                int nrec;
+                {
+                    Timed t(F, FAM_VTF);
+                    nrec = launch_orth(*F.ctx, ORTH_VTF, a);
+                }
+                reduce_to_host(F, nrec, 1, 0);
+                restart = (std::fabs(F.h_red.p[0]) > eps_sqrt);
+            }
+        }
+        if (restart)
+        {
+            expand_basis(F, i, 2 * int64_t(i), nmatop);  // :117-118
+            Timed t(F, FAM_SCALE);
+            launch_scale(*F.ctx, F.f.p, v, F.ldv, F.beta);  // :119
+        }
+        F.Hat(i, i - 1) = restart ? 0.0 : F.beta;  // :127-128
+        F.Hat(i - 1, i) = F.Hat(i, i - 1);
+
+        // w = A v ; w -= H(i,i-1) V[:,i-1] ; alpha = <v, w>   (:131-142) — one kernel
+        apply_op(F, v, F.w.p, true, restart ? nullptr : F.col(i - 1), F.Hat(i, i - 1));
+        (*nmatop)++;
+
+        // f = w - alpha v ; beta = |f| ; Vf = V[:, :i+1]' f   (:145-153) — one pass over V
+        const int i1 = i + 1;
+        OrthArgs a = orth_args(F, i1);
+        a.src = F.w.p;
+        a.dst = F.f.p;
+        a.vi = v;
+        a.alpha_dev = F.red_buf(0) + kSlotAlpha;
+        int nrec;
+        {
+            Timed t(F, FAM_VTF);
+            nrec = launch_orth(*F.ctx, ORTH_RESID_VTF, a);
+        }
+        MISPEC_HIP(hipMemcpyAsync(F.h_red.p + kPartialLd, F.red_buf(0) + kSlotAlpha, sizeof(double), hipMemcpyDeviceToHost,
+                                  F.stream()));
+        reduce_to_host(F, nrec, i1, 1);
+        F.Hat(i, i) = F.h_red.p[kPartialLd];
+        F.beta = F.h_red.p[kSlotBeta];
+        double ortho_err = F.h_red.p[kSlotErr];
+
+        int count = 0;
+        while (count < 5 && ortho_err > kEps * F.beta)  // :156
+        {
+            if (F.beta < beta_thresh)  // :163-168
+            {
+                zero_vector(F, F.f.p);
+                F.beta = 0.0;
+                break;
+            }
+            const double c_im1 = F.h_red.p[i - 1], c_i = F.h_red.p[i];
+            correct_vtf(F, F.f.p, F.f.p, i1);  // :171, :177, :179 — one pass over V
+            F.Hat(i - 1, i) += c_im1;          // :173-175
+            F.Hat(i, i - 1) = F.Hat(i - 1, i);
+            F.Hat(i, i) += c_i;
+            F.beta = F.h_red.p[kSlotBeta];
+            ortho_err = F.h_red.p[kSlotErr];
+            count++;
+        }
+    }
+    F.k = to_m;
+}
+
+// Arnoldi.h:198-295
+void factorize_arnoldi(mispec_fac& F, int from_k, int to_m, int64_t* nmatop)
+{
+    const double beta_thresh = kEps * std::sqrt(double(F.n));
+    zero_H_outside(F, from_k);
+
+    for (int i = from_k; i <= to_m - 1; i++)
+    {
+        bool restart = false;
+        if (F.beta < kNear0)  // :228-233
+        {
+            expand_basis(F, i, 2 * int64_t(i), nmatop);
+            restart = true;
+        }
+        double* v = F.col(i);
+        {
+            Timed t(F, FAM_SCALE);
+            launch_scale(*F.ctx, F.f.p, v, F.ldv, F.beta);  // :236
+        }
+        F.Hat(i, i - 1) = restart ? 0.0 : F.beta;  // :239
+        apply_op(F, v, F.w.p, false, nullptr, 0.0);  // :242
+        (*nmatop)++;
+
+        const int i1 = i + 1;
+        vtf(F, F.w.p, i1, 0);  // h = V' w  (:251)
+        double* h = &F.Hat(0, i);
+        for (int j = 0; j < i1; j++)
+            h[j] = F.h_red.p[j];
+        // f = w - V h ; beta = |f| ; Vf = V' f   (:254-255, :262) — one pass over V
+        correct_vtf(F, F.w.p, F.f.p, i1);
+        F.beta = F.h_red.p[kSlotBeta];
+        if (F.beta > 0.717 * host_norm(h, i1))  // :257
+            continue;
+
+        double ortho_err = F.h_red.p[kSlotErr];
+        int count = 0;
+        while (count < 5 && ortho_err > kEps * F.beta)  // :266
+        {
+            if (F.beta < beta_thresh)
+            {
+                zero_vector(F, F.f.p);
+                F.beta = 0.0;
+                break;
+            }
+            double Vf[kMaxOrthCols];
+            for (int j = 0; j < i1; j++)
+                Vf[j] = F.h_red.p[j];
+            correct_vtf(F, F.f.p, F.f.p, i1);  // :281, :285, :287
+            for (int j = 0; j < i1; j++)
+                h[j] += Vf[j];  // :283
+            F.beta = F.h_red.p[kSlotBeta];
+            ortho_err = F.h_red.p[kSlotErr];
+            count++;
+        }
+    }
+    F.k = to_m;
+}
+
+void require_init(const mispec_fac* F, const char* who)
+{
+    if (!F)
+        throw Error(MISPEC_EINVAL, std::string(who) + ": fac is NULL");
+    if (F->k < 1)
+        throw Error(MISPEC_ELOGIC, std::string(who) + ": need to call init first");
+}
+
+// f <- f*Q(m-1,k-1) + V[:,k]*H(k,k-1) ; beta = |f|   (Arnoldi.h:337-339)
+void update_f_after_compress(mispec_fac& F, double q_last, double h_sub)
+{
+    int nrec;
+    {
+        Timed t(F, FAM_COMPRESS);
+        nrec = launch_axpby(*F.ctx, F.f.p, q_last, F.col(F.k), h_sub, F.nloc, F.partials.p);
+    }
+    reduce_to_host(F, nrec, 0, 0);
+    F.beta = F.h_red.p[kSlotBeta];
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" int mispec_fac_create(mispec_ctx* ctx, const mispec_csr* A, mispec_op_fn op, void* op_user, int64_t n, int ncv,
+                                 int symmetric, mispec_fac** out)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(ctx && out, "mispec_fac_create: NULL argument");
+        MISPEC_REQUIRE((A != nullptr) != (op != nullptr), "mispec_fac_create: give exactly one of A / op");
+        MISPEC_REQUIRE(n >= 1, "mispec_fac_create: n must be positive");
+        MISPEC_REQUIRE(ncv >= 1 && ncv <= n, "mispec_fac_create: need 1 <= ncv <= n");
+        MISPEC_REQUIRE(ncv <= kMaxOrthCols, "mispec_fac_create: the device factorisation holds at most 64 basis vectors (ncv <= 64)");
+        if (A)
+        {
+            MISPEC_REQUIRE(A->ctx == ctx, "mispec_fac_create: matrix belongs to another context");
+            MISPEC_REQUIRE(A->n_rows == n && A->n_cols == n, "mispec_fac_create: operator must be square of size n");
+        }
+        else
+            MISPEC_REQUIRE(ctx->world() == 1, "mispec_fac_create: user operators (host perform_op) cannot be row-sharded");
+        ctx->make_current();
+        auto* F = new mispec_fac();
+        try
+        {
+            F->ctx = ctx;
+            F->A = A;
+            F->op = op;
+            F->op_user = op_user;
+            F->n = n;
+            F->m = ncv;
+            F->symmetric = symmetric != 0;
+            int64_t b, e;
+            if (mispec_shard_range(n, ctx->world(), ctx->rank(), &b, &e) != MISPEC_OK)
+                throw Error(MISPEC_EINVAL, mispec_last_error());
+            F->row_begin = b;
+            F->nloc = e - b;
+            F->block = mispec_shard_block(n, ctx->world());
+            // every n-vector is padded to an even length (16-byte vector accesses) and, when sharded, to the
+            // all-gather block so that a column can be sent as one equal-sized block
+            F->ldv = std::max<int64_t>(round_up(std::max<int64_t>(F->nloc, 1), 2), F->sharded() ? F->block : 0);
+            F->H.assign(size_t(ncv) * ncv, 0.0);
+            F->V.alloc(size_t(F->ldv) * ncv);
+            F->f.alloc(size_t(F->ldv));
+            F->w.alloc(size_t(F->ldv));
+            F->tmp.alloc(size_t(F->ldv));
+            MISPEC_HIP(hipMemsetAsync(F->V.p, 0, F->V.n * sizeof(double), ctx->stream));
+            MISPEC_HIP(hipMemsetAsync(F->f.p, 0, F->f.n * sizeof(double), ctx->stream));
+            MISPEC_HIP(hipMemsetAsync(F->w.p, 0, F->w.n * sizeof(double), ctx->stream));
+            MISPEC_HIP(hipMemsetAsync(F->tmp.p, 0, F->tmp.n * sizeof(double), ctx->stream));
+            if (F->sharded())
+            {
+                F->xfull.alloc(size_t(F->block) * ctx->world());
+                F->gmax.alloc(size_t(ctx->world()));
+            }
+            const int64_t max_rec = int64_t(ctx->num_cu) * 8 + 8;
+            F->partials.alloc(size_t(max_rec) * kPartialLd);
+            const int64_t nparts = A ? spmv_num_blocks(F->nloc) : lanczos_epilogue_records(*ctx, F->nloc);
+            F->alpha_partials.alloc(size_t(std::max<int64_t>(nparts, 1)));
+            F->red.alloc(2 * kPartialLd);
+            MISPEC_HIP(hipMemsetAsync(F->red.p, 0, F->red.n * sizeof(double), ctx->stream));
+            F->Qdev.alloc(size_t(ncv) * ncv);
+            F->d_diag.alloc(size_t(ncv));
+            F->d_subd.alloc(size_t(ncv));
+            F->d_evals.alloc(size_t(ncv));
+            F->d_evecs.alloc(size_t(ncv) * ncv);
+            F->d_Y.alloc(size_t(ncv) * ncv);
+            F->d_info.alloc(1);
+            F->h_red.alloc(kPartialLd + 8);
+            F->h_small.alloc(size_t(ncv) * ncv + 4 * size_t(ncv) + 8);
+            if (op)
+            {
+                F->h_x.alloc(size_t(n));
+                F->h_y.alloc(size_t(n));
+            }
+            MISPEC_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        catch (...)
+        {
+            delete F;
+            throw;
+        }
+        *out = F;
+    });
+}
+
+extern "C" int mispec_fac_destroy(mispec_fac* fac)
+{
+    return guarded([&] {
+        if (fac)
+        {
+            fac->ctx->make_current();
+            (void) hipStreamSynchronize(fac->ctx->stream);
+            delete fac;
+        }
+    });
+}
+
+extern "C" int mispec_fac_init(mispec_fac* fac, const double* v0_host, int64_t* nmatop)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(fac && v0_host && nmatop, "mispec_fac_init: NULL argument");
+        mispec_fac& F = *fac;
+        F.ctx->make_current();
+        zero_vector(F, F.tmp.p);
+        if (F.nloc)
+            MISPEC_HIP(hipMemcpyAsync(F.tmp.p, v0_host + F.row_begin, size_t(F.nloc) * sizeof(double), hipMemcpyHostToDevice,
+                                      F.stream()));
+        sync_stream(F);  // v0_host may be pageable memory that the caller frees right after
+        init_from_tmp(F, nmatop);
+    });
+}
+
+extern "C" int mispec_fac_init_random(mispec_fac* fac, uint64_t seed, int64_t* nmatop)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(fac && nmatop, "mispec_fac_init_random: NULL argument");
+        mispec_fac& F = *fac;
+        F.ctx->make_current();
+        zero_vector(F, F.tmp.p);
+        launch_simple_random(*F.ctx, F.tmp.p, F.row_begin, F.nloc, seed);
+        init_from_tmp(F, nmatop);
+    });
+}
+
+extern "C" int mispec_fac_factorize(mispec_fac* fac, int from_k, int to_m, int64_t* nmatop)
+{
+    return guarded([&] {
+        require_init(fac, "mispec_fac_factorize");
+        MISPEC_REQUIRE(nmatop, "mispec_fac_factorize: nmatop is NULL");
+        mispec_fac& F = *fac;
+        F.ctx->make_current();
+        if (to_m <= from_k)
+            return;
+        MISPEC_REQUIRE(to_m <= F.m && from_k >= 1, "factorize_from: need 1 <= from_k < to_m <= ncv");
+        if (from_k > F.k)  // Lanczos.h:70-75 / Arnoldi.h:206-211
+            throw Error(MISPEC_EINVAL, std::string(F.symmetric ? "Lanczos" : "Arnoldi") + ": from_k (= " + std::to_string(from_k) +
+                                           ") is larger than the current subspace dimension (= " + std::to_string(F.k) + ")");
+        if (F.symmetric)
+            factorize_lanczos(F, from_k, to_m, nmatop);
+        else
+            factorize_arnoldi(F, from_k, to_m, nmatop);
+    });
+}
+
+extern "C" int mispec_fac_subspace_dim(const mispec_fac* fac) { return fac ? fac->k : 0; }
+extern "C" int64_t mispec_fac_local_rows(const mispec_fac* fac) { return fac ? fac->nloc : 0; }
+
+extern "C" int mispec_fac_f_norm(const mispec_fac* fac, double* beta)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(fac && beta, "mispec_fac_f_norm: NULL argument");
+        *beta = fac->beta;
+    });
+}
+
+extern "C" int mispec_fac_get_H(const mispec_fac* fac, double* H_host)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(fac && H_host, "mispec_fac_get_H: NULL argument");
+        std::memcpy(H_host, fac->H.data(), fac->H.size() * sizeof(double));
+    });
+}
+
+extern "C" int mispec_fac_set_H(mispec_fac* fac, const double* H_host, int k)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(fac && H_host && k >= 0 && k <= fac->m, "mispec_fac_set_H: bad argument");
+        std::memcpy(fac->H.data(), H_host, fac->H.size() * sizeof(double));
+        fac->k = k;
+    });
+}
+
+extern "C" int mispec_fac_get_V(const mispec_fac* fac, int ncols, double* V_host)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(fac && V_host && ncols >= 0 && ncols <= fac->m, "mispec_fac_get_V: bad argument");
+        fac->ctx->make_current();
+        MISPEC_HIP(hipStreamSynchronize(fac->ctx->stream));
+        if (ncols && fac->nloc)
+            MISPEC_HIP(hipMemcpy2D(V_host, size_t(fac->nloc) * sizeof(double), fac->V.p, size_t(fac->ldv) * sizeof(double),
+                                   size_t(fac->nloc) * sizeof(double), size_t(ncols), hipMemcpyDeviceToHost));
+    });
+}
+
+extern "C" int mispec_fac_get_f(const mispec_fac* fac, double* f_host)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(fac && f_host, "mispec_fac_get_f: NULL argument");
+        fac->ctx->make_current();
+        MISPEC_HIP(hipStreamSynchronize(fac->ctx->stream));
+        if (fac->nloc)
+            MISPEC_HIP(hipMemcpy(f_host, fac->f.p, size_t(fac->nloc) * sizeof(double), hipMemcpyDeviceToHost));
+    });
+}
+
+extern "C" const double* mispec_fac_V_dev(const mispec_fac* fac, int64_t* ld)
+{
+    if (!fac)
+        return nullptr;
+    if (ld)
+        *ld = fac->ldv;
+    return fac->V.p;
+}
+
+extern "C" int mispec_fac_tridiag_eigen(mispec_fac* fac, double* evals_host, double* evecs_host)
+{
+    return guarded([&] {
+        require_init(fac, "mispec_fac_tridiag_eigen");
+        MISPEC_REQUIRE(evals_host, "mispec_fac_tridiag_eigen: evals is NULL");
+        mispec_fac& F = *fac;
+        MISPEC_REQUIRE(F.symmetric, "mispec_fac_tridiag_eigen: symmetric (Lanczos) factorisations only");
+        F.ctx->make_current();
+        const int m = F.m;
+        double* hs = F.h_small.p;  // [diag m][subd m]
+        for (int i = 0; i < m; i++)
+            hs[i] = F.Hat(i, i);
+        for (int i = 0; i < m; i++)
+            hs[m + i] = (i < m - 1) ? F.Hat(i + 1, i) : 0.0;
+        MISPEC_HIP(hipMemcpyAsync(F.d_diag.p, hs, size_t(m) * 8, hipMemcpyHostToDevice, F.stream()));
+        MISPEC_HIP(hipMemcpyAsync(F.d_subd.p, hs + m, size_t(m) * 8, hipMemcpyHostToDevice, F.stream()));
+        {
+            Timed t(F, FAM_SMALL);
+            launch_tridiag_eigen(*F.ctx, m, F.d_diag.p, F.d_subd.p, F.d_evals.p, F.d_evecs.p, F.d_info.p);
+        }
+        int info = 0;
+        MISPEC_HIP(hipMemcpyAsync(evals_host, F.d_evals.p, size_t(m) * 8, hipMemcpyDeviceToHost, F.stream()));
+        if (evecs_host)
+            MISPEC_HIP(hipMemcpyAsync(evecs_host, F.d_evecs.p, size_t(m) * m * 8, hipMemcpyDeviceToHost, F.stream()));
+        MISPEC_HIP(hipMemcpyAsync(&info, F.d_info.p, sizeof(int), hipMemcpyDeviceToHost, F.stream()));
+        sync_stream(F);
+        if (info != 0)
+            throw Error(MISPEC_ERUNTIME, "TridiagEigen: eigen decomposition failed");  // TridiagEigen.h:204
+    });
+}
+
+extern "C" int mispec_fac_restart_sym(mispec_fac* fac, const double* shifts_host, int nshift)
+{
+    return guarded([&] {
+        require_init(fac, "mispec_fac_restart_sym");
+        mispec_fac& F = *fac;
+        MISPEC_REQUIRE(F.symmetric, "mispec_fac_restart_sym: symmetric (Lanczos) factorisations only");
+        MISPEC_REQUIRE(shifts_host && nshift >= 1 && nshift < F.m, "mispec_fac_restart_sym: need 1 <= nshift < ncv");
+        MISPEC_REQUIRE(F.k == F.m, "mispec_fac_restart_sym: the factorisation must be complete (k == ncv)");
+        F.ctx->make_current();
+        const int m = F.m;
+        double* hs = F.h_small.p;  // [diag m][subd m][Q m*m]
+        for (int i = 0; i < m; i++)
+            hs[i] = F.Hat(i, i);
+        for (int i = 0; i < m; i++)
+            hs[m + i] = (i < m - 1) ? F.Hat(i + 1, i) : 0.0;
+        MISPEC_HIP(hipMemcpyAsync(F.d_diag.p, hs, size_t(m) * 8, hipMemcpyHostToDevice, F.stream()));
+        MISPEC_HIP(hipMemcpyAsync(F.d_subd.p, hs + m, size_t(m) * 8, hipMemcpyHostToDevice, F.stream()));
+        {
+            Timed t(F, FAM_SMALL);
+            launch_restart_sym(*F.ctx, m, F.d_diag.p, F.d_subd.p, shifts_host, nshift, F.Qdev.p);
+        }
+        const int k = m - nshift;  // compress_H decrements k once per shift (Lanczos.h:198-202)
+        // V[:, :k+1] <- V Q  (Arnoldi.h:326-335), in place, straight from the device Q
+        {
+            Timed t(F, FAM_COMPRESS);
+            launch_vq(*F.ctx, F.V.p, F.ldv, m, F.Qdev.p, m, k + 1, F.V.p, F.ldv, F.nloc);
+        }
+        MISPEC_HIP(hipMemcpyAsync(hs, F.d_diag.p, size_t(m) * 8, hipMemcpyDeviceToHost, F.stream()));
+        MISPEC_HIP(hipMemcpyAsync(hs + m, F.d_subd.p, size_t(m) * 8, hipMemcpyDeviceToHost, F.stream()));
+        MISPEC_HIP(hipMemcpyAsync(hs + 2 * m, F.Qdev.p + size_t(k - 1) * m + (m - 1), sizeof(double), hipMemcpyDeviceToHost,
+                                  F.stream()));
+        sync_stream(F);
+        std::fill(F.H.begin(), F.H.end(), 0.0);
+        for (int i = 0; i < m; i++)
+            F.Hat(i, i) = hs[i];
+        for (int i = 0; i < m - 1; i++)
+            F.Hat(i + 1, i) = F.Hat(i, i + 1) = hs[m + i];
+        F.k = k;
+        update_f_after_compress(F, hs[2 * m], F.Hat(k, k - 1));
+    });
+}
+
+extern "C" int mispec_fac_compress_V(mispec_fac* fac, const double* Q_host, const double* H_host, int new_k)
+{
+    return guarded([&] {
+        require_init(fac, "mispec_fac_compress_V");
+        mispec_fac& F = *fac;
+        MISPEC_REQUIRE(Q_host && H_host && new_k >= 1 && new_k < F.m, "mispec_fac_compress_V: bad argument");
+        F.ctx->make_current();
+        const int m = F.m;
+        std::memcpy(F.h_small.p, Q_host, size_t(m) * m * sizeof(double));
+        MISPEC_HIP(hipMemcpyAsync(F.Qdev.p, F.h_small.p, size_t(m) * m * 8, hipMemcpyHostToDevice, F.stream()));
+        std::memcpy(F.H.data(), H_host, F.H.size() * sizeof(double));
+        F.k = new_k;
+        {
+            Timed t(F, FAM_COMPRESS);
+            launch_vq(*F.ctx, F.V.p, F.ldv, m, F.Qdev.p, m, new_k + 1, F.V.p, F.ldv, F.nloc);
+        }
+        update_f_after_compress(F, Q_host[size_t(new_k - 1) * m + (m - 1)], F.Hat(new_k, new_k - 1));
+    });
+}
+
+extern "C" int mispec_fac_ritz_vectors(mispec_fac* fac, const double* Y_host, int ncols, double* X_host, const double** X_dev)
+{
+    return guarded([&] {
+        require_init(fac, "mispec_fac_ritz_vectors");
+        mispec_fac& F = *fac;
+        MISPEC_REQUIRE(Y_host && ncols >= 1 && ncols <= F.m, "mispec_fac_ritz_vectors: bad argument");
+        F.ctx->make_current();
+        const int m = F.m;
+        if (F.X.n < size_t(F.ldv) * size_t(ncols))
+            F.X.alloc(size_t(F.ldv) * size_t(ncols));
+        MISPEC_HIP(hipMemsetAsync(F.X.p, 0, size_t(F.ldv) * size_t(ncols) * sizeof(double), F.stream()));
+        std::memcpy(F.h_small.p, Y_host, size_t(m) * size_t(ncols) * sizeof(double));
+        MISPEC_HIP(hipMemcpyAsync(F.d_Y.p, F.h_small.p, size_t(m) * size_t(ncols) * 8, hipMemcpyHostToDevice, F.stream()));
+        {
+            Timed t(F, FAM_COMPRESS);
+            launch_vq(*F.ctx, F.V.p, F.ldv, m, F.d_Y.p, m, ncols, F.X.p, F.ldv, F.nloc);  // HermEigsBase.h:467
+        }
+        F.x_cols = ncols;
+        if (X_host && F.nloc)
+            MISPEC_HIP(hipMemcpy2DAsync(X_host, size_t(F.nloc) * sizeof(double), F.X.p, size_t(F.ldv) * sizeof(double),
+                                        size_t(F.nloc) * sizeof(double), size_t(ncols), hipMemcpyDeviceToHost, F.stream()));
+        sync_stream(F);
+        if (X_dev)
+            *X_dev = F.X.p;
+    });
+}
+
+extern "C" int mispec_fac_residuals(mispec_fac* fac, const double* lambda_host, int ncols, double* resid_host)
+{
+    return guarded([&] {
+        require_init(fac, "mispec_fac_residuals");
+        mispec_fac& F = *fac;
+        MISPEC_REQUIRE(lambda_host && resid_host && ncols >= 0 && ncols <= F.x_cols,
+                       "mispec_fac_residuals: call mispec_fac_ritz_vectors first");
+        MISPEC_REQUIRE(F.A, "mispec_fac_residuals: needs a device-resident matrix");
+        F.ctx->make_current();
+        for (int j = 0; j < ncols; j++)
+        {
+            const double* x = F.X.p + int64_t(j) * F.ldv;
+            apply_op(F, x, F.tmp.p, false, nullptr, 0.0);
+            const int nrec = launch_resid_norms(*F.ctx, F.tmp.p, x, lambda_host[j], F.nloc, F.partials.p);
+            reduce_to_host(F, nrec, 1, 0);
+            resid_host[j] = std::sqrt(F.h_red.p[kSlotBeta2]) / std::sqrt(F.h_red.p[0]);
+        }
+    });
+}
+
+extern "C" int mispec_fac_profile(mispec_fac* fac, int enable)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(fac, "mispec_fac_profile: NULL argument");
+        fac->ctx->make_current();
+        if (!enable && fac->prof)
+            drain_profile(*fac);
+        fac->prof = enable != 0;
+    });
+}
+
+extern "C" int mispec_fac_get_profile(const mispec_fac* fac_c, mispec_profile* out)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(fac_c && out, "mispec_fac_get_profile: NULL argument");
+        mispec_fac& F = *const_cast<mispec_fac*>(fac_c);
+        F.ctx->make_current();
+        drain_profile(F);
+        out->n_spmv = F.counts[FAM_SPMV];
+        out->n_vtf = F.counts[FAM_VTF];
+        out->n_gemv = F.counts[FAM_GEMV];
+        out->n_scale = F.counts[FAM_SCALE];
+        out->n_compress = F.counts[FAM_COMPRESS];
+        out->n_small = F.counts[FAM_SMALL];
+        out->n_host_sync = F.n_sync;
+        out->ms_spmv = F.ms_acc[FAM_SPMV];
+        out->ms_vtf = F.ms_acc[FAM_VTF];
+        out->ms_gemv = F.ms_acc[FAM_GEMV];
+        out->ms_scale = F.ms_acc[FAM_SCALE];
+        out->ms_compress = F.ms_acc[FAM_COMPRESS];
+        out->ms_small = F.ms_acc[FAM_SMALL];
+        out->spmv_bytes = F.A ? F.A->algorithmic_bytes() : 0.0;
+    });
+}

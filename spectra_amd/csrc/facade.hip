@@ -1,0 +1,195 @@
+// Solver-level C entry points: the header-only templates of include/Spectra/ instantiated inside the
+// library for bindings that cannot instantiate C++ templates (Python ctypes, cgo, JNI ...).
+// Nothing here adds arithmetic: it is Spectra::SymEigsSolver<Spectra::SparseSymMatProd<double>> (or a
+// callback operator with the reference's perform_op contract) behind opaque handles.
+#include <Spectra/SymEigsSolver.h>
+
+#include <cstring>
+#include <memory>
+
+#include "common.hpp"
+
+using namespace mispec;
+
+namespace {
+
+// A user operator supplied as a C function pointer: the duck-typed OpType concept of the reference
+// (SymEigsSolver.h:43-51) expressed for C callers.
+class CallbackOp
+{
+    mispec_ctx* m_ctx;
+    mispec_op_fn m_fn;
+    void* m_user;
+    Spectra::Index m_n;
+
+public:
+    using Scalar = double;
+    CallbackOp(mispec_ctx* ctx, mispec_op_fn fn, void* user, Spectra::Index n) : m_ctx(ctx), m_fn(fn), m_user(user), m_n(n) {}
+    mispec_ctx* mispec_context() const { return m_ctx; }  // where the Krylov basis of this operator lives
+    Spectra::Index rows() const { return m_n; }
+    Spectra::Index cols() const { return m_n; }
+    void perform_op(const double* x_in, double* y_out) const
+    {
+        if (m_fn(m_user, x_in, y_out) != 0)
+            throw std::runtime_error("user perform_op callback reported failure");
+    }
+};
+
+using DevOp = Spectra::SparseSymMatProd<double>;
+using DevSolver = Spectra::SymEigsSolver<DevOp>;
+using CbSolver = Spectra::SymEigsSolver<CallbackOp>;
+
+}  // namespace
+
+struct mispec_symeigs
+{
+    mispec_ctx* ctx = nullptr;
+    std::unique_ptr<DevOp> dev_op;
+    std::unique_ptr<CallbackOp> cb_op;
+    std::unique_ptr<DevSolver> dev;
+    std::unique_ptr<CbSolver> cb;
+    int64_t nev = 0;
+
+    template <typename F>
+    auto visit(F&& f) const
+    {
+        return dev ? f(*dev) : f(*cb);
+    }
+    mispec_fac* fac() const
+    {
+        return visit([](auto& s) { return s.factorization().handle(); });
+    }
+};
+
+extern "C" int mispec_symeigs_create(mispec_ctx* ctx, const mispec_csr* A, int64_t nev, int64_t ncv, mispec_symeigs** out)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(ctx && A && out, "mispec_symeigs_create: NULL argument");
+        auto s = std::make_unique<mispec_symeigs>();
+        s->ctx = ctx;
+        s->nev = nev;
+        s->dev_op = std::make_unique<DevOp>(ctx, const_cast<mispec_csr*>(A));
+        s->dev = std::make_unique<DevSolver>(*s->dev_op, nev, ncv);
+        *out = s.release();
+    });
+}
+
+extern "C" int mispec_symeigs_create_op(mispec_ctx* ctx, mispec_op_fn op, void* op_user, int64_t n, int64_t nev, int64_t ncv,
+                                        mispec_symeigs** out)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(ctx && op && out, "mispec_symeigs_create_op: NULL argument");
+        auto s = std::make_unique<mispec_symeigs>();
+        s->ctx = ctx;
+        s->nev = nev;
+        s->cb_op = std::make_unique<CallbackOp>(ctx, op, op_user, n);
+        s->cb = std::make_unique<CbSolver>(*s->cb_op, nev, ncv);
+        *out = s.release();
+    });
+}
+
+extern "C" int mispec_symeigs_destroy(mispec_symeigs* s)
+{
+    return guarded([&] { delete s; });
+}
+
+extern "C" int mispec_symeigs_init(mispec_symeigs* s, const double* v0_host)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(s, "mispec_symeigs_init: NULL argument");
+        s->visit([&](auto& solver) {
+            if (v0_host)
+                solver.init(v0_host);
+            else
+                solver.init();
+            return 0;
+        });
+    });
+}
+
+extern "C" int mispec_symeigs_compute(mispec_symeigs* s, int selection, int64_t maxit, double tol, int sorting, int64_t* nconv)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(s && nconv, "mispec_symeigs_compute: NULL argument");
+        MISPEC_REQUIRE(selection >= 0 && selection <= int(Spectra::SortRule::BothEnds) && sorting >= 0 &&
+                           sorting <= int(Spectra::SortRule::BothEnds),
+                       "mispec_symeigs_compute: unknown SortRule value");
+        *nconv = s->visit([&](auto& solver) {
+            return int64_t(solver.compute(static_cast<Spectra::SortRule>(selection), Spectra::Index(maxit), tol,
+                                          static_cast<Spectra::SortRule>(sorting)));
+        });
+    });
+}
+
+extern "C" int mispec_symeigs_info(const mispec_symeigs* s)
+{
+    return s ? s->visit([](auto& solver) { return int(solver.info()); }) : int(Spectra::CompInfo::NotComputed);
+}
+extern "C" int64_t mispec_symeigs_num_iterations(const mispec_symeigs* s)
+{
+    return s ? s->visit([](auto& solver) { return int64_t(solver.num_iterations()); }) : 0;
+}
+extern "C" int64_t mispec_symeigs_num_operations(const mispec_symeigs* s)
+{
+    return s ? s->visit([](auto& solver) { return int64_t(solver.num_operations()); }) : 0;
+}
+
+extern "C" int mispec_symeigs_eigenvalues(const mispec_symeigs* s, double* out_host, int64_t* count)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(s && count, "mispec_symeigs_eigenvalues: NULL argument");
+        s->visit([&](auto& solver) {
+            const auto ev = solver.eigenvalues();
+            *count = ev.size();
+            if (out_host)
+                std::memcpy(out_host, ev.data(), size_t(ev.size()) * sizeof(double));
+            return 0;
+        });
+    });
+}
+
+extern "C" int mispec_symeigs_eigenvectors(mispec_symeigs* s, int64_t nvec, double* out_host, int64_t* ncols)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(s && ncols, "mispec_symeigs_eigenvectors: NULL argument");
+        s->visit([&](auto& solver) {
+            if (!out_host)  // keep the result in HBM only
+            {
+                *ncols = solver.eigenvectors_on_device(Spectra::Index(nvec));
+                return 0;
+            }
+            const auto X = solver.eigenvectors(Spectra::Index(nvec));
+            *ncols = X.cols();
+            if (X.size() > 0)
+                std::memcpy(out_host, X.data(), size_t(X.size()) * sizeof(double));
+            return 0;
+        });
+    });
+}
+
+extern "C" int mispec_symeigs_residuals(mispec_symeigs* s, double* resid_host, int64_t* count)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(s && resid_host && count, "mispec_symeigs_residuals: NULL argument");
+        s->visit([&](auto& solver) {
+            const auto ev = solver.eigenvalues();
+            *count = ev.size();
+            if (ev.size() == 0)
+                return 0;
+            (void) solver.eigenvectors_on_device(Spectra::Index(ev.size()));  // X = V*Y stays in HBM
+            const int rc = mispec_fac_residuals(solver.factorization().handle(), ev.data(), int(ev.size()), resid_host);
+            if (rc != MISPEC_OK)
+                throw Error(rc, mispec_last_error());
+            return 0;
+        });
+    });
+}
+
+extern "C" int mispec_symeigs_profile(mispec_symeigs* s, int enable)
+{
+    return s ? mispec_fac_profile(s->fac(), enable) : MISPEC_EINVAL;
+}
+extern "C" int mispec_symeigs_get_profile(const mispec_symeigs* s, mispec_profile* out)
+{
+    return s ? mispec_fac_get_profile(s->fac(), out) : MISPEC_EINVAL;
+}

@@ -1,0 +1,582 @@
+// Length-n dense kernels of the Lanczos / Arnoldi factorisation for gfx950 (all HBM-bound).
+//
+// Common shape ("orth" kernels): a 256-thread workgroup walks 128-row tiles of the column-major
+// basis V (grid-stride over tiles).  Lane l of every wave owns rows (2l, 2l+1) of the tile, so
+// each load is 16 B/lane and 1 KiB contiguous per wave; wave w owns basis columns j = w (mod 4),
+// "slot" jj <-> column w + 4*jj.  All of a tile's loads are issued before the first use (no
+// branches between them), giving up to 16 x 1 KiB in flight per wave.  Each wave keeps its V
+// values in registers, which is what lets   f <- f - V c   and   c' <- V' f   share ONE pass over
+// V (the reference makes two, Lanczos.h:171 and :179): the per-row sums that couple the four
+// waves go through an 8 KiB double-buffered LDS exchange, one barrier per tile.
+// Reductions are two-stage and atomic-free: per-workgroup records -> one fixed-order summing
+// kernel, so results are reproducible run to run.
+//
+// Algorithmic bytes (8*n per vector pass): VTF (ncol+1), RESID_VTF (ncol+2 reads... w, v_i is
+// one of the ncol columns, so ncol+1 reads + 1 write), CORRECT_VTF (ncol+1 reads + 1 write).
+#include "krylov.hpp"
+
+using namespace mispec;
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kTileRows = 128;
+
+__device__ __forceinline__ double wave_reduce_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_reduce_max(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v = fmax(v, __shfl_down(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ double block_reduce_sum(double v, double* red)
+{
+    v = wave_reduce_sum(v);
+    if ((threadIdx.x & 63) == 0)
+        red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+template <int MODE, int MAXS>
+__global__ __launch_bounds__(kThreads) void k_orth(OrthArgs a)
+{
+    constexpr bool kCorrect = (MODE == ORTH_CORRECT_VTF || MODE == ORTH_CORRECT_ONLY);
+    constexpr bool kVtf = (MODE != ORTH_CORRECT_ONLY);
+    __shared__ double cs[kMaxOrthCols];
+    __shared__ __attribute__((aligned(16))) double psum[2][4][kTileRows];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    if (kCorrect)
+    {
+        if (tid < kMaxOrthCols)
+            cs[tid] = (tid < a.ncol) ? a.c_in[tid] : 0.0;
+        __syncthreads();
+    }
+    double alpha = 0.0;
+    if (MODE == ORTH_RESID_VTF)
+        alpha = *a.alpha_dev;
+
+    // column base pointers and coefficients of this wave's slots; slots past ncol alias column 0
+    // with coefficient 0 (their loads hit L1/L2, their results are dropped).
+    const double* colp[MAXS];
+    double cw[MAXS];
+    double acc[MAXS];
+#pragma unroll
+    for (int jj = 0; jj < MAXS; jj++)
+    {
+        const int j = w + 4 * jj;
+        colp[jj] = a.V + int64_t(j < a.ncol ? j : 0) * a.ldv;
+        cw[jj] = (kCorrect && j < kMaxOrthCols) ? cs[j] : 0.0;
+        acc[jj] = 0.0;
+    }
+    double b2 = 0.0, mx = 0.0;
+
+    const int64_t ntiles = (a.n + kTileRows - 1) / kTileRows;
+    int buf = 0;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x)
+    {
+        const int64_t r = t * kTileRows + 2 * lane;
+        const bool valid = r < a.n;  // rows come in even pairs; vectors are zero-padded to an even length
+        const int64_t rc = valid ? r : 0;
+
+        double2 vv[MAXS];
+#pragma unroll
+        for (int jj = 0; jj < MAXS; jj++)
+            vv[jj] = *reinterpret_cast<const double2*>(colp[jj] + rc);
+
+        double2 fv;
+        if (MODE == ORTH_RESID_VTF)
+        {
+            const double2 wv = *reinterpret_cast<const double2*>(a.src + rc);
+            const double2 vi = *reinterpret_cast<const double2*>(a.vi + rc);
+            fv.x = wv.x - alpha * vi.x;  // Lanczos.h:145
+            fv.y = wv.y - alpha * vi.y;
+        }
+        else
+            fv = *reinterpret_cast<const double2*>(a.src + rc);
+        if (!valid)
+        {
+            fv.x = 0.0;
+            fv.y = 0.0;
+        }
+
+        if (kCorrect)
+        {
+            double2 p;
+            p.x = 0.0;
+            p.y = 0.0;
+#pragma unroll
+            for (int jj = 0; jj < MAXS; jj++)
+            {
+                p.x += vv[jj].x * cw[jj];
+                p.y += vv[jj].y * cw[jj];
+            }
+            *reinterpret_cast<double2*>(&psum[buf][w][2 * lane]) = p;
+            __syncthreads();
+            const double2 p0 = *reinterpret_cast<const double2*>(&psum[buf][0][2 * lane]);
+            const double2 p1 = *reinterpret_cast<const double2*>(&psum[buf][1][2 * lane]);
+            const double2 p2 = *reinterpret_cast<const double2*>(&psum[buf][2][2 * lane]);
+            const double2 p3 = *reinterpret_cast<const double2*>(&psum[buf][3][2 * lane]);
+            if (valid)
+            {
+                fv.x -= (p0.x + p1.x) + (p2.x + p3.x);  // Lanczos.h:171 / Arnoldi.h:254
+                fv.y -= (p0.y + p1.y) + (p2.y + p3.y);
+            }
+            buf ^= 1;
+        }
+
+        if (w == 0)
+        {
+            if (MODE != ORTH_VTF && valid)
+                *reinterpret_cast<double2*>(a.dst + r) = fv;
+            b2 += fv.x * fv.x + fv.y * fv.y;
+            mx = fmax(mx, fmax(fabs(fv.x), fabs(fv.y)));
+        }
+        if (kVtf)
+        {
+#pragma unroll
+            for (int jj = 0; jj < MAXS; jj++)
+                acc[jj] += vv[jj].x * fv.x + vv[jj].y * fv.y;
+        }
+    }
+
+    double* rec = a.partials + int64_t(blockIdx.x) * kPartialLd;
+    if (kVtf)
+    {
+#pragma unroll
+        for (int jj = 0; jj < MAXS; jj++)
+        {
+            const double s = wave_reduce_sum(acc[jj]);
+            const int j = w + 4 * jj;
+            if (lane == 0 && j < a.ncol)
+                rec[j] = s;
+        }
+    }
+    if (w == 0)
+    {
+        b2 = wave_reduce_sum(b2);
+        mx = wave_reduce_max(mx);
+        if (lane == 0)
+        {
+            rec[kSlotBeta2] = b2;
+            rec[kSlotMaxAbs] = mx;
+        }
+    }
+}
+
+// One workgroup sums the records column by column in a fixed order.
+__global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restrict__ partials, int nrec, int ncol,
+                                                           double* __restrict__ red, int finish)
+{
+    __shared__ double sh[kPartialLd];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int j = w; j < kPartialLd; j += 16)
+    {
+        const bool is_sum = (j < ncol) || (j == kSlotBeta2);
+        const bool is_max = (j == kSlotMaxAbs);
+        double v = 0.0;
+        if (is_sum || is_max)
+        {
+            for (int b = lane; b < nrec; b += 64)
+            {
+                const double x = partials[int64_t(b) * kPartialLd + j];
+                v = is_max ? fmax(v, x) : v + x;
+            }
+            v = is_max ? wave_reduce_max(v) : wave_reduce_sum(v);
+        }
+        if (lane == 0)
+            sh[j] = v;
+    }
+    __syncthreads();
+    if (tid == 0 && finish)
+    {
+        sh[kSlotBeta] = sqrt(sh[kSlotBeta2]);  // ArnoldiOp.h:152-155: plain sqrt(sum x^2)
+        double err = 0.0;
+        for (int j = 0; j < ncol; j++)
+            err = fmax(err, fabs(sh[j]));
+        sh[kSlotErr] = err;  // Lanczos.h:153 cwiseAbs().maxCoeff()
+    }
+    __syncthreads();
+    if (tid < kPartialLd)
+        red[tid] = sh[tid];
+}
+
+__global__ void k_finish(double* red, int ncol)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+    {
+        red[kSlotBeta] = sqrt(red[kSlotBeta2]);
+        double err = 0.0;
+        for (int j = 0; j < ncol; j++)
+            err = fmax(err, fabs(red[j]));
+        red[kSlotErr] = err;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_reduce_sum(const double* __restrict__ in, int64_t count, double* __restrict__ out)
+{
+    __shared__ double sh[16];
+    double v = 0.0;
+    for (int64_t i = threadIdx.x; i < count; i += 1024)
+        v += in[i];
+    v = wave_reduce_sum(v);
+    if ((threadIdx.x & 63) == 0)
+        sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        double s = 0.0;
+        for (int k = 0; k < 16; k++)
+            s += sh[k];
+        out[0] = s;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_scale(const double* __restrict__ src, double* __restrict__ dst, int64_t npairs,
+                                                     double divisor)
+{
+    for (int64_t i = int64_t(blockIdx.x) * kThreads + threadIdx.x; i < npairs; i += int64_t(gridDim.x) * kThreads)
+    {
+        double2 v = reinterpret_cast<const double2*>(src)[i];
+        v.x = v.x / divisor;  // the reference divides (Lanczos.h:106 `f / beta`), it does not multiply by 1/beta
+        v.y = v.y / divisor;
+        reinterpret_cast<double2*>(dst)[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_axpby(double* __restrict__ f, double a, const double* __restrict__ v, double b,
+                                                     int64_t npairs, double* __restrict__ partials)
+{
+    __shared__ double red[4];
+    double b2 = 0.0;
+    for (int64_t i = int64_t(blockIdx.x) * kThreads + threadIdx.x; i < npairs; i += int64_t(gridDim.x) * kThreads)
+    {
+        double2 x = reinterpret_cast<double2*>(f)[i];
+        const double2 y = reinterpret_cast<const double2*>(v)[i];
+        x.x = x.x * a + y.x * b;  // Arnoldi.h:337
+        x.y = x.y * a + y.y * b;
+        reinterpret_cast<double2*>(f)[i] = x;
+        b2 += x.x * x.x + x.y * x.y;
+    }
+    const double tot = block_reduce_sum(b2, red);
+    if (threadIdx.x == 0)
+    {
+        partials[int64_t(blockIdx.x) * kPartialLd + kSlotBeta2] = tot;
+        partials[int64_t(blockIdx.x) * kPartialLd + kSlotMaxAbs] = 0.0;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_lanczos_epilogue(double* __restrict__ w, const double* __restrict__ v,
+                                                                const double* __restrict__ v_prev, double h_prev,
+                                                                int64_t npairs, double* __restrict__ partials)
+{
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int64_t i = int64_t(blockIdx.x) * kThreads + threadIdx.x; i < npairs; i += int64_t(gridDim.x) * kThreads)
+    {
+        double2 wv = reinterpret_cast<double2*>(w)[i];
+        const double2 vv = reinterpret_cast<const double2*>(v)[i];
+        if (v_prev)
+        {
+            const double2 pv = reinterpret_cast<const double2*>(v_prev)[i];
+            wv.x -= h_prev * pv.x;
+            wv.y -= h_prev * pv.y;
+            reinterpret_cast<double2*>(w)[i] = wv;
+        }
+        acc += vv.x * wv.x + vv.y * wv.y;
+    }
+    const double tot = block_reduce_sum(acc, red);
+    if (threadIdx.x == 0)
+        partials[blockIdx.x] = tot;
+}
+
+// r = y - lambda x : records get |r|^2 (kSlotBeta2) and |x|^2 (slot 0)
+__global__ __launch_bounds__(kThreads) void k_resid_norms(const double* __restrict__ y, const double* __restrict__ x,
+                                                           double lambda, int64_t npairs, double* __restrict__ partials)
+{
+    __shared__ double red[4];
+    __shared__ double red2[4];
+    double r2 = 0.0, x2 = 0.0;
+    for (int64_t i = int64_t(blockIdx.x) * kThreads + threadIdx.x; i < npairs; i += int64_t(gridDim.x) * kThreads)
+    {
+        const double2 yv = reinterpret_cast<const double2*>(y)[i];
+        const double2 xv = reinterpret_cast<const double2*>(x)[i];
+        const double r0 = yv.x - lambda * xv.x, r1 = yv.y - lambda * xv.y;
+        r2 += r0 * r0 + r1 * r1;
+        x2 += xv.x * xv.x + xv.y * xv.y;
+    }
+    const double t1 = block_reduce_sum(r2, red);
+    const double t2 = block_reduce_sum(x2, red2);
+    if (threadIdx.x == 0)
+    {
+        partials[int64_t(blockIdx.x) * kPartialLd + kSlotBeta2] = t1;
+        partials[int64_t(blockIdx.x) * kPartialLd + 0] = t2;
+        partials[int64_t(blockIdx.x) * kPartialLd + kSlotMaxAbs] = 0.0;
+    }
+}
+
+// X[:, 0:p] = V[:, 0:m] * Q.  128-row tiles of V are staged in LDS (all m columns), so the product
+// may overwrite V in place (compress_V): a tile's rows are private to its workgroup and fully read
+// before the first write.  Wave w produces output columns i = w (mod 4).  Q is re-laid out in LDS
+// so that a wave's coefficients for one j are contiguous (broadcast ds_read_b128).
+template <int MAXS>
+__global__ __launch_bounds__(kThreads) void k_vq(const double* __restrict__ V, int64_t ldv, int m,
+                                                  const double* __restrict__ Q, int ldq, int p, double* X, int64_t ldx,
+                                                  int64_t n)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* Vt = smem;                          // [m][128]
+    double* Qs = smem + int64_t(m) * kTileRows;  // [m][4][MAXS]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    for (int idx = tid; idx < m * 4 * MAXS; idx += kThreads)
+    {
+        const int jj = idx % MAXS, ww = (idx / MAXS) & 3, j = idx / (4 * MAXS);
+        const int i = ww + 4 * jj;
+        Qs[idx] = (i < p) ? Q[j + int64_t(i) * ldq] : 0.0;
+    }
+
+    const int64_t ntiles = (n + kTileRows - 1) / kTileRows;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x)
+    {
+        const int64_t r = t * kTileRows + 2 * lane;
+        const bool valid = r < n;
+        const int64_t rc = valid ? r : 0;
+        __syncthreads();  // previous tile fully consumed (and Qs written, first time round)
+        for (int j = w; j < m; j += 4)
+            *reinterpret_cast<double2*>(&Vt[j * kTileRows + 2 * lane]) = *reinterpret_cast<const double2*>(V + int64_t(j) * ldv + rc);
+        __syncthreads();
+
+        double2 acc[MAXS];
+#pragma unroll
+        for (int jj = 0; jj < MAXS; jj++)
+        {
+            acc[jj].x = 0.0;
+            acc[jj].y = 0.0;
+        }
+        for (int j = 0; j < m; j++)
+        {
+            const double2 v = *reinterpret_cast<const double2*>(&Vt[j * kTileRows + 2 * lane]);
+            const double* q = &Qs[(j * 4 + w) * MAXS];
+#pragma unroll
+            for (int jj = 0; jj < MAXS; jj++)
+            {
+                acc[jj].x += v.x * q[jj];  // Arnoldi.h:332-334 (dense form; structural zeros of Q multiply to 0)
+                acc[jj].y += v.y * q[jj];
+            }
+        }
+        if (valid)
+        {
+#pragma unroll
+            for (int jj = 0; jj < MAXS; jj++)
+            {
+                const int i = w + 4 * jj;
+                if (i < p)
+                    *reinterpret_cast<double2*>(X + int64_t(i) * ldx + r) = acc[jj];
+            }
+        }
+    }
+}
+
+// ---- SimpleRandom stream by jump-ahead (Util/SimpleRandom.h:30-52, :56-66, :92-96) -----------------
+__device__ __forceinline__ uint64_t mod_m31(uint64_t x)  // x < 2^62  ->  x mod (2^31 - 1)
+{
+    const uint64_t p = 2147483647ULL;
+    x = (x & p) + (x >> 31);
+    x = (x & p) + (x >> 31);
+    return x >= p ? x - p : x;
+}
+__global__ __launch_bounds__(kThreads) void k_simple_random(double* __restrict__ v, int64_t row_begin, int64_t nloc,
+                                                             uint64_t seed)
+{
+    constexpr int kRun = 16;
+    const int64_t first = (int64_t(blockIdx.x) * kThreads + threadIdx.x) * kRun;
+    if (first >= nloc)
+        return;
+    // state after k steps = s0 * 16807^k mod p ; element g of the stream is the state after g+1 steps
+    uint64_t s0 = seed ? (seed & 2147483647ULL) : 1ULL;
+    uint64_t e = uint64_t(row_begin + first);  // steps already taken before this run
+    uint64_t base = 16807ULL, pw = 1ULL;
+    while (e)
+    {
+        if (e & 1)
+            pw = mod_m31(pw * base);
+        base = mod_m31(base * base);
+        e >>= 1;
+    }
+    uint64_t s = mod_m31(s0 * pw);
+    const int64_t last = (first + kRun < nloc) ? first + kRun : nloc;
+    for (int64_t i = first; i < last; i++)
+    {
+        s = mod_m31(s * 16807ULL);
+        v[i] = double(int64_t(s)) / double(2147483647L) - 0.5;
+    }
+}
+
+int persistent_grid(const mispec_ctx& ctx, int64_t work_items, int per_cu)
+{
+    int64_t g = int64_t(ctx.num_cu) * per_cu;
+    if (g > work_items)
+        g = work_items;
+    if (g < 1)
+        g = 1;
+    return int(g);
+}
+
+template <int MODE>
+void launch_orth_mode(const mispec_ctx& ctx, const OrthArgs& a, int grid)
+{
+    const int slots = (a.ncol + 3) / 4;
+    const dim3 g(static_cast<unsigned>(grid)), b(kThreads);
+    if (slots <= 4)
+        hipLaunchKernelGGL((k_orth<MODE, 4>), g, b, 0, ctx.stream, a);
+    else if (slots <= 8)
+        hipLaunchKernelGGL((k_orth<MODE, 8>), g, b, 0, ctx.stream, a);
+    else if (slots <= 12)
+        hipLaunchKernelGGL((k_orth<MODE, 12>), g, b, 0, ctx.stream, a);
+    else
+        hipLaunchKernelGGL((k_orth<MODE, 16>), g, b, 0, ctx.stream, a);
+}
+
+}  // namespace
+
+namespace mispec {
+
+int launch_orth(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a)
+{
+    MISPEC_REQUIRE(a.ncol >= 0 && a.ncol <= kMaxOrthCols, "orth kernel: more than 64 basis columns");
+    const int64_t ntiles = (a.n + kTileRows - 1) / kTileRows;
+    const int grid = persistent_grid(ctx, ntiles, 4);
+    switch (mode)
+    {
+        case ORTH_VTF:
+            launch_orth_mode<ORTH_VTF>(ctx, a, grid);
+            break;
+        case ORTH_RESID_VTF:
+            launch_orth_mode<ORTH_RESID_VTF>(ctx, a, grid);
+            break;
+        case ORTH_CORRECT_VTF:
+            launch_orth_mode<ORTH_CORRECT_VTF>(ctx, a, grid);
+            break;
+        case ORTH_CORRECT_ONLY:
+            launch_orth_mode<ORTH_CORRECT_ONLY>(ctx, a, grid);
+            break;
+    }
+    MISPEC_HIP(hipGetLastError());
+    return grid;
+}
+
+void launch_reduce_partials(const mispec_ctx& ctx, const double* partials, int nrec, int ncol, double* red, bool finish)
+{
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx.stream, partials, nrec, ncol, red, finish ? 1 : 0);
+    MISPEC_HIP(hipGetLastError());
+}
+
+void launch_finish(const mispec_ctx& ctx, double* red, int ncol)
+{
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, ctx.stream, red, ncol);
+    MISPEC_HIP(hipGetLastError());
+}
+
+void launch_reduce_sum(const mispec_ctx& ctx, const double* in, int64_t count, double* out)
+{
+    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(1024), 0, ctx.stream, in, count, out);
+    MISPEC_HIP(hipGetLastError());
+}
+
+void launch_scale(const mispec_ctx& ctx, const double* src, double* dst, int64_t npad, double divisor)
+{
+    const int64_t npairs = npad / 2;
+    if (npairs == 0)
+        return;
+    const int grid = persistent_grid(ctx, (npairs + kThreads - 1) / kThreads, 8);
+    hipLaunchKernelGGL(k_scale, dim3(unsigned(grid)), dim3(kThreads), 0, ctx.stream, src, dst, npairs, divisor);
+    MISPEC_HIP(hipGetLastError());
+}
+
+int launch_axpby(const mispec_ctx& ctx, double* f, double a, const double* v, double b, int64_t n, double* partials)
+{
+    const int64_t npairs = (n + 1) / 2;
+    const int grid = persistent_grid(ctx, (npairs + kThreads - 1) / kThreads, 4);
+    hipLaunchKernelGGL(k_axpby, dim3(unsigned(grid)), dim3(kThreads), 0, ctx.stream, f, a, v, b, npairs, partials);
+    MISPEC_HIP(hipGetLastError());
+    return grid;
+}
+
+int launch_resid_norms(const mispec_ctx& ctx, const double* y, const double* x, double lambda, int64_t n, double* partials)
+{
+    const int64_t npairs = (n + 1) / 2;
+    const int grid = persistent_grid(ctx, (npairs + kThreads - 1) / kThreads, 4);
+    hipLaunchKernelGGL(k_resid_norms, dim3(unsigned(grid)), dim3(kThreads), 0, ctx.stream, y, x, lambda, npairs, partials);
+    MISPEC_HIP(hipGetLastError());
+    return grid;
+}
+
+void launch_vq(const mispec_ctx& ctx, const double* V, int64_t ldv, int m, const double* Q, int ldq, int p, double* X,
+               int64_t ldx, int64_t n)
+{
+    MISPEC_REQUIRE(m >= 1 && m <= kMaxOrthCols && p >= 1 && p <= kMaxOrthCols, "V*Q kernel: needs 1 <= m, p <= 64");
+    const int64_t ntiles = (n + kTileRows - 1) / kTileRows;
+    const int slots = (p + 3) / 4;
+    const int maxs = slots <= 4 ? 4 : slots <= 8 ? 8 : slots <= 12 ? 12 : 16;
+    const size_t lds = (size_t(m) * kTileRows + size_t(m) * 4 * maxs) * sizeof(double);
+    const int grid = persistent_grid(ctx, ntiles, 2);
+    const dim3 g(static_cast<unsigned>(grid)), b(kThreads);
+#define MISPEC_VQ(S)                                                                                                   \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        MISPEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vq<S>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       int(lds)));                                                                     \
+        hipLaunchKernelGGL((k_vq<S>), g, b, lds, ctx.stream, V, ldv, m, Q, ldq, p, X, ldx, n);                         \
+    } while (0)
+    if (maxs == 4)
+        MISPEC_VQ(4);
+    else if (maxs == 8)
+        MISPEC_VQ(8);
+    else if (maxs == 12)
+        MISPEC_VQ(12);
+    else
+        MISPEC_VQ(16);
+#undef MISPEC_VQ
+    MISPEC_HIP(hipGetLastError());
+}
+
+int lanczos_epilogue_records(const mispec_ctx& ctx, int64_t n)
+{
+    const int64_t npairs = (n + 1) / 2;
+    return persistent_grid(ctx, (npairs + kThreads - 1) / kThreads, 4);
+}
+
+void launch_lanczos_epilogue(const mispec_ctx& ctx, double* w, const double* v, const double* v_prev, double h_prev, int64_t n,
+                             double* partials)
+{
+    const int64_t npairs = (n + 1) / 2;
+    const int grid = lanczos_epilogue_records(ctx, n);
+    hipLaunchKernelGGL(k_lanczos_epilogue, dim3(unsigned(grid)), dim3(kThreads), 0, ctx.stream, w, v, v_prev, h_prev, npairs,
+                       partials);
+    MISPEC_HIP(hipGetLastError());
+}
+
+void launch_simple_random(const mispec_ctx& ctx, double* v, int64_t row_begin, int64_t nloc, uint64_t seed)
+{
+    if (nloc == 0)
+        return;
+    const int64_t threads = (nloc + 15) / 16;
+    hipLaunchKernelGGL(k_simple_random, dim3(unsigned((threads + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx.stream, v,
+                       row_begin, nloc, seed);
+    MISPEC_HIP(hipGetLastError());
+}
+
+}  // namespace mispec

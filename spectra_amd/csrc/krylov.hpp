@@ -1,0 +1,64 @@
+// Length-n dense kernels of the Lanczos/Arnoldi factorisation.
+#pragma once
+#include "common.hpp"
+
+namespace mispec {
+
+// Per-workgroup partial record written by the orthogonalisation kernels and summed by
+// launch_reduce_partials in a fixed order (deterministic: no floating-point atomics anywhere).
+constexpr int kPartialLd = 72;
+constexpr int kSlotBeta2 = 64;   // sum f^2
+constexpr int kSlotMaxAbs = 65;  // max |f|
+constexpr int kSlotBeta = 66;    // sqrt(sum f^2)            (filled by the finish step)
+constexpr int kSlotErr = 67;     // max_j |(V'f)_j|          (filled by the finish step)
+constexpr int kSlotAlpha = 68;   // <v, w> of the SpMV epilogue
+constexpr int kMaxOrthCols = 64; // basis columns handled by one launch (ncv <= 64 on the device path)
+
+enum OrthMode
+{
+    ORTH_VTF = 0,          // c = V'f                                   (ArnoldiOp.h:145-148)
+    ORTH_RESID_VTF = 1,    // f = w - alpha*v_i ; |f|^2 ; c = V'f       (Lanczos.h:145-152 fused)
+    ORTH_CORRECT_VTF = 2,  // dst = src - V c_in ; |dst|^2 ; c = V'dst  (Lanczos.h:171-179 fused)
+    ORTH_CORRECT_ONLY = 3  // dst = src - V c_in ; |dst|^2              (Arnoldi.h:254-255)
+};
+
+struct OrthArgs
+{
+    const double* V = nullptr;  // basis, column-major
+    int64_t ldv = 0;
+    int ncol = 0;               // columns 0..ncol-1 take part
+    int64_t n = 0;              // local rows
+    const double* src = nullptr;  // VTF: f ; RESID: w ; CORRECT: input vector
+    double* dst = nullptr;        // RESID / CORRECT output (may alias src)
+    const double* vi = nullptr;   // RESID: basis column i
+    const double* alpha_dev = nullptr;  // RESID: device scalar
+    const double* c_in = nullptr;       // CORRECT: device coefficients [ncol]
+    double* partials = nullptr;         // [records][kPartialLd]
+};
+
+// All launchers enqueue on ctx.stream and return immediately.
+int launch_orth(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a);  // returns the number of partial records
+// red[0..kPartialLd): column sums of the records (+ max for kSlotMaxAbs); finish additionally fills kSlotBeta / kSlotErr.
+void launch_reduce_partials(const mispec_ctx& ctx, const double* partials, int nrec, int ncol, double* red, bool finish);
+void launch_finish(const mispec_ctx& ctx, double* red, int ncol);
+// out[0] = sum of `count` doubles (SpMV alpha partials), fixed order
+void launch_reduce_sum(const mispec_ctx& ctx, const double* in, int64_t count, double* out);
+// dst = src / divisor over npad elements (v = f / beta, Lanczos.h:106)
+void launch_scale(const mispec_ctx& ctx, const double* src, double* dst, int64_t npad, double divisor);
+// f = f*a + v*b, partial |f|^2 records (Arnoldi.h:337-339); returns the number of records
+int launch_axpby(const mispec_ctx& ctx, double* f, double a, const double* v, double b, int64_t n, double* partials);
+// X[:, 0:p] = V[:, 0:m] * Q (Q device, m x p col-major, ldq); X may alias V (in-place compress_V).
+void launch_vq(const mispec_ctx& ctx, const double* V, int64_t ldv, int m, const double* Q, int ldq, int p, double* X,
+               int64_t ldx, int64_t n);
+// res[j] = || A x_j - lambda_j x_j ||^2 partials and ||x_j||^2 partials are produced by the caller with the kernels above.
+// r = y - lambda*x ; records hold |r|^2 in kSlotBeta2 and |x|^2 in slot 0.
+int launch_resid_norms(const mispec_ctx& ctx, const double* y, const double* x, double lambda, int64_t n, double* partials);
+// Un-fused Lanczos epilogue for user operators (Lanczos.h:139-142): w -= h_prev*v_prev (if v_prev), one partial
+// of <v, w> per workgroup in partials[0 .. lanczos_epilogue_records).
+int lanczos_epilogue_records(const mispec_ctx& ctx, int64_t n);
+void launch_lanczos_epilogue(const mispec_ctx& ctx, double* w, const double* v, const double* v_prev, double h_prev, int64_t n,
+                             double* partials);
+// fill v[i] = SimpleRandom(seed) stream element (row_begin + i), i < nloc, by LCG jump-ahead (Util/SimpleRandom.h:30-123)
+void launch_simple_random(const mispec_ctx& ctx, double* v, int64_t row_begin, int64_t nloc, uint64_t seed);
+
+}  // namespace mispec
