@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""Headline benchmark: BASELINE.json configs[1] — SymEigsSolver on a 10M x 10M, ~15 nnz/row fp64 symmetric CSR,
+k = 20, ncv = 40 — on N MI355X of one node (N > 1: the same matrix row-partitioned, RCCL all-gather of the
+Krylov vector per SpMV = configs[2], strong scaling).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE complete solve: init() + compute(LargestMagn, tol) + eigenvectors() with the matrix already
+resident in HBM (generated there by the counter-hash generator of SURVEY.md §8d).  Rank 0 prints one JSON
+line: value = eigenpairs/s of the whole job; `roofline` = the per-iteration CSR SpMV kernel, algorithmic
+bytes / mean launch duration from HIP events recorded on the solver's stream inside the timed region;
+`cpu_baseline` = the CPU oracle (Eigen-free restatement of the reference, 1 thread like the reference) timed on
+a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--n", type=int, default=10_000_000, help="matrix dimension (default: BASELINE.json configs[1])")
+    p.add_argument("--nev", type=int, default=20)
+    p.add_argument("--ncv", type=int, default=40)
+    p.add_argument("--tol", type=float, default=1e-11,
+                   help="1e-11 so that ||Av - lv||/||v|| <= 1e-10 holds for |l| ~ 2.5 (the criterion is relative to |l|)")
+    p.add_argument("--selection", default="LargestMagn")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-steps", type=int, default=5, help="Lanczos steps of the CPU sample")
+    p.add_argument("--spmv-reps", type=int, default=50, help="stand-alone SpMV launches timed after the solves")
+    return p.parse_args()
+
+
+def cpu_baseline(args, gpu_nops, gpu_nconv):
+    """The oracle (a 'port': Eigen is absent, see oracle/spectra_oracle.hpp) on the host, 1 thread."""
+    import numpy as np
+
+    import oracle as O
+
+    t0 = time.time()
+    rp, ci, v = O.synth_band_csr(args.n)
+    op = O.Op.csr(args.n, args.n, rp, ci, v)
+    t_gen = time.time() - t0
+    secs, nops = O.time_lanczos_steps(op, args.ncv, args.cpu_steps)
+    x = O.simple_random(args.n, 0)
+    t_spmv = op.time_op(x, 3)
+    per_op = secs / nops
+    est_total = per_op * gpu_nops
+    return {
+        "value": gpu_nconv / est_total,
+        "unit": "eigenpairs/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": (f"oracle init() + {args.cpu_steps} Lanczos steps at n={args.n} ({nops} perform_op, {secs:.1f} s, "
+                   f"{per_op:.3f} s/op incl. re-orthogonalisation; matrix generation {t_gen:.1f} s not timed), "
+                   f"extrapolated to the GPU run's {gpu_nops} operations — early steps orthogonalise against few "
+                   f"columns, so this favours the CPU"),
+        "seconds_per_op": per_op,
+        "spmv_seconds": t_spmv,
+        "spmv_gbps": (12.0 * len(v) + 20.0 * args.n + 4) / t_spmv / 1e9,
+    }
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import spectra_amd as sa
+    from spectra_amd import dist as sdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 or args.gpus > 1:
+        rank, world = sdist.init_process_group("nccl")
+        assert world == args.gpus, f"launched {world} ranks for --gpus {args.gpus}"
+    else:
+        rank, world = 0, 1
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    ctx = sdist.make_context(local)
+
+    def barrier():
+        torch.cuda.synchronize()
+        ctx.sync()
+        if world > 1:
+            dist.barrier()
+
+    op = sa.SparseSymMatProd.synth_band(args.n, ctx=ctx)  # resident in HBM before any timing
+    nnz_local = op.nnz()
+    rule = sa.SortRule[args.selection]
+
+    def solve(profile):
+        eigs = sa.SymEigsSolver(op, args.nev, args.ncv)
+        if profile:
+            eigs.profile(True)
+        eigs.init()
+        nconv = eigs.compute(rule, 1000, args.tol)
+        ncols = eigs.eigenvectors(to_host=False)  # V * Y formed in HBM (1.6 GB at n = 1e7; not pulled over PCIe)
+        return eigs, nconv, ncols
+
+    for _ in range(args.warmup):
+        solve(False)
+    barrier()
+    t0 = time.perf_counter()
+    solvers = []
+    total_pairs = 0
+    for _ in range(args.steps):
+        eigs, nconv, ncols = solve(True)
+        total_pairs += nconv
+        solvers.append(eigs)
+    barrier()
+    elapsed = sdist.max_over_ranks(time.perf_counter() - t0)
+
+    # ---- everything below is outside the timed region -------------------------------------------------
+    eigs = solvers[-1]
+    prof = {k: 0.0 for k in eigs.get_profile()}
+    for s in solvers:
+        for k, v in s.get_profile().items():
+            prof[k] = prof[k] + v if k != "spmv_bytes" else v
+    resid = eigs.residuals()
+    evals = eigs.eigenvalues()
+    spmv_ms = prof["ms_spmv"] / max(prof["n_spmv"], 1)
+    spmv_bytes = prof["spmv_bytes"]
+    achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
+
+    # stand-alone SpMV (same kernel, x resident) as a cross-check of the in-loop number
+    x = torch.rand(args.n if world == 1 else int(sa.lib().mispec_shard_block(args.n, world)) * world, dtype=torch.float64,
+                   device="cuda") - 0.5
+    y = torch.empty(op.local_rows() + 2, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    op.spmv_time(x.data_ptr(), y.data_ptr(), 5)
+    alone_ms = op.spmv_time(x.data_ptr(), y.data_ptr(), args.spmv_reps)
+
+    if rank == 0:
+        out = {
+            "metric": "eigenpairs_per_sec",
+            "value": total_pairs / elapsed,
+            "unit": "eigenpairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": ("BASELINE.json configs[1]: SymEigsSolver + SparseSymMatProd, 10M x 10M ~15 nnz/row fp64 "
+                             "symmetric CSR (M-band, SURVEY.md 8d)" if args.n == 10_000_000 else f"M-band n={args.n}"),
+                "n": args.n, "nnz_per_gpu": nnz_local, "nev": args.nev, "ncv": args.ncv, "selection": args.selection,
+                "tol": args.tol, "start_vector": "SimpleRandom(0) (reference default)",
+                "parallelism": f"row-shard x{world}" + (", RCCL all-gather of the Krylov vector per SpMV" if world > 1 else ""),
+            },
+            "roofline": {
+                "kernel": "k_spmv_csr_stream (CSR SpMV fused with w -= beta*v_prev and the alpha dot)",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": None,
+                "bytes_per_launch": spmv_bytes,
+                "ms_per_launch": spmv_ms,
+                "launches": int(prof["n_spmv"]),
+                "standalone_ms_per_launch": alone_ms,
+                "standalone_gbps": spmv_bytes / (alone_ms * 1e-3) / 1e9,
+            },
+            "solve": {
+                "nconv": int(total_pairs // args.steps), "num_operations": int(eigs.num_operations()),
+                "num_iterations": int(eigs.num_iterations()), "max_residual": float(resid.max()) if len(resid) else None,
+                "lambda_max": float(evals.max()) if len(evals) else None, "lambda_min": float(evals.min()) if len(evals) else None,
+                "host_syncs_per_solve": prof["n_host_sync"] / args.steps,
+            },
+            "kernels_ms_per_solve": {k[3:]: prof[k] / args.steps for k in prof if k.startswith("ms_")},
+            "kernels_launches_per_solve": {k[2:]: prof[k] / args.steps for k in prof if k.startswith("n_")},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, int(eigs.num_operations()), int(total_pairs // args.steps))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -303,8 +303,8 @@ extern "C" int mispec_csr_upload(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols
                                  const int32_t* colind_host, const double* val_host, mispec_csr** out)
 {
     return guarded([&] {
-        MISPEC_REQUIRE(out, "mispec_csr_upload: out is NULL");
-        MISPEC_REQUIRE(n_rows == 0 || (colind_host && val_host) || rowptr_host[n_rows] == 0, "mispec_csr_upload: NULL arrays");
+        MISPEC_REQUIRE(ctx && out && rowptr_host, "mispec_csr_upload: NULL argument");
+        MISPEC_REQUIRE((colind_host && val_host) || rowptr_host[n_rows] == 0, "mispec_csr_upload: NULL arrays");
         *out = upload_rows(ctx, n_rows, n_cols, rowptr_host, colind_host, val_host);
     });
 }

@@ -1,0 +1,143 @@
+"""Row-sharded runs: one process per GPU, `torch.distributed` for rendezvous, RCCL over xGMI for the data path.
+
+The eigensolver needs exactly two collectives: an all-gather of the current Krylov vector
+before every SpMV and a sum all-reduce of a few doubles (alpha, |f|^2, V'f) after the reductions.  Two
+transports are offered, both ending in RCCL:
+
+  * "rccl"  (default) — the library's own RCCL communicator (`mispec_ctx_set_comm_rccl`): rank 0 creates an
+    ncclUniqueId, `torch.distributed` broadcasts it, every rank calls ncclCommInitRank.  Collectives are
+    enqueued by C++ on the solver's stream, no Python in the loop.
+  * "torch" — Python callbacks that run `dist.all_gather_into_tensor` / `dist.all_reduce` (backend "nccl" is
+    RCCL on ROCm; "gloo" works for CPU tensors in the tests) on tensors aliasing the library's device buffers.
+    The context must then run on torch's current stream so that torch orders the collectives with the kernels.
+
+`torch` is plumbing here (process group, streams); all arithmetic stays in libmispec.so.
+"""
+import os
+
+import numpy as np
+
+from . import Context, shard_range
+
+
+def init_process_group(backend=None):
+    """Initialise torch.distributed from the torchrun environment (RANK / WORLD_SIZE / MASTER_*)."""
+    import torch
+    import torch.distributed as dist
+
+    if dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world == 1 and "MASTER_ADDR" not in os.environ:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world
+
+
+class _DeviceArray:
+    """Zero-copy view of `count` doubles at a raw device pointer, consumable by torch.as_tensor."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+class TorchComm:
+    """The two collectives on torch tensors (any backend)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def allgather(self, send, recv):
+        """recv[r*len(send):(r+1)*len(send)] = send of rank r."""
+        self.dist.all_gather_into_tensor(recv, send, group=self.group)
+
+    def allreduce_sum(self, buf):
+        self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    # raw-pointer forms used as C callbacks (device memory)
+    def _allgather_ptr(self, send_ptr, recv_ptr, count, stream):
+        import torch
+
+        send = torch.as_tensor(_DeviceArray(send_ptr, count), device="cuda")
+        recv = torch.as_tensor(_DeviceArray(recv_ptr, count * self.world), device="cuda")
+        self.allgather(send, recv)
+        return 0
+
+    def _allreduce_ptr(self, buf_ptr, count, stream):
+        import torch
+
+        self.allreduce_sum(torch.as_tensor(_DeviceArray(buf_ptr, count), device="cuda"))
+        return 0
+
+
+def make_context(device=None, transport=None):
+    """Context for this rank's GPU with the communicator attached (no-op communicator when world == 1).
+
+    Requires torch.distributed to be initialised when WORLD_SIZE > 1."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    transport = transport or os.environ.get("MISPEC_COMM", "rccl")
+    torch.cuda.set_device(device)
+    if world > 1 and transport == "torch":
+        ctx = Context(device, stream=torch.cuda.current_stream().cuda_stream)
+        comm = TorchComm()
+        ctx.set_comm_callbacks(rank, world, comm._allgather_ptr, comm._allreduce_ptr)
+        ctx._comm = comm
+    else:
+        ctx = Context(device)
+        if world > 1:
+            payload = [Context.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(payload, src=0)
+            ctx.set_comm_rccl(rank, world, payload[0])
+    return ctx
+
+
+def max_over_ranks(seconds):
+    """Wall time of the slowest rank (the bench contract's max-over-ranks)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return float(seconds)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([float(seconds)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_rows(local_block, n, group=None):
+    """Assemble the row blocks of every rank (each `local_rows x k`, numpy) into the full n x k array on all ranks."""
+    import torch.distributed as dist
+
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return np.asarray(local_block)
+    parts = [None] * dist.get_world_size(group)
+    dist.all_gather_object(parts, np.asarray(local_block), group=group)
+    full = np.vstack(parts)
+    assert full.shape[0] == n, (full.shape, n)
+    return full
+
+
+def local_rows_of(global_vector, n=None):
+    """This rank's slice of a replicated length-n array (mispec_shard_range)."""
+    import torch.distributed as dist
+
+    if not dist.is_initialized():
+        return global_vector
+    n = len(global_vector) if n is None else n
+    b, e = shard_range(n, dist.get_world_size(), dist.get_rank())
+    return global_vector[b:e]

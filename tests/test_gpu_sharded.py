@@ -1,0 +1,71 @@
+"""Row-sharded path exercised on ONE GPU: `world` host threads, each with its own context,
+stream and row shard, joined by the library's loopback communicator (all-gather of the Krylov vector before
+every SpMV, sum all-reduce of alpha / |f|^2 / V'f).  The SPMD code is the one a multi-process RCCL run
+executes; only the transport differs."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+import oracle as O
+import spectra_amd as sa
+from spectra_amd import _capi
+
+pytestmark = pytest.mark.gpu
+
+
+def run_sharded(world, n, offsets, nev, ncv, rule, tol):
+    lib = sa.lib()
+    grp = C.c_void_p()
+    _capi.check(lib.mispec_loopback_create(world, C.byref(grp)))
+    results, errors = [None] * world, []
+
+    def worker(rank):
+        try:
+            ctx = sa.Context(0)
+            _capi.check(lib.mispec_loopback_attach(grp, ctx.h, rank))
+            ctx.rank, ctx.world = rank, world
+            op = sa.SparseSymMatProd.synth_band(n, offsets=offsets, ctx=ctx)
+            eigs = sa.SymEigsSolver(op, nev, ncv)
+            eigs.init()
+            nconv = eigs.compute(rule, 1000, tol)
+            results[rank] = dict(nconv=nconv, info=eigs.info(), evals=eigs.eigenvalues(), X=eigs.eigenvectors(),
+                                 nops=eigs.num_operations(), niter=eigs.num_iterations(), res=eigs.residuals(),
+                                 rows=sa.shard_range(n, world, rank), local=op.local_rows())
+        except Exception as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    _capi.check(lib.mispec_loopback_destroy(grp))
+    return results
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_equals_unsharded(ctx, world):
+    n, offsets, nev, ncv = 50_001, (1, 2, 3, 100, 101, 5000, 5001), 8, 24
+    single = sa.SymEigsSolver(sa.SparseSymMatProd.synth_band(n, offsets=offsets, ctx=ctx), nev, ncv)
+    single.init()
+    assert single.compute(sa.SortRule.LargestAlge, 1000, 1e-11) == nev
+    ev1, X1 = single.eigenvalues(), single.eigenvectors()
+
+    res = run_sharded(world, n, offsets, nev, ncv, sa.SortRule.LargestAlge, 1e-11)
+    for r in res:
+        assert r["nconv"] == nev and r["info"] == sa.CompInfo.Successful
+        assert np.array_equal(r["evals"], res[0]["evals"])          # every rank holds the same H
+        assert r["nops"] == res[0]["nops"] and r["niter"] == res[0]["niter"]
+        assert r["local"] == r["rows"][1] - r["rows"][0] == r["X"].shape[0]
+        assert r["res"].max() <= 1e-10
+    assert np.abs(res[0]["evals"] - ev1).max() < 1e-10
+    X = np.vstack([r["X"] for r in res])                              # row blocks tile [0, n)
+    assert X.shape == X1.shape
+    assert np.abs(np.abs(np.sum(X * X1, axis=0)) - 1.0).max() < 1e-8  # same vectors up to sign
+    rp, ci, v = O.synth_band_csr(n, offsets=offsets)
+    import scipy.sparse as sp
+    A = sp.csr_matrix((v, ci, rp), shape=(n, n))
+    assert (np.linalg.norm(A @ X - X * res[0]["evals"], axis=0) / np.linalg.norm(X, axis=0)).max() <= 1e-10

@@ -1,0 +1,145 @@
+"""K1 — the CSR SpMV kernel behind Sparse{Sym,Gen}MatProd::perform_op, through the C ABI, vs the CPU oracle.
+
+The kernel adds each row's products in storage order, exactly like the oracle's row-dot (and Eigen's
+row-major product), so agreement with oracle.Op.csr is BIT-EXACT.  Against the reference-semantics
+CSC-lower self-adjoint product (different summation order) the bound is 1e-13 relative.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle as O
+import spectra_amd as sa
+from helpers import SPARSE_CASES, sparse_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_x(n, seed=0):
+    return np.random.default_rng(seed).uniform(-1, 1, n)
+
+
+@pytest.mark.parametrize("n,prob", [(c[0], c[1]) for c in SPARSE_CASES])
+def test_sym_op_on_reference_fixtures(ctx, n, prob):
+    # test/SparseSymMatProd.cpp:37-54 (op * M == mat * M, op(i,j) == coeff) on the reproducible fixture;
+    # only the lower triangle of the (non-symmetric) input may be read (test/SymEigs.cpp:27-28)
+    A, S = sparse_fixture(n, prob)
+    op = sa.SparseSymMatProd(A, ctx=ctx)
+    assert (op.rows(), op.cols()) == (n, n)
+    x = rand_x(n)
+    y = op.perform_op(x)
+    ref_sym = O.Op.csc_sym(n, A.indptr, A.indices, A.data, True).perform_op(x)
+    assert np.abs(y - ref_sym).max() <= 1e-13 * max(1.0, np.abs(ref_sym).max())
+    ref_csr = O.Op.csr(n, n, S.indptr, S.indices, S.data).perform_op(x)
+    assert np.array_equal(y, ref_csr)  # bit-exact: same summation order
+    X = np.random.default_rng(1).uniform(-1, 1, (n, 3))
+    assert np.allclose(op @ X, S @ X, rtol=0, atol=1e-13)
+    i, j = min(45, n - 1), min(22, n - 2)
+    assert op(i, j) == S[i, j] and op(j, i) == S[j, i]
+    # upper-triangle operator of the same input
+    Su = (sp.triu(A) + sp.triu(A, 1).T).tocsr()
+    opu = sa.SparseSymMatProd(A, uplo="U", ctx=ctx)
+    assert np.array_equal(opu.perform_op(x), O.Op.csr(n, n, Su.indptr, Su.indices, Su.data).perform_op(x))
+    # row-major input (Flags = RowMajor)
+    opr = sa.SparseSymMatProd(A.tocsr(), ctx=ctx)
+    assert np.array_equal(opr.perform_op(x), ref_csr)
+
+
+@pytest.mark.parametrize("fmt", ["csr", "csc"])
+def test_gen_op(ctx, fmt):
+    # test/SparseGenMatProd.cpp:37-53
+    n = 300
+    A = sp.random(n, n, density=0.05, random_state=3, format=fmt)
+    A.data[:] = np.random.default_rng(3).uniform(-1, 1, A.nnz)
+    op = sa.SparseGenMatProd(A, ctx=ctx)
+    x = rand_x(n, 4)
+    Ar = A.tocsr()
+    Ar.sort_indices()
+    assert np.array_equal(op.perform_op(x), O.Op.csr(n, n, Ar.indptr, Ar.indices, Ar.data).perform_op(x))
+    Ac = A.tocsc()
+    Ac.sort_indices()
+    ref_csc = O.Op.csc(n, n, Ac.indptr, Ac.indices, Ac.data).perform_op(x)  # the reference default layout
+    assert np.abs(op.perform_op(x) - ref_csc).max() <= 1e-13
+
+
+@pytest.mark.parametrize("n", [1, 2, 255, 256, 257, 511, 1000, 4097])
+def test_ragged_sizes_and_empty_rows(ctx, n):
+    rng = np.random.default_rng(n)
+    A = sp.random(n, n, density=min(1.0, 8.0 / n), random_state=n, format="csr")
+    A.data[:] = rng.uniform(-1, 1, A.nnz)
+    if n > 4:  # force some empty rows
+        A = A.tolil()
+        A[n // 2, :] = 0
+        A[0, :] = 0
+        A = A.tocsr()
+        A.eliminate_zeros()
+    op = sa.SparseGenMatProd(A, ctx=ctx)
+    x = rand_x(n, 9)
+    A.sort_indices()
+    assert np.array_equal(op.perform_op(x), O.Op.csr(n, n, A.indptr, A.indices, A.data).perform_op(x))
+
+
+def test_rows_longer_than_the_lds_chunk(ctx):
+    # a dense-ish row (> 4080 products) must be summed across chunks, still in storage order
+    n = 6000
+    rng = np.random.default_rng(7)
+    rows = [np.full(n, 3), np.full(5000, 700), rng.integers(0, n, 20000)]
+    cols = [np.arange(n), rng.choice(n, 5000, replace=False), rng.integers(0, n, 20000)]
+    r, c = np.concatenate(rows), np.concatenate(cols)
+    A = sp.coo_matrix((rng.uniform(-1, 1, len(r)), (r, c)), shape=(n, n)).tocsr()
+    A.sum_duplicates()
+    A.sort_indices()
+    op = sa.SparseGenMatProd(A, ctx=ctx)
+    x = rand_x(n, 11)
+    assert np.array_equal(op.perform_op(x), O.Op.csr(n, n, A.indptr, A.indices, A.data).perform_op(x))
+
+
+def test_synthetic_band_matrix_is_bit_identical_to_the_cpu_statement(ctx):
+    n = 300000
+    op = sa.SparseSymMatProd.synth_band(n, ctx=ctx)
+    rp, ci, v = op.to_host_csr()
+    rp0, ci0, v0 = O.synth_band_csr(n)
+    assert np.array_equal(rp, rp0) and np.array_equal(ci, ci0) and np.array_equal(v, v0)
+    x = rand_x(n, 2)
+    assert np.array_equal(op.perform_op(x), O.Op.csr(n, n, rp0, ci0, v0).perform_op(x))
+    g = sa.SparseGenMatProd.synth_band(5000, offsets=(1, 2, 50), ctx=ctx)
+    rp1, ci1, v1 = g.to_host_csr()
+    rp2, ci2, v2 = O.synth_band_csr(5000, offsets=(1, 2, 50), symmetric=False)
+    assert np.array_equal(ci1, ci2) and np.array_equal(v1, v2)
+
+
+def test_spmv_linearity_at_full_size(ctx):
+    # size-independent property at BASELINE.json's n = 1e7 (the oracle cannot be run there in seconds):
+    # A(a x + b y) == a A x + b A y up to rounding, and symmetry x'Ay == y'Ax.
+    import torch
+
+    n = 10_000_000
+    op = sa.SparseSymMatProd.synth_band(n, ctx=ctx)
+    assert op.nnz() == 15 * n - 2 * (1 + 2 + 3 + 1000 + 1001 + 100000 + 100001)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.rand(n, dtype=torch.float64, device="cuda", generator=g) - 0.5
+    y = torch.rand(n, dtype=torch.float64, device="cuda", generator=g) - 0.5
+    Ax, Ay, Az = (torch.empty(n, dtype=torch.float64, device="cuda") for _ in range(3))
+    torch.cuda.synchronize()
+    z = 0.75 * x - 1.25 * y
+    torch.cuda.synchronize()
+    op.spmv_device(x.data_ptr(), Ax.data_ptr())
+    op.spmv_device(y.data_ptr(), Ay.data_ptr())
+    op.spmv_device(z.data_ptr(), Az.data_ptr())
+    ctx.sync()
+    lin = (Az - (0.75 * Ax - 1.25 * Ay)).abs().max().item()
+    assert lin < 1e-14 * 16
+    sym = abs(torch.dot(x, Ay).item() - torch.dot(y, Ax).item())
+    assert sym < 1e-9 * abs(torch.dot(x, Ay).item()) + 1e-7
+    # spot-check 1000 rows against the CPU statement of the matrix
+    rows = np.random.default_rng(0).integers(0, n, 1000)
+    xh = x.cpu().numpy()
+    offs = np.array(sorted({0} | {s * o for o in sa.BAND_OFFSETS for s in (1, -1)}))
+    Axh = Ax.cpu().numpy()
+    for i in rows:
+        acc = 0.0
+        for o in offs:
+            j = i + o
+            if 0 <= j < n:
+                acc += O.lib().oracle_synth_value(sa.SYNTH_SEED, min(i, j), max(i, j)) * xh[j]
+        assert Axh[i] == acc
