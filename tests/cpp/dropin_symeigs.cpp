@@ -1,0 +1,168 @@
+// Drop-in check of the header-only API: this file is written the way a Spectra user writes code
+// (compare /root/reference/test/SymEigs.cpp:44-97 and the doc example SymEigsSolver.h:99-126) and is built
+// with a plain host compiler against include/Spectra + libmispec.so:
+//     g++ -std=c++17 -I include tests/cpp/dropin_symeigs.cpp -L spectra_amd -lmispec -Wl,-rpath,$PWD/spectra_amd
+// It needs a GPU to run (tests/test_gpu_cpp_dropin.py).  Eigen is not available here, so matrices are handed
+// over as Spectra::SparseView and results come back as Spectra::DenseVector / DenseMatrix.
+#include <Spectra/SymEigsSolver.h>
+#include <Spectra/MatOp/SparseSymMatProd.h>
+
+#include <cmath>
+#include <cstdio>
+#include <random>
+#include <vector>
+
+using namespace Spectra;
+
+struct Csc
+{
+    int n;
+    std::vector<int> colptr, rowind;
+    std::vector<double> val;
+    SparseView<double> view() const
+    {
+        SparseView<double> v;
+        v.rows = v.cols = n;
+        v.outer = colptr.data();
+        v.inner = rowind.data();
+        v.values = val.data();
+        v.row_major = false;
+        return v;
+    }
+};
+
+// The reproducible fixture of test/SymEigs.cpp:25-42 (libstdc++ RNG), stored column-major like Eigen's default.
+static Csc gen_sparse_data(int n, double prob)
+{
+    std::vector<std::vector<std::pair<int, double>>> cols(n);
+    std::default_random_engine gen;
+    gen.seed(0);
+    std::uniform_real_distribution<double> distr(0.0, 1.0);
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++)
+            if (distr(gen) < prob)
+                cols[j].push_back({i, distr(gen) - 0.5});
+    Csc A;
+    A.n = n;
+    A.colptr.push_back(0);
+    for (int j = 0; j < n; j++)
+    {
+        for (auto& e : cols[j])
+        {
+            A.rowind.push_back(e.first);
+            A.val.push_back(e.second);
+        }
+        A.colptr.push_back((int) A.rowind.size());
+    }
+    return A;
+}
+
+// ||A U - U D||_inf with A = selfadjointView<Lower> of the fixture
+static double residual(const Csc& A, const DenseVector<double>& evals, const DenseMatrix<double>& U)
+{
+    double err = 0.0;
+    std::vector<double> y(A.n);
+    for (Index c = 0; c < U.cols(); c++)
+    {
+        std::fill(y.begin(), y.end(), 0.0);
+        for (int j = 0; j < A.n; j++)
+            for (int p = A.colptr[j]; p < A.colptr[j + 1]; p++)
+            {
+                const int i = A.rowind[p];
+                if (i < j)
+                    continue;
+                y[i] += A.val[p] * U(j, c);
+                if (i != j)
+                    y[j] += A.val[p] * U(i, c);
+            }
+        for (int i = 0; i < A.n; i++)
+            err = std::max(err, std::fabs(y[i] - evals[c] * U(i, c)));
+    }
+    return err;
+}
+
+static int failures = 0;
+#define REQUIRE(cond)                                                      \
+    do                                                                     \
+    {                                                                      \
+        if (!(cond))                                                       \
+        {                                                                  \
+            std::printf("REQUIRE failed at line %d: %s\n", __LINE__, #cond); \
+            failures++;                                                    \
+        }                                                                  \
+    } while (0)
+
+static void run_test_sets(const Csc& A, int k, int m)
+{
+    SparseSymMatProd<double> op(A.view());
+    REQUIRE(op.rows() == A.n && op.cols() == A.n);
+    const SortRule rules[] = {SortRule::LargestMagn, SortRule::LargestAlge, SortRule::SmallestMagn, SortRule::SmallestAlge,
+                              SortRule::BothEnds};
+    for (SortRule rule : rules)
+    {
+        SymEigsSolver<SparseSymMatProd<double>> eigs(op, k, m);
+        eigs.init();
+        const int nconv = (int) eigs.compute(rule);
+        REQUIRE(eigs.info() == CompInfo::Successful);
+        const auto evals = eigs.eigenvalues();
+        const auto evecs = eigs.eigenvectors();
+        const double err = residual(A, evals, evecs);
+        std::printf("n=%d rule=%d nconv=%d niter=%d nops=%d ||AU-UD||_inf=%.3e\n", A.n, (int) rule, nconv,
+                    (int) eigs.num_iterations(), (int) eigs.num_operations(), err);
+        REQUIRE(nconv == k);
+        REQUIRE(err < 1e-9);  // test/SymEigs.cpp:64
+    }
+}
+
+// The documentation example: a user-supplied operator class (SymEigsSolver.h:99-126)
+class MyDiagonalTen
+{
+public:
+    using Scalar = double;
+    int rows() const { return 10; }
+    int cols() const { return 10; }
+    void perform_op(const double* x_in, double* y_out) const
+    {
+        for (int i = 0; i < rows(); i++)
+            y_out[i] = x_in[i] * (i + 1);
+    }
+};
+
+int main()
+{
+    try
+    {
+        MyDiagonalTen op;
+        SymEigsSolver<MyDiagonalTen> eigs(op, 3, 6);
+        eigs.init();
+        eigs.compute(SortRule::LargestAlge);
+        REQUIRE(eigs.info() == CompInfo::Successful);
+        const auto ev = eigs.eigenvalues();
+        REQUIRE(ev.size() == 3);
+        REQUIRE(std::fabs(ev[0] - 10.0) < 1e-10 && std::fabs(ev[1] - 9.0) < 1e-10 && std::fabs(ev[2] - 8.0) < 1e-10);
+        std::printf("diag(1..10): %.12f %.12f %.12f\n", ev[0], ev[1], ev[2]);
+
+        run_test_sets(gen_sparse_data(10, 0.5), 3, 6);      // test/SymEigs.cpp:133-143
+        run_test_sets(gen_sparse_data(100, 0.1), 10, 20);   // :145-155
+        run_test_sets(gen_sparse_data(1000, 0.01), 20, 50); // :157-167
+
+        // constructor argument checks throw std::invalid_argument like the reference (HermEigsBase.h:267-271)
+        bool threw = false;
+        try
+        {
+            SymEigsSolver<MyDiagonalTen> bad(op, 3, 3);
+        }
+        catch (const std::invalid_argument&)
+        {
+            threw = true;
+        }
+        REQUIRE(threw);
+    }
+    catch (const std::exception& e)
+    {
+        std::printf("exception: %s\n", e.what());
+        return 2;
+    }
+    std::printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);
+    return failures ? 1 : 0;
+}

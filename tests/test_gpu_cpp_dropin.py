@@ -1,0 +1,21 @@
+"""The header-only C++ API (include/Spectra) used exactly like upstream Spectra: tests/cpp/dropin_symeigs.cpp is
+compiled by a plain host compiler in __graft_entry__.build() and executed here on the GPU."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cpp_dropin_program():
+    exe = os.path.join(ROOT, "tests", "cpp", "dropin_symeigs.bin")
+    if not os.path.exists(exe):
+        import __graft_entry__ as g
+
+        g.build_cpp_tests()
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    print(out.stdout)
+    assert out.returncode == 0, out.stdout
+    assert "ALL PASSED" in out.stdout and out.stdout.count("||AU-UD||_inf") == 15

@@ -144,9 +144,14 @@ def test_restart_primitives_vs_oracle(ctx):
     for mu in shifts:
         _, Hq, Qi = O.tridiag_qr(Hq, mu)
         Q = Q @ Qi
-    assert np.abs(fac.matrix_H()[:k + 1, :k + 1] - Hq[:k + 1, :k + 1]).max() < 1e-11
+    # Only the leading k x k block, H(k,k-1) and the first k columns of Q are well determined: with exact
+    # shifts the trailing block is the deflated part, whose entries are rounding noise amplified by the
+    # sweeps (the reason the reference keeps deflate_H disabled, HermEigsBase.h:144-146).
+    Hd = fac.matrix_H()
+    assert np.abs(Hd[:k, :k] - Hq[:k, :k]).max() < 1e-11
+    assert abs(Hd[k, k - 1] - Hq[k, k - 1]) < 1e-11
     Vn = V_before @ Q[:, :k + 1]
-    assert np.abs(fac.matrix_V()[:, :k + 1] - Vn).max() < 1e-10
+    assert np.abs(fac.matrix_V()[:, :k] - Vn[:, :k]).max() < 1e-10
     fk = f_before * Q[m - 1, k - 1] + Vn[:, k] * Hq[k, k - 1]
     assert np.abs(fac.vector_f() - fk).max() < 1e-10
     # host-side variant (caller supplies Q and the compressed H)
@@ -154,7 +159,7 @@ def test_restart_primitives_vs_oracle(ctx):
     fac2.init_random(0)
     fac2.factorize_from(1, m)
     fac2.compress_V(Q, Hq, k)
-    assert np.abs(fac2.matrix_V()[:, :k + 1] - fac.matrix_V()[:, :k + 1]).max() < 1e-10
+    assert np.abs(fac2.matrix_V()[:, :k] - fac.matrix_V()[:, :k]).max() < 1e-10
     # continue: back to an m-step factorisation
     fac.factorize_from(k, m)
     check_identities(fac, Sd, m, tol=1e-10)

@@ -1,0 +1,37 @@
+"""Small workload for rocprofv3 --pmc passes (HBM traffic of the hot kernels at BASELINE.json's size).
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d OUT -o fetch -- python tools/pmc_probe.py
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d OUT -o write -- python tools/pmc_probe.py
+
+Launches, in order: 3 x k_scale on an n-vector (calibration: exactly 8n bytes read + 8n written with the same
+16-byte-per-lane access pattern the guide's FETCH_SIZE correction is about), 5 x stand-alone SpMV, then
+init() + one full Lanczos factorisation (39 steps: fused SpMV, RESID_VTF, CORRECT_VTF) and one restart
+(shifted-QR kernel + V*Q).  tools/pmc_summarize.py turns the two CSVs into per-kernel bytes per launch.
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import spectra_amd as sa
+
+n = int(os.environ.get("PROBE_N", 10_000_000))
+ctx = sa.default_context()
+op = sa.SparseSymMatProd.synth_band(n, ctx=ctx)
+x = torch.rand(n, dtype=torch.float64, device="cuda") - 0.5
+y = torch.empty(n, dtype=torch.float64, device="cuda")
+torch.cuda.synchronize()
+for _ in range(5):
+    op.spmv_device(x.data_ptr(), y.data_ptr())
+ctx.sync()
+fac = sa.Factorization(op, 40, True)
+fac.init_random(0)
+fac.factorize_from(1, 40)
+ev, U = fac.tridiag_eigen()
+order = np.argsort(-np.abs(ev))
+fac.restart_sym(ev[order][25:])
+fac.factorize_from(25, 40)
+ctx.sync()
+print("probe done: k =", fac.subspace_dim(), "nops =", fac.num_operations())

@@ -1,0 +1,51 @@
+"""Per-kernel HBM bytes per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
+
+usage: python tools/pmc_summarize.py OUT/fetch_counter_collection.csv OUT/write_counter_collection.csv [n]
+
+FETCH_SIZE / WRITE_SIZE are reported in KiB.  On gfx950 FETCH_SIZE counts 64 B per 128 B request for wide
+coalesced reads (MI355X_MICROARCH.md §HBM), so the read side is calibrated on the k_scale launches of the
+probe, whose traffic is known exactly (8n bytes read, 8n written): factor = known / measured, applied to
+every kernel.  Both raw and corrected numbers are printed.
+"""
+import csv
+import sys
+from collections import defaultdict
+
+
+def load(path, counter):
+    per = defaultdict(list)
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r.get("Counter_Name") != counter:
+                continue
+            per[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return per
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return name.split("(")[0][:60]
+
+
+def main():
+    fetch = load(sys.argv[1], "FETCH_SIZE")
+    write = load(sys.argv[2], "WRITE_SIZE")
+    n = int(sys.argv[3]) if len(sys.argv) > 3 else 10_000_000
+    known = 8.0 * n
+    cal_r = cal_w = 1.0
+    for k in fetch:
+        if "k_scale" in k:
+            cal_r = known / (1024.0 * sum(fetch[k]) / len(fetch[k]))
+    for k in write:
+        if "k_scale" in k:
+            cal_w = known / (1024.0 * sum(write[k]) / len(write[k]))
+    print(f"calibration on k_scale (8n = {known:.3e} B each way): read x{cal_r:.3f}, write x{cal_w:.3f}")
+    print(f"{'kernel':62s} {'launches':>8s} {'fetch_raw_MB':>13s} {'write_raw_MB':>13s} {'hbm_corrected_MB':>17s}")
+    for k in sorted(fetch, key=lambda k: -sum(fetch[k])):
+        fr = 1024.0 * sum(fetch[k]) / len(fetch[k])
+        wr = 1024.0 * sum(write.get(k, [0.0])) / max(len(write.get(k, [0.0])), 1)
+        print(f"{short(k):62s} {len(fetch[k]):8d} {fr / 1e6:13.2f} {wr / 1e6:13.2f} {(fr * cal_r + wr * cal_w) / 1e6:17.2f}")
+
+
+if __name__ == "__main__":
+    main()
