@@ -31,7 +31,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=3)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--n", type=int, default=10_000_000, help="matrix dimension (default: BASELINE.json configs[1])")
+    p.add_argument("--size", dest="n", type=int, default=10_000_000, help="matrix dimension (default: BASELINE.json configs[1])")
     p.add_argument("--nev", type=int, default=20)
     p.add_argument("--ncv", type=int, default=40)
     p.add_argument("--tol", type=float, default=1e-11,
@@ -83,11 +83,13 @@ def main():
     from spectra_amd import dist as sdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 or args.gpus > 1:
+    if world > 1 or args.gpus > 1 or os.environ.get("MISPEC_FORCE_COMM") == "1":
         rank, world = sdist.init_process_group("nccl")
         assert world == args.gpus, f"launched {world} ranks for --gpus {args.gpus}"
+        using_dist = True
     else:
         rank, world = 0, 1
+        using_dist = False
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     ctx = sdist.make_context(local)
@@ -191,7 +193,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, int(eigs.num_operations()), int(total_pairs // args.steps))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if using_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -524,7 +524,7 @@ extern "C" int mispec_spmm_host(const mispec_csr* A, const double* X_host, int64
 {
     return guarded([&] {
         MISPEC_REQUIRE(A && X_host && Y_host && k >= 0, "mispec_spmm_host: bad argument");
-        MISPEC_REQUIRE(A->ctx->world() == 1, "mispec_spmm_host: host-pointer products need an unsharded matrix");
+        MISPEC_REQUIRE(A->ctx->world() == 1, "mispec_spmm_host: host-pointer products need an unsharded matrix");  // world 1 + communicator is fine
         MISPEC_REQUIRE(ldx >= A->n_cols && ldy >= A->n_rows, "mispec_spmm_host: leading dimension too small");
         A->ctx->make_current();
         hipStream_t s = A->ctx->stream;

@@ -96,6 +96,8 @@ extern "C" int mispec_ctx_set_comm(mispec_ctx* ctx, const mispec_comm* comm)
                        "mispec_ctx_set_comm: need 0 <= rank < world");
         MISPEC_REQUIRE(comm->world == 1 || (comm->allgather && comm->allreduce_sum),
                        "mispec_ctx_set_comm: collectives missing");
+        MISPEC_REQUIRE((comm->allgather == nullptr) == (comm->allreduce_sum == nullptr),
+                       "mispec_ctx_set_comm: give both collectives or none");
         ctx->comm = *comm;
     });
 }

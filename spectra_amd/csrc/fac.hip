@@ -57,6 +57,7 @@ struct mispec_fac
     DevBuf<double> V, f, w, tmp, xfull, X, partials, alpha_partials, red, Qdev, d_diag, d_subd, d_evals, d_evecs, d_Y, gmax;
     DevBuf<int> d_info;
     PinnedBuf<double> h_red, h_small, h_x, h_y;
+    int64_t pstride = 0;  // stride between slots of the partial records
     int red_cur = 0;   // which half of `red` holds the latest reduced record
     int x_cols = 0;    // columns currently held in X
 
@@ -72,7 +73,9 @@ struct mispec_fac
     double* col(int j) { return V.p + int64_t(j) * ldv; }
     double* red_buf(int which) { return red.p + which * kPartialLd; }
     hipStream_t stream() const { return ctx->stream; }
-    bool sharded() const { return ctx->world() > 1; }
+    // a communicator is attached (world may be 1: the collectives are then still issued, which is how the
+    // RCCL / torch transports are smoke-tested on a single GPU)
+    bool sharded() const { return ctx->comm.allgather != nullptr; }
 
     ~mispec_fac()
     {
@@ -234,10 +237,10 @@ void reduce_to_host(mispec_fac& F, int nrec, int ncol, int which)
 {
     double* red = F.red_buf(which);
     if (!F.sharded())
-        launch_reduce_partials(*F.ctx, F.partials.p, nrec, ncol, red, true);
+        launch_reduce_partials(*F.ctx, F.partials.p, F.pstride, nrec, ncol, red, true);
     else
     {
-        launch_reduce_partials(*F.ctx, F.partials.p, nrec, ncol, red, false);
+        launch_reduce_partials(*F.ctx, F.partials.p, F.pstride, nrec, ncol, red, false);
         allreduce(F, red, kSlotBeta2 + 1);  // slots [0, 64] are sums
         launch_finish(*F.ctx, red, ncol);
     }
@@ -254,6 +257,7 @@ OrthArgs orth_args(mispec_fac& F, int ncol)
     a.ncol = ncol;
     a.n = F.nloc;
     a.partials = F.partials.p;
+    a.pstride = F.pstride;
     return a;
 }
 
@@ -559,7 +563,7 @@ void update_f_after_compress(mispec_fac& F, double q_last, double h_sub)
     int nrec;
     {
         Timed t(F, FAM_COMPRESS);
-        nrec = launch_axpby(*F.ctx, F.f.p, q_last, F.col(F.k), h_sub, F.nloc, F.partials.p);
+        nrec = launch_axpby(*F.ctx, F.f.p, q_last, F.col(F.k), h_sub, F.nloc, F.partials.p, F.pstride);
     }
     reduce_to_host(F, nrec, 0, 0);
     F.beta = F.h_red.p[kSlotBeta];
@@ -585,7 +589,7 @@ extern "C" int mispec_fac_create(mispec_ctx* ctx, const mispec_csr* A, mispec_op
             MISPEC_REQUIRE(A->n_rows == n && A->n_cols == n, "mispec_fac_create: operator must be square of size n");
         }
         else
-            MISPEC_REQUIRE(ctx->world() == 1, "mispec_fac_create: user operators (host perform_op) cannot be row-sharded");
+            MISPEC_REQUIRE(ctx->comm.allgather == nullptr, "mispec_fac_create: user operators (host perform_op) cannot be row-sharded");
         ctx->make_current();
         auto* F = new mispec_fac();
         try
@@ -621,6 +625,7 @@ extern "C" int mispec_fac_create(mispec_ctx* ctx, const mispec_csr* A, mispec_op
                 F->gmax.alloc(size_t(ctx->world()));
             }
             const int64_t max_rec = int64_t(ctx->num_cu) * 8 + 8;
+            F->pstride = max_rec;
             F->partials.alloc(size_t(max_rec) * kPartialLd);
             const int64_t nparts = A ? spmv_num_blocks(F->nloc) : lanczos_epilogue_records(*ctx, F->nloc);
             F->alpha_partials.alloc(size_t(std::max<int64_t>(nparts, 1)));
@@ -903,7 +908,7 @@ extern "C" int mispec_fac_residuals(mispec_fac* fac, const double* lambda_host, 
         {
             const double* x = F.X.p + int64_t(j) * F.ldv;
             apply_op(F, x, F.tmp.p, false, nullptr, 0.0);
-            const int nrec = launch_resid_norms(*F.ctx, F.tmp.p, x, lambda_host[j], F.nloc, F.partials.p);
+            const int nrec = launch_resid_norms(*F.ctx, F.tmp.p, x, lambda_host[j], F.nloc, F.partials.p, F.pstride);
             reduce_to_host(F, nrec, 1, 0);
             resid_host[j] = std::sqrt(F.h_red.p[kSlotBeta2]) / std::sqrt(F.h_red.p[0]);
         }

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(kThreads) void k_orth(OrthArgs a)
         }
     }
 
-    double* rec = a.partials + int64_t(blockIdx.x) * kPartialLd;
+    double* rec = a.partials + blockIdx.x;  // slot j of this workgroup is rec[j * pstride]
     if (kVtf)
     {
 #pragma unroll
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(kThreads) void k_orth(OrthArgs a)
             const double s = wave_reduce_sum(acc[jj]);
             const int j = w + 4 * jj;
             if (lane == 0 && j < a.ncol)
-                rec[j] = s;
+                rec[int64_t(j) * a.pstride] = s;
         }
     }
     if (w == 0)
@@ -169,15 +169,15 @@ __global__ __launch_bounds__(kThreads) void k_orth(OrthArgs a)
         mx = wave_reduce_max(mx);
         if (lane == 0)
         {
-            rec[kSlotBeta2] = b2;
-            rec[kSlotMaxAbs] = mx;
+            rec[kSlotBeta2 * a.pstride] = b2;
+            rec[kSlotMaxAbs * a.pstride] = mx;
         }
     }
 }
 
 // One workgroup sums the records column by column in a fixed order.
-__global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restrict__ partials, int nrec, int ncol,
-                                                           double* __restrict__ red, int finish)
+__global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restrict__ partials, int64_t pstride, int nrec,
+                                                           int ncol, double* __restrict__ red, int finish)
 {
     __shared__ double sh[kPartialLd];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restri
         {
             for (int b = lane; b < nrec; b += 64)
             {
-                const double x = partials[int64_t(b) * kPartialLd + j];
+                const double x = partials[int64_t(j) * pstride + b];
                 v = is_max ? fmax(v, x) : v + x;
             }
             v = is_max ? wave_reduce_max(v) : wave_reduce_sum(v);
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(kThreads) void k_scale(const double* __restrict__ s
 }
 
 __global__ __launch_bounds__(kThreads) void k_axpby(double* __restrict__ f, double a, const double* __restrict__ v, double b,
-                                                     int64_t npairs, double* __restrict__ partials)
+                                                     int64_t npairs, double* __restrict__ partials, int64_t pstride)
 {
     __shared__ double red[4];
     double b2 = 0.0;
@@ -272,8 +272,8 @@ __global__ __launch_bounds__(kThreads) void k_axpby(double* __restrict__ f, doub
     const double tot = block_reduce_sum(b2, red);
     if (threadIdx.x == 0)
     {
-        partials[int64_t(blockIdx.x) * kPartialLd + kSlotBeta2] = tot;
-        partials[int64_t(blockIdx.x) * kPartialLd + kSlotMaxAbs] = 0.0;
+        partials[kSlotBeta2 * pstride + blockIdx.x] = tot;
+        partials[kSlotMaxAbs * pstride + blockIdx.x] = 0.0;
     }
 }
 
@@ -303,7 +303,8 @@ __global__ __launch_bounds__(kThreads) void k_lanczos_epilogue(double* __restric
 
 // r = y - lambda x : records get |r|^2 (kSlotBeta2) and |x|^2 (slot 0)
 __global__ __launch_bounds__(kThreads) void k_resid_norms(const double* __restrict__ y, const double* __restrict__ x,
-                                                           double lambda, int64_t npairs, double* __restrict__ partials)
+                                                           double lambda, int64_t npairs, double* __restrict__ partials,
+                                                           int64_t pstride)
 {
     __shared__ double red[4];
     __shared__ double red2[4];
@@ -320,9 +321,9 @@ __global__ __launch_bounds__(kThreads) void k_resid_norms(const double* __restri
     const double t2 = block_reduce_sum(x2, red2);
     if (threadIdx.x == 0)
     {
-        partials[int64_t(blockIdx.x) * kPartialLd + kSlotBeta2] = t1;
-        partials[int64_t(blockIdx.x) * kPartialLd + 0] = t2;
-        partials[int64_t(blockIdx.x) * kPartialLd + kSlotMaxAbs] = 0.0;
+        partials[kSlotBeta2 * pstride + blockIdx.x] = t1;
+        partials[0 * pstride + blockIdx.x] = t2;
+        partials[kSlotMaxAbs * pstride + blockIdx.x] = 0.0;
     }
 }
 
@@ -459,6 +460,7 @@ int launch_orth(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a)
     MISPEC_REQUIRE(a.ncol >= 0 && a.ncol <= kMaxOrthCols, "orth kernel: more than 64 basis columns");
     const int64_t ntiles = (a.n + kTileRows - 1) / kTileRows;
     const int grid = persistent_grid(ctx, ntiles, 4);
+    MISPEC_REQUIRE(a.pstride >= grid, "orth kernel: partial-record stride smaller than the grid");
     switch (mode)
     {
         case ORTH_VTF:
@@ -478,9 +480,11 @@ int launch_orth(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a)
     return grid;
 }
 
-void launch_reduce_partials(const mispec_ctx& ctx, const double* partials, int nrec, int ncol, double* red, bool finish)
+void launch_reduce_partials(const mispec_ctx& ctx, const double* partials, int64_t pstride, int nrec, int ncol, double* red,
+                            bool finish)
 {
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx.stream, partials, nrec, ncol, red, finish ? 1 : 0);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx.stream, partials, pstride, nrec, ncol, red,
+                       finish ? 1 : 0);
     MISPEC_HIP(hipGetLastError());
 }
 
@@ -506,20 +510,22 @@ void launch_scale(const mispec_ctx& ctx, const double* src, double* dst, int64_t
     MISPEC_HIP(hipGetLastError());
 }
 
-int launch_axpby(const mispec_ctx& ctx, double* f, double a, const double* v, double b, int64_t n, double* partials)
+int launch_axpby(const mispec_ctx& ctx, double* f, double a, const double* v, double b, int64_t n, double* partials,
+                 int64_t pstride)
 {
     const int64_t npairs = (n + 1) / 2;
     const int grid = persistent_grid(ctx, (npairs + kThreads - 1) / kThreads, 4);
-    hipLaunchKernelGGL(k_axpby, dim3(unsigned(grid)), dim3(kThreads), 0, ctx.stream, f, a, v, b, npairs, partials);
+    hipLaunchKernelGGL(k_axpby, dim3(unsigned(grid)), dim3(kThreads), 0, ctx.stream, f, a, v, b, npairs, partials, pstride);
     MISPEC_HIP(hipGetLastError());
     return grid;
 }
 
-int launch_resid_norms(const mispec_ctx& ctx, const double* y, const double* x, double lambda, int64_t n, double* partials)
+int launch_resid_norms(const mispec_ctx& ctx, const double* y, const double* x, double lambda, int64_t n, double* partials,
+                       int64_t pstride)
 {
     const int64_t npairs = (n + 1) / 2;
     const int grid = persistent_grid(ctx, (npairs + kThreads - 1) / kThreads, 4);
-    hipLaunchKernelGGL(k_resid_norms, dim3(unsigned(grid)), dim3(kThreads), 0, ctx.stream, y, x, lambda, npairs, partials);
+    hipLaunchKernelGGL(k_resid_norms, dim3(unsigned(grid)), dim3(kThreads), 0, ctx.stream, y, x, lambda, npairs, partials, pstride);
     MISPEC_HIP(hipGetLastError());
     return grid;
 }

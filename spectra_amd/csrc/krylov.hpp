@@ -4,8 +4,8 @@
 
 namespace mispec {
 
-// Per-workgroup partial record written by the orthogonalisation kernels and summed by
-// launch_reduce_partials in a fixed order (deterministic: no floating-point atomics anywhere).
+// Per-workgroup partial record (kPartialLd slots) written by the orthogonalisation kernels — stored
+// slot-major so that the summing kernel reads contiguously — and summed by launch_reduce_partials in a fixed order (deterministic: no floating-point atomics anywhere).
 constexpr int kPartialLd = 72;
 constexpr int kSlotBeta2 = 64;   // sum f^2
 constexpr int kSlotMaxAbs = 65;  // max |f|
@@ -33,26 +33,30 @@ struct OrthArgs
     const double* vi = nullptr;   // RESID: basis column i
     const double* alpha_dev = nullptr;  // RESID: device scalar
     const double* c_in = nullptr;       // CORRECT: device coefficients [ncol]
-    double* partials = nullptr;         // [records][kPartialLd]
+    double* partials = nullptr;         // slot-major: partials[slot * pstride + workgroup]
+    int64_t pstride = 0;                // >= number of workgroups of any launch
 };
 
 // All launchers enqueue on ctx.stream and return immediately.
 int launch_orth(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a);  // returns the number of partial records
 // red[0..kPartialLd): column sums of the records (+ max for kSlotMaxAbs); finish additionally fills kSlotBeta / kSlotErr.
-void launch_reduce_partials(const mispec_ctx& ctx, const double* partials, int nrec, int ncol, double* red, bool finish);
+void launch_reduce_partials(const mispec_ctx& ctx, const double* partials, int64_t pstride, int nrec, int ncol, double* red,
+                            bool finish);
 void launch_finish(const mispec_ctx& ctx, double* red, int ncol);
 // out[0] = sum of `count` doubles (SpMV alpha partials), fixed order
 void launch_reduce_sum(const mispec_ctx& ctx, const double* in, int64_t count, double* out);
 // dst = src / divisor over npad elements (v = f / beta, Lanczos.h:106)
 void launch_scale(const mispec_ctx& ctx, const double* src, double* dst, int64_t npad, double divisor);
 // f = f*a + v*b, partial |f|^2 records (Arnoldi.h:337-339); returns the number of records
-int launch_axpby(const mispec_ctx& ctx, double* f, double a, const double* v, double b, int64_t n, double* partials);
+int launch_axpby(const mispec_ctx& ctx, double* f, double a, const double* v, double b, int64_t n, double* partials,
+                 int64_t pstride);
 // X[:, 0:p] = V[:, 0:m] * Q (Q device, m x p col-major, ldq); X may alias V (in-place compress_V).
 void launch_vq(const mispec_ctx& ctx, const double* V, int64_t ldv, int m, const double* Q, int ldq, int p, double* X,
                int64_t ldx, int64_t n);
 // res[j] = || A x_j - lambda_j x_j ||^2 partials and ||x_j||^2 partials are produced by the caller with the kernels above.
 // r = y - lambda*x ; records hold |r|^2 in kSlotBeta2 and |x|^2 in slot 0.
-int launch_resid_norms(const mispec_ctx& ctx, const double* y, const double* x, double lambda, int64_t n, double* partials);
+int launch_resid_norms(const mispec_ctx& ctx, const double* y, const double* x, double lambda, int64_t n, double* partials,
+                       int64_t pstride);
 // Un-fused Lanczos epilogue for user operators (Lanczos.h:139-142): w -= h_prev*v_prev (if v_prev), one partial
 // of <v, w> per workgroup in partials[0 .. lanczos_epilogue_records).
 int lanczos_epilogue_records(const mispec_ctx& ctx, int64_t n);

@@ -48,11 +48,12 @@ class _DeviceArray:
 class TorchComm:
     """The two collectives on torch tensors (any backend)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, stream=None):
         import torch.distributed as dist
 
         self.dist = dist
         self.group = group
+        self.stream = stream  # torch.cuda.Stream the solver runs on (device collectives are ordered against it)
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
 
@@ -67,15 +68,17 @@ class TorchComm:
     def _allgather_ptr(self, send_ptr, recv_ptr, count, stream):
         import torch
 
-        send = torch.as_tensor(_DeviceArray(send_ptr, count), device="cuda")
-        recv = torch.as_tensor(_DeviceArray(recv_ptr, count * self.world), device="cuda")
-        self.allgather(send, recv)
+        with torch.cuda.stream(self.stream):
+            send = torch.as_tensor(_DeviceArray(send_ptr, count), device="cuda")
+            recv = torch.as_tensor(_DeviceArray(recv_ptr, count * self.world), device="cuda")
+            self.allgather(send, recv)
         return 0
 
     def _allreduce_ptr(self, buf_ptr, count, stream):
         import torch
 
-        self.allreduce_sum(torch.as_tensor(_DeviceArray(buf_ptr, count), device="cuda"))
+        with torch.cuda.stream(self.stream):
+            self.allreduce_sum(torch.as_tensor(_DeviceArray(buf_ptr, count), device="cuda"))
         return 0
 
 
@@ -91,15 +94,21 @@ def make_context(device=None, transport=None):
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0"))
     transport = transport or os.environ.get("MISPEC_COMM", "rccl")
+    # MISPEC_FORCE_COMM=1 attaches the communicator even for a single rank, so that the RCCL / torch
+    # transports can be smoke-tested on a 1-GPU box (collectives over one rank are copies / no-ops).
+    force = os.environ.get("MISPEC_FORCE_COMM", "0") == "1" and dist.is_initialized()
     torch.cuda.set_device(device)
-    if world > 1 and transport == "torch":
-        ctx = Context(device, stream=torch.cuda.current_stream().cuda_stream)
-        comm = TorchComm()
+    if (world > 1 or force) and transport == "torch":
+        # a dedicated (non-default) torch stream: the solver's kernels and torch's collectives are both ordered
+        # against it (the default stream's handle is 0, which the C ABI reads as "create your own stream")
+        stream = torch.cuda.Stream(device=device)
+        ctx = Context(device, stream=stream.cuda_stream)
+        comm = TorchComm(stream=stream)
         ctx.set_comm_callbacks(rank, world, comm._allgather_ptr, comm._allreduce_ptr)
         ctx._comm = comm
     else:
         ctx = Context(device)
-        if world > 1:
+        if world > 1 or force:
             payload = [Context.rccl_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(payload, src=0)
             ctx.set_comm_rccl(rank, world, payload[0])
