@@ -1,0 +1,128 @@
+// Shifted QR factorisations of the projected matrix, host side (reference: LinAlg/UpperHessenbergQR.h).
+//   UpperHessenbergQR<double>: H - sI = QR for an upper Hessenberg H   (:45-460)
+//   TridiagQR<double>:         the same for a symmetric tridiagonal T  (:470-711)
+// Same member names as the reference: compute(), matrix_QtHQ(), apply_YQ().  The symmetric solver does
+// NOT use these classes on its fast path — its sweeps run in one LDS-resident kernel (csrc/small.hip,
+// same arithmetic from internal/SmallDense.h); they serve the general solver's restart, user code and
+// the CPU-side unit tests.
+#ifndef MISPEC_SPECTRA_UPPER_HESSENBERG_QR_H
+#define MISPEC_SPECTRA_UPPER_HESSENBERG_QR_H
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../internal/Dense.h"
+#include "../internal/SmallDenseGen.h"
+
+namespace Spectra {
+
+template <typename Scalar = double>
+class UpperHessenbergQR
+{
+protected:
+    using Matrix = DenseMatrix<Scalar>;
+    Index m_n = 0;
+    Scalar m_shift = 0;
+    std::vector<double> m_rot;   // cos[0..n-1), sin at m_rot[n + i]
+    std::vector<double> m_QtHQ;  // n x n column-major
+    bool m_computed = false;
+
+    void require_computed(const char* who) const
+    {
+        if (!m_computed)
+            throw std::logic_error(std::string(who) + ": need to call compute() first");
+    }
+
+public:
+    explicit UpperHessenbergQR(Index size = 0) : m_n(size) {}
+    UpperHessenbergQR(const Matrix& mat, const Scalar& shift = Scalar(0)) { compute(mat, shift); }
+    virtual ~UpperHessenbergQR() {}
+
+    // Only the upper triangle and the sub-diagonal of mat are read.
+    virtual void compute(const Matrix& mat, const Scalar& shift = Scalar(0))
+    {
+        m_n = mat.rows();
+        if (m_n != mat.cols())
+            throw std::invalid_argument("UpperHessenbergQR: matrix must be square");
+        m_shift = shift;
+        const int n = static_cast<int>(m_n);
+        m_QtHQ.assign(mat.data(), mat.data() + std::size_t(n) * n);
+        m_rot.assign(std::size_t(2) * n, 0.0);
+        double dummy = 0.0;
+        mispec::small::hess_shifted_qr(n, m_QtHQ.data(), n, shift, &dummy, 1, 0, m_rot.data());
+        m_computed = true;
+    }
+
+    // dest <- Q'HQ = RQ + sI
+    virtual void matrix_QtHQ(Matrix& dest) const
+    {
+        require_computed("UpperHessenbergQR");
+        dest.resize(m_n, m_n);
+        std::copy(m_QtHQ.begin(), m_QtHQ.end(), dest.data());
+    }
+
+    // Y <- Y * Q = Y * G1 * G2 * ...
+    void apply_YQ(Matrix& Y) const
+    {
+        require_computed("UpperHessenbergQR");
+        const Index nrow = Y.rows();
+        for (Index i = 0; i < m_n - 1; i++)
+        {
+            const double c = m_rot[std::size_t(i)], s = m_rot[std::size_t(m_n + i)];
+            Scalar* a = Y.data() + i * nrow;
+            Scalar* b = a + nrow;
+            for (Index j = 0; j < nrow; j++)
+            {
+                const Scalar t = a[j];
+                a[j] = c * t - s * b[j];
+                b[j] = s * t + c * b[j];
+            }
+        }
+    }
+};
+
+template <typename Scalar = double>
+class TridiagQR : public UpperHessenbergQR<Scalar>
+{
+    using Base = UpperHessenbergQR<Scalar>;
+    using typename Base::Matrix;
+    using Base::m_computed;
+    using Base::m_n;
+    using Base::m_QtHQ;
+    using Base::m_rot;
+    using Base::m_shift;
+
+public:
+    explicit TridiagQR(Index size = 0) : Base(size) {}
+    TridiagQR(const Matrix& mat, const Scalar& shift = Scalar(0)) { compute(mat, shift); }
+
+    // Only the diagonal and the sub-diagonal of mat are read.
+    void compute(const Matrix& mat, const Scalar& shift = Scalar(0)) override
+    {
+        m_n = mat.rows();
+        if (m_n != mat.cols())
+            throw std::invalid_argument("TridiagQR: matrix must be square");
+        m_shift = shift;
+        const int n = static_cast<int>(m_n);
+        std::vector<double> diag(static_cast<std::size_t>(n)), subd(static_cast<std::size_t>(n), 0.0), work(std::size_t(4) * n);
+        for (int i = 0; i < n; i++)
+            diag[std::size_t(i)] = mat(i, i);
+        for (int i = 0; i < n - 1; i++)
+            subd[std::size_t(i)] = mat(i + 1, i);
+        double dummy = 0.0;
+        mispec::small::tridiag_shifted_qr(n, diag.data(), subd.data(), shift, &dummy, 1, 0, work.data(),
+                                          mispec::small::Lanes{0, 1});
+        m_rot.assign(work.begin(), work.begin() + 2 * n);  // [cos | sin]
+        m_QtHQ.assign(std::size_t(n) * n, 0.0);
+        for (int i = 0; i < n; i++)
+            m_QtHQ[std::size_t(i) * n + i] = diag[std::size_t(i)];
+        for (int i = 0; i < n - 1; i++)
+            m_QtHQ[std::size_t(i) * n + i + 1] = m_QtHQ[std::size_t(i + 1) * n + i] = subd[std::size_t(i)];
+        m_computed = true;
+    }
+};
+
+}  // namespace Spectra
+
+#endif

@@ -1,6 +1,6 @@
 // ncv x ncv dense algorithms of the restart, written once for two targets:
 //   * device: one wavefront, T / rotations / Q resident in LDS, lane l owning rows l, l+64, ... of Q
-//     (small.hip);
+//     (spectra_amd/csrc/small.hip);
 //   * host: the same code with a single "lane" (used by include/Spectra/LinAlg/*.h when the Krylov
 //     dimension exceeds what the device kernels hold, and for user operators).
 // The scalar recurrences are executed redundantly by every lane (identical values, uniform control
@@ -29,11 +29,22 @@ constexpr double kEps = DBL_EPSILON;     // TypeTraits<double>::epsilon()
 constexpr double kMinPos = DBL_MIN;      // TypeTraits<double>::min()
 constexpr double kNear0 = DBL_MIN * 10;  // near_0 (Arnoldi.h:50)
 
-// Which rows of an m-row matrix this executor updates.
+// Which rows (or columns) of a small matrix this executor updates, and how executors rendezvous.
+// Host: one lane, no synchronisation.  Device: the 64 lanes of the single wavefront that runs the
+// kernel; sync() is the workgroup barrier (also a compiler barrier for the LDS-resident arrays).
 struct Lanes
 {
     int first;   // lane id
     int stride;  // number of lanes
+    MISPEC_HD void sync() const
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // == __syncthreads(), spelled with builtins so that this header needs no HIP runtime include
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
+    }
 };
 
 // r = sqrt(a^2+b^2), c = a/r, s = b/r for a >= b > 0 (Givens.h:28-86)

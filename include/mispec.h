@@ -177,6 +177,11 @@ int mispec_fac_ritz_vectors(mispec_fac* fac, const double* Y_host, int ncols, do
  * evaluated on the device (parity check at sizes the CPU oracle cannot reach). resid_host[ncols]. */
 int mispec_fac_residuals(mispec_fac* fac, const double* lambda_host, int ncols, double* resid_host);
 
+/* Complex pairs of the general solver: x_j = V (Yre_j + i Yim_j), lambda_j = (re, im) interleaved;
+ * resid_host[j] = || A x_j - lambda_j x_j ||_2 / || x_j ||_2, evaluated on the device. Y*: ncv x ncols col-major. */
+int mispec_fac_residuals_complex(mispec_fac* fac, const double* Yre_host, const double* Yim_host, const double* lambda_host,
+                                 int ncols, double* resid_host);
+
 /* Profile of the factorisation so far: counts and accumulated HIP-event time (ms) per kernel family.
  * Timing is only collected between mispec_fac_profile(fac, 1) and mispec_fac_profile(fac, 0). */
 typedef struct mispec_profile
@@ -218,6 +223,42 @@ int mispec_symeigs_eigenvectors(mispec_symeigs* s, int64_t nvec, double* out_hos
 int mispec_symeigs_residuals(mispec_symeigs* s, double* resid_host, int64_t* count);
 int mispec_symeigs_get_profile(const mispec_symeigs* s, mispec_profile* out);
 int mispec_symeigs_profile(mispec_symeigs* s, int enable);
+
+/* ---------------------------------------------------------------------------
+ * General (non-symmetric) solver: Spectra::GenEigsSolver<Spectra::SparseGenMatProd<double>> behind a handle.
+ * Argument meaning and defaults as GenEigsBase.h:419-423, :442-476, :501-525, :548-610.
+ * Complex results are interleaved (re, im) doubles.
+ * ------------------------------------------------------------------------- */
+typedef struct mispec_geneigs mispec_geneigs;
+int mispec_geneigs_create(mispec_ctx* ctx, const mispec_csr* A, int64_t nev, int64_t ncv, mispec_geneigs** out);
+int mispec_geneigs_create_op(mispec_ctx* ctx, mispec_op_fn op, void* op_user, int64_t n, int64_t nev, int64_t ncv,
+                             mispec_geneigs** out);
+int mispec_geneigs_destroy(mispec_geneigs* s);
+int mispec_geneigs_init(mispec_geneigs* s, const double* v0_host /* NULL = init() */);
+int mispec_geneigs_compute(mispec_geneigs* s, int selection, int64_t maxit, double tol, int sorting, int64_t* nconv);
+int mispec_geneigs_info(const mispec_geneigs* s);
+int64_t mispec_geneigs_num_iterations(const mispec_geneigs* s);
+int64_t mispec_geneigs_num_operations(const mispec_geneigs* s);
+int mispec_geneigs_eigenvalues(const mispec_geneigs* s, double* out_host /* 2*count */, int64_t* count);
+/* out_host: local_rows x ncols complex, column-major, interleaved (2 * local_rows * ncols doubles) */
+int mispec_geneigs_eigenvectors(mispec_geneigs* s, int64_t nvec, double* out_host, int64_t* ncols);
+/* || A x - lambda x || / || x || of the converged pairs, evaluated on the device (device matrices only) */
+int mispec_geneigs_residuals(mispec_geneigs* s, double* resid_host, int64_t* count);
+int mispec_geneigs_get_profile(const mispec_geneigs* s, mispec_profile* out);
+int mispec_geneigs_profile(mispec_geneigs* s, int enable);
+
+/* ---------------------------------------------------------------------------
+ * Host-side ncv x ncv kernels of the general restart (include/Spectra/internal/SmallDenseGen.h), exported
+ * for parity tests and non-C++ callers.  They need no GPU.  All matrices n x n column-major.
+ *   mispec_hess_qr_host          UpperHessenbergQR: H - sI = QR ; Q, Q'HQ = RQ + sI     (UpperHessenbergQR.h:136-255)
+ *   mispec_double_shift_qr_host  DoubleShiftQR: H^2 - sH + tI = QR ; Q, Q'HQ            (DoubleShiftQR.h:358-467)
+ *   mispec_hess_schur_host       UpperHessenbergSchur: H = U T U'                       (UpperHessenbergSchur.h:354-421)
+ *   mispec_hess_eigen_host       UpperHessenbergEigen: complex eigenpairs, interleaved  (UpperHessenbergEigen.h:231-327)
+ * ------------------------------------------------------------------------- */
+int mispec_hess_qr_host(int n, const double* H, double shift, double* Q, double* QtHQ);
+int mispec_double_shift_qr_host(int n, const double* H, double s, double t, double* Q, double* QtHQ);
+int mispec_hess_schur_host(int n, const double* H, double* T, double* U);
+int mispec_hess_eigen_host(int n, const double* H, double* evals, double* evecs);
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,7 @@ def build(force=False):
     """Compile oracle/liboracle.so with the committed Makefile (g++ -O2)."""
     if force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-        for f in ("oracle_capi.cpp", "spectra_oracle.hpp", "synth_matrix.h")
+        for f in ("oracle_capi.cpp", "spectra_oracle.hpp", "spectra_oracle_gen.hpp", "synth_matrix.h")
     ):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _LIB_PATH
@@ -86,6 +86,19 @@ def lib():
             "oracle_symeigs_eigenvalues": (C.c_long, [vp, dp]),
             "oracle_symeigs_eigenvectors": (C.c_long, [vp, C.c_long, dp]),
             "oracle_symeigs_time_steps": (C.c_double, [vp, C.c_long, C.c_long, lp]),
+            "oracle_hess_qr": (C.c_int, [C.c_long, dp, C.c_double, dp, dp]),
+            "oracle_double_shift_qr": (C.c_int, [C.c_long, dp, C.c_double, C.c_double, dp, dp]),
+            "oracle_hess_schur": (C.c_int, [C.c_long, dp, dp, dp]),
+            "oracle_hess_eigen": (C.c_int, [C.c_long, dp, dp, dp]),
+            "oracle_geneigs_create": (vp, [vp, C.c_long, C.c_long]),
+            "oracle_geneigs_free": (None, [vp]),
+            "oracle_geneigs_init": (C.c_int, [vp, dp]),
+            "oracle_geneigs_compute": (C.c_long, [vp, C.c_int, C.c_long, C.c_double, C.c_int]),
+            "oracle_geneigs_info": (C.c_int, [vp]),
+            "oracle_geneigs_num_iterations": (C.c_long, [vp]),
+            "oracle_geneigs_num_operations": (C.c_long, [vp]),
+            "oracle_geneigs_eigenvalues": (C.c_long, [vp, dp]),
+            "oracle_geneigs_eigenvectors": (C.c_long, [vp, C.c_long, dp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -346,6 +359,86 @@ class SymEigsSolver:
     def __del__(self):
         try:
             lib().oracle_symeigs_free(self.h)
+        except Exception:
+            pass
+
+
+def hess_qr(H, shift):
+    """UpperHessenbergQR (real): returns (Q, Q'HQ = RQ + sI)."""
+    H = np.asfortranarray(H, dtype=np.float64)
+    n = H.shape[0]
+    Q, D = np.empty((n, n), order="F"), np.empty((n, n), order="F")
+    _check(lib().oracle_hess_qr(n, _dp(H), shift, _dp(Q), _dp(D)))
+    return Q, D
+
+
+def double_shift_qr(H, s, t):
+    """DoubleShiftQR: H^2 - sH + tI = QR; returns (Q, Q'HQ)."""
+    H = np.asfortranarray(H, dtype=np.float64)
+    n = H.shape[0]
+    Q, D = np.empty((n, n), order="F"), np.empty((n, n), order="F")
+    _check(lib().oracle_double_shift_qr(n, _dp(H), s, t, _dp(Q), _dp(D)))
+    return Q, D
+
+
+def hess_schur(H):
+    H = np.asfortranarray(H, dtype=np.float64)
+    n = H.shape[0]
+    T, U = np.empty((n, n), order="F"), np.empty((n, n), order="F")
+    _check(lib().oracle_hess_schur(n, _dp(H), _dp(T), _dp(U)))
+    return T, U
+
+
+def hess_eigen(H):
+    H = np.asfortranarray(H, dtype=np.float64)
+    n = H.shape[0]
+    ev = np.empty(n, dtype=np.complex128)
+    V = np.empty((n, n), dtype=np.complex128, order="F")
+    _check(lib().oracle_hess_eigen(n, _dp(H), ev.ctypes.data_as(C.POINTER(C.c_double)), V.ctypes.data_as(C.POINTER(C.c_double))))
+    return ev, V
+
+
+class GenEigsSolver:
+    """GenEigsSolver.h / GenEigsBase.h on the oracle (real matrices, complex results)."""
+
+    def __init__(self, op, nev, ncv):
+        self.op, self.nev, self.ncv, self.n = op, nev, min(ncv, op.n), op.n
+        self.h = lib().oracle_geneigs_create(op.h, nev, ncv)
+        if not self.h:
+            raise ValueError(lib().oracle_last_error().decode())
+
+    def init(self, v0=None):
+        v0 = None if v0 is None else _f64(v0)
+        _check(lib().oracle_geneigs_init(self.h, _dp(v0)))
+
+    def compute(self, selection=LargestMagn, maxit=1000, tol=1e-10, sorting=LargestMagn):
+        rc = lib().oracle_geneigs_compute(self.h, selection, maxit, tol, sorting)
+        _check(rc)
+        return rc
+
+    def info(self):
+        return lib().oracle_geneigs_info(self.h)
+
+    def num_iterations(self):
+        return lib().oracle_geneigs_num_iterations(self.h)
+
+    def num_operations(self):
+        return lib().oracle_geneigs_num_operations(self.h)
+
+    def eigenvalues(self):
+        out = np.empty(self.nev, dtype=np.complex128)
+        cnt = lib().oracle_geneigs_eigenvalues(self.h, out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out[:cnt].copy()
+
+    def eigenvectors(self, nvec=None):
+        nvec = self.nev if nvec is None else nvec
+        out = np.zeros((self.n, max(nvec, 1)), dtype=np.complex128, order="F")
+        cnt = lib().oracle_geneigs_eigenvectors(self.h, nvec, out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out[:, :cnt].copy(order="F")
+
+    def __del__(self):
+        try:
+            lib().oracle_geneigs_free(self.h)
         except Exception:
             pass
 

@@ -4,6 +4,7 @@
 //  spectra_oracle.hpp for scope and pinning status.
 // =============================================================================
 #include "spectra_oracle.hpp"
+#include "spectra_oracle_gen.hpp"
 #include "synth_matrix.h"
 
 #include <chrono>
@@ -335,6 +336,123 @@ double oracle_symeigs_time_steps(void* op, long ncv, long nsteps, long* nops_out
     const auto t1 = std::chrono::steady_clock::now();
     *nops_out = nops;
     return std::chrono::duration<double>(t1 - t0).count();
+}
+
+
+// ---- general (non-symmetric) path: LinAlg/UpperHessenbergQR.h, DoubleShiftQR.h, UpperHessenbergSchur.h,
+// ---- UpperHessenbergEigen.h, GenEigsBase.h ------------------------------------------------------------
+int oracle_hess_qr(long n, const double* Hm, double shift, double* Q, double* QtHQ)
+{
+    return guarded([&] {
+        Mat M(n, n);
+        std::memcpy(M.a.data(), Hm, sizeof(double) * n * n);
+        UpperHessenbergQR qr;
+        qr.compute(M, shift);
+        if (Q)
+        {
+            Mat q(n, n);
+            q.set_identity();
+            qr.apply_YQ(q);
+            std::memcpy(Q, q.a.data(), sizeof(double) * n * n);
+        }
+        if (QtHQ)
+        {
+            Mat d;
+            qr.matrix_QtHQ(d);
+            std::memcpy(QtHQ, d.a.data(), sizeof(double) * n * n);
+        }
+    });
+}
+int oracle_double_shift_qr(long n, const double* Hm, double s, double t, double* Q, double* QtHQ)
+{
+    return guarded([&] {
+        Mat M(n, n);
+        std::memcpy(M.a.data(), Hm, sizeof(double) * n * n);
+        DoubleShiftQR qr;
+        qr.compute(M, s, t);
+        if (Q)
+        {
+            Mat q(n, n);
+            q.set_identity();
+            qr.apply_YQ(q);
+            std::memcpy(Q, q.a.data(), sizeof(double) * n * n);
+        }
+        if (QtHQ)
+        {
+            Mat d;
+            qr.matrix_QtHQ(d);
+            std::memcpy(QtHQ, d.a.data(), sizeof(double) * n * n);
+        }
+    });
+}
+int oracle_hess_schur(long n, const double* Hm, double* T, double* U)
+{
+    return guarded([&] {
+        Mat M(n, n);
+        std::memcpy(M.a.data(), Hm, sizeof(double) * n * n);
+        UpperHessenbergSchur sc;
+        sc.compute(M);
+        std::memcpy(T, sc.T.a.data(), sizeof(double) * n * n);
+        std::memcpy(U, sc.U.a.data(), sizeof(double) * n * n);
+    });
+}
+// evals: n complex (interleaved re,im); evecs: n x n complex column-major interleaved
+int oracle_hess_eigen(long n, const double* Hm, double* evals, double* evecs)
+{
+    return guarded([&] {
+        Mat M(n, n);
+        std::memcpy(M.a.data(), Hm, sizeof(double) * n * n);
+        UpperHessenbergEigen eg;
+        eg.compute(M);
+        std::memcpy(evals, eg.eivalues.data(), sizeof(Complex) * n);
+        if (evecs)
+        {
+            std::vector<Complex> V = eg.eigenvectors();
+            std::memcpy(evecs, V.data(), sizeof(Complex) * n * n);
+        }
+    });
+}
+
+void* oracle_geneigs_create(void* op, long nev, long ncv)
+{
+    GenEigs* s = nullptr;
+    int rc = guarded([&] { s = new GenEigs(*static_cast<Op*>(op), nev, ncv); });
+    return rc == 0 ? s : nullptr;
+}
+void oracle_geneigs_free(void* s) { delete static_cast<GenEigs*>(s); }
+int oracle_geneigs_init(void* s, const double* v0)
+{
+    auto* S = static_cast<GenEigs*>(s);
+    return guarded([&] {
+        if (v0)
+            S->init(v0);
+        else
+            S->init();
+    });
+}
+long oracle_geneigs_compute(void* s, int selection, long maxit, double tol, int sorting)
+{
+    auto* S = static_cast<GenEigs*>(s);
+    long nconv = 0;
+    int rc = guarded(
+        [&] { nconv = S->compute(static_cast<SortRule>(selection), maxit, tol, static_cast<SortRule>(sorting)); });
+    return rc == 0 ? nconv : rc;
+}
+int oracle_geneigs_info(void* s) { return static_cast<int>(static_cast<GenEigs*>(s)->info); }
+long oracle_geneigs_num_iterations(void* s) { return static_cast<GenEigs*>(s)->niter; }
+long oracle_geneigs_num_operations(void* s) { return static_cast<GenEigs*>(s)->nmatop; }
+long oracle_geneigs_eigenvalues(void* s, double* out)  // interleaved complex
+{
+    std::vector<Complex> ev = static_cast<GenEigs*>(s)->eigenvalues();
+    std::memcpy(out, ev.data(), sizeof(Complex) * ev.size());
+    return static_cast<long>(ev.size());
+}
+long oracle_geneigs_eigenvectors(void* s, long nvec, double* out)  // n x ncols complex column-major interleaved
+{
+    Index ncols = 0;
+    std::vector<Complex> X = static_cast<GenEigs*>(s)->eigenvectors(nvec, ncols);
+    std::memcpy(out, X.data(), sizeof(Complex) * X.size());
+    return ncols;
 }
 
 }  // extern "C"

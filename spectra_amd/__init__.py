@@ -16,8 +16,8 @@ import numpy as np
 from . import _capi
 from ._capi import MispecError, Profile, build_library, check, lib
 
-__all__ = ["SortRule", "CompInfo", "Context", "SparseSymMatProd", "SparseGenMatProd", "SymEigsSolver", "Factorization",
-           "tridiag_qr", "tridiag_eigen", "MispecError", "build_library", "shard_range", "BAND_OFFSETS", "SYNTH_SEED"]
+__all__ = ["SortRule", "CompInfo", "Context", "SparseSymMatProd", "SparseGenMatProd", "SymEigsSolver", "GenEigsSolver",
+           "Factorization", "tridiag_qr", "tridiag_eigen", "hess_qr", "double_shift_qr", "hess_schur", "hess_eigen", "MispecError", "build_library", "shard_range", "BAND_OFFSETS", "SYNTH_SEED"]
 
 BAND_OFFSETS = (1, 2, 3, 1000, 1001, 100000, 100001)  # SURVEY.md §8(d) "M-band": 15 nnz/row with the diagonal
 SYNTH_SEED = 20240607
@@ -346,6 +346,118 @@ class SymEigsSolver:
             lib().mispec_symeigs_destroy(self.h)
         except Exception:
             pass
+
+
+class GenEigsSolver:
+    """GenEigsSolver.h:139-186 / GenEigsBase.h: complex eigenvalues / eigenvectors of a general real matrix."""
+
+    def __init__(self, op, nev, ncv, ctx=None):
+        self.op = op
+        h = C.c_void_p()
+        if isinstance(op, _DeviceMatrix):
+            self.ctx = op.ctx
+            check(lib().mispec_geneigs_create(self.ctx.h, op.h, int(nev), int(ncv), C.byref(h)))
+            self._user = None
+        else:
+            self.ctx = ctx or default_context()
+            self._user = _UserOp(op)
+            check(lib().mispec_geneigs_create_op(self.ctx.h, self._user.cb, None, int(op.rows()), int(nev), int(ncv),
+                                                 C.byref(h)))
+        self.h = h
+        self.nev, self.ncv = int(nev), int(ncv)
+
+    def init(self, init_resid=None):
+        v0 = None if init_resid is None else _f64(init_resid)
+        if v0 is not None and v0.shape != (self.op.rows(),):
+            raise ValueError("init: the initial residual vector must have n entries")
+        check(lib().mispec_geneigs_init(self.h, _dp(v0)))
+
+    def compute(self, selection=SortRule.LargestMagn, maxit=1000, tol=1e-10, sorting=SortRule.LargestMagn):
+        nconv = C.c_int64()
+        check(lib().mispec_geneigs_compute(self.h, int(selection), int(maxit), float(tol), int(sorting), C.byref(nconv)))
+        return nconv.value
+
+    def info(self):
+        return CompInfo(lib().mispec_geneigs_info(self.h))
+
+    def num_iterations(self):
+        return lib().mispec_geneigs_num_iterations(self.h)
+
+    def num_operations(self):
+        return lib().mispec_geneigs_num_operations(self.h)
+
+    def eigenvalues(self):
+        out = np.empty(self.nev, dtype=np.complex128)
+        cnt = C.c_int64()
+        check(lib().mispec_geneigs_eigenvalues(self.h, out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(cnt)))
+        return out[:cnt.value].copy()
+
+    def eigenvectors(self, nvec=None):
+        nvec = self.nev if nvec is None else int(nvec)
+        rows = self.op.local_rows() if isinstance(self.op, _DeviceMatrix) else self.op.rows()
+        out = np.zeros((rows, max(min(nvec, self.nev), 1)), dtype=np.complex128, order="F")
+        cnt = C.c_int64()
+        check(lib().mispec_geneigs_eigenvectors(self.h, nvec, out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(cnt)))
+        return np.asfortranarray(out[:, :cnt.value])
+
+    def residuals(self):
+        """||A x - lambda x|| / ||x|| of the converged (complex) pairs, evaluated on the device."""
+        out = np.empty(self.nev)
+        cnt = C.c_int64()
+        check(lib().mispec_geneigs_residuals(self.h, _dp(out), C.byref(cnt)))
+        return out[:cnt.value].copy()
+
+    def profile(self, enable):
+        check(lib().mispec_geneigs_profile(self.h, int(bool(enable))))
+
+    def get_profile(self):
+        p = Profile()
+        check(lib().mispec_geneigs_get_profile(self.h, C.byref(p)))
+        return p.as_dict()
+
+    def __del__(self):
+        try:
+            lib().mispec_geneigs_destroy(self.h)
+        except Exception:
+            pass
+
+
+def hess_qr(H, shift):
+    """UpperHessenbergQR on the host (the general restart's real-shift step): returns (Q, Q'HQ)."""
+    H = np.asfortranarray(H, dtype=np.float64)
+    n = H.shape[0]
+    Q, D = np.empty((n, n), order="F"), np.empty((n, n), order="F")
+    check(lib().mispec_hess_qr_host(n, _dp(H), float(shift), _dp(Q), _dp(D)))
+    return Q, D
+
+
+def double_shift_qr(H, s, t):
+    """DoubleShiftQR on the host: H^2 - sH + tI = QR; returns (Q, Q'HQ)."""
+    H = np.asfortranarray(H, dtype=np.float64)
+    n = H.shape[0]
+    Q, D = np.empty((n, n), order="F"), np.empty((n, n), order="F")
+    check(lib().mispec_double_shift_qr_host(n, _dp(H), float(s), float(t), _dp(Q), _dp(D)))
+    return Q, D
+
+
+def hess_schur(H):
+    """UpperHessenbergSchur on the host: returns (T, U) with H = U T U'."""
+    H = np.asfortranarray(H, dtype=np.float64)
+    n = H.shape[0]
+    T, U = np.empty((n, n), order="F"), np.empty((n, n), order="F")
+    check(lib().mispec_hess_schur_host(n, _dp(H), _dp(T), _dp(U)))
+    return T, U
+
+
+def hess_eigen(H):
+    """UpperHessenbergEigen on the host: complex (eigenvalues, eigenvectors)."""
+    H = np.asfortranarray(H, dtype=np.float64)
+    n = H.shape[0]
+    ev = np.empty(n, dtype=np.complex128)
+    V = np.empty((n, n), dtype=np.complex128, order="F")
+    check(lib().mispec_hess_eigen_host(n, _dp(H), ev.ctypes.data_as(C.POINTER(C.c_double)),
+                                       V.ctypes.data_as(C.POINTER(C.c_double))))
+    return ev, V
 
 
 class Factorization:

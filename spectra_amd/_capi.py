@@ -102,6 +102,7 @@ SIGNATURES = {
     "mispec_fac_compress_V": (C.c_int, [_vp, _dp, _dp, C.c_int]),
     "mispec_fac_ritz_vectors": (C.c_int, [_vp, _dp, C.c_int, _dp, _vpp]),
     "mispec_fac_residuals": (C.c_int, [_vp, _dp, C.c_int, _dp]),
+    "mispec_fac_residuals_complex": (C.c_int, [_vp, _dp, _dp, _dp, C.c_int, _dp]),
     "mispec_fac_profile": (C.c_int, [_vp, C.c_int]),
     "mispec_fac_get_profile": (C.c_int, [_vp, C.POINTER(Profile)]),
     "mispec_tridiag_qr": (C.c_int, [_vp, C.c_int, _dp, C.c_double, _dp, _dp]),
@@ -119,6 +120,23 @@ SIGNATURES = {
     "mispec_symeigs_residuals": (C.c_int, [_vp, _dp, _lp]),
     "mispec_symeigs_get_profile": (C.c_int, [_vp, C.POINTER(Profile)]),
     "mispec_symeigs_profile": (C.c_int, [_vp, C.c_int]),
+    "mispec_geneigs_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vpp]),
+    "mispec_geneigs_create_op": (C.c_int, [_vp, op_fn, _vp, C.c_int64, C.c_int64, C.c_int64, _vpp]),
+    "mispec_geneigs_destroy": (C.c_int, [_vp]),
+    "mispec_geneigs_init": (C.c_int, [_vp, _dp]),
+    "mispec_geneigs_compute": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_double, C.c_int, _lp]),
+    "mispec_geneigs_info": (C.c_int, [_vp]),
+    "mispec_geneigs_num_iterations": (C.c_int64, [_vp]),
+    "mispec_geneigs_num_operations": (C.c_int64, [_vp]),
+    "mispec_geneigs_eigenvalues": (C.c_int, [_vp, _dp, _lp]),
+    "mispec_geneigs_eigenvectors": (C.c_int, [_vp, C.c_int64, _dp, _lp]),
+    "mispec_geneigs_residuals": (C.c_int, [_vp, _dp, _lp]),
+    "mispec_geneigs_get_profile": (C.c_int, [_vp, C.POINTER(Profile)]),
+    "mispec_geneigs_profile": (C.c_int, [_vp, C.c_int]),
+    "mispec_hess_qr_host": (C.c_int, [C.c_int, _dp, C.c_double, _dp, _dp]),
+    "mispec_double_shift_qr_host": (C.c_int, [C.c_int, _dp, C.c_double, C.c_double, _dp, _dp]),
+    "mispec_hess_schur_host": (C.c_int, [C.c_int, _dp, _dp, _dp]),
+    "mispec_hess_eigen_host": (C.c_int, [C.c_int, _dp, _dp, _dp]),
 }
 
 _lib = None

@@ -915,6 +915,40 @@ extern "C" int mispec_fac_residuals(mispec_fac* fac, const double* lambda_host, 
     });
 }
 
+extern "C" int mispec_fac_residuals_complex(mispec_fac* fac, const double* Yre_host, const double* Yim_host,
+                                           const double* lambda_host, int ncols, double* resid_host)
+{
+    return guarded([&] {
+        require_init(fac, "mispec_fac_residuals_complex");
+        mispec_fac& F = *fac;
+        MISPEC_REQUIRE(Yre_host && Yim_host && lambda_host && resid_host && ncols >= 0 && ncols <= F.m,
+                       "mispec_fac_residuals_complex: bad argument");
+        MISPEC_REQUIRE(F.A, "mispec_fac_residuals_complex: needs a device-resident matrix");
+        F.ctx->make_current();
+        const int m = F.m;
+        if (F.X.n < size_t(F.ldv) * 2)
+            F.X.alloc(size_t(F.ldv) * 2);
+        F.x_cols = 0;
+        double* xr = F.X.p;
+        double* xi = F.X.p + F.ldv;
+        for (int j = 0; j < ncols; j++)
+        {
+            // [x_r | x_i] = V * [Re y_j | Im y_j]
+            std::memcpy(F.h_small.p, Yre_host + size_t(j) * m, size_t(m) * sizeof(double));
+            std::memcpy(F.h_small.p + m, Yim_host + size_t(j) * m, size_t(m) * sizeof(double));
+            MISPEC_HIP(hipMemcpyAsync(F.d_Y.p, F.h_small.p, size_t(2 * m) * 8, hipMemcpyHostToDevice, F.stream()));
+            MISPEC_HIP(hipMemsetAsync(F.X.p, 0, size_t(F.ldv) * 2 * sizeof(double), F.stream()));
+            launch_vq(*F.ctx, F.V.p, F.ldv, m, F.d_Y.p, m, 2, F.X.p, F.ldv, F.nloc);
+            apply_op(F, xr, F.tmp.p, false, nullptr, 0.0);
+            apply_op(F, xi, F.w.p, false, nullptr, 0.0);
+            const int nrec = launch_resid_norms_complex(*F.ctx, F.tmp.p, F.w.p, xr, xi, lambda_host[2 * j], lambda_host[2 * j + 1],
+                                                        F.nloc, F.partials.p, F.pstride);
+            reduce_to_host(F, nrec, 1, 0);
+            resid_host[j] = std::sqrt(F.h_red.p[kSlotBeta2]) / std::sqrt(F.h_red.p[0]);
+        }
+    });
+}
+
 extern "C" int mispec_fac_profile(mispec_fac* fac, int enable)
 {
     return guarded([&] {

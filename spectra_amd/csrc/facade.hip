@@ -2,6 +2,11 @@
 // library for bindings that cannot instantiate C++ templates (Python ctypes, cgo, JNI ...).
 // Nothing here adds arithmetic: it is Spectra::SymEigsSolver<Spectra::SparseSymMatProd<double>> (or a
 // callback operator with the reference's perform_op contract) behind opaque handles.
+#include <Spectra/GenEigsSolver.h>
+#include <Spectra/LinAlg/DoubleShiftQR.h>
+#include <Spectra/LinAlg/UpperHessenbergEigen.h>
+#include <Spectra/LinAlg/UpperHessenbergQR.h>
+#include <Spectra/LinAlg/UpperHessenbergSchur.h>
 #include <Spectra/SymEigsSolver.h>
 
 #include <cstring>
@@ -192,4 +197,222 @@ extern "C" int mispec_symeigs_profile(mispec_symeigs* s, int enable)
 extern "C" int mispec_symeigs_get_profile(const mispec_symeigs* s, mispec_profile* out)
 {
     return s ? mispec_fac_get_profile(s->fac(), out) : MISPEC_EINVAL;
+}
+
+// =================================================================================================
+// General solver facade
+// =================================================================================================
+namespace {
+using GenDevOp = Spectra::SparseGenMatProd<double>;
+using GenDevSolver = Spectra::GenEigsSolver<GenDevOp>;
+using GenCbSolver = Spectra::GenEigsSolver<CallbackOp>;
+}  // namespace
+
+struct mispec_geneigs
+{
+    std::unique_ptr<GenDevOp> dev_op;
+    std::unique_ptr<CallbackOp> cb_op;
+    std::unique_ptr<GenDevSolver> dev;
+    std::unique_ptr<GenCbSolver> cb;
+    template <typename F>
+    auto visit(F&& f) const
+    {
+        return dev ? f(*dev) : f(*cb);
+    }
+    mispec_fac* fac() const
+    {
+        return visit([](auto& s) { return s.factorization().handle(); });
+    }
+};
+
+extern "C" int mispec_geneigs_create(mispec_ctx* ctx, const mispec_csr* A, int64_t nev, int64_t ncv, mispec_geneigs** out)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(ctx && A && out, "mispec_geneigs_create: NULL argument");
+        auto s = std::make_unique<mispec_geneigs>();
+        s->dev_op = std::make_unique<GenDevOp>(ctx, const_cast<mispec_csr*>(A));
+        s->dev = std::make_unique<GenDevSolver>(*s->dev_op, nev, ncv);
+        *out = s.release();
+    });
+}
+extern "C" int mispec_geneigs_create_op(mispec_ctx* ctx, mispec_op_fn op, void* op_user, int64_t n, int64_t nev, int64_t ncv,
+                                        mispec_geneigs** out)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(ctx && op && out, "mispec_geneigs_create_op: NULL argument");
+        auto s = std::make_unique<mispec_geneigs>();
+        s->cb_op = std::make_unique<CallbackOp>(ctx, op, op_user, n);
+        s->cb = std::make_unique<GenCbSolver>(*s->cb_op, nev, ncv);
+        *out = s.release();
+    });
+}
+extern "C" int mispec_geneigs_destroy(mispec_geneigs* s)
+{
+    return guarded([&] { delete s; });
+}
+extern "C" int mispec_geneigs_init(mispec_geneigs* s, const double* v0_host)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(s, "mispec_geneigs_init: NULL argument");
+        s->visit([&](auto& solver) {
+            if (v0_host)
+                solver.init(v0_host);
+            else
+                solver.init();
+            return 0;
+        });
+    });
+}
+extern "C" int mispec_geneigs_compute(mispec_geneigs* s, int selection, int64_t maxit, double tol, int sorting, int64_t* nconv)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(s && nconv, "mispec_geneigs_compute: NULL argument");
+        MISPEC_REQUIRE(selection >= 0 && selection <= int(Spectra::SortRule::BothEnds) && sorting >= 0 &&
+                           sorting <= int(Spectra::SortRule::BothEnds),
+                       "mispec_geneigs_compute: unknown SortRule value");
+        *nconv = s->visit([&](auto& solver) {
+            return int64_t(solver.compute(static_cast<Spectra::SortRule>(selection), Spectra::Index(maxit), tol,
+                                          static_cast<Spectra::SortRule>(sorting)));
+        });
+    });
+}
+extern "C" int mispec_geneigs_info(const mispec_geneigs* s)
+{
+    return s ? s->visit([](auto& solver) { return int(solver.info()); }) : int(Spectra::CompInfo::NotComputed);
+}
+extern "C" int64_t mispec_geneigs_num_iterations(const mispec_geneigs* s)
+{
+    return s ? s->visit([](auto& solver) { return int64_t(solver.num_iterations()); }) : 0;
+}
+extern "C" int64_t mispec_geneigs_num_operations(const mispec_geneigs* s)
+{
+    return s ? s->visit([](auto& solver) { return int64_t(solver.num_operations()); }) : 0;
+}
+extern "C" int mispec_geneigs_eigenvalues(const mispec_geneigs* s, double* out_host, int64_t* count)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(s && count, "mispec_geneigs_eigenvalues: NULL argument");
+        s->visit([&](auto& solver) {
+            const auto ev = solver.eigenvalues();
+            *count = ev.size();
+            if (out_host)
+                std::memcpy(out_host, ev.data(), size_t(ev.size()) * sizeof(std::complex<double>));
+            return 0;
+        });
+    });
+}
+extern "C" int mispec_geneigs_eigenvectors(mispec_geneigs* s, int64_t nvec, double* out_host, int64_t* ncols)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(s && ncols && out_host, "mispec_geneigs_eigenvectors: NULL argument");
+        s->visit([&](auto& solver) {
+            const auto X = solver.eigenvectors(Spectra::Index(nvec));
+            *ncols = X.cols();
+            if (X.size() > 0)
+                std::memcpy(out_host, X.data(), size_t(X.size()) * sizeof(std::complex<double>));
+            return 0;
+        });
+    });
+}
+extern "C" int mispec_geneigs_residuals(mispec_geneigs* s, double* resid_host, int64_t* count)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(s && resid_host && count, "mispec_geneigs_residuals: NULL argument");
+        s->visit([&](auto& solver) {
+            const auto r = solver.residuals();
+            *count = r.size();
+            if (r.size() > 0)
+                std::memcpy(resid_host, r.data(), size_t(r.size()) * sizeof(double));
+            return 0;
+        });
+    });
+}
+extern "C" int mispec_geneigs_profile(mispec_geneigs* s, int enable)
+{
+    return s ? mispec_fac_profile(s->fac(), enable) : MISPEC_EINVAL;
+}
+extern "C" int mispec_geneigs_get_profile(const mispec_geneigs* s, mispec_profile* out)
+{
+    return s ? mispec_fac_get_profile(s->fac(), out) : MISPEC_EINVAL;
+}
+
+// =================================================================================================
+// Host-side small kernels of the general restart (no GPU involved)
+// =================================================================================================
+namespace {
+Spectra::DenseMatrix<double> as_matrix(int n, const double* p)
+{
+    Spectra::DenseMatrix<double> M(n, n);
+    std::memcpy(M.data(), p, size_t(n) * n * sizeof(double));
+    return M;
+}
+Spectra::DenseMatrix<double> identity(int n)
+{
+    Spectra::DenseMatrix<double> M(n, n);
+    for (int j = 0; j < n; j++)
+        for (int i = 0; i < n; i++)
+            M(i, j) = (i == j) ? 1.0 : 0.0;
+    return M;
+}
+}  // namespace
+
+extern "C" int mispec_hess_qr_host(int n, const double* H, double shift, double* Q, double* QtHQ)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(H && n >= 2, "mispec_hess_qr_host: bad argument");
+        Spectra::UpperHessenbergQR<double> qr(as_matrix(n, H), shift);
+        if (Q)
+        {
+            auto q = identity(n);
+            qr.apply_YQ(q);
+            std::memcpy(Q, q.data(), size_t(n) * n * sizeof(double));
+        }
+        if (QtHQ)
+        {
+            Spectra::DenseMatrix<double> d;
+            qr.matrix_QtHQ(d);
+            std::memcpy(QtHQ, d.data(), size_t(n) * n * sizeof(double));
+        }
+    });
+}
+extern "C" int mispec_double_shift_qr_host(int n, const double* H, double s, double t, double* Q, double* QtHQ)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(H && n >= 3, "mispec_double_shift_qr_host: bad argument");
+        Spectra::DoubleShiftQR<double> qr(as_matrix(n, H), s, t);
+        if (Q)
+        {
+            auto q = identity(n);
+            qr.apply_YQ(q);
+            std::memcpy(Q, q.data(), size_t(n) * n * sizeof(double));
+        }
+        if (QtHQ)
+        {
+            Spectra::DenseMatrix<double> d;
+            qr.matrix_QtHQ(d);
+            std::memcpy(QtHQ, d.data(), size_t(n) * n * sizeof(double));
+        }
+    });
+}
+extern "C" int mispec_hess_schur_host(int n, const double* H, double* T, double* U)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(H && T && U && n >= 1, "mispec_hess_schur_host: bad argument");
+        Spectra::UpperHessenbergSchur<double> sc(as_matrix(n, H));
+        std::memcpy(T, sc.matrix_T().data(), size_t(n) * n * sizeof(double));
+        std::memcpy(U, sc.matrix_U().data(), size_t(n) * n * sizeof(double));
+    });
+}
+extern "C" int mispec_hess_eigen_host(int n, const double* H, double* evals, double* evecs)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(H && evals && n >= 1, "mispec_hess_eigen_host: bad argument");
+        Spectra::UpperHessenbergEigen<double> eg(as_matrix(n, H));
+        std::memcpy(evals, eg.eigenvalues().data(), size_t(n) * sizeof(std::complex<double>));
+        if (evecs)
+        {
+            const auto V = eg.eigenvectors();
+            std::memcpy(evecs, V.data(), size_t(n) * n * sizeof(std::complex<double>));
+        }
+    });
 }

@@ -327,6 +327,34 @@ __global__ __launch_bounds__(kThreads) void k_resid_norms(const double* __restri
     }
 }
 
+__global__ __launch_bounds__(kThreads) void k_resid_norms_complex(const double* __restrict__ yr, const double* __restrict__ yi,
+                                                                   const double* __restrict__ xr, const double* __restrict__ xi,
+                                                                   double a, double b, int64_t npairs,
+                                                                   double* __restrict__ partials, int64_t pstride)
+{
+    __shared__ double red[4];
+    __shared__ double red2[4];
+    double r2 = 0.0, x2 = 0.0;
+    for (int64_t i = int64_t(blockIdx.x) * kThreads + threadIdx.x; i < npairs; i += int64_t(gridDim.x) * kThreads)
+    {
+        const double2 pr = reinterpret_cast<const double2*>(yr)[i], pi = reinterpret_cast<const double2*>(yi)[i];
+        const double2 qr = reinterpret_cast<const double2*>(xr)[i], qi = reinterpret_cast<const double2*>(xi)[i];
+        // (y_r + i y_i) - (a + i b)(x_r + i x_i)
+        const double e0 = pr.x - (a * qr.x - b * qi.x), f0 = pi.x - (b * qr.x + a * qi.x);
+        const double e1 = pr.y - (a * qr.y - b * qi.y), f1 = pi.y - (b * qr.y + a * qi.y);
+        r2 += e0 * e0 + f0 * f0 + e1 * e1 + f1 * f1;
+        x2 += qr.x * qr.x + qi.x * qi.x + qr.y * qr.y + qi.y * qi.y;
+    }
+    const double t1 = block_reduce_sum(r2, red);
+    const double t2 = block_reduce_sum(x2, red2);
+    if (threadIdx.x == 0)
+    {
+        partials[kSlotBeta2 * pstride + blockIdx.x] = t1;
+        partials[0 * pstride + blockIdx.x] = t2;
+        partials[kSlotMaxAbs * pstride + blockIdx.x] = 0.0;
+    }
+}
+
 // X[:, 0:p] = V[:, 0:m] * Q.  128-row tiles of V are staged in LDS (all m columns), so the product
 // may overwrite V in place (compress_V): a tile's rows are private to its workgroup and fully read
 // before the first write.  Wave w produces output columns i = w (mod 4).  Q is re-laid out in LDS
@@ -526,6 +554,17 @@ int launch_resid_norms(const mispec_ctx& ctx, const double* y, const double* x, 
     const int64_t npairs = (n + 1) / 2;
     const int grid = persistent_grid(ctx, (npairs + kThreads - 1) / kThreads, 4);
     hipLaunchKernelGGL(k_resid_norms, dim3(unsigned(grid)), dim3(kThreads), 0, ctx.stream, y, x, lambda, npairs, partials, pstride);
+    MISPEC_HIP(hipGetLastError());
+    return grid;
+}
+
+int launch_resid_norms_complex(const mispec_ctx& ctx, const double* yr, const double* yi, const double* xr, const double* xi,
+                               double a, double b, int64_t n, double* partials, int64_t pstride)
+{
+    const int64_t npairs = (n + 1) / 2;
+    const int grid = persistent_grid(ctx, (npairs + kThreads - 1) / kThreads, 4);
+    hipLaunchKernelGGL(k_resid_norms_complex, dim3(unsigned(grid)), dim3(kThreads), 0, ctx.stream, yr, yi, xr, xi, a, b, npairs,
+                       partials, pstride);
     MISPEC_HIP(hipGetLastError());
     return grid;
 }

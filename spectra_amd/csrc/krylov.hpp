@@ -57,6 +57,10 @@ void launch_vq(const mispec_ctx& ctx, const double* V, int64_t ldv, int m, const
 // r = y - lambda*x ; records hold |r|^2 in kSlotBeta2 and |x|^2 in slot 0.
 int launch_resid_norms(const mispec_ctx& ctx, const double* y, const double* x, double lambda, int64_t n, double* partials,
                        int64_t pstride);
+// complex pair (x_r + i x_i, lambda = a + i b): records hold |A x - lambda x|^2 in kSlotBeta2 and |x|^2 in slot 0,
+// given y_r = A x_r, y_i = A x_i
+int launch_resid_norms_complex(const mispec_ctx& ctx, const double* yr, const double* yi, const double* xr, const double* xi,
+                               double a, double b, int64_t n, double* partials, int64_t pstride);
 // Un-fused Lanczos epilogue for user operators (Lanczos.h:139-142): w -= h_prev*v_prev (if v_prev), one partial
 // of <v, w> per workgroup in partials[0 .. lanczos_epilogue_records).
 int lanczos_epilogue_records(const mispec_ctx& ctx, int64_t n);

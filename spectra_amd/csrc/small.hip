@@ -4,7 +4,7 @@
 // from HBM, 12.8 KB at ncv = 40), and only 2*ncv doubles cross PCIe per restart.
 #include "small.hpp"
 
-#include "small_dense.hpp"
+#include <Spectra/internal/SmallDense.h>
 
 using namespace mispec;
 

@@ -1,0 +1,104 @@
+"""a7 / a18 / a19 — GenEigsSolver (implicitly-restarted Arnoldi) on the GPU through the C ABI vs the CPU oracle,
+on the reference's own solver tests (test/GenEigs.cpp:38-174) and on the config-4 style benchmark matrix."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle as O
+import spectra_amd as sa
+
+pytestmark = pytest.mark.gpu
+
+GEN_CASES = [(10, 0.5, 3, 6), (100, 0.1, 10, 30), (1000, 0.01, 20, 50)]
+RULES_GEN = ["LargestMagn", "LargestReal", "LargestImag", "SmallestMagn", "SmallestReal", "SmallestImag"]
+ALLOW_FAIL = {"SmallestMagn", "SmallestImag"}  # test/GenEigs.cpp:98,106
+
+
+def gen_fixture(n, prob):
+    r, c, v = O.gen_sparse_data(n, prob)
+    A = sp.coo_matrix((v, (r, c)), shape=(n, n)).tocsc()
+    A.sort_indices()
+    return A
+
+
+def match_sets(a, b, tol):
+    """every value of a has a partner in b within tol (conjugate pairs may come in either order)"""
+    return all(np.abs(b - x).min() < tol for x in a) and all(np.abs(a - x).min() < tol for x in b)
+
+
+@pytest.mark.parametrize("n,prob,k,m", GEN_CASES)
+@pytest.mark.parametrize("rule", RULES_GEN)
+def test_gen_fixtures_all_rules(ctx, n, prob, k, m, rule):
+    A = gen_fixture(n, prob)
+    op = sa.SparseGenMatProd(A, ctx=ctx)          # ColMajor input, the reference default
+    eigs = sa.GenEigsSolver(op, k, m)
+    eigs.init()
+    nconv = eigs.compute(sa.SortRule[rule], 300)   # test/GenEigs.cpp:44 maxit = 300
+    ref = O.GenEigsSolver(O.Op.csc(n, n, A.indptr, A.indices, A.data), k, m)
+    ref.init()
+    o_nconv = ref.compute(getattr(O, rule), 300)
+    if eigs.info() != sa.CompInfo.Successful:
+        assert rule in ALLOW_FAIL and ref.info() != O.Successful   # fails exactly where the reference may fail
+        assert len(eigs.eigenvalues()) == nconv < k
+        return
+    assert ref.info() == O.Successful and nconv == o_nconv == k
+    evals, evecs = eigs.eigenvalues(), eigs.eigenvectors()
+    assert np.abs(A @ evecs - evecs * evals).max() < 1e-9          # test/GenEigs.cpp:67-70
+    assert match_sets(evals, ref.eigenvalues(), 1e-9)
+    assert abs(eigs.num_operations() - ref.num_operations()) <= max(3 * m, 0.15 * ref.num_operations())
+    res = eigs.residuals()                                          # evaluated on the device
+    host = np.linalg.norm(A @ evecs - evecs * evals, axis=0) / np.linalg.norm(evecs, axis=0)
+    assert np.abs(res - host).max() < 1e-12
+
+
+def test_gen_user_operator_and_errors(ctx):
+    rng = np.random.default_rng(5)
+    M = rng.uniform(-1, 1, (60, 60))
+
+    class Op:
+        def rows(self):
+            return 60
+
+        def cols(self):
+            return 60
+
+        def perform_op(self, x):
+            return M @ x
+
+    eigs = sa.GenEigsSolver(Op(), 6, 20, ctx=ctx)
+    eigs.init()
+    assert eigs.compute(sa.SortRule.LargestMagn) == 6 and eigs.info() == sa.CompInfo.Successful
+    ev, U = eigs.eigenvalues(), eigs.eigenvectors()
+    assert np.abs(M @ U - U * ev).max() < 1e-9
+    full = np.linalg.eigvals(M)
+    assert all(np.abs(full - x).min() < 1e-9 for x in ev)
+    assert np.all(np.diff(np.abs(ev)) <= 1e-12)           # default sorting LargestMagn
+    for nev, ncv in [(0, 5), (59, 60), (3, 4), (3, 61)]:   # GenEigsBase.h:419-423
+        with pytest.raises(ValueError, match="must satisfy"):
+            sa.GenEigsSolver(Op(), nev, ncv, ctx=ctx)
+    with pytest.raises(ValueError):                        # symmetric-only rule (SelectionRule.h:72-80)
+        eigs.init()
+        eigs.compute(sa.SortRule.LargestAlge)
+
+
+@pytest.mark.parametrize("n", [200_000, 5_000_000])
+def test_config4_nonsymmetric_band(ctx, n):
+    # BASELINE.json configs[3]: GenEigsSolver on a 5M x 5M non-symmetric CSR (~15 nnz/row), k = 10, ncv = 30.
+    op = sa.SparseGenMatProd.synth_band(n, ctx=ctx)
+    eigs = sa.GenEigsSolver(op, 10, 30)
+    eigs.init()
+    nconv = eigs.compute(sa.SortRule.LargestMagn, 1000, 1e-11)
+    assert nconv == 10 and eigs.info() == sa.CompInfo.Successful
+    res = eigs.residuals()
+    assert res.max() <= 1e-10, res
+    evals = eigs.eigenvalues()
+    assert np.all(np.diff(np.abs(evals)) <= 1e-12)
+    if n <= 200_000:
+        rp, ci, v = O.synth_band_csr(n, symmetric=False)
+        ref = O.GenEigsSolver(O.Op.csr(n, n, rp, ci, v), 10, 30)
+        ref.init()
+        assert ref.compute(O.LargestMagn, 1000, 1e-11) == 10
+        assert match_sets(evals, ref.eigenvalues(), 1e-9)
+        A = sp.csr_matrix((v, ci, rp), shape=(n, n))
+        X = eigs.eigenvectors()
+        assert (np.linalg.norm(A @ X - X * evals, axis=0) / np.linalg.norm(X, axis=0)).max() <= 1e-10
