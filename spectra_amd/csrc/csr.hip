@@ -17,6 +17,7 @@
 #include "csr.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -24,9 +25,12 @@ using namespace mispec;
 
 namespace {
 
-constexpr int kThreads = 256;
-constexpr int kCap = 4080;       // products per LDS chunk: (4080+4)*8 B + 32 B <= 32 KiB -> 5 workgroups / CU
-constexpr int kLoadIters = 4;    // 256 threads * 4 entries * 4 steps = 4096 >= kCap + 3
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+constexpr int kLoadIters = 4;  // THREADS * 4 entries * 4 steps = 16 * THREADS >= cap + 3
+// products per LDS chunk for a THREADS-row workgroup: 256 -> (4080+4)*8 B + 32 B <= 32 KiB -> 5 workgroups / CU
+constexpr int chunk_cap(int threads) { return threads * 16 - 16; }
 
 __device__ __forceinline__ double wave_reduce_sum(double v)
 {
@@ -46,13 +50,14 @@ __device__ __forceinline__ double block_reduce_sum(double v, double* red)
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-template <bool EPI>
+template <bool EPI, bool NT, int kThreads>
 __global__ __launch_bounds__(kThreads) void k_spmv_csr_stream(const int32_t* __restrict__ rowptr,
                                                                const int32_t* __restrict__ colind,
                                                                const double* __restrict__ val,
                                                                const double* __restrict__ x, double* __restrict__ y,
                                                                int64_t nrows, int nblocks, SpmvEpilogue epi)
 {
+    constexpr int kCap = chunk_cap(kThreads);
     __shared__ __attribute__((aligned(16))) double prod[kCap + 4];
     __shared__ double red[4];
 
@@ -91,9 +96,22 @@ __global__ __launch_bounds__(kThreads) void k_spmv_csr_stream(const int32_t* __r
         for (int it = 0; it < kLoadIters; it++)
         {
             const int base = min(a0 + tid * 4 + it * (kThreads * 4), last);
-            va[it][0] = *reinterpret_cast<const double2*>(val + base);
-            va[it][1] = *reinterpret_cast<const double2*>(val + base + 2);
-            ci[it] = *reinterpret_cast<const int4*>(colind + base);
+            // val / col_ind are read exactly once per SpMV: non-temporal, so they do not evict x from L2
+            if (NT)
+            {
+                const v2d a01 = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(val + base));
+                const v2d a23 = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(val + base + 2));
+                const v4i c4 = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(colind + base));
+                va[it][0] = make_double2(a01.x, a01.y);
+                va[it][1] = make_double2(a23.x, a23.y);
+                ci[it] = make_int4(c4.x, c4.y, c4.z, c4.w);
+            }
+            else
+            {
+                va[it][0] = *reinterpret_cast<const double2*>(val + base);
+                va[it][1] = *reinterpret_cast<const double2*>(val + base + 2);
+                ci[it] = *reinterpret_cast<const int4*>(colind + base);
+            }
         }
         // phase 2: gather x
         double xg[kLoadIters][4];
@@ -143,6 +161,10 @@ __global__ __launch_bounds__(kThreads) void k_spmv_csr_stream(const int32_t* __r
             y[row] = yv;
             contrib = epi.v_rows[row] * yv;  // Lanczos.h:142 partial <v, w>
         }
+        if (kThreads < 256 && tid < 4)
+            red[tid] = 0.0;
+        if (kThreads < 256)
+            __syncthreads();
         const double total = block_reduce_sum(contrib, red);
         if (tid == 0)
             epi.partials[lb] = total;
@@ -277,6 +299,12 @@ mispec_csr* upload_rows(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const i
 
 namespace mispec {
 
+int spmv_rows_per_block()
+{
+    static const int rows = (getenv("MISPEC_SPMV_ROWS") && atoi(getenv("MISPEC_SPMV_ROWS")) == 128) ? 128 : 256;
+    return rows;
+}
+
 void launch_spmv(const mispec_csr& A, const double* x_dev, double* y_dev, const SpmvEpilogue* epi)
 {
     const int64_t nloc = A.local_rows();
@@ -284,13 +312,29 @@ void launch_spmv(const mispec_csr& A, const double* x_dev, double* y_dev, const 
         return;
     const int nblocks = spmv_num_blocks(nloc);
     const int per = (nblocks + 7) >> 3;
-    const dim3 grid(unsigned(per * 8)), block(kThreads);
-    if (epi)
-        hipLaunchKernelGGL(k_spmv_csr_stream<true>, grid, block, 0, A.ctx->stream, A.rowptr.p, A.colind.p, A.val.p, x_dev,
-                           y_dev, nloc, nblocks, *epi);
+    const int threads = spmv_rows_per_block();
+    const dim3 grid(unsigned(per * 8)), block(static_cast<unsigned>(threads));
+    static const bool nt = getenv("MISPEC_SPMV_NT") ? atoi(getenv("MISPEC_SPMV_NT")) != 0 : false;
+    const SpmvEpilogue e = epi ? *epi : SpmvEpilogue{};
+#define MISPEC_SPMV(E, N)                                                                                               \
+    do                                                                                                                  \
+    {                                                                                                                   \
+        if (threads == 128)                                                                                             \
+            hipLaunchKernelGGL((k_spmv_csr_stream<E, N, 128>), grid, block, 0, A.ctx->stream, A.rowptr.p, A.colind.p,   \
+                               A.val.p, x_dev, y_dev, nloc, nblocks, e);                                                \
+        else                                                                                                            \
+            hipLaunchKernelGGL((k_spmv_csr_stream<E, N, 256>), grid, block, 0, A.ctx->stream, A.rowptr.p, A.colind.p,   \
+                               A.val.p, x_dev, y_dev, nloc, nblocks, e);                                                \
+    } while (0)
+    if (epi && nt)
+        MISPEC_SPMV(true, true);
+    else if (epi)
+        MISPEC_SPMV(true, false);
+    else if (nt)
+        MISPEC_SPMV(false, true);
     else
-        hipLaunchKernelGGL(k_spmv_csr_stream<false>, grid, block, 0, A.ctx->stream, A.rowptr.p, A.colind.p, A.val.p, x_dev,
-                           y_dev, nloc, nblocks, SpmvEpilogue{});
+        MISPEC_SPMV(false, false);
+#undef MISPEC_SPMV
     MISPEC_HIP(hipGetLastError());
 }
 

@@ -36,9 +36,13 @@ struct SpmvEpilogue
     double* partials = nullptr;       // one double per block, deterministic second stage elsewhere
 };
 
-// Rows per SpMV workgroup (one thread per row in the reduction phase).
-constexpr int kSpmvRowsPerBlock = 256;
-inline int spmv_num_blocks(int64_t local_rows) { return int((local_rows + kSpmvRowsPerBlock - 1) / kSpmvRowsPerBlock); }
+// Rows per SpMV workgroup (one thread per row in the reduction phase): 256, or 128 with MISPEC_SPMV_ROWS=128.
+int spmv_rows_per_block();
+inline int spmv_num_blocks(int64_t local_rows)
+{
+    const int r = spmv_rows_per_block();
+    return int((local_rows + r - 1) / r);
+}
 
 void launch_spmv(const mispec_csr& A, const double* x_dev, double* y_dev, const SpmvEpilogue* epi);
 

@@ -15,9 +15,13 @@
 // one of the ncol columns, so ncol+1 reads + 1 write), CORRECT_VTF (ncol+1 reads + 1 write).
 #include "krylov.hpp"
 
+#include <cstdlib>
+
 using namespace mispec;
 
 namespace {
+
+typedef double v2d __attribute__((ext_vector_type(2)));
 
 constexpr int kThreads = 256;
 constexpr int kTileRows = 128;
@@ -45,13 +49,16 @@ __device__ __forceinline__ double block_reduce_sum(double v, double* red)
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-template <int MODE, int MAXS>
+// R = row pairs per lane and tile: a tile is 128*R rows, and each wave reads R consecutive KiB of every
+// column it owns (longer contiguous runs per column stream).
+template <int MODE, int MAXS, int R>
 __global__ __launch_bounds__(kThreads) void k_orth(OrthArgs a)
 {
     constexpr bool kCorrect = (MODE == ORTH_CORRECT_VTF || MODE == ORTH_CORRECT_ONLY);
     constexpr bool kVtf = (MODE != ORTH_CORRECT_ONLY);
+    constexpr int kRows = kTileRows * R;
     __shared__ double cs[kMaxOrthCols];
-    __shared__ __attribute__((aligned(16))) double psum[2][4][kTileRows];
+    __shared__ __attribute__((aligned(16))) double psum[2][4][kRows];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -82,72 +89,99 @@ __global__ __launch_bounds__(kThreads) void k_orth(OrthArgs a)
     }
     double b2 = 0.0, mx = 0.0;
 
-    const int64_t ntiles = (a.n + kTileRows - 1) / kTileRows;
+    const int64_t ntiles = (a.n + kRows - 1) / kRows;
     int buf = 0;
     for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x)
     {
-        const int64_t r = t * kTileRows + 2 * lane;
-        const bool valid = r < a.n;  // rows come in even pairs; vectors are zero-padded to an even length
-        const int64_t rc = valid ? r : 0;
+        int64_t r[R], rc[R];
+        bool valid[R];
+#pragma unroll
+        for (int q = 0; q < R; q++)
+        {
+            r[q] = t * kRows + q * kTileRows + 2 * lane;
+            valid[q] = r[q] < a.n;  // rows come in even pairs; vectors are zero-padded to an even length
+            rc[q] = valid[q] ? r[q] : 0;
+        }
 
-        double2 vv[MAXS];
+        double2 vv[MAXS][R];
 #pragma unroll
         for (int jj = 0; jj < MAXS; jj++)
-            vv[jj] = *reinterpret_cast<const double2*>(colp[jj] + rc);
+#pragma unroll
+            for (int q = 0; q < R; q++)
+                vv[jj][q] = *reinterpret_cast<const double2*>(colp[jj] + rc[q]);
 
-        double2 fv;
-        if (MODE == ORTH_RESID_VTF)
+        double2 fv[R];
+#pragma unroll
+        for (int q = 0; q < R; q++)
         {
-            const double2 wv = *reinterpret_cast<const double2*>(a.src + rc);
-            const double2 vi = *reinterpret_cast<const double2*>(a.vi + rc);
-            fv.x = wv.x - alpha * vi.x;  // Lanczos.h:145
-            fv.y = wv.y - alpha * vi.y;
-        }
-        else
-            fv = *reinterpret_cast<const double2*>(a.src + rc);
-        if (!valid)
-        {
-            fv.x = 0.0;
-            fv.y = 0.0;
+            if (MODE == ORTH_RESID_VTF)
+            {
+                const double2 wv = *reinterpret_cast<const double2*>(a.src + rc[q]);
+                const double2 vi = *reinterpret_cast<const double2*>(a.vi + rc[q]);
+                fv[q].x = wv.x - alpha * vi.x;  // Lanczos.h:145
+                fv[q].y = wv.y - alpha * vi.y;
+            }
+            else
+                fv[q] = *reinterpret_cast<const double2*>(a.src + rc[q]);
+            if (!valid[q])
+            {
+                fv[q].x = 0.0;
+                fv[q].y = 0.0;
+            }
         }
 
         if (kCorrect)
         {
-            double2 p;
-            p.x = 0.0;
-            p.y = 0.0;
 #pragma unroll
-            for (int jj = 0; jj < MAXS; jj++)
+            for (int q = 0; q < R; q++)
             {
-                p.x += vv[jj].x * cw[jj];
-                p.y += vv[jj].y * cw[jj];
+                double2 p;
+                p.x = 0.0;
+                p.y = 0.0;
+#pragma unroll
+                for (int jj = 0; jj < MAXS; jj++)
+                {
+                    p.x += vv[jj][q].x * cw[jj];
+                    p.y += vv[jj][q].y * cw[jj];
+                }
+                *reinterpret_cast<double2*>(&psum[buf][w][q * kTileRows + 2 * lane]) = p;
             }
-            *reinterpret_cast<double2*>(&psum[buf][w][2 * lane]) = p;
             __syncthreads();
-            const double2 p0 = *reinterpret_cast<const double2*>(&psum[buf][0][2 * lane]);
-            const double2 p1 = *reinterpret_cast<const double2*>(&psum[buf][1][2 * lane]);
-            const double2 p2 = *reinterpret_cast<const double2*>(&psum[buf][2][2 * lane]);
-            const double2 p3 = *reinterpret_cast<const double2*>(&psum[buf][3][2 * lane]);
-            if (valid)
+#pragma unroll
+            for (int q = 0; q < R; q++)
             {
-                fv.x -= (p0.x + p1.x) + (p2.x + p3.x);  // Lanczos.h:171 / Arnoldi.h:254
-                fv.y -= (p0.y + p1.y) + (p2.y + p3.y);
+                const int o = q * kTileRows + 2 * lane;
+                const double2 p0 = *reinterpret_cast<const double2*>(&psum[buf][0][o]);
+                const double2 p1 = *reinterpret_cast<const double2*>(&psum[buf][1][o]);
+                const double2 p2 = *reinterpret_cast<const double2*>(&psum[buf][2][o]);
+                const double2 p3 = *reinterpret_cast<const double2*>(&psum[buf][3][o]);
+                if (valid[q])
+                {
+                    fv[q].x -= (p0.x + p1.x) + (p2.x + p3.x);  // Lanczos.h:171 / Arnoldi.h:254
+                    fv[q].y -= (p0.y + p1.y) + (p2.y + p3.y);
+                }
             }
             buf ^= 1;
         }
 
         if (w == 0)
         {
-            if (MODE != ORTH_VTF && valid)
-                *reinterpret_cast<double2*>(a.dst + r) = fv;
-            b2 += fv.x * fv.x + fv.y * fv.y;
-            mx = fmax(mx, fmax(fabs(fv.x), fabs(fv.y)));
+#pragma unroll
+            for (int q = 0; q < R; q++)
+            {
+                if (MODE != ORTH_VTF && valid[q])
+                    *reinterpret_cast<double2*>(a.dst + r[q]) = fv[q];
+                b2 += fv[q].x * fv[q].x + fv[q].y * fv[q].y;
+                mx = fmax(mx, fmax(fabs(fv[q].x), fabs(fv[q].y)));
+            }
         }
         if (kVtf)
         {
 #pragma unroll
             for (int jj = 0; jj < MAXS; jj++)
-                acc[jj] += vv[jj].x * fv.x + vv[jj].y * fv.y;
+#pragma unroll
+                for (int q = 0; q < R; q++)
+                    acc[jj] += vv[jj][q].x * fv[q].x + vv[jj][q].y * fv[q].y;
         }
     }
 
@@ -359,6 +393,20 @@ __global__ __launch_bounds__(kThreads) void k_resid_norms_complex(const double* 
 // may overwrite V in place (compress_V): a tile's rows are private to its workgroup and fully read
 // before the first write.  Wave w produces output columns i = w (mod 4).  Q is re-laid out in LDS
 // so that a wave's coefficients for one j are contiguous (broadcast ds_read_b128).
+// this wave's columns (w, w+4, ...) of one 128-row tile -> registers; surplus slots re-read column w
+template <int NJ>
+__device__ __forceinline__ void vq_fetch(v2d (&pre)[NJ], const double* __restrict__ V, int64_t ldv, int w, int nj,
+                                         int64_t r, int64_t n)
+{
+    const int64_t rc = (r < n) ? r : 0;
+#pragma unroll
+    for (int jj = 0; jj < NJ; jj++)
+    {
+        const int jc = (jj < nj) ? (w + 4 * jj) : w;
+        pre[jj] = *reinterpret_cast<const v2d*>(V + int64_t(jc) * ldv + rc);
+    }
+}
+
 template <int MAXS>
 __global__ __launch_bounds__(kThreads) void k_vq(const double* __restrict__ V, int64_t ldv, int m,
                                                   const double* __restrict__ Q, int ldq, int p, double* X, int64_t ldx,
@@ -369,6 +417,8 @@ __global__ __launch_bounds__(kThreads) void k_vq(const double* __restrict__ V, i
     double* Qs = smem + int64_t(m) * kTileRows;  // [m][4][MAXS]
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int kMaxJ = kMaxOrthCols / 4;  // input columns per wave
+    const int nj = (m - w + 3) / 4;          // this wave stages columns w, w+4, ...
 
     for (int idx = tid; idx < m * 4 * MAXS; idx += kThreads)
     {
@@ -377,16 +427,25 @@ __global__ __launch_bounds__(kThreads) void k_vq(const double* __restrict__ V, i
         Qs[idx] = (i < p) ? Q[j + int64_t(i) * ldq] : 0.0;
     }
 
+    // Software pipeline: the next tile's rows travel HBM -> registers while the current tile is multiplied
+    // out of LDS, so the load latency hides behind the FMAs and stores of the tile before.
     const int64_t ntiles = (n + kTileRows - 1) / kTileRows;
-    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x)
+    v2d pre[kMaxJ];
+    int64_t t = blockIdx.x;
+    if (t < ntiles)
+        vq_fetch<kMaxJ>(pre, V, ldv, w, nj, t * kTileRows + 2 * lane, n);
+    for (; t < ntiles; t += gridDim.x)
     {
         const int64_t r = t * kTileRows + 2 * lane;
         const bool valid = r < n;
-        const int64_t rc = valid ? r : 0;
         __syncthreads();  // previous tile fully consumed (and Qs written, first time round)
-        for (int j = w; j < m; j += 4)
-            *reinterpret_cast<double2*>(&Vt[j * kTileRows + 2 * lane]) = *reinterpret_cast<const double2*>(V + int64_t(j) * ldv + rc);
+#pragma unroll
+        for (int jj = 0; jj < kMaxJ; jj++)
+            if (jj < nj)
+                *reinterpret_cast<v2d*>(&Vt[(w + 4 * jj) * kTileRows + 2 * lane]) = pre[jj];
         __syncthreads();
+        if (t + gridDim.x < ntiles)
+            vq_fetch<kMaxJ>(pre, V, ldv, w, nj, (t + gridDim.x) * kTileRows + 2 * lane, n);
 
         double2 acc[MAXS];
 #pragma unroll
@@ -454,6 +513,13 @@ __global__ __launch_bounds__(kThreads) void k_simple_random(double* __restrict__
     }
 }
 
+// Tuning knob read once from the environment (0 = use the built-in default).
+int env_int(const char* name)
+{
+    const char* e = getenv(name);
+    return e ? atoi(e) : 0;
+}
+
 int persistent_grid(const mispec_ctx& ctx, int64_t work_items, int per_cu)
 {
     int64_t g = int64_t(ctx.num_cu) * per_cu;
@@ -464,19 +530,47 @@ int persistent_grid(const mispec_ctx& ctx, int64_t work_items, int per_cu)
     return int(g);
 }
 
+int env_int(const char* name);
+
 template <int MODE>
 void launch_orth_mode(const mispec_ctx& ctx, const OrthArgs& a, int grid)
 {
+    // One instantiation per slot count (columns per wave, ceil(ncol / 4)): a wave then issues exactly the
+    // loads it needs — with a coarser set of sizes the surplus slots re-read column 0 and spend L1/L2 bandwidth.
     const int slots = (a.ncol + 3) / 4;
+    static const int rknob = env_int("MISPEC_ORTH_R");
+    const bool two = (rknob != 1) && slots <= 10;
     const dim3 g(static_cast<unsigned>(grid)), b(kThreads);
-    if (slots <= 4)
-        hipLaunchKernelGGL((k_orth<MODE, 4>), g, b, 0, ctx.stream, a);
-    else if (slots <= 8)
-        hipLaunchKernelGGL((k_orth<MODE, 8>), g, b, 0, ctx.stream, a);
-    else if (slots <= 12)
-        hipLaunchKernelGGL((k_orth<MODE, 12>), g, b, 0, ctx.stream, a);
-    else
-        hipLaunchKernelGGL((k_orth<MODE, 16>), g, b, 0, ctx.stream, a);
+    switch (slots)
+    {
+#define MISPEC_ORTH_CASE(S)                                                      \
+    case S:                                                                      \
+        if (two)                                                                 \
+            hipLaunchKernelGGL((k_orth<MODE, S, 2>), g, b, 0, ctx.stream, a);    \
+        else                                                                     \
+            hipLaunchKernelGGL((k_orth<MODE, S, 1>), g, b, 0, ctx.stream, a);    \
+        break;
+        case 0:
+            MISPEC_ORTH_CASE(1)
+            MISPEC_ORTH_CASE(2)
+            MISPEC_ORTH_CASE(3)
+            MISPEC_ORTH_CASE(4)
+            MISPEC_ORTH_CASE(5)
+            MISPEC_ORTH_CASE(6)
+            MISPEC_ORTH_CASE(7)
+            MISPEC_ORTH_CASE(8)
+            MISPEC_ORTH_CASE(9)
+            MISPEC_ORTH_CASE(10)
+            MISPEC_ORTH_CASE(11)
+            MISPEC_ORTH_CASE(12)
+            MISPEC_ORTH_CASE(13)
+            MISPEC_ORTH_CASE(14)
+            MISPEC_ORTH_CASE(15)
+        default:
+            hipLaunchKernelGGL((k_orth<MODE, 16, 1>), g, b, 0, ctx.stream, a);
+            break;
+#undef MISPEC_ORTH_CASE
+    }
 }
 
 }  // namespace
@@ -486,8 +580,11 @@ namespace mispec {
 int launch_orth(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a)
 {
     MISPEC_REQUIRE(a.ncol >= 0 && a.ncol <= kMaxOrthCols, "orth kernel: more than 64 basis columns");
-    const int64_t ntiles = (a.n + kTileRows - 1) / kTileRows;
-    const int grid = persistent_grid(ctx, ntiles, 4);
+    static const int rknob = env_int("MISPEC_ORTH_R");
+    const int rows = kTileRows * ((rknob != 1 && (a.ncol + 3) / 4 <= 10) ? 2 : 1);
+    const int64_t ntiles = (a.n + rows - 1) / rows;
+    static const int knob = env_int("MISPEC_ORTH_BLOCKS_PER_CU");
+    const int grid = persistent_grid(ctx, ntiles, knob > 0 ? knob : 4);
     MISPEC_REQUIRE(a.pstride >= grid, "orth kernel: partial-record stride smaller than the grid");
     switch (mode)
     {
@@ -577,7 +674,8 @@ void launch_vq(const mispec_ctx& ctx, const double* V, int64_t ldv, int m, const
     const int slots = (p + 3) / 4;
     const int maxs = slots <= 4 ? 4 : slots <= 8 ? 8 : slots <= 12 ? 12 : 16;
     const size_t lds = (size_t(m) * kTileRows + size_t(m) * 4 * maxs) * sizeof(double);
-    const int grid = persistent_grid(ctx, ntiles, 2);
+    static const int vq_knob = env_int("MISPEC_VQ_BLOCKS_PER_CU");
+    const int grid = persistent_grid(ctx, ntiles, vq_knob > 0 ? vq_knob : 3);
     const dim3 g(static_cast<unsigned>(grid)), b(kThreads);
 #define MISPEC_VQ(S)                                                                                                   \
     do                                                                                                                 \
