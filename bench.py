@@ -38,6 +38,7 @@ def parse():
                    help="1e-11 so that ||Av - lv||/||v|| <= 1e-10 holds for |l| ~ 2.5 (the criterion is relative to |l|)")
     p.add_argument("--selection", default="LargestMagn")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     p.add_argument("--cpu-steps", type=int, default=5, help="Lanczos steps of the CPU sample")
     p.add_argument("--spmv-reps", type=int, default=50, help="stand-alone SpMV launches timed after the solves")
     return p.parse_args()
@@ -120,7 +121,7 @@ def main():
     solvers = []
     total_pairs = 0
     for _ in range(args.steps):
-        eigs, nconv, ncols = solve(True)
+        eigs, nconv, ncols = solve(not args.no_profile)
         total_pairs += nconv
         solvers.append(eigs)
     barrier()

@@ -67,6 +67,8 @@ __global__ __launch_bounds__(kThreads) void k_spmv_csr_stream(const int32_t* __r
     const int lb = (int(blockIdx.x) & 7) * per + (int(blockIdx.x) >> 3);
     if (lb >= nblocks)
         return;
+    if (EPI && epi.status && *epi.status != 0)
+        return;
 
     const int tid = threadIdx.x;
     const int64_t row0 = int64_t(lb) * kThreads;
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(kThreads) void k_spmv_csr_stream(const int32_t* __r
             const int64_t row = row0 + tid;
             double yv = acc;
             if (epi.v_prev)
-                yv -= epi.h_prev * epi.v_prev[row];  // Lanczos.h:139
+                yv -= (epi.h_prev_dev ? *epi.h_prev_dev : epi.h_prev) * epi.v_prev[row];  // Lanczos.h:139
             y[row] = yv;
             contrib = epi.v_rows[row] * yv;  // Lanczos.h:142 partial <v, w>
         }

@@ -33,6 +33,8 @@ struct SpmvEpilogue
     const double* v_rows = nullptr;   // local rows of the input vector (the new basis column)
     const double* v_prev = nullptr;   // previous basis column, or nullptr when restarting (Lanczos.h:138)
     double h_prev = 0.0;              // H(i,i-1); used only when v_prev != nullptr
+    const double* h_prev_dev = nullptr;  // if set, H(i,i-1) is read from device memory instead (device-driven steps)
+    const int* status = nullptr;      // if set, the launch is a no-op unless *status == 0
     double* partials = nullptr;       // one double per block, deterministic second stage elsewhere
 };
 

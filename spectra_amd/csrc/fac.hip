@@ -17,6 +17,7 @@
 #include "small.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 using namespace mispec;
@@ -56,7 +57,10 @@ struct mispec_fac
 
     DevBuf<double> V, f, w, tmp, xfull, X, partials, alpha_partials, red, Qdev, d_diag, d_subd, d_evals, d_evecs, d_Y, gmax;
     DevBuf<int> d_info;
+    DevBuf<StepState> d_state;     // device-driven step bookkeeping (krylov.hpp)
+    PinnedBuf<StepState> h_state;  // its pinned host mirror
     PinnedBuf<double> h_red, h_small, h_x, h_y;
+    bool device_steps = true;      // MISPEC_HOST_STEPS=1 forces the host-synchronous path
     int64_t pstride = 0;  // stride between slots of the partial records
     int red_cur = 0;   // which half of `red` holds the latest reduced record
     int x_cols = 0;    // columns currently held in X
@@ -185,7 +189,8 @@ void allreduce_max_scalar(mispec_fac& F, double* dev_scalar)
 // y = Op(x).  x_loc / y_loc: this shard's rows (device).  With `lanczos_epi`, additionally
 // y -= h_prev * v_prev (when v_prev != nullptr) and alpha = <x, y> is left in red_buf(0)[kSlotAlpha]
 // (device) — Lanczos.h:131-142.
-void apply_op(mispec_fac& F, const double* x_loc, double* y_loc, bool lanczos_epi, const double* v_prev, double h_prev)
+void apply_op(mispec_fac& F, const double* x_loc, double* y_loc, bool lanczos_epi, const double* v_prev, double h_prev,
+              const double* h_prev_dev = nullptr, const int* status = nullptr)
 {
     double* alpha_dev = F.red_buf(0) + kSlotAlpha;
     if (F.A)
@@ -204,6 +209,8 @@ void apply_op(mispec_fac& F, const double* x_loc, double* y_loc, bool lanczos_ep
             epi.v_rows = x_loc;
             epi.v_prev = v_prev;
             epi.h_prev = h_prev;
+            epi.h_prev_dev = h_prev_dev;
+            epi.status = status;
             epi.partials = F.alpha_partials.p;
             launch_spmv(*F.A, x, y_loc, &epi);
         }
@@ -231,22 +238,31 @@ void apply_op(mispec_fac& F, const double* x_loc, double* y_loc, bool lanczos_ep
     }
 }
 
-// Reduce the per-workgroup records of the last orth/axpby launch into red_buf(which) and bring the
-// record to the host (h_red).  One stream synchronisation.
-void reduce_to_host(mispec_fac& F, int nrec, int ncol, int which)
+// Reduce the per-workgroup records of the last orth/axpby launch into red_buf(which); `fin` is the scalar
+// tail executed on the device after the (all-)reduction.  No host synchronisation.
+void reduce_record(mispec_fac& F, int nrec, int ncol, int which, const FinishArgs& fin)
 {
     double* red = F.red_buf(which);
     if (!F.sharded())
-        launch_reduce_partials(*F.ctx, F.partials.p, F.pstride, nrec, ncol, red, true);
+        launch_reduce_partials(*F.ctx, F.partials.p, F.pstride, nrec, ncol, red, fin);
     else
     {
-        launch_reduce_partials(*F.ctx, F.partials.p, F.pstride, nrec, ncol, red, false);
+        FinishArgs none;
+        none.mode = kFinishNone;
+        launch_reduce_partials(*F.ctx, F.partials.p, F.pstride, nrec, ncol, red, none);
         allreduce(F, red, kSlotBeta2 + 1);  // slots [0, 64] are sums
-        launch_finish(*F.ctx, red, ncol);
+        launch_finish(*F.ctx, red, ncol, fin);
     }
-    MISPEC_HIP(hipMemcpyAsync(F.h_red.p, red, kPartialLd * sizeof(double), hipMemcpyDeviceToHost, F.stream()));
-    sync_stream(F);
     F.red_cur = which;
+}
+
+// Same, then bring the record to the host (h_red).  One stream synchronisation.
+void reduce_to_host(mispec_fac& F, int nrec, int ncol, int which)
+{
+    FinishArgs fin;  // norms only
+    reduce_record(F, nrec, ncol, which, fin);
+    MISPEC_HIP(hipMemcpyAsync(F.h_red.p, F.red_buf(which), kPartialLd * sizeof(double), hipMemcpyDeviceToHost, F.stream()));
+    sync_stream(F);
 }
 
 OrthArgs orth_args(mispec_fac& F, int ncol)
@@ -406,87 +422,196 @@ void zero_H_outside(mispec_fac& F, int from_k)  // Lanczos.h:85-86 / Arnoldi.h:2
             F.Hat(i, j) = 0.0;
 }
 
-// Lanczos.h:62-187
-void factorize_lanczos(mispec_fac& F, int from_k, int to_m, int64_t* nmatop)
+// The while loop of Lanczos.h:156-182 on the host path, entered with `count` corrections already applied and
+// h_red / red_cur describing the latest record of step i.
+void lanczos_corrections_host(mispec_fac& F, int i, int count)
 {
     const double beta_thresh = kEps * std::sqrt(double(F.n));
-    const double eps_sqrt = std::sqrt(kEps);
-    zero_H_outside(F, from_k);
-
-    for (int i = from_k; i <= to_m - 1; i++)
+    const int i1 = i + 1;
+    double ortho_err = F.h_red.p[kSlotErr];
+    while (count < 5 && ortho_err > kEps * F.beta)  // :156
     {
-        bool restart = (F.beta < kNear0);  // :99
-        double* v = F.col(i);
-        if (!restart)
+        if (F.beta < beta_thresh)  // :163-168
         {
-            {
-                Timed t(F, FAM_SCALE);
-                launch_scale(*F.ctx, F.f.p, v, F.ldv, F.beta);  // :106
-            }
-            if (F.beta < eps_sqrt)  // :107-113 (rare)
-            {
-                OrthArgs a = orth_args(F, 1);
-                a.V = F.col(i - 1);
-                a.src = v;
-                int nrec;
-                {
-                    Timed t(F, FAM_VTF);
-                    nrec = launch_orth(*F.ctx, ORTH_VTF, a);
-                }
-                reduce_to_host(F, nrec, 1, 0);
-                restart = (std::fabs(F.h_red.p[0]) > eps_sqrt);
-            }
+            zero_vector(F, F.f.p);
+            F.beta = 0.0;
+            break;
         }
-        if (restart)
+        const double c_im1 = F.h_red.p[i - 1], c_i = F.h_red.p[i];
+        correct_vtf(F, F.f.p, F.f.p, i1);  // :171, :177, :179 — one pass over V
+        F.Hat(i - 1, i) += c_im1;          // :173-175
+        F.Hat(i, i - 1) = F.Hat(i - 1, i);
+        F.Hat(i, i) += c_i;
+        F.beta = F.h_red.p[kSlotBeta];
+        ortho_err = F.h_red.p[kSlotErr];
+        count++;
+    }
+}
+
+// One whole step of Lanczos.h:88-183 with every decision taken on the host (2-3 stream synchronisations).
+// Used for user operators, for the rare restart / breakdown branches, and when MISPEC_HOST_STEPS=1.
+void lanczos_step_host(mispec_fac& F, int i, int64_t* nmatop)
+{
+    const double eps_sqrt = std::sqrt(kEps);
+    bool restart = (F.beta < kNear0);  // :99
+    double* v = F.col(i);
+    if (!restart)
+    {
         {
-            expand_basis(F, i, 2 * int64_t(i), nmatop);  // :117-118
             Timed t(F, FAM_SCALE);
-            launch_scale(*F.ctx, F.f.p, v, F.ldv, F.beta);  // :119
+            launch_scale(*F.ctx, F.f.p, v, F.ldv, F.beta);  // :106
         }
-        F.Hat(i, i - 1) = restart ? 0.0 : F.beta;  // :127-128
-        F.Hat(i - 1, i) = F.Hat(i, i - 1);
+        if (F.beta < eps_sqrt)  // :107-113 (rare)
+        {
+            OrthArgs a = orth_args(F, 1);
+            a.V = F.col(i - 1);
+            a.src = v;
+            int nrec;
+            {
+                Timed t(F, FAM_VTF);
+                nrec = launch_orth(*F.ctx, ORTH_VTF, a);
+            }
+            reduce_to_host(F, nrec, 1, 0);
+            restart = (std::fabs(F.h_red.p[0]) > eps_sqrt);
+        }
+    }
+    if (restart)
+    {
+        expand_basis(F, i, 2 * int64_t(i), nmatop);  // :117-118
+        Timed t(F, FAM_SCALE);
+        launch_scale(*F.ctx, F.f.p, v, F.ldv, F.beta);  // :119
+    }
+    F.Hat(i, i - 1) = restart ? 0.0 : F.beta;  // :127-128
+    F.Hat(i - 1, i) = F.Hat(i, i - 1);
 
-        // w = A v ; w -= H(i,i-1) V[:,i-1] ; alpha = <v, w>   (:131-142) — one kernel
-        apply_op(F, v, F.w.p, true, restart ? nullptr : F.col(i - 1), F.Hat(i, i - 1));
-        (*nmatop)++;
+    // w = A v ; w -= H(i,i-1) V[:,i-1] ; alpha = <v, w>   (:131-142) — one kernel
+    apply_op(F, v, F.w.p, true, restart ? nullptr : F.col(i - 1), F.Hat(i, i - 1));
+    (*nmatop)++;
 
-        // f = w - alpha v ; beta = |f| ; Vf = V[:, :i+1]' f   (:145-153) — one pass over V
-        const int i1 = i + 1;
+    // f = w - alpha v ; beta = |f| ; Vf = V[:, :i+1]' f   (:145-153) — one pass over V
+    const int i1 = i + 1;
+    OrthArgs a = orth_args(F, i1);
+    a.src = F.w.p;
+    a.dst = F.f.p;
+    a.vi = v;
+    a.alpha_dev = F.red_buf(0) + kSlotAlpha;
+    int nrec;
+    {
+        Timed t(F, FAM_VTF);
+        nrec = launch_orth(*F.ctx, ORTH_RESID_VTF, a);
+    }
+    MISPEC_HIP(hipMemcpyAsync(F.h_red.p + kPartialLd, F.red_buf(0) + kSlotAlpha, sizeof(double), hipMemcpyDeviceToHost,
+                              F.stream()));
+    reduce_to_host(F, nrec, i1, 1);
+    F.Hat(i, i) = F.h_red.p[kPartialLd];
+    F.beta = F.h_red.p[kSlotBeta];
+    lanczos_corrections_host(F, i, 0);
+}
+
+// One step of the device-driven path: every kernel is enqueued, nothing is read back.  The scalar decisions
+// of the step (restart test, need for a correction, breakdown) are taken by the finish code on the device and
+// recorded in F.d_state; a kernel that must not run any more turns itself into a no-op.
+constexpr int kSpeculativeCorrections = 2;
+void lanczos_step_device(mispec_fac& F, int i)
+{
+    StepState* st = F.d_state.p;
+    double* v = F.col(i);
+    {
+        Timed t(F, FAM_SCALE);
+        launch_scale_step(*F.ctx, F.f.p, v, F.ldv, st, i, std::sqrt(kEps));
+    }
+    apply_op(F, v, F.w.p, true, F.col(i - 1), 0.0, &st->subd[i - 1], &st->status);
+
+    const int i1 = i + 1;
+    FinishArgs fin;
+    fin.st = st;
+    fin.step = i;
+    fin.eps = kEps;
+    fin.beta_thresh = kEps * std::sqrt(double(F.n));
+    fin.max_spec = kSpeculativeCorrections;
+    {
         OrthArgs a = orth_args(F, i1);
         a.src = F.w.p;
         a.dst = F.f.p;
         a.vi = v;
         a.alpha_dev = F.red_buf(0) + kSlotAlpha;
-        int nrec;
-        {
-            Timed t(F, FAM_VTF);
-            nrec = launch_orth(*F.ctx, ORTH_RESID_VTF, a);
-        }
-        MISPEC_HIP(hipMemcpyAsync(F.h_red.p + kPartialLd, F.red_buf(0) + kSlotAlpha, sizeof(double), hipMemcpyDeviceToHost,
-                                  F.stream()));
-        reduce_to_host(F, nrec, i1, 1);
-        F.Hat(i, i) = F.h_red.p[kPartialLd];
-        F.beta = F.h_red.p[kSlotBeta];
-        double ortho_err = F.h_red.p[kSlotErr];
+        a.status = &st->status;
+        Timed t(F, FAM_VTF);
+        const int nrec = launch_orth(*F.ctx, ORTH_RESID_VTF, a);
+        fin.mode = kFinishStepFirst;
+        fin.alpha_src = F.red_buf(0) + kSlotAlpha;
+        reduce_record(F, nrec, i1, 1, fin);
+    }
+    for (int c = 0; c < kSpeculativeCorrections; c++)
+    {
+        OrthArgs a = orth_args(F, i1);
+        a.src = F.f.p;
+        a.dst = F.f.p;
+        a.c_in = F.red_buf(F.red_cur);
+        a.status = &st->status;
+        a.need_corr = &st->need_corr;
+        Timed t(F, FAM_GEMV);
+        const int nrec = launch_orth(*F.ctx, ORTH_CORRECT_VTF, a);
+        fin.mode = kFinishStepCorr;
+        fin.prev_red = F.red_buf(F.red_cur);
+        reduce_record(F, nrec, i1, F.red_cur ^ 1, fin);
+    }
+}
 
-        int count = 0;
-        while (count < 5 && ortho_err > kEps * F.beta)  // :156
+// Lanczos.h:62-187
+void factorize_lanczos(mispec_fac& F, int from_k, int to_m, int64_t* nmatop)
+{
+    zero_H_outside(F, from_k);
+    const bool fast = F.device_steps && F.A != nullptr;
+    int i = from_k;
+    while (i <= to_m - 1)
+    {
+        if (!fast)
         {
-            if (F.beta < beta_thresh)  // :163-168
-            {
-                zero_vector(F, F.f.p);
-                F.beta = 0.0;
-                break;
-            }
-            const double c_im1 = F.h_red.p[i - 1], c_i = F.h_red.p[i];
-            correct_vtf(F, F.f.p, F.f.p, i1);  // :171, :177, :179 — one pass over V
-            F.Hat(i - 1, i) += c_im1;          // :173-175
-            F.Hat(i, i - 1) = F.Hat(i - 1, i);
-            F.Hat(i, i) += c_i;
-            F.beta = F.h_red.p[kSlotBeta];
-            ortho_err = F.h_red.p[kSlotErr];
-            count++;
+            lanczos_step_host(F, i, nmatop);
+            i++;
+            continue;
         }
+        // ---- device-driven run of steps i .. to_m-1 -------------------------------------------------
+        StepState& hs = *F.h_state.p;
+        std::memset(&hs, 0, sizeof(StepState));
+        hs.beta = F.beta;
+        hs.status = kStepOk;
+        for (int j = 0; j < F.m; j++)
+        {
+            hs.diag[j] = F.Hat(j, j);
+            hs.subd[j] = (j + 1 < F.m) ? F.Hat(j + 1, j) : 0.0;
+        }
+        MISPEC_HIP(hipMemcpyAsync(F.d_state.p, &hs, sizeof(StepState), hipMemcpyHostToDevice, F.stream()));
+        for (int s = i; s <= to_m - 1; s++)
+            lanczos_step_device(F, s);
+        MISPEC_HIP(hipMemcpyAsync(&hs, F.d_state.p, sizeof(StepState), hipMemcpyDeviceToHost, F.stream()));
+        sync_stream(F);
+
+        const int status = hs.status;
+        const int stop = (status == kStepOk) ? to_m : hs.stop_step;
+        const int last_done = (status == kStepOk) ? to_m - 1 : (status == kStepSmallBeta ? stop - 1 : stop);
+        for (int j = i; j <= last_done; j++)  // bring H of the executed steps home
+        {
+            F.Hat(j, j) = hs.diag[j];
+            F.Hat(j, j - 1) = F.Hat(j - 1, j) = hs.subd[j - 1];
+        }
+        *nmatop += (last_done - i + 1);
+        F.beta = hs.beta;
+        if (status == kStepOk)
+            break;
+        // ---- the rare branches continue on the host path, then the device path resumes ---------------
+        if (status == kStepSmallBeta)
+            lanczos_step_host(F, stop, nmatop);
+        else
+        {
+            F.red_cur = (hs.stop_count % 2 == 0) ? 1 : 0;  // RESID -> red[1], then the corrections alternate
+            MISPEC_HIP(hipMemcpyAsync(F.h_red.p, F.red_buf(F.red_cur), kPartialLd * sizeof(double), hipMemcpyDeviceToHost,
+                                      F.stream()));
+            sync_stream(F);
+            lanczos_corrections_host(F, stop, hs.stop_count);  // kStepTinyF takes the clamp branch at once
+        }
+        i = stop + 1;
     }
     F.k = to_m;
 }
@@ -638,6 +763,9 @@ extern "C" int mispec_fac_create(mispec_ctx* ctx, const mispec_csr* A, mispec_op
             F->d_evecs.alloc(size_t(ncv) * ncv);
             F->d_Y.alloc(size_t(ncv) * ncv);
             F->d_info.alloc(1);
+            F->d_state.alloc(1);
+            F->h_state.alloc(1);
+            F->device_steps = !(getenv("MISPEC_HOST_STEPS") && atoi(getenv("MISPEC_HOST_STEPS")) != 0);
             F->h_red.alloc(kPartialLd + 8);
             F->h_small.alloc(size_t(ncv) * ncv + 4 * size_t(ncv) + 8);
             if (op)

@@ -60,6 +60,11 @@ __global__ __launch_bounds__(kThreads) void k_orth(OrthArgs a)
     __shared__ double cs[kMaxOrthCols];
     __shared__ __attribute__((aligned(16))) double psum[2][4][kRows];
 
+    if (a.status && *a.status != kStepOk)
+        return;
+    if (a.need_corr && *a.need_corr == 0)
+        return;
+
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -209,9 +214,58 @@ __global__ __launch_bounds__(kThreads) void k_orth(OrthArgs a)
     }
 }
 
+// Executed by ONE thread after a reduction: the scalar tail of a Lanczos step.
+__device__ void finish_record(double* red, int ncol, const FinishArgs& fa)
+{
+    if (fa.mode == kFinishNone)
+        return;
+    const double beta = sqrt(red[kSlotBeta2]);  // ArnoldiOp.h:152-155: plain sqrt(sum x^2)
+    double err = 0.0;
+    for (int j = 0; j < ncol; j++)
+        err = fmax(err, fabs(red[j]));  // Lanczos.h:153 cwiseAbs().maxCoeff()
+    red[kSlotBeta] = beta;
+    red[kSlotErr] = err;
+    if (fa.mode == kFinishNorms)
+        return;
+    StepState* st = fa.st;
+    if (st->status != kStepOk)
+        return;
+    if (fa.mode == kFinishStepFirst)
+    {
+        st->alpha = *fa.alpha_src;
+        st->diag[fa.step] = st->alpha;  // Lanczos.h:142
+        st->count = 0;
+    }
+    else
+    {
+        if (!st->need_corr)
+            return;  // this correction was not executed
+        st->subd[fa.step - 1] += fa.prev_red[fa.step - 1];  // Lanczos.h:173-175
+        st->diag[fa.step] += fa.prev_red[fa.step];
+        st->count++;
+    }
+    st->beta = beta;
+    st->err = err;
+    int need = (st->count < 5) && (err > fa.eps * beta);  // Lanczos.h:156
+    if (need && beta < fa.beta_thresh)                    // Lanczos.h:163
+    {
+        st->status = kStepTinyF;
+        st->stop_step = fa.step;
+        st->stop_count = st->count;
+        need = 0;
+    }
+    else if (need && st->count >= fa.max_spec)
+    {
+        st->status = kStepMoreCorr;
+        st->stop_step = fa.step;
+        st->stop_count = st->count;
+    }
+    st->need_corr = need;
+}
+
 // One workgroup sums the records column by column in a fixed order.
 __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restrict__ partials, int64_t pstride, int nrec,
-                                                           int ncol, double* __restrict__ red, int finish)
+                                                           int ncol, double* __restrict__ red, FinishArgs fin)
 {
     __shared__ double sh[kPartialLd];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -233,29 +287,17 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restri
             sh[j] = v;
     }
     __syncthreads();
-    if (tid == 0 && finish)
-    {
-        sh[kSlotBeta] = sqrt(sh[kSlotBeta2]);  // ArnoldiOp.h:152-155: plain sqrt(sum x^2)
-        double err = 0.0;
-        for (int j = 0; j < ncol; j++)
-            err = fmax(err, fabs(sh[j]));
-        sh[kSlotErr] = err;  // Lanczos.h:153 cwiseAbs().maxCoeff()
-    }
+    if (tid == 0)
+        finish_record(sh, ncol, fin);
     __syncthreads();
     if (tid < kPartialLd)
         red[tid] = sh[tid];
 }
 
-__global__ void k_finish(double* red, int ncol)
+__global__ void k_finish(double* red, int ncol, FinishArgs fin)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0)
-    {
-        red[kSlotBeta] = sqrt(red[kSlotBeta2]);
-        double err = 0.0;
-        for (int j = 0; j < ncol; j++)
-            err = fmax(err, fabs(red[j]));
-        red[kSlotErr] = err;
-    }
+        finish_record(red, ncol, fin);
 }
 
 __global__ __launch_bounds__(1024) void k_reduce_sum(const double* __restrict__ in, int64_t count, double* __restrict__ out)
@@ -285,6 +327,33 @@ __global__ __launch_bounds__(kThreads) void k_scale(const double* __restrict__ s
         double2 v = reinterpret_cast<const double2*>(src)[i];
         v.x = v.x / divisor;  // the reference divides (Lanczos.h:106 `f / beta`), it does not multiply by 1/beta
         v.y = v.y / divisor;
+        reinterpret_cast<double2*>(dst)[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_scale_step(const double* __restrict__ src, double* __restrict__ dst,
+                                                          int64_t npairs, StepState* st, int step, double eps_sqrt)
+{
+    if (st->status != kStepOk)
+        return;
+    const double beta = st->beta;
+    if (beta < eps_sqrt)  // includes beta < near_0: Lanczos.h:99 and :107-113 are resolved on the host path
+    {
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+        {
+            st->status = kStepSmallBeta;
+            st->stop_step = step;
+            st->stop_count = 0;
+        }
+        return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        st->subd[step - 1] = beta;  // Lanczos.h:127-128
+    for (int64_t i = int64_t(blockIdx.x) * kThreads + threadIdx.x; i < npairs; i += int64_t(gridDim.x) * kThreads)
+    {
+        double2 v = reinterpret_cast<const double2*>(src)[i];
+        v.x = v.x / beta;
+        v.y = v.y / beta;
         reinterpret_cast<double2*>(dst)[i] = v;
     }
 }
@@ -606,16 +675,24 @@ int launch_orth(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a)
 }
 
 void launch_reduce_partials(const mispec_ctx& ctx, const double* partials, int64_t pstride, int nrec, int ncol, double* red,
-                            bool finish)
+                            const FinishArgs& fin)
 {
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx.stream, partials, pstride, nrec, ncol, red,
-                       finish ? 1 : 0);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx.stream, partials, pstride, nrec, ncol, red, fin);
     MISPEC_HIP(hipGetLastError());
 }
 
-void launch_finish(const mispec_ctx& ctx, double* red, int ncol)
+void launch_finish(const mispec_ctx& ctx, double* red, int ncol, const FinishArgs& fin)
 {
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, ctx.stream, red, ncol);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, ctx.stream, red, ncol, fin);
+    MISPEC_HIP(hipGetLastError());
+}
+
+void launch_scale_step(const mispec_ctx& ctx, const double* src, double* dst, int64_t npad, StepState* st, int step,
+                       double eps_sqrt)
+{
+    const int64_t npairs = npad / 2;
+    const int grid = persistent_grid(ctx, (npairs + kThreads - 1) / kThreads, 8);
+    hipLaunchKernelGGL(k_scale_step, dim3(unsigned(grid)), dim3(kThreads), 0, ctx.stream, src, dst, npairs, st, step, eps_sqrt);
     MISPEC_HIP(hipGetLastError());
 }
 

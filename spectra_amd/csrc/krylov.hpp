@@ -22,6 +22,49 @@ enum OrthMode
     ORTH_CORRECT_ONLY = 3  // dst = src - V c_in ; |dst|^2              (Arnoldi.h:254-255)
 };
 
+// Device-resident bookkeeping of the Lanczos recurrence, so that a whole factorize_from(k, m) can be
+// enqueued without the host reading anything back: every kernel of a step looks at `status` (and the
+// correction kernels at `need_corr`) and turns into a no-op once the fast path has to stop.
+struct StepState
+{
+    double beta;   // |f| after the last completed reduction
+    double alpha;  // H(i,i) before corrections
+    double err;    // max |V'f|
+    int count;     // corrections applied in the current step (Lanczos.h:155)
+    int need_corr; // the while-condition of Lanczos.h:156 for the next correction
+    int status;    // kStepOk or the reason the device path stopped
+    int stop_step; // step at which it stopped
+    int stop_count;
+    int pad_;
+    double diag[kMaxOrthCols];  // H(i,i)
+    double subd[kMaxOrthCols];  // H(i+1,i)
+};
+enum
+{
+    kStepOk = 0,
+    kStepSmallBeta = 1,  // beta < sqrt(eps) at the start of a step: the reference's restart heuristics run on the host path
+    kStepMoreCorr = 2,   // a third correction is needed: continue the loop on the host path
+    kStepTinyF = 3       // beta < eps*sqrt(n) inside the loop (Lanczos.h:163-168): host zeroes f
+};
+enum
+{
+    kFinishNone = 0,
+    kFinishNorms = 1,      // beta = sqrt(sum f^2), err = max|c|
+    kFinishStepFirst = 2,  // + bookkeeping after f = w - alpha v (Lanczos.h:142-153)
+    kFinishStepCorr = 3    // + bookkeeping after one correction (Lanczos.h:171-180)
+};
+struct FinishArgs
+{
+    int mode = kFinishNorms;
+    StepState* st = nullptr;
+    int step = 0;
+    const double* alpha_src = nullptr;  // first: device scalar <v, w>
+    const double* prev_red = nullptr;   // corr: the coefficients the correction used (H(i-1,i) += c[i-1], H(i,i) += c[i])
+    double eps = 0.0;
+    double beta_thresh = 0.0;
+    int max_spec = 2;  // corrections that are enqueued speculatively per step
+};
+
 struct OrthArgs
 {
     const double* V = nullptr;  // basis, column-major
@@ -35,18 +78,24 @@ struct OrthArgs
     const double* c_in = nullptr;       // CORRECT: device coefficients [ncol]
     double* partials = nullptr;         // slot-major: partials[slot * pstride + workgroup]
     int64_t pstride = 0;                // >= number of workgroups of any launch
+    const int* status = nullptr;        // optional predicate: run only while *status == kStepOk ...
+    const int* need_corr = nullptr;     // ... and (if given) *need_corr != 0
 };
 
 // All launchers enqueue on ctx.stream and return immediately.
 int launch_orth(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a);  // returns the number of partial records
 // red[0..kPartialLd): column sums of the records (+ max for kSlotMaxAbs); finish additionally fills kSlotBeta / kSlotErr.
 void launch_reduce_partials(const mispec_ctx& ctx, const double* partials, int64_t pstride, int nrec, int ncol, double* red,
-                            bool finish);
-void launch_finish(const mispec_ctx& ctx, double* red, int ncol);
+                            const FinishArgs& fin);
+void launch_finish(const mispec_ctx& ctx, double* red, int ncol, const FinishArgs& fin);
 // out[0] = sum of `count` doubles (SpMV alpha partials), fixed order
 void launch_reduce_sum(const mispec_ctx& ctx, const double* in, int64_t count, double* out);
 // dst = src / divisor over npad elements (v = f / beta, Lanczos.h:106)
 void launch_scale(const mispec_ctx& ctx, const double* src, double* dst, int64_t npad, double divisor);
+// Step start on the device path: if st->beta < eps_sqrt stop (kStepSmallBeta); else dst = src / st->beta and
+// st->subd[step-1] = st->beta (Lanczos.h:99-128 without the restart branch)
+void launch_scale_step(const mispec_ctx& ctx, const double* src, double* dst, int64_t npad, StepState* st, int step,
+                       double eps_sqrt);
 // f = f*a + v*b, partial |f|^2 records (Arnoldi.h:337-339); returns the number of records
 int launch_axpby(const mispec_ctx& ctx, double* f, double a, const double* v, double b, int64_t n, double* partials,
                  int64_t pstride);

@@ -205,3 +205,25 @@ def test_full_size_c2_residuals(ctx):
         out.append((eigs.eigenvalues(), eigs.num_operations(), eigs.num_iterations()))
     assert np.array_equal(out[0][0], out[1][0]) and out[0][1:] == out[1][1:]
     assert np.all(np.diff(out[0][0]) <= 0) and np.abs(out[0][0]).min() > 2.0
+
+
+def test_device_driven_steps_equal_host_driven_steps():
+    # The device-driven factorisation (no host read-back inside factorize_from) must take exactly the decisions
+    # the host-synchronous path takes: same kernels, same order => bit-identical results and counters.
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); import spectra_amd as sa\n"
+        "op = sa.SparseSymMatProd.synth_band(300000)\n"
+        "e = sa.SymEigsSolver(op, 12, 30); e.init(); n = e.compute(sa.SortRule.LargestMagn, 1000, 1e-11)\n"
+        "print(n, e.num_operations(), e.num_iterations(), e.eigenvalues().tobytes().hex(), e.get_profile()['n_host_sync'])\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for host in ("0", "1"):
+        env = dict(os.environ, MISPEC_HOST_STEPS=host)
+        r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        outs.append(r.stdout.split())
+    assert outs[0][:4] == outs[1][:4]
+    assert float(outs[0][4]) < 0.25 * float(outs[1][4])  # and with far fewer host synchronisations
