@@ -33,6 +33,12 @@ template <typename T>
 struct has_device_matrix<T, std::void_t<decltype(std::declval<const T&>().mispec_matrix())>> : std::true_type
 {};
 template <typename T, typename = void>
+struct has_device_solver : std::false_type
+{};
+template <typename T>
+struct has_device_solver<T, std::void_t<decltype(std::declval<const T&>().mispec_solver())>> : std::true_type
+{};
+template <typename T, typename = void>
 struct has_device_context : std::false_type
 {};
 template <typename T>
@@ -92,7 +98,17 @@ protected:
         m_fac = std::shared_ptr<mispec_fac>(raw, [](mispec_fac* p) { (void) mispec_fac_destroy(p); });
     }
     template <typename T = OpType>
-    typename std::enable_if<!internal::has_device_matrix<T>::value>::type bind(bool symmetric)
+    typename std::enable_if<internal::has_device_solver<T>::value>::type bind(bool symmetric)
+    {
+        m_ctx = internal::borrow_context(m_op.mispec_context());
+        mispec_fac* raw = nullptr;
+        internal::check(
+            mispec_fac_create_shiftsolve(m_ctx.get(), m_op.mispec_solver(), static_cast<int>(m_m), symmetric ? 1 : 0, &raw));
+        m_fac = std::shared_ptr<mispec_fac>(raw, [](mispec_fac* p) { (void) mispec_fac_destroy(p); });
+    }
+    template <typename T = OpType>
+    typename std::enable_if<!internal::has_device_matrix<T>::value && !internal::has_device_solver<T>::value>::type bind(
+        bool symmetric)
     {
         m_ctx = internal::context_of(m_op);
         mispec_fac* raw = nullptr;

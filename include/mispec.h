@@ -127,6 +127,24 @@ int mispec_spmm_host(const mispec_csr* A, const double* X_host, int64_t ldx, int
 int mispec_spmv_time(const mispec_csr* A, const double* x_dev, double* y_dev, int reps, float* ms_per_launch);
 
 /* ---------------------------------------------------------------------------
+ * Shift-and-invert operator  y = (A - sigma I)^{-1} x  for symmetric A — replaces SparseSymShiftSolve
+ * (MatOp/SparseSymShiftSolve.h:36-111, which delegates to Eigen::SparseLU).  The factorisation is redone
+ * by set_shift (host, once per shift); every solve runs on the device: a recursive partitioned banded
+ * LDL' when the half-bandwidth is <= 32, a dense inverse + GEMV when n <= 4096 (the reference's own test
+ * fixtures); other sparsity patterns are rejected (MISPEC_EINVAL).  Input: one triangle of a compressed
+ * matrix, as for mispec_csr_from_triangle.
+ * ------------------------------------------------------------------------- */
+typedef struct mispec_symshift mispec_symshift;
+int mispec_symshift_create(mispec_ctx* ctx, int64_t n, const int32_t* outer_host, const int32_t* inner_host,
+                           const double* val_host, char uplo, int row_major, mispec_symshift** out);
+int mispec_symshift_destroy(mispec_symshift* S);
+int64_t mispec_symshift_rows(const mispec_symshift* S);
+/* set_shift(sigma) (SparseSymShiftSolve.h:85-95): MISPEC_EINVAL "factorization failed with the given shift" on breakdown */
+int mispec_symshift_set_shift(mispec_symshift* S, double sigma);
+int mispec_symshift_solve(const mispec_symshift* S, const double* x_dev, double* y_dev);        /* device pointers */
+int mispec_symshift_solve_host(const mispec_symshift* S, const double* x_host, double* y_host); /* literal perform_op */
+
+/* ---------------------------------------------------------------------------
  * Factorisation A V = V H + f e' kept in HBM — replaces LinAlg/Arnoldi.h + LinAlg/Lanczos.h.
  * V is local_rows x ncv column-major, H is ncv x ncv (host copy is authoritative), f is local_rows.
  * ------------------------------------------------------------------------- */
@@ -138,6 +156,8 @@ typedef int (*mispec_op_fn)(void* user, const double* x_in_host, double* y_out_h
  * symmetric=0: Arnoldi (Arnoldi.h). */
 int mispec_fac_create(mispec_ctx* ctx, const mispec_csr* A, mispec_op_fn op, void* op_user, int64_t n, int ncv,
                       int symmetric, mispec_fac** out);
+/* The same with the operator (A - sigma I)^{-1} of a device-resident shift solver (SymEigsShiftSolver path). */
+int mispec_fac_create_shiftsolve(mispec_ctx* ctx, const mispec_symshift* S, int ncv, int symmetric, mispec_fac** out);
 int mispec_fac_destroy(mispec_fac* fac);
 /* Arnoldi::init (Arnoldi.h:136-195).  v0_host: n doubles (the GLOBAL vector; each shard takes its rows).
  * *nmatop is incremented once per operator application, like op_counter. */
@@ -210,6 +230,9 @@ typedef struct mispec_symeigs mispec_symeigs;
 int mispec_symeigs_create(mispec_ctx* ctx, const mispec_csr* A, int64_t nev, int64_t ncv, mispec_symeigs** out);
 int mispec_symeigs_create_op(mispec_ctx* ctx, mispec_op_fn op, void* op_user, int64_t n, int64_t nev, int64_t ncv,
                              mispec_symeigs** out);
+/* Spectra::SymEigsShiftSolver<Spectra::SparseSymShiftSolve<double>> (SymEigsShiftSolver.h:190-195): calls
+ * set_shift(sigma) on S, iterates on (A - sigma I)^{-1} and maps the Ritz values back (lambda = 1/nu + sigma). */
+int mispec_symeigs_create_shift(mispec_ctx* ctx, mispec_symshift* S, int64_t nev, int64_t ncv, double sigma, mispec_symeigs** out);
 int mispec_symeigs_destroy(mispec_symeigs* s);
 int mispec_symeigs_init(mispec_symeigs* s, const double* v0_host /* NULL = init() */);
 int mispec_symeigs_compute(mispec_symeigs* s, int selection, int64_t maxit, double tol, int sorting, int64_t* nconv);

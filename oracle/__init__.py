@@ -63,6 +63,7 @@ def lib():
             "oracle_op_dense_sym": (vp, [C.c_long, dp]),
             "oracle_op_dense_gen": (vp, [C.c_long, dp]),
             "oracle_op_diag": (vp, [C.c_long, dp]),
+            "oracle_op_callback": (vp, [C.c_long, C.CFUNCTYPE(None, dp, dp)]),
             "oracle_op_free": (None, [vp]),
             "oracle_op_rows": (C.c_long, [vp]),
             "oracle_op_apply": (None, [vp, dp, dp]),
@@ -249,6 +250,15 @@ class Op:
     def dense_gen(cls, A):
         A = np.asfortranarray(A, dtype=np.float64)
         return cls(lib().oracle_op_dense_gen(A.shape[0], _dp(A)), A.shape[0])
+
+    @classmethod
+    def callback(cls, n, fn):
+        """fn(x: ndarray) -> ndarray; e.g. a scipy LU solve standing in for Eigen::SparseLU (SparseSymShiftSolve.h:104-109)."""
+        def tramp(xp, yp):
+            x = np.ctypeslib.as_array(xp, shape=(n,))
+            np.ctypeslib.as_array(yp, shape=(n,))[:] = fn(x)
+        cb = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double))(tramp)
+        return cls(lib().oracle_op_callback(n, cb), n, keep=(cb,))
 
     @classmethod
     def diag(cls, d):

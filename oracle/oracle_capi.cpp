@@ -217,6 +217,13 @@ void* oracle_op_diag(long n, const double* d)
             y[i] = x[i] * dv[i];
     });
 }
+// operator given as a C callback (tests: a scipy factorisation playing the role of Eigen::SparseLU in
+// MatOp/SparseSymShiftSolve.h:104-109)
+typedef void (*oracle_op_cb)(const double* x, double* y);
+void* oracle_op_callback(long n, oracle_op_cb cb)
+{
+    return new CallbackOp(n, [cb](const double* x, double* y) { cb(x, y); });
+}
 void oracle_op_free(void* op) { delete static_cast<Op*>(op); }
 long oracle_op_rows(void* op) { return static_cast<Op*>(op)->rows(); }
 void oracle_op_apply(void* op, const double* x, double* y) { static_cast<Op*>(op)->perform_op(x, y); }

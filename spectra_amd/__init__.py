@@ -16,7 +16,8 @@ import numpy as np
 from . import _capi
 from ._capi import MispecError, Profile, build_library, check, lib
 
-__all__ = ["SortRule", "CompInfo", "Context", "SparseSymMatProd", "SparseGenMatProd", "SymEigsSolver", "GenEigsSolver",
+__all__ = ["SortRule", "CompInfo", "Context", "SparseSymMatProd", "SparseGenMatProd", "SparseSymShiftSolve", "SymEigsSolver",
+           "SymEigsShiftSolver", "GenEigsSolver",
            "Factorization", "tridiag_qr", "tridiag_eigen", "hess_qr", "double_shift_qr", "hess_schur", "hess_eigen", "MispecError", "build_library", "shard_range", "BAND_OFFSETS", "SYNTH_SEED"]
 
 BAND_OFFSETS = (1, 2, 3, 1000, 1001, 100000, 100001)  # SURVEY.md §8(d) "M-band": 15 nnz/row with the diagonal
@@ -249,6 +250,47 @@ def _synth(cls, n, offsets, seed, symmetric, ctx):
     return obj
 
 
+class SparseSymShiftSolve:
+    """MatOp/SparseSymShiftSolve.h: y = (A - sigma I)^{-1} x, solved on the GPU after set_shift(sigma)."""
+
+    def __init__(self, mat, uplo="L", ctx=None):
+        self.ctx = ctx or default_context()
+        n, nc, outer, inner, val, row_major = _compressed(mat)
+        if n != nc:
+            raise ValueError("SparseSymShiftSolve: matrix must be square")
+        h = C.c_void_p()
+        check(lib().mispec_symshift_create(self.ctx.h, n, _ip(outer), _ip(inner), _dp(val), uplo.encode()[0:1], int(row_major),
+                                           C.byref(h)))
+        self.h = h
+        self.n = n
+
+    def rows(self):
+        return self.n
+
+    def cols(self):
+        return self.n
+
+    def local_rows(self):
+        return self.n
+
+    def set_shift(self, sigma):
+        check(lib().mispec_symshift_set_shift(self.h, float(sigma)))
+
+    def perform_op(self, x_in):
+        x = _f64(x_in)
+        if x.shape != (self.n,):
+            raise ValueError("perform_op: x_in must have n entries")
+        y = np.empty(self.n)
+        check(lib().mispec_symshift_solve_host(self.h, _dp(x), _dp(y)))
+        return y
+
+    def __del__(self):
+        try:
+            lib().mispec_symshift_destroy(self.h)
+        except Exception:
+            pass
+
+
 class _UserOp:
     """Adapter for a Python operator with rows(), cols(), perform_op(x_in) -> y (host numpy arrays)."""
 
@@ -346,6 +388,23 @@ class SymEigsSolver:
             lib().mispec_symeigs_destroy(self.h)
         except Exception:
             pass
+
+
+class SymEigsShiftSolver(SymEigsSolver):
+    """SymEigsShiftSolver.h:190-195: eigenvalues closest to sigma via (A - sigma I)^{-1}; the constructor calls
+    op.set_shift(sigma) and eigenvalues() are mapped back (lambda = 1/nu + sigma)."""
+
+    def __init__(self, op, nev, ncv, sigma, ctx=None):
+        if isinstance(op, SparseSymShiftSolve):
+            self.op = op
+            self.ctx = op.ctx
+            self._user = None
+            h = C.c_void_p()
+            check(lib().mispec_symeigs_create_shift(self.ctx.h, op.h, int(nev), int(ncv), float(sigma), C.byref(h)))
+            self.h = h
+            self.nev, self.ncv = int(nev), int(ncv)
+        else:
+            raise TypeError("SymEigsShiftSolver: pass a SparseSymShiftSolve operator")
 
 
 class GenEigsSolver:

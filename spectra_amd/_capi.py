@@ -84,7 +84,14 @@ SIGNATURES = {
     "mispec_spmv_host": (C.c_int, [_vp, _dp, _dp]),
     "mispec_spmm_host": (C.c_int, [_vp, _dp, C.c_int64, C.c_int, _dp, C.c_int64]),
     "mispec_spmv_time": (C.c_int, [_vp, _vp, _vp, C.c_int, C.POINTER(C.c_float)]),
+    "mispec_symshift_create": (C.c_int, [_vp, C.c_int64, _ip, _ip, _dp, C.c_char, C.c_int, _vpp]),
+    "mispec_symshift_destroy": (C.c_int, [_vp]),
+    "mispec_symshift_rows": (C.c_int64, [_vp]),
+    "mispec_symshift_set_shift": (C.c_int, [_vp, C.c_double]),
+    "mispec_symshift_solve": (C.c_int, [_vp, _vp, _vp]),
+    "mispec_symshift_solve_host": (C.c_int, [_vp, _dp, _dp]),
     "mispec_fac_create": (C.c_int, [_vp, _vp, op_fn, _vp, C.c_int64, C.c_int, C.c_int, _vpp]),
+    "mispec_fac_create_shiftsolve": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vpp]),
     "mispec_fac_destroy": (C.c_int, [_vp]),
     "mispec_fac_init": (C.c_int, [_vp, _dp, _lp]),
     "mispec_fac_init_random": (C.c_int, [_vp, C.c_uint64, _lp]),
@@ -109,6 +116,7 @@ SIGNATURES = {
     "mispec_tridiag_eigen": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
     "mispec_symeigs_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vpp]),
     "mispec_symeigs_create_op": (C.c_int, [_vp, op_fn, _vp, C.c_int64, C.c_int64, C.c_int64, _vpp]),
+    "mispec_symeigs_create_shift": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_double, _vpp]),
     "mispec_symeigs_destroy": (C.c_int, [_vp]),
     "mispec_symeigs_init": (C.c_int, [_vp, _dp]),
     "mispec_symeigs_compute": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_double, C.c_int, _lp]),

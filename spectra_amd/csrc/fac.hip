@@ -14,6 +14,7 @@
 //     same H because all reductions end in an all-reduce.
 #include "csr.hpp"
 #include "krylov.hpp"
+#include "shiftsolve.hpp"
 #include "small.hpp"
 
 #include <cmath>
@@ -42,6 +43,7 @@ struct mispec_fac
 {
     mispec_ctx* ctx = nullptr;
     const mispec_csr* A = nullptr;
+    const mispec_symshift* S = nullptr;  // operator = (A - sigma I)^{-1} on the device
     mispec_op_fn op = nullptr;
     void* op_user = nullptr;
     int64_t n = 0;     // global dimension
@@ -216,6 +218,13 @@ void apply_op(mispec_fac& F, const double* x_loc, double* y_loc, bool lanczos_ep
         }
         else
             launch_spmv(*F.A, x, y_loc, nullptr);
+    }
+    else if (F.S)
+    {
+        Timed t(F, FAM_SPMV);
+        launch_shiftsolve(*F.S, x_loc, y_loc);
+        if (lanczos_epi)
+            launch_lanczos_epilogue(*F.ctx, y_loc, x_loc, v_prev, h_prev, F.nloc, F.alpha_partials.p);
     }
     else
     {
@@ -699,12 +708,13 @@ void update_f_after_compress(mispec_fac& F, double q_last, double h_sub)
 // =================================================================================================
 // C ABI
 // =================================================================================================
-extern "C" int mispec_fac_create(mispec_ctx* ctx, const mispec_csr* A, mispec_op_fn op, void* op_user, int64_t n, int ncv,
-                                 int symmetric, mispec_fac** out)
+namespace {
+int fac_create_impl(mispec_ctx* ctx, const mispec_csr* A, const mispec_symshift* S, mispec_op_fn op, void* op_user, int64_t n,
+                    int ncv, int symmetric, mispec_fac** out)
 {
     return guarded([&] {
         MISPEC_REQUIRE(ctx && out, "mispec_fac_create: NULL argument");
-        MISPEC_REQUIRE((A != nullptr) != (op != nullptr), "mispec_fac_create: give exactly one of A / op");
+        MISPEC_REQUIRE(int(A != nullptr) + int(S != nullptr) + int(op != nullptr) == 1, "mispec_fac_create: give exactly one operator");
         MISPEC_REQUIRE(n >= 1, "mispec_fac_create: n must be positive");
         MISPEC_REQUIRE(ncv >= 1 && ncv <= n, "mispec_fac_create: need 1 <= ncv <= n");
         MISPEC_REQUIRE(ncv <= kMaxOrthCols, "mispec_fac_create: the device factorisation holds at most 64 basis vectors (ncv <= 64)");
@@ -714,13 +724,17 @@ extern "C" int mispec_fac_create(mispec_ctx* ctx, const mispec_csr* A, mispec_op
             MISPEC_REQUIRE(A->n_rows == n && A->n_cols == n, "mispec_fac_create: operator must be square of size n");
         }
         else
-            MISPEC_REQUIRE(ctx->comm.allgather == nullptr, "mispec_fac_create: user operators (host perform_op) cannot be row-sharded");
+            MISPEC_REQUIRE(ctx->comm.allgather == nullptr,
+                           "mispec_fac_create: user operators and shift solvers cannot be row-sharded");
+        if (S)
+            MISPEC_REQUIRE(S->ctx == ctx && S->n == n, "mispec_fac_create: shift solver belongs to another context / size");
         ctx->make_current();
         auto* F = new mispec_fac();
         try
         {
             F->ctx = ctx;
             F->A = A;
+            F->S = S;
             F->op = op;
             F->op_user = op_user;
             F->n = n;
@@ -782,6 +796,23 @@ extern "C" int mispec_fac_create(mispec_ctx* ctx, const mispec_csr* A, mispec_op
         }
         *out = F;
     });
+}
+}  // namespace
+
+extern "C" int mispec_fac_create(mispec_ctx* ctx, const mispec_csr* A, mispec_op_fn op, void* op_user, int64_t n, int ncv,
+                                 int symmetric, mispec_fac** out)
+{
+    return fac_create_impl(ctx, A, nullptr, op, op_user, n, ncv, symmetric, out);
+}
+
+extern "C" int mispec_fac_create_shiftsolve(mispec_ctx* ctx, const mispec_symshift* S, int ncv, int symmetric, mispec_fac** out)
+{
+    if (!S)
+    {
+        set_last_error("mispec_fac_create_shiftsolve: NULL solver");
+        return MISPEC_EINVAL;
+    }
+    return fac_create_impl(ctx, nullptr, S, nullptr, nullptr, S->n, ncv, symmetric, out);
 }
 
 extern "C" int mispec_fac_destroy(mispec_fac* fac)

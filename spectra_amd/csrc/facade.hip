@@ -7,6 +7,7 @@
 #include <Spectra/LinAlg/UpperHessenbergEigen.h>
 #include <Spectra/LinAlg/UpperHessenbergQR.h>
 #include <Spectra/LinAlg/UpperHessenbergSchur.h>
+#include <Spectra/SymEigsShiftSolver.h>
 #include <Spectra/SymEigsSolver.h>
 
 #include <cstring>
@@ -43,6 +44,8 @@ public:
 using DevOp = Spectra::SparseSymMatProd<double>;
 using DevSolver = Spectra::SymEigsSolver<DevOp>;
 using CbSolver = Spectra::SymEigsSolver<CallbackOp>;
+using ShiftOp = Spectra::SparseSymShiftSolve<double>;
+using ShiftSolver = Spectra::SymEigsShiftSolver<ShiftOp>;
 
 }  // namespace
 
@@ -51,14 +54,21 @@ struct mispec_symeigs
     mispec_ctx* ctx = nullptr;
     std::unique_ptr<DevOp> dev_op;
     std::unique_ptr<CallbackOp> cb_op;
+    std::unique_ptr<ShiftOp> shift_op;
     std::unique_ptr<DevSolver> dev;
     std::unique_ptr<CbSolver> cb;
+    std::unique_ptr<ShiftSolver> shift;
     int64_t nev = 0;
 
     template <typename F>
     auto visit(F&& f) const
     {
-        return dev ? f(*dev) : f(*cb);
+        // the three solver types share HermEigsBase's interface; go through the common base where possible
+        if (dev)
+            return f(*dev);
+        if (shift)
+            return f(*shift);
+        return f(*cb);
     }
     mispec_fac* fac() const
     {
@@ -89,6 +99,20 @@ extern "C" int mispec_symeigs_create_op(mispec_ctx* ctx, mispec_op_fn op, void* 
         s->nev = nev;
         s->cb_op = std::make_unique<CallbackOp>(ctx, op, op_user, n);
         s->cb = std::make_unique<CbSolver>(*s->cb_op, nev, ncv);
+        *out = s.release();
+    });
+}
+
+extern "C" int mispec_symeigs_create_shift(mispec_ctx* ctx, mispec_symshift* S, int64_t nev, int64_t ncv, double sigma,
+                                           mispec_symeigs** out)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(ctx && S && out, "mispec_symeigs_create_shift: NULL argument");
+        auto s = std::make_unique<mispec_symeigs>();
+        s->ctx = ctx;
+        s->nev = nev;
+        s->shift_op = std::make_unique<ShiftOp>(ctx, S);
+        s->shift = std::make_unique<ShiftSolver>(*s->shift_op, nev, ncv, sigma);
         *out = s.release();
     });
 }

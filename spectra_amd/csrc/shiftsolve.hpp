@@ -1,0 +1,33 @@
+// Shift-and-invert operator y = (A - sigma I)^{-1} x held on the device (shiftsolve.hip).
+#pragma once
+#include <memory>
+
+#include "common.hpp"
+
+namespace mispec {
+struct BandLevel;
+constexpr int64_t kMaxBandwidth = 32;  // banded path: half-bandwidth of A - sigma I
+constexpr int64_t kMaxDense = 4096;    // dense path: matrix dimension
+}  // namespace mispec
+
+struct mispec_symshift
+{
+    mispec_ctx* ctx = nullptr;
+    int64_t n = 0;
+    // the selected triangle of A as (row >= col) triplets, host memory (the factorisation is redone per shift)
+    std::vector<int64_t> rows, cols;
+    std::vector<double> vals;
+    int64_t half_bandwidth = 0;
+    double sigma = 0.0;
+    bool factored = false;
+    bool dense = false;
+    std::unique_ptr<mispec::BandLevel> top;  // banded path
+    mispec::DevBuf<double> inverse;          // dense path: (A - sigma I)^{-1}, n x n column-major
+    mutable mispec::DevBuf<double> stage_x, stage_y;
+    ~mispec_symshift();
+};
+
+namespace mispec {
+// y = (A - sigma I)^{-1} x, device pointers of n doubles, enqueued on the context stream
+void launch_shiftsolve(const mispec_symshift& S, const double* x_dev, double* y_dev);
+}  // namespace mispec

@@ -1,0 +1,113 @@
+"""a20 — SymEigsShiftSolver + SparseSymShiftSolve (shift-and-invert, solve on the GPU) vs the oracle and the
+reference's tests (test/SymEigsShift.cpp:44-185, test/Example1.cpp:70-98), and config 5 (2M x 2M banded, k = 6)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+import oracle as O
+import spectra_amd as sa
+from helpers import RULES_SYM, cycle_laplacian, sparse_fixture
+
+pytestmark = pytest.mark.gpu
+
+SHIFT_CASES = [(10, 0.5, 3, 6, 1.0), (100, 0.1, 10, 20, 10.0), (1000, 0.01, 20, 50, 100.0)]  # test/SymEigsShift.cpp:148-185
+
+
+def banded_spd(n, b, seed=0):
+    rng = np.random.default_rng(seed)
+    diags = [rng.uniform(-0.5, 0.5, n - d) for d in range(1, b + 1)]
+    A = sp.diags([rng.uniform(-0.5, 0.5, n) + b + 0.5] + diags + diags, [0] + list(range(1, b + 1)) + [-d for d in range(1, b + 1)],
+                 format="csc")
+    return A
+
+
+@pytest.mark.parametrize("n,b", [(50, 1), (1000, 3), (5000, 2), (100_000, 3), (300_001, 5), (20_000, 16)])
+def test_banded_solve_matches_sparse_lu(ctx, n, b):
+    A = banded_spd(n, b, seed=n)
+    op = sa.SparseSymShiftSolve(sp.tril(A).tocsc(), ctx=ctx)
+    for sigma in (0.0, -1.5):
+        op.set_shift(sigma)
+        lu = spla.splu((A - sigma * sp.identity(n)).tocsc())
+        x = np.random.default_rng(1).uniform(-1, 1, n)
+        y = op.perform_op(x)
+        ref = lu.solve(x)
+        assert np.abs(y - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+        assert np.linalg.norm((A - sigma * sp.identity(n)) @ y - x) <= 1e-12 * np.linalg.norm(x)   # SURVEY §8f bar
+
+
+def test_dense_path_and_failures(ctx):
+    A, S = sparse_fixture(100, 0.1)
+    op = sa.SparseSymShiftSolve(A, ctx=ctx)            # random pattern: full bandwidth -> dense inverse
+    with pytest.raises(AssertionError, match="set_shift"):   # std::logic_error: solve before set_shift
+        op.perform_op(np.ones(100))
+    op.set_shift(10.0)
+    x = np.random.default_rng(0).uniform(-1, 1, 100)
+    ref = np.linalg.solve(S.toarray() - 10.0 * np.eye(100), x)
+    assert np.abs(op.perform_op(x) - ref).max() < 1e-13
+    with pytest.raises(ValueError, match="factorization failed"):  # SparseSymShiftSolve.h:93-94
+        sa.SparseSymShiftSolve(sp.identity(50, format="csc") * 2.0, ctx=ctx).set_shift(2.0)
+    big = sp.random(6000, 6000, density=1e-3, random_state=0, format="csc")
+    with pytest.raises(ValueError, match="only banded"):
+        sa.SparseSymShiftSolve(big + big.T, ctx=ctx).set_shift(1.0)
+
+
+@pytest.mark.parametrize("n,prob,k,m,sigma", SHIFT_CASES)
+@pytest.mark.parametrize("rule", RULES_SYM)
+def test_shift_fixtures_all_rules(ctx, n, prob, k, m, sigma, rule):
+    # test/SymEigsShift.cpp: maxit = 500; SmallestMagn is allow_fail (:100)
+    A, S = sparse_fixture(n, prob)
+    op = sa.SparseSymShiftSolve(A, ctx=ctx)
+    eigs = sa.SymEigsShiftSolver(op, k, m, sigma)
+    eigs.init()
+    nconv = eigs.compute(sa.SortRule[rule], 500)
+    lu = spla.splu((S - sigma * sp.identity(n)).tocsc())
+    ref = O.SymEigsSolver(O.Op.callback(n, lu.solve), k, m, sigma=sigma)
+    ref.init()
+    o_nconv = ref.compute(getattr(O, rule), 500)
+    if eigs.info() != sa.CompInfo.Successful:
+        assert rule == "SmallestMagn" and ref.info() != O.Successful
+        return
+    assert nconv == k == o_nconv
+    evals, evecs = eigs.eigenvalues(), eigs.eigenvectors()
+    assert np.abs(S @ evecs - evecs * evals).max() < 1e-9           # test/SymEigsShift.cpp:72-76
+    assert np.abs(np.sort(evals) - np.sort(ref.eigenvalues())).max() < 1e-9
+    assert np.all(np.diff(evals) <= 0)
+
+
+@pytest.mark.parametrize("k,m", [(3, 6), (5, 12), (6, 12)])
+def test_example1_smallest_by_shift_invert(ctx, k, m):
+    # test/Example1.cpp:70-98: cycle Laplacian n = 20, sigma = -1e-6, tol 1e-15, SmallestAlge ordering
+    M = cycle_laplacian(20)
+    true = np.sort(1.0 - np.cos(2 * np.pi * np.arange(20) / 20))
+    op = sa.SparseSymShiftSolve(sp.csc_matrix(M), ctx=ctx)
+    eigs = sa.SymEigsShiftSolver(op, k, m, -1e-6)
+    eigs.init()
+    nconv = eigs.compute(sa.SortRule.LargestMagn, 1000, 1e-15, sa.SortRule.SmallestAlge)
+    assert eigs.info() == sa.CompInfo.Successful and nconv == k
+    evals, evecs = eigs.eigenvalues(), eigs.eigenvectors()
+    assert np.abs(M @ evecs - evecs * evals).max() < 1e-9 and np.abs(true[:k] - evals).max() < 1e-9
+
+
+@pytest.mark.parametrize("n", [100_000, 2_000_000])
+def test_config5_banded(ctx, n):
+    # BASELINE.json configs[4]: SymEigsShiftSolver, 2M x 2M banded (half-bandwidth 3, definite), sigma = 0, k = 6, ncv = 20:
+    # the 6 eigenvalues closest to 0 (= the smallest ones of a positive definite matrix)
+    A = banded_spd(n, 3, seed=5)
+    op = sa.SparseSymShiftSolve(sp.tril(A).tocsc(), ctx=ctx)
+    eigs = sa.SymEigsShiftSolver(op, 6, 20, 0.0)
+    eigs.init()
+    nconv = eigs.compute(sa.SortRule.LargestMagn, 1000, 1e-11)
+    assert nconv == 6 and eigs.info() == sa.CompInfo.Successful
+    evals, X = eigs.eigenvalues(), eigs.eigenvectors()
+    res = np.linalg.norm(A @ X - X * evals, axis=0) / np.linalg.norm(X, axis=0)
+    assert res.max() <= 1e-10, res
+    if n <= 100_000:
+        ref = np.sort(spla.eigsh(A, k=6, sigma=0.0, which="LM", tol=1e-13)[0])[::-1]
+        assert np.abs(evals - ref).max() < 1e-9
+        lu = spla.splu(A.tocsc())
+        o = O.SymEigsSolver(O.Op.callback(n, lu.solve), 6, 20, sigma=0.0)
+        o.init()
+        assert o.compute(O.LargestMagn, 1000, 1e-11) == 6
+        assert np.abs(o.eigenvalues() - evals).max() < 1e-9
+        assert abs(o.num_operations() - eigs.num_operations()) <= 40
