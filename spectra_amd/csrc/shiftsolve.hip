@@ -2,7 +2,7 @@
 // (replaces MatOp/SparseSymShiftSolve.h:85-109, which delegates to Eigen::SparseLU).
 //
 // Two factorisations, chosen from the half-bandwidth b of A - sigma I at set_shift():
-//   * banded (b <= 32): a recursive "partition + Schur complement" LDL' — the parallel form of a band
+//   * banded (b <= 8): a recursive "partition + Schur complement" LDL' — the parallel form of a band
 //     solve.  The rows are cut into chunks of L rows; the last b rows of every chunk form a separator,
 //     the rest (the interior) of different chunks are decoupled.  Factor (host, once per shift): banded
 //     LDL' of every interior block, the spikes W = M_II^{-1} M_IS, and the Schur complement of the
@@ -52,6 +52,11 @@ struct HostBand
 // ---- kernels ------------------------------------------------------------------------------------------
 // Chunk p owns rows [p*L, min((p+1)*L, N)); its interior is the chunk minus the last b rows (the last chunk
 // has no separator).  Lf(k, d, p) multiplies z_{k-d-1}; everything chunk-interleaved: index (k*b + d)*P + p.
+//
+// One thread per chunk.  The recurrence is sequential in k, so the only latency that may sit on the critical
+// path is the FMA chain itself: the last B unknowns live in registers (never re-read from memory), and the
+// factor entries / right-hand sides of the next U rows are loaded as one batch before they are needed.
+template <int B, int U>
 __global__ __launch_bounds__(kThreads) void k_chunk_solve(int64_t N, int b, int64_t L, int64_t P, const double* __restrict__ Lf,
                                                            const double* __restrict__ Dinv, const double* __restrict__ f,
                                                            double* __restrict__ y)
@@ -61,23 +66,73 @@ __global__ __launch_bounds__(kThreads) void k_chunk_solve(int64_t N, int b, int6
         return;
     const int64_t row0 = p * L;
     const int64_t m = ((p == P - 1) ? N : (row0 + L - b)) - row0;  // interior rows
-    // forward: z_k = f_k - sum_d Lf(k,d) z_{k-d-1};  kept in y
-    for (int64_t k = 0; k < m; k++)
+    double hist[B];                                                // hist[d] = unknown k-d-1 (forward) / k+d+1 (backward)
+#pragma unroll
+    for (int d = 0; d < B; d++)
+        hist[d] = 0.0;
+    // forward: z_k = f_k - sum_d Lf(k,d) z_{k-d-1}
+    for (int64_t k0 = 0; k0 < m; k0 += U)
     {
-        double acc = f[row0 + k];
-        const int dmax = int(k < b ? k : b);
-        for (int d = dmax - 1; d >= 0; d--)  // the most recent unknown (d = 0) enters last
-            acc -= Lf[(k * b + d) * P + p] * y[row0 + k - d - 1];
-        y[row0 + k] = acc;
+        double fk[U], lf[U][B];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+        {
+            const int64_t k = (k0 + u < m) ? k0 + u : m - 1;
+            fk[u] = f[row0 + k];
+#pragma unroll
+            for (int d = 0; d < B; d++)
+                lf[u][d] = (d < b) ? Lf[(k * b + d) * P + p] : 0.0;  // rows k < b hold zeros for the missing neighbours
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+        {
+            if (k0 + u < m)
+            {
+                double acc = fk[u];
+#pragma unroll
+                for (int d = B - 1; d >= 0; d--)  // the most recent unknown (d = 0) enters last
+                    acc -= lf[u][d] * hist[d];
+#pragma unroll
+                for (int d = B - 1; d > 0; d--)
+                    hist[d] = hist[d - 1];
+                hist[0] = acc;
+                y[row0 + k0 + u] = acc;
+            }
+        }
     }
     // diagonal and backward: y_k = z_k / D_k - sum_d Lf(k+d+1, d) y_{k+d+1}
-    for (int64_t k = m - 1; k >= 0; k--)
+#pragma unroll
+    for (int d = 0; d < B; d++)
+        hist[d] = 0.0;
+    for (int64_t k0 = m - 1; k0 >= 0; k0 -= U)
     {
-        double acc = y[row0 + k] * Dinv[k * P + p];
-        const int dmax = int((m - 1 - k) < b ? (m - 1 - k) : b);
-        for (int d = dmax - 1; d >= 0; d--)
-            acc -= Lf[((k + d + 1) * b + d) * P + p] * y[row0 + k + d + 1];
-        y[row0 + k] = acc;
+        double zk[U], di[U], lf[U][B];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+        {
+            const int64_t k = (k0 - u >= 0) ? k0 - u : 0;
+            zk[u] = y[row0 + k];
+            di[u] = Dinv[k * P + p];
+#pragma unroll
+            for (int d = 0; d < B; d++)
+                lf[u][d] = (d < b && k + d + 1 < m) ? Lf[((k + d + 1) * b + d) * P + p] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+        {
+            if (k0 - u >= 0)
+            {
+                double acc = zk[u] * di[u];
+#pragma unroll
+                for (int d = B - 1; d >= 0; d--)
+                    acc -= lf[u][d] * hist[d];
+#pragma unroll
+                for (int d = B - 1; d > 0; d--)
+                    hist[d] = hist[d - 1];
+                hist[0] = acc;
+                y[row0 + k0 - u] = acc;
+            }
+        }
     }
 }
 
@@ -165,13 +220,15 @@ struct mispec::BandLevel
     int64_t N = 0, L = 0, P = 1;
     int b = 0;
     DevBuf<double> Lf, Dinv, W, band, y, g, xs;
+    DevBuf<double> inv;  // last level only: explicit inverse (N x N), applied by a dense GEMV
     std::unique_ptr<BandLevel> next;
 };
 
 namespace {
 
-constexpr int64_t kChunk = 128;       // rows per chunk
-constexpr int64_t kSingleChunk = 768; // a level this small is one chunk (one thread)
+constexpr int64_t kChunk = 128;         // rows per chunk
+constexpr int64_t kSingleChunk = 2048;  // a level this small is not partitioned any further: its inverse is formed
+                                        // explicitly (banded LDL' solves of the unit vectors) and applied as a GEMV
 
 void throw_singular()
 {
@@ -183,6 +240,7 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev)
 {
     const int64_t N = M.n;
     const int b = M.b;
+    MISPEC_REQUIRE(b <= 64, "internal: band wider than the chunk kernel supports");
     lev.N = N;
     lev.b = b;
     int64_t L = std::max<int64_t>(kChunk, 4 * int64_t(b));
@@ -244,7 +302,36 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev)
                 Lf[(size_t(k) * b + d) * P + p] = Lc[size_t(k) * b + d];
         }
         if (P == 1)
+        {
+            // last level: explicit inverse, column by column
+            std::vector<double> inv(size_t(N) * N, 0.0), e(static_cast<size_t>(N));
+            for (int64_t c = 0; c < N; c++)
+            {
+                std::fill(e.begin(), e.end(), 0.0);
+                e[size_t(c)] = 1.0;
+                for (int64_t k = c; k < m; k++)  // forward (zero above c)
+                {
+                    double acc = e[size_t(k)];
+                    const int dk2 = int(std::min<int64_t>(k, b));
+                    for (int d = dk2 - 1; d >= 0; d--)
+                        acc -= Lc[size_t(k) * b + d] * e[size_t(k - d - 1)];
+                    e[size_t(k)] = acc;
+                }
+                for (int64_t k = m - 1; k >= 0; k--)
+                {
+                    double acc = e[size_t(k)] / D[size_t(k)];
+                    const int dk2 = int(std::min<int64_t>(m - 1 - k, b));
+                    for (int d = dk2 - 1; d >= 0; d--)
+                        acc -= Lc[size_t(k + d + 1) * b + d] * e[size_t(k + d + 1)];
+                    e[size_t(k)] = acc;
+                }
+                std::copy(e.begin(), e.end(), inv.begin() + size_t(c) * N);
+            }
+            ctx->make_current();
+            lev.inv.alloc(inv.size());
+            MISPEC_HIP(hipMemcpy(lev.inv.p, inv.data(), inv.size() * sizeof(double), hipMemcpyHostToDevice));
             break;
+        }
         // ---- spikes W = M_II^{-1} M_IS and their contribution to the Schur complement -------------------
         auto solve_block = [&](std::vector<double>& v) {
             for (int64_t k = 0; k < m; k++)
@@ -357,18 +444,38 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev)
     }
 }
 
+void launch_chunk_solve(const mispec_ctx& ctx, const BandLevel& lev, dim3 grid, const double* f, double* y)
+{
+#define MISPEC_CHUNK(B, U)                                                                                                  \
+    hipLaunchKernelGGL((k_chunk_solve<B, U>), grid, dim3(kThreads), 0, ctx.stream, lev.N, lev.b, lev.L, lev.P, lev.Lf.p, \
+                       lev.Dinv.p, f, y)
+    if (lev.b <= 4)
+        MISPEC_CHUNK(4, 8);
+    else if (lev.b <= 8)
+        MISPEC_CHUNK(8, 4);
+    else if (lev.b <= 16)
+        MISPEC_CHUNK(16, 2);
+    else
+        MISPEC_CHUNK(64, 1);
+#undef MISPEC_CHUNK
+    MISPEC_HIP(hipGetLastError());
+}
+
 void solve_level(const mispec_ctx& ctx, const BandLevel& lev, const double* f, double* x)
 {
     const auto blocks = [](int64_t n) { return dim3(unsigned((n + kThreads - 1) / kThreads)); };
     if (lev.P == 1)
     {
-        hipLaunchKernelGGL(k_chunk_solve, dim3(1), dim3(kThreads), 0, ctx.stream, lev.N, lev.b, lev.L, lev.P, lev.Lf.p, lev.Dinv.p, f,
-                           x);
-        MISPEC_HIP(hipGetLastError());
+        if (lev.inv.p)
+        {
+            hipLaunchKernelGGL(k_dense_gemv, blocks(lev.N), dim3(kThreads), 0, ctx.stream, int(lev.N), lev.inv.p, f, x);
+            MISPEC_HIP(hipGetLastError());
+        }
+        else
+            launch_chunk_solve(ctx, lev, dim3(1), f, x);
         return;
     }
-    hipLaunchKernelGGL(k_chunk_solve, blocks(lev.P), dim3(kThreads), 0, ctx.stream, lev.N, lev.b, lev.L, lev.P, lev.Lf.p,
-                       lev.Dinv.p, f, lev.y.p);
+    launch_chunk_solve(ctx, lev, blocks(lev.P), f, lev.y.p);
     hipLaunchKernelGGL(k_sep_rhs, blocks((lev.P - 1) * lev.b), dim3(kThreads), 0, ctx.stream, lev.N, lev.b, lev.L, lev.P,
                        lev.band.p, f, lev.y.p, lev.g.p);
     MISPEC_HIP(hipGetLastError());
@@ -548,7 +655,7 @@ extern "C" int mispec_symshift_set_shift(mispec_symshift* S, double sigma)
         }
         else
             throw Error(MISPEC_EINVAL,
-                        "SparseSymShiftSolve: only banded matrices (half-bandwidth <= 32) or n <= 4096 are supported on the GPU "
+                        "SparseSymShiftSolve: only banded matrices (half-bandwidth <= 8) or n <= 4096 are supported on the GPU "
                         "(the reference uses a general sparse LU)");
         S->factored = true;
     });

@@ -6,7 +6,7 @@
 
 namespace mispec {
 struct BandLevel;
-constexpr int64_t kMaxBandwidth = 32;  // banded path: half-bandwidth of A - sigma I
+constexpr int64_t kMaxBandwidth = 8;   // banded path: half-bandwidth of A - sigma I (the Schur levels widen it to 2b-1 each)
 constexpr int64_t kMaxDense = 4096;    // dense path: matrix dimension
 }  // namespace mispec
 

@@ -4,10 +4,15 @@
 //     g++ -std=c++17 -I include tests/cpp/dropin_symeigs.cpp -L spectra_amd -lmispec -Wl,-rpath,$PWD/spectra_amd
 // It needs a GPU to run (tests/test_gpu_cpp_dropin.py).  Eigen is not available here, so matrices are handed
 // over as Spectra::SparseView and results come back as Spectra::DenseVector / DenseMatrix.
-#include <Spectra/SymEigsSolver.h>
+#include <Spectra/GenEigsSolver.h>
+#include <Spectra/MatOp/SparseGenMatProd.h>
 #include <Spectra/MatOp/SparseSymMatProd.h>
+#include <Spectra/MatOp/SparseSymShiftSolve.h>
+#include <Spectra/SymEigsShiftSolver.h>
+#include <Spectra/SymEigsSolver.h>
 
 #include <cmath>
+#include <complex>
 #include <cstdio>
 #include <random>
 #include <vector>
@@ -114,6 +119,52 @@ static void run_test_sets(const Csc& A, int k, int m)
     }
 }
 
+// test/GenEigs.cpp:38-108 on the same fixture read as a general matrix (complex results)
+static void run_gen_sets(const Csc& A, int k, int m)
+{
+    SparseGenMatProd<double> op(A.view());
+    const SortRule rules[] = {SortRule::LargestMagn, SortRule::LargestReal, SortRule::LargestImag, SortRule::SmallestReal};
+    for (SortRule rule : rules)
+    {
+        GenEigsSolver<SparseGenMatProd<double>> eigs(op, k, m);
+        eigs.init();
+        const int nconv = (int) eigs.compute(rule, 300);
+        REQUIRE(eigs.info() == CompInfo::Successful);
+        const auto evals = eigs.eigenvalues();
+        const auto evecs = eigs.eigenvectors();
+        double err = 0.0;
+        std::vector<std::complex<double>> y(A.n);
+        for (Index c = 0; c < evecs.cols(); c++)
+        {
+            std::fill(y.begin(), y.end(), std::complex<double>(0, 0));
+            for (int j = 0; j < A.n; j++)
+                for (int p = A.colptr[j]; p < A.colptr[j + 1]; p++)
+                    y[A.rowind[p]] += A.val[p] * evecs(j, c);
+            for (int i = 0; i < A.n; i++)
+                err = std::max(err, std::abs(y[i] - evals[c] * evecs(i, c)));
+        }
+        std::printf("gen n=%d rule=%d nconv=%d nops=%d ||AU-UD||_inf=%.3e\n", A.n, (int) rule, nconv, (int) eigs.num_operations(), err);
+        REQUIRE(nconv == k);
+        REQUIRE(err < 1e-9);  // test/GenEigs.cpp:70
+    }
+}
+
+// test/SymEigsShift.cpp: eigenvalues closest to sigma through (A - sigma I)^{-1}
+static void run_shift(const Csc& A, int k, int m, double sigma)
+{
+    SparseSymShiftSolve<double> op(A.view());
+    SymEigsShiftSolver<SparseSymShiftSolve<double>> eigs(op, k, m, sigma);
+    eigs.init();
+    const int nconv = (int) eigs.compute(SortRule::LargestMagn, 500);
+    REQUIRE(eigs.info() == CompInfo::Successful);
+    const auto evals = eigs.eigenvalues();
+    const auto evecs = eigs.eigenvectors();
+    const double err = residual(A, evals, evecs);
+    std::printf("shift n=%d sigma=%g nconv=%d nops=%d ||AU-UD||_inf=%.3e\n", A.n, sigma, nconv, (int) eigs.num_operations(), err);
+    REQUIRE(nconv == k);
+    REQUIRE(err < 1e-9);  // test/SymEigsShift.cpp:76
+}
+
 // The documentation example: a user-supplied operator class (SymEigsSolver.h:99-126)
 class MyDiagonalTen
 {
@@ -145,6 +196,11 @@ int main()
         run_test_sets(gen_sparse_data(10, 0.5), 3, 6);      // test/SymEigs.cpp:133-143
         run_test_sets(gen_sparse_data(100, 0.1), 10, 20);   // :145-155
         run_test_sets(gen_sparse_data(1000, 0.01), 20, 50); // :157-167
+
+        run_gen_sets(gen_sparse_data(100, 0.1), 10, 30);    // test/GenEigs.cpp:154-163
+        run_gen_sets(gen_sparse_data(1000, 0.01), 20, 50);  // :165-174
+        run_shift(gen_sparse_data(100, 0.1), 10, 20, 10.0);     // test/SymEigsShift.cpp:160-171
+        run_shift(gen_sparse_data(1000, 0.01), 20, 50, 100.0);  // :173-185
 
         // constructor argument checks throw std::invalid_argument like the reference (HermEigsBase.h:267-271)
         bool threw = false;

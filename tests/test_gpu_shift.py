@@ -22,7 +22,7 @@ def banded_spd(n, b, seed=0):
     return A
 
 
-@pytest.mark.parametrize("n,b", [(50, 1), (1000, 3), (5000, 2), (100_000, 3), (300_001, 5), (20_000, 16)])
+@pytest.mark.parametrize("n,b", [(50, 1), (1000, 3), (5000, 2), (100_000, 3), (300_001, 5), (200_000, 8), (3000, 16)])
 def test_banded_solve_matches_sparse_lu(ctx, n, b):
     A = banded_spd(n, b, seed=n)
     op = sa.SparseSymShiftSolve(sp.tril(A).tocsc(), ctx=ctx)
