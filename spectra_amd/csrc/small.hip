@@ -6,6 +6,8 @@
 
 #include <Spectra/internal/SmallDense.h>
 
+#include <cstdlib>
+
 using namespace mispec;
 
 namespace {
@@ -69,6 +71,287 @@ __global__ __launch_bounds__(64) void k_restart_sym(int m, double* __restrict__ 
         Qout[idx] = Q[idx];
 }
 
+
+// ===================================================================================================
+// Register-resident variants for m <= 64 (one wavefront, lane i <-> row/entry i).
+//
+// The generic kernels above keep diag / subdiag in LDS, so every step of the scalar recurrences pays LDS
+// round trips on its critical path.  Here lane i holds diag[i] and subdiag[i] in registers; a scalar
+// read is a v_readlane, a scalar write a v_cndmask, the deflation scans are one ballot, and the chain
+// d[k], e[k] -> rotation -> d[k+1], e[k+1] is carried in registers from one rotation to the next.  Only the
+// accumulated Q lives in LDS, and of its two active columns one stays in registers between rotations.
+// Same arithmetic as internal/SmallDense.h (tridiag_eigen, tridiag_shifted_qr), except that
+// stable_scaling's hypot(a, b) is evaluated as a * sqrt(1 + (b/a)^2) (within 1 ulp of it).
+// ===================================================================================================
+__device__ __forceinline__ double rdlane(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void wrlane(double& reg, int lane, int target, double value)
+{
+    reg = (lane == target) ? value : reg;
+}
+__device__ __forceinline__ double lane_below(double v)  // value of lane+1 (0 past the end)
+{
+    return __shfl_down(v, 1, 64);
+}
+__device__ __forceinline__ int highest_bit(unsigned long long m) { return 63 - __clzll((long long) m); }
+
+__device__ __forceinline__ void givens_fast(double x, double y, double& r, double& c, double& s)
+{
+    const double xsign = (x > 0.0) ? 1.0 : -1.0;
+    const double xabs = fabs(x);
+    if (y == 0.0)
+    {
+        c = (x == 0.0) ? 1.0 : xsign;
+        s = 0.0;
+        r = xabs;
+        return;
+    }
+    const double ysign = (y > 0.0) ? 1.0 : -1.0;
+    const double yabs = fabs(y);
+    if (x == 0.0)
+    {
+        c = 0.0;
+        s = -ysign;
+        r = yabs;
+        return;
+    }
+    const bool xbig = xabs >= yabs;
+    const double a = xbig ? xabs : yabs, b = xbig ? yabs : xabs;
+    const double t = b / a;
+    double ca, sb;  // a/r, b/r
+    if (t >= 0.1 * 0x1p-13)
+    {
+        r = a * sqrt(1.0 + t * t);
+        ca = a / r;
+        sb = b / r;
+    }
+    else
+    {
+        const double t2 = t * t;
+        ca = 1.0 - t2 * (0.5 - t2 * (0.375 - 0.3125 * t2));
+        sb = t * ca;
+        r = a + 0.5 * b * t * (1.0 - t2 * (0.25 - 0.125 * t2));
+    }
+    c = xsign * (xbig ? ca : sb);
+    s = -ysign * (xbig ? sb : ca);
+}
+
+// Q <- Q * G over columns (k, k+1) with column k carried in `qa` (this lane's row); returns the new carried column.
+__device__ __forceinline__ double rotate_cols(double* Q, int n, int lane, int k, double c, double s, double qa)
+{
+    double qb = 0.0;
+    if (lane < n)
+        qb = Q[(k + 1) * n + lane];
+    const double na = c * qa - s * qb;
+    const double nb = s * qa + c * qb;
+    if (lane < n)
+        Q[k * n + lane] = na;
+    return nb;
+}
+
+__global__ __launch_bounds__(64) void k_tridiag_eigen_w64(int n, const double* __restrict__ diag_in,
+                                                           const double* __restrict__ subd_in, double* __restrict__ evals,
+                                                           double* __restrict__ evecs, int* __restrict__ info)
+{
+    extern __shared__ __attribute__((aligned(16))) double Q[];  // n x n
+    const int lane = threadIdx.x;
+    double d = (lane < n) ? diag_in[lane] : 0.0;
+    double e = (lane < n - 1) ? subd_in[lane] : 0.0;
+    for (int idx = lane; idx < n * n; idx += 64)
+        Q[idx] = (idx / n == idx % n) ? 1.0 : 0.0;
+    __syncthreads();
+
+    // scale by the largest magnitude (TridiagEigen.h:139-152)
+    double scale = fmax(fabs(d), fabs(e));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        scale = fmax(scale, __shfl_xor(scale, off, 64));
+    int rc = 0;
+    if (scale < small::kNear0)
+        d = 0.0;
+    else
+    {
+        d = d / scale;
+        e = e / scale;
+        int end = n - 1, start = 0, iter = 0;
+        const double precision_inv = 1.0 / small::kEps;
+        while (end > 0)
+        {
+            // deflation scan over [start, end) (TridiagEigen.h:167-178), all lanes at once
+            const double dn = lane_below(d);
+            const bool inrange = lane >= start && lane < end;
+            const double sc = precision_inv * e;
+            if (inrange && (fabs(e) <= small::kMinPos || sc * sc <= (fabs(d) + fabs(dn))))
+                e = 0.0;
+            const unsigned long long nz = __ballot(e != 0.0 && lane < n - 1);
+            const unsigned long long below_end = nz & ((end >= 64) ? ~0ull : ((1ull << end) - 1ull));
+            end = below_end ? highest_bit(below_end) + 1 : 0;  // largest unreduced block at the end (:181-182)
+            if (end <= 0)
+                break;
+            iter++;
+            if (iter > 30 * n)
+            {
+                rc = 1;
+                break;
+            }
+            const unsigned long long zeros = ~nz & ((1ull << (end - 1)) - 1ull);  // e[j] == 0, j < end-1
+            start = zeros ? highest_bit(zeros) + 1 : 0;                         // (:195-197)
+
+            // one implicit QR step with Wilkinson shift on [start, end] (TridiagEigen.h:44-108)
+            const double d_end1 = rdlane(d, end - 1), d_end = rdlane(d, end), e_end1 = rdlane(e, end - 1);
+            const double td = (d_end1 - d_end) * 0.5;
+            double mu = d_end;
+            if (td == 0.0)
+                mu -= fabs(e_end1);
+            else if (e_end1 != 0.0)
+            {
+                const double e2 = e_end1 * e_end1;
+                const double h = small::eigen_hypot(td, e_end1);
+                if (e2 == 0.0)
+                    mu -= e_end1 / ((td + (td > 0.0 ? h : -h)) / e_end1);
+                else
+                    mu -= e2 / (td + (td > 0.0 ? h : -h));
+            }
+            double dk = rdlane(d, start), ek = rdlane(e, start), ekm1 = 0.0;
+            double x = dk - mu, z = ek;
+            double qa = (lane < n) ? Q[start * n + lane] : 0.0;
+            int k = start;
+            for (; k < end && z != 0.0; ++k)
+            {
+                double c, s;
+                small::eigen_make_givens(x, z, c, s);
+                const double dk1 = rdlane(d, k + 1);
+                const double ek1 = (k < end - 1) ? rdlane(e, k + 1) : 0.0;
+                const double sdk = s * dk + c * ek;
+                const double dkp1 = s * ek + c * dk1;
+                const double ndk = c * (c * dk - s * ek) - s * (c * ek - s * dk1);
+                const double ndk1 = s * sdk + c * dkp1;
+                const double nek = c * sdk - s * dkp1;
+                if (k > start)
+                    wrlane(e, lane, k - 1, c * ekm1 - s * z);
+                wrlane(d, lane, k, ndk);
+                wrlane(d, lane, k + 1, ndk1);
+                wrlane(e, lane, k, nek);
+                x = nek;
+                double nek1 = ek1;
+                if (k < end - 1)
+                {
+                    z = -s * ek1;
+                    nek1 = c * ek1;
+                    wrlane(e, lane, k + 1, nek1);
+                }
+                dk = ndk1;
+                ek = nek1;
+                ekm1 = nek;
+                qa = rotate_cols(Q, n, lane, k, c, s, qa);
+            }
+            if (lane < n)
+                Q[k * n + lane] = qa;  // the carried column goes back to LDS
+        }
+        d *= scale;
+    }
+    __syncthreads();
+    if (lane < n)
+        evals[lane] = d;
+    for (int idx = lane; idx < n * n; idx += 64)
+        evecs[idx] = Q[idx];
+    if (lane == 0)
+        *info = rc;
+}
+
+__global__ __launch_bounds__(64) void k_restart_sym_w64(int m, double* __restrict__ diag_io, double* __restrict__ subd_io,
+                                                         ShiftList shifts, int nshift, double* __restrict__ Qout)
+{
+    extern __shared__ __attribute__((aligned(16))) double Q[];  // m x m
+    const int lane = threadIdx.x;
+    double d = (lane < m) ? diag_io[lane] : 0.0;
+    double e = (lane < m - 1) ? subd_io[lane] : 0.0;
+    for (int idx = lane; idx < m * m; idx += 64)
+        Q[idx] = (idx / m == idx % m) ? 1.0 : 0.0;
+    __syncthreads();
+    const int n1 = m - 1, n2 = m - 2;
+    for (int sh = 0; sh < nshift; sh++)
+    {
+        const double shift = shifts.mu[sh];
+        // saved T with tiny sub-diagonals deflated (UpperHessenbergQR.h:526-539)
+        const double Td = d;
+        double Te = e;
+        {
+            const double dn = lane_below(d);
+            if (lane < n1 && fabs(e) <= small::kEps * (fabs(d) + fabs(dn)))
+                Te = 0.0;
+        }
+        // Givens sweep on T - shift*I (:541-590); lane i keeps rotation i
+        double rc = 0.0, rs = 0.0;
+        double r_diag = rdlane(Td, 0) - shift;
+        double r_supd = (n1 > 0) ? rdlane(Te, 0) : 0.0;
+        double qa = (lane < m) ? Q[lane] : 0.0;
+        for (int i = 0; i < n1; i++)
+        {
+            const double te_i = rdlane(Te, i);
+            const double td_i1 = rdlane(Td, i + 1) - shift;
+            const double te_i1 = (i < n2) ? rdlane(Te, i + 1) : 0.0;
+            double r, c, s;
+            givens_fast(r_diag, te_i, r, c, s);
+            wrlane(rc, lane, i, c);
+            wrlane(rs, lane, i, s);
+            r_diag = s * r_supd + c * td_i1;
+            if (i < n2)
+                r_supd = c * te_i1;
+            qa = rotate_cols(Q, m, lane, i, c, s, qa);  // apply_YQ (:403-416)
+        }
+        if (lane < m)
+            Q[n1 * m + lane] = qa;
+        // Q'TQ from the saved T (:627-693)
+        d = Td;
+        e = Te;
+        {
+            double x = rdlane(Td, 0), y = (n1 > 0) ? rdlane(Te, 0) : 0.0;
+            for (int i = 0; i < n1; i++)
+            {
+                const double c = rdlane(rc, i), s = rdlane(rs, i);
+                const double z = rdlane(Td, i + 1);
+                const double cs = c * s, c2 = c * c, s2 = s * s;
+                const double c2x = c2 * x, s2x = s2 * x, c2z = c2 * z, s2z = s2 * z;
+                const double csy2 = 2.0 * c * s * y;
+                const double nx = c2x - csy2 + s2z;
+                double ny = cs * (x - z) + (c2 - s2) * y;
+                const double nz = s2x + csy2 + c2z;
+                double nw = 0.0;
+                if (i < n2)
+                {
+                    const double ci1 = rdlane(rc, i + 1), si1 = rdlane(rs, i + 1);
+                    const double te_i1 = rdlane(Te, i + 1);
+                    const double o = -s * te_i1;
+                    nw = te_i1 * c;
+                    ny = ci1 * ny - si1 * o;
+                }
+                wrlane(d, lane, i, nx);
+                wrlane(e, lane, i, ny);
+                x = nz;
+                y = nw;
+            }
+            wrlane(d, lane, n1, x);
+        }
+        {
+            const double dn = lane_below(d);
+            if (lane < n1 && fabs(e) <= small::kEps * (fabs(d) + fabs(dn)))
+                e = 0.0;
+        }
+    }
+    __syncthreads();
+    if (lane < m)
+        diag_io[lane] = d;
+    if (lane < m - 1)
+        subd_io[lane] = e;
+    for (int idx = lane; idx < m * m; idx += 64)
+        Qout[idx] = Q[idx];
+}
+
 }  // namespace
 
 namespace mispec {
@@ -77,6 +360,14 @@ void launch_tridiag_eigen(const mispec_ctx& ctx, int n, const double* diag, cons
                           int* info)
 {
     MISPEC_REQUIRE(n >= 1 && n <= kMaxSmallDim, "tridiag_eigen kernel: dimension out of range");
+    static const bool generic = getenv("MISPEC_SMALL_GENERIC") && atoi(getenv("MISPEC_SMALL_GENERIC")) != 0;
+    if (n <= 64 && !generic)
+    {
+        hipLaunchKernelGGL(k_tridiag_eigen_w64, dim3(1), dim3(64), size_t(n) * n * sizeof(double), ctx.stream, n, diag, subd, evals,
+                           evecs, info);
+        MISPEC_HIP(hipGetLastError());
+        return;
+    }
     const size_t lds = (size_t(2) * n + size_t(n) * n) * sizeof(double);
     MISPEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tridiag_eigen), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    int(lds)));
@@ -92,6 +383,14 @@ void launch_restart_sym(const mispec_ctx& ctx, int m, double* diag, double* subd
     ShiftList sl;
     for (int i = 0; i < nshift; i++)
         sl.mu[i] = shifts_host[i];
+    static const bool generic = getenv("MISPEC_SMALL_GENERIC") && atoi(getenv("MISPEC_SMALL_GENERIC")) != 0;
+    if (m <= 64 && !generic)
+    {
+        hipLaunchKernelGGL(k_restart_sym_w64, dim3(1), dim3(64), size_t(m) * m * sizeof(double), ctx.stream, m, diag, subd, sl,
+                           nshift, Q);
+        MISPEC_HIP(hipGetLastError());
+        return;
+    }
     const size_t lds = (size_t(6) * m + size_t(m) * m) * sizeof(double);
     MISPEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_restart_sym), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    int(lds)));
