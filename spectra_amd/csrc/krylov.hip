@@ -263,28 +263,50 @@ __device__ void finish_record(double* red, int ncol, const FinishArgs& fa)
     st->need_corr = need;
 }
 
-// One workgroup sums the records column by column in a fixed order.
+// One workgroup sums the records in a fixed order.  Thread t owns record t (and t+1024, ...): it issues the
+// loads of all its slots back to back (coalesced across the wave, one memory latency in total — the records
+// were written by other XCDs, so every load comes from beyond the L2), each wave shuffle-reduces every
+// slot, and sixteen per-wave partials per slot are added by one thread.
 __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restrict__ partials, int64_t pstride, int nrec,
                                                            int ncol, double* __restrict__ red, FinishArgs fin)
 {
+    __shared__ double wsum[16][kPartialLd];
     __shared__ double sh[kPartialLd];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int j = w; j < kPartialLd; j += 16)
+    // slots [0, ncol) are sums, kSlotBeta2 a sum, kSlotMaxAbs a max
+    for (int j0 = 0; j0 < kPartialLd; j0 += 8)
     {
-        const bool is_sum = (j < ncol) || (j == kSlotBeta2);
-        const bool is_max = (j == kSlotMaxAbs);
-        double v = 0.0;
-        if (is_sum || is_max)
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
         {
-            for (int b = lane; b < nrec; b += 64)
-            {
-                const double x = partials[int64_t(j) * pstride + b];
-                v = is_max ? fmax(v, x) : v + x;
-            }
-            v = is_max ? wave_reduce_max(v) : wave_reduce_sum(v);
+            const int j = j0 + u;
+            const bool is_sum = (j < ncol) || (j == kSlotBeta2);
+            const bool is_max = (j == kSlotMaxAbs);
+            v[u] = 0.0;
+            if (is_sum || is_max)
+                for (int b = tid; b < nrec; b += 1024)
+                {
+                    const double x = partials[int64_t(j) * pstride + b];
+                    v[u] = is_max ? fmax(v[u], x) : v[u] + x;
+                }
         }
-        if (lane == 0)
-            sh[j] = v;
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+        {
+            const int j = j0 + u;
+            const double r = (j == kSlotMaxAbs) ? wave_reduce_max(v[u]) : wave_reduce_sum(v[u]);
+            if (lane == 0)
+                wsum[w][j] = r;
+        }
+    }
+    __syncthreads();
+    if (tid < kPartialLd)
+    {
+        double acc = 0.0;
+        for (int k = 0; k < 16; k++)
+            acc = (tid == kSlotMaxAbs) ? fmax(acc, wsum[k][tid]) : acc + wsum[k][tid];
+        sh[tid] = acc;
     }
     __syncthreads();
     if (tid == 0)
