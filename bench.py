@@ -74,6 +74,25 @@ def cpu_baseline(args, gpu_nops, gpu_nconv):
     }
 
 
+def pmc_traffic(n):
+    """HBM bytes per launch of the fused SpMV as measured by the committed PMC passes (tools/pmc_summarize.py), or None."""
+    import glob
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    for path in sorted(glob.glob(os.path.join(here, "profiles", "*pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            if int(d.get("n", -1)) != int(n):
+                continue
+            for name, rec in d["kernels"].items():
+                if name.startswith("k_spmv_csr_stream<true"):
+                    return float(rec["hbm_bytes"])
+        except Exception:  # noqa: BLE001 - a malformed summary just means "no PMC figure"
+            continue
+    return None
+
+
 def main():
     args = parse()
     import numpy as np
@@ -114,6 +133,19 @@ def main():
         ncols = eigs.eigenvectors(to_host=False)  # V * Y formed in HBM (1.6 GB at n = 1e7; not pulled over PCIe)
         return eigs, nconv, ncols
 
+    exchange_note = None
+    if world > 1:
+        # Self-check of the point-to-point neighbour exchange (outside the timed region): if the solve it drives
+        # does not reach the residual bar on every rank, every rank falls back to the plain all-gather.
+        chk, nconv_chk, _ = solve(False)
+        r = chk.residuals()
+        bad = int(nconv_chk < args.nev or not np.all(np.isfinite(r)) or float(r.max()) > 1e-8)
+        flag = torch.tensor([bad], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()) and chk.exchange_info()[0]:
+            os.environ["MISPEC_EXCHANGE"] = "allgather"
+            exchange_note = "neighbour exchange failed its residual self-check; all-gather used"
+        del chk
     for _ in range(args.warmup):
         solve(False)
     barrier()
@@ -147,6 +179,15 @@ def main():
     op.spmv_time(x.data_ptr(), y.data_ptr(), 5)
     alone_ms = op.spmv_time(x.data_ptr(), y.data_ptr(), args.spmv_reps)
 
+    halo, recv_doubles = eigs.exchange_info()
+    if world == 1:
+        exchange_desc = ""
+    elif halo:
+        exchange_desc = (f", RCCL point-to-point exchange of the referenced parts of the Krylov vector per SpMV "
+                         f"({recv_doubles * 8 / 1e6:.2f} MB received by rank 0; the all-gather would move "
+                         f"{(world - 1) * int(sa.lib().mispec_shard_block(args.n, world)) * 8 / 1e6:.1f} MB)")
+    else:
+        exchange_desc = ", RCCL all-gather of the Krylov vector per SpMV" + (f" ({exchange_note})" if exchange_note else "")
     if rank == 0:
         out = {
             "metric": "eigenpairs_per_sec",
@@ -166,7 +207,7 @@ def main():
                              "symmetric CSR (M-band, SURVEY.md 8d)" if args.n == 10_000_000 else f"M-band n={args.n}"),
                 "n": args.n, "nnz_per_gpu": nnz_local, "nev": args.nev, "ncv": args.ncv, "selection": args.selection,
                 "tol": args.tol, "start_vector": "SimpleRandom(0) (reference default)",
-                "parallelism": f"row-shard x{world}" + (", RCCL all-gather of the Krylov vector per SpMV" if world > 1 else ""),
+                "parallelism": f"row-shard x{world}" + exchange_desc,
             },
             "roofline": {
                 "kernel": "k_spmv_csr_stream (CSR SpMV fused with w -= beta*v_prev and the alpha dot)",
@@ -175,7 +216,9 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": pmc_traffic(args.n) if world == 1 else None,
+                "traffic_source": "bytes per launch of the in-loop SpMV from the newest profiles/*pmc_traffic.json "
+                                  "(rocprofv3 PMC passes need their own profiler run; see profiles/README.md)",
                 "bytes_per_launch": spmv_bytes,
                 "ms_per_launch": spmv_ms,
                 "launches": int(prof["n_spmv"]),

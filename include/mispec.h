@@ -63,6 +63,14 @@ typedef struct mispec_comm
     int (*allgather)(void* user, const double* send_dev, double* recv_dev, int64_t count_per_rank, void* hip_stream);
     int (*allreduce_sum)(void* user, double* buf_dev, int64_t count, void* hip_stream);
     void* user;
+    /* Optional (NULL = not provided): personalised exchange of sub-ranges.  Send send_count[p] doubles starting
+     * at send_dev + send_off[p] to every peer p and receive recv_count[p] doubles from p into
+     * recv_dev + recv_off[p]; the entries for p == rank are ignored; the offset/count arrays (host memory,
+     * `world` entries) stay valid for the lifetime of the matrix.  When present, a matrix whose rows reference
+     * only a small part of the other ranks' rows (banded / stencil matrices: neighbour halos) uses this instead
+     * of the full all-gather; MISPEC_EXCHANGE=allgather forces the all-gather. */
+    int (*exchange)(void* user, const double* send_dev, const int64_t* send_off, const int64_t* send_count,
+                    double* recv_dev, const int64_t* recv_off, const int64_t* recv_count, void* hip_stream);
 } mispec_comm;
 int mispec_ctx_set_comm(mispec_ctx* ctx, const mispec_comm* comm);
 /* Built-in communicator over RCCL (librccl.so.1 is dlopen'ed on first use).  unique_id is the 128-byte
@@ -169,6 +177,10 @@ int mispec_fac_init_random(mispec_fac* fac, uint64_t seed, int64_t* nmatop);
 int mispec_fac_factorize(mispec_fac* fac, int from_k, int to_m, int64_t* nmatop);
 int mispec_fac_subspace_dim(const mispec_fac* fac);          /* subspace_dim() */
 int mispec_fac_f_norm(const mispec_fac* fac, double* beta);  /* f_norm() */
+/* How a sharded device matrix moves the Krylov vector before each product: *halo = 1 if only the referenced
+ * parts of the other ranks' slices are exchanged point-to-point (recv_doubles of them per product), 0 if the
+ * full all-gather is used (or the context is not sharded). */
+int mispec_fac_exchange_info(const mispec_fac* fac, int* halo, int64_t* recv_doubles);
 int mispec_fac_get_H(const mispec_fac* fac, double* H_host); /* matrix_H(), ncv x ncv col-major */
 int mispec_fac_set_H(mispec_fac* fac, const double* H_host, int k); /* after a host-side compress_H */
 /* matrix_V().leftCols(ncols) / vector_f() of this shard to host (ld = local_rows). */
@@ -245,6 +257,7 @@ int mispec_symeigs_eigenvectors(mispec_symeigs* s, int64_t nvec, double* out_hos
 /* Residuals ||A x - lambda x|| / ||x|| of the converged pairs, computed on the device. */
 int mispec_symeigs_residuals(mispec_symeigs* s, double* resid_host, int64_t* count);
 int mispec_symeigs_get_profile(const mispec_symeigs* s, mispec_profile* out);
+int mispec_symeigs_exchange_info(const mispec_symeigs* s, int* halo, int64_t* recv_doubles); /* see mispec_fac_exchange_info */
 int mispec_symeigs_profile(mispec_symeigs* s, int enable);
 
 /* ---------------------------------------------------------------------------

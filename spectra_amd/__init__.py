@@ -61,6 +61,11 @@ def _ip(a):
     return a.ctypes.data_as(C.POINTER(C.c_int32)) if a is not None else None
 
 
+def shard_block(n, world):
+    """Rows per rank of the equal-block row partition (mispec_shard_block)."""
+    return int(lib().mispec_shard_block(n, world))
+
+
 def shard_range(n, world, rank):
     """Rows [begin, end) owned by `rank` (equal even-sized blocks, see mispec_shard_range)."""
     b, e = C.c_int64(), C.c_int64()
@@ -383,6 +388,12 @@ class SymEigsSolver:
         check(lib().mispec_symeigs_get_profile(self.h, C.byref(p)))
         return p.as_dict()
 
+    def exchange_info(self):
+        """(halo, doubles received per product): how a sharded matrix moves the Krylov vector (mispec_fac_exchange_info)."""
+        halo, cnt = C.c_int(0), C.c_int64(0)
+        check(lib().mispec_symeigs_exchange_info(self.h, C.byref(halo), C.byref(cnt)))
+        return bool(halo.value), int(cnt.value)
+
     def __del__(self):
         try:
             lib().mispec_symeigs_destroy(self.h)
@@ -613,6 +624,11 @@ class Factorization:
         p = Profile()
         check(lib().mispec_fac_get_profile(self.h, C.byref(p)))
         return p.as_dict()
+
+    def exchange_info(self):
+        halo, cnt = C.c_int(0), C.c_int64(0)
+        check(lib().mispec_fac_exchange_info(self.h, C.byref(halo), C.byref(cnt)))
+        return bool(halo.value), int(cnt.value)
 
     def __del__(self):
         try:

@@ -32,11 +32,13 @@ def build_library(force=False, verbose=False):
 op_fn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))
 allgather_fn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 allreduce_fn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+exchange_fn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p,
+                          C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p)
 
 
 class Comm(C.Structure):
     _fields_ = [("rank", C.c_int), ("world", C.c_int), ("allgather", allgather_fn), ("allreduce_sum", allreduce_fn),
-                ("user", C.c_void_p)]
+                ("user", C.c_void_p), ("exchange", exchange_fn)]
 
 
 class Profile(C.Structure):
@@ -98,6 +100,7 @@ SIGNATURES = {
     "mispec_fac_factorize": (C.c_int, [_vp, C.c_int, C.c_int, _lp]),
     "mispec_fac_subspace_dim": (C.c_int, [_vp]),
     "mispec_fac_f_norm": (C.c_int, [_vp, _dp]),
+    "mispec_fac_exchange_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "mispec_fac_get_H": (C.c_int, [_vp, _dp]),
     "mispec_fac_set_H": (C.c_int, [_vp, _dp, C.c_int]),
     "mispec_fac_get_V": (C.c_int, [_vp, C.c_int, _dp]),
@@ -127,6 +130,7 @@ SIGNATURES = {
     "mispec_symeigs_eigenvectors": (C.c_int, [_vp, C.c_int64, _dp, _lp]),
     "mispec_symeigs_residuals": (C.c_int, [_vp, _dp, _lp]),
     "mispec_symeigs_get_profile": (C.c_int, [_vp, C.POINTER(Profile)]),
+    "mispec_symeigs_exchange_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "mispec_symeigs_profile": (C.c_int, [_vp, C.c_int]),
     "mispec_geneigs_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vpp]),
     "mispec_geneigs_create_op": (C.c_int, [_vp, op_fn, _vp, C.c_int64, C.c_int64, C.c_int64, _vpp]),

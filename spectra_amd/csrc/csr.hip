@@ -297,6 +297,35 @@ mispec_csr* upload_rows(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const i
     return A;
 }
 
+// Smallest / largest column referenced inside every rank's row block (block = rows per rank): which part of
+// the other ranks' slices of x this shard's SpMV reads.  lo starts at INT64_MAX, hi at -1.
+constexpr int kMaxPeers = 64;
+__global__ __launch_bounds__(256) void k_col_ranges(const int32_t* __restrict__ colind, int64_t nnz, int64_t block, int world,
+                                                     long long* __restrict__ lo, long long* __restrict__ hi)
+{
+    __shared__ int s_lo[kMaxPeers], s_hi[kMaxPeers];
+    for (int p = threadIdx.x; p < world; p += blockDim.x)
+    {
+        s_lo[p] = 0x7fffffff;
+        s_hi[p] = -1;
+    }
+    __syncthreads();
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < nnz; i += int64_t(gridDim.x) * blockDim.x)
+    {
+        const int c = colind[i];
+        const int p = int(int64_t(c) / block);
+        atomicMin(&s_lo[p], c);
+        atomicMax(&s_hi[p], c);
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < world; p += blockDim.x)
+        if (s_hi[p] >= 0)
+        {
+            atomicMin(&lo[p], (long long) s_lo[p]);
+            atomicMax(&hi[p], (long long) s_hi[p]);
+        }
+}
+
 }  // namespace
 
 namespace mispec {
@@ -338,6 +367,37 @@ void launch_spmv(const mispec_csr& A, const double* x_dev, double* y_dev, const 
         MISPEC_SPMV(false, false);
 #undef MISPEC_SPMV
     MISPEC_HIP(hipGetLastError());
+}
+
+bool column_ranges(const mispec_csr& A, int64_t block, int world, std::vector<int64_t>& lo, std::vector<int64_t>& hi)
+{
+    lo.assign(size_t(world), INT64_MAX);
+    hi.assign(size_t(world), -1);
+    if (world > kMaxPeers)
+        return false;
+    if (A.nnz == 0)
+        return true;
+    DevBuf<long long> d;
+    d.alloc(2 * size_t(world));
+    std::vector<long long> h(2 * size_t(world));
+    for (int p = 0; p < world; p++)
+    {
+        h[size_t(p)] = INT64_MAX;
+        h[size_t(world + p)] = -1;
+    }
+    MISPEC_HIP(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(long long), hipMemcpyHostToDevice, A.ctx->stream));
+    const int grid = int(std::min<int64_t>((A.nnz + 255) / 256, int64_t(A.ctx->num_cu) * 8));
+    hipLaunchKernelGGL(k_col_ranges, dim3(unsigned(grid)), dim3(256), 0, A.ctx->stream, A.colind.p, A.nnz, block, world, d.p,
+                       d.p + world);
+    MISPEC_HIP(hipGetLastError());
+    MISPEC_HIP(hipMemcpyAsync(h.data(), d.p, h.size() * sizeof(long long), hipMemcpyDeviceToHost, A.ctx->stream));
+    MISPEC_HIP(hipStreamSynchronize(A.ctx->stream));
+    for (int p = 0; p < world; p++)
+    {
+        lo[size_t(p)] = h[size_t(p)];
+        hi[size_t(p)] = h[size_t(world + p)];
+    }
+    return true;
 }
 
 }  // namespace mispec

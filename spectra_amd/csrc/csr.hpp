@@ -1,5 +1,7 @@
 // Device-resident CSR row shard (the A behind SparseSymMatProd / SparseGenMatProd) and the SpMV launcher.
 #pragma once
+#include <vector>
+
 #include "common.hpp"
 
 struct mispec_csr
@@ -47,5 +49,10 @@ inline int spmv_num_blocks(int64_t local_rows)
 }
 
 void launch_spmv(const mispec_csr& A, const double* x_dev, double* y_dev, const SpmvEpilogue* epi);
+
+// For every rank p of a `world`-way row partition with `block` rows per rank: the smallest (lo[p]) and largest
+// (hi[p]) column index this shard references inside p's rows; hi[p] = -1 when it references none.  Returns
+// false (nothing computed) when world exceeds the kernel's peer limit.  Synchronises the stream.
+bool column_ranges(const mispec_csr& A, int64_t block, int world, std::vector<int64_t>& lo, std::vector<int64_t>& hi);
 
 }  // namespace mispec

@@ -141,6 +141,10 @@ struct RcclApi
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -164,6 +168,10 @@ RcclApi& rccl()
         api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(api.handle, "ncclAllGather"));
         api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.handle, "ncclAllReduce"));
         api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
+        api.Send = reinterpret_cast<decltype(api.Send)>(dlsym(api.handle, "ncclSend"));
+        api.Recv = reinterpret_cast<decltype(api.Recv)>(dlsym(api.handle, "ncclRecv"));
+        api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(dlsym(api.handle, "ncclGroupStart"));
+        api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(dlsym(api.handle, "ncclGroupEnd"));
     });
     if (!api.handle || !api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.AllReduce)
         throw Error(MISPEC_ERUNTIME, "RCCL is not available (dlopen librccl.so.1 failed)");
@@ -179,6 +187,7 @@ void rccl_check(ncclResult_t r, const char* what)
 struct RcclComm
 {
     ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
 };
 
 int rccl_allgather(void* user, const double* send, double* recv, int64_t count, void* stream)
@@ -195,6 +204,27 @@ int rccl_allreduce(void* user, double* buf, int64_t count, void* stream)
         auto* c = static_cast<RcclComm*>(user);
         rccl_check(rccl().AllReduce(buf, buf, size_t(count), ncclDouble, ncclSum, c->comm, static_cast<hipStream_t>(stream)),
                    "ncclAllReduce");
+    });
+}
+// Neighbour exchange: every non-empty range is one ncclSend / ncclRecv of a group, so the transfers to all
+// peers run concurrently on their own xGMI links.
+int rccl_exchange(void* user, const double* send, const int64_t* send_off, const int64_t* send_count, double* recv,
+                  const int64_t* recv_off, const int64_t* recv_count, void* stream)
+{
+    return guarded([&] {
+        auto* c = static_cast<RcclComm*>(user);
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        rccl_check(rccl().GroupStart(), "ncclGroupStart");
+        for (int p = 0; p < c->world; p++)
+        {
+            if (p == c->rank)
+                continue;
+            if (send_count[p] > 0)
+                rccl_check(rccl().Send(send + send_off[p], size_t(send_count[p]), ncclDouble, p, c->comm, s), "ncclSend");
+            if (recv_count[p] > 0)
+                rccl_check(rccl().Recv(recv + recv_off[p], size_t(recv_count[p]), ncclDouble, p, c->comm, s), "ncclRecv");
+        }
+        rccl_check(rccl().GroupEnd(), "ncclGroupEnd");
     });
 }
 void rccl_free(void* p)
@@ -239,7 +269,10 @@ extern "C" int mispec_ctx_set_comm_rccl(mispec_ctx* ctx, int rank, int world, co
             ctx->comm_owner_free(ctx->comm_owner);
         ctx->comm_owner = c;
         ctx->comm_owner_free = rccl_free;
-        ctx->comm = mispec_comm{rank, world, rccl_allgather, rccl_allreduce, c};
+        c->rank = rank;
+        c->world = world;
+        const bool p2p = rccl().Send && rccl().Recv && rccl().GroupStart && rccl().GroupEnd;
+        ctx->comm = mispec_comm{rank, world, rccl_allgather, rccl_allreduce, c, p2p ? rccl_exchange : nullptr};
     });
 }
 
@@ -257,6 +290,7 @@ struct mispec_loopback
     int arrived = 0;
     uint64_t generation = 0;
     std::vector<const double*> send;
+    std::vector<const int64_t*> send_off, send_count;
     std::vector<double*> bufs;
     std::vector<int> devices;
     struct Endpoint
@@ -298,6 +332,31 @@ int loopback_allgather(void* user, const double* send, double* recv, int64_t cou
         g->barrier();
     });
 }
+// pull model: every rank publishes its send buffer and tables, then copies what the peers address to it
+int loopback_exchange(void* user, const double* send, const int64_t* send_off, const int64_t* send_count, double* recv,
+                      const int64_t* recv_off, const int64_t* recv_count, void* stream)
+{
+    return guarded([&] {
+        auto* ep = static_cast<mispec_loopback::Endpoint*>(user);
+        mispec_loopback* g = ep->grp;
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        MISPEC_HIP(hipStreamSynchronize(s));
+        g->send[ep->rank] = send;
+        g->send_off[ep->rank] = send_off;
+        g->send_count[ep->rank] = send_count;
+        g->barrier();
+        for (int r = 0; r < g->world; r++)
+        {
+            if (r == ep->rank || recv_count[r] <= 0)
+                continue;
+            MISPEC_REQUIRE(g->send_count[r][ep->rank] == recv_count[r], "loopback exchange: send/recv counts disagree");
+            MISPEC_HIP(hipMemcpyAsync(recv + recv_off[r], g->send[r] + g->send_off[r][ep->rank],
+                                      size_t(recv_count[r]) * sizeof(double), hipMemcpyDeviceToDevice, s));
+        }
+        MISPEC_HIP(hipStreamSynchronize(s));
+        g->barrier();
+    });
+}
 int loopback_allreduce(void* user, double* buf, int64_t count, void* stream)
 {
     return guarded([&] {
@@ -328,6 +387,8 @@ extern "C" int mispec_loopback_create(int world, mispec_loopback** out)
         auto* g = new mispec_loopback();
         g->world = world;
         g->send.assign(size_t(world), nullptr);
+        g->send_off.assign(size_t(world), nullptr);
+        g->send_count.assign(size_t(world), nullptr);
         g->bufs.assign(size_t(world), nullptr);
         g->endpoints.resize(size_t(world));
         for (int r = 0; r < world; r++)
@@ -340,7 +401,8 @@ extern "C" int mispec_loopback_attach(mispec_loopback* grp, mispec_ctx* ctx, int
 {
     return guarded([&] {
         MISPEC_REQUIRE(grp && ctx && rank >= 0 && rank < grp->world, "mispec_loopback_attach: bad argument");
-        ctx->comm = mispec_comm{rank, grp->world, loopback_allgather, loopback_allreduce, &grp->endpoints[size_t(rank)]};
+        ctx->comm = mispec_comm{rank, grp->world, loopback_allgather, loopback_allreduce, &grp->endpoints[size_t(rank)],
+                                loopback_exchange};
     });
 }
 

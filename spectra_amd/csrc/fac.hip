@@ -64,6 +64,11 @@ struct mispec_fac
     PinnedBuf<double> h_red, h_small, h_x, h_y;
     bool device_steps = true;      // MISPEC_HOST_STEPS=1 forces the host-synchronous path
     int64_t pstride = 0;  // stride between slots of the partial records
+    // Neighbour exchange plan (sharded device matrices): per peer, which part of my slice it reads and which
+    // part of its slice I read.  halo == false: the full all-gather is used.
+    bool halo = false;
+    std::vector<int64_t> send_off, send_count, recv_off, recv_count;
+    int64_t halo_recv = 0;  // doubles received per exchange
     int red_cur = 0;   // which half of `red` holds the latest reduced record
     int x_cols = 0;    // columns currently held in X
 
@@ -188,6 +193,79 @@ void allreduce_max_scalar(mispec_fac& F, double* dev_scalar)
     sync_stream(F);
 }
 
+// Decide between the all-gather and the neighbour exchange for this matrix (collective: every rank calls it and
+// every rank reaches the same decision, because the decision is a function of the all-gathered table).
+void plan_exchange(mispec_fac& F)
+{
+    F.halo = false;
+    const mispec_comm& cm = F.ctx->comm;
+    const int W = cm.world, me = cm.rank;
+    if (!F.A || !F.sharded() || !cm.exchange || W < 2)
+        return;
+    const char* e = getenv("MISPEC_EXCHANGE");
+    if (e && std::string(e) == "allgather")
+        return;
+    std::vector<int64_t> lo, hi;
+    const bool have = column_ranges(*F.A, F.block, W, lo, hi);
+    // table[q][2p], table[q][2p+1]: first row and row count of rank p's slice that rank q reads
+    DevBuf<double> mine, table;
+    mine.alloc(2 * size_t(W));
+    table.alloc(2 * size_t(W) * W);
+    std::vector<double> h(2 * size_t(W), 0.0);
+    for (int p = 0; p < W; p++)
+    {
+        if (!have)
+        {
+            h[2 * size_t(p)] = -1.0;  // "cannot tell": forces the all-gather on every rank
+            continue;
+        }
+        if (p == me || hi[size_t(p)] < 0)
+            continue;
+        h[2 * size_t(p)] = double(lo[size_t(p)]);
+        h[2 * size_t(p) + 1] = double(hi[size_t(p)] - lo[size_t(p)] + 1);
+    }
+    MISPEC_HIP(hipMemcpyAsync(mine.p, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, F.stream()));
+    comm_check(cm.allgather(cm.user, mine.p, table.p, 2 * int64_t(W), F.stream()), "all-gather (exchange plan)");
+    std::vector<double> t(2 * size_t(W) * W);
+    MISPEC_HIP(hipMemcpyAsync(t.data(), table.p, t.size() * sizeof(double), hipMemcpyDeviceToHost, F.stream()));
+    MISPEC_HIP(hipStreamSynchronize(F.stream()));
+    int64_t worst = 0;
+    for (int q = 0; q < W; q++)
+    {
+        int64_t total = 0;
+        for (int p = 0; p < W; p++)
+        {
+            if (t[(size_t(q) * W + p) * 2] < 0.0)
+                return;
+            total += int64_t(t[(size_t(q) * W + p) * 2 + 1]);
+        }
+        worst = std::max(worst, total);
+    }
+    const bool force = e && std::string(e) == "halo";
+    if (!force && 2 * worst > int64_t(W - 1) * F.block)
+        return;  // the referenced parts are most of the vector: one all-gather is the better collective
+    F.send_off.assign(size_t(W), 0);
+    F.send_count.assign(size_t(W), 0);
+    F.recv_off.assign(size_t(W), 0);
+    F.recv_count.assign(size_t(W), 0);
+    F.halo_recv = 0;
+    for (int p = 0; p < W; p++)
+    {
+        if (p == me)
+            continue;
+        // what I read of p's slice lands at its global position in x_full
+        F.recv_off[size_t(p)] = int64_t(t[(size_t(me) * W + p) * 2]);
+        F.recv_count[size_t(p)] = int64_t(t[(size_t(me) * W + p) * 2 + 1]);
+        F.halo_recv += F.recv_count[size_t(p)];
+        // what p reads of my slice, relative to my first row
+        F.send_count[size_t(p)] = int64_t(t[(size_t(p) * W + me) * 2 + 1]);
+        F.send_off[size_t(p)] = F.send_count[size_t(p)] ? int64_t(t[(size_t(p) * W + me) * 2]) - F.row_begin : 0;
+        MISPEC_REQUIRE(F.send_off[size_t(p)] >= 0 && F.send_off[size_t(p)] + F.send_count[size_t(p)] <= F.nloc,
+                       "exchange plan: a peer references rows outside this shard");
+    }
+    F.halo = true;
+}
+
 // y = Op(x).  x_loc / y_loc: this shard's rows (device).  With `lanczos_epi`, additionally
 // y -= h_prev * v_prev (when v_prev != nullptr) and alpha = <x, y> is left in red_buf(0)[kSlotAlpha]
 // (device) — Lanczos.h:131-142.
@@ -200,8 +278,18 @@ void apply_op(mispec_fac& F, const double* x_loc, double* y_loc, bool lanczos_ep
         const double* x = x_loc;
         if (F.sharded())
         {
-            // all-gather of the Krylov vector over xGMI; blocks are equal-sized and padded
-            comm_check(F.ctx->comm.allgather(F.ctx->comm.user, x_loc, F.xfull.p, F.block, F.stream()), "all-gather");
+            if (F.halo)
+            {
+                // the matrix references only parts of the other slices: own slice by a local copy, the referenced
+                // parts by concurrent point-to-point transfers
+                MISPEC_HIP(hipMemcpyAsync(F.xfull.p + F.row_begin, x_loc, size_t(F.nloc) * sizeof(double),
+                                          hipMemcpyDeviceToDevice, F.stream()));
+                comm_check(F.ctx->comm.exchange(F.ctx->comm.user, x_loc, F.send_off.data(), F.send_count.data(), F.xfull.p,
+                                                F.recv_off.data(), F.recv_count.data(), F.stream()),
+                           "neighbour exchange");
+            }
+            else  // all-gather of the Krylov vector over xGMI; blocks are equal-sized and padded
+                comm_check(F.ctx->comm.allgather(F.ctx->comm.user, x_loc, F.xfull.p, F.block, F.stream()), "all-gather");
             x = F.xfull.p;
         }
         Timed t(F, FAM_SPMV);
@@ -520,9 +608,19 @@ void lanczos_step_host(mispec_fac& F, int i, int64_t* nmatop)
 // One step of the device-driven path: every kernel is enqueued, nothing is read back.  The scalar decisions
 // of the step (restart test, need for a correction, breakdown) are taken by the finish code on the device and
 // recorded in F.d_state; a kernel that must not run any more turns itself into a no-op.
-constexpr int kSpeculativeCorrections = 2;
+// Correction passes enqueued ahead of the decision.  The first one practically always runs (V'f of the plain
+// three-term recurrence is above eps*beta), a second one almost never: enqueueing it blindly costs three no-op
+// launches on one device, but a real all-reduce per step when sharded — so it is left to the host path there.
+int speculative_corrections(const mispec_fac& F)
+{
+    static const int knob = getenv("MISPEC_SPEC_CORR") ? atoi(getenv("MISPEC_SPEC_CORR")) : 0;
+    if (knob >= 1 && knob <= 4)
+        return knob;
+    return (F.sharded() && F.ctx->world() > 1) ? 1 : 2;
+}
 void lanczos_step_device(mispec_fac& F, int i)
 {
+    const int kSpeculativeCorrections = speculative_corrections(F);
     StepState* st = F.d_state.p;
     double* v = F.col(i);
     {
@@ -761,6 +859,7 @@ int fac_create_impl(mispec_ctx* ctx, const mispec_csr* A, const mispec_symshift*
             if (F->sharded())
             {
                 F->xfull.alloc(size_t(F->block) * ctx->world());
+                MISPEC_HIP(hipMemsetAsync(F->xfull.p, 0, F->xfull.n * sizeof(double), ctx->stream));
                 F->gmax.alloc(size_t(ctx->world()));
             }
             const int64_t max_rec = int64_t(ctx->num_cu) * 8 + 8;
@@ -788,6 +887,7 @@ int fac_create_impl(mispec_ctx* ctx, const mispec_csr* A, const mispec_symshift*
                 F->h_y.alloc(size_t(n));
             }
             MISPEC_HIP(hipStreamSynchronize(ctx->stream));
+            plan_exchange(*F);
         }
         catch (...)
         {
@@ -876,6 +976,15 @@ extern "C" int mispec_fac_factorize(mispec_fac* fac, int from_k, int to_m, int64
 
 extern "C" int mispec_fac_subspace_dim(const mispec_fac* fac) { return fac ? fac->k : 0; }
 extern "C" int64_t mispec_fac_local_rows(const mispec_fac* fac) { return fac ? fac->nloc : 0; }
+
+extern "C" int mispec_fac_exchange_info(const mispec_fac* fac, int* halo, int64_t* recv_doubles)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(fac && halo && recv_doubles, "mispec_fac_exchange_info: NULL argument");
+        *halo = fac->halo ? 1 : 0;
+        *recv_doubles = fac->halo ? fac->halo_recv : (fac->sharded() ? fac->block * (fac->ctx->world() - 1) : 0);
+    });
+}
 
 extern "C" int mispec_fac_f_norm(const mispec_fac* fac, double* beta)
 {

@@ -15,8 +15,13 @@ from spectra_amd import _capi
 pytestmark = pytest.mark.gpu
 
 
-def run_sharded(world, n, offsets, nev, ncv, rule, tol):
+def run_sharded(world, n, offsets, nev, ncv, rule, tol, exchange=None):
+    import os
+
     lib = sa.lib()
+    old_env = os.environ.pop("MISPEC_EXCHANGE", None)
+    if exchange:
+        os.environ["MISPEC_EXCHANGE"] = exchange  # read when the factorisation plans its exchange
     grp = C.c_void_p()
     _capi.check(lib.mispec_loopback_create(world, C.byref(grp)))
     results, errors = [None] * world, []
@@ -32,7 +37,7 @@ def run_sharded(world, n, offsets, nev, ncv, rule, tol):
             nconv = eigs.compute(rule, 1000, tol)
             results[rank] = dict(nconv=nconv, info=eigs.info(), evals=eigs.eigenvalues(), X=eigs.eigenvectors(),
                                  nops=eigs.num_operations(), niter=eigs.num_iterations(), res=eigs.residuals(),
-                                 rows=sa.shard_range(n, world, rank), local=op.local_rows())
+                                 rows=sa.shard_range(n, world, rank), local=op.local_rows(), exchange=eigs.exchange_info())
         except Exception as e:  # noqa: BLE001
             errors.append((rank, repr(e)))
 
@@ -41,6 +46,9 @@ def run_sharded(world, n, offsets, nev, ncv, rule, tol):
         t.start()
     for t in threads:
         t.join(timeout=600)
+    os.environ.pop("MISPEC_EXCHANGE", None)
+    if old_env is not None:
+        os.environ["MISPEC_EXCHANGE"] = old_env
     assert not errors, errors
     _capi.check(lib.mispec_loopback_destroy(grp))
     return results
@@ -69,3 +77,33 @@ def test_sharded_equals_unsharded(ctx, world):
     import scipy.sparse as sp
     A = sp.csr_matrix((v, ci, rp), shape=(n, n))
     assert (np.linalg.norm(A @ X - X * res[0]["evals"], axis=0) / np.linalg.norm(X, axis=0)).max() <= 1e-10
+
+
+@pytest.mark.parametrize("world", [2, 5])
+def test_neighbour_exchange_equals_allgather(world):
+    # A banded matrix references only a halo of the neighbouring shards: the plan must pick the point-to-point
+    # exchange, move far fewer doubles than the all-gather, and change nothing in the results (same x values reach
+    # the same SpMV) — bit-identical eigenvalues and counters.
+    n, offsets, nev, ncv = 40_003, (1, 2, 3, 50, 51, 1500, 1501), 6, 20
+    halo = run_sharded(world, n, offsets, nev, ncv, sa.SortRule.LargestMagn, 1e-11)
+    full = run_sharded(world, n, offsets, nev, ncv, sa.SortRule.LargestMagn, 1e-11, exchange="allgather")
+    block = sa.shard_block(n, world)
+    for rank, (h, f) in enumerate(zip(halo, full)):
+        assert h["exchange"][0] and not f["exchange"][0]
+        neighbours = (rank > 0) + (rank < world - 1)
+        assert h["exchange"][1] == 1501 * neighbours
+        assert f["exchange"][1] == block * (world - 1)
+        assert h["nconv"] == f["nconv"] == nev
+        assert np.array_equal(h["evals"], f["evals"]) and np.array_equal(h["X"], f["X"])
+        assert (h["nops"], h["niter"]) == (f["nops"], f["niter"])
+
+
+def test_wide_pattern_keeps_the_allgather():
+    # couplings across half the matrix: every rank reads most of every other slice -> one all-gather is kept
+    n, world = 30_000, 3
+    res = run_sharded(world, n, (1, 7000, 14000), 4, 16, sa.SortRule.LargestAlge, 1e-10)
+    forced = run_sharded(world, n, (1, 7000, 14000), 4, 16, sa.SortRule.LargestAlge, 1e-10, exchange="halo")
+    for r, f in zip(res, forced):
+        assert not r["exchange"][0] and f["exchange"][0]
+        assert np.array_equal(r["evals"], f["evals"]) and r["nops"] == f["nops"]
+        assert r["res"].max() <= 1e-9

@@ -1,6 +1,9 @@
 """Per-kernel HBM bytes per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
 
-usage: python tools/pmc_summarize.py OUT/fetch_counter_collection.csv OUT/write_counter_collection.csv [n]
+usage: python tools/pmc_summarize.py OUT/fetch_counter_collection.csv OUT/write_counter_collection.csv [n] [out.json]
+
+With out.json, the corrected bytes per launch are also written as {"n": n, "kernels": {name: {"launches", "hbm_bytes"}}};
+bench.py reads the newest profiles/*pmc_traffic.json of the matching n to fill `roofline.traffic`.
 
 FETCH_SIZE / WRITE_SIZE are reported in KiB.  On gfx950 FETCH_SIZE counts 64 B per 128 B request for wide
 coalesced reads (MI355X_MICROARCH.md §HBM), so the read side is calibrated on the k_scale launches of the
@@ -8,6 +11,7 @@ probe, whose traffic is known exactly (8n bytes read, 8n written): factor = know
 every kernel.  Both raw and corrected numbers are printed.
 """
 import csv
+import json
 import sys
 from collections import defaultdict
 
@@ -41,10 +45,17 @@ def main():
             cal_w = known / (1024.0 * sum(write[k]) / len(write[k]))
     print(f"calibration on k_scale (8n = {known:.3e} B each way): read x{cal_r:.3f}, write x{cal_w:.3f}")
     print(f"{'kernel':62s} {'launches':>8s} {'fetch_raw_MB':>13s} {'write_raw_MB':>13s} {'hbm_corrected_MB':>17s}")
+    kernels = {}
     for k in sorted(fetch, key=lambda k: -sum(fetch[k])):
         fr = 1024.0 * sum(fetch[k]) / len(fetch[k])
         wr = 1024.0 * sum(write.get(k, [0.0])) / max(len(write.get(k, [0.0])), 1)
         print(f"{short(k):62s} {len(fetch[k]):8d} {fr / 1e6:13.2f} {wr / 1e6:13.2f} {(fr * cal_r + wr * cal_w) / 1e6:17.2f}")
+        kernels[short(k)] = {"launches": len(fetch[k]), "hbm_bytes": fr * cal_r + wr * cal_w}
+    if len(sys.argv) > 4:
+        with open(sys.argv[4], "w") as f:
+            json.dump({"n": n, "calibration": {"read": cal_r, "write": cal_w, "on": "k_scale (8n bytes each way)"},
+                       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/pmc_probe.py",
+                       "kernels": kernels}, f, indent=1)
 
 
 if __name__ == "__main__":
