@@ -215,7 +215,9 @@ int mispec_fac_residuals_complex(mispec_fac* fac, const double* Yre_host, const 
                                  int ncols, double* resid_host);
 
 /* Profile of the factorisation so far: counts and accumulated HIP-event time (ms) per kernel family.
- * Timing is only collected between mispec_fac_profile(fac, 1) and mispec_fac_profile(fac, 0). */
+ * Timing is only collected between mispec_fac_profile(fac, level) and mispec_fac_profile(fac, 0); level 1 brackets
+ * every kernel family with an event pair, level 2 only the operator applications (the SpMV roofline figure) —
+ * the event records cost a few microseconds each, which matters when the shards are small. */
 typedef struct mispec_profile
 {
     int64_t n_spmv, n_vtf, n_gemv, n_scale, n_compress, n_small, n_host_sync;

@@ -381,7 +381,7 @@ class SymEigsSolver:
         return out[:cnt.value].copy()
 
     def profile(self, enable):
-        check(lib().mispec_symeigs_profile(self.h, int(bool(enable))))
+        check(lib().mispec_symeigs_profile(self.h, int(enable)))  # 0 off, 1 all families, 2 SpMV only
 
     def get_profile(self):
         p = Profile()
@@ -478,7 +478,7 @@ class GenEigsSolver:
         return out[:cnt.value].copy()
 
     def profile(self, enable):
-        check(lib().mispec_geneigs_profile(self.h, int(bool(enable))))
+        check(lib().mispec_geneigs_profile(self.h, int(enable)))
 
     def get_profile(self):
         p = Profile()
@@ -618,7 +618,7 @@ class Factorization:
         return out
 
     def profile(self, enable):
-        check(lib().mispec_fac_profile(self.h, int(bool(enable))))
+        check(lib().mispec_fac_profile(self.h, int(enable)))
 
     def get_profile(self):
         p = Profile()

@@ -17,6 +17,8 @@
 #include "shiftsolve.hpp"
 #include "small.hpp"
 
+#include <Spectra/internal/SmallDense.h>
+
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -60,6 +62,8 @@ struct mispec_fac
     DevBuf<double> V, f, w, tmp, xfull, X, partials, alpha_partials, red, Qdev, d_diag, d_subd, d_evals, d_evecs, d_Y, gmax;
     DevBuf<int> d_info;
     DevBuf<StepState> d_state;     // device-driven step bookkeeping (krylov.hpp)
+    DevBuf<double> d_H;            // device-driven Arnoldi: the columns of H written by the steps (m x m)
+    PinnedBuf<double> h_H;
     PinnedBuf<StepState> h_state;  // its pinned host mirror
     PinnedBuf<double> h_red, h_small, h_x, h_y;
     bool device_steps = true;      // MISPEC_HOST_STEPS=1 forces the host-synchronous path
@@ -73,7 +77,7 @@ struct mispec_fac
     int x_cols = 0;    // columns currently held in X
 
     // profile
-    bool prof = false;
+    int prof = 0;  // 0 off, 1 every kernel family, 2 only the operator applications
     int64_t counts[FAM_COUNT] = {0, 0, 0, 0, 0, 0};
     int64_t n_sync = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[FAM_COUNT];
@@ -112,7 +116,10 @@ struct Timed
     Timed(mispec_fac& f, int family) : F(f), fam(family)
     {
         F.counts[fam]++;
-        if (!F.prof)
+        // level 2: only the operator applications are timed — plus the cheap scale kernel that precedes each of
+        // them, because an event's timestamp is only ordered after the previous *event*, not after the previous
+        // kernel: without that pair the SpMV interval would absorb the scale kernel (measured: +30 us).
+        if (!F.prof || (F.prof == 2 && fam != FAM_SPMV && fam != FAM_SCALE))
             return;
         e0 = take();
         e1 = take();
@@ -723,60 +730,157 @@ void factorize_lanczos(mispec_fac& F, int from_k, int to_m, int64_t* nmatop)
     F.k = to_m;
 }
 
+// The correction loop of an Arnoldi step (Arnoldi.h:264-291), host decisions.  On entry F.h_red holds the
+// record of the last f (V'f, beta, err) and red_buf(F.red_cur) the same on the device.
+void arnoldi_corrections_host(mispec_fac& F, int i)
+{
+    const double beta_thresh = kEps * std::sqrt(double(F.n));
+    const int i1 = i + 1;
+    double* h = &F.Hat(0, i);
+    double ortho_err = F.h_red.p[kSlotErr];
+    int count = 0;
+    while (count < 5 && ortho_err > kEps * F.beta)  // :266
+    {
+        if (F.beta < beta_thresh)
+        {
+            zero_vector(F, F.f.p);
+            F.beta = 0.0;
+            break;
+        }
+        double Vf[kMaxOrthCols];
+        for (int j = 0; j < i1; j++)
+            Vf[j] = F.h_red.p[j];
+        correct_vtf(F, F.f.p, F.f.p, i1);  // :281, :285, :287
+        for (int j = 0; j < i1; j++)
+            h[j] += Vf[j];  // :283
+        F.beta = F.h_red.p[kSlotBeta];
+        ortho_err = F.h_red.p[kSlotErr];
+        count++;
+    }
+}
+
+// One Arnoldi step with the host reading every scalar back (Arnoldi.h:225-292).
+void arnoldi_step_host(mispec_fac& F, int i, int64_t* nmatop)
+{
+    bool restart = false;
+    if (F.beta < kNear0)  // :228-233
+    {
+        expand_basis(F, i, 2 * int64_t(i), nmatop);
+        restart = true;
+    }
+    double* v = F.col(i);
+    {
+        Timed t(F, FAM_SCALE);
+        launch_scale(*F.ctx, F.f.p, v, F.ldv, F.beta);  // :236
+    }
+    F.Hat(i, i - 1) = restart ? 0.0 : F.beta;  // :239
+    apply_op(F, v, F.w.p, false, nullptr, 0.0);  // :242
+    (*nmatop)++;
+
+    const int i1 = i + 1;
+    vtf(F, F.w.p, i1, 0);  // h = V' w  (:251)
+    double* h = &F.Hat(0, i);
+    for (int j = 0; j < i1; j++)
+        h[j] = F.h_red.p[j];
+    // f = w - V h ; beta = |f| ; Vf = V' f   (:254-255, :262) — one pass over V
+    correct_vtf(F, F.w.p, F.f.p, i1);
+    F.beta = F.h_red.p[kSlotBeta];
+    if (F.beta > 0.717 * host_norm(h, i1))  // :257
+        return;
+    arnoldi_corrections_host(F, i);
+}
+
+// The same step enqueued without reading anything back: h, |h|, beta and the 0.717 test live in device
+// memory; a step that needs the correction loop (or the restart branch) stops the device run.
+void arnoldi_step_device(mispec_fac& F, int i)
+{
+    StepState* st = F.d_state.p;
+    double* v = F.col(i);
+    {
+        Timed t(F, FAM_SCALE);
+        launch_scale_step(*F.ctx, F.f.p, v, F.ldv, st, i, kNear0);  // :228 (restart branch -> host), :236, :239
+    }
+    apply_op(F, v, F.w.p, false, nullptr, 0.0);  // :242
+
+    const int i1 = i + 1;
+    FinishArgs fin;
+    fin.st = st;
+    fin.step = i;
+    fin.eps = kEps;
+    fin.beta_thresh = kEps * std::sqrt(double(F.n));
+    fin.hcol = F.d_H.p + size_t(i) * F.m;
+    {
+        OrthArgs a = orth_args(F, i1);
+        a.src = F.w.p;
+        a.status = &st->status;
+        Timed t(F, FAM_VTF);
+        const int nrec = launch_orth(*F.ctx, ORTH_VTF, a);
+        fin.mode = kFinishArnoldiH;
+        reduce_record(F, nrec, i1, 0, fin);
+    }
+    {
+        OrthArgs a = orth_args(F, i1);
+        a.src = F.w.p;
+        a.dst = F.f.p;
+        a.c_in = F.red_buf(0);
+        a.status = &st->status;
+        Timed t(F, FAM_GEMV);
+        const int nrec = launch_orth(*F.ctx, ORTH_CORRECT_VTF, a);
+        fin.mode = kFinishArnoldiF;
+        reduce_record(F, nrec, i1, 1, fin);
+    }
+}
+
 // Arnoldi.h:198-295
 void factorize_arnoldi(mispec_fac& F, int from_k, int to_m, int64_t* nmatop)
 {
-    const double beta_thresh = kEps * std::sqrt(double(F.n));
     zero_H_outside(F, from_k);
-
-    for (int i = from_k; i <= to_m - 1; i++)
+    const bool fast = F.device_steps && F.A != nullptr;
+    int i = from_k;
+    while (i <= to_m - 1)
     {
-        bool restart = false;
-        if (F.beta < kNear0)  // :228-233
+        if (!fast)
         {
-            expand_basis(F, i, 2 * int64_t(i), nmatop);
-            restart = true;
-        }
-        double* v = F.col(i);
-        {
-            Timed t(F, FAM_SCALE);
-            launch_scale(*F.ctx, F.f.p, v, F.ldv, F.beta);  // :236
-        }
-        F.Hat(i, i - 1) = restart ? 0.0 : F.beta;  // :239
-        apply_op(F, v, F.w.p, false, nullptr, 0.0);  // :242
-        (*nmatop)++;
-
-        const int i1 = i + 1;
-        vtf(F, F.w.p, i1, 0);  // h = V' w  (:251)
-        double* h = &F.Hat(0, i);
-        for (int j = 0; j < i1; j++)
-            h[j] = F.h_red.p[j];
-        // f = w - V h ; beta = |f| ; Vf = V' f   (:254-255, :262) — one pass over V
-        correct_vtf(F, F.w.p, F.f.p, i1);
-        F.beta = F.h_red.p[kSlotBeta];
-        if (F.beta > 0.717 * host_norm(h, i1))  // :257
+            arnoldi_step_host(F, i, nmatop);
+            i++;
             continue;
-
-        double ortho_err = F.h_red.p[kSlotErr];
-        int count = 0;
-        while (count < 5 && ortho_err > kEps * F.beta)  // :266
-        {
-            if (F.beta < beta_thresh)
-            {
-                zero_vector(F, F.f.p);
-                F.beta = 0.0;
-                break;
-            }
-            double Vf[kMaxOrthCols];
-            for (int j = 0; j < i1; j++)
-                Vf[j] = F.h_red.p[j];
-            correct_vtf(F, F.f.p, F.f.p, i1);  // :281, :285, :287
-            for (int j = 0; j < i1; j++)
-                h[j] += Vf[j];  // :283
-            F.beta = F.h_red.p[kSlotBeta];
-            ortho_err = F.h_red.p[kSlotErr];
-            count++;
         }
+        // ---- device-driven run of steps i .. to_m-1 -------------------------------------------------
+        StepState& hs = *F.h_state.p;
+        std::memset(&hs, 0, sizeof(StepState));
+        hs.beta = F.beta;
+        hs.status = kStepOk;
+        MISPEC_HIP(hipMemcpyAsync(F.d_state.p, &hs, sizeof(StepState), hipMemcpyHostToDevice, F.stream()));
+        for (int s = i; s <= to_m - 1; s++)
+            arnoldi_step_device(F, s);
+        MISPEC_HIP(hipMemcpyAsync(&hs, F.d_state.p, sizeof(StepState), hipMemcpyDeviceToHost, F.stream()));
+        MISPEC_HIP(hipMemcpyAsync(F.h_H.p, F.d_H.p, size_t(F.m) * F.m * sizeof(double), hipMemcpyDeviceToHost, F.stream()));
+        sync_stream(F);
+
+        const int status = hs.status;
+        const int stop = (status == kStepOk) ? to_m : hs.stop_step;
+        const int last_done = (status == kStepOk) ? to_m - 1 : (status == kStepSmallBeta ? stop - 1 : stop);
+        for (int j = i; j <= last_done; j++)  // bring H of the executed steps home
+        {
+            F.Hat(j, j - 1) = hs.subd[j - 1];
+            for (int r = 0; r <= j; r++)
+                F.Hat(r, j) = F.h_H.p[size_t(j) * F.m + r];
+        }
+        *nmatop += (last_done - i + 1);
+        F.beta = hs.beta;
+        if (status == kStepOk)
+            break;
+        // ---- the rare branches continue on the host path, then the device path resumes ---------------
+        if (status == kStepSmallBeta)
+            arnoldi_step_host(F, stop, nmatop);
+        else
+        {
+            F.red_cur = 1;  // VTF -> red[0], f = w - Vh -> red[1]
+            MISPEC_HIP(hipMemcpyAsync(F.h_red.p, F.red_buf(1), kPartialLd * sizeof(double), hipMemcpyDeviceToHost, F.stream()));
+            sync_stream(F);
+            arnoldi_corrections_host(F, stop);  // kStepTinyF takes the clamp branch at once
+        }
+        i = stop + 1;
     }
     F.k = to_m;
 }
@@ -877,6 +981,11 @@ int fac_create_impl(mispec_ctx* ctx, const mispec_csr* A, const mispec_symshift*
             F->d_Y.alloc(size_t(ncv) * ncv);
             F->d_info.alloc(1);
             F->d_state.alloc(1);
+            if (!F->symmetric)
+            {
+                F->d_H.alloc(size_t(ncv) * ncv);
+                F->h_H.alloc(size_t(ncv) * ncv);
+            }
             F->h_state.alloc(1);
             F->device_steps = !(getenv("MISPEC_HOST_STEPS") && atoi(getenv("MISPEC_HOST_STEPS")) != 0);
             F->h_red.alloc(kPartialLd + 8);
@@ -1057,6 +1166,25 @@ extern "C" int mispec_fac_tridiag_eigen(mispec_fac* fac, double* evals_host, dou
             hs[i] = F.Hat(i, i);
         for (int i = 0; i < m; i++)
             hs[m + i] = (i < m - 1) ? F.Hat(i + 1, i) : 0.0;
+        // H is on the host at this point (one read-back per factorisation sweep) and the Ritz pairs go back to the
+        // host for the convergence test, so by default the m x m eigen-decomposition — a serial chain of rotations,
+        // ~25 us on a host core against ~0.6 ms on one wavefront — runs where the data is.  MISPEC_SMALL=device
+        // keeps it on the GPU (k_tridiag_eigen_w64 / k_tridiag_eigen; same routine, internal/SmallDense.h).
+        static const bool on_device = getenv("MISPEC_SMALL") && std::string(getenv("MISPEC_SMALL")) == "device";
+        if (!on_device)
+        {
+            F.counts[FAM_SMALL]++;
+            std::vector<double> Q(evecs_host ? 0 : size_t(m) * m);
+            double* q = evecs_host ? evecs_host : Q.data();
+            std::fill(q, q + size_t(m) * m, 0.0);
+            for (int i = 0; i < m; i++)
+                q[size_t(i) * m + i] = 1.0;
+            const int rc = small::tridiag_eigen(m, hs, hs + m, q, m, small::Lanes{0, 1});
+            if (rc != 0)
+                throw Error(MISPEC_ERUNTIME, "TridiagEigen: eigen decomposition failed");  // TridiagEigen.h:204
+            std::copy(hs, hs + m, evals_host);
+            return;
+        }
         MISPEC_HIP(hipMemcpyAsync(F.d_diag.p, hs, size_t(m) * 8, hipMemcpyHostToDevice, F.stream()));
         MISPEC_HIP(hipMemcpyAsync(F.d_subd.p, hs + m, size_t(m) * 8, hipMemcpyHostToDevice, F.stream()));
         {
@@ -1224,7 +1352,7 @@ extern "C" int mispec_fac_profile(mispec_fac* fac, int enable)
         fac->ctx->make_current();
         if (!enable && fac->prof)
             drain_profile(*fac);
-        fac->prof = enable != 0;
+        fac->prof = (enable == 2) ? 2 : (enable != 0 ? 1 : 0);
     });
 }
 

@@ -230,6 +230,33 @@ __device__ void finish_record(double* red, int ncol, const FinishArgs& fa)
     StepState* st = fa.st;
     if (st->status != kStepOk)
         return;
+    if (fa.mode == kFinishArnoldiH)
+    {
+        double s = 0.0;
+        for (int j = 0; j < ncol; j++)
+        {
+            fa.hcol[j] = red[j];                            // Arnoldi.h:251
+            s = __dadd_rn(s, __dmul_rn(red[j], red[j]));    // the host path's plain loop (no contraction)
+        }
+        st->alpha = sqrt(s);
+        return;
+    }
+    if (fa.mode == kFinishArnoldiF)
+    {
+        st->beta = beta;
+        st->err = err;
+        st->count = 0;
+        st->need_corr = 0;
+        if (beta > 0.717 * st->alpha)  // Arnoldi.h:257: no re-orthogonalisation needed
+            return;
+        if (err > fa.eps * beta)       // Arnoldi.h:266: corrections run on the host path
+        {
+            st->status = (beta < fa.beta_thresh) ? kStepTinyF : kStepMoreCorr;
+            st->stop_step = fa.step;
+            st->stop_count = 0;
+        }
+        return;
+    }
     if (fa.mode == kFinishStepFirst)
     {
         st->alpha = *fa.alpha_src;
@@ -263,50 +290,76 @@ __device__ void finish_record(double* red, int ncol, const FinishArgs& fa)
     st->need_corr = need;
 }
 
-// One workgroup sums the records in a fixed order.  Thread t owns record t (and t+1024, ...): it issues the
-// loads of all its slots back to back (coalesced across the wave, one memory latency in total — the records
-// were written by other XCDs, so every load comes from beyond the L2), each wave shuffle-reduces every
-// slot, and sixteen per-wave partials per slot are added by one thread.
+// One workgroup sums the records in a fixed order.  A wave owns up to three slots per pass; its lane l adds
+// the records l, l+64, l+128, ... of each.  All loads of a pass are issued before the first add: the records were
+// written by other XCDs, so they come from beyond the L2 and one load latency is several microseconds — the kernel
+// must pay it once, not once per slot.  One shuffle tree per slot then finishes the sum.
+// Pass A covers columns 0..47 (wave g: g, g+16, g+32) and, while columns 46/47 are not in use, the two scalar
+// slots in their place; pass B (only for more than 46 columns) covers the rest.
+template <int NS>
+__device__ __forceinline__ void reduce_slots(const double* __restrict__ partials, int64_t pstride, int nrec, const int (&slot)[NS],
+                                             int lane, double* sh)
+{
+    constexpr int kBatch = 16;  // records per lane and round: 1024 records per round
+    double acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+        acc[s] = 0.0;
+    for (int base = 0; base < nrec; base += 64 * kBatch)
+    {
+        double x[NS][kBatch];
+#pragma unroll
+        for (int s = 0; s < NS; s++)
+#pragma unroll
+            for (int k = 0; k < kBatch; k++)
+            {
+                const int b = base + lane + 64 * k;
+                x[s][k] = (slot[s] >= 0 && b < nrec) ? partials[int64_t(slot[s]) * pstride + b] : 0.0;
+            }
+#pragma unroll
+        for (int s = 0; s < NS; s++)
+#pragma unroll
+            for (int k = 0; k < kBatch; k++)
+                acc[s] = (slot[s] == kSlotMaxAbs) ? fmax(acc[s], x[s][k]) : acc[s] + x[s][k];
+    }
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+    {
+        if (slot[s] < 0)
+            continue;  // wave-uniform
+        const double r = (slot[s] == kSlotMaxAbs) ? wave_reduce_max(acc[s]) : wave_reduce_sum(acc[s]);
+        if (lane == 0)
+            sh[slot[s]] = r;
+    }
+}
+
 __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restrict__ partials, int64_t pstride, int nrec,
                                                            int ncol, double* __restrict__ red, FinishArgs fin)
 {
-    __shared__ double wsum[16][kPartialLd];
     __shared__ double sh[kPartialLd];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    // slots [0, ncol) are sums, kSlotBeta2 a sum, kSlotMaxAbs a max
-    for (int j0 = 0; j0 < kPartialLd; j0 += 8)
-    {
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++)
-        {
-            const int j = j0 + u;
-            const bool is_sum = (j < ncol) || (j == kSlotBeta2);
-            const bool is_max = (j == kSlotMaxAbs);
-            v[u] = 0.0;
-            if (is_sum || is_max)
-                for (int b = tid; b < nrec; b += 1024)
-                {
-                    const double x = partials[int64_t(j) * pstride + b];
-                    v[u] = is_max ? fmax(v[u], x) : v[u] + x;
-                }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++)
-        {
-            const int j = j0 + u;
-            const double r = (j == kSlotMaxAbs) ? wave_reduce_max(v[u]) : wave_reduce_sum(v[u]);
-            if (lane == 0)
-                wsum[w][j] = r;
-        }
-    }
-    __syncthreads();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid < kPartialLd)
+        sh[tid] = 0.0;
+    __syncthreads();
+    const bool scalars_in_a = ncol <= 46;
     {
-        double acc = 0.0;
-        for (int k = 0; k < 16; k++)
-            acc = (tid == kSlotMaxAbs) ? fmax(acc, wsum[k][tid]) : acc + wsum[k][tid];
-        sh[tid] = acc;
+        int slot[3];
+        slot[0] = (g < ncol) ? g : -1;
+        slot[1] = (g + 16 < ncol) ? g + 16 : -1;
+        slot[2] = (g + 32 < ncol) ? g + 32 : -1;
+        if (scalars_in_a && g == 14)
+            slot[2] = kSlotMaxAbs;
+        if (scalars_in_a && g == 15)
+            slot[2] = kSlotBeta2;
+        reduce_slots<3>(partials, pstride, nrec, slot, lane, sh);
+    }
+    if (!scalars_in_a)
+    {
+        int slot[2];
+        slot[0] = (g + 48 < ncol) ? g + 48 : -1;
+        slot[1] = (g == 0) ? kSlotBeta2 : (g == 1 ? kSlotMaxAbs : -1);
+        reduce_slots<2>(partials, pstride, nrec, slot, lane, sh);
     }
     __syncthreads();
     if (tid == 0)

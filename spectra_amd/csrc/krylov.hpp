@@ -28,7 +28,7 @@ enum OrthMode
 struct StepState
 {
     double beta;   // |f| after the last completed reduction
-    double alpha;  // H(i,i) before corrections
+    double alpha;  // Lanczos: H(i,i) before corrections; Arnoldi: |h| of the current step
     double err;    // max |V'f|
     int count;     // corrections applied in the current step (Lanczos.h:155)
     int need_corr; // the while-condition of Lanczos.h:156 for the next correction
@@ -51,7 +51,9 @@ enum
     kFinishNone = 0,
     kFinishNorms = 1,      // beta = sqrt(sum f^2), err = max|c|
     kFinishStepFirst = 2,  // + bookkeeping after f = w - alpha v (Lanczos.h:142-153)
-    kFinishStepCorr = 3    // + bookkeeping after one correction (Lanczos.h:171-180)
+    kFinishStepCorr = 3,   // + bookkeeping after one correction (Lanczos.h:171-180)
+    kFinishArnoldiH = 4,   // Arnoldi: red[0..ncol) is h = V'w -> H(:, step), |h| (Arnoldi.h:251)
+    kFinishArnoldiF = 5    // Arnoldi: after f = w - Vh: beta, the 0.717 test and the need for corrections (Arnoldi.h:255-266)
 };
 struct FinishArgs
 {
@@ -63,6 +65,7 @@ struct FinishArgs
     double eps = 0.0;
     double beta_thresh = 0.0;
     int max_spec = 2;  // corrections that are enqueued speculatively per step
+    double* hcol = nullptr;  // Arnoldi: device column `step` of H
 };
 
 struct OrthArgs

@@ -102,3 +102,27 @@ def test_config4_nonsymmetric_band(ctx, n):
         A = sp.csr_matrix((v, ci, rp), shape=(n, n))
         X = eigs.eigenvectors()
         assert (np.linalg.norm(A @ X - X * evals, axis=0) / np.linalg.norm(X, axis=0)).max() <= 1e-10
+
+
+def test_device_driven_arnoldi_steps_equal_host_driven_steps():
+    # Device-driven Arnoldi steps (h, |h|, beta and the 0.717 test kept in device memory) must take exactly the
+    # decisions of the host-synchronous path: same kernels in the same order => bit-identical results and counters,
+    # with far fewer host synchronisations.
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); import spectra_amd as sa\n"
+        "op = sa.SparseGenMatProd.synth_band(200000)\n"
+        "e = sa.GenEigsSolver(op, 8, 24); e.init(); n = e.compute(sa.SortRule.LargestMagn, 1000, 1e-11)\n"
+        "print(n, e.num_operations(), e.num_iterations(), e.eigenvalues().tobytes().hex(), e.get_profile()['n_host_sync'])\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for host in ("0", "1"):
+        env = dict(os.environ, MISPEC_HOST_STEPS=host)
+        r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        outs.append(r.stdout.split())
+    assert outs[0][:4] == outs[1][:4]
+    assert float(outs[0][4]) < 0.5 * float(outs[1][4])

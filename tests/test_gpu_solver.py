@@ -227,3 +227,27 @@ def test_device_driven_steps_equal_host_driven_steps():
         outs.append(r.stdout.split())
     assert outs[0][:4] == outs[1][:4]
     assert float(outs[0][4]) < 0.25 * float(outs[1][4])  # and with far fewer host synchronisations
+
+
+def test_ritz_pairs_on_device_or_host_give_the_same_solve():
+    # The m x m eigen-decomposition of the restart runs on the host by default (H is already there) and on one
+    # wavefront with MISPEC_SMALL=device; both are the same routine (internal/SmallDense.h), so the solves agree
+    # to rounding and take the same number of operations.
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); import spectra_amd as sa\n"
+        "op = sa.SparseSymMatProd.synth_band(200000)\n"
+        "e = sa.SymEigsSolver(op, 10, 30); e.init(); n = e.compute(sa.SortRule.BothEnds, 1000, 1e-11)\n"
+        "print(n, e.num_operations(), e.num_iterations(), ' '.join(repr(float(x)) for x in e.eigenvalues()))\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for mode in ("host", "device"):
+        env = dict(os.environ, MISPEC_SMALL=mode)
+        r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        outs.append(r.stdout.split())
+    assert outs[0][:3] == outs[1][:3]
+    a, b = np.array(outs[0][3:], dtype=float), np.array(outs[1][3:], dtype=float)
+    assert np.abs(a - b).max() <= 1e-12
