@@ -39,6 +39,12 @@ template <typename T>
 struct has_device_solver<T, std::void_t<decltype(std::declval<const T&>().mispec_solver())>> : std::true_type
 {};
 template <typename T, typename = void>
+struct has_device_product : std::false_type
+{};
+template <typename T>
+struct has_device_product<T, std::void_t<decltype(std::declval<const T&>().mispec_product_second())>> : std::true_type
+{};
+template <typename T, typename = void>
 struct has_device_context : std::false_type
 {};
 template <typename T>
@@ -97,6 +103,18 @@ protected:
                                           symmetric ? 1 : 0, &raw));
         m_fac = std::shared_ptr<mispec_fac>(raw, [](mispec_fac* p) { (void) mispec_fac_destroy(p); });
     }
+    // y = A2 (A x) with both factors in HBM (contrib/PartialSVDSolver.h's A'A / AA' operators)
+    template <typename T = OpType>
+    typename std::enable_if<internal::has_device_product<T>::value>::type bind(bool symmetric)
+    {
+        if (!symmetric)
+            throw std::invalid_argument("Arnoldi: product operators are symmetric (Lanczos) only");
+        m_ctx = internal::borrow_context(m_op.mispec_context());
+        mispec_fac* raw = nullptr;
+        internal::check(mispec_fac_create_product(m_ctx.get(), m_op.mispec_product_first(), m_op.mispec_product_second(),
+                                                  static_cast<int>(m_m), &raw));
+        m_fac = std::shared_ptr<mispec_fac>(raw, [](mispec_fac* p) { (void) mispec_fac_destroy(p); });
+    }
     template <typename T = OpType>
     typename std::enable_if<internal::has_device_solver<T>::value>::type bind(bool symmetric)
     {
@@ -107,8 +125,9 @@ protected:
         m_fac = std::shared_ptr<mispec_fac>(raw, [](mispec_fac* p) { (void) mispec_fac_destroy(p); });
     }
     template <typename T = OpType>
-    typename std::enable_if<!internal::has_device_matrix<T>::value && !internal::has_device_solver<T>::value>::type bind(
-        bool symmetric)
+    typename std::enable_if<!internal::has_device_matrix<T>::value && !internal::has_device_solver<T>::value &&
+                            !internal::has_device_product<T>::value>::type
+    bind(bool symmetric)
     {
         m_ctx = internal::context_of(m_op);
         mispec_fac* raw = nullptr;

@@ -1,0 +1,267 @@
+// Truncated SVD of a sparse matrix through the symmetric eigen solver — counterpart of the reference's
+// contrib/PartialSVDSolver.h:16-213 (same classes, members and defaults): the k largest singular
+// triplets of an m x n matrix M from the k largest eigenpairs of M'M (tall, m > n) or MM' (wide).
+//
+// MI355X form: M and M' are both copied to HBM as CSR once (the CSC arrays of M are the CSR arrays of
+// M'), and the operator y = M'(M x) / M(M' x) is two chained CSR-stream SpMVs inside the device Lanczos
+// loop (mispec_fac_create_product); the Krylov basis never leaves the GPU.  perform_op() keeps the
+// reference's host-pointer contract for callers that use the operator classes directly.
+// Dense MatrixType (the reference's default template argument) is outside this library's scope: pass a
+// Spectra::SparseView<double> or, with Eigen on the include path, an Eigen::SparseMatrix<double>.
+#ifndef MISPEC_SPECTRA_PARTIAL_SVD_SOLVER_H
+#define MISPEC_SPECTRA_PARTIAL_SVD_SOLVER_H
+
+#include <algorithm>
+#include <cmath>
+#include <memory>
+#include <vector>
+
+#include "../SymEigsSolver.h"
+
+namespace Spectra {
+
+namespace internal {
+
+// M (rows x cols) and M' as device CSR matrices built from one compressed host matrix.
+struct DeviceCsrPair
+{
+    CtxPtr ctx;
+    std::shared_ptr<mispec_csr> mat, mat_t;
+
+    DeviceCsrPair(const SparseView<double, int>& v, CtxPtr c) : ctx(c ? c : default_context())
+    {
+        mispec_csr *a = nullptr, *at = nullptr;
+        if (v.row_major)
+        {
+            check(mispec_csr_upload(ctx.get(), v.rows, v.cols, v.outer, v.inner, v.values, &a));
+            mat.reset(a, [](mispec_csr* p) { (void) mispec_csr_destroy(p); });
+            check(mispec_csr_from_csc(ctx.get(), v.cols, v.rows, v.outer, v.inner, v.values, &at));
+            mat_t.reset(at, [](mispec_csr* p) { (void) mispec_csr_destroy(p); });
+        }
+        else
+        {
+            check(mispec_csr_from_csc(ctx.get(), v.rows, v.cols, v.outer, v.inner, v.values, &a));
+            mat.reset(a, [](mispec_csr* p) { (void) mispec_csr_destroy(p); });
+            check(mispec_csr_upload(ctx.get(), v.cols, v.rows, v.outer, v.inner, v.values, &at));
+            mat_t.reset(at, [](mispec_csr* p) { (void) mispec_csr_destroy(p); });
+        }
+    }
+};
+
+inline SparseView<double, int> svd_view(const SparseView<double, int>& v) { return v; }
+#ifdef MISPEC_HAVE_EIGEN
+template <int Flags>
+SparseView<double, int> svd_view(const Eigen::SparseMatrix<double, Flags, int>& m)
+{
+    if (!m.isCompressed())
+        throw std::invalid_argument("PartialSVDSolver: the sparse matrix must be compressed (call makeCompressed())");
+    SparseView<double, int> v;
+    v.rows = m.rows();
+    v.cols = m.cols();
+    v.outer = m.outerIndexPtr();
+    v.inner = m.innerIndexPtr();
+    v.values = m.valuePtr();
+    v.row_major = (Flags & Eigen::RowMajorBit) != 0;
+    return v;
+}
+#endif
+
+}  // namespace internal
+
+// Abstract class for matrix operation (contrib/PartialSVDSolver.h:16-34) + the hooks the device Lanczos binds.
+template <typename Scalar_>
+class SVDMatOp
+{
+public:
+    using Scalar = Scalar_;
+    static_assert(std::is_same<Scalar_, double>::value, "the MI355X path computes in fp64: Scalar must be double");
+
+    virtual Index rows() const = 0;
+    virtual Index cols() const = 0;
+    // y_out = A' * A * x_in or y_out = A * A' * x_in   (host pointers)
+    virtual void perform_op(const Scalar* x_in, Scalar* y_out) const = 0;
+
+    virtual mispec_ctx* mispec_context() const = 0;
+    virtual const mispec_csr* mispec_product_first() const = 0;   // applied to x
+    virtual const mispec_csr* mispec_product_second() const = 0;  // applied to the result
+
+    virtual ~SVDMatOp() {}
+};
+
+// Operation of a tall matrix in SVD: eigenvalues of A' * A   (contrib/PartialSVDSolver.h:36-72)
+template <typename Scalar, typename MatrixType>
+class SVDTallMatOp : public SVDMatOp<Scalar>
+{
+    std::shared_ptr<internal::DeviceCsrPair> m_dev;
+    const Index m_dim;
+    mutable std::vector<Scalar> m_cache;
+
+public:
+    SVDTallMatOp(const MatrixType& mat, internal::CtxPtr ctx = internal::CtxPtr()) :
+        SVDTallMatOp(std::make_shared<internal::DeviceCsrPair>(internal::svd_view(mat), ctx))
+    {}
+    explicit SVDTallMatOp(std::shared_ptr<internal::DeviceCsrPair> dev) :
+        m_dev(dev),
+        m_dim((std::min)(mispec_csr_rows(dev->mat.get()), mispec_csr_cols(dev->mat.get()))),
+        m_cache(static_cast<std::size_t>(mispec_csr_rows(dev->mat.get())))
+    {}
+
+    // These are the rows and columns of A' * A
+    Index rows() const override { return m_dim; }
+    Index cols() const override { return m_dim; }
+
+    // y_out = A' * A * x_in
+    void perform_op(const Scalar* x_in, Scalar* y_out) const override
+    {
+        internal::check(mispec_spmv_host(m_dev->mat.get(), x_in, m_cache.data()));
+        internal::check(mispec_spmv_host(m_dev->mat_t.get(), m_cache.data(), y_out));
+    }
+
+    mispec_ctx* mispec_context() const override { return m_dev->ctx.get(); }
+    const mispec_csr* mispec_product_first() const override { return m_dev->mat.get(); }
+    const mispec_csr* mispec_product_second() const override { return m_dev->mat_t.get(); }
+};
+
+// Operation of a wide matrix in SVD: eigenvalues of A * A'   (contrib/PartialSVDSolver.h:74-110)
+template <typename Scalar, typename MatrixType>
+class SVDWideMatOp : public SVDMatOp<Scalar>
+{
+    std::shared_ptr<internal::DeviceCsrPair> m_dev;
+    const Index m_dim;
+    mutable std::vector<Scalar> m_cache;
+
+public:
+    SVDWideMatOp(const MatrixType& mat, internal::CtxPtr ctx = internal::CtxPtr()) :
+        SVDWideMatOp(std::make_shared<internal::DeviceCsrPair>(internal::svd_view(mat), ctx))
+    {}
+    explicit SVDWideMatOp(std::shared_ptr<internal::DeviceCsrPair> dev) :
+        m_dev(dev),
+        m_dim((std::min)(mispec_csr_rows(dev->mat.get()), mispec_csr_cols(dev->mat.get()))),
+        m_cache(static_cast<std::size_t>(mispec_csr_cols(dev->mat.get())))
+    {}
+
+    // These are the rows and columns of A * A'
+    Index rows() const override { return m_dim; }
+    Index cols() const override { return m_dim; }
+
+    // y_out = A * A' * x_in
+    void perform_op(const Scalar* x_in, Scalar* y_out) const override
+    {
+        internal::check(mispec_spmv_host(m_dev->mat_t.get(), x_in, m_cache.data()));
+        internal::check(mispec_spmv_host(m_dev->mat.get(), m_cache.data(), y_out));
+    }
+
+    mispec_ctx* mispec_context() const override { return m_dev->ctx.get(); }
+    const mispec_csr* mispec_product_first() const override { return m_dev->mat_t.get(); }
+    const mispec_csr* mispec_product_second() const override { return m_dev->mat.get(); }
+};
+
+// Partial SVD solver (contrib/PartialSVDSolver.h:112-209)
+template <typename MatrixType = SparseView<double, int>>
+class PartialSVDSolver
+{
+private:
+    using Scalar = double;
+    using Matrix = DenseMatrix<Scalar>;
+    using Vector = DenseVector<Scalar>;
+
+    std::shared_ptr<internal::DeviceCsrPair> m_dev;
+    const Index m_m;
+    const Index m_n;
+    std::unique_ptr<SVDMatOp<Scalar>> m_op;
+    std::unique_ptr<SymEigsSolver<SVDMatOp<Scalar>>> m_eigs;
+    Index m_nconv = 0;
+    Matrix m_evecs;
+
+    // mat * (evecs[:, :k] ./ sqrt(evals[:k]))  on the device matrix `A` (rows x inner)
+    Matrix scaled_product(const mispec_csr* A, Index k) const
+    {
+        const Vector evals = m_eigs->eigenvalues();
+        Matrix scaled(m_evecs.rows(), k);
+        for (Index j = 0; j < k; j++)
+        {
+            const Scalar s = std::sqrt(evals[j]);
+            for (Index i = 0; i < m_evecs.rows(); i++)
+                scaled(i, j) = m_evecs(i, j) / s;
+        }
+        Matrix res(static_cast<Index>(mispec_csr_rows(A)), k);
+        if (k > 0)
+            internal::check(
+                mispec_spmm_host(A, scaled.data(), scaled.rows(), static_cast<int>(k), res.data(), res.rows()));
+        return res;
+    }
+
+public:
+    // Constructor
+    PartialSVDSolver(const MatrixType& mat, Index ncomp, Index ncv, internal::CtxPtr ctx = internal::CtxPtr()) :
+        m_dev(std::make_shared<internal::DeviceCsrPair>(internal::svd_view(mat), ctx)),
+        m_m(static_cast<Index>(mispec_csr_rows(m_dev->mat.get()))),
+        m_n(static_cast<Index>(mispec_csr_cols(m_dev->mat.get())))
+    {
+        // Determine the matrix type, tall or wide
+        if (m_m > m_n)
+            m_op.reset(new SVDTallMatOp<Scalar, MatrixType>(m_dev));
+        else
+            m_op.reset(new SVDWideMatOp<Scalar, MatrixType>(m_dev));
+        // Solver object
+        m_eigs.reset(new SymEigsSolver<SVDMatOp<Scalar>>(*m_op, ncomp, ncv));
+    }
+
+    // Computation
+    Index compute(Index maxit = 1000, Scalar tol = 1e-10)
+    {
+        m_eigs->init();
+        m_nconv = m_eigs->compute(SortRule::LargestAlge, maxit, tol);
+        m_evecs = Matrix();
+        return m_nconv;
+    }
+
+    CompInfo info() const { return m_eigs->info(); }
+    Index num_iterations() const { return m_eigs->num_iterations(); }
+    Index num_operations() const { return m_eigs->num_operations(); }
+
+    // The converged singular values
+    Vector singular_values() const
+    {
+        Vector svals = m_eigs->eigenvalues();
+        for (Index i = 0; i < svals.size(); i++)
+            svals[i] = std::sqrt(svals[i]);
+        return svals;
+    }
+
+    // The converged left singular vectors
+    Matrix matrix_U(Index nu)
+    {
+        if (m_evecs.cols() < 1)
+            m_evecs = m_eigs->eigenvectors();
+        nu = (std::min)(nu, m_nconv);
+        if (m_m <= m_n)
+            return left_cols(nu);
+        return scaled_product(m_dev->mat.get(), nu);
+    }
+
+    // The converged right singular vectors
+    Matrix matrix_V(Index nv)
+    {
+        if (m_evecs.cols() < 1)
+            m_evecs = m_eigs->eigenvectors();
+        nv = (std::min)(nv, m_nconv);
+        if (m_m > m_n)
+            return left_cols(nv);
+        return scaled_product(m_dev->mat_t.get(), nv);
+    }
+
+private:
+    Matrix left_cols(Index k) const
+    {
+        Matrix res(m_evecs.rows(), k);
+        for (Index j = 0; j < k; j++)
+            for (Index i = 0; i < m_evecs.rows(); i++)
+                res(i, j) = m_evecs(i, j);
+        return res;
+    }
+};
+
+}  // namespace Spectra
+
+#endif  // MISPEC_SPECTRA_PARTIAL_SVD_SOLVER_H

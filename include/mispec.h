@@ -165,6 +165,10 @@ typedef int (*mispec_op_fn)(void* user, const double* x_in_host, double* y_out_h
 int mispec_fac_create(mispec_ctx* ctx, const mispec_csr* A, mispec_op_fn op, void* op_user, int64_t n, int ncv,
                       int symmetric, mispec_fac** out);
 /* The same with the operator (A - sigma I)^{-1} of a device-resident shift solver (SymEigsShiftSolver path). */
+/* Product operator y = A2 (A x) with A (p x n) and A2 (n x p) resident in HBM — the SVDTallMatOp (A2 = A') /
+ * SVDWideMatOp (A = M', A2 = M) of contrib/PartialSVDSolver.h:36-110 as two chained SpMVs; symmetric (Lanczos).
+ * Not available on a row-sharded context. */
+int mispec_fac_create_product(mispec_ctx* ctx, const mispec_csr* A, const mispec_csr* A2, int ncv, mispec_fac** out);
 int mispec_fac_create_shiftsolve(mispec_ctx* ctx, const mispec_symshift* S, int ncv, int symmetric, mispec_fac** out);
 int mispec_fac_destroy(mispec_fac* fac);
 /* Arnoldi::init (Arnoldi.h:136-195).  v0_host: n doubles (the GLOBAL vector; each shard takes its rows).
@@ -246,6 +250,9 @@ int mispec_symeigs_create_op(mispec_ctx* ctx, mispec_op_fn op, void* op_user, in
                              mispec_symeigs** out);
 /* Spectra::SymEigsShiftSolver<Spectra::SparseSymShiftSolve<double>> (SymEigsShiftSolver.h:190-195): calls
  * set_shift(sigma) on S, iterates on (A - sigma I)^{-1} and maps the Ritz values back (lambda = 1/nu + sigma). */
+/* SymEigsSolver over the product operator of mispec_fac_create_product (PartialSVDSolver's inner solver). */
+int mispec_symeigs_create_product(mispec_ctx* ctx, const mispec_csr* A, const mispec_csr* A2, int64_t nev, int64_t ncv,
+                                  mispec_symeigs** out);
 int mispec_symeigs_create_shift(mispec_ctx* ctx, mispec_symshift* S, int64_t nev, int64_t ncv, double sigma, mispec_symeigs** out);
 int mispec_symeigs_destroy(mispec_symeigs* s);
 int mispec_symeigs_init(mispec_symeigs* s, const double* v0_host /* NULL = init() */);

@@ -50,6 +50,7 @@ def lib():
             "oracle_lcg_states": (None, [C.c_long, C.c_long, lp]),
             "oracle_minstd_states": (None, [C.c_long, C.c_long, lp]),
             "oracle_gen_sparse_data": (C.c_long, [C.c_int, C.c_double, ip, ip, dp]),
+            "oracle_gen_sparse_data_rect": (C.c_long, [C.c_int, C.c_int, C.c_double, ip, ip, dp]),
             "oracle_synth_band_csr": (C.c_long, [C.c_long, C.c_ulonglong, lp, C.c_int, C.c_int, ip, ip, dp]),
             "oracle_synth_value": (C.c_double, [C.c_ulonglong, C.c_ulonglong, C.c_ulonglong]),
             "oracle_givens": (None, [C.c_double, C.c_double, dp, dp, dp]),
@@ -165,6 +166,43 @@ def gen_sparse_data(n, prob):
     v = np.empty(cnt)
     lib().oracle_gen_sparse_data(n, prob, _ip(r), _ip(c), _dp(v))
     return r, c, v
+
+
+def gen_sparse_data_rect(m, n, prob):
+    """test/SVD.cpp:17-33 fixture (m x n) as COO (rows, cols, vals)."""
+    cnt = lib().oracle_gen_sparse_data_rect(m, n, prob, None, None, None)
+    r = np.empty(cnt, dtype=np.int32)
+    c = np.empty(cnt, dtype=np.int32)
+    v = np.empty(cnt)
+    lib().oracle_gen_sparse_data_rect(m, n, prob, _ip(r), _ip(c), _dp(v))
+    return r, c, v
+
+
+def partial_svd(A, ncomp, ncv, maxit=1000, tol=1e-10):
+    """contrib/PartialSVDSolver.h:112-209 restated on top of the SymEigs oracle: A is a scipy sparse matrix; the
+    operator A'A (tall) / AA' (wide) is applied through a callback (two scipy products, :64-71 / :102-109).
+    Returns (nconv, singular values, U, V)."""
+    import scipy.sparse as sp
+
+    A = sp.csr_matrix(A)
+    At = sp.csr_matrix(A.T)
+    m, n = A.shape
+    tall = m > n
+    dim = min(m, n)
+    op = Op.callback(dim, (lambda x: At @ (A @ x)) if tall else (lambda x: A @ (At @ x)))
+    eigs = SymEigsSolver(op, ncomp, ncv)
+    eigs.init()
+    nconv = eigs.compute(LargestAlge, maxit, tol)
+    ev = eigs.eigenvalues()
+    X = eigs.eigenvectors()
+    sv = np.sqrt(ev)
+    if tall:
+        V = X
+        U = A @ (X / sv)
+    else:
+        U = X
+        V = At @ (X / sv)
+    return nconv, sv, U, V
 
 
 BAND_OFFSETS = (1, 2, 3, 1000, 1001, 100000, 100001)  # SURVEY §8(d) M-band

@@ -92,6 +92,29 @@ long oracle_gen_sparse_data(int n, double prob, int* rows, int* cols, double* va
     return cnt;
 }
 
+// ---- test/SVD.cpp:17-33 gen_sparse_data(m, n, prob): the rectangular fixture of the partial SVD tests --
+long oracle_gen_sparse_data_rect(int m, int n, double prob, int* rows, int* cols, double* vals)
+{
+    std::default_random_engine gen;
+    gen.seed(0);
+    std::uniform_real_distribution<double> distr(0.0, 1.0);
+    long cnt = 0;
+    for (int i = 0; i < m; i++)
+        for (int j = 0; j < n; j++)
+            if (distr(gen) < prob)
+            {
+                const double v = distr(gen) - 0.5;
+                if (rows)
+                {
+                    rows[cnt] = i;
+                    cols[cnt] = j;
+                    vals[cnt] = v;
+                }
+                cnt++;
+            }
+    return cnt;
+}
+
 // ---- synthetic benchmark matrices ------------------------------
 // Row i holds columns i+off for every signed offset in {0} U {+-offsets[k]} that lands in [0,n),
 // ascending.  rowptr may be NULL to just count.

@@ -17,7 +17,7 @@ from . import _capi
 from ._capi import MispecError, Profile, build_library, check, lib
 
 __all__ = ["SortRule", "CompInfo", "Context", "SparseSymMatProd", "SparseGenMatProd", "SparseSymShiftSolve", "SymEigsSolver",
-           "SymEigsShiftSolver", "GenEigsSolver",
+           "SymEigsShiftSolver", "GenEigsSolver", "SVDMatOp", "PartialSVDSolver", "shard_block",
            "Factorization", "tridiag_qr", "tridiag_eigen", "hess_qr", "double_shift_qr", "hess_schur", "hess_eigen", "MispecError", "build_library", "shard_range", "BAND_OFFSETS", "SYNTH_SEED"]
 
 BAND_OFFSETS = (1, 2, 3, 1000, 1001, 100000, 100001)  # SURVEY.md §8(d) "M-band": 15 nnz/row with the diagonal
@@ -315,6 +315,69 @@ class _UserOp:
         self.cb = _capi.op_fn(tramp)
 
 
+class SVDMatOp:
+    """contrib/PartialSVDSolver.h:16-110: the operator A'A (tall A, SVDTallMatOp) or AA' (wide A, SVDWideMatOp) as two
+    device CSR matrices applied one after the other inside the device Lanczos loop."""
+
+    def __init__(self, mat, ctx=None):
+        import scipy.sparse as sp
+
+        self.ctx = ctx or default_context()
+        mat = sp.csr_matrix(mat)
+        self.m, self.n = mat.shape
+        self.mat = SparseGenMatProd(mat, ctx=self.ctx)
+        self.mat_t = SparseGenMatProd(sp.csr_matrix(mat.T), ctx=self.ctx)
+        self.tall = self.m > self.n
+        self.first, self.second = (self.mat, self.mat_t) if self.tall else (self.mat_t, self.mat)
+
+    def rows(self):
+        return min(self.m, self.n)
+
+    cols = rows
+
+    def local_rows(self):
+        return self.rows()
+
+    def perform_op(self, x):
+        return self.second.perform_op(self.first.perform_op(x))
+
+
+class PartialSVDSolver:
+    """contrib/PartialSVDSolver.h:112-209: the ncomp largest singular triplets through SymEigsSolver(LargestAlge)."""
+
+    def __init__(self, mat, ncomp, ncv, ctx=None):
+        self.op = SVDMatOp(mat, ctx)
+        self.eigs = SymEigsSolver(self.op, ncomp, ncv)
+        self.nconv = 0
+        self._evecs = None
+
+    def compute(self, maxit=1000, tol=1e-10):
+        self.eigs.init()
+        self.nconv = self.eigs.compute(SortRule.LargestAlge, maxit, tol)
+        self._evecs = None
+        return self.nconv
+
+    def singular_values(self):
+        return np.sqrt(self.eigs.eigenvalues())
+
+    def _vectors(self):
+        if self._evecs is None:
+            self._evecs = self.eigs.eigenvectors()
+        return self._evecs
+
+    def _scaled(self, A, k):
+        ev = self.eigs.eigenvalues()
+        return A @ np.asfortranarray(self._vectors()[:, :k] / np.sqrt(ev[:k]))
+
+    def matrix_U(self, nu):
+        nu = min(int(nu), self.nconv)
+        return self._vectors()[:, :nu] if self.op.m <= self.op.n else self._scaled(self.op.mat, nu)
+
+    def matrix_V(self, nv):
+        nv = min(int(nv), self.nconv)
+        return self._vectors()[:, :nv] if self.op.m > self.op.n else self._scaled(self.op.mat_t, nv)
+
+
 class SymEigsSolver:
     """SymEigsSolver.h:133-160 / HermEigsBase.h: init(), compute(), info(), eigenvalues(), eigenvectors() ..."""
 
@@ -324,6 +387,10 @@ class SymEigsSolver:
         if isinstance(op, _DeviceMatrix):
             self.ctx = op.ctx
             check(lib().mispec_symeigs_create(self.ctx.h, op.h, int(nev), int(ncv), C.byref(h)))
+            self._user = None
+        elif isinstance(op, SVDMatOp):  # y = A2 (A x), both factors in HBM
+            self.ctx = op.ctx
+            check(lib().mispec_symeigs_create_product(self.ctx.h, op.first.h, op.second.h, int(nev), int(ncv), C.byref(h)))
             self._user = None
         else:  # any object with rows(), cols(), perform_op(x) -> y: the reference's OpType concept
             self.ctx = ctx or default_context()
@@ -360,7 +427,7 @@ class SymEigsSolver:
         return out[:cnt.value].copy()
 
     def local_rows(self):
-        return self.op.local_rows() if isinstance(self.op, _DeviceMatrix) else self.op.rows()
+        return self.op.local_rows() if isinstance(self.op, (_DeviceMatrix, SVDMatOp)) else self.op.rows()
 
     def eigenvectors(self, nvec=None, to_host=True):
         """n x nconv (this shard's rows).  to_host=False leaves the result in HBM and returns the column count."""

@@ -94,6 +94,7 @@ SIGNATURES = {
     "mispec_symshift_solve_host": (C.c_int, [_vp, _dp, _dp]),
     "mispec_fac_create": (C.c_int, [_vp, _vp, op_fn, _vp, C.c_int64, C.c_int, C.c_int, _vpp]),
     "mispec_fac_create_shiftsolve": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vpp]),
+    "mispec_fac_create_product": (C.c_int, [_vp, _vp, _vp, C.c_int, _vpp]),
     "mispec_fac_destroy": (C.c_int, [_vp]),
     "mispec_fac_init": (C.c_int, [_vp, _dp, _lp]),
     "mispec_fac_init_random": (C.c_int, [_vp, C.c_uint64, _lp]),
@@ -120,6 +121,7 @@ SIGNATURES = {
     "mispec_symeigs_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vpp]),
     "mispec_symeigs_create_op": (C.c_int, [_vp, op_fn, _vp, C.c_int64, C.c_int64, C.c_int64, _vpp]),
     "mispec_symeigs_create_shift": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_double, _vpp]),
+    "mispec_symeigs_create_product": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int64, _vpp]),
     "mispec_symeigs_destroy": (C.c_int, [_vp]),
     "mispec_symeigs_init": (C.c_int, [_vp, _dp]),
     "mispec_symeigs_compute": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_double, C.c_int, _lp]),

@@ -45,6 +45,7 @@ struct mispec_fac
 {
     mispec_ctx* ctx = nullptr;
     const mispec_csr* A = nullptr;
+    const mispec_csr* A2 = nullptr;      // product operator y = A2 (A x) (contrib/PartialSVDSolver.h: A'A or AA'); else nullptr
     const mispec_symshift* S = nullptr;  // operator = (A - sigma I)^{-1} on the device
     mispec_op_fn op = nullptr;
     void* op_user = nullptr;
@@ -59,6 +60,7 @@ struct mispec_fac
     double beta = 0.0;
     std::vector<double> H;  // m x m column-major, host
 
+    DevBuf<double> mid;  // product operator: A x
     DevBuf<double> V, f, w, tmp, xfull, X, partials, alpha_partials, red, Qdev, d_diag, d_subd, d_evals, d_evecs, d_Y, gmax;
     DevBuf<int> d_info;
     DevBuf<StepState> d_state;     // device-driven step bookkeeping (krylov.hpp)
@@ -300,6 +302,13 @@ void apply_op(mispec_fac& F, const double* x_loc, double* y_loc, bool lanczos_ep
             x = F.xfull.p;
         }
         Timed t(F, FAM_SPMV);
+        const mispec_csr* last = F.A;
+        if (F.A2)  // y = A2 (A x): the epilogue rides on the second product
+        {
+            launch_spmv(*F.A, x, F.mid.p, nullptr);
+            x = F.mid.p;
+            last = F.A2;
+        }
         if (lanczos_epi)
         {
             SpmvEpilogue epi;
@@ -309,10 +318,10 @@ void apply_op(mispec_fac& F, const double* x_loc, double* y_loc, bool lanczos_ep
             epi.h_prev_dev = h_prev_dev;
             epi.status = status;
             epi.partials = F.alpha_partials.p;
-            launch_spmv(*F.A, x, y_loc, &epi);
+            launch_spmv(*last, x, y_loc, &epi);
         }
         else
-            launch_spmv(*F.A, x, y_loc, nullptr);
+            launch_spmv(*last, x, y_loc, nullptr);
     }
     else if (F.S)
     {
@@ -912,7 +921,7 @@ void update_f_after_compress(mispec_fac& F, double q_last, double h_sub)
 // =================================================================================================
 namespace {
 int fac_create_impl(mispec_ctx* ctx, const mispec_csr* A, const mispec_symshift* S, mispec_op_fn op, void* op_user, int64_t n,
-                    int ncv, int symmetric, mispec_fac** out)
+                    int ncv, int symmetric, mispec_fac** out, const mispec_csr* A2 = nullptr)
 {
     return guarded([&] {
         MISPEC_REQUIRE(ctx && out, "mispec_fac_create: NULL argument");
@@ -920,7 +929,14 @@ int fac_create_impl(mispec_ctx* ctx, const mispec_csr* A, const mispec_symshift*
         MISPEC_REQUIRE(n >= 1, "mispec_fac_create: n must be positive");
         MISPEC_REQUIRE(ncv >= 1 && ncv <= n, "mispec_fac_create: need 1 <= ncv <= n");
         MISPEC_REQUIRE(ncv <= kMaxOrthCols, "mispec_fac_create: the device factorisation holds at most 64 basis vectors (ncv <= 64)");
-        if (A)
+        if (A && A2)
+        {
+            MISPEC_REQUIRE(A->ctx == ctx && A2->ctx == ctx, "mispec_fac_create_product: matrix belongs to another context");
+            MISPEC_REQUIRE(A->n_cols == n && A2->n_rows == n && A2->n_cols == A->n_rows,
+                           "mispec_fac_create_product: need A (p x n) and A2 (n x p)");
+            MISPEC_REQUIRE(ctx->comm.allgather == nullptr, "mispec_fac_create_product: product operators cannot be row-sharded");
+        }
+        else if (A)
         {
             MISPEC_REQUIRE(A->ctx == ctx, "mispec_fac_create: matrix belongs to another context");
             MISPEC_REQUIRE(A->n_rows == n && A->n_cols == n, "mispec_fac_create: operator must be square of size n");
@@ -936,6 +952,9 @@ int fac_create_impl(mispec_ctx* ctx, const mispec_csr* A, const mispec_symshift*
         {
             F->ctx = ctx;
             F->A = A;
+            F->A2 = A2;
+            if (A2)
+                F->mid.alloc(size_t(round_up(std::max<int64_t>(A->n_rows, 1), 2)) + 2);
             F->S = S;
             F->op = op;
             F->op_user = op_user;
@@ -1012,6 +1031,16 @@ extern "C" int mispec_fac_create(mispec_ctx* ctx, const mispec_csr* A, mispec_op
                                  int symmetric, mispec_fac** out)
 {
     return fac_create_impl(ctx, A, nullptr, op, op_user, n, ncv, symmetric, out);
+}
+
+extern "C" int mispec_fac_create_product(mispec_ctx* ctx, const mispec_csr* A, const mispec_csr* A2, int ncv, mispec_fac** out)
+{
+    if (!A || !A2)
+    {
+        set_last_error("mispec_fac_create_product: NULL matrix");
+        return MISPEC_EINVAL;
+    }
+    return fac_create_impl(ctx, A, nullptr, nullptr, nullptr, A->n_cols, ncv, 1, out, A2);
 }
 
 extern "C" int mispec_fac_create_shiftsolve(mispec_ctx* ctx, const mispec_symshift* S, int ncv, int symmetric, mispec_fac** out)
@@ -1376,6 +1405,6 @@ extern "C" int mispec_fac_get_profile(const mispec_fac* fac_c, mispec_profile* o
         out->ms_scale = F.ms_acc[FAM_SCALE];
         out->ms_compress = F.ms_acc[FAM_COMPRESS];
         out->ms_small = F.ms_acc[FAM_SMALL];
-        out->spmv_bytes = F.A ? F.A->algorithmic_bytes() : 0.0;
+        out->spmv_bytes = (F.A ? F.A->algorithmic_bytes() : 0.0) + (F.A2 ? F.A2->algorithmic_bytes() : 0.0);
     });
 }

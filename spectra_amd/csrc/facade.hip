@@ -12,6 +12,7 @@
 
 #include <cstring>
 #include <memory>
+#include <vector>
 
 #include "common.hpp"
 
@@ -41,11 +42,36 @@ public:
     }
 };
 
+// y = A2 (A x) on two device matrices (the operator of contrib/PartialSVDSolver.h) for C callers.
+class ProductOp
+{
+    mispec_ctx* m_ctx;
+    const mispec_csr *m_first, *m_second;
+    mutable std::vector<double> m_cache;
+
+public:
+    using Scalar = double;
+    ProductOp(mispec_ctx* ctx, const mispec_csr* first, const mispec_csr* second) :
+        m_ctx(ctx), m_first(first), m_second(second), m_cache(size_t(mispec_csr_rows(first)))
+    {}
+    mispec_ctx* mispec_context() const { return m_ctx; }
+    const mispec_csr* mispec_product_first() const { return m_first; }
+    const mispec_csr* mispec_product_second() const { return m_second; }
+    Spectra::Index rows() const { return Spectra::Index(mispec_csr_cols(m_first)); }
+    Spectra::Index cols() const { return rows(); }
+    void perform_op(const double* x_in, double* y_out) const
+    {
+        Spectra::internal::check(mispec_spmv_host(m_first, x_in, m_cache.data()));
+        Spectra::internal::check(mispec_spmv_host(m_second, m_cache.data(), y_out));
+    }
+};
+
 using DevOp = Spectra::SparseSymMatProd<double>;
 using DevSolver = Spectra::SymEigsSolver<DevOp>;
 using CbSolver = Spectra::SymEigsSolver<CallbackOp>;
 using ShiftOp = Spectra::SparseSymShiftSolve<double>;
 using ShiftSolver = Spectra::SymEigsShiftSolver<ShiftOp>;
+using ProdSolver = Spectra::SymEigsSolver<ProductOp>;
 
 }  // namespace
 
@@ -55,6 +81,8 @@ struct mispec_symeigs
     std::unique_ptr<DevOp> dev_op;
     std::unique_ptr<CallbackOp> cb_op;
     std::unique_ptr<ShiftOp> shift_op;
+    std::unique_ptr<ProductOp> prod_op;
+    std::unique_ptr<ProdSolver> prod;
     std::unique_ptr<DevSolver> dev;
     std::unique_ptr<CbSolver> cb;
     std::unique_ptr<ShiftSolver> shift;
@@ -68,6 +96,8 @@ struct mispec_symeigs
             return f(*dev);
         if (shift)
             return f(*shift);
+        if (prod)
+            return f(*prod);
         return f(*cb);
     }
     mispec_fac* fac() const
@@ -113,6 +143,20 @@ extern "C" int mispec_symeigs_create_shift(mispec_ctx* ctx, mispec_symshift* S, 
         s->nev = nev;
         s->shift_op = std::make_unique<ShiftOp>(ctx, S);
         s->shift = std::make_unique<ShiftSolver>(*s->shift_op, nev, ncv, sigma);
+        *out = s.release();
+    });
+}
+
+extern "C" int mispec_symeigs_create_product(mispec_ctx* ctx, const mispec_csr* A, const mispec_csr* A2, int64_t nev, int64_t ncv,
+                                             mispec_symeigs** out)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(ctx && A && A2 && out, "mispec_symeigs_create_product: NULL argument");
+        auto s = std::make_unique<mispec_symeigs>();
+        s->ctx = ctx;
+        s->nev = nev;
+        s->prod_op = std::make_unique<ProductOp>(ctx, A, A2);
+        s->prod = std::make_unique<ProdSolver>(*s->prod_op, nev, ncv);
         *out = s.release();
     });
 }

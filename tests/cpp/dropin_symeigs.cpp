@@ -10,6 +10,7 @@
 #include <Spectra/MatOp/SparseSymShiftSolve.h>
 #include <Spectra/SymEigsShiftSolver.h>
 #include <Spectra/SymEigsSolver.h>
+#include <Spectra/contrib/PartialSVDSolver.h>
 
 #include <cmath>
 #include <complex>
@@ -179,6 +180,65 @@ public:
     }
 };
 
+// test/SVD.cpp:17-67: partial SVD of the rectangular sparse fixture; without Eigen's JacobiSVD the check is the
+// singular-triplet residual  ||A v - s u||, ||A' u - s v|| <= 1e-9  and the descending order of s.
+static void run_svd(int m, int n, int k, int ncv)
+{
+    std::vector<std::vector<std::pair<int, double>>> cols(n);
+    std::default_random_engine gen;
+    gen.seed(0);
+    std::uniform_real_distribution<double> distr(0.0, 1.0);
+    for (int i = 0; i < m; i++)
+        for (int j = 0; j < n; j++)
+            if (distr(gen) < 0.1)
+                cols[j].push_back({i, distr(gen) - 0.5});
+    std::vector<int> colptr{0}, rowind;
+    std::vector<double> val;
+    for (int j = 0; j < n; j++)
+    {
+        for (auto& e : cols[j])
+        {
+            rowind.push_back(e.first);
+            val.push_back(e.second);
+        }
+        colptr.push_back((int) rowind.size());
+    }
+    SparseView<double> A;
+    A.rows = m;
+    A.cols = n;
+    A.outer = colptr.data();
+    A.inner = rowind.data();
+    A.values = val.data();
+    A.row_major = false;
+
+    PartialSVDSolver<SparseView<double>> svds(A, k, ncv);
+    const int nconv = (int) svds.compute();
+    REQUIRE(nconv == k);
+    const auto s = svds.singular_values();
+    const auto U = svds.matrix_U(k);
+    const auto V = svds.matrix_V(k);
+    REQUIRE(U.rows() == m && U.cols() == k && V.rows() == n && V.cols() == k);
+    double err = 0.0;
+    for (int c = 0; c < k; c++)
+    {
+        std::vector<double> av(m, 0.0), atu(n, 0.0);
+        for (int j = 0; j < n; j++)
+            for (int p = colptr[j]; p < colptr[j + 1]; p++)
+            {
+                av[rowind[p]] += val[p] * V(j, c);
+                atu[j] += val[p] * U(rowind[p], c);
+            }
+        for (int i = 0; i < m; i++)
+            err = std::fmax(err, std::fabs(av[i] - s[c] * U(i, c)));
+        for (int j = 0; j < n; j++)
+            err = std::fmax(err, std::fabs(atu[j] - s[c] * V(j, c)));
+        if (c > 0)
+            REQUIRE(s[c] <= s[c - 1]);
+    }
+    std::printf("svd %dx%d k=%d nconv=%d s0=%.12f triplet residual=%.3e\n", m, n, k, nconv, s[0], err);
+    REQUIRE(err < 1e-9);
+}
+
 int main()
 {
     try
@@ -201,6 +261,9 @@ int main()
         run_gen_sets(gen_sparse_data(1000, 0.01), 20, 50);  // :165-174
         run_shift(gen_sparse_data(100, 0.1), 10, 20, 10.0);     // test/SymEigsShift.cpp:160-171
         run_shift(gen_sparse_data(1000, 0.01), 20, 50, 100.0);  // :173-185
+
+        run_svd(1000, 100, 5, 10);  // test/SVD.cpp:105-114 (tall sparse)
+        run_svd(100, 1000, 5, 10);  // :116-125 (wide sparse)
 
         // constructor argument checks throw std::invalid_argument like the reference (HermEigsBase.h:267-271)
         bool threw = false;
