@@ -16,6 +16,8 @@
 // Bound: HBM.  Algorithmic bytes per launch: 12*nnz + 4*(rows+1) + 8*cols + 8*rows.
 #include "csr.hpp"
 
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -336,7 +338,8 @@ int spmv_rows_per_block()
     return rows;
 }
 
-void launch_spmv(const mispec_csr& A, const double* x_dev, double* y_dev, const SpmvEpilogue* epi)
+void launch_spmv(const mispec_csr& A, const double* x_dev, double* y_dev, const SpmvEpilogue* epi, hipEvent_t ev_start,
+                 hipEvent_t ev_stop)
 {
     const int64_t nloc = A.local_rows();
     if (nloc == 0)
@@ -347,15 +350,25 @@ void launch_spmv(const mispec_csr& A, const double* x_dev, double* y_dev, const 
     const dim3 grid(unsigned(per * 8)), block(static_cast<unsigned>(threads));
     static const bool nt = getenv("MISPEC_SPMV_NT") ? atoi(getenv("MISPEC_SPMV_NT")) != 0 : false;
     const SpmvEpilogue e = epi ? *epi : SpmvEpilogue{};
-#define MISPEC_SPMV(E, N)                                                                                               \
-    do                                                                                                                  \
-    {                                                                                                                   \
-        if (threads == 128)                                                                                             \
-            hipLaunchKernelGGL((k_spmv_csr_stream<E, N, 128>), grid, block, 0, A.ctx->stream, A.rowptr.p, A.colind.p,   \
-                               A.val.p, x_dev, y_dev, nloc, nblocks, e);                                                \
-        else                                                                                                            \
-            hipLaunchKernelGGL((k_spmv_csr_stream<E, N, 256>), grid, block, 0, A.ctx->stream, A.rowptr.p, A.colind.p,   \
-                               A.val.p, x_dev, y_dev, nloc, nblocks, e);                                                \
+    // With an event pair the launch is timed through the dispatch's own completion signal (start/stop of the
+    // kernel itself, as a profiler sees it) instead of marker packets around it.
+#define MISPEC_SPMV_LAUNCH(K)                                                                                          \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if (ev_start && ev_stop)                                                                                       \
+            hipExtLaunchKernelGGL((K), grid, block, 0, A.ctx->stream, ev_start, ev_stop, 0, A.rowptr.p, A.colind.p,   \
+                                  A.val.p, x_dev, y_dev, nloc, nblocks, e);                                           \
+        else                                                                                                           \
+            hipLaunchKernelGGL((K), grid, block, 0, A.ctx->stream, A.rowptr.p, A.colind.p, A.val.p, x_dev, y_dev,    \
+                               nloc, nblocks, e);                                                                      \
+    } while (0)
+#define MISPEC_SPMV(E, N)                                          \
+    do                                                             \
+    {                                                              \
+        if (threads == 128)                                        \
+            MISPEC_SPMV_LAUNCH((k_spmv_csr_stream<E, N, 128>));    \
+        else                                                       \
+            MISPEC_SPMV_LAUNCH((k_spmv_csr_stream<E, N, 256>));    \
     } while (0)
     if (epi && nt)
         MISPEC_SPMV(true, true);
@@ -366,6 +379,7 @@ void launch_spmv(const mispec_csr& A, const double* x_dev, double* y_dev, const 
     else
         MISPEC_SPMV(false, false);
 #undef MISPEC_SPMV
+#undef MISPEC_SPMV_LAUNCH
     MISPEC_HIP(hipGetLastError());
 }
 

@@ -48,7 +48,9 @@ inline int spmv_num_blocks(int64_t local_rows)
     return int((local_rows + r - 1) / r);
 }
 
-void launch_spmv(const mispec_csr& A, const double* x_dev, double* y_dev, const SpmvEpilogue* epi);
+// ev_start / ev_stop (both or none): HIP events bound to this dispatch's start and completion.
+void launch_spmv(const mispec_csr& A, const double* x_dev, double* y_dev, const SpmvEpilogue* epi, hipEvent_t ev_start = nullptr,
+                 hipEvent_t ev_stop = nullptr);
 
 // For every rank p of a `world`-way row partition with `block` rows per rank: the smallest (lo[p]) and largest
 // (hi[p]) column index this shard references inside p's rows; hi[p] = -1 when it references none.  Returns

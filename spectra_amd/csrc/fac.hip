@@ -20,6 +20,7 @@
 #include <Spectra/internal/SmallDense.h>
 
 #include <cmath>
+#include <memory>
 #include <cstdlib>
 #include <cstring>
 
@@ -109,6 +110,19 @@ struct mispec_fac
 
 namespace {
 
+hipEvent_t take_event(mispec_fac& F)
+{
+    if (!F.ev_pool.empty())
+    {
+        hipEvent_t e = F.ev_pool.back();
+        F.ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    MISPEC_HIP(hipEventCreate(&e));
+    return e;
+}
+
 // RAII timing scope: records a HIP-event pair on the context stream around the enclosed launches.
 struct Timed
 {
@@ -118,27 +132,13 @@ struct Timed
     Timed(mispec_fac& f, int family) : F(f), fam(family)
     {
         F.counts[fam]++;
-        // level 2: only the operator applications are timed — plus the cheap scale kernel that precedes each of
-        // them, because an event's timestamp is only ordered after the previous *event*, not after the previous
-        // kernel: without that pair the SpMV interval would absorb the scale kernel (measured: +30 us).
-        if (!F.prof || (F.prof == 2 && fam != FAM_SPMV && fam != FAM_SCALE))
+        if (!F.prof || (F.prof == 2 && fam != FAM_SPMV))  // level 2: only the operator applications are timed
             return;
         e0 = take();
         e1 = take();
         (void) hipEventRecord(e0, F.stream());
     }
-    hipEvent_t take()
-    {
-        if (!F.ev_pool.empty())
-        {
-            hipEvent_t e = F.ev_pool.back();
-            F.ev_pool.pop_back();
-            return e;
-        }
-        hipEvent_t e;
-        MISPEC_HIP(hipEventCreate(&e));
-        return e;
-    }
+    hipEvent_t take() { return take_event(F); }
     ~Timed()
     {
         if (!F.prof || !e0)
@@ -301,7 +301,20 @@ void apply_op(mispec_fac& F, const double* x_loc, double* y_loc, bool lanczos_ep
                 comm_check(F.ctx->comm.allgather(F.ctx->comm.user, x_loc, F.xfull.p, F.block, F.stream()), "all-gather");
             x = F.xfull.p;
         }
-        Timed t(F, FAM_SPMV);
+        // A single SpMV is timed through its own dispatch (start/stop of the kernel, no marker packets in the
+        // stream); the two-kernel product operator through an event pair around both.
+        const bool own_events = F.prof && !F.A2;
+        std::unique_ptr<Timed> scope;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (own_events)
+        {
+            F.counts[FAM_SPMV]++;
+            e0 = take_event(F);
+            e1 = take_event(F);
+            F.ev[FAM_SPMV].emplace_back(e0, e1);
+        }
+        else
+            scope.reset(new Timed(F, FAM_SPMV));
         const mispec_csr* last = F.A;
         if (F.A2)  // y = A2 (A x): the epilogue rides on the second product
         {
@@ -318,10 +331,10 @@ void apply_op(mispec_fac& F, const double* x_loc, double* y_loc, bool lanczos_ep
             epi.h_prev_dev = h_prev_dev;
             epi.status = status;
             epi.partials = F.alpha_partials.p;
-            launch_spmv(*last, x, y_loc, &epi);
+            launch_spmv(*last, x, y_loc, &epi, e0, e1);
         }
         else
-            launch_spmv(*last, x, y_loc, nullptr);
+            launch_spmv(*last, x, y_loc, nullptr, e0, e1);
     }
     else if (F.S)
     {
