@@ -379,8 +379,22 @@ __global__ __launch_bounds__(1024) void k_reduce_sum(const double* __restrict__ 
 {
     __shared__ double sh[16];
     double v = 0.0;
-    for (int64_t i = threadIdx.x; i < count; i += 1024)
-        v += in[i];
+    // thread t adds in[t], in[t+1024], ... in that order; the loads of a batch are all issued before the first add
+    // (the partials were written by other XCDs: one load latency per batch instead of one per element)
+    constexpr int kBatch = 40;
+    for (int64_t base = threadIdx.x; base < count; base += int64_t(kBatch) * 1024)
+    {
+        double x[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; k++)
+        {
+            const int64_t i = base + int64_t(k) * 1024;
+            x[k] = (i < count) ? in[i] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < kBatch; k++)
+            v += x[k];
+    }
     v = wave_reduce_sum(v);
     if ((threadIdx.x & 63) == 0)
         sh[threadIdx.x >> 6] = v;
