@@ -56,12 +56,13 @@ struct HostBand
 // One thread per chunk.  The recurrence is sequential in k, so the only latency that may sit on the critical
 // path is the FMA chain itself: the last B unknowns live in registers (never re-read from memory), and the
 // factor entries / right-hand sides of the next U rows are loaded as one batch before they are needed.
+constexpr int kChunkThreads = 64;  // one wavefront per workgroup: the chunks spread over all CUs, 512 VGPRs per lane
 template <int B, int U>
-__global__ __launch_bounds__(kThreads) void k_chunk_solve(int64_t N, int b, int64_t L, int64_t P, const double* __restrict__ Lf,
+__global__ __launch_bounds__(kChunkThreads) void k_chunk_solve(int64_t N, int b, int64_t L, int64_t P, const double* __restrict__ Lf,
                                                            const double* __restrict__ Dinv, const double* __restrict__ f,
                                                            double* __restrict__ y)
 {
-    const int64_t p = int64_t(blockIdx.x) * kThreads + threadIdx.x;
+    const int64_t p = int64_t(blockIdx.x) * kChunkThreads + threadIdx.x;
     if (p >= P)
         return;
     const int64_t row0 = p * L;
@@ -187,27 +188,37 @@ __global__ __launch_bounds__(kThreads) void k_back_subst(int64_t N, int b, int64
     x[r] = acc;
 }
 
-// y = Ainv * x, Ainv dense n x n column-major: one wave per 64 rows would be uncoalesced — here a workgroup
-// takes a 256-row slab and walks the columns (coalesced down the rows), x broadcast from LDS in tiles.
-__global__ __launch_bounds__(kThreads) void k_dense_gemv(int n, const double* __restrict__ Ainv, const double* __restrict__ x,
+// y = Ainv * x, Ainv dense n x n stored ROW-major: one wavefront per row reads its row coalesced, x comes from
+// the L2, and a shuffle tree finishes the dot product — n waves in flight instead of n/256 workgroups that each
+// walk all the columns (the first version: 233 us at n = 1830, i.e. a third of a banded solve).
+__global__ __launch_bounds__(kThreads) void k_dense_gemv(int n, const double* __restrict__ Arow, const double* __restrict__ x,
                                                           double* __restrict__ y)
 {
-    __shared__ double xs[1024];
-    const int r = blockIdx.x * kThreads + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    if (r >= n)
+        return;
+    const double* a = Arow + size_t(r) * n;
     double acc = 0.0;
-    for (int c0 = 0; c0 < n; c0 += 1024)
-    {
-        const int nc = min(1024, n - c0);
-        __syncthreads();
-        for (int c = threadIdx.x; c < nc; c += kThreads)
-            xs[c] = x[c0 + c];
-        __syncthreads();
-        if (r < n)
-            for (int c = 0; c < nc; c++)
-                acc += Ainv[size_t(c0 + c) * n + r] * xs[c];
-    }
-    if (r < n)
+#pragma unroll 8
+    for (int c = lane; c < n; c += 64)
+        acc += a[c] * x[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        acc += __shfl_down(acc, off, 64);
+    if (lane == 0)
         y[r] = acc;
+}
+
+// column-major host inverse -> row-major device copy
+void upload_row_major(const std::vector<double>& inv, int64_t n, DevBuf<double>& dst)
+{
+    std::vector<double> rm(inv.size());
+    for (int64_t c = 0; c < n; c++)
+        for (int64_t r = 0; r < n; r++)
+            rm[size_t(r) * n + c] = inv[size_t(c) * n + r];
+    dst.alloc(rm.size());
+    MISPEC_HIP(hipMemcpy(dst.p, rm.data(), rm.size() * sizeof(double), hipMemcpyHostToDevice));
 }
 
 }  // namespace
@@ -328,8 +339,7 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev)
                 std::copy(e.begin(), e.end(), inv.begin() + size_t(c) * N);
             }
             ctx->make_current();
-            lev.inv.alloc(inv.size());
-            MISPEC_HIP(hipMemcpy(lev.inv.p, inv.data(), inv.size() * sizeof(double), hipMemcpyHostToDevice));
+            upload_row_major(inv, N, lev.inv);
             break;
         }
         // ---- spikes W = M_II^{-1} M_IS and their contribution to the Schur complement -------------------
@@ -447,14 +457,16 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev)
 void launch_chunk_solve(const mispec_ctx& ctx, const BandLevel& lev, dim3 grid, const double* f, double* y)
 {
 #define MISPEC_CHUNK(B, U)                                                                                                  \
-    hipLaunchKernelGGL((k_chunk_solve<B, U>), grid, dim3(kThreads), 0, ctx.stream, lev.N, lev.b, lev.L, lev.P, lev.Lf.p, \
+    hipLaunchKernelGGL((k_chunk_solve<B, U>), grid, dim3(kChunkThreads), 0, ctx.stream, lev.N, lev.b, lev.L, lev.P, lev.Lf.p, \
                        lev.Dinv.p, f, y)
+    // U rows of factor entries are in flight per lane and batch ((B + 2) * U doubles): as deep as the register
+    // file allows, because with one lane per chunk nothing else hides the load latency
     if (lev.b <= 4)
-        MISPEC_CHUNK(4, 8);
+        MISPEC_CHUNK(4, 32);
     else if (lev.b <= 8)
-        MISPEC_CHUNK(8, 4);
+        MISPEC_CHUNK(8, 16);
     else if (lev.b <= 16)
-        MISPEC_CHUNK(16, 2);
+        MISPEC_CHUNK(16, 8);
     else
         MISPEC_CHUNK(64, 1);
 #undef MISPEC_CHUNK
@@ -468,14 +480,14 @@ void solve_level(const mispec_ctx& ctx, const BandLevel& lev, const double* f, d
     {
         if (lev.inv.p)
         {
-            hipLaunchKernelGGL(k_dense_gemv, blocks(lev.N), dim3(kThreads), 0, ctx.stream, int(lev.N), lev.inv.p, f, x);
+            hipLaunchKernelGGL(k_dense_gemv, dim3(unsigned((lev.N + 3) / 4)), dim3(kThreads), 0, ctx.stream, int(lev.N), lev.inv.p, f, x);
             MISPEC_HIP(hipGetLastError());
         }
         else
             launch_chunk_solve(ctx, lev, dim3(1), f, x);
         return;
     }
-    launch_chunk_solve(ctx, lev, blocks(lev.P), f, lev.y.p);
+    launch_chunk_solve(ctx, lev, dim3(unsigned((lev.P + kChunkThreads - 1) / kChunkThreads)), f, lev.y.p);
     hipLaunchKernelGGL(k_sep_rhs, blocks((lev.P - 1) * lev.b), dim3(kThreads), 0, ctx.stream, lev.N, lev.b, lev.L, lev.P,
                        lev.band.p, f, lev.y.p, lev.g.p);
     MISPEC_HIP(hipGetLastError());
@@ -557,7 +569,7 @@ void launch_shiftsolve(const mispec_symshift& S, const double* x_dev, double* y_
         throw Error(MISPEC_ELOGIC, "SparseSymShiftSolve: need to call set_shift() first");
     if (S.dense)
     {
-        hipLaunchKernelGGL(k_dense_gemv, dim3(unsigned((S.n + kThreads - 1) / kThreads)), dim3(kThreads), 0, S.ctx->stream, int(S.n),
+        hipLaunchKernelGGL(k_dense_gemv, dim3(unsigned((S.n + 3) / 4)), dim3(kThreads), 0, S.ctx->stream, int(S.n),
                            S.inverse.p, x_dev, y_dev);
         MISPEC_HIP(hipGetLastError());
     }
@@ -649,8 +661,7 @@ extern "C" int mispec_symshift_set_shift(mispec_symshift* S, double sigma)
             for (int64_t i = 0; i < n; i++)
                 A[size_t(i) * n + i] -= sigma;
             dense_inverse(int(n), A, inv);
-            S->inverse.alloc(inv.size());
-            MISPEC_HIP(hipMemcpy(S->inverse.p, inv.data(), inv.size() * sizeof(double), hipMemcpyHostToDevice));
+            upload_row_major(inv, n, S->inverse);
             S->dense = true;
         }
         else
