@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <string>
 
 using namespace mispec;
 
@@ -38,8 +39,18 @@ struct HostBand
     int64_t n = 0;
     int b = 0;
     std::vector<double> a;  // n x (b + 1), row-major
+    // read-only view of an unshifted band kept elsewhere (the operator's resident copy): M = *view - shift * I.
+    // Used for the top level when it is factored on the device, so that no shifted host copy has to be built.
+    const std::vector<double>* view = nullptr;
+    const double* view_dev = nullptr;  // the same unshifted band in device memory
+    double shift = 0.0;
     double& at(int64_t i, int d) { return a[size_t(i) * (b + 1) + d]; }
-    double at(int64_t i, int d) const { return a[size_t(i) * (b + 1) + d]; }
+    double at(int64_t i, int d) const
+    {
+        if (view)
+            return (*view)[size_t(i) * (b + 1) + d] - (d == 0 ? shift : 0.0);
+        return a[size_t(i) * (b + 1) + d];
+    }
     double get(int64_t i, int64_t j) const  // symmetric access, 0 outside the band
     {
         if (i < j)
@@ -188,6 +199,197 @@ __global__ __launch_bounds__(kThreads) void k_back_subst(int64_t N, int b, int64
     x[r] = acc;
 }
 
+// dst = src with sigma subtracted from the diagonal entries (column 0 of the n x (b+1) row-major band)
+__global__ __launch_bounds__(kThreads) void k_band_shift(int64_t total, int bw, double sigma, const double* __restrict__ src,
+                                                          double* __restrict__ dst)
+{
+    for (int64_t i = int64_t(blockIdx.x) * kThreads + threadIdx.x; i < total; i += int64_t(gridDim.x) * kThreads)
+        dst[i] = src[i] - ((i % bw) == 0 ? sigma : 0.0);
+}
+
+// ---- factorisation of the top level on the device -------------------------------------------------------
+// One lane per chunk, the three steps of the host routine below (factor_level) in the same order of operations:
+//   1. banded LDL' of the chunk's interior block (the last B rows of L and D kept in registers),
+//   2. the 2b spikes  W = M_II^{-1} M_IS  (forward/backward substitution with the factor just written),
+//   3. the chunk's (2b x 2b) contribution  M_SI W  to the Schur complement of its two separators.
+// band: N x (b+1) row-major, band[i*(b+1)+d] = M(i, i-d).  W (N x 2b row-major) and C (P x 2b x 2b) must be
+// zero on entry.  *fail is set when a pivot vanishes.
+template <int B>
+__global__ __launch_bounds__(kChunkThreads) void k_chunk_factor(int64_t N, int b, int64_t L, int64_t P, double tiny,
+                                                                 const double* __restrict__ band, double* __restrict__ Lf,
+                                                                 double* __restrict__ Dinv, double* __restrict__ W,
+                                                                 double* __restrict__ C, int* __restrict__ fail)
+{
+    const int64_t p = int64_t(blockIdx.x) * kChunkThreads + threadIdx.x;
+    if (p >= P)
+        return;
+    const int64_t row0 = p * L;
+    const int64_t m = ((p == P - 1) ? N : (row0 + L - b)) - row0;  // interior rows
+    const int bw = b + 1;
+    // ---- 1. LDL' ---------------------------------------------------------------------------------------
+    {
+        double Lw[B][B], Dw[B];  // Lw[i][d] = L(k-1-i, k-1-i-d-1), Dw[i] = D(k-1-i)
+#pragma unroll
+        for (int i = 0; i < B; i++)
+        {
+            Dw[i] = 1.0;
+#pragma unroll
+            for (int d = 0; d < B; d++)
+                Lw[i][d] = 0.0;
+        }
+        for (int64_t k = 0; k < m; k++)
+        {
+            const int dk = int(k < b ? k : b);
+            const double* mrow = band + (row0 + k) * bw;
+            double lrow[B];
+#pragma unroll
+            for (int d = B - 1; d >= 0; d--)
+            {
+                lrow[d] = 0.0;
+                if (d < dk)
+                {
+                    double v = mrow[d + 1];
+#pragma unroll
+                    for (int e = B - 1; e > d; e--)
+                        if (e < dk)
+                            v -= lrow[e] * Dw[e] * Lw[d][e - d - 1];
+                    lrow[d] = v / Dw[d];
+                }
+            }
+            double dv = mrow[0];
+#pragma unroll
+            for (int d = 0; d < B; d++)
+                if (d < dk)
+                    dv -= lrow[d] * lrow[d] * Dw[d];
+            if (!(fabs(dv) > tiny))
+            {
+                *fail = 1;
+                dv = 1.0;
+            }
+            Dinv[k * P + p] = 1.0 / dv;
+#pragma unroll
+            for (int d = 0; d < B; d++)
+                if (d < b)
+                    Lf[(k * b + d) * P + p] = lrow[d];
+#pragma unroll
+            for (int i = B - 1; i > 0; i--)
+            {
+                Dw[i] = Dw[i - 1];
+#pragma unroll
+                for (int d = 0; d < B; d++)
+                    Lw[i][d] = Lw[i - 1][d];
+            }
+            Dw[0] = dv;
+#pragma unroll
+            for (int d = 0; d < B; d++)
+                Lw[0][d] = lrow[d];
+        }
+    }
+    if (P == 1)
+        return;
+    // ---- 2. spikes: side 0 couples to separator p-1 (rows row0-b..row0-1), side 1 to separator p --------
+    const int w2 = 2 * b;
+    for (int side = 0; side < 2; side++)
+    {
+        if ((side == 0 && p == 0) || (side == 1 && p == P - 1))
+            continue;
+        double hist[B][B];  // hist[c][d] = unknown k-d-1 (forward) / k+d+1 (backward) of right-hand side c
+#pragma unroll
+        for (int c = 0; c < B; c++)
+#pragma unroll
+            for (int d = 0; d < B; d++)
+                hist[c][d] = 0.0;
+        for (int64_t k = 0; k < m; k++)
+        {
+            double lf[B];
+#pragma unroll
+            for (int d = 0; d < B; d++)
+                lf[d] = (d < b) ? Lf[(k * b + d) * P + p] : 0.0;
+            const int dk = int(k < b ? k : b);
+#pragma unroll
+            for (int c = 0; c < B; c++)
+            {
+                if (c >= b)
+                    continue;
+                double acc = 0.0;
+                if (side == 0)
+                {
+                    if (k <= c)
+                        acc = band[(row0 + k) * bw + (k + b - c)];
+                }
+                else if (k >= m + c - b)
+                    acc = band[(row0 + m + c) * bw + (m + c - k)];
+#pragma unroll
+                for (int d = B - 1; d >= 0; d--)
+                    if (d < dk)
+                        acc -= lf[d] * hist[c][d];
+#pragma unroll
+                for (int d = B - 1; d > 0; d--)
+                    hist[c][d] = hist[c][d - 1];
+                hist[c][0] = acc;
+                W[(row0 + k) * w2 + side * b + c] = acc;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < B; c++)
+#pragma unroll
+            for (int d = 0; d < B; d++)
+                hist[c][d] = 0.0;
+        for (int64_t k = m - 1; k >= 0; k--)
+        {
+            const double di = Dinv[k * P + p];
+            double lf[B];
+#pragma unroll
+            for (int d = 0; d < B; d++)
+                lf[d] = (d < b && k + d + 1 < m) ? Lf[((k + d + 1) * b + d) * P + p] : 0.0;
+#pragma unroll
+            for (int c = 0; c < B; c++)
+            {
+                if (c >= b)
+                    continue;
+                double acc = W[(row0 + k) * w2 + side * b + c] * di;
+#pragma unroll
+                for (int d = B - 1; d >= 0; d--)
+                    acc -= lf[d] * hist[c][d];
+#pragma unroll
+                for (int d = B - 1; d > 0; d--)
+                    hist[c][d] = hist[c][d - 1];
+                hist[c][0] = acc;
+                W[(row0 + k) * w2 + side * b + c] = acc;
+            }
+        }
+    }
+    // ---- 3. C(s1, s2) = sum_k M(separator row s1, interior k) * spike_s2[k] --------------------------------
+    double* Cp = C + p * int64_t(w2) * w2;
+    for (int side1 = 0; side1 < 2; side1++)
+    {
+        if ((side1 == 0 && p == 0) || (side1 == 1 && p == P - 1))
+            continue;
+        for (int c1 = 0; c1 < b; c1++)
+            for (int s2 = 0; s2 < w2; s2++)
+            {
+                const int side2 = s2 / b;
+                if ((side2 == 0 && p == 0) || (side2 == 1 && p == P - 1))
+                    continue;
+                double acc = 0.0;
+                if (side1 == 0)
+                {
+                    const int64_t kend = (b < m) ? b : m;
+                    for (int64_t k = 0; k < kend; k++)
+                        if (k <= c1)
+                            acc += band[(row0 + k) * bw + (k + b - c1)] * W[(row0 + k) * w2 + s2];
+                }
+                else
+                {
+                    for (int64_t k = (m - b > 0 ? m - b : 0); k < m; k++)
+                        if (k >= m + c1 - b)
+                            acc += band[(row0 + m + c1) * bw + (m + c1 - k)] * W[(row0 + k) * w2 + s2];
+                }
+                Cp[(side1 * b + c1) * w2 + s2] = acc;
+            }
+    }
+}
+
 // y = Ainv * x, Ainv dense n x n stored ROW-major: one wavefront per row reads its row coalesced, x comes from
 // the L2, and a shuffle tree finishes the dot product — n waves in flight instead of n/256 workgroups that each
 // walk all the columns (the first version: 233 us at n = 1830, i.e. a third of a banded solve).
@@ -246,6 +448,27 @@ void throw_singular()
     throw Error(MISPEC_EINVAL, "SparseSymShiftSolve: factorization failed with the given shift");
 }
 
+// chunk length and chunk count of a level
+void plan_level(int64_t N, int b, int64_t& L, int64_t& P)
+{
+    L = std::max<int64_t>(kChunk, 4 * int64_t(b));
+    P = (N <= std::max<int64_t>(kSingleChunk, 8 * int64_t(b))) ? 1 : N / L;
+    if (P < 2)
+    {
+        P = 1;
+        L = N;
+    }
+}
+
+// whether a level of this shape is factored by k_chunk_factor (MISPEC_SHIFT_FACTOR=host keeps everything on the host)
+bool factored_on_device(int64_t N, int b)
+{
+    static const bool host_only = getenv("MISPEC_SHIFT_FACTOR") && std::string(getenv("MISPEC_SHIFT_FACTOR")) == "host";
+    int64_t L, P;
+    plan_level(N, b, L, P);
+    return P > 1 && b <= 8 && !host_only;
+}
+
 // Factor the band matrix M (destroyed) into `lev`, recursively.
 void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev)
 {
@@ -254,31 +477,106 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev)
     MISPEC_REQUIRE(b <= 64, "internal: band wider than the chunk kernel supports");
     lev.N = N;
     lev.b = b;
-    int64_t L = std::max<int64_t>(kChunk, 4 * int64_t(b));
-    int64_t P = (N <= std::max<int64_t>(kSingleChunk, 8 * int64_t(b))) ? 1 : N / L;
-    if (P < 2)
-    {
-        P = 1;
-        L = N;
-    }
+    int64_t L, P;
+    plan_level(N, b, L, P);
     lev.L = L;
     lev.P = P;
     const int64_t mmax = (P == 1) ? N : std::max<int64_t>(L - b, N - (P - 1) * L);  // longest interior
     double scale = 0.0;
     for (int64_t i = 0; i < N; i++)
-        scale = std::max(scale, std::fabs(M.at(i, 0)));
+        scale = std::max(scale, std::fabs(static_cast<const HostBand&>(M).at(i, 0)));
     const double tiny = scale * 1e-14 + 1e-300;
 
-    std::vector<double> Lf(size_t(mmax) * std::max(b, 1) * P, 0.0), Dinv(size_t(mmax) * P, 0.0);
-    std::vector<double> W(size_t(N) * 2 * std::max(b, 1), 0.0);
+    const bool on_device = factored_on_device(N, b);
+    MISPEC_REQUIRE(on_device || !M.view, "internal: a band view is only valid for a level factored on the device");
+    const size_t lf_size = size_t(mmax) * std::max(b, 1) * P, dinv_size = size_t(mmax) * P, w_size = size_t(N) * 2 * std::max(b, 1);
+    std::vector<double> Lf, Dinv, W;  // host images of the factor (host path only)
+    if (!on_device)
+    {
+        Lf.assign(lf_size, 0.0);
+        Dinv.assign(dinv_size, 0.0);
+        W.assign(w_size, 0.0);
+    }
     const int64_t nsep = (P - 1) * b;
     HostBand S;  // Schur complement of the separators
     S.n = nsep;
     S.b = (P > 1) ? std::min<int64_t>(2 * b - 1, std::max<int64_t>(nsep - 1, 0)) : 0;
     S.a.assign(size_t(std::max<int64_t>(nsep, 1)) * (S.b + 1), 0.0);
 
+    // ---- the top level of a large matrix is factored on the device (one lane per chunk, k_chunk_factor); the
+    // ---- Schur complement comes back as per-chunk blocks and is assembled here, in the order of the host loop
+    if (on_device)
+    {
+        ctx->make_current();
+        const int w2 = 2 * b;
+        lev.band.alloc(size_t(N) * (b + 1));
+        if (M.view_dev)
+        {
+            const int64_t total = N * (b + 1);
+            hipLaunchKernelGGL(k_band_shift, dim3(unsigned(std::min<int64_t>((total + kThreads - 1) / kThreads, 4096))), dim3(kThreads),
+                               0, ctx->stream, total, b + 1, M.shift, M.view_dev, lev.band.p);
+            MISPEC_HIP(hipGetLastError());
+        }
+        else
+            MISPEC_HIP(hipMemcpyAsync(lev.band.p, M.a.data(), M.a.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        lev.Lf.alloc(lf_size);
+        lev.Dinv.alloc(dinv_size);
+        lev.W.alloc(w_size);
+        DevBuf<double> Cdev;
+        Cdev.alloc(size_t(P) * w2 * w2);
+        DevBuf<int> fail;
+        fail.alloc(1);
+        MISPEC_HIP(hipMemsetAsync(lev.Lf.p, 0, lf_size * sizeof(double), ctx->stream));
+        MISPEC_HIP(hipMemsetAsync(lev.Dinv.p, 0, dinv_size * sizeof(double), ctx->stream));
+        MISPEC_HIP(hipMemsetAsync(lev.W.p, 0, w_size * sizeof(double), ctx->stream));
+        MISPEC_HIP(hipMemsetAsync(Cdev.p, 0, Cdev.n * sizeof(double), ctx->stream));
+        MISPEC_HIP(hipMemsetAsync(fail.p, 0, sizeof(int), ctx->stream));
+        const dim3 grid(unsigned((P + kChunkThreads - 1) / kChunkThreads));
+        if (b <= 4)
+            hipLaunchKernelGGL((k_chunk_factor<4>), grid, dim3(kChunkThreads), 0, ctx->stream, N, b, L, P, tiny, lev.band.p,
+                               lev.Lf.p, lev.Dinv.p, lev.W.p, Cdev.p, fail.p);
+        else
+            hipLaunchKernelGGL((k_chunk_factor<8>), grid, dim3(kChunkThreads), 0, ctx->stream, N, b, L, P, tiny, lev.band.p,
+                               lev.Lf.p, lev.Dinv.p, lev.W.p, Cdev.p, fail.p);
+        MISPEC_HIP(hipGetLastError());
+        std::vector<double> Cc(Cdev.n);
+        int failed = 0;
+        MISPEC_HIP(hipMemcpyAsync(Cc.data(), Cdev.p, Cc.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        MISPEC_HIP(hipMemcpyAsync(&failed, fail.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        MISPEC_HIP(hipStreamSynchronize(ctx->stream));
+        if (failed)
+            throw_singular();
+        for (int64_t p = 0; p < P; p++)
+            for (int side1 = 0; side1 < 2; side1++)
+            {
+                if ((side1 == 0 && p == 0) || (side1 == 1 && p == P - 1))
+                    continue;
+                for (int c1 = 0; c1 < b; c1++)
+                {
+                    const int64_t s1 = (side1 == 0 ? (p - 1) : p) * b + c1;
+                    for (int side2 = 0; side2 < 2; side2++)
+                    {
+                        if ((side2 == 0 && p == 0) || (side2 == 1 && p == P - 1))
+                            continue;
+                        for (int c2 = 0; c2 < b; c2++)
+                        {
+                            const int64_t s2 = (side2 == 0 ? (p - 1) : p) * b + c2;
+                            if (s2 > s1)
+                                continue;  // lower triangle only
+                            const double acc = Cc[(size_t(p) * w2 + size_t(side1 * b + c1)) * w2 + size_t(side2 * b + c2)];
+                            if (acc != 0.0)
+                            {
+                                MISPEC_REQUIRE(s1 - s2 <= S.b, "internal: Schur complement wider than expected");
+                                S.at(s1, int(s1 - s2)) -= acc;
+                            }
+                        }
+                    }
+                }
+            }
+    }
+
     std::vector<double> D, Lc, rhs, sol;
-    for (int64_t p = 0; p < P; p++)
+    for (int64_t p = 0; p < (on_device ? 0 : P); p++)
     {
         const int64_t row0 = p * L;
         const int64_t m = ((p == P - 1) ? N : (row0 + L - b)) - row0;
@@ -424,7 +722,7 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev)
         for (int64_t p = 0; p < P - 1; p++)
             for (int c1 = 0; c1 < b; c1++)
                 for (int c2 = 0; c2 <= c1; c2++)
-                    S.at(p * b + c1, c1 - c2) += M.at((p + 1) * L - b + c1, c1 - c2);
+                    S.at(p * b + c1, c1 - c2) += static_cast<const HostBand&>(M).at((p + 1) * L - b + c1, c1 - c2);
     }
 
     // ---- upload this level ---------------------------------------------------------------------------
@@ -434,13 +732,19 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev)
         if (!src.empty())
             MISPEC_HIP(hipMemcpyAsync(dst.p, src.data(), src.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     };
-    up(lev.Lf, Lf);
-    up(lev.Dinv, Dinv);
+    if (!on_device)
+    {
+        up(lev.Lf, Lf);
+        up(lev.Dinv, Dinv);
+    }
     lev.y.alloc(size_t(N));
     if (P > 1)
     {
-        up(lev.W, W);
-        up(lev.band, M.a);
+        if (!on_device)
+        {
+            up(lev.W, W);
+            up(lev.band, M.a);
+        }
         lev.g.alloc(size_t(nsep));
         lev.xs.alloc(size_t(nsep));
     }
@@ -595,21 +899,49 @@ extern "C" int mispec_symshift_create(mispec_ctx* ctx, int64_t n, const int32_t*
         auto S = std::make_unique<mispec_symshift>();
         S->ctx = ctx;
         S->n = n;
-        // keep the selected triangle as (row >= col) triplets, like selfadjointView<Uplo> (SparseSymShiftSolve.h:87)
-        for (int64_t o = 0; o < n; o++)
-            for (int32_t p = outer[o]; p < outer[o + 1]; p++)
-            {
-                const int64_t in = inner[p];
-                MISPEC_REQUIRE(in >= 0 && in < n, "mispec_symshift_create: index out of range");
-                const int64_t r = row_major ? o : in, c = row_major ? in : o;
-                if (lower ? (r >= c) : (r <= c))
+        // the selected triangle, like selfadjointView<Uplo> (SparseSymShiftSolve.h:87): first its bandwidth ...
+        auto for_each_entry = [&](auto&& fn) {
+            for (int64_t o = 0; o < n; o++)
+                for (int32_t p = outer[o]; p < outer[o + 1]; p++)
                 {
-                    S->rows.push_back(r >= c ? r : c);
-                    S->cols.push_back(r >= c ? c : r);
-                    S->vals.push_back(val[p]);
-                    S->half_bandwidth = std::max<int64_t>(S->half_bandwidth, r >= c ? r - c : c - r);
+                    const int64_t in = inner[p];
+                    MISPEC_REQUIRE(in >= 0 && in < n, "mispec_symshift_create: index out of range");
+                    const int64_t r = row_major ? o : in, c = row_major ? in : o;
+                    if (lower ? (r >= c) : (r <= c))
+                        fn(r >= c ? r : c, r >= c ? c : r, val[p]);
                 }
+        };
+        int64_t count = 0;
+        for_each_entry([&](int64_t r, int64_t c, double) {
+            S->half_bandwidth = std::max<int64_t>(S->half_bandwidth, r - c);
+            count++;
+        });
+        if (S->half_bandwidth <= kMaxBandwidth)
+        {
+            // ... then, for a band, the band itself (assembled once; every set_shift() starts from it)
+            S->band_b = int(std::max<int64_t>(1, std::min<int64_t>(S->half_bandwidth, n - 1)));  // a diagonal matrix: width 1, zeros
+            const size_t bw = size_t(S->band_b) + 1;
+            S->band0.assign(size_t(n) * bw, 0.0);
+            for_each_entry([&](int64_t r, int64_t c, double v) { S->band0[size_t(r) * bw + size_t(r - c)] += v; });
+            if (factored_on_device(n, S->band_b))
+            {
+                ctx->make_current();
+                S->band0_dev.alloc(S->band0.size());
+                MISPEC_HIP(hipMemcpy(S->band0_dev.p, S->band0.data(), S->band0.size() * sizeof(double), hipMemcpyHostToDevice));
             }
+        }
+        else
+        {
+            // ... or (row >= col) triplets for the dense path
+            S->rows.reserve(size_t(count));
+            S->cols.reserve(size_t(count));
+            S->vals.reserve(size_t(count));
+            for_each_entry([&](int64_t r, int64_t c, double v) {
+                S->rows.push_back(r);
+                S->cols.push_back(c);
+                S->vals.push_back(v);
+            });
+        }
         *out = S.release();
     });
 }
@@ -639,12 +971,19 @@ extern "C" int mispec_symshift_set_shift(mispec_symshift* S, double sigma)
         {
             HostBand M;
             M.n = n;
-            M.b = int(std::max<int64_t>(1, std::min<int64_t>(b, n - 1)));  // a diagonal matrix is a band of width 1 with zeros
-            M.a.assign(size_t(n) * (M.b + 1), 0.0);
-            for (size_t e = 0; e < S->vals.size(); e++)
-                M.at(S->rows[e], int(S->rows[e] - S->cols[e])) += S->vals[e];
-            for (int64_t i = 0; i < n; i++)
-                M.at(i, 0) -= sigma;
+            M.b = S->band_b;
+            if (S->band0_dev.p && factored_on_device(n, M.b))
+            {
+                M.view = &S->band0;  // A - sigma I is formed on the device from the resident band
+                M.view_dev = S->band0_dev.p;
+                M.shift = sigma;
+            }
+            else
+            {
+                M.a = S->band0;
+                for (int64_t i = 0; i < n; i++)
+                    M.at(i, 0) -= sigma;
+            }
             S->top = std::make_unique<BandLevel>();
             factor_level(S->ctx, M, *S->top);
             S->dense = false;

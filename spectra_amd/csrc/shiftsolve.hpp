@@ -18,6 +18,11 @@ struct mispec_symshift
     std::vector<int64_t> rows, cols;
     std::vector<double> vals;
     int64_t half_bandwidth = 0;
+    // banded path: the unshifted band A(i, i-d), n x (band_b + 1) row-major, built once at construction — on the
+    // host (separator rows, pivots' scale) and resident in HBM (the device factorisation shifts a copy of it)
+    std::vector<double> band0;
+    mispec::DevBuf<double> band0_dev;
+    int band_b = 0;
     double sigma = 0.0;
     bool factored = false;
     bool dense = false;

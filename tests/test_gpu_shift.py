@@ -52,6 +52,32 @@ def test_dense_path_and_failures(ctx):
         sa.SparseSymShiftSolve(big + big.T, ctx=ctx).set_shift(1.0)
 
 
+def test_device_factorisation_reports_vanishing_pivots_and_matches_the_host_one(ctx):
+    # large n: the top level is factored by k_chunk_factor on the device (one lane per chunk)
+    with pytest.raises(ValueError, match="factorization failed"):
+        sa.SparseSymShiftSolve(sp.identity(20_000, format="csc") * 2.0, ctx=ctx).set_shift(2.0)
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, numpy as np, scipy.sparse as sp; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import spectra_amd as sa; from test_gpu_shift import banded_spd\n"
+        "out = []\n"
+        "for n, b in ((60000, 3), (40000, 7)):\n"
+        "    A = banded_spd(n, b, seed=5); op = sa.SparseSymShiftSolve(sp.tril(A).tocsc()); op.set_shift(-0.25)\n"
+        "    out.append(op.perform_op(np.linspace(-1, 1, n)))\n"
+        "sys.stdout.write(np.concatenate(out).tobytes().hex())\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for mode in ("device", "host"):
+        env = dict(os.environ, MISPEC_SHIFT_FACTOR=mode)
+        r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        res.append(np.frombuffer(bytes.fromhex(r.stdout.strip()), dtype=np.float64))
+    assert np.abs(res[0] - res[1]).max() <= 1e-13 * np.abs(res[1]).max()
+
+
 @pytest.mark.parametrize("n,prob,k,m,sigma", SHIFT_CASES)
 @pytest.mark.parametrize("rule", RULES_SYM)
 def test_shift_fixtures_all_rules(ctx, n, prob, k, m, sigma, rule):
