@@ -41,7 +41,7 @@ def parse():
     p.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     p.add_argument("--profile-level", type=int, default=2, choices=[1, 2],
                     help="HIP-event instrumentation of the timed solves: 2 = operator applications only (default), 1 = every kernel family")
-    p.add_argument("--cpu-steps", type=int, default=5, help="Lanczos steps of the CPU sample")
+    p.add_argument("--cpu-steps", type=int, default=20, help="Lanczos steps of the CPU sample (about 10 s of one host core at n = 1e7)")
     p.add_argument("--spmv-reps", type=int, default=50, help="stand-alone SpMV launches timed after the solves")
     return p.parse_args()
 
