@@ -769,7 +769,7 @@ void arnoldi_corrections_host(mispec_fac& F, int i)
             F.beta = 0.0;
             break;
         }
-        double Vf[kMaxOrthCols];
+        double Vf[kMaxCols];
         for (int j = 0; j < i1; j++)
             Vf[j] = F.h_red.p[j];
         correct_vtf(F, F.f.p, F.f.p, i1);  // :281, :285, :287
@@ -915,6 +915,23 @@ void require_init(const mispec_fac* F, const char* who)
         throw Error(MISPEC_ELOGIC, std::string(who) + ": need to call init first");
 }
 
+// V[:, :p] <- V Q with the m x m Q in F.Qdev (Arnoldi.h:326-335).  In place for ncv <= 64; a wider basis goes through
+// the eigenvector workspace, because a panelled product cannot overwrite its own input.
+void compress_basis(mispec_fac& F, int p)
+{
+    const int m = F.m;
+    if (m <= kPanelCols)
+    {
+        launch_vq(*F.ctx, F.V.p, F.ldv, m, F.Qdev.p, m, p, F.V.p, F.ldv, F.nloc);
+        return;
+    }
+    if (F.X.n < size_t(F.ldv) * size_t(p))
+        F.X.alloc(size_t(F.ldv) * size_t(p));
+    F.x_cols = 0;  // whatever Ritz vectors were held there are gone
+    launch_vq(*F.ctx, F.V.p, F.ldv, m, F.Qdev.p, m, p, F.X.p, F.ldv, F.nloc);
+    MISPEC_HIP(hipMemcpyAsync(F.V.p, F.X.p, size_t(F.ldv) * size_t(p) * sizeof(double), hipMemcpyDeviceToDevice, F.stream()));
+}
+
 // f <- f*Q(m-1,k-1) + V[:,k]*H(k,k-1) ; beta = |f|   (Arnoldi.h:337-339)
 void update_f_after_compress(mispec_fac& F, double q_last, double h_sub)
 {
@@ -941,7 +958,7 @@ int fac_create_impl(mispec_ctx* ctx, const mispec_csr* A, const mispec_symshift*
         MISPEC_REQUIRE(int(A != nullptr) + int(S != nullptr) + int(op != nullptr) == 1, "mispec_fac_create: give exactly one operator");
         MISPEC_REQUIRE(n >= 1, "mispec_fac_create: n must be positive");
         MISPEC_REQUIRE(ncv >= 1 && ncv <= n, "mispec_fac_create: need 1 <= ncv <= n");
-        MISPEC_REQUIRE(ncv <= kMaxOrthCols, "mispec_fac_create: the device factorisation holds at most 64 basis vectors (ncv <= 64)");
+        MISPEC_REQUIRE(ncv <= kMaxCols, "mispec_fac_create: the device factorisation holds at most 128 basis vectors (ncv <= 128)");
         if (A && A2)
         {
             MISPEC_REQUIRE(A->ctx == ctx && A2->ctx == ctx, "mispec_fac_create_product: matrix belongs to another context");
@@ -1269,7 +1286,7 @@ extern "C" int mispec_fac_restart_sym(mispec_fac* fac, const double* shifts_host
         // V[:, :k+1] <- V Q  (Arnoldi.h:326-335), in place, straight from the device Q
         {
             Timed t(F, FAM_COMPRESS);
-            launch_vq(*F.ctx, F.V.p, F.ldv, m, F.Qdev.p, m, k + 1, F.V.p, F.ldv, F.nloc);
+            compress_basis(F, k + 1);
         }
         MISPEC_HIP(hipMemcpyAsync(hs, F.d_diag.p, size_t(m) * 8, hipMemcpyDeviceToHost, F.stream()));
         MISPEC_HIP(hipMemcpyAsync(hs + m, F.d_subd.p, size_t(m) * 8, hipMemcpyDeviceToHost, F.stream()));
@@ -1300,7 +1317,7 @@ extern "C" int mispec_fac_compress_V(mispec_fac* fac, const double* Q_host, cons
         F.k = new_k;
         {
             Timed t(F, FAM_COMPRESS);
-            launch_vq(*F.ctx, F.V.p, F.ldv, m, F.Qdev.p, m, new_k + 1, F.V.p, F.ldv, F.nloc);
+            compress_basis(F, new_k + 1);
         }
         update_f_after_compress(F, Q_host[size_t(new_k - 1) * m + (m - 1)], F.Hat(new_k, new_k - 1));
     });

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(kThreads) void k_orth(OrthArgs a)
     constexpr bool kCorrect = (MODE == ORTH_CORRECT_VTF || MODE == ORTH_CORRECT_ONLY);
     constexpr bool kVtf = (MODE != ORTH_CORRECT_ONLY);
     constexpr int kRows = kTileRows * R;
-    __shared__ double cs[kMaxOrthCols];
+    __shared__ double cs[kPanelCols];
     __shared__ __attribute__((aligned(16))) double psum[2][4][kRows];
 
     if (a.status && *a.status != kStepOk)
@@ -71,8 +71,8 @@ __global__ __launch_bounds__(kThreads) void k_orth(OrthArgs a)
 
     if (kCorrect)
     {
-        if (tid < kMaxOrthCols)
-            cs[tid] = (tid < a.ncol) ? a.c_in[tid] : 0.0;
+        if (tid < kPanelCols)
+            cs[tid] = (tid < a.ncol) ? a.c_in[a.col0 + tid] : 0.0;
         __syncthreads();
     }
     double alpha = 0.0;
@@ -88,8 +88,8 @@ __global__ __launch_bounds__(kThreads) void k_orth(OrthArgs a)
     for (int jj = 0; jj < MAXS; jj++)
     {
         const int j = w + 4 * jj;
-        colp[jj] = a.V + int64_t(j < a.ncol ? j : 0) * a.ldv;
-        cw[jj] = (kCorrect && j < kMaxOrthCols) ? cs[j] : 0.0;
+        colp[jj] = a.V + int64_t(a.col0 + (j < a.ncol ? j : 0)) * a.ldv;
+        cw[jj] = (kCorrect && j < kPanelCols) ? cs[j] : 0.0;
         acc[jj] = 0.0;
     }
     double b2 = 0.0, mx = 0.0;
@@ -199,10 +199,10 @@ __global__ __launch_bounds__(kThreads) void k_orth(OrthArgs a)
             const double s = wave_reduce_sum(acc[jj]);
             const int j = w + 4 * jj;
             if (lane == 0 && j < a.ncol)
-                rec[int64_t(j) * a.pstride] = s;
+                rec[int64_t(a.col0 + j) * a.pstride] = s;
         }
     }
-    if (w == 0)
+    if (w == 0 && a.norms)
     {
         b2 = wave_reduce_sum(b2);
         mx = wave_reduce_max(mx);
@@ -294,8 +294,6 @@ __device__ void finish_record(double* red, int ncol, const FinishArgs& fa)
 // the records l, l+64, l+128, ... of each.  All loads of a pass are issued before the first add: the records were
 // written by other XCDs, so they come from beyond the L2 and one load latency is several microseconds — the kernel
 // must pay it once, not once per slot.  One shuffle tree per slot then finishes the sum.
-// Pass A covers columns 0..47 (wave g: g, g+16, g+32) and, while columns 46/47 are not in use, the two scalar
-// slots in their place; pass B (only for more than 46 columns) covers the rest.
 template <int NS>
 __device__ __forceinline__ void reduce_slots(const double* __restrict__ partials, int64_t pstride, int nrec, const int (&slot)[NS],
                                              int lane, double* sh)
@@ -342,24 +340,30 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restri
     if (tid < kPartialLd)
         sh[tid] = 0.0;
     __syncthreads();
-    const bool scalars_in_a = ncol <= 46;
+    // column passes of 48 (wave g: c0+g, c0+g+16, c0+g+32); the two scalar slots ride in the last pass when its
+    // positions 46/47 are free, otherwise in a pass of their own
+    bool scalars_done = false;
+    for (int c0 = 0; c0 == 0 || c0 < ncol; c0 += 48)
     {
         int slot[3];
-        slot[0] = (g < ncol) ? g : -1;
-        slot[1] = (g + 16 < ncol) ? g + 16 : -1;
-        slot[2] = (g + 32 < ncol) ? g + 32 : -1;
-        if (scalars_in_a && g == 14)
-            slot[2] = kSlotMaxAbs;
-        if (scalars_in_a && g == 15)
-            slot[2] = kSlotBeta2;
+        slot[0] = (c0 + g < ncol) ? c0 + g : -1;
+        slot[1] = (c0 + g + 16 < ncol) ? c0 + g + 16 : -1;
+        slot[2] = (c0 + g + 32 < ncol) ? c0 + g + 32 : -1;
+        if (ncol <= c0 + 46)  // block-uniform: only true in the last pass
+        {
+            if (g == 14)
+                slot[2] = kSlotMaxAbs;
+            if (g == 15)
+                slot[2] = kSlotBeta2;
+            scalars_done = true;
+        }
         reduce_slots<3>(partials, pstride, nrec, slot, lane, sh);
     }
-    if (!scalars_in_a)
+    if (!scalars_done)
     {
-        int slot[2];
-        slot[0] = (g + 48 < ncol) ? g + 48 : -1;
-        slot[1] = (g == 0) ? kSlotBeta2 : (g == 1 ? kSlotMaxAbs : -1);
-        reduce_slots<2>(partials, pstride, nrec, slot, lane, sh);
+        int slot[1];
+        slot[0] = (g == 0) ? kSlotBeta2 : (g == 1 ? kSlotMaxAbs : -1);
+        reduce_slots<1>(partials, pstride, nrec, slot, lane, sh);
     }
     __syncthreads();
     if (tid == 0)
@@ -568,14 +572,14 @@ __device__ __forceinline__ void vq_fetch(v2d (&pre)[NJ], const double* __restric
 template <int MAXS>
 __global__ __launch_bounds__(kThreads) void k_vq(const double* __restrict__ V, int64_t ldv, int m,
                                                   const double* __restrict__ Q, int ldq, int p, double* X, int64_t ldx,
-                                                  int64_t n)
+                                                  int64_t n, int accumulate)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Vt = smem;                          // [m][128]
     double* Qs = smem + int64_t(m) * kTileRows;  // [m][4][MAXS]
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int kMaxJ = kMaxOrthCols / 4;  // input columns per wave
+    constexpr int kMaxJ = kPanelCols / 4;  // input columns per wave
     const int nj = (m - w + 3) / 4;          // this wave stages columns w, w+4, ...
 
     for (int idx = tid; idx < m * 4 * MAXS; idx += kThreads)
@@ -611,6 +615,8 @@ __global__ __launch_bounds__(kThreads) void k_vq(const double* __restrict__ V, i
         {
             acc[jj].x = 0.0;
             acc[jj].y = 0.0;
+            if (accumulate && valid && w + 4 * jj < p)  // a later panel of input columns adds to the earlier ones' result
+                acc[jj] = *reinterpret_cast<const double2*>(X + int64_t(w + 4 * jj) * ldx + r);
         }
         for (int j = 0; j < m; j++)
         {
@@ -735,14 +741,23 @@ void launch_orth_mode(const mispec_ctx& ctx, const OrthArgs& a, int grid)
 
 namespace mispec {
 
-int launch_orth(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a)
+namespace {
+int orth_tile_rows(int ncol)
 {
-    MISPEC_REQUIRE(a.ncol >= 0 && a.ncol <= kMaxOrthCols, "orth kernel: more than 64 basis columns");
     static const int rknob = env_int("MISPEC_ORTH_R");
-    const int rows = kTileRows * ((rknob != 1 && (a.ncol + 3) / 4 <= 10) ? 2 : 1);
-    const int64_t ntiles = (a.n + rows - 1) / rows;
-    static const int knob = env_int("MISPEC_ORTH_BLOCKS_PER_CU");
-    const int grid = persistent_grid(ctx, ntiles, knob > 0 ? knob : 4);
+    return kTileRows * ((rknob != 1 && (ncol + 3) / 4 <= 10) ? 2 : 1);
+}
+
+// one launch over at most kPanelCols columns; grid == 0: choose it from the tile count
+int launch_orth_panel(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a, int grid)
+{
+    if (grid == 0)
+    {
+        const int rows = orth_tile_rows(a.ncol);
+        const int64_t ntiles = (a.n + rows - 1) / rows;
+        static const int knob = env_int("MISPEC_ORTH_BLOCKS_PER_CU");
+        grid = persistent_grid(ctx, ntiles, knob > 0 ? knob : 4);
+    }
     MISPEC_REQUIRE(a.pstride >= grid, "orth kernel: partial-record stride smaller than the grid");
     switch (mode)
     {
@@ -760,6 +775,80 @@ int launch_orth(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a)
             break;
     }
     MISPEC_HIP(hipGetLastError());
+    return grid;
+}
+}  // namespace
+
+// Up to kPanelCols columns: one launch.  Wider bases (ncv up to kMaxCols) are processed in column panels that all
+// write into the same partial records (slot = global column index), so one reduction serves the whole step:
+//   VTF          every panel computes its part of c = V'x; the first one also |x|^2
+//   RESID_VTF    panel 0 forms f = w - alpha v_i, |f|^2 and its part of V'f; the others V'f on the finished f
+//   CORRECT_*    dst = src - V c needs every panel before V'dst: the panels subtract one after the other, the last
+//                one (where dst is final) also computes |dst|^2 and its part of V'dst, then the other panels' parts
+//                follow on the finished dst.  V is read 1.5 times instead of once — the price of ncv > 64.
+int launch_orth(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a)
+{
+    MISPEC_REQUIRE(a.ncol >= 0 && a.ncol <= kMaxCols, "orth kernel: more than 128 basis columns");
+    if (a.ncol <= kPanelCols)
+    {
+        OrthArgs one = a;
+        one.col0 = 0;
+        one.norms = 1;
+        return launch_orth_panel(ctx, mode, one, 0);
+    }
+    const int npan = (a.ncol + kPanelCols - 1) / kPanelCols;
+    // all panels must leave the same number of records: one grid for all, valid for the coarsest tiling
+    const int64_t ntiles = (a.n + 2 * kTileRows - 1) / (2 * kTileRows);
+    static const int knob = env_int("MISPEC_ORTH_BLOCKS_PER_CU");
+    const int grid = persistent_grid(ctx, ntiles, knob > 0 ? knob : 4);
+    auto panel = [&](int q) {
+        OrthArgs b = a;
+        b.col0 = q * kPanelCols;
+        b.ncol = std::min(kPanelCols, a.ncol - b.col0);
+        b.norms = 0;
+        return b;
+    };
+    switch (mode)
+    {
+        case ORTH_VTF:
+            for (int q = 0; q < npan; q++)
+            {
+                OrthArgs b = panel(q);
+                b.norms = (q == 0);
+                launch_orth_panel(ctx, ORTH_VTF, b, grid);
+            }
+            break;
+        case ORTH_RESID_VTF:
+            for (int q = 0; q < npan; q++)
+            {
+                OrthArgs b = panel(q);
+                if (q == 0)
+                    b.norms = 1;
+                else
+                    b.src = a.dst;  // the finished f
+                launch_orth_panel(ctx, q == 0 ? ORTH_RESID_VTF : ORTH_VTF, b, grid);
+            }
+            break;
+        case ORTH_CORRECT_VTF:
+        case ORTH_CORRECT_ONLY:
+            for (int q = 0; q < npan; q++)
+            {
+                OrthArgs b = panel(q);
+                if (q > 0)
+                    b.src = a.dst;
+                const bool last = (q == npan - 1);
+                b.norms = last;
+                launch_orth_panel(ctx, (last && mode == ORTH_CORRECT_VTF) ? ORTH_CORRECT_VTF : ORTH_CORRECT_ONLY, b, grid);
+            }
+            if (mode == ORTH_CORRECT_VTF)
+                for (int q = 0; q + 1 < npan; q++)
+                {
+                    OrthArgs b = panel(q);
+                    b.src = a.dst;
+                    launch_orth_panel(ctx, ORTH_VTF, b, grid);
+                }
+            break;
+    }
     return grid;
 }
 
@@ -832,10 +921,11 @@ int launch_resid_norms_complex(const mispec_ctx& ctx, const double* yr, const do
     return grid;
 }
 
-void launch_vq(const mispec_ctx& ctx, const double* V, int64_t ldv, int m, const double* Q, int ldq, int p, double* X,
-               int64_t ldx, int64_t n)
+namespace {
+// one launch: at most kPanelCols input and output columns
+void launch_vq_panel(const mispec_ctx& ctx, const double* V, int64_t ldv, int m, const double* Q, int ldq, int p, double* X,
+                     int64_t ldx, int64_t n, int accumulate)
 {
-    MISPEC_REQUIRE(m >= 1 && m <= kMaxOrthCols && p >= 1 && p <= kMaxOrthCols, "V*Q kernel: needs 1 <= m, p <= 64");
     const int64_t ntiles = (n + kTileRows - 1) / kTileRows;
     const int slots = (p + 3) / 4;
     const int maxs = slots <= 4 ? 4 : slots <= 8 ? 8 : slots <= 12 ? 12 : 16;
@@ -848,7 +938,7 @@ void launch_vq(const mispec_ctx& ctx, const double* V, int64_t ldv, int m, const
     {                                                                                                                  \
         MISPEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vq<S>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                        int(lds)));                                                                     \
-        hipLaunchKernelGGL((k_vq<S>), g, b, lds, ctx.stream, V, ldv, m, Q, ldq, p, X, ldx, n);                         \
+        hipLaunchKernelGGL((k_vq<S>), g, b, lds, ctx.stream, V, ldv, m, Q, ldq, p, X, ldx, n, accumulate);             \
     } while (0)
     if (maxs == 4)
         MISPEC_VQ(4);
@@ -860,6 +950,25 @@ void launch_vq(const mispec_ctx& ctx, const double* V, int64_t ldv, int m, const
         MISPEC_VQ(16);
 #undef MISPEC_VQ
     MISPEC_HIP(hipGetLastError());
+}
+}  // namespace
+
+// X = V Q.  Up to kPanelCols x kPanelCols: one launch, X may alias V.  Wider: panels of output columns, each
+// accumulated over panels of input columns (X must not alias V then; V is read once per output panel).
+void launch_vq(const mispec_ctx& ctx, const double* V, int64_t ldv, int m, const double* Q, int ldq, int p, double* X,
+               int64_t ldx, int64_t n)
+{
+    MISPEC_REQUIRE(m >= 1 && m <= kMaxCols && p >= 1 && p <= kMaxCols, "V*Q kernel: needs 1 <= m, p <= 128");
+    if (m <= kPanelCols && p <= kPanelCols)
+    {
+        launch_vq_panel(ctx, V, ldv, m, Q, ldq, p, X, ldx, n, 0);
+        return;
+    }
+    MISPEC_REQUIRE(X != V, "V*Q kernel: in-place products need m, p <= 64");
+    for (int p0 = 0; p0 < p; p0 += kPanelCols)
+        for (int m0 = 0; m0 < m; m0 += kPanelCols)
+            launch_vq_panel(ctx, V + int64_t(m0) * ldv, ldv, std::min(kPanelCols, m - m0), Q + m0 + int64_t(p0) * ldq, ldq,
+                            std::min(kPanelCols, p - p0), X + int64_t(p0) * ldx, ldx, n, m0 > 0);
 }
 
 int lanczos_epilogue_records(const mispec_ctx& ctx, int64_t n)

@@ -6,13 +6,14 @@ namespace mispec {
 
 // Per-workgroup partial record (kPartialLd slots) written by the orthogonalisation kernels — stored
 // slot-major so that the summing kernel reads contiguously — and summed by launch_reduce_partials in a fixed order (deterministic: no floating-point atomics anywhere).
-constexpr int kPartialLd = 72;
-constexpr int kSlotBeta2 = 64;   // sum f^2
-constexpr int kSlotMaxAbs = 65;  // max |f|
-constexpr int kSlotBeta = 66;    // sqrt(sum f^2)            (filled by the finish step)
-constexpr int kSlotErr = 67;     // max_j |(V'f)_j|          (filled by the finish step)
-constexpr int kSlotAlpha = 68;   // <v, w> of the SpMV epilogue
-constexpr int kMaxOrthCols = 64; // basis columns handled by one launch (ncv <= 64 on the device path)
+constexpr int kMaxCols = 128;    // basis columns of a factorisation (ncv <= 128: the restart kernels hold an m x m Q in LDS)
+constexpr int kPanelCols = 64;   // basis columns handled by ONE orthogonalisation / V*Q launch; wider bases go in panels
+constexpr int kPartialLd = kMaxCols + 8;
+constexpr int kSlotBeta2 = kMaxCols;       // sum f^2
+constexpr int kSlotMaxAbs = kMaxCols + 1;  // max |f|
+constexpr int kSlotBeta = kMaxCols + 2;    // sqrt(sum f^2)            (filled by the finish step)
+constexpr int kSlotErr = kMaxCols + 3;     // max_j |(V'f)_j|          (filled by the finish step)
+constexpr int kSlotAlpha = kMaxCols + 4;   // <v, w> of the SpMV epilogue
 
 enum OrthMode
 {
@@ -36,8 +37,8 @@ struct StepState
     int stop_step; // step at which it stopped
     int stop_count;
     int pad_;
-    double diag[kMaxOrthCols];  // H(i,i)
-    double subd[kMaxOrthCols];  // H(i+1,i)
+    double diag[kMaxCols];  // H(i,i)
+    double subd[kMaxCols];  // H(i+1,i)
 };
 enum
 {
@@ -72,7 +73,9 @@ struct OrthArgs
 {
     const double* V = nullptr;  // basis, column-major
     int64_t ldv = 0;
-    int ncol = 0;               // columns 0..ncol-1 take part
+    int ncol = 0;               // columns 0..ncol-1 take part (launch_orth splits more than kPanelCols into panels)
+    int col0 = 0;               // set by launch_orth: first basis column of this panel (V column, c_in entry, record slot)
+    int norms = 1;              // set by launch_orth: this panel writes the |f|^2 / max|f| slots
     int64_t n = 0;              // local rows
     const double* src = nullptr;  // VTF: f ; RESID: w ; CORRECT: input vector
     double* dst = nullptr;        // RESID / CORRECT output (may alias src)

@@ -74,7 +74,8 @@ def test_arnoldi_cpp_identities_user_op(ctx, symmetric):
         f2.factorize_from(3, 5)                                             # Lanczos.h:70-75
 
 
-@pytest.mark.parametrize("n,prob,m", [(100, 0.1, 20), (1000, 0.01, 50), (1000, 0.01, 64)])
+@pytest.mark.parametrize("n,prob,m", [(100, 0.1, 20), (1000, 0.01, 50), (1000, 0.01, 64), (1000, 0.01, 65), (1000, 0.01, 100),
+                                      (1000, 0.01, 128)])  # more than 64 columns: column panels
 def test_lanczos_on_device_matrix_vs_oracle(ctx, n, prob, m):
     A, S = sparse_fixture(n, prob)
     op = sa.SparseSymMatProd(A, ctx=ctx)
@@ -165,3 +166,27 @@ def test_restart_primitives_vs_oracle(ctx):
     check_identities(fac, Sd, m, tol=1e-10)
     Y = np.random.default_rng(0).uniform(-1, 1, (m, 5))
     assert np.abs(fac.ritz_vectors(Y) - fac.matrix_V() @ Y).max() < 1e-12
+
+
+def test_wide_basis_restart_and_limits(ctx):
+    # ncv > 64: orthogonalisation in column panels, out-of-place V*Q, LDS-resident restart kernel
+    n, m, k = 3000, 100, 45
+    A, S = sparse_fixture(1000, 0.01)
+    S3 = sp.block_diag([S, S * 0.5 + sp.identity(1000), S * 0.25 - sp.identity(1000)], format="csr")
+    fac = sa.Factorization(sa.SparseGenMatProd(S3, ctx=ctx), m, True)
+    fac.init_random(0)
+    fac.factorize_from(1, m)
+    check_identities(fac, S3.toarray(), m, tol=1e-11)
+    ev, U = fac.tridiag_eigen()
+    order = np.argsort(-np.abs(ev))
+    fac.restart_sym(ev[order][k:])
+    assert fac.subspace_dim() == k
+    V, H, f = fac.matrix_V(k), fac.matrix_H()[:k, :k], fac.vector_f()
+    Sd = S3.toarray()
+    resid = Sd @ V - V @ H
+    resid[:, k - 1] -= f
+    assert np.abs(resid).max() < 1e-10 and np.abs(V.T @ V - np.eye(k)).max() < 1e-11   # A V = V H + f e_k'
+    fac.factorize_from(k, m)
+    check_identities(fac, Sd, m, tol=1e-10)
+    with pytest.raises(ValueError, match="128"):
+        sa.Factorization(sa.SparseGenMatProd(S3, ctx=ctx), 129, True)

@@ -126,3 +126,17 @@ def test_device_driven_arnoldi_steps_equal_host_driven_steps():
         outs.append(r.stdout.split())
     assert outs[0][:4] == outs[1][:4]
     assert float(outs[0][4]) < 0.5 * float(outs[1][4])
+
+
+def test_gen_wide_basis(ctx):
+    # GenEigsSolver with ncv = 80 (> 64 columns: panelled Arnoldi orthogonalisation)
+    from helpers import sparse_fixture
+
+    n, nev, ncv = 1000, 30, 80
+    A, _ = sparse_fixture(n, 0.01)
+    eigs = sa.GenEigsSolver(sa.SparseGenMatProd(A, ctx=ctx), nev, ncv)
+    eigs.init()
+    nconv = eigs.compute(sa.SortRule.LargestMagn, 1000, 1e-10)
+    assert nconv >= nev - 1  # a conjugate pair may be split at the nev boundary
+    ev, U = eigs.eigenvalues(), eigs.eigenvectors()
+    assert np.abs(A @ U - U * ev).max() <= 1e-9

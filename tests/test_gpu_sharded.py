@@ -107,3 +107,16 @@ def test_wide_pattern_keeps_the_allgather():
         assert not r["exchange"][0] and f["exchange"][0]
         assert np.array_equal(r["evals"], f["evals"]) and r["nops"] == f["nops"]
         assert r["res"].max() <= 1e-9
+
+
+def test_sharded_wide_basis(ctx):
+    # ncv > 64 on two shards: panelled orthogonalisation + one all-reduce of the whole record per reduction
+    n, offsets, nev, ncv = 30_001, (1, 2, 3, 100, 101, 2000, 2001), 34, 80
+    single = sa.SymEigsSolver(sa.SparseSymMatProd.synth_band(n, offsets=offsets, ctx=ctx), nev, ncv)
+    single.init()
+    assert single.compute(sa.SortRule.LargestMagn, 1000, 1e-11) == nev
+    res = run_sharded(2, n, offsets, nev, ncv, sa.SortRule.LargestMagn, 1e-11)
+    for r in res:
+        assert r["nconv"] == nev and np.array_equal(r["evals"], res[0]["evals"])
+        assert r["res"].max() <= 1e-10
+    assert np.abs(res[0]["evals"] - single.eigenvalues()).max() < 1e-10

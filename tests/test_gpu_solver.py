@@ -251,3 +251,31 @@ def test_ritz_pairs_on_device_or_host_give_the_same_solve():
     assert outs[0][:3] == outs[1][:3]
     a, b = np.array(outs[0][3:], dtype=float), np.array(outs[1][3:], dtype=float)
     assert np.abs(a - b).max() <= 1e-12
+
+
+@pytest.mark.parametrize("rule", ["LargestMagn", "BothEnds"])
+def test_many_eigenpairs_wide_basis(ctx, rule):
+    # nev = 45, ncv = 100: beyond one 64-column panel (the reference has no such limit)
+    n, nev, ncv = 1000, 45, 100
+    A, S = sparse_fixture(n, 0.01)
+    eigs = sa.SymEigsSolver(sa.SparseSymMatProd(A, ctx=ctx), nev, ncv)
+    eigs.init()
+    assert eigs.compute(sa.SortRule[rule], 1000, 1e-10) == nev
+    ev, U = eigs.eigenvalues(), eigs.eigenvectors()
+    assert np.abs(S @ U - U * ev).max() <= 1e-9
+    oe = O.SymEigsSolver(O.Op.csr(n, n, S.indptr, S.indices, S.data), nev, ncv)
+    oe.init()
+    assert oe.compute(getattr(O, rule), 1000, 1e-10) == nev
+    assert np.abs(ev - oe.eigenvalues()).max() <= 1e-9
+    assert eigs.num_operations() == pytest.approx(oe.num_operations(), rel=0.15)
+
+
+def test_wide_basis_at_scale(ctx):
+    n, nev, ncv = 300_000, 40, 96
+    op = sa.SparseSymMatProd.synth_band(n, ctx=ctx)
+    eigs = sa.SymEigsSolver(op, nev, ncv)
+    eigs.init()
+    assert eigs.compute(sa.SortRule.LargestAlge, 1000, 1e-11) == nev
+    assert eigs.residuals().max() <= 1e-10
+    ev = eigs.eigenvalues()
+    assert np.all(np.diff(ev) <= 0)
