@@ -66,6 +66,11 @@ def lib():
             "oracle_op_diag": (vp, [C.c_long, dp]),
             "oracle_op_callback": (vp, [C.c_long, C.CFUNCTYPE(None, dp, dp)]),
             "oracle_op_free": (None, [vp]),
+            "oracle_geigs_reginv_create": (vp, [C.c_long, ip, ip, dp, ip, ip, dp, C.c_long, C.c_long]),
+            "oracle_geigs_free": (None, [vp]),
+            "oracle_geigs_symeigs": (vp, [vp]),
+            "oracle_geigs_cg_solve": (C.c_long, [vp, dp, dp]),
+            "oracle_geigs_bprod": (None, [vp, dp, dp]),
             "oracle_op_rows": (C.c_long, [vp]),
             "oracle_op_apply": (None, [vp, dp, dp]),
             "oracle_op_time": (C.c_double, [vp, dp, dp, C.c_int]),
@@ -407,6 +412,44 @@ class SymEigsSolver:
     def __del__(self):
         try:
             lib().oracle_symeigs_free(self.h)
+        except Exception:
+            pass
+
+
+class SymGEigsRegInvSolver(SymEigsSolver):
+    """SymGEigsSolver<SparseSymMatProd, SparseRegularInverse, GEigsMode::RegularInverse> (SymGEigsSolver.h:224-238) on the
+    oracle: A, B scipy sparse matrices of which the lower triangle is used; B^{-1} by the restated conjugate gradient,
+    inner products in the B-inner product."""
+
+    def __init__(self, A, B, nev, ncv):
+        import scipy.sparse as sp
+
+        A, B = sp.csc_matrix(A), sp.csc_matrix(B)
+        A.sort_indices()
+        B.sort_indices()
+        n = A.shape[0]
+        self._keep = (_i32(A.indptr), _i32(A.indices), _f64(A.data), _i32(B.indptr), _i32(B.indices), _f64(B.data))
+        k = self._keep
+        self.holder = lib().oracle_geigs_reginv_create(n, _ip(k[0]), _ip(k[1]), _dp(k[2]), _ip(k[3]), _ip(k[4]), _dp(k[5]), nev, ncv)
+        if not self.holder:
+            raise ValueError(lib().oracle_last_error().decode())
+        self.h = lib().oracle_geigs_symeigs(self.holder)
+        self.op, self.nev, self.ncv, self.n = None, nev, min(ncv, n), n
+
+    def cg_solve(self, rhs):
+        """B^{-1} rhs; returns (x, iterations) — iterations == -1: not converged."""
+        x = np.empty(self.n)
+        it = lib().oracle_geigs_cg_solve(self.holder, _dp(_f64(rhs)), _dp(x))
+        return x, it
+
+    def b_product(self, x):
+        y = np.empty(self.n)
+        lib().oracle_geigs_bprod(self.holder, _dp(_f64(x)), _dp(y))
+        return y
+
+    def __del__(self):
+        try:
+            lib().oracle_geigs_free(self.holder)
         except Exception:
             pass
 

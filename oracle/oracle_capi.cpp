@@ -310,6 +310,38 @@ void* oracle_symeigs_create(void* op, long nev, long ncv)
     return rc == 0 ? s : nullptr;
 }
 void oracle_symeigs_free(void* s) { delete static_cast<SymEigs*>(s); }
+
+// ---- generalized problem, regular-inverse mode (SymGEigsSolver.h:224-238 + SparseRegularInverse.h) ----------
+// A and B as CSC of which the lower triangle is used (the reference's defaults).  The returned holder owns
+// everything; oracle_geigs_symeigs() gives the inner solver for the oracle_symeigs_* calls (do not free it).
+struct GEigsHolder
+{
+    SparseSymCsc A, B;
+    RegularInverse binv;
+    RegInvOp op;
+    SymEigs eigs;
+    GEigsHolder(long n, const int* acp, const int* ari, const double* av, const int* bcp, const int* bri, const double* bv, long nev,
+                long ncv) :
+        A(n, acp, ari, av, true), B(n, bcp, bri, bv, true), binv(B), op(A, binv), eigs(op, nev, ncv, &B)
+    {}
+};
+void* oracle_geigs_reginv_create(long n, const int* acp, const int* ari, const double* av, const int* bcp, const int* bri,
+                                 const double* bv, long nev, long ncv)
+{
+    GEigsHolder* h = nullptr;
+    int rc = guarded([&] { h = new GEigsHolder(n, acp, ari, av, bcp, bri, bv, nev, ncv); });
+    return rc == 0 ? h : nullptr;
+}
+void oracle_geigs_free(void* h) { delete static_cast<GEigsHolder*>(h); }
+void* oracle_geigs_symeigs(void* h) { return &static_cast<GEigsHolder*>(h)->eigs; }
+// x = B^{-1} rhs by the restated ConjugateGradient; returns the iteration count, or -1 if it did not converge
+long oracle_geigs_cg_solve(void* h, const double* rhs, double* x)
+{
+    auto* H = static_cast<GEigsHolder*>(h);
+    const bool ok = H->binv.solve(rhs, x);
+    return ok ? long(H->binv.last_iterations) : -1;
+}
+void oracle_geigs_bprod(void* h, const double* x, double* y) { static_cast<GEigsHolder*>(h)->B.perform_op(x, y); }
 void oracle_symeigs_set_shift_invert(void* s, double sigma)
 {
     static_cast<SymEigs*>(s)->shift_invert = true;

@@ -31,6 +31,7 @@
 #include <functional>
 #include <stdexcept>
 #include <string>
+#include <limits>
 #include <vector>
 
 namespace oracle {
@@ -333,6 +334,91 @@ inline double max_abs(const double* x, Index n)
 // ----------------------------------------------------------------------------
 // LinAlg/Givens.h:22-86 StableScaling<double>::run (real overload)
 // Given a >= b > 0: r = sqrt(a^2+b^2), c = a/r, s = b/r.
+// ----------------------------------------------------------------------------
+// Generalized problem A x = lambda B x, regular-inverse mode.
+//   MatOp/SparseRegularInverse.h:55-127 — B held as a sparse matrix of which the Uplo triangle is used;
+//     perform_op: y = selfadjointView<Uplo>(B) x (:122-127);  solve: y = B^{-1} x by Eigen::ConjugateGradient
+//     with its defaults (:85-96): lower triangle, diagonal (Jacobi) preconditioner, tolerance = epsilon,
+//     at most 2n iterations, start vector 0.
+//   MatOp/internal/SymGEigsRegInvOp.h:76-81 — the Krylov operator y = B^{-1} (A x).
+// [Eigen] ConjugateGradient is restated from Eigen 3.4.0's published algorithm
+// (IterativeLinearSolvers/ConjugateGradient.h, conjugate_gradient()): r = b; stop when |r|^2 (updated by
+// recurrence) < max(tol^2 |b|^2, min); p = M^{-1} r; each iteration  t = B p, alpha = (r.z)/(p.t), x += alpha p,
+// r -= alpha t, z = M^{-1} r, beta = (r.z)_new/(r.z)_old, p = z + beta p.
+// ----------------------------------------------------------------------------
+struct RegularInverse
+{
+    const SparseSymCsc& B;
+    const Index n;
+    std::vector<double> invdiag;
+    mutable Index last_iterations = 0;
+    explicit RegularInverse(const SparseSymCsc& B_) : B(B_), n(B_.n), invdiag(B_.n, 1.0)
+    {
+        for (Index j = 0; j < n; j++)  // DiagonalPreconditioner: 1/diag, 1 where the diagonal entry is zero or absent
+            for (int p = B.colptr[j]; p < B.colptr[j + 1]; p++)
+                if (B.rowind[p] == j && B.val[p] != 0.0)
+                    invdiag[j] = 1.0 / B.val[p];
+    }
+    // returns false if the iteration limit was hit before the tolerance
+    bool solve(const double* rhs, double* x) const
+    {
+        std::vector<double> r(rhs, rhs + n), p(n), z(n), tmp(n);
+        std::fill(x, x + n, 0.0);
+        last_iterations = 0;
+        const double rhs2 = dot(rhs, rhs, n);
+        if (rhs2 == 0.0)
+            return true;
+        const double tol = kEps;
+        const double threshold = std::max(tol * tol * rhs2, std::numeric_limits<double>::min());
+        double r2 = dot(r.data(), r.data(), n);
+        if (r2 < threshold)
+            return true;
+        for (Index i = 0; i < n; i++)
+            p[i] = invdiag[i] * r[i];
+        double abs_new = dot(r.data(), p.data(), n);
+        const Index max_iters = 2 * n;
+        Index it = 0;
+        while (it < max_iters)
+        {
+            B.perform_op(p.data(), tmp.data());
+            const double alpha = abs_new / dot(p.data(), tmp.data(), n);
+            for (Index i = 0; i < n; i++)
+                x[i] += alpha * p[i];
+            for (Index i = 0; i < n; i++)
+                r[i] -= alpha * tmp[i];
+            r2 = dot(r.data(), r.data(), n);
+            if (r2 < threshold)
+                break;
+            for (Index i = 0; i < n; i++)
+                z[i] = invdiag[i] * r[i];
+            const double abs_old = abs_new;
+            abs_new = dot(r.data(), z.data(), n);
+            const double beta = abs_new / abs_old;
+            for (Index i = 0; i < n; i++)
+                p[i] = z[i] + beta * p[i];
+            it++;
+        }
+        last_iterations = it;
+        return r2 < threshold;
+    }
+};
+
+// SymGEigsRegInvOp.h:76-81
+struct RegInvOp : Op
+{
+    const Op& A;
+    const RegularInverse& Binv;
+    mutable std::vector<double> cache;
+    RegInvOp(const Op& A_, const RegularInverse& Binv_) : A(A_), Binv(Binv_), cache(Binv_.n) {}
+    Index rows() const override { return Binv.n; }
+    void perform_op(const double* x, double* y) const override
+    {
+        A.perform_op(x, cache.data());
+        if (!Binv.solve(cache.data(), y))
+            throw std::runtime_error("SparseRegularInverse: CG solver does not converge");  // SparseRegularInverse.h:113-114
+    }
+};
+
 // ----------------------------------------------------------------------------
 inline void stable_scaling(double a, double b, double& r, double& c, double& s)
 {
@@ -765,13 +851,39 @@ public:
     std::vector<double> f;
     double beta = 0.0;
 
-    Factorization(const Op& op_, Index m_) : op(op_), n(op_.rows()), m(m_) {}
+    // Generalized problems (SymGEigsSolver.h:224-238, RegularInverse mode): inner products are taken in the B-inner
+    // product, MatOp/internal/ArnoldiOp.h:68-101 — B*y is formed first (m_cache), then the plain dot / V' product.
+    // bop == nullptr is the IdentityBOp specialisation (:113-162): plain dot, norm and V'y.
+    const Op* bop = nullptr;
+    mutable std::vector<double> bcache;
+
+    Factorization(const Op& op_, Index m_, const Op* bop_ = nullptr) : op(op_), n(op_.rows()), m(m_), bop(bop_) {}
+
+    double ip(const double* x, const double* y) const  // ArnoldiOp::inner_product
+    {
+        if (!bop)
+            return dot(x, y, n);
+        bcache.resize(n);
+        bop->perform_op(y, bcache.data());
+        return dot(x, bcache.data(), n);
+    }
+    double nrm(const double* x) const { return std::sqrt(ip(x, x)); }  // ArnoldiOp::norm
+    void adj(Index ncol, const double* y, double* res) const          // ArnoldiOp::adjoint_product
+    {
+        if (!bop)
+        {
+            adjoint_product(V.a.data(), n, n, ncol, y, res);
+            return;
+        }
+        bcache.resize(n);
+        bop->perform_op(y, bcache.data());
+        adjoint_product(V.a.data(), n, n, ncol, bcache.data(), res);
+    }
 
     // Arnoldi.h:66-115
     void expand_basis(Index ncol, Index seed, std::vector<double>& fv, double& fnorm, Index& op_counter)
     {
         std::vector<double> v(n), Vf(ncol);
-        const double* Vp = V.a.data();
         for (Index iter = 0; iter < 5; iter++)
         {
             SimpleRandom rng(static_cast<unsigned long>(seed + 123 * iter));
@@ -783,7 +895,7 @@ public:
             }
             else
                 rng.fill(fv.data(), n);
-            adjoint_product(Vp, n, n, ncol, fv.data(), Vf.data());
+            adj(ncol, fv.data(), Vf.data());
             for (Index j = 0; j < ncol; j++)  // f -= V * Vf
             {
                 const double cj = Vf[j];
@@ -791,8 +903,8 @@ public:
                 for (Index i = 0; i < n; i++)
                     fv[i] -= vj[i] * cj;
             }
-            fnorm = norm2(fv.data(), n);
-            adjoint_product(Vp, n, n, ncol, fv.data(), Vf.data());
+            fnorm = nrm(fv.data());
+            adj(ncol, fv.data(), Vf.data());
             double ortho_err = max_abs(Vf.data(), ncol);
             int count = 0;
             while (count < 3 && ortho_err >= kEps * fnorm)
@@ -804,8 +916,8 @@ public:
                     for (Index i = 0; i < n; i++)
                         fv[i] -= vj[i] * cj;
                 }
-                fnorm = norm2(fv.data(), n);
-                adjoint_product(Vp, n, n, ncol, fv.data(), Vf.data());
+                fnorm = nrm(fv.data());
+                adj(ncol, fv.data(), Vf.data());
                 ortho_err = max_abs(Vf.data(), ncol);
                 count++;
             }
@@ -820,13 +932,13 @@ public:
         V.resize(n, m);
         H.resize(m, m);
         f.assign(n, 0.0);
-        const double v0norm = norm2(v0, n);
+        const double v0norm = nrm(v0);
         if (v0norm < kNear0)
             throw std::invalid_argument("initial residual vector cannot be zero");
         double* v = V.col(0);
         op.perform_op(v0, v);
         op_counter++;
-        const double vnorm = norm2(v, n);
+        const double vnorm = nrm(v);
         if (vnorm < kNear0)
             for (Index i = 0; i < n; i++)
                 v[i] = v0[i] / v0norm;  // :162-165
@@ -836,7 +948,7 @@ public:
         std::vector<double> w(n);
         op.perform_op(v, w.data());
         op_counter++;
-        H(0, 0) = dot(v, w.data(), n);
+        H(0, 0) = ip(v, w.data());
         for (Index i = 0; i < n; i++)
             f[i] = w[i] - v[i] * H(0, 0);
         if (max_abs(f.data(), n) < kEps * std::fabs(H(0, 0)))  // :183-191
@@ -845,7 +957,7 @@ public:
             beta = 0.0;
         }
         else
-            beta = norm2(f.data(), n);
+            beta = nrm(f.data());
         k = 1;
     }
 
@@ -893,7 +1005,7 @@ public:
                     v[r] = f[r] / beta;  // :106
                 if (beta < eps_sqrt)
                 {
-                    const double Viv = dot(V.col(i - 1), v, n);  // :110
+                    const double Viv = ip(V.col(i - 1), v);  // :110
                     restart = (std::fabs(Viv) > eps_sqrt);
                 }
             }
@@ -916,14 +1028,14 @@ public:
                 for (Index r = 0; r < n; r++)
                     w[r] -= h * vp[r];
             }
-            H(i, i) = dot(v, w.data(), n);  // :142
+            H(i, i) = ip(v, w.data());  // :142
             const double hii = H(i, i);
             for (Index r = 0; r < n; r++)
                 f[r] = w[r] - hii * v[r];  // :145
-            beta = norm2(f.data(), n);      // :146
+            beta = nrm(f.data());      // :146
 
             const Index i1 = i + 1;
-            adjoint_product(V.a.data(), n, n, i1, f.data(), Vf.data());  // :152
+            adj(i1, f.data(), Vf.data());  // :152
             double ortho_err = max_abs(Vf.data(), i1);
             int count = 0;
             while (count < 5 && ortho_err > kEps * beta)  // :156
@@ -938,8 +1050,8 @@ public:
                 H(i - 1, i) += Vf[i - 1];     // :173-175
                 H(i, i - 1) = H(i - 1, i);
                 H(i, i) += Vf[i];
-                beta = norm2(f.data(), n);    // :177
-                adjoint_product(V.a.data(), n, n, i1, f.data(), Vf.data());
+                beta = nrm(f.data());    // :177
+                adj(i1, f.data(), Vf.data());
                 ortho_err = max_abs(Vf.data(), i1);
                 count++;
             }
@@ -1047,7 +1159,7 @@ public:
         const double* vk = V.col(k);
         for (Index r = 0; r < n; r++)
             f[r] = f[r] * q + vk[r] * h;  // :337
-        beta = norm2(f.data(), n);
+        beta = nrm(f.data());
     }
 };
 
@@ -1069,8 +1181,10 @@ public:
     bool shift_invert = false;
     double sigma = 0.0;
 
-    SymEigs(const Op& op_, Index nev_, Index ncv_) :
-        op(op_), n(op_.rows()), nev(nev_), ncv(ncv_ > n ? n : ncv_), fac(op_, ncv_ > n ? n : ncv_)
+    // bop_: the B operator of a generalized problem in regular-inverse mode (HermEigsBase<ModeMatOp, BOpType>,
+    // SymGEigsSolver.h:224-238); nullptr = standard problem
+    SymEigs(const Op& op_, Index nev_, Index ncv_, const Op* bop_ = nullptr) :
+        op(op_), n(op_.rows()), nev(nev_), ncv(ncv_ > n ? n : ncv_), fac(op_, ncv_ > n ? n : ncv_, bop_)
     {
         // HermEigsBase.h:267-271
         if (nev_ < 1 || nev_ > n - 1)
