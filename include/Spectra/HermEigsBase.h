@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <stdexcept>
+#include <utility>
 #include <vector>
 
 #include "LinAlg/Lanczos.h"
@@ -32,7 +33,9 @@ class IdentityBOp
 template <typename OpType, typename BOpType = IdentityBOp>
 class HermEigsBase
 {
-    static_assert(std::is_same<BOpType, IdentityBOp>::value, "only standard problems (B = I) run on the device path");
+    // BOpType other than IdentityBOp: the generalized problem in regular-inverse mode — OpType is then a
+    // SymGEigsRegInvOp, whose device hooks tell the factorisation to use the B-inner product
+    // (reference: ArnoldiOp<Scalar, OpType, BOpType>, MatOp/internal/ArnoldiOp.h:36-101).
 
 private:
     using Scalar = typename OpType::Scalar;
@@ -44,6 +47,8 @@ private:
     using LanczosFac = Lanczos<OpType>;
 
 protected:
+    // An operator passed as an rvalue is moved into this container and m_op refers to it (reference :73-79)
+    std::vector<OpType> m_op_container;
     const OpType& m_op;   // matrix operator for A
     const Index m_n;      // dimension of A
     const Index m_nev;    // number of eigenvalues requested
@@ -60,6 +65,12 @@ private:
     CompInfo m_info;
 
     static Index check_ncv(Index ncv, Index n) { return ncv > n ? n : ncv; }
+    static std::vector<OpType> create_op_container(OpType&& rval)
+    {
+        std::vector<OpType> container;
+        container.emplace_back(std::move(rval));
+        return container;
+    }
 
     // Ritz pairs of H, wanted ones first (reference :205-224)
     void retrieve_ritzpair(SortRule selection)
@@ -173,6 +184,19 @@ public:
         m_nmatop(0),
         m_niter(0),
         m_fac(op, m_ncv),
+        m_info(CompInfo::NotComputed)
+    {}
+
+    // Same for an operator object the solver is to own (the generalized solvers build theirs on the fly; reference :275-288)
+    HermEigsBase(OpType&& op, const BOpType& /*Bop*/, Index nev, Index ncv) :
+        m_op_container(create_op_container(std::move(op))),
+        m_op(m_op_container.front()),
+        m_n(m_op.rows()),
+        m_nev(nev),
+        m_ncv(check_args(m_op.rows(), nev, ncv)),
+        m_nmatop(0),
+        m_niter(0),
+        m_fac(m_op, m_ncv),
         m_info(CompInfo::NotComputed)
     {}
 

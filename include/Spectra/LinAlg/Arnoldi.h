@@ -45,6 +45,12 @@ template <typename T>
 struct has_device_product<T, std::void_t<decltype(std::declval<const T&>().mispec_product_second())>> : std::true_type
 {};
 template <typename T, typename = void>
+struct has_device_geigs : std::false_type
+{};
+template <typename T>
+struct has_device_geigs<T, std::void_t<decltype(std::declval<const T&>().mispec_geigs_b_operator())>> : std::true_type
+{};
+template <typename T, typename = void>
 struct has_device_context : std::false_type
 {};
 template <typename T>
@@ -115,6 +121,18 @@ protected:
                                                   static_cast<int>(m_m), &raw));
         m_fac = std::shared_ptr<mispec_fac>(raw, [](mispec_fac* p) { (void) mispec_fac_destroy(p); });
     }
+    // generalized problem, regular-inverse mode: y = B^{-1}(A x) with B-inner products, A and B on the device
+    template <typename T = OpType>
+    typename std::enable_if<internal::has_device_geigs<T>::value>::type bind(bool symmetric)
+    {
+        if (!symmetric)
+            throw std::invalid_argument("Arnoldi: the generalized regular-inverse operator is symmetric (Lanczos) only");
+        m_ctx = internal::borrow_context(m_op.mispec_context());
+        mispec_fac* raw = nullptr;
+        internal::check(mispec_fac_create_geigs_reginv(m_ctx.get(), m_op.mispec_geigs_matrix(), m_op.mispec_geigs_b_operator(),
+                                                       static_cast<int>(m_m), &raw));
+        m_fac = std::shared_ptr<mispec_fac>(raw, [](mispec_fac* p) { (void) mispec_fac_destroy(p); });
+    }
     template <typename T = OpType>
     typename std::enable_if<internal::has_device_solver<T>::value>::type bind(bool symmetric)
     {
@@ -126,7 +144,7 @@ protected:
     }
     template <typename T = OpType>
     typename std::enable_if<!internal::has_device_matrix<T>::value && !internal::has_device_solver<T>::value &&
-                            !internal::has_device_product<T>::value>::type
+                            !internal::has_device_product<T>::value && !internal::has_device_geigs<T>::value>::type
     bind(bool symmetric)
     {
         m_ctx = internal::context_of(m_op);

@@ -165,6 +165,26 @@ typedef int (*mispec_op_fn)(void* user, const double* x_in_host, double* y_out_h
 int mispec_fac_create(mispec_ctx* ctx, const mispec_csr* A, mispec_op_fn op, void* op_user, int64_t n, int ncv,
                       int symmetric, mispec_fac** out);
 /* The same with the operator (A - sigma I)^{-1} of a device-resident shift solver (SymEigsShiftSolver path). */
+/* ---------------------------------------------------------------------------
+ * Generalized symmetric problem A x = lambda B x, regular-inverse mode
+ * (SymGEigsSolver.h:224-238 with MatOp/SparseRegularInverse.h:55-127).
+ * mispec_reginv is the B operator: the chosen triangle of B mirrored into a
+ * CSR matrix in HBM; perform_op = B x, solve = B^{-1} x by conjugate gradient
+ * (Jacobi preconditioner, tolerance epsilon, <= 2n iterations: the defaults
+ * the reference inherits from Eigen::ConjugateGradient).
+ * ------------------------------------------------------------------------- */
+typedef struct mispec_reginv mispec_reginv;
+int mispec_reginv_create(mispec_ctx* ctx, int64_t n, const int32_t* outer_host, const int32_t* inner_host,
+                         const double* val_host, char uplo, int row_major, mispec_reginv** out);
+int mispec_reginv_destroy(mispec_reginv* B);
+int64_t mispec_reginv_rows(const mispec_reginv* B);
+int mispec_reginv_perform_op_host(const mispec_reginv* B, const double* x_host, double* y_host); /* y = B x      */
+int mispec_reginv_solve_host(const mispec_reginv* B, const double* x_host, double* y_host);      /* y = B^-1 x   */
+int64_t mispec_reginv_last_iterations(const mispec_reginv* B);                                   /* of that solve */
+/* Lanczos factorisation of y = B^{-1}(A x) in the B-inner product (MatOp/internal/SymGEigsRegInvOp.h:76-81 +
+ * ArnoldiOp.h:68-101): every dot product / norm / V'f of Lanczos.h is taken as x'By.  Single GPU. */
+int mispec_fac_create_geigs_reginv(mispec_ctx* ctx, const mispec_csr* A, const mispec_reginv* B, int ncv, mispec_fac** out);
+
 /* Product operator y = A2 (A x) with A (p x n) and A2 (n x p) resident in HBM — the SVDTallMatOp (A2 = A') /
  * SVDWideMatOp (A = M', A2 = M) of contrib/PartialSVDSolver.h:36-110 as two chained SpMVs; symmetric (Lanczos).
  * Not available on a row-sharded context. */
@@ -250,6 +270,9 @@ int mispec_symeigs_create_op(mispec_ctx* ctx, mispec_op_fn op, void* op_user, in
                              mispec_symeigs** out);
 /* Spectra::SymEigsShiftSolver<Spectra::SparseSymShiftSolve<double>> (SymEigsShiftSolver.h:190-195): calls
  * set_shift(sigma) on S, iterates on (A - sigma I)^{-1} and maps the Ritz values back (lambda = 1/nu + sigma). */
+/* SymGEigsSolver<SparseSymMatProd, SparseRegularInverse, GEigsMode::RegularInverse>. */
+int mispec_symeigs_create_geigs_reginv(mispec_ctx* ctx, const mispec_csr* A, const mispec_reginv* B, int64_t nev, int64_t ncv,
+                                       mispec_symeigs** out);
 /* SymEigsSolver over the product operator of mispec_fac_create_product (PartialSVDSolver's inner solver). */
 int mispec_symeigs_create_product(mispec_ctx* ctx, const mispec_csr* A, const mispec_csr* A2, int64_t nev, int64_t ncv,
                                   mispec_symeigs** out);

@@ -17,7 +17,7 @@ from . import _capi
 from ._capi import MispecError, Profile, build_library, check, lib
 
 __all__ = ["SortRule", "CompInfo", "Context", "SparseSymMatProd", "SparseGenMatProd", "SparseSymShiftSolve", "SymEigsSolver",
-           "SymEigsShiftSolver", "GenEigsSolver", "SVDMatOp", "PartialSVDSolver", "shard_block",
+           "SymEigsShiftSolver", "GenEigsSolver", "SVDMatOp", "PartialSVDSolver", "SparseRegularInverse", "SymGEigsSolver", "shard_block",
            "Factorization", "tridiag_qr", "tridiag_eigen", "hess_qr", "double_shift_qr", "hess_schur", "hess_eigen", "MispecError", "build_library", "shard_range", "BAND_OFFSETS", "SYNTH_SEED"]
 
 BAND_OFFSETS = (1, 2, 3, 1000, 1001, 100000, 100001)  # SURVEY.md §8(d) "M-band": 15 nnz/row with the diagonal
@@ -315,6 +315,52 @@ class _UserOp:
         self.cb = _capi.op_fn(tramp)
 
 
+class SparseRegularInverse:
+    """MatOp/SparseRegularInverse.h: the B operator of a generalized problem — perform_op = B x, solve = B^{-1} x by a
+    conjugate-gradient iteration on the GPU (the reference's Eigen::ConjugateGradient defaults)."""
+
+    def __init__(self, mat, uplo="L", ctx=None):
+        self.ctx = ctx or default_context()
+        n, nc, outer, inner, val, row_major = _compressed(mat)
+        if n != nc:
+            raise ValueError("SparseRegularInverse: matrix must be square")
+        h = C.c_void_p()
+        check(lib().mispec_reginv_create(self.ctx.h, n, _ip(outer), _ip(inner), _dp(val), uplo.encode()[0:1], int(row_major),
+                                         C.byref(h)))
+        self.h = h
+        self.n = n
+
+    def rows(self):
+        return self.n
+
+    cols = rows
+
+    def perform_op(self, x_in):
+        x = _f64(x_in)
+        if x.shape != (self.n,):
+            raise ValueError("perform_op: x_in must have n entries")
+        y = np.empty(self.n)
+        check(lib().mispec_reginv_perform_op_host(self.h, _dp(x), _dp(y)))
+        return y
+
+    def solve(self, x_in):
+        x = _f64(x_in)
+        if x.shape != (self.n,):
+            raise ValueError("solve: x_in must have n entries")
+        y = np.empty(self.n)
+        check(lib().mispec_reginv_solve_host(self.h, _dp(x), _dp(y)))
+        return y
+
+    def last_iterations(self):
+        return int(lib().mispec_reginv_last_iterations(self.h))
+
+    def __del__(self):
+        try:
+            lib().mispec_reginv_destroy(self.h)
+        except Exception:
+            pass
+
+
 class SVDMatOp:
     """contrib/PartialSVDSolver.h:16-110: the operator A'A (tall A, SVDTallMatOp) or AA' (wide A, SVDWideMatOp) as two
     device CSR matrices applied one after the other inside the device Lanczos loop."""
@@ -378,6 +424,26 @@ class PartialSVDSolver:
         return self._vectors()[:, :nv] if self.op.m > self.op.n else self._scaled(self.op.mat_t, nv)
 
 
+class _GEigsRegInvOp:
+    """MatOp/internal/SymGEigsRegInvOp.h: y = B^{-1} A x."""
+
+    def __init__(self, A, B):
+        if not isinstance(A, SparseSymMatProd) or not isinstance(B, SparseRegularInverse):
+            raise TypeError("SymGEigsSolver: needs a SparseSymMatProd and a SparseRegularInverse")
+        if A.rows() != B.rows():
+            raise ValueError("SymGEigsSolver: A and B must have the same size")
+        self.A, self.B = A, B
+
+    def rows(self):
+        return self.B.rows()
+
+    cols = rows
+    local_rows = rows
+
+    def perform_op(self, x):
+        return self.B.solve(self.A.perform_op(x))
+
+
 class SymEigsSolver:
     """SymEigsSolver.h:133-160 / HermEigsBase.h: init(), compute(), info(), eigenvalues(), eigenvectors() ..."""
 
@@ -387,6 +453,10 @@ class SymEigsSolver:
         if isinstance(op, _DeviceMatrix):
             self.ctx = op.ctx
             check(lib().mispec_symeigs_create(self.ctx.h, op.h, int(nev), int(ncv), C.byref(h)))
+            self._user = None
+        elif isinstance(op, _GEigsRegInvOp):  # y = B^{-1}(A x) in the B-inner product
+            self.ctx = op.A.ctx
+            check(lib().mispec_symeigs_create_geigs_reginv(self.ctx.h, op.A.h, op.B.h, int(nev), int(ncv), C.byref(h)))
             self._user = None
         elif isinstance(op, SVDMatOp):  # y = A2 (A x), both factors in HBM
             self.ctx = op.ctx
@@ -427,7 +497,7 @@ class SymEigsSolver:
         return out[:cnt.value].copy()
 
     def local_rows(self):
-        return self.op.local_rows() if isinstance(self.op, (_DeviceMatrix, SVDMatOp)) else self.op.rows()
+        return self.op.local_rows() if isinstance(self.op, (_DeviceMatrix, SVDMatOp, _GEigsRegInvOp)) else self.op.rows()
 
     def eigenvectors(self, nvec=None, to_host=True):
         """n x nconv (this shard's rows).  to_host=False leaves the result in HBM and returns the column count."""
@@ -466,6 +536,16 @@ class SymEigsSolver:
             lib().mispec_symeigs_destroy(self.h)
         except Exception:
             pass
+
+
+class SymGEigsSolver(SymEigsSolver):
+    """SymGEigsSolver<OpType, BOpType, GEigsMode::RegularInverse> (SymGEigsSolver.h:224-238): A x = lambda B x with
+    op = SparseSymMatProd(A) and Bop = SparseRegularInverse(B); B-orthonormal eigenvectors."""
+
+    def __init__(self, op, Bop, nev, ncv, mode="RegularInverse"):
+        if mode != "RegularInverse":
+            raise ValueError("SymGEigsSolver: only GEigsMode::RegularInverse runs on the device path")
+        super().__init__(_GEigsRegInvOp(op, Bop), nev, ncv)
 
 
 class SymEigsShiftSolver(SymEigsSolver):

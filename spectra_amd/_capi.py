@@ -122,6 +122,14 @@ SIGNATURES = {
     "mispec_symeigs_create_op": (C.c_int, [_vp, op_fn, _vp, C.c_int64, C.c_int64, C.c_int64, _vpp]),
     "mispec_symeigs_create_shift": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_double, _vpp]),
     "mispec_symeigs_create_product": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int64, _vpp]),
+    "mispec_symeigs_create_geigs_reginv": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int64, _vpp]),
+    "mispec_reginv_create": (C.c_int, [_vp, C.c_int64, _ip, _ip, _dp, C.c_char, C.c_int, _vpp]),
+    "mispec_reginv_destroy": (C.c_int, [_vp]),
+    "mispec_reginv_rows": (C.c_int64, [_vp]),
+    "mispec_reginv_perform_op_host": (C.c_int, [_vp, _dp, _dp]),
+    "mispec_reginv_solve_host": (C.c_int, [_vp, _dp, _dp]),
+    "mispec_reginv_last_iterations": (C.c_int64, [_vp]),
+    "mispec_fac_create_geigs_reginv": (C.c_int, [_vp, _vp, _vp, C.c_int, _vpp]),
     "mispec_symeigs_destroy": (C.c_int, [_vp]),
     "mispec_symeigs_init": (C.c_int, [_vp, _dp]),
     "mispec_symeigs_compute": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_double, C.c_int, _lp]),

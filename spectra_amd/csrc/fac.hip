@@ -14,6 +14,7 @@
 //     same H because all reductions end in an all-reduce.
 #include "csr.hpp"
 #include "krylov.hpp"
+#include "reginv.hpp"
 #include "shiftsolve.hpp"
 #include "small.hpp"
 
@@ -48,6 +49,9 @@ struct mispec_fac
     const mispec_csr* A = nullptr;
     const mispec_csr* A2 = nullptr;      // product operator y = A2 (A x) (contrib/PartialSVDSolver.h: A'A or AA'); else nullptr
     const mispec_symshift* S = nullptr;  // operator = (A - sigma I)^{-1} on the device
+    // Generalized problem in regular-inverse mode (SymGEigsSolver.h:224-238): operator y = B^{-1}(A x) and every
+    // inner product taken as x'By (ArnoldiOp.h:68-101).  bx holds B*(the vector the product is taken with).
+    const mispec_reginv* Bop = nullptr;
     mispec_op_fn op = nullptr;
     void* op_user = nullptr;
     int64_t n = 0;     // global dimension
@@ -62,6 +66,7 @@ struct mispec_fac
     std::vector<double> H;  // m x m column-major, host
 
     DevBuf<double> mid;  // product operator: A x
+    DevBuf<double> bx;
     DevBuf<double> V, f, w, tmp, xfull, X, partials, alpha_partials, red, Qdev, d_diag, d_subd, d_evals, d_evecs, d_Y, gmax;
     DevBuf<int> d_info;
     DevBuf<StepState> d_state;     // device-driven step bookkeeping (krylov.hpp)
@@ -275,6 +280,32 @@ void plan_exchange(mispec_fac& F)
     F.halo = true;
 }
 
+// ---- B-inner products (generalized problems) -------------------------------------------------------------
+int persistent_grid_records(const mispec_fac& F)
+{
+    const int64_t g = std::min<int64_t>(int64_t(F.ctx->num_cu) * 4, (F.nloc + 255) / 256);
+    return int(std::max<int64_t>(g, 1));
+}
+// F.bx = B y
+void b_apply(mispec_fac& F, const double* y)
+{
+    launch_spmv(*F.Bop->B, y, F.bx.p, nullptr);
+}
+// out_dev[0] = x' B y  (device scalar, fixed-order two-stage sum)
+void b_inner_to(mispec_fac& F, const double* x, const double* y, double* out_dev)
+{
+    b_apply(F, y);
+    const int nrec = persistent_grid_records(F);
+    launch_dot_record(*F.ctx, x, F.bx.p, F.nloc, F.partials.p, F.pstride, nrec);
+    launch_reduce_sum(*F.ctx, F.partials.p + int64_t(kSlotBeta2) * F.pstride, nrec, out_dev);
+}
+// After an orthogonalisation launch that left `nrec` records for c = V'(B x) (taken with F.bx = B x): overwrite
+// the two scalar slots with x'Bx and max|x|, so that the usual reduction yields the B-norm.
+void b_norm_slots(mispec_fac& F, const double* x, int nrec)
+{
+    launch_dot_record(*F.ctx, x, F.bx.p, F.nloc, F.partials.p, F.pstride, nrec);
+}
+
 // y = Op(x).  x_loc / y_loc: this shard's rows (device).  With `lanczos_epi`, additionally
 // y -= h_prev * v_prev (when v_prev != nullptr) and alpha = <x, y> is left in red_buf(0)[kSlotAlpha]
 // (device) — Lanczos.h:131-142.
@@ -315,6 +346,23 @@ void apply_op(mispec_fac& F, const double* x_loc, double* y_loc, bool lanczos_ep
         }
         else
             scope.reset(new Timed(F, FAM_SPMV));
+        if (F.Bop)
+        {
+            // y = B^{-1} (A x)  (SymGEigsRegInvOp.h:76-81); the Lanczos epilogue in the B-inner product follows below
+            scope.reset();
+            {
+                Timed t(F, FAM_SPMV);
+                launch_spmv(*F.A, x, F.mid.p, nullptr);
+                reginv_solve(*F.Bop, F.mid.p, y_loc);
+            }
+            if (lanczos_epi)
+            {
+                if (v_prev)  // w -= H(i,i-1) v_prev  (Lanczos.h:138-139); its plain-dot by-product is not used
+                    launch_lanczos_epilogue(*F.ctx, y_loc, x_loc, v_prev, h_prev, F.nloc, F.alpha_partials.p);
+                b_inner_to(F, x_loc, y_loc, alpha_dev);  // H(i,i) = <v, w>_B  (:142)
+            }
+            return;
+        }
         const mispec_csr* last = F.A;
         if (F.A2)  // y = A2 (A x): the epilogue rides on the second product
         {
@@ -411,7 +459,14 @@ void vtf(mispec_fac& F, const double* x, int ncol, int which)
     int nrec;
     {
         Timed t(F, FAM_VTF);
+        if (F.Bop)  // c = V'(B x), |x|_B  (ArnoldiOp.h:68-101)
+        {
+            b_apply(F, x);
+            a.src = F.bx.p;
+        }
         nrec = launch_orth(*F.ctx, ORTH_VTF, a);
+        if (F.Bop)
+            b_norm_slots(F, x, nrec);
     }
     reduce_to_host(F, nrec, ncol, which);
 }
@@ -427,9 +482,41 @@ void correct_vtf(mispec_fac& F, const double* src, double* dst, int ncol)
     int nrec;
     {
         Timed t(F, FAM_GEMV);
-        nrec = launch_orth(*F.ctx, ORTH_CORRECT_VTF, a);
+        if (!F.Bop)
+            nrec = launch_orth(*F.ctx, ORTH_CORRECT_VTF, a);
+        else
+        {
+            (void) launch_orth(*F.ctx, ORTH_CORRECT_ONLY, a);  // dst = src - V c
+            b_apply(F, dst);
+            OrthArgs b = orth_args(F, ncol);
+            b.src = F.bx.p;
+            nrec = launch_orth(*F.ctx, ORTH_VTF, b);  // V'(B dst)
+            b_norm_slots(F, dst, nrec);               // |dst|_B
+        }
     }
     reduce_to_host(F, nrec, ncol, F.red_cur ^ 1);
+}
+
+// f = w - alpha v (alpha: device scalar), then |f| and V[:, :ncol]' f — Lanczos.h:145-153 / Arnoldi.h:177.
+// Returns the record count; the caller reduces.
+int resid_vtf(mispec_fac& F, const double* w, const double* v, const double* alpha_dev, double* f, int ncol)
+{
+    OrthArgs a = orth_args(F, F.Bop ? 0 : ncol);
+    a.src = w;
+    a.dst = f;
+    a.vi = v;
+    a.alpha_dev = alpha_dev;
+    Timed t(F, FAM_VTF);
+    int nrec = launch_orth(*F.ctx, ORTH_RESID_VTF, a);
+    if (F.Bop)  // the plain by-products of that launch are replaced by the B-inner-product ones
+    {
+        b_apply(F, f);
+        OrthArgs b = orth_args(F, ncol);
+        b.src = F.bx.p;
+        nrec = launch_orth(*F.ctx, ORTH_VTF, b);
+        b_norm_slots(F, f, nrec);
+    }
+    return nrec;
 }
 
 double host_norm(const double* x, int n)
@@ -505,16 +592,8 @@ void init_from_tmp(mispec_fac& F, int64_t* nmatop)
     apply_op(F, v, F.w.p, true, nullptr, 0.0);  // :173-176  w = A v ; H(0,0) = <v, w>
     (*nmatop)++;
 
-    OrthArgs a = orth_args(F, 1);  // f = w - v H(0,0)  (:177) ; the V'f by-product is not used here
-    a.src = F.w.p;
-    a.dst = F.f.p;
-    a.vi = v;
-    a.alpha_dev = F.red_buf(0) + kSlotAlpha;
-    int nrec;
-    {
-        Timed t(F, FAM_VTF);
-        nrec = launch_orth(*F.ctx, ORTH_RESID_VTF, a);
-    }
+    // f = w - v H(0,0)  (:177) ; the V'f by-product is not used here
+    const int nrec = resid_vtf(F, F.w.p, v, F.red_buf(0) + kSlotAlpha, F.f.p, 1);
     MISPEC_HIP(hipMemcpyAsync(F.h_red.p + kPartialLd, F.red_buf(0) + kSlotAlpha, sizeof(double), hipMemcpyDeviceToHost,
                               F.stream()));
     reduce_to_host(F, nrec, 1, 1);
@@ -595,6 +674,11 @@ void lanczos_step_host(mispec_fac& F, int i, int64_t* nmatop)
             int nrec;
             {
                 Timed t(F, FAM_VTF);
+                if (F.Bop)  // <V[:, i-1], v>_B
+                {
+                    b_apply(F, v);
+                    a.src = F.bx.p;
+                }
                 nrec = launch_orth(*F.ctx, ORTH_VTF, a);
             }
             reduce_to_host(F, nrec, 1, 0);
@@ -616,16 +700,7 @@ void lanczos_step_host(mispec_fac& F, int i, int64_t* nmatop)
 
     // f = w - alpha v ; beta = |f| ; Vf = V[:, :i+1]' f   (:145-153) — one pass over V
     const int i1 = i + 1;
-    OrthArgs a = orth_args(F, i1);
-    a.src = F.w.p;
-    a.dst = F.f.p;
-    a.vi = v;
-    a.alpha_dev = F.red_buf(0) + kSlotAlpha;
-    int nrec;
-    {
-        Timed t(F, FAM_VTF);
-        nrec = launch_orth(*F.ctx, ORTH_RESID_VTF, a);
-    }
+    const int nrec = resid_vtf(F, F.w.p, v, F.red_buf(0) + kSlotAlpha, F.f.p, i1);
     MISPEC_HIP(hipMemcpyAsync(F.h_red.p + kPartialLd, F.red_buf(0) + kSlotAlpha, sizeof(double), hipMemcpyDeviceToHost,
                               F.stream()));
     reduce_to_host(F, nrec, i1, 1);
@@ -698,7 +773,7 @@ void lanczos_step_device(mispec_fac& F, int i)
 void factorize_lanczos(mispec_fac& F, int from_k, int to_m, int64_t* nmatop)
 {
     zero_H_outside(F, from_k);
-    const bool fast = F.device_steps && F.A != nullptr;
+    const bool fast = F.device_steps && F.A != nullptr && F.Bop == nullptr;
     int i = from_k;
     while (i <= to_m - 1)
     {
@@ -939,6 +1014,11 @@ void update_f_after_compress(mispec_fac& F, double q_last, double h_sub)
     {
         Timed t(F, FAM_COMPRESS);
         nrec = launch_axpby(*F.ctx, F.f.p, q_last, F.col(F.k), h_sub, F.nloc, F.partials.p, F.pstride);
+        if (F.Bop)  // beta = |f|_B  (Arnoldi.h:339 through ArnoldiOp::norm)
+        {
+            b_apply(F, F.f.p);
+            b_norm_slots(F, F.f.p, nrec);
+        }
     }
     reduce_to_host(F, nrec, 0, 0);
     F.beta = F.h_red.p[kSlotBeta];
@@ -951,7 +1031,7 @@ void update_f_after_compress(mispec_fac& F, double q_last, double h_sub)
 // =================================================================================================
 namespace {
 int fac_create_impl(mispec_ctx* ctx, const mispec_csr* A, const mispec_symshift* S, mispec_op_fn op, void* op_user, int64_t n,
-                    int ncv, int symmetric, mispec_fac** out, const mispec_csr* A2 = nullptr)
+                    int ncv, int symmetric, mispec_fac** out, const mispec_csr* A2 = nullptr, const mispec_reginv* Bop = nullptr)
 {
     return guarded([&] {
         MISPEC_REQUIRE(ctx && out, "mispec_fac_create: NULL argument");
@@ -959,6 +1039,12 @@ int fac_create_impl(mispec_ctx* ctx, const mispec_csr* A, const mispec_symshift*
         MISPEC_REQUIRE(n >= 1, "mispec_fac_create: n must be positive");
         MISPEC_REQUIRE(ncv >= 1 && ncv <= n, "mispec_fac_create: need 1 <= ncv <= n");
         MISPEC_REQUIRE(ncv <= kMaxCols, "mispec_fac_create: the device factorisation holds at most 128 basis vectors (ncv <= 128)");
+        if (Bop)
+        {
+            MISPEC_REQUIRE(A && !A2 && symmetric, "mispec_fac_create_geigs_reginv: needs a symmetric device matrix A");
+            MISPEC_REQUIRE(Bop->ctx == ctx && Bop->n == n, "mispec_fac_create_geigs_reginv: B belongs to another context / size");
+            MISPEC_REQUIRE(ctx->comm.allgather == nullptr, "mispec_fac_create_geigs_reginv: generalized problems cannot be row-sharded");
+        }
         if (A && A2)
         {
             MISPEC_REQUIRE(A->ctx == ctx && A2->ctx == ctx, "mispec_fac_create_product: matrix belongs to another context");
@@ -983,8 +1069,14 @@ int fac_create_impl(mispec_ctx* ctx, const mispec_csr* A, const mispec_symshift*
             F->ctx = ctx;
             F->A = A;
             F->A2 = A2;
-            if (A2)
+            F->Bop = Bop;
+            if (A2 || Bop)
                 F->mid.alloc(size_t(round_up(std::max<int64_t>(A->n_rows, 1), 2)) + 2);
+            if (Bop)
+            {
+                F->bx.alloc(size_t(round_up(std::max<int64_t>(n, 1), 2)) + 2);
+                MISPEC_HIP(hipMemsetAsync(F->bx.p, 0, F->bx.n * sizeof(double), ctx->stream));
+            }
             F->S = S;
             F->op = op;
             F->op_user = op_user;
@@ -1071,6 +1163,16 @@ extern "C" int mispec_fac_create_product(mispec_ctx* ctx, const mispec_csr* A, c
         return MISPEC_EINVAL;
     }
     return fac_create_impl(ctx, A, nullptr, nullptr, nullptr, A->n_cols, ncv, 1, out, A2);
+}
+
+extern "C" int mispec_fac_create_geigs_reginv(mispec_ctx* ctx, const mispec_csr* A, const mispec_reginv* B, int ncv, mispec_fac** out)
+{
+    if (!A || !B)
+    {
+        set_last_error("mispec_fac_create_geigs_reginv: NULL operand");
+        return MISPEC_EINVAL;
+    }
+    return fac_create_impl(ctx, A, nullptr, nullptr, nullptr, A->n_rows, ncv, 1, out, nullptr, B);
 }
 
 extern "C" int mispec_fac_create_shiftsolve(mispec_ctx* ctx, const mispec_symshift* S, int ncv, int symmetric, mispec_fac** out)
@@ -1362,7 +1464,14 @@ extern "C" int mispec_fac_residuals(mispec_fac* fac, const double* lambda_host, 
         for (int j = 0; j < ncols; j++)
         {
             const double* x = F.X.p + int64_t(j) * F.ldv;
-            apply_op(F, x, F.tmp.p, false, nullptr, 0.0);
+            if (F.Bop)  // generalized problem: || A x - lambda B x || / || B x ||
+            {
+                launch_spmv(*F.A, x, F.tmp.p, nullptr);
+                b_apply(F, x);
+                x = F.bx.p;
+            }
+            else
+                apply_op(F, x, F.tmp.p, false, nullptr, 0.0);
             const int nrec = launch_resid_norms(*F.ctx, F.tmp.p, x, lambda_host[j], F.nloc, F.partials.p, F.pstride);
             reduce_to_host(F, nrec, 1, 0);
             resid_host[j] = std::sqrt(F.h_red.p[kSlotBeta2]) / std::sqrt(F.h_red.p[0]);

@@ -9,6 +9,7 @@
 #include <Spectra/LinAlg/UpperHessenbergSchur.h>
 #include <Spectra/SymEigsShiftSolver.h>
 #include <Spectra/SymEigsSolver.h>
+#include <Spectra/SymGEigsSolver.h>
 
 #include <cstring>
 #include <memory>
@@ -72,6 +73,8 @@ using CbSolver = Spectra::SymEigsSolver<CallbackOp>;
 using ShiftOp = Spectra::SparseSymShiftSolve<double>;
 using ShiftSolver = Spectra::SymEigsShiftSolver<ShiftOp>;
 using ProdSolver = Spectra::SymEigsSolver<ProductOp>;
+using RegInvBOp = Spectra::SparseRegularInverse<double>;
+using GEigsSolver = Spectra::SymGEigsSolver<DevOp, RegInvBOp, Spectra::GEigsMode::RegularInverse>;
 
 }  // namespace
 
@@ -83,6 +86,8 @@ struct mispec_symeigs
     std::unique_ptr<ShiftOp> shift_op;
     std::unique_ptr<ProductOp> prod_op;
     std::unique_ptr<ProdSolver> prod;
+    std::unique_ptr<RegInvBOp> b_op;
+    std::unique_ptr<GEigsSolver> geigs;
     std::unique_ptr<DevSolver> dev;
     std::unique_ptr<CbSolver> cb;
     std::unique_ptr<ShiftSolver> shift;
@@ -98,6 +103,8 @@ struct mispec_symeigs
             return f(*shift);
         if (prod)
             return f(*prod);
+        if (geigs)
+            return f(*geigs);
         return f(*cb);
     }
     mispec_fac* fac() const
@@ -157,6 +164,21 @@ extern "C" int mispec_symeigs_create_product(mispec_ctx* ctx, const mispec_csr* 
         s->nev = nev;
         s->prod_op = std::make_unique<ProductOp>(ctx, A, A2);
         s->prod = std::make_unique<ProdSolver>(*s->prod_op, nev, ncv);
+        *out = s.release();
+    });
+}
+
+extern "C" int mispec_symeigs_create_geigs_reginv(mispec_ctx* ctx, const mispec_csr* A, const mispec_reginv* B, int64_t nev, int64_t ncv,
+                                                  mispec_symeigs** out)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(ctx && A && B && out, "mispec_symeigs_create_geigs_reginv: NULL argument");
+        auto s = std::make_unique<mispec_symeigs>();
+        s->ctx = ctx;
+        s->nev = nev;
+        s->dev_op = std::make_unique<DevOp>(ctx, const_cast<mispec_csr*>(A));
+        s->b_op = std::make_unique<RegInvBOp>(ctx, const_cast<mispec_reginv*>(B));
+        s->geigs = std::make_unique<GEigsSolver>(*s->dev_op, *s->b_op, nev, ncv);
         *out = s.release();
     });
 }
