@@ -10,6 +10,7 @@
 #include <Spectra/MatOp/SparseSymShiftSolve.h>
 #include <Spectra/SymEigsShiftSolver.h>
 #include <Spectra/SymEigsSolver.h>
+#include <Spectra/SymGEigsSolver.h>
 #include <Spectra/contrib/PartialSVDSolver.h>
 
 #include <cmath>
@@ -180,6 +181,75 @@ public:
     }
 };
 
+// test/SymGEigsRegInv.cpp:35-106: A = sprand(n, prob) (lower triangle used), B = A'A + 0.1 I, regular-inverse mode;
+// ||A U - B U D||_inf <= 1e-9 with the symmetric A the solver sees.
+static void run_geigs(int n, double prob, int k, int m)
+{
+    const Csc A = gen_sparse_data(n, prob);
+    // B = A'A + 0.1 I, assembled densely (n <= 1000) and stored as a full CSC matrix
+    std::vector<double> Bd((size_t) n * n, 0.0);
+    for (int j = 0; j < n; j++)
+        for (int p = A.colptr[j]; p < A.colptr[j + 1]; p++)
+            for (int jj = 0; jj < n; jj++)
+                for (int q = A.colptr[jj]; q < A.colptr[jj + 1]; q++)
+                    if (A.rowind[q] == A.rowind[p])
+                        Bd[(size_t) jj * n + j] += A.val[p] * A.val[q];
+    for (int i = 0; i < n; i++)
+        Bd[(size_t) i * n + i] += 0.1;
+    Csc B;
+    B.n = n;
+    B.colptr.push_back(0);
+    for (int j = 0; j < n; j++)
+    {
+        for (int i = 0; i < n; i++)
+            if (Bd[(size_t) j * n + i] != 0.0)
+            {
+                B.rowind.push_back(i);
+                B.val.push_back(Bd[(size_t) j * n + i]);
+            }
+        B.colptr.push_back((int) B.rowind.size());
+    }
+    using OpType = SparseSymMatProd<double>;
+    using BOpType = SparseRegularInverse<double>;
+    OpType op(A.view());
+    BOpType Bop(B.view());
+    const SortRule rules[] = {SortRule::LargestMagn, SortRule::LargestAlge, SortRule::SmallestAlge, SortRule::BothEnds};
+    for (SortRule rule : rules)
+    {
+        SymGEigsSolver<OpType, BOpType, GEigsMode::RegularInverse> eigs(op, Bop, k, m);
+        eigs.init();
+        const int nconv = (int) eigs.compute(rule, 100);
+        REQUIRE(eigs.info() == CompInfo::Successful);
+        REQUIRE(nconv == k);
+        const auto evals = eigs.eigenvalues();
+        const auto U = eigs.eigenvectors();
+        double err = 0.0;
+        for (int c = 0; c < nconv; c++)
+        {
+            std::vector<double> au(n, 0.0), bu(n, 0.0);
+            for (int j = 0; j < n; j++)
+            {
+                for (int p = A.colptr[j]; p < A.colptr[j + 1]; p++)  // selfadjointView<Lower>(A)
+                {
+                    const int i = A.rowind[p];
+                    if (i < j)
+                        continue;
+                    au[i] += A.val[p] * U(j, c);
+                    if (i != j)
+                        au[j] += A.val[p] * U(i, c);
+                }
+                for (int p = B.colptr[j]; p < B.colptr[j + 1]; p++)
+                    bu[B.rowind[p]] += B.val[p] * U(j, c);
+            }
+            for (int i = 0; i < n; i++)
+                err = std::fmax(err, std::fabs(au[i] - evals[c] * bu[i]));
+        }
+        std::printf("geigs n=%d rule=%d nconv=%d niter=%d nops=%d ||AU-BUD||_inf=%.3e\n", n, (int) rule, nconv,
+                    (int) eigs.num_iterations(), (int) eigs.num_operations(), err);
+        REQUIRE(err < 1e-9);  // test/SymGEigsRegInv.cpp:82
+    }
+}
+
 // test/SVD.cpp:17-67: partial SVD of the rectangular sparse fixture; without Eigen's JacobiSVD the check is the
 // singular-triplet residual  ||A v - s u||, ||A' u - s v|| <= 1e-9  and the descending order of s.
 static void run_svd(int m, int n, int k, int ncv)
@@ -262,6 +332,8 @@ int main()
         run_shift(gen_sparse_data(100, 0.1), 10, 20, 10.0);     // test/SymEigsShift.cpp:160-171
         run_shift(gen_sparse_data(1000, 0.01), 20, 50, 100.0);  // :173-185
 
+        run_geigs(10, 0.5, 3, 6);      // test/SymGEigsRegInv.cpp:109-119
+        run_geigs(100, 0.1, 10, 20);   // :121-131
         run_svd(1000, 100, 5, 10);  // test/SVD.cpp:105-114 (tall sparse)
         run_svd(100, 1000, 5, 10);  // :116-125 (wide sparse)
 
