@@ -3,7 +3,10 @@
   C5  SymEigsShiftSolver on a 2M x 2M banded (half-bandwidth 3) definite matrix, sigma = 0, k = 6, ncv = 20
 Prints one JSON object per configuration (eigenpairs/s, per-kernel times, residuals).
 
-    python tools/bench_configs.py [c4] [c5]
+    python tools/bench_configs.py [c4] [c5] [g1]
+
+  G1  SymGEigsSolver (regular-inverse mode) on a 2M x 2M pencil: A the M-band pattern, B a tridiagonal mass matrix;
+      k = 6, ncv = 20 — not a BASELINE.json config, recorded as the measurement of SURVEY.md 8f row 4
 """
 import json
 import os
@@ -16,7 +19,7 @@ import scipy.sparse as sp
 
 import spectra_amd as sa
 
-which = [a.lower() for a in sys.argv[1:]] or ["c4", "c5"]
+which = [a.lower() for a in sys.argv[1:]] or ["c4", "c5", "g1"]
 ctx = sa.default_context()
 
 
@@ -78,3 +81,20 @@ if "c5" in which:
                       "num_iterations": s.num_iterations(), "max_residual": float(res.max()),
                       "ingest_seconds": t_ingest, "set_shift_seconds": t_factor, "set_shift_seconds_warm": t_factor2, "solve_ms": p["ms_spmv"] / p["n_spmv"],
                       "kernels_ms": {k[3:]: round(v, 2) for k, v in p.items() if k.startswith("ms_")}}))
+
+if "g1" in which:
+    import oracle as O  # only the matrix generator (test infrastructure) is used here, nothing is timed through it
+
+    n = 2_000_000
+    rp, ci, v = O.synth_band_csr(n)
+    A = sp.csr_matrix((v, ci, rp), shape=(n, n))
+    B = sp.diags([np.full(n - 1, 1.0 / 6.0), np.full(n, 4.0 / 6.0), np.full(n - 1, 1.0 / 6.0)], [-1, 0, 1], format="csc")
+    aop = sa.SparseSymMatProd(sp.tril(A).tocsc(), ctx=ctx)
+    bop = sa.SparseRegularInverse(B, ctx=ctx)
+    dt, s, nconv = timed(lambda: sa.SymGEigsSolver(aop, bop, 6, 20), lambda s: s.compute(sa.SortRule.LargestAlge, 1000, 1e-10),
+                         reps=1)
+    res = s.residuals()
+    print(json.dumps({"config": "G1 SymGEigsSolver<RegularInverse> 2M x 2M, A M-band, B tridiagonal mass, k=6, ncv=20, tol 1e-10",
+                      "seconds": dt, "eigenpairs_per_s": nconv / dt, "nconv": nconv, "num_operations": s.num_operations(),
+                      "num_iterations": s.num_iterations(), "max_residual": float(res.max()),
+                      "cg_iterations_last_solve": bop.last_iterations()}))
