@@ -26,35 +26,44 @@
 namespace Spectra {
 
 namespace internal {
+// std::void_t for C++11/14 (the reference only requires C++11)
+template <typename... Ts>
+struct make_void
+{
+    typedef void type;
+};
+template <typename... Ts>
+using void_t = typename make_void<Ts...>::type;
+
 template <typename T, typename = void>
 struct has_device_matrix : std::false_type
 {};
 template <typename T>
-struct has_device_matrix<T, std::void_t<decltype(std::declval<const T&>().mispec_matrix())>> : std::true_type
+struct has_device_matrix<T, void_t<decltype(std::declval<const T&>().mispec_matrix())>> : std::true_type
 {};
 template <typename T, typename = void>
 struct has_device_solver : std::false_type
 {};
 template <typename T>
-struct has_device_solver<T, std::void_t<decltype(std::declval<const T&>().mispec_solver())>> : std::true_type
+struct has_device_solver<T, void_t<decltype(std::declval<const T&>().mispec_solver())>> : std::true_type
 {};
 template <typename T, typename = void>
 struct has_device_product : std::false_type
 {};
 template <typename T>
-struct has_device_product<T, std::void_t<decltype(std::declval<const T&>().mispec_product_second())>> : std::true_type
+struct has_device_product<T, void_t<decltype(std::declval<const T&>().mispec_product_second())>> : std::true_type
 {};
 template <typename T, typename = void>
 struct has_device_geigs : std::false_type
 {};
 template <typename T>
-struct has_device_geigs<T, std::void_t<decltype(std::declval<const T&>().mispec_geigs_b_operator())>> : std::true_type
+struct has_device_geigs<T, void_t<decltype(std::declval<const T&>().mispec_geigs_b_operator())>> : std::true_type
 {};
 template <typename T, typename = void>
 struct has_device_context : std::false_type
 {};
 template <typename T>
-struct has_device_context<T, std::void_t<decltype(std::declval<const T&>().mispec_context())>> : std::true_type
+struct has_device_context<T, void_t<decltype(std::declval<const T&>().mispec_context())>> : std::true_type
 {};
 // The context a host-pointer operator wants its Krylov basis on: its own, if it names one.
 template <typename T>

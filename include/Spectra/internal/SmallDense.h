@@ -51,7 +51,7 @@ struct Lanes
 MISPEC_HD inline void stable_scaling(double a, double b, double& r, double& c, double& s)
 {
     const double t = b / a;
-    const double cutoff = 0.1 * 0x1p-13;  // 0.1 * eps^(1/4), eps = 2^-52
+    const double cutoff = 0.1 * 1.220703125e-4;  // 0.1 * eps^(1/4), eps = 2^-52
     if (t >= cutoff)
     {
         r = hypot(a, b);

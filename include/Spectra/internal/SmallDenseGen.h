@@ -108,7 +108,7 @@ class DoubleShiftStep
         if (a < kNear0)
             return 0.0;
         const double r2 = b / a, r3 = c / a;
-        const double cutoff = 0.1 * 0x1p-13;
+        const double cutoff = 0.1 * 1.220703125e-4;
         const double r = r2 * r2 + r3 * r3;
         return a * ((r2 >= cutoff || r3 >= cutoff) ? std::sqrt(1.0 + r) : (1.0 + r * (0.5 - 0.125 * r)));
     }
@@ -118,7 +118,7 @@ class DoubleShiftStep
         const double sgn = (x1 > 0.0) ? 1.0 : -1.0;
         x1 = std::fabs(x1);
         const double r2 = x2 / x1, r3 = x3 / x1;
-        const double cutoff = 0.1 * 0x1p-13;
+        const double cutoff = 0.1 * 1.220703125e-4;
         double r = r2 * r2 + r3 * r3;
         r = (std::fabs(r2) >= cutoff || std::fabs(r3) >= cutoff) ? 1.0 / std::sqrt(1.0 + r) : (1.0 - r * (0.5 - 0.375 * r));
         x1 = sgn * r;
