@@ -1,6 +1,6 @@
 // Francis double-shift QR step on a real upper Hessenberg matrix, host side
 // (reference: LinAlg/DoubleShiftQR.h:20-470): H^2 - sH + tI = QR handled implicitly with 3-element
-// Householder reflectors.  Same members as the reference: compute(mat, s, t), matrix_QtHQ(), apply_YQ().
+// Householder reflectors.  Same members as the reference: compute(mat, s, t), matrix_QtHQ(), apply_QtY(), apply_YQ().
 #ifndef MISPEC_SPECTRA_DOUBLE_SHIFT_QR_H
 #define MISPEC_SPECTRA_DOUBLE_SHIFT_QR_H
 
@@ -45,6 +45,23 @@ public:
             throw std::logic_error("DoubleShiftQR: need to call compute() first");
         dest.resize(m_n, m_n);
         std::copy(m_H.begin(), m_H.end(), dest.data());
+    }
+
+    // y <- Q' y   (reference :410-422)
+    void apply_QtY(DenseVector<Scalar>& y) const
+    {
+        if (!m_computed)
+            throw std::logic_error("DoubleShiftQR: need to call compute() first");
+        std::vector<double> out(static_cast<std::size_t>(m_n));
+        for (Index j = 0; j < m_n; j++)
+        {
+            double acc = 0.0;
+            for (Index k = 0; k < m_n; k++)
+                acc += m_Q[std::size_t(j) * m_n + k] * y[k];
+            out[std::size_t(j)] = acc;
+        }
+        for (Index j = 0; j < m_n; j++)
+            y[j] = out[std::size_t(j)];
     }
 
     // Y <- Y * Q

@@ -1,7 +1,8 @@
 // Shifted QR factorisations of the projected matrix, host side (reference: LinAlg/UpperHessenbergQR.h).
 //   UpperHessenbergQR<double>: H - sI = QR for an upper Hessenberg H   (:45-460)
 //   TridiagQR<double>:         the same for a symmetric tridiagonal T  (:470-711)
-// Same member names as the reference: compute(), matrix_QtHQ(), apply_YQ().  The symmetric solver does
+// Same member names as the reference: compute(), matrix_R(), matrix_QtHQ(), apply_QY(), apply_QtY(), apply_YQ(),
+// apply_YQt() (vector and matrix forms, :204-460).  The symmetric solver does
 // NOT use these classes on its fast path — its sweeps run in one LDS-resident kernel (csrc/small.hip,
 // same arithmetic from internal/SmallDense.h); they serve the general solver's restart, user code and
 // the CPU-side unit tests.
@@ -26,7 +27,23 @@ protected:
     Scalar m_shift = 0;
     std::vector<double> m_rot;   // cos[0..n-1), sin at m_rot[n + i]
     std::vector<double> m_QtHQ;  // n x n column-major
+    std::vector<double> m_Hs;    // H - sI as given (the part compute() reads), for matrix_R()
     bool m_computed = false;
+    using Vector = DenseVector<Scalar>;
+
+    // Q = G_0 G_1 ... G_{n-2}; on the pair (i, i+1) G_i is [c s; -s c]  (reference :84-92)
+    // rows of an (n x ncol) block: Y <- G_i Y  (transpose == false)  or  Y <- G_i' Y
+    void rotate_rows(Scalar* Y, Index ldy, Index ncol, Index i, bool transpose) const
+    {
+        const double c = m_rot[std::size_t(i)], s = transpose ? -m_rot[std::size_t(m_n + i)] : m_rot[std::size_t(m_n + i)];
+        for (Index j = 0; j < ncol; j++)
+        {
+            Scalar* col = Y + j * ldy;
+            const Scalar a = col[i], b = col[i + 1];
+            col[i] = c * a + s * b;
+            col[i + 1] = -s * a + c * b;
+        }
+    }
 
     void require_computed(const char* who) const
     {
@@ -48,10 +65,73 @@ public:
         m_shift = shift;
         const int n = static_cast<int>(m_n);
         m_QtHQ.assign(mat.data(), mat.data() + std::size_t(n) * n);
+        m_Hs.assign(std::size_t(n) * n, 0.0);
+        for (int j = 0; j < n; j++)
+            for (int i = 0; i <= (j + 1 < n ? j + 1 : n - 1); i++)
+                m_Hs[std::size_t(j) * n + i] = mat(i, j) - (i == j ? shift : Scalar(0));
         m_rot.assign(std::size_t(2) * n, 0.0);
         double dummy = 0.0;
         mispec::small::hess_shifted_qr(n, m_QtHQ.data(), n, shift, &dummy, 1, 0, m_rot.data());
         m_computed = true;
+    }
+
+    // The R factor of H - sI = QR, an upper triangular matrix (reference :204-210)
+    virtual Matrix matrix_R() const
+    {
+        require_computed("UpperHessenbergQR");
+        Matrix R(m_n, m_n);
+        std::copy(m_Hs.begin(), m_Hs.end(), R.data());
+        for (Index i = 0; i < m_n - 1; i++)  // R = G_{n-2}' ... G_0' (H - sI)
+            rotate_rows(R.data(), m_n, m_n, i, true);
+        for (Index j = 0; j < m_n; j++)
+            for (Index i = j + 1; i < m_n; i++)
+                R(i, j) = Scalar(0);
+        return R;
+    }
+
+    // Y <- Q Y = G_0 G_1 ... Y   (reference :266-287, :322-346)
+    void apply_QY(Vector& Y) const
+    {
+        require_computed("UpperHessenbergQR");
+        for (Index i = m_n - 2; i >= 0; i--)
+            rotate_rows(Y.data(), m_n, 1, i, false);
+    }
+    void apply_QY(Matrix& Y) const
+    {
+        require_computed("UpperHessenbergQR");
+        for (Index i = m_n - 2; i >= 0; i--)
+            rotate_rows(Y.data(), Y.rows(), Y.cols(), i, false);
+    }
+    // Y <- Q' Y   (reference :293-316, :352-377)
+    void apply_QtY(Vector& Y) const
+    {
+        require_computed("UpperHessenbergQR");
+        for (Index i = 0; i < m_n - 1; i++)
+            rotate_rows(Y.data(), m_n, 1, i, true);
+    }
+    void apply_QtY(Matrix& Y) const
+    {
+        require_computed("UpperHessenbergQR");
+        for (Index i = 0; i < m_n - 1; i++)
+            rotate_rows(Y.data(), Y.rows(), Y.cols(), i, true);
+    }
+    // Y <- Y Q'   (reference :429-459)
+    void apply_YQt(Matrix& Y) const
+    {
+        require_computed("UpperHessenbergQR");
+        const Index nrow = Y.rows();
+        for (Index i = m_n - 2; i >= 0; i--)
+        {
+            const double c = m_rot[std::size_t(i)], s = m_rot[std::size_t(m_n + i)];
+            Scalar* a = Y.data() + i * nrow;
+            Scalar* b = a + nrow;
+            for (Index j = 0; j < nrow; j++)
+            {
+                const Scalar t = a[j];
+                a[j] = c * t + s * b[j];
+                b[j] = -s * t + c * b[j];
+            }
+        }
     }
 
     // dest <- Q'HQ = RQ + sI
@@ -114,6 +194,11 @@ public:
         mispec::small::tridiag_shifted_qr(n, diag.data(), subd.data(), shift, &dummy, 1, 0, work.data(),
                                           mispec::small::Lanes{0, 1});
         m_rot.assign(work.begin(), work.begin() + 2 * n);  // [cos | sin]
+        this->m_Hs.assign(std::size_t(n) * n, 0.0);
+        for (int i = 0; i < n; i++)
+            this->m_Hs[std::size_t(i) * n + i] = mat(i, i) - shift;
+        for (int i = 0; i < n - 1; i++)
+            this->m_Hs[std::size_t(i) * n + i + 1] = this->m_Hs[std::size_t(i + 1) * n + i] = mat(i + 1, i);
         m_QtHQ.assign(std::size_t(n) * n, 0.0);
         for (int i = 0; i < n; i++)
             m_QtHQ[std::size_t(i) * n + i] = diag[std::size_t(i)];

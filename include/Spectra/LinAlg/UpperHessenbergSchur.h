@@ -4,6 +4,7 @@
 #define MISPEC_SPECTRA_UPPER_HESSENBERG_SCHUR_H
 
 #include <stdexcept>
+#include <utility>
 
 #include "../internal/Dense.h"
 #include "../internal/SmallDenseGen.h"
@@ -47,6 +48,10 @@ public:
             throw std::logic_error("UpperHessenbergSchur: need to call compute() first");
         return m_U;
     }
+
+    // Hand the results over without a copy (reference :443-451)
+    void swap_T(Matrix& other) { std::swap(m_T, other); }
+    void swap_U(Matrix& other) { std::swap(m_U, other); }
 };
 
 }  // namespace Spectra

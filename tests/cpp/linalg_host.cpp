@@ -1,0 +1,228 @@
+// Host-side LinAlg classes of the header API, checked the way the reference's own unit tests check theirs
+// (/root/reference/test/QR.cpp:20-98, test/Eigen.cpp, test/Schur.cpp): Q orthogonal, R upper triangular,
+// H - sI = QR, Q'HQ, every apply_* against the explicit product, eigen / Schur residuals — all to 1e-12.
+// Plain C++11, no GPU, no library: g++ -std=c++11 -I include tests/cpp/linalg_host.cpp
+#include <Spectra/LinAlg/DoubleShiftQR.h>
+#include <Spectra/LinAlg/TridiagEigen.h>
+#include <Spectra/LinAlg/UpperHessenbergEigen.h>
+#include <Spectra/LinAlg/UpperHessenbergQR.h>
+#include <Spectra/LinAlg/UpperHessenbergSchur.h>
+
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <random>
+
+using namespace Spectra;
+using Matrix = DenseMatrix<double>;
+using Vector = DenseVector<double>;
+
+static int failures = 0;
+#define REQUIRE(cond)                                                        \
+    do                                                                       \
+    {                                                                        \
+        if (!(cond))                                                         \
+        {                                                                    \
+            std::printf("REQUIRE failed at line %d: %s\n", __LINE__, #cond); \
+            failures++;                                                      \
+        }                                                                    \
+    } while (0)
+
+static std::mt19937 gen(123);
+static double rnd() { return std::uniform_real_distribution<double>(-1.0, 1.0)(gen); }
+
+static Matrix random_matrix(Index r, Index c)
+{
+    Matrix M(r, c);
+    for (Index j = 0; j < c; j++)
+        for (Index i = 0; i < r; i++)
+            M(i, j) = rnd();
+    return M;
+}
+static Matrix identity(Index n)
+{
+    Matrix I(n, n);
+    for (Index j = 0; j < n; j++)
+        for (Index i = 0; i < n; i++)
+            I(i, j) = (i == j) ? 1.0 : 0.0;
+    return I;
+}
+static Matrix mul(const Matrix& A, const Matrix& B, bool ta = false, bool tb = false)
+{
+    const Index m = ta ? A.cols() : A.rows(), k = ta ? A.rows() : A.cols(), n = tb ? B.rows() : B.cols();
+    Matrix C(m, n);
+    for (Index j = 0; j < n; j++)
+        for (Index i = 0; i < m; i++)
+        {
+            double acc = 0.0;
+            for (Index l = 0; l < k; l++)
+                acc += (ta ? A(l, i) : A(i, l)) * (tb ? B(j, l) : B(l, j));
+            C(i, j) = acc;
+        }
+    return C;
+}
+static double max_diff(const Matrix& A, const Matrix& B)
+{
+    double e = 0.0;
+    for (Index j = 0; j < A.cols(); j++)
+        for (Index i = 0; i < A.rows(); i++)
+            e = std::fmax(e, std::fabs(A(i, j) - B(i, j)));
+    return e;
+}
+
+// test/QR.cpp:20-98
+template <typename Solver>
+static void run_qr(const Matrix& H, double shift)
+{
+    const Index n = H.rows();
+    const double tol = 1e-12;
+    Solver decomp(H, shift);
+    Matrix Hs = H;
+    for (Index i = 0; i < n; i++)
+        Hs(i, i) -= shift;
+    const Matrix I = identity(n);
+    Matrix Q = I;
+    decomp.apply_QY(Q);
+    REQUIRE(max_diff(mul(Q, Q, true, false), I) <= tol);
+    REQUIRE(max_diff(mul(Q, Q, false, true), I) <= tol);
+    const Matrix R = decomp.matrix_R();
+    double lower = 0.0;
+    for (Index j = 0; j < n; j++)
+        for (Index i = j + 1; i < n; i++)
+            lower = std::fmax(lower, std::fabs(R(i, j)));
+    REQUIRE(lower <= tol);
+    REQUIRE(max_diff(Hs, mul(Q, R)) <= tol);
+    Matrix QtHQ;
+    decomp.matrix_QtHQ(QtHQ);
+    REQUIRE(max_diff(QtHQ, mul(mul(Q, H, true, false), Q)) <= tol);
+    const Matrix Y = random_matrix(n, n);
+    Matrix T = Y;
+    decomp.apply_QY(T);
+    REQUIRE(max_diff(T, mul(Q, Y)) <= tol);
+    T = Y;
+    decomp.apply_YQ(T);
+    REQUIRE(max_diff(T, mul(Y, Q)) <= tol);
+    T = Y;
+    decomp.apply_QtY(T);
+    REQUIRE(max_diff(T, mul(Q, Y, true, false)) <= tol);
+    T = Y;
+    decomp.apply_YQt(T);
+    REQUIRE(max_diff(T, mul(Y, Q, false, true)) <= tol);
+    Vector y(n), qy(n), qty(n);
+    for (Index i = 0; i < n; i++)
+        y[i] = rnd();
+    qy = y;
+    decomp.apply_QY(qy);
+    qty = y;
+    decomp.apply_QtY(qty);
+    double e1 = 0.0, e2 = 0.0;
+    for (Index i = 0; i < n; i++)
+    {
+        double a = 0.0, b = 0.0;
+        for (Index l = 0; l < n; l++)
+        {
+            a += Q(i, l) * y[l];
+            b += Q(l, i) * y[l];
+        }
+        e1 = std::fmax(e1, std::fabs(qy[i] - a));
+        e2 = std::fmax(e2, std::fabs(qty[i] - b));
+    }
+    REQUIRE(e1 <= tol && e2 <= tol);
+}
+
+int main()
+{
+    const Index n = 100;
+    // upper Hessenberg and symmetric tridiagonal test matrices (test/QR.cpp:100-135)
+    Matrix H = random_matrix(n, n);
+    for (Index j = 0; j < n; j++)
+        for (Index i = j + 2; i < n; i++)
+            H(i, j) = 0.0;
+    Matrix T(n, n);
+    for (Index j = 0; j < n; j++)
+        for (Index i = 0; i < n; i++)
+            T(i, j) = 0.0;
+    for (Index i = 0; i < n; i++)
+        T(i, i) = rnd();
+    for (Index i = 0; i + 1 < n; i++)
+        T(i + 1, i) = T(i, i + 1) = rnd();
+    run_qr<UpperHessenbergQR<double>>(H, 0.0);
+    run_qr<UpperHessenbergQR<double>>(H, 1.2345);
+    run_qr<UpperHessenbergQR<double>>(T, 0.6789);
+    run_qr<TridiagQR<double>>(T, 0.0);
+    run_qr<TridiagQR<double>>(T, 1.2345);
+
+    // TridiagEigen: T X = X D, X orthogonal (test/Eigen.cpp:60-90)
+    {
+        TridiagEigen<double> eig(T);
+        const Vector ev = eig.eigenvalues();
+        const Matrix X = eig.eigenvectors();
+        Matrix XD = X;
+        for (Index j = 0; j < n; j++)
+            for (Index i = 0; i < n; i++)
+                XD(i, j) *= ev[j];
+        REQUIRE(max_diff(mul(T, X), XD) <= 1e-12);
+        REQUIRE(max_diff(mul(X, X, true, false), identity(n)) <= 1e-12);
+    }
+    // DoubleShiftQR: Q orthogonal, Q'HQ Hessenberg and similar (DoubleShiftQR.h:400-467)
+    {
+        const double s = 0.3, t = 0.7;
+        DoubleShiftQR<double> ds(H, s, t);
+        Matrix Q = identity(n);
+        ds.apply_YQ(Q);
+        REQUIRE(max_diff(mul(Q, Q, true, false), identity(n)) <= 1e-12);
+        Matrix QtHQ;
+        ds.matrix_QtHQ(QtHQ);
+        REQUIRE(max_diff(QtHQ, mul(mul(Q, H, true, false), Q)) <= 1e-11);
+        Vector y(n), qty(n);
+        for (Index i = 0; i < n; i++)
+            y[i] = rnd();
+        qty = y;
+        ds.apply_QtY(qty);
+        double e = 0.0;
+        for (Index i = 0; i < n; i++)
+        {
+            double b = 0.0;
+            for (Index l = 0; l < n; l++)
+                b += Q(l, i) * y[l];
+            e = std::fmax(e, std::fabs(qty[i] - b));
+        }
+        REQUIRE(e <= 1e-12);
+    }
+    // UpperHessenbergSchur: H = U T U', U orthogonal, T quasi upper triangular (test/Schur.cpp)
+    {
+        UpperHessenbergSchur<double> schur(H);
+        const Matrix& Ts = schur.matrix_T();
+        const Matrix& U = schur.matrix_U();
+        REQUIRE(max_diff(mul(U, U, true, false), identity(n)) <= 1e-12);
+        REQUIRE(max_diff(mul(mul(U, Ts), U, false, true), H) <= 1e-11);
+        double low = 0.0;
+        for (Index j = 0; j < n; j++)
+            for (Index i = j + 2; i < n; i++)
+                low = std::fmax(low, std::fabs(Ts(i, j)));
+        REQUIRE(low == 0.0);
+        Matrix Tt, Ut;
+        UpperHessenbergSchur<double> again(H);
+        again.swap_T(Tt);
+        again.swap_U(Ut);
+        REQUIRE(max_diff(Tt, Ts) == 0.0 && max_diff(Ut, U) == 0.0);
+    }
+    // UpperHessenbergEigen: H x = lambda x for complex pairs (test/Eigen.cpp:28-58)
+    {
+        UpperHessenbergEigen<double> eig(H);
+        const auto ev = eig.eigenvalues();
+        const auto X = eig.eigenvectors();
+        double err = 0.0;
+        for (Index j = 0; j < n; j++)
+            for (Index i = 0; i < n; i++)
+            {
+                std::complex<double> acc(0.0, 0.0);
+                for (Index l = 0; l < n; l++)
+                    acc += H(i, l) * X(l, j);
+                err = std::fmax(err, std::abs(acc - ev[j] * X(i, j)));
+            }
+        REQUIRE(err <= 1e-10);
+    }
+    std::printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);
+    return failures ? 1 : 0;
+}
