@@ -16,6 +16,7 @@
 #include "krylov.hpp"
 
 #include <cstdlib>
+#include <string>
 
 using namespace mispec;
 
@@ -642,6 +643,104 @@ __global__ __launch_bounds__(kThreads) void k_vq(const double* __restrict__ V, i
     }
 }
 
+// ---- V*Q on the f64 matrix cores ------------------------------------------------------------------------------
+// X' = Q' V' in 16x16x4 MFMA steps (v_mfma_f64_16x16x4_f64): A = Q' (16 output columns x 4 input columns), B = V'
+// (4 input columns x 16 rows), D = 16 output columns x 16 rows.  Operand layout (one f64 per lane): A[i][k] and
+// B[k][j] live in lane (i or j) + 16 k; D[i][j]: j = lane & 15, i = (lane >> 4) + 4 reg.  So a lane's B operand is
+// one element of V — 16 consecutive rows of one column per quarter-wave, straight from HBM, no LDS staging — and
+// a store of one D register covers 16 consecutive rows of four columns.  A wave owns 16*NB rows of the tile and
+// reads all m columns of them before it writes, which keeps the in-place update (X aliasing V) legal.
+typedef double v4d __attribute__((ext_vector_type(4)));
+// Lane (j, k) = (lane & 15, lane >> 4) loads the row PAIR (2j, 2j+1) of input column 4kb + k as one 16-byte
+// access; the even rows feed one MFMA, the odd rows a second one, and the two D registers of a lane go back as one
+// 16-byte store.  A wave therefore covers 32*NB rows per tile with 1 KiB per load instruction.
+template <int KB, int MB, int NB>  // ceil(m/4), ceil(p/16) upper bounds; 32-row blocks per wave
+__global__ __launch_bounds__(kThreads) void k_vq_mfma(const double* __restrict__ V, int64_t ldv, int m,
+                                                       const double* __restrict__ Q, int ldq, int p, double* X, int64_t ldx,
+                                                       int64_t n, int accumulate)
+{
+    extern __shared__ __attribute__((aligned(16))) double qfrag[];  // [kb][mb][64]: A fragments of Q'
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kbn = (m + 3) / 4, mbn = (p + 15) / 16;
+    for (int idx = tid; idx < kbn * mbn * 64; idx += kThreads)
+    {
+        const int l = idx & 63, mb = (idx >> 6) % mbn, kb = (idx >> 6) / mbn;
+        const int k = 4 * kb + (l >> 4), i = 16 * mb + (l & 15);
+        qfrag[idx] = (k < m && i < p) ? Q[k + int64_t(i) * ldq] : 0.0;
+    }
+    __syncthreads();
+    constexpr int kRowsPerWave = 32 * NB;
+    constexpr int kRowsPerBlock = 4 * kRowsPerWave;
+    const int64_t ntiles = (n + kRowsPerBlock - 1) / kRowsPerBlock;
+    const int jrow = lane & 15, kq = lane >> 4;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x)
+    {
+        const int64_t row0 = t * kRowsPerBlock + int64_t(w) * kRowsPerWave;
+        v2d b[KB][NB];
+#pragma unroll
+        for (int kb = 0; kb < KB; kb++)
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++)
+            {
+                const int col = 4 * kb + kq;
+                const int64_t r = row0 + 32 * nb + 2 * jrow;  // rows come in even pairs (vectors are padded to an even length)
+                const bool ok = (kb < kbn) && (col < m) && (r < n);
+                const v2d v = *reinterpret_cast<const v2d*>(V + int64_t(ok ? col : 0) * ldv + (ok ? r : 0));
+                b[kb][nb] = ok ? v : v2d{0.0, 0.0};
+            }
+#pragma unroll
+        for (int mb = 0; mb < MB; mb++)
+        {
+            if (mb >= mbn)  // block-uniform; no `break`, so that the loop unrolls and b[][] stays in registers
+                continue;
+            v4d even[NB], odd[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++)
+            {
+                even[nb] = v4d{0.0, 0.0, 0.0, 0.0};
+                odd[nb] = v4d{0.0, 0.0, 0.0, 0.0};
+                if (accumulate)
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++)
+                    {
+                        const int i = 16 * mb + kq + 4 * reg;
+                        const int64_t r = row0 + 32 * nb + 2 * jrow;
+                        if (i < p && r < n)
+                        {
+                            const v2d x = *reinterpret_cast<const v2d*>(X + int64_t(i) * ldx + r);
+                            even[nb][reg] = x.x;
+                            odd[nb][reg] = x.y;
+                        }
+                    }
+            }
+#pragma unroll
+            for (int kb = 0; kb < KB; kb++)
+            {
+                if (kb >= kbn)
+                    continue;
+                const double a = qfrag[(kb * mbn + mb) * 64 + lane];
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++)
+                {
+                    even[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[kb][nb].x, even[nb], 0, 0, 0);
+                    odd[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[kb][nb].y, odd[nb], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++)
+                {
+                    const int i = 16 * mb + kq + 4 * reg;
+                    const int64_t r = row0 + 32 * nb + 2 * jrow;
+                    if (i < p && r < n)
+                        *reinterpret_cast<v2d*>(X + int64_t(i) * ldx + r) = v2d{even[nb][reg], odd[nb][reg]};
+                }
+        }
+    }
+}
+
 // ---- SimpleRandom stream by jump-ahead (Util/SimpleRandom.h:30-52, :56-66, :92-96) -----------------
 __device__ __forceinline__ uint64_t mod_m31(uint64_t x)  // x < 2^62  ->  x mod (2^31 - 1)
 {
@@ -926,6 +1025,31 @@ namespace {
 void launch_vq_panel(const mispec_ctx& ctx, const double* V, int64_t ldv, int m, const double* Q, int ldq, int p, double* X,
                      int64_t ldx, int64_t n, int accumulate)
 {
+    static const char* impl = getenv("MISPEC_VQ");
+    static const bool use_mfma = impl ? std::string(impl) == "mfma" : false;
+    if (use_mfma)
+    {
+        constexpr int NB = 2;
+        const int64_t ntiles_m = (n + 4 * 32 * NB - 1) / (4 * 32 * NB);
+        static const int knob_m = env_int("MISPEC_VQ_BLOCKS_PER_CU");
+        const int grid_m = persistent_grid(ctx, ntiles_m, knob_m > 0 ? knob_m : 4);
+        const size_t lds_m = size_t((m + 3) / 4) * size_t((p + 15) / 16) * 64 * sizeof(double);
+        const dim3 gm(static_cast<unsigned>(grid_m)), bm(kThreads);
+#define MISPEC_VQM(KB, MB)                                                                                                  \
+    hipLaunchKernelGGL((k_vq_mfma<KB, MB, NB>), gm, bm, lds_m, ctx.stream, V, ldv, m, Q, ldq, p, X, ldx, n, accumulate)
+        const int kbn = (m + 3) / 4, mbn = (p + 15) / 16;
+        if (kbn <= 8 && mbn <= 2)
+            MISPEC_VQM(8, 2);
+        else if (kbn <= 12 && mbn <= 2)
+            MISPEC_VQM(12, 2);
+        else if (kbn <= 12)
+            MISPEC_VQM(12, 4);
+        else
+            MISPEC_VQM(16, 4);
+#undef MISPEC_VQM
+        MISPEC_HIP(hipGetLastError());
+        return;
+    }
     const int64_t ntiles = (n + kTileRows - 1) / kTileRows;
     const int slots = (p + 3) / 4;
     const int maxs = slots <= 4 ? 4 : slots <= 8 ? 8 : slots <= 12 ? 12 : 16;

@@ -190,3 +190,27 @@ def test_wide_basis_restart_and_limits(ctx):
     check_identities(fac, Sd, m, tol=1e-10)
     with pytest.raises(ValueError, match="128"):
         sa.Factorization(sa.SparseGenMatProd(S3, ctx=ctx), 129, True)
+
+
+def test_vq_on_matrix_cores_matches_fma_kernel():
+    # V <- V Q has two implementations: plain f64 FMAs out of LDS (default: already HBM-bound) and
+    # v_mfma_f64_16x16x4_f64 (MISPEC_VQ=mfma).  Same products, different summation order: agree to rounding.
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import spectra_amd as sa; from helpers import sparse_fixture\n"
+        "A, S = sparse_fixture(1000, 0.01)\n"
+        "fac = sa.Factorization(sa.SparseSymMatProd(A), 50, True); fac.init_random(0); fac.factorize_from(1, 50)\n"
+        "ev, U = fac.tridiag_eigen(); order = np.argsort(-np.abs(ev)); fac.restart_sym(ev[order][23:])\n"
+        "sys.stdout.write(np.concatenate([fac.matrix_V(24).ravel(), fac.vector_f()]).tobytes().hex())\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for impl in ("fma", "mfma"):
+        env = dict(os.environ, MISPEC_VQ=impl)
+        r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        res.append(np.frombuffer(bytes.fromhex(r.stdout.strip()), dtype=np.float64))
+    assert np.abs(res[0] - res[1]).max() <= 1e-13
