@@ -68,7 +68,8 @@ SparseView<double, int> svd_view(const Eigen::SparseMatrix<double, Flags, int>& 
 
 }  // namespace internal
 
-// Abstract class for matrix operation (contrib/PartialSVDSolver.h:16-34) + the hooks the device Lanczos binds.
+// Common interface of the two operators (reference: contrib/PartialSVDSolver.h:16-34) plus the hooks through which the
+// device Lanczos finds the two matrices.
 template <typename Scalar_>
 class SVDMatOp
 {
@@ -88,7 +89,7 @@ public:
     virtual ~SVDMatOp() {}
 };
 
-// Operation of a tall matrix in SVD: eigenvalues of A' * A   (contrib/PartialSVDSolver.h:36-72)
+// m > n: the Gram operator x -> A'(A x) of size n   (reference: contrib/PartialSVDSolver.h:36-72)
 template <typename Scalar, typename MatrixType>
 class SVDTallMatOp : public SVDMatOp<Scalar>
 {
@@ -106,11 +107,11 @@ public:
         m_cache(static_cast<std::size_t>(mispec_csr_rows(dev->mat.get())))
     {}
 
-    // These are the rows and columns of A' * A
+    // dimension of the Gram operator
     Index rows() const override { return m_dim; }
     Index cols() const override { return m_dim; }
 
-    // y_out = A' * A * x_in
+    // host-pointer form: first A x into the cache, then A' applied to it
     void perform_op(const Scalar* x_in, Scalar* y_out) const override
     {
         internal::check(mispec_spmv_host(m_dev->mat.get(), x_in, m_cache.data()));
@@ -122,7 +123,7 @@ public:
     const mispec_csr* mispec_product_second() const override { return m_dev->mat_t.get(); }
 };
 
-// Operation of a wide matrix in SVD: eigenvalues of A * A'   (contrib/PartialSVDSolver.h:74-110)
+// m <= n: the operator x -> A(A' x) of size m   (reference: contrib/PartialSVDSolver.h:74-110)
 template <typename Scalar, typename MatrixType>
 class SVDWideMatOp : public SVDMatOp<Scalar>
 {
@@ -140,11 +141,11 @@ public:
         m_cache(static_cast<std::size_t>(mispec_csr_cols(dev->mat.get())))
     {}
 
-    // These are the rows and columns of A * A'
+    // dimension of that operator
     Index rows() const override { return m_dim; }
     Index cols() const override { return m_dim; }
 
-    // y_out = A * A' * x_in
+    // host-pointer form: A' x into the cache, then A applied to it
     void perform_op(const Scalar* x_in, Scalar* y_out) const override
     {
         internal::check(mispec_spmv_host(m_dev->mat_t.get(), x_in, m_cache.data()));
@@ -198,16 +199,16 @@ public:
         m_m(static_cast<Index>(mispec_csr_rows(m_dev->mat.get()))),
         m_n(static_cast<Index>(mispec_csr_cols(m_dev->mat.get())))
     {
-        // Determine the matrix type, tall or wide
+        // pick the smaller of the two Gram operators
         if (m_m > m_n)
             m_op.reset(new SVDTallMatOp<Scalar, MatrixType>(m_dev));
         else
             m_op.reset(new SVDWideMatOp<Scalar, MatrixType>(m_dev));
-        // Solver object
+        // the symmetric eigen solver that does the work
         m_eigs.reset(new SymEigsSolver<SVDMatOp<Scalar>>(*m_op, ncomp, ncv));
     }
 
-    // Computation
+    // runs the eigen solver for the largest eigenvalues of the Gram operator; returns how many converged
     Index compute(Index maxit = 1000, Scalar tol = 1e-10)
     {
         m_eigs->init();
@@ -220,7 +221,7 @@ public:
     Index num_iterations() const { return m_eigs->num_iterations(); }
     Index num_operations() const { return m_eigs->num_operations(); }
 
-    // The converged singular values
+    // sigma_i = sqrt(lambda_i) of the converged pairs, largest first
     Vector singular_values() const
     {
         Vector svals = m_eigs->eigenvalues();
@@ -229,7 +230,7 @@ public:
         return svals;
     }
 
-    // The converged left singular vectors
+    // U: the eigenvectors themselves (wide case) or A V / sigma (tall case)
     Matrix matrix_U(Index nu)
     {
         if (m_evecs.cols() < 1)
@@ -240,7 +241,7 @@ public:
         return scaled_product(m_dev->mat.get(), nu);
     }
 
-    // The converged right singular vectors
+    // V: the eigenvectors themselves (tall case) or A' U / sigma (wide case)
     Matrix matrix_V(Index nv)
     {
         if (m_evecs.cols() < 1)
