@@ -1373,18 +1373,48 @@ extern "C" int mispec_fac_restart_sym(mispec_fac* fac, const double* shifts_host
         MISPEC_REQUIRE(F.k == F.m, "mispec_fac_restart_sym: the factorisation must be complete (k == ncv)");
         F.ctx->make_current();
         const int m = F.m;
+        const int k = m - nshift;  // compress_H decrements k once per shift (Lanczos.h:198-202)
         double* hs = F.h_small.p;  // [diag m][subd m][Q m*m]
         for (int i = 0; i < m; i++)
             hs[i] = F.Hat(i, i);
         for (int i = 0; i < m; i++)
             hs[m + i] = (i < m - 1) ? F.Hat(i + 1, i) : 0.0;
+        // Where the (m-k) shifted QR sweeps run.  One GPU: on the device (k_restart_sym*, 0.24 ms, < 1 % of a restart
+        // cycle).  Row-sharded: every rank would repeat the same serial 0.24 ms while its share of the n-sized work
+        // shrinks with the rank count, so the sweeps run on the host core (same routine, internal/SmallDense.h,
+        // ~40 us) and only Q (m x m) is uploaded.  MISPEC_RESTART=host|device overrides.
+        static const char* where = getenv("MISPEC_RESTART");
+        const bool on_host = where ? std::string(where) == "host" : (F.sharded() && F.ctx->world() > 1);
+        if (on_host)
+        {
+            F.counts[FAM_SMALL]++;
+            double* Q = hs + 2 * m;
+            std::fill(Q, Q + size_t(m) * m, 0.0);
+            for (int i = 0; i < m; i++)
+                Q[size_t(i) * m + i] = 1.0;
+            std::vector<double> work(size_t(4) * m);
+            for (int sft = 0; sft < nshift; sft++)
+                small::tridiag_shifted_qr(m, hs, hs + m, shifts_host[sft], Q, m, m, work.data(), small::Lanes{0, 1});
+            MISPEC_HIP(hipMemcpyAsync(F.Qdev.p, Q, size_t(m) * m * 8, hipMemcpyHostToDevice, F.stream()));
+            {
+                Timed t(F, FAM_COMPRESS);
+                compress_basis(F, k + 1);
+            }
+            std::fill(F.H.begin(), F.H.end(), 0.0);
+            for (int i = 0; i < m; i++)
+                F.Hat(i, i) = hs[i];
+            for (int i = 0; i < m - 1; i++)
+                F.Hat(i + 1, i) = F.Hat(i, i + 1) = hs[m + i];
+            F.k = k;
+            update_f_after_compress(F, Q[size_t(k - 1) * m + (m - 1)], F.Hat(k, k - 1));  // syncs: Q has been consumed by then
+            return;
+        }
         MISPEC_HIP(hipMemcpyAsync(F.d_diag.p, hs, size_t(m) * 8, hipMemcpyHostToDevice, F.stream()));
         MISPEC_HIP(hipMemcpyAsync(F.d_subd.p, hs + m, size_t(m) * 8, hipMemcpyHostToDevice, F.stream()));
         {
             Timed t(F, FAM_SMALL);
             launch_restart_sym(*F.ctx, m, F.d_diag.p, F.d_subd.p, shifts_host, nshift, F.Qdev.p);
         }
-        const int k = m - nshift;  // compress_H decrements k once per shift (Lanczos.h:198-202)
         // V[:, :k+1] <- V Q  (Arnoldi.h:326-335), in place, straight from the device Q
         {
             Timed t(F, FAM_COMPRESS);

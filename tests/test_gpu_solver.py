@@ -243,14 +243,16 @@ def test_ritz_pairs_on_device_or_host_give_the_same_solve():
         "print(n, e.num_operations(), e.num_iterations(), ' '.join(repr(float(x)) for x in e.eigenvalues()))\n"
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for mode in ("host", "device"):
-        env = dict(os.environ, MISPEC_SMALL=mode)
+    for mode in ("host", "device", "host+restart"):
+        env = dict(os.environ, MISPEC_SMALL=mode.split("+")[0])
+        if mode.endswith("+restart"):
+            env["MISPEC_RESTART"] = "host"  # the shifted-QR sweeps of the restart on the host too (default when sharded)
         r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
         outs.append(r.stdout.split())
-    assert outs[0][:3] == outs[1][:3]
-    a, b = np.array(outs[0][3:], dtype=float), np.array(outs[1][3:], dtype=float)
-    assert np.abs(a - b).max() <= 1e-12
+    assert outs[0][:3] == outs[1][:3] == outs[2][:3]
+    a, b, c = (np.array(o[3:], dtype=float) for o in outs)
+    assert np.abs(a - b).max() <= 1e-12 and np.abs(a - c).max() <= 1e-12
 
 
 @pytest.mark.parametrize("rule", ["LargestMagn", "BothEnds"])
