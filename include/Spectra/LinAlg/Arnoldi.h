@@ -60,6 +60,12 @@ template <typename T>
 struct has_device_geigs<T, void_t<decltype(std::declval<const T&>().mispec_geigs_b_operator())>> : std::true_type
 {};
 template <typename T, typename = void>
+struct has_device_geigs_shift : std::false_type
+{};
+template <typename T>
+struct has_device_geigs_shift<T, void_t<decltype(std::declval<const T&>().mispec_geigs_shift_solver())>> : std::true_type
+{};
+template <typename T, typename = void>
 struct has_device_context : std::false_type
 {};
 template <typename T>
@@ -142,6 +148,19 @@ protected:
                                                        static_cast<int>(m_m), &raw));
         m_fac = std::shared_ptr<mispec_fac>(raw, [](mispec_fac* p) { (void) mispec_fac_destroy(p); });
     }
+    // generalized problem, shift modes: y = (A - sigma B)^{-1} B x (Cayley: x + 2 sigma * that), B-inner products
+    template <typename T = OpType>
+    typename std::enable_if<internal::has_device_geigs_shift<T>::value>::type bind(bool symmetric)
+    {
+        if (!symmetric)
+            throw std::invalid_argument("Arnoldi: the generalized shift operators are symmetric (Lanczos) only");
+        m_ctx = internal::borrow_context(m_op.mispec_context());
+        mispec_fac* raw = nullptr;
+        internal::check(mispec_fac_create_geigs_shift(m_ctx.get(), m_op.mispec_geigs_shift_solver(), m_op.mispec_geigs_shift_b(),
+                                                      m_op.mispec_geigs_shift_cayley() ? 1 : 0, m_op.mispec_geigs_shift_sigma(),
+                                                      static_cast<int>(m_m), &raw));
+        m_fac = std::shared_ptr<mispec_fac>(raw, [](mispec_fac* p) { (void) mispec_fac_destroy(p); });
+    }
     template <typename T = OpType>
     typename std::enable_if<internal::has_device_solver<T>::value>::type bind(bool symmetric)
     {
@@ -153,7 +172,8 @@ protected:
     }
     template <typename T = OpType>
     typename std::enable_if<!internal::has_device_matrix<T>::value && !internal::has_device_solver<T>::value &&
-                            !internal::has_device_product<T>::value && !internal::has_device_geigs<T>::value>::type
+                            !internal::has_device_product<T>::value && !internal::has_device_geigs<T>::value &&
+                            !internal::has_device_geigs_shift<T>::value>::type
     bind(bool symmetric)
     {
         m_ctx = internal::context_of(m_op);

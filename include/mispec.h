@@ -145,6 +145,13 @@ int mispec_spmv_time(const mispec_csr* A, const double* x_dev, double* y_dev, in
 typedef struct mispec_symshift mispec_symshift;
 int mispec_symshift_create(mispec_ctx* ctx, int64_t n, const int32_t* outer_host, const int32_t* inner_host,
                            const double* val_host, char uplo, int row_major, mispec_symshift** out);
+/* Pencil form — SymShiftInvert<double, Eigen::Sparse, Eigen::Sparse> (MatOp/SymShiftInvert.h:140-208): the operator
+ * (A - sigma B)^{-1} for two sparse symmetric matrices given by one triangle each; same restrictions as above on
+ * the pattern of A - sigma B (banded with half-bandwidth <= 8, or n <= 4096). */
+int mispec_symshift_create_pencil(mispec_ctx* ctx, int64_t n, const int32_t* a_outer, const int32_t* a_inner,
+                                  const double* a_val, char a_uplo, int a_row_major, const int32_t* b_outer,
+                                  const int32_t* b_inner, const double* b_val, char b_uplo, int b_row_major,
+                                  mispec_symshift** out);
 int mispec_symshift_destroy(mispec_symshift* S);
 int64_t mispec_symshift_rows(const mispec_symshift* S);
 /* set_shift(sigma) (SparseSymShiftSolve.h:85-95): MISPEC_EINVAL "factorization failed with the given shift" on breakdown */
@@ -184,6 +191,13 @@ int64_t mispec_reginv_last_iterations(const mispec_reginv* B);                  
 /* Lanczos factorisation of y = B^{-1}(A x) in the B-inner product (MatOp/internal/SymGEigsRegInvOp.h:76-81 +
  * ArnoldiOp.h:68-101): every dot product / norm / V'f of Lanczos.h is taken as x'By.  Single GPU. */
 int mispec_fac_create_geigs_reginv(mispec_ctx* ctx, const mispec_csr* A, const mispec_reginv* B, int ncv, mispec_fac** out);
+
+/* The shift modes of the generalized solver (SymGEigsShiftSolver.h:36-207): operator y = (A - sigma B)^{-1} M x in the
+ * B-inner product, with S the pencil solver of mispec_symshift_create_pencil (shift already set), B the matrix of the
+ * inner product, and M = B (shift-invert and buckling modes) or, with cayley != 0, M = A + sigma B evaluated as
+ * x + 2 sigma (A - sigma B)^{-1} B x (SymGEigsCayleyOp.h:88-99). */
+int mispec_fac_create_geigs_shift(mispec_ctx* ctx, const mispec_symshift* S, const mispec_csr* B, int cayley, double sigma, int ncv,
+                                  mispec_fac** out);
 
 /* Product operator y = A2 (A x) with A (p x n) and A2 (n x p) resident in HBM — the SVDTallMatOp (A2 = A') /
  * SVDWideMatOp (A = M', A2 = M) of contrib/PartialSVDSolver.h:36-110 as two chained SpMVs; symmetric (Lanczos).
@@ -273,6 +287,11 @@ int mispec_symeigs_create_op(mispec_ctx* ctx, mispec_op_fn op, void* op_user, in
 /* SymGEigsSolver<SparseSymMatProd, SparseRegularInverse, GEigsMode::RegularInverse>. */
 int mispec_symeigs_create_geigs_reginv(mispec_ctx* ctx, const mispec_csr* A, const mispec_reginv* B, int64_t nev, int64_t ncv,
                                        mispec_symeigs** out);
+/* SymGEigsShiftSolver<SymShiftInvert, SparseSymMatProd, mode>: mode 0 = ShiftInvert (lambda = 1/nu + sigma),
+ * 1 = Buckling (lambda = sigma nu / (nu - 1); S built from (K, KG), B = K), 2 = Cayley (lambda = sigma (nu+1)/(nu-1)).
+ * Calls set_shift(sigma) on S. */
+int mispec_symeigs_create_geigs_shift(mispec_ctx* ctx, mispec_symshift* S, const mispec_csr* B, int mode, int64_t nev, int64_t ncv,
+                                      double sigma, mispec_symeigs** out);
 /* SymEigsSolver over the product operator of mispec_fac_create_product (PartialSVDSolver's inner solver). */
 int mispec_symeigs_create_product(mispec_ctx* ctx, const mispec_csr* A, const mispec_csr* A2, int64_t nev, int64_t ncv,
                                   mispec_symeigs** out);

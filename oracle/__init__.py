@@ -85,6 +85,7 @@ def lib():
             "oracle_symeigs_create": (vp, [vp, C.c_long, C.c_long]),
             "oracle_symeigs_free": (None, [vp]),
             "oracle_symeigs_set_shift_invert": (None, [vp, C.c_double]),
+            "oracle_symeigs_create_b": (vp, [vp, vp, C.c_long, C.c_long, C.c_int, C.c_double]),
             "oracle_symeigs_init": (C.c_int, [vp, dp]),
             "oracle_symeigs_compute": (C.c_long, [vp, C.c_int, C.c_long, C.c_double, C.c_int]),
             "oracle_symeigs_info": (C.c_int, [vp]),
@@ -452,6 +453,37 @@ class SymGEigsRegInvSolver(SymEigsSolver):
             lib().oracle_geigs_free(self.holder)
         except Exception:
             pass
+
+
+class SymGEigsShiftSolver(SymEigsSolver):
+    """SymGEigsShiftSolver<SymShiftInvert, SparseSymMatProd, mode> (SymGEigsShiftSolver.h:36-207) on the oracle.
+    A, B: scipy sparse matrices whose lower triangles define the symmetric pencil (for mode "Buckling": A = K, B = KG and
+    the inner product / product operator is K, as in the reference).  inv(A - sigma B) is a scipy sparse LU applied
+    through a callback (the reference delegates it to Eigen::SparseLU, third party)."""
+
+    MODES = {"ShiftInvert": 1, "Buckling": 2, "Cayley": 3}
+
+    def __init__(self, A, B, nev, ncv, sigma, mode="ShiftInvert"):
+        import scipy.sparse as sp
+        import scipy.sparse.linalg as spla
+
+        sym = lambda M: (sp.tril(M) + sp.tril(M, -1).T).tocsc()
+        As, Bs = sym(sp.csc_matrix(A)), sym(sp.csc_matrix(B))
+        n = As.shape[0]
+        lu = spla.splu((As - sigma * Bs).tocsc())
+        P = As if mode == "Buckling" else Bs  # the BOpType: K for buckling, B otherwise
+        Plow = sp.tril(P).tocsc()
+        Plow.sort_indices()
+        if mode == "Cayley":
+            fn = lambda x: x + 2.0 * sigma * lu.solve(P @ x)
+        else:
+            fn = lambda x: lu.solve(P @ x)
+        self._op = Op.callback(n, fn)
+        self._bop = Op.csc_sym(n, Plow.indptr, Plow.indices, Plow.data, lower=True)
+        self.h = lib().oracle_symeigs_create_b(self._op.h, self._bop.h, nev, ncv, self.MODES[mode], float(sigma))
+        if not self.h:
+            raise ValueError(lib().oracle_last_error().decode())
+        self.op, self.nev, self.ncv, self.n = self._op, nev, min(ncv, n), n
 
 
 def hess_qr(H, shift):

@@ -310,6 +310,19 @@ void* oracle_symeigs_create(void* op, long nev, long ncv)
     return rc == 0 ? s : nullptr;
 }
 void oracle_symeigs_free(void* s) { delete static_cast<SymEigs*>(s); }
+// generalized problems with an explicit B-inner product (HermEigsBase<ModeMatOp, BOpType>): op is the Krylov operator,
+// bop the operator y = B x; transform: 1 shift-invert, 2 buckling, 3 Cayley (SymGEigsShiftSolver.h), 0 none
+void* oracle_symeigs_create_b(void* op, void* bop, long nev, long ncv, int transform, double sigma)
+{
+    SymEigs* s = nullptr;
+    int rc = guarded([&] {
+        s = new SymEigs(*static_cast<Op*>(op), nev, ncv, static_cast<Op*>(bop));
+        s->sigma = sigma;
+        s->shift_invert = (transform == 1);
+        s->transform = transform;
+    });
+    return rc == 0 ? s : nullptr;
+}
 
 // ---- generalized problem, regular-inverse mode (SymGEigsSolver.h:224-238 + SparseRegularInverse.h) ----------
 // A and B as CSC of which the lower triangle is used (the reference's defaults).  The returned holder owns

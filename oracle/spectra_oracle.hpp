@@ -1179,6 +1179,9 @@ public:
     std::vector<char> ritz_conv;
     CompInfo info = CompInfo::NotComputed;
     bool shift_invert = false;
+    // back-transform of the Ritz values in the generalized shift modes (SymGEigsShiftSolver.h:59-65, :109-116, :160-167):
+    // 0 none / shift_invert flag, 2 buckling lambda = sigma nu / (nu - 1), 3 Cayley lambda = sigma (nu + 1) / (nu - 1)
+    int transform = 0;
     double sigma = 0.0;
 
     // bop_: the B operator of a generalized problem in regular-inverse mode (HermEigsBase<ModeMatOp, BOpType>,
@@ -1291,6 +1294,12 @@ public:
         if (shift_invert)
             for (Index i = 0; i < nev; i++)
                 ritz_val[i] = 1.0 / ritz_val[i] + sigma;
+        else if (transform == 2)
+            for (Index i = 0; i < nev; i++)
+                ritz_val[i] = sigma * ritz_val[i] / (ritz_val[i] - 1.0);
+        else if (transform == 3)
+            for (Index i = 0; i < nev; i++)
+                ritz_val[i] = sigma * (ritz_val[i] + 1.0) / (ritz_val[i] - 1.0);
         if (sort_rule != SortRule::LargestAlge && sort_rule != SortRule::LargestMagn &&
             sort_rule != SortRule::SmallestAlge && sort_rule != SortRule::SmallestMagn)
             throw std::invalid_argument("unsupported sorting rule");

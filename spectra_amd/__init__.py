@@ -17,7 +17,7 @@ from . import _capi
 from ._capi import MispecError, Profile, build_library, check, lib
 
 __all__ = ["SortRule", "CompInfo", "Context", "SparseSymMatProd", "SparseGenMatProd", "SparseSymShiftSolve", "SymEigsSolver",
-           "SymEigsShiftSolver", "GenEigsSolver", "SVDMatOp", "PartialSVDSolver", "SparseRegularInverse", "SymGEigsSolver", "shard_block",
+           "SymEigsShiftSolver", "GenEigsSolver", "SVDMatOp", "PartialSVDSolver", "SparseRegularInverse", "SymGEigsSolver", "SymShiftInvert", "SymGEigsShiftSolver", "shard_block",
            "Factorization", "tridiag_qr", "tridiag_eigen", "hess_qr", "double_shift_qr", "hess_schur", "hess_eigen", "MispecError", "build_library", "shard_range", "BAND_OFFSETS", "SYNTH_SEED"]
 
 BAND_OFFSETS = (1, 2, 3, 1000, 1001, 100000, 100001)  # SURVEY.md §8(d) "M-band": 15 nnz/row with the diagonal
@@ -315,6 +315,44 @@ class _UserOp:
         self.cb = _capi.op_fn(tramp)
 
 
+class SymShiftInvert:
+    """MatOp/SymShiftInvert.h (sparse A, sparse B): y = (A - sigma B)^{-1} x, factored on the GPU at set_shift(sigma)."""
+
+    def __init__(self, A, B, uplo_a="L", uplo_b="L", ctx=None):
+        self.ctx = ctx or default_context()
+        n, nc, ao, ai, av, arm = _compressed(A)
+        nb, ncb, bo, bi, bv, brm = _compressed(B)
+        if n != nc or nb != n or ncb != n:
+            raise ValueError("SymShiftInvert: A and B must be square matrices of the same size")
+        h = C.c_void_p()
+        check(lib().mispec_symshift_create_pencil(self.ctx.h, n, _ip(ao), _ip(ai), _dp(av), uplo_a.encode()[0:1], int(arm),
+                                                  _ip(bo), _ip(bi), _dp(bv), uplo_b.encode()[0:1], int(brm), C.byref(h)))
+        self.h = h
+        self.n = n
+
+    def rows(self):
+        return self.n
+
+    cols = rows
+
+    def set_shift(self, sigma):
+        check(lib().mispec_symshift_set_shift(self.h, float(sigma)))
+
+    def perform_op(self, x_in):
+        x = _f64(x_in)
+        if x.shape != (self.n,):
+            raise ValueError("perform_op: x_in must have n entries")
+        y = np.empty(self.n)
+        check(lib().mispec_symshift_solve_host(self.h, _dp(x), _dp(y)))
+        return y
+
+    def __del__(self):
+        try:
+            lib().mispec_symshift_destroy(self.h)
+        except Exception:
+            pass
+
+
 class SparseRegularInverse:
     """MatOp/SparseRegularInverse.h: the B operator of a generalized problem — perform_op = B x, solve = B^{-1} x by a
     conjugate-gradient iteration on the GPU (the reference's Eigen::ConjugateGradient defaults)."""
@@ -458,6 +496,11 @@ class SymEigsSolver:
             self.ctx = op.A.ctx
             check(lib().mispec_symeigs_create_geigs_reginv(self.ctx.h, op.A.h, op.B.h, int(nev), int(ncv), C.byref(h)))
             self._user = None
+        elif isinstance(op, _GEigsShiftOp):  # y = (A - sigma B)^{-1} B x (+ Cayley), B-inner product
+            self.ctx = op.S.ctx
+            check(lib().mispec_symeigs_create_geigs_shift(self.ctx.h, op.S.h, op.B.h, op.mode, int(nev), int(ncv), float(op.sigma),
+                                                          C.byref(h)))
+            self._user = None
         elif isinstance(op, SVDMatOp):  # y = A2 (A x), both factors in HBM
             self.ctx = op.ctx
             check(lib().mispec_symeigs_create_product(self.ctx.h, op.first.h, op.second.h, int(nev), int(ncv), C.byref(h)))
@@ -497,7 +540,7 @@ class SymEigsSolver:
         return out[:cnt.value].copy()
 
     def local_rows(self):
-        return self.op.local_rows() if isinstance(self.op, (_DeviceMatrix, SVDMatOp, _GEigsRegInvOp)) else self.op.rows()
+        return self.op.local_rows() if isinstance(self.op, (_DeviceMatrix, SVDMatOp, _GEigsRegInvOp, _GEigsShiftOp)) else self.op.rows()
 
     def eigenvectors(self, nvec=None, to_host=True):
         """n x nconv (this shard's rows).  to_host=False leaves the result in HBM and returns the column count."""
@@ -536,6 +579,36 @@ class SymEigsSolver:
             lib().mispec_symeigs_destroy(self.h)
         except Exception:
             pass
+
+
+class _GEigsShiftOp:
+    """MatOp/internal/SymGEigs{ShiftInvert,Buckling,Cayley}Op.h."""
+
+    MODES = {"ShiftInvert": 0, "Buckling": 1, "Cayley": 2}
+
+    def __init__(self, S, B, sigma, mode):
+        if not isinstance(S, SymShiftInvert) or not isinstance(B, SparseSymMatProd):
+            raise TypeError("SymGEigsShiftSolver: needs a SymShiftInvert and a SparseSymMatProd")
+        if mode not in self.MODES:
+            raise ValueError("SymGEigsShiftSolver: mode must be ShiftInvert, Buckling or Cayley")
+        if S.rows() != B.rows():
+            raise ValueError("SymGEigsShiftSolver: the operators must have the same size")
+        self.S, self.B, self.sigma, self.mode = S, B, float(sigma), self.MODES[mode]
+
+    def rows(self):
+        return self.S.rows()
+
+    cols = rows
+    local_rows = rows
+
+
+class SymGEigsShiftSolver(SymEigsSolver):
+    """SymGEigsShiftSolver<SymShiftInvert, SparseSymMatProd, mode> (SymGEigsShiftSolver.h:36-207): eigenvalues of the pencil
+    near sigma.  op = SymShiftInvert(A, B) (for Buckling: (K, KG)), Bop = SparseSymMatProd of the inner-product matrix
+    (B, or K for Buckling).  set_shift(sigma) is called on op by the solver."""
+
+    def __init__(self, op, Bop, nev, ncv, sigma, mode="ShiftInvert"):
+        super().__init__(_GEigsShiftOp(op, Bop, sigma, mode), nev, ncv)
 
 
 class SymGEigsSolver(SymEigsSolver):

@@ -52,6 +52,13 @@ struct mispec_fac
     // Generalized problem in regular-inverse mode (SymGEigsSolver.h:224-238): operator y = B^{-1}(A x) and every
     // inner product taken as x'By (ArnoldiOp.h:68-101).  bx holds B*(the vector the product is taken with).
     const mispec_reginv* Bop = nullptr;
+    // ... or in one of the shift modes of SymGEigsShiftSolver.h (operator (A - sigma B)^{-1} M x through F.S, with
+    // M = B for shift-invert / buckling and M = A + sigma B for Cayley): Bcsr is the matrix of the inner product;
+    // the Cayley operator is evaluated as x + 2 sigma (A - sigma B)^{-1} B x (SymGEigsCayleyOp.h:88-99).
+    const mispec_csr* Bcsr = nullptr;
+    bool cayley = false;
+    double cay_sigma = 0.0;
+    bool bmode() const { return Bop != nullptr || Bcsr != nullptr; }
     mispec_op_fn op = nullptr;
     void* op_user = nullptr;
     int64_t n = 0;     // global dimension
@@ -289,7 +296,7 @@ int persistent_grid_records(const mispec_fac& F)
 // F.bx = B y
 void b_apply(mispec_fac& F, const double* y)
 {
-    launch_spmv(*F.Bop->B, y, F.bx.p, nullptr);
+    launch_spmv(F.Bcsr ? *F.Bcsr : *F.Bop->B, y, F.bx.p, nullptr);
 }
 // out_dev[0] = x' B y  (device scalar, fixed-order two-stage sum)
 void b_inner_to(mispec_fac& F, const double* x, const double* y, double* out_dev)
@@ -384,6 +391,25 @@ void apply_op(mispec_fac& F, const double* x_loc, double* y_loc, bool lanczos_ep
         else
             launch_spmv(*last, x, y_loc, nullptr, e0, e1);
     }
+    else if (F.S && F.Bcsr)
+    {
+        // generalized shift modes (SymGEigsShiftInvertOp.h:70-75, SymGEigsBucklingOp.h:53-57, SymGEigsCayleyOp.h:88-99):
+        // y = (A - sigma B)^{-1} B x, and for Cayley y = x + 2 sigma * that
+        {
+            Timed t(F, FAM_SPMV);
+            b_apply(F, x_loc);
+            launch_shiftsolve(*F.S, F.bx.p, y_loc);
+            if (F.cayley)
+                (void) launch_axpby(*F.ctx, y_loc, 2.0 * F.cay_sigma, x_loc, 1.0, F.nloc, F.partials.p, F.pstride);
+        }
+        if (lanczos_epi)
+        {
+            if (v_prev)
+                launch_lanczos_epilogue(*F.ctx, y_loc, x_loc, v_prev, h_prev, F.nloc, F.alpha_partials.p);
+            b_inner_to(F, x_loc, y_loc, alpha_dev);
+        }
+        return;
+    }
     else if (F.S)
     {
         Timed t(F, FAM_SPMV);
@@ -459,13 +485,13 @@ void vtf(mispec_fac& F, const double* x, int ncol, int which)
     int nrec;
     {
         Timed t(F, FAM_VTF);
-        if (F.Bop)  // c = V'(B x), |x|_B  (ArnoldiOp.h:68-101)
+        if (F.bmode())  // c = V'(B x), |x|_B  (ArnoldiOp.h:68-101)
         {
             b_apply(F, x);
             a.src = F.bx.p;
         }
         nrec = launch_orth(*F.ctx, ORTH_VTF, a);
-        if (F.Bop)
+        if (F.bmode())
             b_norm_slots(F, x, nrec);
     }
     reduce_to_host(F, nrec, ncol, which);
@@ -482,7 +508,7 @@ void correct_vtf(mispec_fac& F, const double* src, double* dst, int ncol)
     int nrec;
     {
         Timed t(F, FAM_GEMV);
-        if (!F.Bop)
+        if (!F.bmode())
             nrec = launch_orth(*F.ctx, ORTH_CORRECT_VTF, a);
         else
         {
@@ -501,14 +527,14 @@ void correct_vtf(mispec_fac& F, const double* src, double* dst, int ncol)
 // Returns the record count; the caller reduces.
 int resid_vtf(mispec_fac& F, const double* w, const double* v, const double* alpha_dev, double* f, int ncol)
 {
-    OrthArgs a = orth_args(F, F.Bop ? 0 : ncol);
+    OrthArgs a = orth_args(F, F.bmode() ? 0 : ncol);
     a.src = w;
     a.dst = f;
     a.vi = v;
     a.alpha_dev = alpha_dev;
     Timed t(F, FAM_VTF);
     int nrec = launch_orth(*F.ctx, ORTH_RESID_VTF, a);
-    if (F.Bop)  // the plain by-products of that launch are replaced by the B-inner-product ones
+    if (F.bmode())  // the plain by-products of that launch are replaced by the B-inner-product ones
     {
         b_apply(F, f);
         OrthArgs b = orth_args(F, ncol);
@@ -674,7 +700,7 @@ void lanczos_step_host(mispec_fac& F, int i, int64_t* nmatop)
             int nrec;
             {
                 Timed t(F, FAM_VTF);
-                if (F.Bop)  // <V[:, i-1], v>_B
+                if (F.bmode())  // <V[:, i-1], v>_B
                 {
                     b_apply(F, v);
                     a.src = F.bx.p;
@@ -773,7 +799,7 @@ void lanczos_step_device(mispec_fac& F, int i)
 void factorize_lanczos(mispec_fac& F, int from_k, int to_m, int64_t* nmatop)
 {
     zero_H_outside(F, from_k);
-    const bool fast = F.device_steps && F.A != nullptr && F.Bop == nullptr;
+    const bool fast = F.device_steps && F.A != nullptr && !F.bmode();
     int i = from_k;
     while (i <= to_m - 1)
     {
@@ -1014,7 +1040,7 @@ void update_f_after_compress(mispec_fac& F, double q_last, double h_sub)
     {
         Timed t(F, FAM_COMPRESS);
         nrec = launch_axpby(*F.ctx, F.f.p, q_last, F.col(F.k), h_sub, F.nloc, F.partials.p, F.pstride);
-        if (F.Bop)  // beta = |f|_B  (Arnoldi.h:339 through ArnoldiOp::norm)
+        if (F.bmode())  // beta = |f|_B  (Arnoldi.h:339 through ArnoldiOp::norm)
         {
             b_apply(F, F.f.p);
             b_norm_slots(F, F.f.p, nrec);
@@ -1031,7 +1057,8 @@ void update_f_after_compress(mispec_fac& F, double q_last, double h_sub)
 // =================================================================================================
 namespace {
 int fac_create_impl(mispec_ctx* ctx, const mispec_csr* A, const mispec_symshift* S, mispec_op_fn op, void* op_user, int64_t n,
-                    int ncv, int symmetric, mispec_fac** out, const mispec_csr* A2 = nullptr, const mispec_reginv* Bop = nullptr)
+                    int ncv, int symmetric, mispec_fac** out, const mispec_csr* A2 = nullptr, const mispec_reginv* Bop = nullptr,
+                    const mispec_csr* Bcsr = nullptr, bool cayley = false, double cay_sigma = 0.0)
 {
     return guarded([&] {
         MISPEC_REQUIRE(ctx && out, "mispec_fac_create: NULL argument");
@@ -1044,6 +1071,12 @@ int fac_create_impl(mispec_ctx* ctx, const mispec_csr* A, const mispec_symshift*
             MISPEC_REQUIRE(A && !A2 && symmetric, "mispec_fac_create_geigs_reginv: needs a symmetric device matrix A");
             MISPEC_REQUIRE(Bop->ctx == ctx && Bop->n == n, "mispec_fac_create_geigs_reginv: B belongs to another context / size");
             MISPEC_REQUIRE(ctx->comm.allgather == nullptr, "mispec_fac_create_geigs_reginv: generalized problems cannot be row-sharded");
+        }
+        if (Bcsr)
+        {
+            MISPEC_REQUIRE(S && !A && symmetric, "mispec_fac_create_geigs_shift: needs a shift solver and the B matrix");
+            MISPEC_REQUIRE(Bcsr->ctx == ctx && Bcsr->n_rows == n && Bcsr->n_cols == n,
+                           "mispec_fac_create_geigs_shift: B belongs to another context / size");
         }
         if (A && A2)
         {
@@ -1072,7 +1105,10 @@ int fac_create_impl(mispec_ctx* ctx, const mispec_csr* A, const mispec_symshift*
             F->Bop = Bop;
             if (A2 || Bop)
                 F->mid.alloc(size_t(round_up(std::max<int64_t>(A->n_rows, 1), 2)) + 2);
-            if (Bop)
+            F->Bcsr = Bcsr;
+            F->cayley = cayley;
+            F->cay_sigma = cay_sigma;
+            if (Bop || Bcsr)
             {
                 F->bx.alloc(size_t(round_up(std::max<int64_t>(n, 1), 2)) + 2);
                 MISPEC_HIP(hipMemsetAsync(F->bx.p, 0, F->bx.n * sizeof(double), ctx->stream));
@@ -1173,6 +1209,17 @@ extern "C" int mispec_fac_create_geigs_reginv(mispec_ctx* ctx, const mispec_csr*
         return MISPEC_EINVAL;
     }
     return fac_create_impl(ctx, A, nullptr, nullptr, nullptr, A->n_rows, ncv, 1, out, nullptr, B);
+}
+
+extern "C" int mispec_fac_create_geigs_shift(mispec_ctx* ctx, const mispec_symshift* S, const mispec_csr* B, int cayley, double sigma,
+                                             int ncv, mispec_fac** out)
+{
+    if (!S || !B)
+    {
+        set_last_error("mispec_fac_create_geigs_shift: NULL operand");
+        return MISPEC_EINVAL;
+    }
+    return fac_create_impl(ctx, nullptr, S, nullptr, nullptr, S->n, ncv, 1, out, nullptr, nullptr, B, cayley != 0, sigma);
 }
 
 extern "C" int mispec_fac_create_shiftsolve(mispec_ctx* ctx, const mispec_symshift* S, int ncv, int symmetric, mispec_fac** out)

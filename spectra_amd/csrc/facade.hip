@@ -9,6 +9,7 @@
 #include <Spectra/LinAlg/UpperHessenbergSchur.h>
 #include <Spectra/SymEigsShiftSolver.h>
 #include <Spectra/SymEigsSolver.h>
+#include <Spectra/SymGEigsShiftSolver.h>
 #include <Spectra/SymGEigsSolver.h>
 
 #include <cstring>
@@ -75,6 +76,10 @@ using ShiftSolver = Spectra::SymEigsShiftSolver<ShiftOp>;
 using ProdSolver = Spectra::SymEigsSolver<ProductOp>;
 using RegInvBOp = Spectra::SparseRegularInverse<double>;
 using GEigsSolver = Spectra::SymGEigsSolver<DevOp, RegInvBOp, Spectra::GEigsMode::RegularInverse>;
+using PencilOp = Spectra::SymShiftInvert<double>;
+using GShiftInvert = Spectra::SymGEigsShiftSolver<PencilOp, DevOp, Spectra::GEigsMode::ShiftInvert>;
+using GBuckling = Spectra::SymGEigsShiftSolver<PencilOp, DevOp, Spectra::GEigsMode::Buckling>;
+using GCayley = Spectra::SymGEigsShiftSolver<PencilOp, DevOp, Spectra::GEigsMode::Cayley>;
 
 }  // namespace
 
@@ -88,6 +93,10 @@ struct mispec_symeigs
     std::unique_ptr<ProdSolver> prod;
     std::unique_ptr<RegInvBOp> b_op;
     std::unique_ptr<GEigsSolver> geigs;
+    std::unique_ptr<PencilOp> pencil_op;
+    std::unique_ptr<GShiftInvert> g_shift;
+    std::unique_ptr<GBuckling> g_buckling;
+    std::unique_ptr<GCayley> g_cayley;
     std::unique_ptr<DevSolver> dev;
     std::unique_ptr<CbSolver> cb;
     std::unique_ptr<ShiftSolver> shift;
@@ -105,6 +114,12 @@ struct mispec_symeigs
             return f(*prod);
         if (geigs)
             return f(*geigs);
+        if (g_shift)
+            return f(*g_shift);
+        if (g_buckling)
+            return f(*g_buckling);
+        if (g_cayley)
+            return f(*g_cayley);
         return f(*cb);
     }
     mispec_fac* fac() const
@@ -179,6 +194,27 @@ extern "C" int mispec_symeigs_create_geigs_reginv(mispec_ctx* ctx, const mispec_
         s->dev_op = std::make_unique<DevOp>(ctx, const_cast<mispec_csr*>(A));
         s->b_op = std::make_unique<RegInvBOp>(ctx, const_cast<mispec_reginv*>(B));
         s->geigs = std::make_unique<GEigsSolver>(*s->dev_op, *s->b_op, nev, ncv);
+        *out = s.release();
+    });
+}
+
+extern "C" int mispec_symeigs_create_geigs_shift(mispec_ctx* ctx, mispec_symshift* S, const mispec_csr* B, int mode, int64_t nev, int64_t ncv,
+                                                 double sigma, mispec_symeigs** out)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(ctx && S && B && out, "mispec_symeigs_create_geigs_shift: NULL argument");
+        MISPEC_REQUIRE(mode >= 0 && mode <= 2, "mispec_symeigs_create_geigs_shift: mode must be 0 (shift-invert), 1 (buckling) or 2 (Cayley)");
+        auto s = std::make_unique<mispec_symeigs>();
+        s->ctx = ctx;
+        s->nev = nev;
+        s->pencil_op = std::make_unique<PencilOp>(ctx, S);
+        s->dev_op = std::make_unique<DevOp>(ctx, const_cast<mispec_csr*>(B));
+        if (mode == 0)
+            s->g_shift = std::make_unique<GShiftInvert>(*s->pencil_op, *s->dev_op, nev, ncv, sigma);
+        else if (mode == 1)
+            s->g_buckling = std::make_unique<GBuckling>(*s->pencil_op, *s->dev_op, nev, ncv, sigma);
+        else
+            s->g_cayley = std::make_unique<GCayley>(*s->pencil_op, *s->dev_op, nev, ncv, sigma);
         *out = s.release();
     });
 }

@@ -43,12 +43,14 @@ struct HostBand
     // Used for the top level when it is factored on the device, so that no shifted host copy has to be built.
     const std::vector<double>* view = nullptr;
     const double* view_dev = nullptr;  // the same unshifted band in device memory
+    const std::vector<double>* viewB = nullptr;  // pencil: M = *view - shift * *viewB (same layout); nullptr: B = I
+    const double* viewB_dev = nullptr;
     double shift = 0.0;
     double& at(int64_t i, int d) { return a[size_t(i) * (b + 1) + d]; }
     double at(int64_t i, int d) const
     {
         if (view)
-            return (*view)[size_t(i) * (b + 1) + d] - (d == 0 ? shift : 0.0);
+            return (*view)[size_t(i) * (b + 1) + d] - shift * (viewB ? (*viewB)[size_t(i) * (b + 1) + d] : (d == 0 ? 1.0 : 0.0));
         return a[size_t(i) * (b + 1) + d];
     }
     double get(int64_t i, int64_t j) const  // symmetric access, 0 outside the band
@@ -200,11 +202,12 @@ __global__ __launch_bounds__(kThreads) void k_back_subst(int64_t N, int b, int64
 }
 
 // dst = src with sigma subtracted from the diagonal entries (column 0 of the n x (b+1) row-major band)
+// (pencil: dst = src - sigma * srcB entry by entry, the bands share one layout)
 __global__ __launch_bounds__(kThreads) void k_band_shift(int64_t total, int bw, double sigma, const double* __restrict__ src,
-                                                          double* __restrict__ dst)
+                                                          const double* __restrict__ srcB, double* __restrict__ dst)
 {
     for (int64_t i = int64_t(blockIdx.x) * kThreads + threadIdx.x; i < total; i += int64_t(gridDim.x) * kThreads)
-        dst[i] = src[i] - ((i % bw) == 0 ? sigma : 0.0);
+        dst[i] = src[i] - sigma * (srcB ? srcB[i] : ((i % bw) == 0 ? 1.0 : 0.0));
 }
 
 // ---- factorisation of the top level on the device -------------------------------------------------------
@@ -514,7 +517,7 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev)
         {
             const int64_t total = N * (b + 1);
             hipLaunchKernelGGL(k_band_shift, dim3(unsigned(std::min<int64_t>((total + kThreads - 1) / kThreads, 4096))), dim3(kThreads),
-                               0, ctx->stream, total, b + 1, M.shift, M.view_dev, lev.band.p);
+                               0, ctx->stream, total, b + 1, M.shift, M.view_dev, M.viewB_dev, lev.band.p);
             MISPEC_HIP(hipGetLastError());
         }
         else
@@ -888,62 +891,129 @@ mispec_symshift::~mispec_symshift() {}
 // =================================================================================================
 // C ABI
 // =================================================================================================
-extern "C" int mispec_symshift_create(mispec_ctx* ctx, int64_t n, const int32_t* outer, const int32_t* inner, const double* val,
-                                      char uplo, int row_major, mispec_symshift** out)
+namespace {
+struct TriangleInput
+{
+    const int32_t* outer;
+    const int32_t* inner;
+    const double* val;
+    bool lower;
+    bool row_major;
+};
+
+// calls fn(row >= col, value) for every entry of the selected triangle, like selfadjointView<Uplo>
+template <typename Fn>
+void for_each_entry(const TriangleInput& T, int64_t n, Fn&& fn)
+{
+    for (int64_t o = 0; o < n; o++)
+        for (int32_t p = T.outer[o]; p < T.outer[o + 1]; p++)
+        {
+            const int64_t in = T.inner[p];
+            MISPEC_REQUIRE(in >= 0 && in < n, "mispec_symshift_create: index out of range");
+            const int64_t r = T.row_major ? o : in, c = T.row_major ? in : o;
+            if (T.lower ? (r >= c) : (r <= c))
+                fn(r >= c ? r : c, r >= c ? c : r, T.val[p]);
+        }
+}
+
+int symshift_create_impl(mispec_ctx* ctx, int64_t n, const TriangleInput& A, const TriangleInput* B, mispec_symshift** out)
 {
     return guarded([&] {
-        MISPEC_REQUIRE(ctx && out && outer && n >= 1, "mispec_symshift_create: bad argument");
-        MISPEC_REQUIRE(uplo == 'L' || uplo == 'U' || uplo == 'l' || uplo == 'u', "mispec_symshift_create: uplo must be 'L' or 'U'");
+        MISPEC_REQUIRE(ctx && out && A.outer && n >= 1, "mispec_symshift_create: bad argument");
         MISPEC_REQUIRE(ctx->comm.allgather == nullptr, "mispec_symshift_create: shift-and-invert operators cannot be row-sharded");
-        const bool lower = (uplo == 'L' || uplo == 'l');
         auto S = std::make_unique<mispec_symshift>();
         S->ctx = ctx;
         S->n = n;
-        // the selected triangle, like selfadjointView<Uplo> (SparseSymShiftSolve.h:87): first its bandwidth ...
-        auto for_each_entry = [&](auto&& fn) {
-            for (int64_t o = 0; o < n; o++)
-                for (int32_t p = outer[o]; p < outer[o + 1]; p++)
-                {
-                    const int64_t in = inner[p];
-                    MISPEC_REQUIRE(in >= 0 && in < n, "mispec_symshift_create: index out of range");
-                    const int64_t r = row_major ? o : in, c = row_major ? in : o;
-                    if (lower ? (r >= c) : (r <= c))
-                        fn(r >= c ? r : c, r >= c ? c : r, val[p]);
-                }
-        };
-        int64_t count = 0;
-        for_each_entry([&](int64_t r, int64_t c, double) {
+        S->pencil = (B != nullptr);
+        // first the bandwidth of the triangle(s) ...
+        int64_t countA = 0, countB = 0;
+        for_each_entry(A, n, [&](int64_t r, int64_t c, double) {
             S->half_bandwidth = std::max<int64_t>(S->half_bandwidth, r - c);
-            count++;
+            countA++;
         });
+        if (B)
+            for_each_entry(*B, n, [&](int64_t r, int64_t c, double) {
+                S->half_bandwidth = std::max<int64_t>(S->half_bandwidth, r - c);
+                countB++;
+            });
         if (S->half_bandwidth <= kMaxBandwidth)
         {
             // ... then, for a band, the band itself (assembled once; every set_shift() starts from it)
             S->band_b = int(std::max<int64_t>(1, std::min<int64_t>(S->half_bandwidth, n - 1)));  // a diagonal matrix: width 1, zeros
             const size_t bw = size_t(S->band_b) + 1;
             S->band0.assign(size_t(n) * bw, 0.0);
-            for_each_entry([&](int64_t r, int64_t c, double v) { S->band0[size_t(r) * bw + size_t(r - c)] += v; });
+            for_each_entry(A, n, [&](int64_t r, int64_t c, double v) { S->band0[size_t(r) * bw + size_t(r - c)] += v; });
+            if (B)
+            {
+                S->bandB0.assign(size_t(n) * bw, 0.0);
+                for_each_entry(*B, n, [&](int64_t r, int64_t c, double v) { S->bandB0[size_t(r) * bw + size_t(r - c)] += v; });
+            }
             if (factored_on_device(n, S->band_b))
             {
                 ctx->make_current();
                 S->band0_dev.alloc(S->band0.size());
                 MISPEC_HIP(hipMemcpy(S->band0_dev.p, S->band0.data(), S->band0.size() * sizeof(double), hipMemcpyHostToDevice));
+                if (B)
+                {
+                    S->bandB0_dev.alloc(S->bandB0.size());
+                    MISPEC_HIP(hipMemcpy(S->bandB0_dev.p, S->bandB0.data(), S->bandB0.size() * sizeof(double), hipMemcpyHostToDevice));
+                }
             }
         }
         else
         {
             // ... or (row >= col) triplets for the dense path
-            S->rows.reserve(size_t(count));
-            S->cols.reserve(size_t(count));
-            S->vals.reserve(size_t(count));
-            for_each_entry([&](int64_t r, int64_t c, double v) {
+            S->rows.reserve(size_t(countA));
+            S->cols.reserve(size_t(countA));
+            S->vals.reserve(size_t(countA));
+            for_each_entry(A, n, [&](int64_t r, int64_t c, double v) {
                 S->rows.push_back(r);
                 S->cols.push_back(c);
                 S->vals.push_back(v);
             });
+            if (B)
+                for_each_entry(*B, n, [&](int64_t r, int64_t c, double v) {
+                    S->rowsB.push_back(r);
+                    S->colsB.push_back(c);
+                    S->valsB.push_back(v);
+                });
         }
         *out = S.release();
     });
+}
+
+bool parse_uplo(char uplo, bool& lower)
+{
+    lower = (uplo == 'L' || uplo == 'l');
+    return lower || uplo == 'U' || uplo == 'u';
+}
+}  // namespace
+
+extern "C" int mispec_symshift_create(mispec_ctx* ctx, int64_t n, const int32_t* outer, const int32_t* inner, const double* val,
+                                      char uplo, int row_major, mispec_symshift** out)
+{
+    bool lower;
+    if (!parse_uplo(uplo, lower))
+    {
+        set_last_error("mispec_symshift_create: uplo must be 'L' or 'U'");
+        return MISPEC_EINVAL;
+    }
+    return symshift_create_impl(ctx, n, TriangleInput{outer, inner, val, lower, row_major != 0}, nullptr, out);
+}
+
+extern "C" int mispec_symshift_create_pencil(mispec_ctx* ctx, int64_t n, const int32_t* a_outer, const int32_t* a_inner,
+                                             const double* a_val, char a_uplo, int a_row_major, const int32_t* b_outer,
+                                             const int32_t* b_inner, const double* b_val, char b_uplo, int b_row_major,
+                                             mispec_symshift** out)
+{
+    bool la, lb;
+    if (!parse_uplo(a_uplo, la) || !parse_uplo(b_uplo, lb) || !b_outer)
+    {
+        set_last_error("mispec_symshift_create_pencil: bad argument (uplo must be 'L' or 'U', B must be given)");
+        return MISPEC_EINVAL;
+    }
+    const TriangleInput B{b_outer, b_inner, b_val, lb, b_row_major != 0};
+    return symshift_create_impl(ctx, n, TriangleInput{a_outer, a_inner, a_val, la, a_row_major != 0}, &B, out);
 }
 
 extern "C" int mispec_symshift_destroy(mispec_symshift* S)
@@ -974,15 +1044,24 @@ extern "C" int mispec_symshift_set_shift(mispec_symshift* S, double sigma)
             M.b = S->band_b;
             if (S->band0_dev.p && factored_on_device(n, M.b))
             {
-                M.view = &S->band0;  // A - sigma I is formed on the device from the resident band
+                M.view = &S->band0;  // A - sigma I (or A - sigma B) is formed on the device from the resident band(s)
                 M.view_dev = S->band0_dev.p;
+                if (S->pencil)
+                {
+                    M.viewB = &S->bandB0;
+                    M.viewB_dev = S->bandB0_dev.p;
+                }
                 M.shift = sigma;
             }
             else
             {
                 M.a = S->band0;
-                for (int64_t i = 0; i < n; i++)
-                    M.at(i, 0) -= sigma;
+                if (S->pencil)
+                    for (size_t e = 0; e < M.a.size(); e++)
+                        M.a[e] -= sigma * S->bandB0[e];
+                else
+                    for (int64_t i = 0; i < n; i++)
+                        M.at(i, 0) -= sigma;
             }
             S->top = std::make_unique<BandLevel>();
             factor_level(S->ctx, M, *S->top);
@@ -997,8 +1076,16 @@ extern "C" int mispec_symshift_set_shift(mispec_symshift* S, double sigma)
                 if (S->rows[e] != S->cols[e])
                     A[size_t(S->rows[e]) * n + S->cols[e]] += S->vals[e];
             }
-            for (int64_t i = 0; i < n; i++)
-                A[size_t(i) * n + i] -= sigma;
+            if (S->pencil)
+                for (size_t e = 0; e < S->valsB.size(); e++)
+                {
+                    A[size_t(S->colsB[e]) * n + S->rowsB[e]] -= sigma * S->valsB[e];
+                    if (S->rowsB[e] != S->colsB[e])
+                        A[size_t(S->rowsB[e]) * n + S->colsB[e]] -= sigma * S->valsB[e];
+                }
+            else
+                for (int64_t i = 0; i < n; i++)
+                    A[size_t(i) * n + i] -= sigma;
             dense_inverse(int(n), A, inv);
             upload_row_major(inv, n, S->inverse);
             S->dense = true;

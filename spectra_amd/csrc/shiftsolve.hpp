@@ -23,6 +23,13 @@ struct mispec_symshift
     std::vector<double> band0;
     mispec::DevBuf<double> band0_dev;
     int band_b = 0;
+    // pencil form (SymShiftInvert, MatOp/SymShiftInvert.h:140-208): the operator is (A - sigma B)^{-1}; B is kept the
+    // same way as A (band on host + device, or triplets for the dense path).  Empty: B = I.
+    bool pencil = false;
+    std::vector<double> bandB0;
+    mispec::DevBuf<double> bandB0_dev;
+    std::vector<int64_t> rowsB, colsB;
+    std::vector<double> valsB;
     double sigma = 0.0;
     bool factored = false;
     bool dense = false;

@@ -10,6 +10,7 @@
 #include <Spectra/MatOp/SparseSymShiftSolve.h>
 #include <Spectra/SymEigsShiftSolver.h>
 #include <Spectra/SymEigsSolver.h>
+#include <Spectra/SymGEigsShiftSolver.h>
 #include <Spectra/SymGEigsSolver.h>
 #include <Spectra/contrib/PartialSVDSolver.h>
 
@@ -183,10 +184,10 @@ public:
 
 // test/SymGEigsRegInv.cpp:35-106: A = sprand(n, prob) (lower triangle used), B = A'A + 0.1 I, regular-inverse mode;
 // ||A U - B U D||_inf <= 1e-9 with the symmetric A the solver sees.
-static void run_geigs(int n, double prob, int k, int m)
+// B = A'A + 0.1 I as a full CSC matrix (assembled densely: n <= 1000)
+static Csc gram_plus_ridge(const Csc& A)
 {
-    const Csc A = gen_sparse_data(n, prob);
-    // B = A'A + 0.1 I, assembled densely (n <= 1000) and stored as a full CSC matrix
+    const int n = A.n;
     std::vector<double> Bd((size_t) n * n, 0.0);
     for (int j = 0; j < n; j++)
         for (int p = A.colptr[j]; p < A.colptr[j + 1]; p++)
@@ -209,6 +210,69 @@ static void run_geigs(int n, double prob, int k, int m)
             }
         B.colptr.push_back((int) B.rowind.size());
     }
+    return B;
+}
+
+// max |selfadjointView<Lower>(P) U - selfadjointView<Lower>(Q) U D|
+static double pencil_residual(const Csc& P, const Csc& Q, const DenseVector<double>& evals, const DenseMatrix<double>& U)
+{
+    const int n = P.n;
+    double err = 0.0;
+    for (Index c = 0; c < U.cols(); c++)
+    {
+        std::vector<double> pu(n, 0.0), qu(n, 0.0);
+        const Csc* mats[2] = {&P, &Q};
+        std::vector<double>* outs[2] = {&pu, &qu};
+        for (int w = 0; w < 2; w++)
+            for (int j = 0; j < n; j++)
+                for (int p = mats[w]->colptr[j]; p < mats[w]->colptr[j + 1]; p++)
+                {
+                    const int i = mats[w]->rowind[p];
+                    if (i < j)
+                        continue;
+                    (*outs[w])[i] += mats[w]->val[p] * U(j, c);
+                    if (i != j)
+                        (*outs[w])[j] += mats[w]->val[p] * U(i, c);
+                }
+        for (int i = 0; i < n; i++)
+            err = std::fmax(err, std::fabs(pu[i] - evals[c] * qu[i]));
+    }
+    return err;
+}
+
+// test/SymGEigsShift.cpp sparse-sparse cases (:121-141 shift-invert, :214-234 buckling, :307-327 Cayley), sigma = 1.2345
+template <GEigsMode Mode>
+static void run_geigs_shift(const char* name)
+{
+    const int n = 100, k = 10, m = 20;
+    const double sigma = 1.2345;
+    const Csc A = gen_sparse_data(n, 0.1);
+    const Csc B = gram_plus_ridge(A);
+    const bool buckling = (Mode == GEigsMode::Buckling);
+    const Csc& first = buckling ? B : A;   // buckling: the pencil is (K, KG) = (B, A) and the inner product is K
+    const Csc& second = buckling ? A : B;
+    using OpType = SymShiftInvert<double>;
+    using BOpType = SparseSymMatProd<double>;
+    OpType op(first.view(), second.view());
+    BOpType Bop((buckling ? first : second).view());
+    const SortRule rules[] = {SortRule::LargestMagn, SortRule::LargestAlge, SortRule::SmallestAlge, SortRule::BothEnds};
+    for (SortRule rule : rules)
+    {
+        SymGEigsShiftSolver<OpType, BOpType, Mode> eigs(op, Bop, k, m, sigma);
+        eigs.init();
+        const int nconv = (int) eigs.compute(rule, 100);
+        REQUIRE(eigs.info() == CompInfo::Successful);
+        REQUIRE(nconv == k);
+        const double err = pencil_residual(first, second, eigs.eigenvalues(), eigs.eigenvectors());
+        std::printf("geigs-%s rule=%d nconv=%d nops=%d ||AU-BUD||_inf=%.3e\n", name, (int) rule, nconv, (int) eigs.num_operations(), err);
+        REQUIRE(err < 1e-9);  // test/SymGEigsShift.cpp:91
+    }
+}
+
+static void run_geigs(int n, double prob, int k, int m)
+{
+    const Csc A = gen_sparse_data(n, prob);
+    const Csc B = gram_plus_ridge(A);
     using OpType = SparseSymMatProd<double>;
     using BOpType = SparseRegularInverse<double>;
     OpType op(A.view());
@@ -334,6 +398,9 @@ int main()
 
         run_geigs(10, 0.5, 3, 6);      // test/SymGEigsRegInv.cpp:109-119
         run_geigs(100, 0.1, 10, 20);   // :121-131
+        run_geigs_shift<GEigsMode::ShiftInvert>("shiftinvert");
+        run_geigs_shift<GEigsMode::Buckling>("buckling");
+        run_geigs_shift<GEigsMode::Cayley>("cayley");
         run_svd(1000, 100, 5, 10);  // test/SVD.cpp:105-114 (tall sparse)
         run_svd(100, 1000, 5, 10);  // :116-125 (wide sparse)
 

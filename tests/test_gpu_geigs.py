@@ -72,3 +72,62 @@ def test_generalized_at_scale(ctx):
     assert (np.linalg.norm(R, axis=0) / np.linalg.norm(B @ U, axis=0)).max() <= 1e-8
     assert eigs.residuals().max() <= 1e-8
     assert np.abs(U.T @ (B @ U) - np.eye(k)).max() <= 1e-9
+
+
+# ---- shift modes (SymGEigsShiftSolver.h; test/SymGEigsShift.cpp sparse-sparse cases, sigma = 1.2345, k = 10, m = 20) ----
+def shift_fixture(mode):
+    A, B, As = geigs_fixture(100, 0.1)
+    if mode == "Buckling":  # gen_sparse_data(100, KG, K): the pencil is (K, KG) and the inner product is K
+        return B, A, (sp.tril(B) + sp.tril(B, -1).T).tocsc(), As
+    return A, B, As, B
+
+
+@pytest.mark.parametrize("mode", ["ShiftInvert", "Buckling", "Cayley"])
+@pytest.mark.parametrize("rule", RULES)
+def test_shift_modes_fixtures(ctx, mode, rule):
+    A, B, As, Bs = shift_fixture(mode)
+    k, m, sigma = 10, 20, 1.2345
+    op = sa.SymShiftInvert(A, B, ctx=ctx)
+    Bop = sa.SparseSymMatProd(A if mode == "Buckling" else B, ctx=ctx)
+    eigs = sa.SymGEigsShiftSolver(op, Bop, k, m, sigma, mode)
+    eigs.init()
+    nconv = eigs.compute(sa.SortRule[rule], 100)
+    assert eigs.info() == sa.CompInfo.Successful and nconv == k
+    ev, U = eigs.eigenvalues(), eigs.eigenvectors()
+    assert np.abs(As @ U - (Bs @ U) * ev).max() <= 1e-9          # the reference's bar
+    oe = O.SymGEigsShiftSolver(A, B, k, m, sigma, mode)
+    oe.init()
+    assert oe.compute(getattr(O, rule), 100) == k
+    assert np.abs(ev - oe.eigenvalues()).max() <= 1e-8 * max(1.0, np.abs(ev).max())
+
+
+def test_pencil_operator_and_errors(ctx):
+    A, B, As, Bs = shift_fixture("ShiftInvert")
+    op = sa.SymShiftInvert(A, B, ctx=ctx)
+    op.set_shift(0.5)
+    x = np.random.default_rng(2).uniform(-1, 1, 100)
+    ref = np.linalg.solve((As - 0.5 * B).toarray(), x)
+    assert np.abs(op.perform_op(x) - ref).max() <= 1e-10 * np.abs(ref).max()
+    with pytest.raises(ValueError, match="same size"):
+        sa.SymShiftInvert(A, sp.identity(50, format="csc"), ctx=ctx)
+    with pytest.raises(ValueError, match="sigma cannot be zero"):
+        sa.SymGEigsShiftSolver(op, sa.SparseSymMatProd(B, ctx=ctx), 5, 12, 0.0, "Cayley")
+
+
+def test_banded_pencil_at_scale(ctx):
+    # 1D stiffness / mass pencil (tridiagonal K and M, n = 400k): the six eigenvalues closest to sigma
+    n, k, m, sigma = 400_000, 6, 20, 0.0
+    K = sp.diags([np.full(n - 1, -1.0), np.full(n, 2.0), np.full(n - 1, -1.0)], [-1, 0, 1], format="csc")
+    M = sp.diags([np.full(n - 1, 1.0 / 6.0), np.full(n, 4.0 / 6.0), np.full(n - 1, 1.0 / 6.0)], [-1, 0, 1], format="csc")
+    op = sa.SymShiftInvert(K, M, ctx=ctx)
+    eigs = sa.SymGEigsShiftSolver(op, sa.SparseSymMatProd(M, ctx=ctx), k, m, sigma, "ShiftInvert")
+    eigs.init()
+    assert eigs.compute(sa.SortRule.LargestMagn, 300, 1e-10) == k
+    ev, U = np.sort(eigs.eigenvalues()), eigs.eigenvectors()
+    j = np.arange(1, k + 1)
+    theta = j * np.pi / (n + 1)
+    exact = 12.0 * np.sin(theta / 2) ** 2 / (2.0 + np.cos(theta))   # (2 - 2 cos t) / ((4 + 2 cos t) / 6), cancellation-free
+    # K has condition number ~ n^2 = 1.6e11: the smallest eigenvalues carry a relative error of that times epsilon
+    assert np.abs(ev / exact - 1.0).max() <= 1e-4
+    R = K @ U - (M @ U) * eigs.eigenvalues()
+    assert (np.linalg.norm(R, axis=0) / np.linalg.norm(M @ U, axis=0)).max() <= 1e-8

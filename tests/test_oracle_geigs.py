@@ -52,3 +52,28 @@ def test_reginv_fixtures(n, prob, k, m, rule):
 
     want = wanted_by_rule(full, rule, k)
     assert np.abs(np.sort(ev) - np.sort(want)).max() <= 1e-8 * max(1.0, np.abs(want).max())
+
+
+# ---- shift modes (test/SymGEigsShift.cpp: sparse-sparse cases :121-141, :214-234, :307-327; sigma = 1.2345) ----------
+def shift_fixture(mode):
+    A, B, As = geigs_fixture(100, 0.1)
+    if mode == "Buckling":  # gen_sparse_data(100, KG, K): K = KG'KG + 0.1 I is the first operand, KG the second
+        return B, A, (sp.tril(B) + sp.tril(B, -1).T).tocsc(), As
+    return A, B, As, B
+
+
+@pytest.mark.parametrize("mode", ["ShiftInvert", "Buckling", "Cayley"])
+@pytest.mark.parametrize("rule", RULES)
+def test_shift_modes_fixtures(mode, rule):
+    A, B, As, Bs = shift_fixture(mode)
+    k, m, sigma = 10, 20, 1.2345
+    s = O.SymGEigsShiftSolver(A, B, k, m, sigma, mode)
+    s.init()
+    nconv = s.compute(getattr(O, rule), 100)
+    assert s.info() == O.Successful and nconv == k
+    ev, U = s.eigenvalues(), s.eigenvectors()
+    assert np.abs(As @ U - (Bs @ U) * ev).max() <= 1e-9          # the reference's bar (:88-92)
+    # the pairs found are eigenpairs of the pencil: compare with the dense generalized spectrum
+    full = sla.eigvals(As.toarray(), Bs.toarray())
+    full = np.sort(full.real[np.abs(full.imag) < 1e-8])
+    assert all(np.abs(full - lam).min() <= 1e-7 * max(1.0, abs(lam)) for lam in ev)
