@@ -60,6 +60,12 @@ template <typename T>
 struct has_device_geigs<T, void_t<decltype(std::declval<const T&>().mispec_geigs_b_operator())>> : std::true_type
 {};
 template <typename T, typename = void>
+struct has_device_geigs_cholesky : std::false_type
+{};
+template <typename T>
+struct has_device_geigs_cholesky<T, void_t<decltype(std::declval<const T&>().mispec_geigs_cholesky_factor())>> : std::true_type
+{};
+template <typename T, typename = void>
 struct has_device_geigs_shift : std::false_type
 {};
 template <typename T>
@@ -148,6 +154,18 @@ protected:
                                                        static_cast<int>(m_m), &raw));
         m_fac = std::shared_ptr<mispec_fac>(raw, [](mispec_fac* p) { (void) mispec_fac_destroy(p); });
     }
+    // generalized problem, Cholesky mode: y = L^{-1} A L^{-T} x, plain inner products
+    template <typename T = OpType>
+    typename std::enable_if<internal::has_device_geigs_cholesky<T>::value>::type bind(bool symmetric)
+    {
+        if (!symmetric)
+            throw std::invalid_argument("Arnoldi: the generalized Cholesky operator is symmetric (Lanczos) only");
+        m_ctx = internal::borrow_context(m_op.mispec_context());
+        mispec_fac* raw = nullptr;
+        internal::check(mispec_fac_create_geigs_cholesky(m_ctx.get(), m_op.mispec_geigs_cholesky_matrix(),
+                                                         m_op.mispec_geigs_cholesky_factor(), static_cast<int>(m_m), &raw));
+        m_fac = std::shared_ptr<mispec_fac>(raw, [](mispec_fac* p) { (void) mispec_fac_destroy(p); });
+    }
     // generalized problem, shift modes: y = (A - sigma B)^{-1} B x (Cayley: x + 2 sigma * that), B-inner products
     template <typename T = OpType>
     typename std::enable_if<internal::has_device_geigs_shift<T>::value>::type bind(bool symmetric)
@@ -173,7 +191,7 @@ protected:
     template <typename T = OpType>
     typename std::enable_if<!internal::has_device_matrix<T>::value && !internal::has_device_solver<T>::value &&
                             !internal::has_device_product<T>::value && !internal::has_device_geigs<T>::value &&
-                            !internal::has_device_geigs_shift<T>::value>::type
+                            !internal::has_device_geigs_shift<T>::value && !internal::has_device_geigs_cholesky<T>::value>::type
     bind(bool symmetric)
     {
         m_ctx = internal::context_of(m_op);

@@ -9,11 +9,18 @@
 //
 // The Lanczos process runs on y = B^{-1}(A x) with every inner product taken as x'By, so the Ritz vectors are
 // B-orthonormal eigenvectors of the pencil and need no back-transformation (SymGEigsSolver.h:224-238).
-// The Cholesky mode needs triangular solves with a sparse Cholesky factor of B and is not provided.
+// The **Cholesky** mode (SymGEigsSolver.h:142-208) solves the standard problem L^{-1} A L^{-T} y = lambda y with
+// B = L L' and returns x = L^{-T} y; its device B operator holds a dense factor (n <= 4096):
+//
+//     SparseCholesky<double> Bop(B);
+//     SymGEigsSolver<SparseSymMatProd<double>, SparseCholesky<double>, GEigsMode::Cholesky> geigs(op, Bop, nev, ncv);
 #ifndef MISPEC_SPECTRA_SYM_GEIGS_SOLVER_H
 #define MISPEC_SPECTRA_SYM_GEIGS_SOLVER_H
 
+#include <vector>
+
 #include "HermEigsBase.h"
+#include "MatOp/internal/SymGEigsCholeskyOp.h"
 #include "MatOp/internal/SymGEigsRegInvOp.h"
 #include "Util/GEigsMode.h"
 
@@ -23,6 +30,38 @@ namespace Spectra {
 template <typename OpType, typename BOpType, GEigsMode Mode>
 class SymGEigsSolver
 {};
+
+// Partial specialization for mode = GEigsMode::Cholesky (reference :142-208)
+template <typename OpType, typename BOpType>
+class SymGEigsSolver<OpType, BOpType, GEigsMode::Cholesky> : public HermEigsBase<SymGEigsCholeskyOp<OpType, BOpType>, IdentityBOp>
+{
+private:
+    using Scalar = typename OpType::Scalar;
+    using Matrix = DenseMatrix<Scalar>;
+    using ModeMatOp = SymGEigsCholeskyOp<OpType, BOpType>;
+    using Base = HermEigsBase<ModeMatOp, IdentityBOp>;
+    const BOpType& m_Bop;
+
+public:
+    SymGEigsSolver(OpType& op, BOpType& Bop, Index nev, Index ncv) : Base(ModeMatOp(op, Bop), IdentityBOp(), nev, ncv), m_Bop(Bop) {}
+
+    // eigenvectors of the pencil: x = L^{-T} y  (reference :186-199)
+    Matrix eigenvectors(Index nvec) const override
+    {
+        Matrix res = Base::eigenvectors(nvec);
+        std::vector<Scalar> in(static_cast<std::size_t>(res.rows())), out(static_cast<std::size_t>(res.rows()));
+        for (Index i = 0; i < res.cols(); i++)
+        {
+            for (Index r = 0; r < res.rows(); r++)
+                in[static_cast<std::size_t>(r)] = res(r, i);
+            m_Bop.upper_triangular_solve(in.data(), out.data());
+            for (Index r = 0; r < res.rows(); r++)
+                res(r, i) = out[static_cast<std::size_t>(r)];
+        }
+        return res;
+    }
+    Matrix eigenvectors() const override { return SymGEigsSolver<OpType, BOpType, GEigsMode::Cholesky>::eigenvectors(this->m_nev); }
+};
 
 // Partial specialization for mode = GEigsMode::RegularInverse (reference :224-238)
 template <typename OpType, typename BOpType>

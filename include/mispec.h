@@ -192,6 +192,20 @@ int64_t mispec_reginv_last_iterations(const mispec_reginv* B);                  
  * ArnoldiOp.h:68-101): every dot product / norm / V'f of Lanczos.h is taken as x'By.  Single GPU. */
 int mispec_fac_create_geigs_reginv(mispec_ctx* ctx, const mispec_csr* A, const mispec_reginv* B, int ncv, mispec_fac** out);
 
+/* Cholesky mode (SymGEigsSolver.h:142-208 with MatOp/SparseCholesky.h:36-128): B = L L' factored once (dense factor,
+ * n <= 4096), the triangular solves y = L^{-1} x / y = L^{-T} x as GEMVs with the explicit inverse factor in HBM;
+ * the operator of the standard problem is L^{-1} A L^{-T}.  mispec_cholesky_info: 0 = Successful, 3 = NumericalIssue
+ * (B not positive definite), as SparseCholesky::info(). */
+typedef struct mispec_cholesky mispec_cholesky;
+int mispec_cholesky_create(mispec_ctx* ctx, int64_t n, const int32_t* outer_host, const int32_t* inner_host,
+                           const double* val_host, char uplo, int row_major, mispec_cholesky** out);
+int mispec_cholesky_destroy(mispec_cholesky* B);
+int64_t mispec_cholesky_rows(const mispec_cholesky* B);
+int mispec_cholesky_info(const mispec_cholesky* B);
+int mispec_cholesky_lower_solve_host(const mispec_cholesky* B, const double* x_host, double* y_host); /* lower_triangular_solve */
+int mispec_cholesky_upper_solve_host(const mispec_cholesky* B, const double* x_host, double* y_host); /* upper_triangular_solve */
+int mispec_fac_create_geigs_cholesky(mispec_ctx* ctx, const mispec_csr* A, const mispec_cholesky* B, int ncv, mispec_fac** out);
+
 /* The shift modes of the generalized solver (SymGEigsShiftSolver.h:36-207): operator y = (A - sigma B)^{-1} M x in the
  * B-inner product, with S the pencil solver of mispec_symshift_create_pencil (shift already set), B the matrix of the
  * inner product, and M = B (shift-invert and buckling modes) or, with cayley != 0, M = A + sigma B evaluated as
@@ -287,6 +301,9 @@ int mispec_symeigs_create_op(mispec_ctx* ctx, mispec_op_fn op, void* op_user, in
 /* SymGEigsSolver<SparseSymMatProd, SparseRegularInverse, GEigsMode::RegularInverse>. */
 int mispec_symeigs_create_geigs_reginv(mispec_ctx* ctx, const mispec_csr* A, const mispec_reginv* B, int64_t nev, int64_t ncv,
                                        mispec_symeigs** out);
+/* SymGEigsSolver<SparseSymMatProd, SparseCholesky, GEigsMode::Cholesky>; eigenvectors are back-transformed by L^{-T}. */
+int mispec_symeigs_create_geigs_cholesky(mispec_ctx* ctx, const mispec_csr* A, const mispec_cholesky* B, int64_t nev, int64_t ncv,
+                                         mispec_symeigs** out);
 /* SymGEigsShiftSolver<SymShiftInvert, SparseSymMatProd, mode>: mode 0 = ShiftInvert (lambda = 1/nu + sigma),
  * 1 = Buckling (lambda = sigma nu / (nu - 1); S built from (K, KG), B = K), 2 = Cayley (lambda = sigma (nu+1)/(nu-1)).
  * Calls set_shift(sigma) on S. */

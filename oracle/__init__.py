@@ -455,6 +455,30 @@ class SymGEigsRegInvSolver(SymEigsSolver):
             pass
 
 
+class SymGEigsCholeskySolver(SymEigsSolver):
+    """SymGEigsSolver<SparseSymMatProd, SparseCholesky, GEigsMode::Cholesky> (SymGEigsSolver.h:142-208) on the oracle:
+    the standard problem L^{-1} A L^{-T} y = lambda y through a callback (dense Cholesky of B by numpy — the reference
+    delegates it to Eigen::SimplicialLLT — and scipy triangular solves), eigenvectors x = L^{-T} y."""
+
+    def __init__(self, A, B, nev, ncv):
+        import scipy.linalg as sla
+        import scipy.sparse as sp
+
+        sym = lambda M: (sp.tril(M) + sp.tril(M, -1).T).tocsr()
+        As = sym(sp.csc_matrix(A))
+        self._L = np.linalg.cholesky(sym(sp.csc_matrix(B)).toarray())
+        self._sla = sla
+        L = self._L
+        n = As.shape[0]
+        fn = lambda x: sla.solve_triangular(L, As @ sla.solve_triangular(L, x, lower=True, trans="T"), lower=True)
+        self._op = Op.callback(n, fn)
+        super().__init__(self._op, nev, ncv)
+
+    def eigenvectors(self, nvec=None):
+        Y = super().eigenvectors(nvec)
+        return self._sla.solve_triangular(self._L, Y, lower=True, trans="T")
+
+
 class SymGEigsShiftSolver(SymEigsSolver):
     """SymGEigsShiftSolver<SymShiftInvert, SparseSymMatProd, mode> (SymGEigsShiftSolver.h:36-207) on the oracle.
     A, B: scipy sparse matrices whose lower triangles define the symmetric pencil (for mode "Buckling": A = K, B = KG and

@@ -17,7 +17,7 @@ from . import _capi
 from ._capi import MispecError, Profile, build_library, check, lib
 
 __all__ = ["SortRule", "CompInfo", "Context", "SparseSymMatProd", "SparseGenMatProd", "SparseSymShiftSolve", "SymEigsSolver",
-           "SymEigsShiftSolver", "GenEigsSolver", "SVDMatOp", "PartialSVDSolver", "SparseRegularInverse", "SymGEigsSolver", "SymShiftInvert", "SymGEigsShiftSolver", "shard_block",
+           "SymEigsShiftSolver", "GenEigsSolver", "SVDMatOp", "PartialSVDSolver", "SparseRegularInverse", "SparseCholesky", "SymGEigsSolver", "SymShiftInvert", "SymGEigsShiftSolver", "shard_block",
            "Factorization", "tridiag_qr", "tridiag_eigen", "hess_qr", "double_shift_qr", "hess_schur", "hess_eigen", "MispecError", "build_library", "shard_range", "BAND_OFFSETS", "SYNTH_SEED"]
 
 BAND_OFFSETS = (1, 2, 3, 1000, 1001, 100000, 100001)  # SURVEY.md §8(d) "M-band": 15 nnz/row with the diagonal
@@ -315,6 +315,50 @@ class _UserOp:
         self.cb = _capi.op_fn(tramp)
 
 
+class SparseCholesky:
+    """MatOp/SparseCholesky.h: B = L L' (dense factor on the GPU, n <= 4096); lower_triangular_solve = L^{-1} x,
+    upper_triangular_solve = L^{-T} x; info() like the reference (NumericalIssue when B is not positive definite)."""
+
+    def __init__(self, mat, uplo="L", ctx=None):
+        self.ctx = ctx or default_context()
+        n, nc, outer, inner, val, row_major = _compressed(mat)
+        if n != nc:
+            raise ValueError("SparseCholesky: matrix must be square")
+        h = C.c_void_p()
+        check(lib().mispec_cholesky_create(self.ctx.h, n, _ip(outer), _ip(inner), _dp(val), uplo.encode()[0:1], int(row_major),
+                                           C.byref(h)))
+        self.h = h
+        self.n = n
+
+    def rows(self):
+        return self.n
+
+    cols = rows
+
+    def info(self):
+        return CompInfo(lib().mispec_cholesky_info(self.h))
+
+    def _solve(self, fn, x_in):
+        x = _f64(x_in)
+        if x.shape != (self.n,):
+            raise ValueError("triangular solve: x_in must have n entries")
+        y = np.empty(self.n)
+        check(fn(self.h, _dp(x), _dp(y)))
+        return y
+
+    def lower_triangular_solve(self, x_in):
+        return self._solve(lib().mispec_cholesky_lower_solve_host, x_in)
+
+    def upper_triangular_solve(self, x_in):
+        return self._solve(lib().mispec_cholesky_upper_solve_host, x_in)
+
+    def __del__(self):
+        try:
+            lib().mispec_cholesky_destroy(self.h)
+        except Exception:
+            pass
+
+
 class SymShiftInvert:
     """MatOp/SymShiftInvert.h (sparse A, sparse B): y = (A - sigma B)^{-1} x, factored on the GPU at set_shift(sigma)."""
 
@@ -496,6 +540,10 @@ class SymEigsSolver:
             self.ctx = op.A.ctx
             check(lib().mispec_symeigs_create_geigs_reginv(self.ctx.h, op.A.h, op.B.h, int(nev), int(ncv), C.byref(h)))
             self._user = None
+        elif isinstance(op, _GEigsCholeskyOp):  # y = L^{-1} A L^{-T} x
+            self.ctx = op.A.ctx
+            check(lib().mispec_symeigs_create_geigs_cholesky(self.ctx.h, op.A.h, op.B.h, int(nev), int(ncv), C.byref(h)))
+            self._user = None
         elif isinstance(op, _GEigsShiftOp):  # y = (A - sigma B)^{-1} B x (+ Cayley), B-inner product
             self.ctx = op.S.ctx
             check(lib().mispec_symeigs_create_geigs_shift(self.ctx.h, op.S.h, op.B.h, op.mode, int(nev), int(ncv), float(op.sigma),
@@ -540,7 +588,7 @@ class SymEigsSolver:
         return out[:cnt.value].copy()
 
     def local_rows(self):
-        return self.op.local_rows() if isinstance(self.op, (_DeviceMatrix, SVDMatOp, _GEigsRegInvOp, _GEigsShiftOp)) else self.op.rows()
+        return self.op.local_rows() if isinstance(self.op, (_DeviceMatrix, SVDMatOp, _GEigsRegInvOp, _GEigsShiftOp, _GEigsCholeskyOp)) else self.op.rows()
 
     def eigenvectors(self, nvec=None, to_host=True):
         """n x nconv (this shard's rows).  to_host=False leaves the result in HBM and returns the column count."""
@@ -581,6 +629,26 @@ class SymEigsSolver:
             pass
 
 
+class _GEigsCholeskyOp:
+    """MatOp/internal/SymGEigsCholeskyOp.h: y = L^{-1} A L^{-T} x."""
+
+    def __init__(self, A, B):
+        if not isinstance(A, SparseSymMatProd) or not isinstance(B, SparseCholesky):
+            raise TypeError("SymGEigsSolver (Cholesky mode): needs a SparseSymMatProd and a SparseCholesky")
+        if A.rows() != B.rows():
+            raise ValueError("SymGEigsSolver: A and B must have the same size")
+        self.A, self.B = A, B
+
+    def rows(self):
+        return self.B.rows()
+
+    cols = rows
+    local_rows = rows
+
+    def perform_op(self, x):
+        return self.B.lower_triangular_solve(self.A.perform_op(self.B.upper_triangular_solve(x)))
+
+
 class _GEigsShiftOp:
     """MatOp/internal/SymGEigs{ShiftInvert,Buckling,Cayley}Op.h."""
 
@@ -612,13 +680,17 @@ class SymGEigsShiftSolver(SymEigsSolver):
 
 
 class SymGEigsSolver(SymEigsSolver):
-    """SymGEigsSolver<OpType, BOpType, GEigsMode::RegularInverse> (SymGEigsSolver.h:224-238): A x = lambda B x with
-    op = SparseSymMatProd(A) and Bop = SparseRegularInverse(B); B-orthonormal eigenvectors."""
+    """SymGEigsSolver<OpType, BOpType, mode> (SymGEigsSolver.h:142-238): A x = lambda B x.
+    mode "RegularInverse": Bop = SparseRegularInverse(B), B-orthonormal eigenvectors straight from the Lanczos basis;
+    mode "Cholesky": Bop = SparseCholesky(B), standard problem L^{-1} A L^{-T}, eigenvectors back-transformed by L^{-T}."""
 
     def __init__(self, op, Bop, nev, ncv, mode="RegularInverse"):
-        if mode != "RegularInverse":
-            raise ValueError("SymGEigsSolver: only GEigsMode::RegularInverse runs on the device path")
-        super().__init__(_GEigsRegInvOp(op, Bop), nev, ncv)
+        if mode == "RegularInverse":
+            super().__init__(_GEigsRegInvOp(op, Bop), nev, ncv)
+        elif mode == "Cholesky":
+            super().__init__(_GEigsCholeskyOp(op, Bop), nev, ncv)
+        else:
+            raise ValueError("SymGEigsSolver: mode must be RegularInverse or Cholesky (the shift modes are SymGEigsShiftSolver)")
 
 
 class SymEigsShiftSolver(SymEigsSolver):

@@ -123,6 +123,14 @@ SIGNATURES = {
     "mispec_symeigs_create_shift": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_double, _vpp]),
     "mispec_symeigs_create_product": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int64, _vpp]),
     "mispec_symeigs_create_geigs_reginv": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int64, _vpp]),
+    "mispec_symeigs_create_geigs_cholesky": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int64, _vpp]),
+    "mispec_cholesky_create": (C.c_int, [_vp, C.c_int64, _ip, _ip, _dp, C.c_char, C.c_int, _vpp]),
+    "mispec_cholesky_destroy": (C.c_int, [_vp]),
+    "mispec_cholesky_rows": (C.c_int64, [_vp]),
+    "mispec_cholesky_info": (C.c_int, [_vp]),
+    "mispec_cholesky_lower_solve_host": (C.c_int, [_vp, _dp, _dp]),
+    "mispec_cholesky_upper_solve_host": (C.c_int, [_vp, _dp, _dp]),
+    "mispec_fac_create_geigs_cholesky": (C.c_int, [_vp, _vp, _vp, C.c_int, _vpp]),
     "mispec_symeigs_create_geigs_shift": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_double, _vpp]),
     "mispec_symshift_create_pencil": (C.c_int, [_vp, C.c_int64, _ip, _ip, _dp, C.c_char, C.c_int, _ip, _ip, _dp, C.c_char, C.c_int, _vpp]),
     "mispec_fac_create_geigs_shift": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int, _vpp]),

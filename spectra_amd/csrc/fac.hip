@@ -14,6 +14,7 @@
 //     same H because all reductions end in an all-reduce.
 #include "csr.hpp"
 #include "krylov.hpp"
+#include "cholesky.hpp"
 #include "reginv.hpp"
 #include "shiftsolve.hpp"
 #include "small.hpp"
@@ -52,6 +53,8 @@ struct mispec_fac
     // Generalized problem in regular-inverse mode (SymGEigsSolver.h:224-238): operator y = B^{-1}(A x) and every
     // inner product taken as x'By (ArnoldiOp.h:68-101).  bx holds B*(the vector the product is taken with).
     const mispec_reginv* Bop = nullptr;
+    // Cholesky mode (SymGEigsSolver.h:142-208): operator y = L^{-1} A L^{-T} x with B = L L', plain inner products
+    const mispec_cholesky* Chol = nullptr;
     // ... or in one of the shift modes of SymGEigsShiftSolver.h (operator (A - sigma B)^{-1} M x through F.S, with
     // M = B for shift-invert / buckling and M = A + sigma B for Cayley): Bcsr is the matrix of the inner product;
     // the Cayley operator is evaluated as x + 2 sigma (A - sigma B)^{-1} B x (SymGEigsCayleyOp.h:88-99).
@@ -353,6 +356,23 @@ void apply_op(mispec_fac& F, const double* x_loc, double* y_loc, bool lanczos_ep
         }
         else
             scope.reset(new Timed(F, FAM_SPMV));
+        if (F.Chol)
+        {
+            // y = L^{-1} A L^{-T} x  (SymGEigsCholeskyOp.h:63-71): two dense triangular-inverse GEMVs around the SpMV
+            scope.reset();
+            {
+                Timed t(F, FAM_SPMV);
+                launch_cholesky_solve(*F.Chol, true, x, F.mid.p);
+                launch_spmv(*F.A, F.mid.p, F.bx.p, nullptr);
+                launch_cholesky_solve(*F.Chol, false, F.bx.p, y_loc);
+            }
+            if (lanczos_epi)
+            {
+                launch_lanczos_epilogue(*F.ctx, y_loc, x_loc, v_prev, h_prev, F.nloc, F.alpha_partials.p);
+                launch_reduce_sum(*F.ctx, F.alpha_partials.p, lanczos_epilogue_records(*F.ctx, F.nloc), alpha_dev);
+            }
+            return;
+        }
         if (F.Bop)
         {
             // y = B^{-1} (A x)  (SymGEigsRegInvOp.h:76-81); the Lanczos epilogue in the B-inner product follows below
@@ -799,7 +819,7 @@ void lanczos_step_device(mispec_fac& F, int i)
 void factorize_lanczos(mispec_fac& F, int from_k, int to_m, int64_t* nmatop)
 {
     zero_H_outside(F, from_k);
-    const bool fast = F.device_steps && F.A != nullptr && !F.bmode();
+    const bool fast = F.device_steps && F.A != nullptr && !F.bmode() && F.Chol == nullptr;
     int i = from_k;
     while (i <= to_m - 1)
     {
@@ -1058,7 +1078,8 @@ void update_f_after_compress(mispec_fac& F, double q_last, double h_sub)
 namespace {
 int fac_create_impl(mispec_ctx* ctx, const mispec_csr* A, const mispec_symshift* S, mispec_op_fn op, void* op_user, int64_t n,
                     int ncv, int symmetric, mispec_fac** out, const mispec_csr* A2 = nullptr, const mispec_reginv* Bop = nullptr,
-                    const mispec_csr* Bcsr = nullptr, bool cayley = false, double cay_sigma = 0.0)
+                    const mispec_csr* Bcsr = nullptr, bool cayley = false, double cay_sigma = 0.0,
+                    const mispec_cholesky* Chol = nullptr)
 {
     return guarded([&] {
         MISPEC_REQUIRE(ctx && out, "mispec_fac_create: NULL argument");
@@ -1071,6 +1092,13 @@ int fac_create_impl(mispec_ctx* ctx, const mispec_csr* A, const mispec_symshift*
             MISPEC_REQUIRE(A && !A2 && symmetric, "mispec_fac_create_geigs_reginv: needs a symmetric device matrix A");
             MISPEC_REQUIRE(Bop->ctx == ctx && Bop->n == n, "mispec_fac_create_geigs_reginv: B belongs to another context / size");
             MISPEC_REQUIRE(ctx->comm.allgather == nullptr, "mispec_fac_create_geigs_reginv: generalized problems cannot be row-sharded");
+        }
+        if (Chol)
+        {
+            MISPEC_REQUIRE(A && !A2 && !Bop && symmetric, "mispec_fac_create_geigs_cholesky: needs a symmetric device matrix A");
+            MISPEC_REQUIRE(Chol->ctx == ctx && Chol->n == n, "mispec_fac_create_geigs_cholesky: B belongs to another context / size");
+            MISPEC_REQUIRE(Chol->info == 0, "SymGEigsSolver: the Cholesky factorisation of B failed (B must be positive definite)");
+            MISPEC_REQUIRE(ctx->comm.allgather == nullptr, "mispec_fac_create_geigs_cholesky: generalized problems cannot be row-sharded");
         }
         if (Bcsr)
         {
@@ -1105,6 +1133,12 @@ int fac_create_impl(mispec_ctx* ctx, const mispec_csr* A, const mispec_symshift*
             F->Bop = Bop;
             if (A2 || Bop)
                 F->mid.alloc(size_t(round_up(std::max<int64_t>(A->n_rows, 1), 2)) + 2);
+            F->Chol = Chol;
+            if (Chol)
+            {
+                F->mid.alloc(size_t(round_up(std::max<int64_t>(n, 1), 2)) + 2);
+                F->bx.alloc(size_t(round_up(std::max<int64_t>(n, 1), 2)) + 2);
+            }
             F->Bcsr = Bcsr;
             F->cayley = cayley;
             F->cay_sigma = cay_sigma;
@@ -1146,7 +1180,7 @@ int fac_create_impl(mispec_ctx* ctx, const mispec_csr* A, const mispec_symshift*
             const int64_t max_rec = int64_t(ctx->num_cu) * 8 + 8;
             F->pstride = max_rec;
             F->partials.alloc(size_t(max_rec) * kPartialLd);
-            const int64_t nparts = A ? spmv_num_blocks(F->nloc) : lanczos_epilogue_records(*ctx, F->nloc);
+            const int64_t nparts = std::max<int64_t>(A ? spmv_num_blocks(F->nloc) : 0, lanczos_epilogue_records(*ctx, F->nloc));
             F->alpha_partials.alloc(size_t(std::max<int64_t>(nparts, 1)));
             F->red.alloc(2 * kPartialLd);
             MISPEC_HIP(hipMemsetAsync(F->red.p, 0, F->red.n * sizeof(double), ctx->stream));
@@ -1220,6 +1254,16 @@ extern "C" int mispec_fac_create_geigs_shift(mispec_ctx* ctx, const mispec_symsh
         return MISPEC_EINVAL;
     }
     return fac_create_impl(ctx, nullptr, S, nullptr, nullptr, S->n, ncv, 1, out, nullptr, nullptr, B, cayley != 0, sigma);
+}
+
+extern "C" int mispec_fac_create_geigs_cholesky(mispec_ctx* ctx, const mispec_csr* A, const mispec_cholesky* B, int ncv, mispec_fac** out)
+{
+    if (!A || !B)
+    {
+        set_last_error("mispec_fac_create_geigs_cholesky: NULL operand");
+        return MISPEC_EINVAL;
+    }
+    return fac_create_impl(ctx, A, nullptr, nullptr, nullptr, A->n_rows, ncv, 1, out, nullptr, nullptr, nullptr, false, 0.0, B);
 }
 
 extern "C" int mispec_fac_create_shiftsolve(mispec_ctx* ctx, const mispec_symshift* S, int ncv, int symmetric, mispec_fac** out)

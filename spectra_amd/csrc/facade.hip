@@ -76,6 +76,8 @@ using ShiftSolver = Spectra::SymEigsShiftSolver<ShiftOp>;
 using ProdSolver = Spectra::SymEigsSolver<ProductOp>;
 using RegInvBOp = Spectra::SparseRegularInverse<double>;
 using GEigsSolver = Spectra::SymGEigsSolver<DevOp, RegInvBOp, Spectra::GEigsMode::RegularInverse>;
+using CholBOp = Spectra::SparseCholesky<double>;
+using GCholesky = Spectra::SymGEigsSolver<DevOp, CholBOp, Spectra::GEigsMode::Cholesky>;
 using PencilOp = Spectra::SymShiftInvert<double>;
 using GShiftInvert = Spectra::SymGEigsShiftSolver<PencilOp, DevOp, Spectra::GEigsMode::ShiftInvert>;
 using GBuckling = Spectra::SymGEigsShiftSolver<PencilOp, DevOp, Spectra::GEigsMode::Buckling>;
@@ -93,6 +95,8 @@ struct mispec_symeigs
     std::unique_ptr<ProdSolver> prod;
     std::unique_ptr<RegInvBOp> b_op;
     std::unique_ptr<GEigsSolver> geigs;
+    std::unique_ptr<CholBOp> chol_op;
+    std::unique_ptr<GCholesky> g_cholesky;
     std::unique_ptr<PencilOp> pencil_op;
     std::unique_ptr<GShiftInvert> g_shift;
     std::unique_ptr<GBuckling> g_buckling;
@@ -114,6 +118,8 @@ struct mispec_symeigs
             return f(*prod);
         if (geigs)
             return f(*geigs);
+        if (g_cholesky)
+            return f(*g_cholesky);
         if (g_shift)
             return f(*g_shift);
         if (g_buckling)
@@ -194,6 +200,21 @@ extern "C" int mispec_symeigs_create_geigs_reginv(mispec_ctx* ctx, const mispec_
         s->dev_op = std::make_unique<DevOp>(ctx, const_cast<mispec_csr*>(A));
         s->b_op = std::make_unique<RegInvBOp>(ctx, const_cast<mispec_reginv*>(B));
         s->geigs = std::make_unique<GEigsSolver>(*s->dev_op, *s->b_op, nev, ncv);
+        *out = s.release();
+    });
+}
+
+extern "C" int mispec_symeigs_create_geigs_cholesky(mispec_ctx* ctx, const mispec_csr* A, const mispec_cholesky* B, int64_t nev,
+                                                    int64_t ncv, mispec_symeigs** out)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(ctx && A && B && out, "mispec_symeigs_create_geigs_cholesky: NULL argument");
+        auto s = std::make_unique<mispec_symeigs>();
+        s->ctx = ctx;
+        s->nev = nev;
+        s->dev_op = std::make_unique<DevOp>(ctx, const_cast<mispec_csr*>(A));
+        s->chol_op = std::make_unique<CholBOp>(ctx, const_cast<mispec_cholesky*>(B));
+        s->g_cholesky = std::make_unique<GCholesky>(*s->dev_op, *s->chol_op, nev, ncv);
         *out = s.release();
     });
 }

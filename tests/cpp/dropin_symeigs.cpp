@@ -269,6 +269,31 @@ static void run_geigs_shift(const char* name)
     }
 }
 
+// test/SymGEigsCholesky.cpp:44-133 on the sparse fixtures: Cholesky mode, eigenvectors back-transformed by L^{-T}
+static void run_geigs_cholesky(int n, double prob, int k, int m)
+{
+    const Csc A = gen_sparse_data(n, prob);
+    const Csc B = gram_plus_ridge(A);
+    using OpType = SparseSymMatProd<double>;
+    using BOpType = SparseCholesky<double>;
+    OpType op(A.view());
+    BOpType Bop(B.view());
+    REQUIRE(Bop.info() == CompInfo::Successful);
+    const SortRule rules[] = {SortRule::LargestMagn, SortRule::LargestAlge, SortRule::SmallestAlge, SortRule::BothEnds};
+    for (SortRule rule : rules)
+    {
+        SymGEigsSolver<OpType, BOpType, GEigsMode::Cholesky> eigs(op, Bop, k, m);
+        eigs.init();
+        const int nconv = (int) eigs.compute(rule, 100);
+        REQUIRE(eigs.info() == CompInfo::Successful);
+        REQUIRE(nconv == k);
+        const double err = pencil_residual(A, B, eigs.eigenvalues(), eigs.eigenvectors());
+        std::printf("geigs-cholesky n=%d rule=%d nconv=%d nops=%d ||AU-BUD||_inf=%.3e\n", n, (int) rule, nconv,
+                    (int) eigs.num_operations(), err);
+        REQUIRE(err < 1e-9);
+    }
+}
+
 static void run_geigs(int n, double prob, int k, int m)
 {
     const Csc A = gen_sparse_data(n, prob);
@@ -398,6 +423,8 @@ int main()
 
         run_geigs(10, 0.5, 3, 6);      // test/SymGEigsRegInv.cpp:109-119
         run_geigs(100, 0.1, 10, 20);   // :121-131
+        run_geigs_cholesky(10, 0.5, 3, 6);     // test/SymGEigsCholesky.cpp:172-183
+        run_geigs_cholesky(100, 0.1, 10, 20);  // :185-196
         run_geigs_shift<GEigsMode::ShiftInvert>("shiftinvert");
         run_geigs_shift<GEigsMode::Buckling>("buckling");
         run_geigs_shift<GEigsMode::Cayley>("cayley");

@@ -131,3 +131,55 @@ def test_banded_pencil_at_scale(ctx):
     assert np.abs(ev / exact - 1.0).max() <= 1e-4
     R = K @ U - (M @ U) * eigs.eigenvalues()
     assert (np.linalg.norm(R, axis=0) / np.linalg.norm(M @ U, axis=0)).max() <= 1e-8
+
+
+# ---- Cholesky mode (SymGEigsSolver.h:142-208; test/SymGEigsCholesky.cpp sparse cases, test/Example3.cpp) --------------
+def test_sparse_cholesky_operator(ctx):
+    A, B, _ = geigs_fixture(100, 0.1)
+    Bop = sa.SparseCholesky(B, ctx=ctx)
+    assert Bop.info() == sa.CompInfo.Successful
+    L = np.linalg.cholesky(B.toarray())
+    x = np.random.default_rng(4).uniform(-1, 1, 100)
+    assert np.abs(Bop.lower_triangular_solve(x) - np.linalg.solve(L, x)).max() <= 1e-11
+    assert np.abs(Bop.upper_triangular_solve(x) - np.linalg.solve(L.T, x)).max() <= 1e-11
+    bad = sa.SparseCholesky(sp.diags([1.0, -1.0, 2.0], format="csc"), ctx=ctx)      # not positive definite
+    assert bad.info() == sa.CompInfo.NumericalIssue
+    with pytest.raises(ValueError, match="positive definite"):
+        sa.SymGEigsSolver(sa.SparseSymMatProd(sp.identity(3, format="csc"), ctx=ctx), bad, 1, 2, "Cholesky")
+    with pytest.raises(ValueError, match="4096"):
+        sa.SparseCholesky(sp.identity(5000, format="csc"), ctx=ctx)
+
+
+@pytest.mark.parametrize("n,prob,k,m", GEIGS_CASES)
+@pytest.mark.parametrize("rule", RULES)
+def test_cholesky_fixtures(ctx, n, prob, k, m, rule):
+    A, B, As = geigs_fixture(n, prob)
+    eigs = sa.SymGEigsSolver(sa.SparseSymMatProd(A, ctx=ctx), sa.SparseCholesky(B, ctx=ctx), k, m, "Cholesky")
+    eigs.init()
+    nconv = eigs.compute(sa.SortRule[rule], 100)
+    assert eigs.info() == sa.CompInfo.Successful and nconv == k
+    ev, U = eigs.eigenvalues(), eigs.eigenvectors()
+    assert np.abs(As @ U - (B @ U) * ev).max() <= 1e-9          # test/SymGEigsCholesky.cpp:85-89
+    assert np.abs(U.T @ (B @ U) - np.eye(k)).max() <= 1e-9
+    oe = O.SymGEigsCholeskySolver(A, B, k, m)
+    oe.init()
+    assert oe.compute(getattr(O, rule), 100) == k
+    assert np.abs(ev - oe.eigenvalues()).max() <= 1e-9 * max(1.0, np.abs(ev).max())
+    assert eigs.num_operations() == pytest.approx(oe.num_operations(), rel=0.2)
+
+
+def test_example3_issue115(ctx):
+    # test/Example3.cpp:61-94 (case 1): A = M positive SEMI-definite, B = C + 1e5 M, nef = 4, ncv = 5
+    C_tri = [(0, 0, 1.1807575e+08), (1, 1, 304744.5), (1, 5, -152372.25), (2, 2, 304744.5), (2, 4, 152372.25), (3, 3, 15403.85),
+             (4, 2, 152372.25), (4, 4, 101581.5), (5, 1, -152372.25), (5, 5, 101581.5)]
+    M_tri = [(0, 0, 1000.0), (1, 1, 1000.0), (2, 2, 1000.0)]
+    mk = lambda tri: sp.coo_matrix(([v for _, _, v in tri], ([i for i, _, _ in tri], [j for _, j, _ in tri])), shape=(6, 6)).tocsc()
+    A, B = mk(M_tri), (mk(C_tri) + 1.0e5 * mk(M_tri)).tocsc()
+    Bop = sa.SparseCholesky(B, ctx=ctx)
+    assert Bop.info() == sa.CompInfo.Successful
+    eigs = sa.SymGEigsSolver(sa.SparseSymMatProd(A, ctx=ctx), Bop, 4, 5, "Cholesky")
+    eigs.init()
+    eigs.compute(sa.SortRule.LargestMagn)
+    assert eigs.info() == sa.CompInfo.Successful
+    ev, U = eigs.eigenvalues(), eigs.eigenvectors()
+    assert np.abs(A @ U - (B @ U) * ev).max() <= 1e-9
