@@ -152,6 +152,10 @@ int mispec_symshift_create_pencil(mispec_ctx* ctx, int64_t n, const int32_t* a_o
                                   const double* a_val, char a_uplo, int a_row_major, const int32_t* b_outer,
                                   const int32_t* b_inner, const double* b_val, char b_uplo, int b_row_major,
                                   mispec_symshift** out);
+/* General (non-symmetric) form — SparseGenRealShiftSolve (MatOp/SparseGenRealShiftSolve.h:33-99): every stored
+ * entry of the CSC / CSR matrix is used; dense factorisation with partial pivoting, n <= 4096. */
+int mispec_symshift_create_general(mispec_ctx* ctx, int64_t n, const int32_t* outer_host, const int32_t* inner_host,
+                                   const double* val_host, int row_major, mispec_symshift** out);
 int mispec_symshift_destroy(mispec_symshift* S);
 int64_t mispec_symshift_rows(const mispec_symshift* S);
 /* set_shift(sigma) (SparseSymShiftSolve.h:85-95): MISPEC_EINVAL "factorization failed with the given shift" on breakdown */
@@ -337,6 +341,9 @@ typedef struct mispec_geneigs mispec_geneigs;
 int mispec_geneigs_create(mispec_ctx* ctx, const mispec_csr* A, int64_t nev, int64_t ncv, mispec_geneigs** out);
 int mispec_geneigs_create_op(mispec_ctx* ctx, mispec_op_fn op, void* op_user, int64_t n, int64_t nev, int64_t ncv,
                              mispec_geneigs** out);
+/* GenEigsRealShiftSolver<SparseGenRealShiftSolve> (GenEigsRealShiftSolver.h:36-82): Arnoldi on (A - sigma I)^{-1},
+ * eigenvalues mapped back by lambda = 1/nu + sigma.  Calls set_shift(sigma) on S. */
+int mispec_geneigs_create_shift(mispec_ctx* ctx, mispec_symshift* S, int64_t nev, int64_t ncv, double sigma, mispec_geneigs** out);
 int mispec_geneigs_destroy(mispec_geneigs* s);
 int mispec_geneigs_init(mispec_geneigs* s, const double* v0_host /* NULL = init() */);
 int mispec_geneigs_compute(mispec_geneigs* s, int selection, int64_t maxit, double tol, int sorting, int64_t* nconv);

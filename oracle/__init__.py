@@ -85,6 +85,7 @@ def lib():
             "oracle_symeigs_create": (vp, [vp, C.c_long, C.c_long]),
             "oracle_symeigs_free": (None, [vp]),
             "oracle_symeigs_set_shift_invert": (None, [vp, C.c_double]),
+            "oracle_geneigs_set_shift_invert": (None, [vp, C.c_double]),
             "oracle_symeigs_create_b": (vp, [vp, vp, C.c_long, C.c_long, C.c_int, C.c_double]),
             "oracle_symeigs_init": (C.c_int, [vp, dp]),
             "oracle_symeigs_compute": (C.c_long, [vp, C.c_int, C.c_long, C.c_double, C.c_int]),
@@ -546,13 +547,16 @@ def hess_eigen(H):
 
 
 class GenEigsSolver:
-    """GenEigsSolver.h / GenEigsBase.h on the oracle (real matrices, complex results)."""
+    """GenEigsSolver.h / GenEigsBase.h on the oracle (real matrices, complex results).  sigma: the op is already
+    (A - sigma I)^{-1} and the Ritz values are mapped back as in GenEigsRealShiftSolver.h:52-58."""
 
-    def __init__(self, op, nev, ncv):
+    def __init__(self, op, nev, ncv, sigma=None):
         self.op, self.nev, self.ncv, self.n = op, nev, min(ncv, op.n), op.n
         self.h = lib().oracle_geneigs_create(op.h, nev, ncv)
         if not self.h:
             raise ValueError(lib().oracle_last_error().decode())
+        if sigma is not None:
+            lib().oracle_geneigs_set_shift_invert(self.h, float(sigma))
 
     def init(self, v0=None):
         v0 = None if v0 is None else _f64(v0)

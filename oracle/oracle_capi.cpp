@@ -495,6 +495,11 @@ void* oracle_geneigs_create(void* op, long nev, long ncv)
     return rc == 0 ? s : nullptr;
 }
 void oracle_geneigs_free(void* s) { delete static_cast<GenEigs*>(s); }
+void oracle_geneigs_set_shift_invert(void* s, double sigma)
+{
+    static_cast<GenEigs*>(s)->shift_invert = true;
+    static_cast<GenEigs*>(s)->sigma = sigma;
+}
 int oracle_geneigs_init(void* s, const double* v0)
 {
     auto* S = static_cast<GenEigs*>(s);

@@ -953,6 +953,9 @@ public:
     std::vector<Complex> ritz_vec;  // ncv x nev column-major
     std::vector<char> ritz_conv;
     CompInfo info = CompInfo::NotComputed;
+    // GenEigsRealShiftSolver.h:52-58: lambda = 1 / nu + sigma before the final sort
+    bool shift_invert = false;
+    double sigma = 0.0;
 
     static bool is_complex(const Complex& v) { return v.imag() != 0.0; }
     static bool is_conj(const Complex& a, const Complex& b) { return a == std::conj(b); }
@@ -1074,6 +1077,9 @@ public:
     // :345-401
     void sort_ritzpair(SortRule sort_rule)
     {
+        if (shift_invert)
+            for (Index i = 0; i < nev; i++)
+                ritz_val[i] = Complex(1.0, 0.0) / ritz_val[i] + sigma;
         std::vector<Index> ind;
         try
         {

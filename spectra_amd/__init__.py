@@ -17,7 +17,7 @@ from . import _capi
 from ._capi import MispecError, Profile, build_library, check, lib
 
 __all__ = ["SortRule", "CompInfo", "Context", "SparseSymMatProd", "SparseGenMatProd", "SparseSymShiftSolve", "SymEigsSolver",
-           "SymEigsShiftSolver", "GenEigsSolver", "SVDMatOp", "PartialSVDSolver", "SparseRegularInverse", "SparseCholesky", "SymGEigsSolver", "SymShiftInvert", "SymGEigsShiftSolver", "shard_block",
+           "SymEigsShiftSolver", "GenEigsSolver", "SVDMatOp", "PartialSVDSolver", "SparseRegularInverse", "SparseCholesky", "SymGEigsSolver", "SymShiftInvert", "SymGEigsShiftSolver", "SparseGenRealShiftSolve", "GenEigsRealShiftSolver", "shard_block",
            "Factorization", "tridiag_qr", "tridiag_eigen", "hess_qr", "double_shift_qr", "hess_schur", "hess_eigen", "MispecError", "build_library", "shard_range", "BAND_OFFSETS", "SYNTH_SEED"]
 
 BAND_OFFSETS = (1, 2, 3, 1000, 1001, 100000, 100001)  # SURVEY.md §8(d) "M-band": 15 nnz/row with the diagonal
@@ -710,6 +710,57 @@ class SymEigsShiftSolver(SymEigsSolver):
             raise TypeError("SymEigsShiftSolver: pass a SparseSymShiftSolve operator")
 
 
+class SparseGenRealShiftSolve:
+    """MatOp/SparseGenRealShiftSolve.h: y = (A - sigma I)^{-1} x for a general sparse A (dense device factorisation,
+    n <= 4096)."""
+
+    def __init__(self, mat, ctx=None):
+        self.ctx = ctx or default_context()
+        n, nc, outer, inner, val, row_major = _compressed(mat)
+        if n != nc:
+            raise ValueError("SparseGenRealShiftSolve: matrix must be square")
+        h = C.c_void_p()
+        check(lib().mispec_symshift_create_general(self.ctx.h, n, _ip(outer), _ip(inner), _dp(val), int(row_major), C.byref(h)))
+        self.h = h
+        self.n = n
+
+    def rows(self):
+        return self.n
+
+    cols = rows
+    local_rows = rows
+
+    def set_shift(self, sigma):
+        check(lib().mispec_symshift_set_shift(self.h, float(sigma)))
+
+    def perform_op(self, x_in):
+        x = _f64(x_in)
+        if x.shape != (self.n,):
+            raise ValueError("perform_op: x_in must have n entries")
+        y = np.empty(self.n)
+        check(lib().mispec_symshift_solve_host(self.h, _dp(x), _dp(y)))
+        return y
+
+    def __del__(self):
+        try:
+            lib().mispec_symshift_destroy(self.h)
+        except Exception:
+            pass
+
+
+class _GenShiftBinding:
+    def __init__(self, S, sigma):
+        if not isinstance(S, SparseGenRealShiftSolve):
+            raise TypeError("GenEigsRealShiftSolver: needs a SparseGenRealShiftSolve")
+        self.S, self.sigma = S, float(sigma)
+
+    def rows(self):
+        return self.S.rows()
+
+    cols = rows
+    local_rows = rows
+
+
 class GenEigsSolver:
     """GenEigsSolver.h:139-186 / GenEigsBase.h: complex eigenvalues / eigenvectors of a general real matrix."""
 
@@ -719,6 +770,10 @@ class GenEigsSolver:
         if isinstance(op, _DeviceMatrix):
             self.ctx = op.ctx
             check(lib().mispec_geneigs_create(self.ctx.h, op.h, int(nev), int(ncv), C.byref(h)))
+            self._user = None
+        elif isinstance(op, _GenShiftBinding):  # Arnoldi on (A - sigma I)^{-1}
+            self.ctx = op.S.ctx
+            check(lib().mispec_geneigs_create_shift(self.ctx.h, op.S.h, int(nev), int(ncv), float(op.sigma), C.byref(h)))
             self._user = None
         else:
             self.ctx = ctx or default_context()
@@ -783,6 +838,14 @@ class GenEigsSolver:
         except Exception:
             pass
 
+
+
+class GenEigsRealShiftSolver(GenEigsSolver):
+    """GenEigsRealShiftSolver.h:36-82: eigenvalues of a general real A closest to the real shift sigma; op is a
+    SparseGenRealShiftSolve (the solver calls set_shift(sigma)); lambda = 1/nu + sigma."""
+
+    def __init__(self, op, nev, ncv, sigma):
+        super().__init__(_GenShiftBinding(op, sigma), nev, ncv)
 
 def hess_qr(H, shift):
     """UpperHessenbergQR on the host (the general restart's real-shift step): returns (Q, Q'HQ)."""

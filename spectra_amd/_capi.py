@@ -155,6 +155,8 @@ SIGNATURES = {
     "mispec_symeigs_profile": (C.c_int, [_vp, C.c_int]),
     "mispec_geneigs_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vpp]),
     "mispec_geneigs_create_op": (C.c_int, [_vp, op_fn, _vp, C.c_int64, C.c_int64, C.c_int64, _vpp]),
+    "mispec_geneigs_create_shift": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_double, _vpp]),
+    "mispec_symshift_create_general": (C.c_int, [_vp, C.c_int64, _ip, _ip, _dp, C.c_int, _vpp]),
     "mispec_geneigs_destroy": (C.c_int, [_vp]),
     "mispec_geneigs_init": (C.c_int, [_vp, _dp]),
     "mispec_geneigs_compute": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_double, C.c_int, _lp]),

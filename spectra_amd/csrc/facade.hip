@@ -2,6 +2,7 @@
 // library for bindings that cannot instantiate C++ templates (Python ctypes, cgo, JNI ...).
 // Nothing here adds arithmetic: it is Spectra::SymEigsSolver<Spectra::SparseSymMatProd<double>> (or a
 // callback operator with the reference's perform_op contract) behind opaque handles.
+#include <Spectra/GenEigsRealShiftSolver.h>
 #include <Spectra/GenEigsSolver.h>
 #include <Spectra/LinAlg/DoubleShiftQR.h>
 #include <Spectra/LinAlg/UpperHessenbergEigen.h>
@@ -357,18 +358,26 @@ namespace {
 using GenDevOp = Spectra::SparseGenMatProd<double>;
 using GenDevSolver = Spectra::GenEigsSolver<GenDevOp>;
 using GenCbSolver = Spectra::GenEigsSolver<CallbackOp>;
+using GenShiftOp = Spectra::SparseGenRealShiftSolve<double>;
+using GenShiftSolver = Spectra::GenEigsRealShiftSolver<GenShiftOp>;
 }  // namespace
 
 struct mispec_geneigs
 {
     std::unique_ptr<GenDevOp> dev_op;
     std::unique_ptr<CallbackOp> cb_op;
+    std::unique_ptr<GenShiftOp> shift_op;
     std::unique_ptr<GenDevSolver> dev;
     std::unique_ptr<GenCbSolver> cb;
+    std::unique_ptr<GenShiftSolver> shift;
     template <typename F>
     auto visit(F&& f) const
     {
-        return dev ? f(*dev) : f(*cb);
+        if (dev)
+            return f(*dev);
+        if (shift)
+            return f(*shift);
+        return f(*cb);
     }
     mispec_fac* fac() const
     {
@@ -394,6 +403,16 @@ extern "C" int mispec_geneigs_create_op(mispec_ctx* ctx, mispec_op_fn op, void* 
         auto s = std::make_unique<mispec_geneigs>();
         s->cb_op = std::make_unique<CallbackOp>(ctx, op, op_user, n);
         s->cb = std::make_unique<GenCbSolver>(*s->cb_op, nev, ncv);
+        *out = s.release();
+    });
+}
+extern "C" int mispec_geneigs_create_shift(mispec_ctx* ctx, mispec_symshift* S, int64_t nev, int64_t ncv, double sigma, mispec_geneigs** out)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(ctx && S && out, "mispec_geneigs_create_shift: NULL argument");
+        auto s = std::make_unique<mispec_geneigs>();
+        s->shift_op = std::make_unique<GenShiftOp>(ctx, S);
+        s->shift = std::make_unique<GenShiftSolver>(*s->shift_op, nev, ncv, sigma);
         *out = s.release();
     });
 }

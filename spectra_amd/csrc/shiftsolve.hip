@@ -1001,6 +1001,35 @@ extern "C" int mispec_symshift_create(mispec_ctx* ctx, int64_t n, const int32_t*
     return symshift_create_impl(ctx, n, TriangleInput{outer, inner, val, lower, row_major != 0}, nullptr, out);
 }
 
+// SparseGenRealShiftSolve (MatOp/SparseGenRealShiftSolve.h:33-99): y = (A - sigma I)^{-1} x for a general sparse A.
+// The reference factors with Eigen::SparseLU; here the dense path is used (LU with partial pivoting, explicit
+// inverse, GEMV), so n <= 4096.
+extern "C" int mispec_symshift_create_general(mispec_ctx* ctx, int64_t n, const int32_t* outer, const int32_t* inner, const double* val,
+                                              int row_major, mispec_symshift** out)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(ctx && out && outer && n >= 1, "mispec_symshift_create_general: bad argument");
+        MISPEC_REQUIRE(n <= kMaxDense,
+                       "SparseGenRealShiftSolve: only n <= 4096 is supported on the GPU (the reference uses a general sparse LU)");
+        MISPEC_REQUIRE(ctx->comm.allgather == nullptr, "mispec_symshift_create_general: shift-and-invert operators cannot be row-sharded");
+        auto S = std::make_unique<mispec_symshift>();
+        S->ctx = ctx;
+        S->n = n;
+        S->general = true;
+        S->half_bandwidth = n;  // never the banded (symmetric) path
+        for (int64_t o = 0; o < n; o++)
+            for (int32_t p = outer[o]; p < outer[o + 1]; p++)
+            {
+                const int64_t in = inner[p];
+                MISPEC_REQUIRE(in >= 0 && in < n, "mispec_symshift_create_general: index out of range");
+                S->rows.push_back(row_major ? o : in);
+                S->cols.push_back(row_major ? in : o);
+                S->vals.push_back(val[p]);
+            }
+        *out = S.release();
+    });
+}
+
 extern "C" int mispec_symshift_create_pencil(mispec_ctx* ctx, int64_t n, const int32_t* a_outer, const int32_t* a_inner,
                                              const double* a_val, char a_uplo, int a_row_major, const int32_t* b_outer,
                                              const int32_t* b_inner, const double* b_val, char b_uplo, int b_row_major,
@@ -1037,7 +1066,7 @@ extern "C" int mispec_symshift_set_shift(mispec_symshift* S, double sigma)
         S->factored = false;
         S->sigma = sigma;
         const int64_t n = S->n, b = S->half_bandwidth;
-        if (b <= kMaxBandwidth)
+        if (!S->general && b <= kMaxBandwidth)
         {
             HostBand M;
             M.n = n;
@@ -1073,7 +1102,7 @@ extern "C" int mispec_symshift_set_shift(mispec_symshift* S, double sigma)
             for (size_t e = 0; e < S->vals.size(); e++)
             {
                 A[size_t(S->cols[e]) * n + S->rows[e]] += S->vals[e];
-                if (S->rows[e] != S->cols[e])
+                if (!S->general && S->rows[e] != S->cols[e])  // symmetric operators keep one triangle: mirror it
                     A[size_t(S->rows[e]) * n + S->cols[e]] += S->vals[e];
             }
             if (S->pencil)

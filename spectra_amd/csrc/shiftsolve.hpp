@@ -25,6 +25,8 @@ struct mispec_symshift
     int band_b = 0;
     // pencil form (SymShiftInvert, MatOp/SymShiftInvert.h:140-208): the operator is (A - sigma B)^{-1}; B is kept the
     // same way as A (band on host + device, or triplets for the dense path).  Empty: B = I.
+    // general (non-symmetric) matrix — SparseGenRealShiftSolve: every stored entry is used as it is; dense path only
+    bool general = false;
     bool pencil = false;
     std::vector<double> bandB0;
     mispec::DevBuf<double> bandB0_dev;

@@ -4,6 +4,7 @@
 //     g++ -std=c++17 -I include tests/cpp/dropin_symeigs.cpp -L spectra_amd -lmispec -Wl,-rpath,$PWD/spectra_amd
 // It needs a GPU to run (tests/test_gpu_cpp_dropin.py).  Eigen is not available here, so matrices are handed
 // over as Spectra::SparseView and results come back as Spectra::DenseVector / DenseMatrix.
+#include <Spectra/GenEigsRealShiftSolver.h>
 #include <Spectra/GenEigsSolver.h>
 #include <Spectra/MatOp/SparseGenMatProd.h>
 #include <Spectra/MatOp/SparseSymMatProd.h>
@@ -269,6 +270,36 @@ static void run_geigs_shift(const char* name)
     }
 }
 
+// test/GenEigsRealShift.cpp:46-105 on the sparse fixture: eigenvalues of a general matrix closest to sigma
+static void run_gen_real_shift(int n, double prob, int k, int m, double sigma)
+{
+    const Csc A = gen_sparse_data(n, prob);
+    SparseGenRealShiftSolve<double> op(A.view());
+    const SortRule rules[] = {SortRule::LargestMagn, SortRule::LargestReal, SortRule::LargestImag, SortRule::SmallestReal};
+    for (SortRule rule : rules)
+    {
+        GenEigsRealShiftSolver<SparseGenRealShiftSolve<double>> eigs(op, k, m, sigma);
+        eigs.init();
+        const int nconv = (int) eigs.compute(rule, 500);
+        REQUIRE(eigs.info() == CompInfo::Successful);
+        const auto evals = eigs.eigenvalues();
+        const auto U = eigs.eigenvectors();
+        double err = 0.0;
+        for (Index c = 0; c < U.cols(); c++)
+        {
+            std::vector<std::complex<double>> au(n, std::complex<double>(0.0, 0.0));
+            for (int j = 0; j < n; j++)
+                for (int p = A.colptr[j]; p < A.colptr[j + 1]; p++)
+                    au[A.rowind[p]] += A.val[p] * U(j, c);
+            for (int i = 0; i < n; i++)
+                err = std::fmax(err, std::abs(au[i] - evals[c] * U(i, c)));
+        }
+        std::printf("gen-realshift n=%d rule=%d nconv=%d nops=%d ||AU-UD||_inf=%.3e\n", n, (int) rule, nconv, (int) eigs.num_operations(), err);
+        REQUIRE(nconv >= k - 1);
+        REQUIRE(err < 1e-8);  // test/GenEigsRealShift.cpp:69
+    }
+}
+
 // test/SymGEigsCholesky.cpp:44-133 on the sparse fixtures: Cholesky mode, eigenvectors back-transformed by L^{-T}
 static void run_geigs_cholesky(int n, double prob, int k, int m)
 {
@@ -423,6 +454,7 @@ int main()
 
         run_geigs(10, 0.5, 3, 6);      // test/SymGEigsRegInv.cpp:109-119
         run_geigs(100, 0.1, 10, 20);   // :121-131
+        run_gen_real_shift(100, 0.1, 10, 30, 10.0);  // test/GenEigsRealShift.cpp:158-168
         run_geigs_cholesky(10, 0.5, 3, 6);     // test/SymGEigsCholesky.cpp:172-183
         run_geigs_cholesky(100, 0.1, 10, 20);  // :185-196
         run_geigs_shift<GEigsMode::ShiftInvert>("shiftinvert");

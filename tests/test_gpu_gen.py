@@ -140,3 +140,43 @@ def test_gen_wide_basis(ctx):
     assert nconv >= nev - 1  # a conjugate pair may be split at the nev boundary
     ev, U = eigs.eigenvalues(), eigs.eigenvectors()
     assert np.abs(A @ U - U * ev).max() <= 1e-9
+
+
+# ---- GenEigsRealShiftSolver + SparseGenRealShiftSolve (GenEigsRealShiftSolver.h; test/GenEigsRealShift.cpp:146-180) -----
+REAL_SHIFT_CASES = [(10, 0.5, 3, 6, 1.0), (100, 0.1, 10, 30, 10.0), (1000, 0.01, 20, 50, 100.0)]
+
+
+@pytest.mark.parametrize("n,prob,k,m,sigma", REAL_SHIFT_CASES)
+@pytest.mark.parametrize("rule", ["LargestMagn", "LargestReal", "LargestImag", "SmallestReal"])
+def test_real_shift_fixtures(ctx, n, prob, k, m, sigma, rule):
+    import scipy.sparse.linalg as spla
+    from helpers import sparse_fixture
+
+    A, _ = sparse_fixture(n, prob)
+    op = sa.SparseGenRealShiftSolve(A, ctx=ctx)
+    eigs = sa.GenEigsRealShiftSolver(op, k, m, sigma)
+    eigs.init()
+    nconv = eigs.compute(sa.SortRule[rule], 500)
+    assert eigs.info() == sa.CompInfo.Successful and nconv >= k - 1  # a conjugate pair may be split at the nev boundary
+    ev, U = eigs.eigenvalues(), eigs.eigenvectors()
+    assert np.abs(A @ U - U * ev).max() <= 1e-8            # test/GenEigsRealShift.cpp:66-70
+    lu = spla.splu((A - sigma * sp.identity(n)).tocsc())
+    oe = O.GenEigsSolver(O.Op.callback(n, lu.solve), k, m, sigma=sigma)
+    oe.init()
+    oe.compute(getattr(O, rule), 500)
+    ev0 = oe.eigenvalues()
+    assert len(ev0) == len(ev)
+    assert all(np.abs(ev0 - lam).min() <= 1e-7 * max(1.0, abs(lam)) for lam in ev)
+
+
+def test_real_shift_operator(ctx):
+    from helpers import sparse_fixture
+
+    A, _ = sparse_fixture(100, 0.1)
+    op = sa.SparseGenRealShiftSolve(A, ctx=ctx)
+    op.set_shift(10.0)
+    x = np.random.default_rng(5).uniform(-1, 1, 100)
+    ref = np.linalg.solve(A.toarray() - 10.0 * np.eye(100), x)
+    assert np.abs(op.perform_op(x) - ref).max() <= 1e-12
+    with pytest.raises(ValueError, match="4096"):
+        sa.SparseGenRealShiftSolve(sp.identity(5000, format="csc"), ctx=ctx)

@@ -105,3 +105,24 @@ def test_gen_constructor_checks():
     for nev, ncv in [(0, 5), (9, 10), (3, 4), (3, 11)]:  # GenEigsBase.h:419-423
         with pytest.raises(ValueError):
             O.GenEigsSolver(op, nev, ncv)
+
+
+# ---- GenEigsRealShiftSolver (test/GenEigsRealShift.cpp sparse cases :146-180; bar 1e-8, compute(selection, 500)) -------
+REAL_SHIFT_CASES = [(10, 0.5, 3, 6, 1.0), (100, 0.1, 10, 30, 10.0), (1000, 0.01, 20, 50, 100.0)]
+
+
+@pytest.mark.parametrize("n,prob,k,m,sigma", REAL_SHIFT_CASES)
+@pytest.mark.parametrize("rule", ["LargestMagn", "LargestReal", "LargestImag", "SmallestReal"])
+def test_real_shift_fixtures(n, prob, k, m, sigma, rule):
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+
+    r, c, v = O.gen_sparse_data(n, prob)
+    A = sp.coo_matrix((v, (r, c)), shape=(n, n)).tocsc()
+    lu = spla.splu((A - sigma * sp.identity(n)).tocsc())
+    eigs = O.GenEigsSolver(O.Op.callback(n, lu.solve), k, m, sigma=sigma)
+    eigs.init()
+    nconv = eigs.compute(getattr(O, rule), 500)
+    assert eigs.info() == O.Successful and nconv >= k - 1
+    ev, U = eigs.eigenvalues(), eigs.eigenvectors()
+    assert np.abs(A @ U - U * ev).max() <= 1e-8
