@@ -232,6 +232,10 @@ def main():
                 "bytes_per_launch": spmv_bytes,
                 "ms_per_launch": spmv_ms,
                 "launches": int(prof["n_spmv"]),
+                # the launch that is timed also does w -= beta*v_prev and the <v, w> partials (Lanczos.h:139,142): two more
+                # vector streams (v_prev, v) that the BASELINE.md formula above does not credit
+                "fused_epilogue_bytes_per_launch": spmv_bytes + 16.0 * op.local_rows(),
+                "fused_epilogue_frac": (spmv_bytes + 16.0 * op.local_rows()) / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if spmv_ms > 0 else 0.0,
                 "standalone_ms_per_launch": alone_ms,
                 "standalone_gbps": spmv_bytes / (alone_ms * 1e-3) / 1e9,
             },
