@@ -76,8 +76,9 @@ def cpu_baseline(args, gpu_nops, gpu_nconv):
     }
 
 
-def pmc_traffic(n):
-    """HBM bytes per launch of the fused SpMV as measured by the committed PMC passes (tools/pmc_summarize.py), or None."""
+def pmc_traffic(n, coded):
+    """HBM bytes per launch of the fused SpMV (offset-coded or int32-index instantiation, whichever the solve used) as
+    measured by the committed PMC passes (tools/pmc_summarize.py), or None."""
     import glob
 
     here = os.path.dirname(os.path.abspath(__file__))
@@ -88,7 +89,9 @@ def pmc_traffic(n):
             if int(d.get("n", -1)) != int(n):
                 continue
             for name, rec in d["kernels"].items():
-                if name.startswith("k_spmv_csr_stream<true"):
+                args_ = name.split("<", 1)[1].rstrip(">").split(",") if "<" in name else []
+                is_coded = len(args_) >= 4 and args_[3].strip() == "true"
+                if name.startswith("k_spmv_csr_stream<true") and is_coded == bool(coded):
                     return float(rec["hbm_bytes"])
         except Exception:  # noqa: BLE001 - a malformed summary just means "no PMC figure"
             continue
@@ -226,10 +229,17 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": pmc_traffic(args.n) if world == 1 else None,
+                "traffic": pmc_traffic(args.n, op.offset_codes() > 0) if world == 1 else None,
                 "traffic_source": "bytes per launch of the in-loop SpMV from the newest profiles/*pmc_traffic.json "
                                   "(rocprofv3 PMC passes need their own profiler run; see profiles/README.md)",
                 "bytes_per_launch": spmv_bytes,
+                "bytes_note": "algorithmic bytes of a CSR SpMV with int32 indices: 12 nnz + 4 (rows+1) + 8 cols + 8 rows (SURVEY.md 8d)",
+                # what this matrix's index format makes the kernel move at least (x once): with offset codes the column
+                # index costs 1 byte instead of 4, so `achieved` can exceed what the same time buys in raw HBM bytes
+                "index_format": (f"offset codes: 1 byte per entry into {op.offset_codes()} diagonals" if op.offset_codes() > 0
+                                 else "int32 column indices"),
+                "stored_bytes_per_launch": op.stored_bytes(),
+                "stored_gbps": op.stored_bytes() / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0,
                 "ms_per_launch": spmv_ms,
                 "launches": int(prof["n_spmv"]),
                 # the launch that is timed also does w -= beta*v_prev and the <v, w> partials (Lanczos.h:139,142): two more

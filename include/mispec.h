@@ -116,6 +116,16 @@ int64_t mispec_csr_rows(const mispec_csr* A);       /* global row count (rows() 
 int64_t mispec_csr_cols(const mispec_csr* A);       /* global column count */
 int64_t mispec_csr_local_rows(const mispec_csr* A); /* rows held by this shard */
 int64_t mispec_csr_local_nnz(const mispec_csr* A);
+/* Index format the SpMV uses for this shard: 0 = plain int32 column indices (12 bytes per stored entry), d > 0 =
+ * offset codes, one byte per entry into a dictionary of d <= 256 distinct diagonals col - row (9 bytes per entry).
+ * Chosen at construction whenever the dictionary fits; MISPEC_SPMV_CODES=0 in the environment turns it off. */
+int mispec_csr_offset_codes(const mispec_csr* A);
+/* Per-matrix switch between the two index formats (both give bit-identical products); no effect when the matrix
+ * has no dictionary. */
+int mispec_csr_use_offset_codes(mispec_csr* A, int enable);
+/* Bytes one SpMV with this shard has to move, x counted once.  stored = 0: the CSR/int32 figure
+ * 12 nnz + 4 (rows+1) + 8 cols + 8 rows that roofline numbers are quoted on; stored != 0: with the index format in use. */
+double mispec_csr_spmv_bytes(const mispec_csr* A, int stored);
 /* A(i,j) of the stored (mirrored) matrix; 0 when absent.  Replaces operator()(i,j) (SparseSymMatProd.h:101-104).
  * Only rows of this shard can be queried. */
 int mispec_csr_coeff(const mispec_csr* A, int64_t i, int64_t j, double* out);

@@ -183,6 +183,17 @@ class _DeviceMatrix:
     def algorithmic_bytes(self):
         return 12.0 * self.nnz() + 4.0 * (self.local_rows() + 1) + 8.0 * self.cols() + 8.0 * self.local_rows()
 
+    def offset_codes(self):
+        """0: the SpMV reads int32 column indices; d > 0: one-byte codes into a dictionary of d diagonals."""
+        return int(lib().mispec_csr_offset_codes(self.h))
+
+    def use_offset_codes(self, enable=True):
+        check(lib().mispec_csr_use_offset_codes(self.h, 1 if enable else 0))
+
+    def stored_bytes(self):
+        """Compulsory SpMV traffic with the index format in use (9 instead of 12 bytes per entry with offset codes)."""
+        return float(lib().mispec_csr_spmv_bytes(self.h, 1))
+
     def to_host_csr(self):
         nl, nnz = self.local_rows(), self.nnz()
         rp = np.empty(nl + 1, dtype=np.int32)

@@ -13,7 +13,14 @@
 //   * blockIdx -> row-block map is XCD-aware: hardware sends block b to XCD b%8, so XCD k is
 //     given the k-th contiguous eighth of the rows and its private 4 MiB L2 sees one sliding
 //     window of x instead of eight interleaved ones.
-// Bound: HBM.  Algorithmic bytes per launch: 12*nnz + 4*(rows+1) + 8*cols + 8*rows.
+//   * offset-coded variant (CODES): when every stored entry lies on one of <= 256 distinct diagonals
+//     (banded / stencil matrices, all of BASELINE.json's configs) the matrix also keeps one byte per
+//     entry, col = global_row + dict[code], and the kernel streams 9 instead of 12 bytes per entry.
+//     The row of an entry is found through a byte table that the row-owning threads write into LDS
+//     while the streaming loads are in flight (it aliases the product buffer, which is not live yet);
+//     products and summation order are unchanged, so the result is bit-identical to the plain kernel.
+// Bound: HBM.  Algorithmic bytes per launch: 12*nnz + 4*(rows+1) + 8*cols + 8*rows (CSR with int32
+// indices); the offset-coded variant's compulsory traffic is 9*nnz + ... .
 #include "csr.hpp"
 
 #include <hip/hip_ext.h>
@@ -33,6 +40,18 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 constexpr int kLoadIters = 4;  // THREADS * 4 entries * 4 steps = 16 * THREADS >= cap + 3
 // products per LDS chunk for a THREADS-row workgroup: 256 -> (4080+4)*8 B + 32 B <= 32 KiB -> 5 workgroups / CU
 constexpr int chunk_cap(int threads) { return threads * 16 - 16; }
+// offset-coded variant: 1 KiB of the 32 KiB goes to the dictionary -> (3952+4)*8 + 1024 + 32 B, still 5 workgroups / CU
+constexpr int chunk_cap_codes(int threads) { return threads * 16 - 144; }
+constexpr int kMaxDict = 256;
+
+struct SpmvCodes
+{
+    const uint8_t* codes;
+    const int32_t* dict;
+    int ndict;
+    int col_max;       // n_cols - 1
+    int64_t row_begin; // global index of local row 0
+};
 
 __device__ __forceinline__ double wave_reduce_sum(double v)
 {
@@ -52,16 +71,17 @@ __device__ __forceinline__ double block_reduce_sum(double v, double* red)
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-template <bool EPI, bool NT, int kThreads>
+template <bool EPI, bool NT, int kThreads, bool CODES>
 __global__ __launch_bounds__(kThreads) void k_spmv_csr_stream(const int32_t* __restrict__ rowptr,
                                                                const int32_t* __restrict__ colind,
                                                                const double* __restrict__ val,
                                                                const double* __restrict__ x, double* __restrict__ y,
-                                                               int64_t nrows, int nblocks, SpmvEpilogue epi)
+                                                               int64_t nrows, int nblocks, SpmvEpilogue epi, SpmvCodes cd)
 {
-    constexpr int kCap = chunk_cap(kThreads);
+    constexpr int kCap = CODES ? chunk_cap_codes(kThreads) : chunk_cap(kThreads);
     __shared__ __attribute__((aligned(16))) double prod[kCap + 4];
     __shared__ double red[4];
+    __shared__ int dict_s[CODES ? kMaxDict : 1];
 
     // XCD-aware map: gridDim.x == 8 * per; block b runs on XCD b % 8 and takes the (b/8)-th
     // row-block of that XCD's contiguous range.
@@ -84,6 +104,10 @@ __global__ __launch_bounds__(kThreads) void k_spmv_csr_stream(const int32_t* __r
         re = rowptr[row0 + tid + 1];
     }
 
+    if (CODES && tid < cd.ndict)
+        dict_s[tid] = cd.dict[tid];  // visible after the first barrier of the chunk loop
+    const uint32_t grow0 = uint32_t(cd.row_begin + row0);
+
     double acc = 0.0;
     for (int cs = bs; cs < be;)
     {
@@ -105,16 +129,58 @@ __global__ __launch_bounds__(kThreads) void k_spmv_csr_stream(const int32_t* __r
             {
                 const v2d a01 = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(val + base));
                 const v2d a23 = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(val + base + 2));
-                const v4i c4 = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(colind + base));
                 va[it][0] = make_double2(a01.x, a01.y);
                 va[it][1] = make_double2(a23.x, a23.y);
-                ci[it] = make_int4(c4.x, c4.y, c4.z, c4.w);
+                if (CODES)
+                    ci[it].x = int(__builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(cd.codes + base)));
+                else
+                {
+                    const v4i c4 = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(colind + base));
+                    ci[it] = make_int4(c4.x, c4.y, c4.z, c4.w);
+                }
             }
             else
             {
                 va[it][0] = *reinterpret_cast<const double2*>(val + base);
                 va[it][1] = *reinterpret_cast<const double2*>(val + base + 2);
-                ci[it] = *reinterpret_cast<const int4*>(colind + base);
+                if (CODES)
+                    ci[it].x = int(*reinterpret_cast<const uint32_t*>(cd.codes + base));
+                else
+                    ci[it] = *reinterpret_cast<const int4*>(colind + base);
+            }
+        }
+        if (CODES)
+        {
+            // Row table: thread r stamps r on the entries of row r inside this chunk.  The table lives in the
+            // product buffer, which nobody reads or writes until the second barrier below.
+            uint8_t* rowid = reinterpret_cast<uint8_t*>(prod);
+            const int flo = max(rs, cs), fhi = min(re, ce);
+            for (int k = flo; k < fhi; k++)
+                rowid[k - a0] = uint8_t(tid);
+            __syncthreads();
+            uint32_t rid[kLoadIters];
+#pragma unroll
+            for (int it = 0; it < kLoadIters; it++)
+            {
+                const int base = min(a0 + tid * 4 + it * (kThreads * 4), last);
+                rid[it] = *reinterpret_cast<const uint32_t*>(rowid + (base - a0));
+            }
+            __syncthreads();
+            // col = global row + dict[code]; entries outside [cs, ce) (alignment lead-in, padding) carry
+            // stale row ids: clamp so the gather stays inside x — their products are never summed.
+#pragma unroll
+            for (int it = 0; it < kLoadIters; it++)
+            {
+                const uint32_t c4 = uint32_t(ci[it].x);
+                const uint32_t r4 = rid[it];
+                const int c0 = int(grow0 + (r4 & 255u) + uint32_t(dict_s[c4 & 255u]));
+                const int c1 = int(grow0 + ((r4 >> 8) & 255u) + uint32_t(dict_s[(c4 >> 8) & 255u]));
+                const int c2 = int(grow0 + ((r4 >> 16) & 255u) + uint32_t(dict_s[(c4 >> 16) & 255u]));
+                const int c3 = int(grow0 + (r4 >> 24) + uint32_t(dict_s[c4 >> 24]));
+                ci[it].x = min(max(c0, 0), cd.col_max);
+                ci[it].y = min(max(c1, 0), cd.col_max);
+                ci[it].z = min(max(c2, 0), cd.col_max);
+                ci[it].w = min(max(c3, 0), cd.col_max);
             }
         }
         // phase 2: gather x
@@ -216,7 +282,7 @@ __host__ __device__ inline int64_t band_prefix(const BandSpec& s, int64_t n, int
 
 __global__ void k_synth_band(BandSpec spec, int64_t n, int64_t row_begin, int64_t nloc, int64_t base_nnz, uint64_t seed,
                              int symmetric, int32_t* __restrict__ rowptr, int32_t* __restrict__ colind,
-                             double* __restrict__ val)
+                             double* __restrict__ val, uint8_t* __restrict__ codes)
 {
     const int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (r > nloc)
@@ -235,6 +301,8 @@ __global__ void k_synth_band(BandSpec spec, int64_t n, int64_t row_begin, int64_
         const uint64_t b = symmetric ? uint64_t(i < j ? j : i) : uint64_t(j);
         colind[p] = int32_t(j);
         val[p] = synth_value(seed, a, b);
+        if (codes)
+            codes[p] = uint8_t(k);  // dictionary = the offset list itself
         p++;
     }
 }
@@ -248,6 +316,52 @@ void alloc_entries(mispec_csr& A, int64_t nnz)
     MISPEC_HIP(hipMemsetAsync(A.colind.p, 0, cap * sizeof(int32_t), A.ctx->stream));
     MISPEC_HIP(hipMemsetAsync(A.val.p, 0, cap * sizeof(double), A.ctx->stream));
     A.nnz = nnz;
+}
+
+void alloc_codes(mispec_csr& A)
+{
+    const size_t cap = size_t(round_up(A.nnz, 4) + 8);
+    A.codes.alloc(cap);
+    MISPEC_HIP(hipMemsetAsync(A.codes.p, 0, cap, A.ctx->stream));
+}
+
+// Host side of the offset-coded format: one byte per entry of rows [b, e) if the shard's entries lie on at most
+// kMaxDict distinct diagonals (col - global row), nothing otherwise.
+bool build_offset_codes(int64_t b, int64_t e, const int32_t* rowptr, const int32_t* colind, std::vector<int32_t>& dict,
+                        std::vector<uint8_t>& codes)
+{
+    constexpr int kSlots = 1024;  // open addressing, <= 25 % full
+    int64_t key[kSlots];
+    int code_of[kSlots];
+    std::fill(key, key + kSlots, INT64_MIN);
+    dict.clear();
+    codes.resize(size_t(rowptr[e] - rowptr[b]));
+    const int64_t p0 = rowptr[b];
+    int64_t last_d = INT64_MIN;
+    int last_code = 0;
+    for (int64_t i = b; i < e; i++)
+        for (int64_t p = rowptr[i]; p < rowptr[i + 1]; p++)
+        {
+            const int64_t d = int64_t(colind[p]) - i;
+            if (d != last_d)
+            {
+                unsigned h = unsigned(uint64_t(d) * 0x9E3779B97F4A7C15ULL >> 54) & (kSlots - 1);
+                while (key[h] != INT64_MIN && key[h] != d)
+                    h = (h + 1) & (kSlots - 1);
+                if (key[h] == INT64_MIN)
+                {
+                    if (int(dict.size()) == kMaxDict)
+                        return false;
+                    key[h] = d;
+                    code_of[h] = int(dict.size());
+                    dict.push_back(int32_t(d));
+                }
+                last_d = d;
+                last_code = code_of[h];
+            }
+            codes[size_t(p - p0)] = uint8_t(last_code);
+        }
+    return !dict.empty();
 }
 
 // Upload host CSR rows [begin,end) of a global matrix.
@@ -288,6 +402,16 @@ mispec_csr* upload_rows(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const i
                                       ctx->stream));
             MISPEC_HIP(hipMemcpyAsync(A->val.p, val + p0, size_t(p1 - p0) * sizeof(double), hipMemcpyHostToDevice,
                                       ctx->stream));
+        }
+        std::vector<int32_t> dict;
+        std::vector<uint8_t> codes;
+        if (p1 > p0 && spmv_codes_enabled() && build_offset_codes(b, e, rowptr, colind, dict, codes))
+        {
+            alloc_codes(*A);
+            A->dict.alloc(dict.size());
+            MISPEC_HIP(hipMemcpyAsync(A->codes.p, codes.data(), codes.size(), hipMemcpyHostToDevice, ctx->stream));
+            MISPEC_HIP(hipMemcpyAsync(A->dict.p, dict.data(), dict.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+            A->ndict = int(dict.size());
         }
         MISPEC_HIP(hipStreamSynchronize(ctx->stream));
     }
@@ -332,6 +456,12 @@ __global__ __launch_bounds__(256) void k_col_ranges(const int32_t* __restrict__ 
 
 namespace mispec {
 
+bool spmv_codes_enabled()
+{
+    static const bool on = getenv("MISPEC_SPMV_CODES") ? atoi(getenv("MISPEC_SPMV_CODES")) != 0 : true;
+    return on;
+}
+
 int spmv_rows_per_block()
 {
     static const int rows = (getenv("MISPEC_SPMV_ROWS") && atoi(getenv("MISPEC_SPMV_ROWS")) == 128) ? 128 : 256;
@@ -350,6 +480,8 @@ void launch_spmv(const mispec_csr& A, const double* x_dev, double* y_dev, const 
     const dim3 grid(unsigned(per * 8)), block(static_cast<unsigned>(threads));
     static const bool nt = getenv("MISPEC_SPMV_NT") ? atoi(getenv("MISPEC_SPMV_NT")) != 0 : false;
     const SpmvEpilogue e = epi ? *epi : SpmvEpilogue{};
+    const bool coded = A.ndict > 0 && A.use_codes && threads == 256 && spmv_codes_enabled();
+    const SpmvCodes cd{A.codes.p, A.dict.p, A.ndict, int(A.n_cols - 1), A.row_begin};
     // With an event pair the launch is timed through the dispatch's own completion signal (start/stop of the
     // kernel itself, as a profiler sees it) instead of marker packets around it.
 #define MISPEC_SPMV_LAUNCH(K)                                                                                          \
@@ -357,18 +489,20 @@ void launch_spmv(const mispec_csr& A, const double* x_dev, double* y_dev, const 
     {                                                                                                                  \
         if (ev_start && ev_stop)                                                                                       \
             hipExtLaunchKernelGGL((K), grid, block, 0, A.ctx->stream, ev_start, ev_stop, 0, A.rowptr.p, A.colind.p,   \
-                                  A.val.p, x_dev, y_dev, nloc, nblocks, e);                                           \
+                                  A.val.p, x_dev, y_dev, nloc, nblocks, e, cd);                                       \
         else                                                                                                           \
             hipLaunchKernelGGL((K), grid, block, 0, A.ctx->stream, A.rowptr.p, A.colind.p, A.val.p, x_dev, y_dev,    \
-                               nloc, nblocks, e);                                                                      \
+                               nloc, nblocks, e, cd);                                                                  \
     } while (0)
 #define MISPEC_SPMV(E, N)                                          \
     do                                                             \
     {                                                              \
-        if (threads == 128)                                        \
-            MISPEC_SPMV_LAUNCH((k_spmv_csr_stream<E, N, 128>));    \
-        else                                                       \
-            MISPEC_SPMV_LAUNCH((k_spmv_csr_stream<E, N, 256>));    \
+        if (coded)                                                        \
+            MISPEC_SPMV_LAUNCH((k_spmv_csr_stream<E, N, 256, true>));     \
+        else if (threads == 128)                                          \
+            MISPEC_SPMV_LAUNCH((k_spmv_csr_stream<E, N, 128, false>));    \
+        else                                                              \
+            MISPEC_SPMV_LAUNCH((k_spmv_csr_stream<E, N, 256, false>));    \
     } while (0)
     if (epi && nt)
         MISPEC_SPMV(true, true);
@@ -558,10 +692,19 @@ extern "C" int mispec_csr_synth_band(mispec_ctx* ctx, int64_t n, uint64_t seed, 
             const int64_t base = band_prefix(spec, n, b);
             alloc_entries(*A, band_prefix(spec, n, e) - base);
             A->rowptr.alloc(size_t(nloc) + 1);
+            if (spmv_codes_enabled() && A->nnz > 0)
+            {
+                alloc_codes(*A);
+                std::vector<int32_t> dict(offs.begin(), offs.end());
+                A->dict.alloc(dict.size());
+                MISPEC_HIP(hipMemcpyAsync(A->dict.p, dict.data(), dict.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+                MISPEC_HIP(hipStreamSynchronize(ctx->stream));  // dict is a local
+                A->ndict = int(dict.size());
+            }
             const int threads = 256;
             const unsigned blocks = unsigned((nloc + 1 + threads - 1) / threads);
             hipLaunchKernelGGL(k_synth_band, dim3(blocks), dim3(threads), 0, ctx->stream, spec, n, b, nloc, base, seed,
-                               symmetric, A->rowptr.p, A->colind.p, A->val.p);
+                               symmetric, A->rowptr.p, A->colind.p, A->val.p, A->codes.p);
             MISPEC_HIP(hipGetLastError());
             MISPEC_HIP(hipStreamSynchronize(ctx->stream));
         }
@@ -588,6 +731,23 @@ extern "C" int64_t mispec_csr_rows(const mispec_csr* A) { return A ? A->n_rows :
 extern "C" int64_t mispec_csr_cols(const mispec_csr* A) { return A ? A->n_cols : 0; }
 extern "C" int64_t mispec_csr_local_rows(const mispec_csr* A) { return A ? A->local_rows() : 0; }
 extern "C" int64_t mispec_csr_local_nnz(const mispec_csr* A) { return A ? A->nnz : 0; }
+extern "C" int mispec_csr_offset_codes(const mispec_csr* A)
+{
+    return A && A->use_codes && spmv_codes_enabled() && spmv_rows_per_block() == 256 ? A->ndict : 0;
+}
+extern "C" int mispec_csr_use_offset_codes(mispec_csr* A, int enable)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(A, "mispec_csr_use_offset_codes: NULL argument");
+        A->use_codes = enable != 0;
+    });
+}
+extern "C" double mispec_csr_spmv_bytes(const mispec_csr* A, int stored)
+{
+    if (!A)
+        return 0.0;
+    return stored && mispec_csr_offset_codes(A) > 0 ? A->stored_bytes() : A->algorithmic_bytes();
+}
 
 extern "C" int mispec_csr_coeff(const mispec_csr* A, int64_t i, int64_t j, double* out)
 {

@@ -15,6 +15,13 @@ struct mispec_csr
     mispec::DevBuf<int32_t> rowptr;  // local_rows + 1, offsets into colind/val (start at 0)
     mispec::DevBuf<int32_t> colind;  // nnz rounded up to 4, +8 slack, padded with column 0 / value 0
     mispec::DevBuf<double> val;
+    // Offset-coded column indices (optional second index format, used by the SpMV when present): matrices whose
+    // entries lie on at most 256 distinct diagonals (banded / stencil matrices) keep one byte per entry,
+    // col = global_row + dict[code]; 9 instead of 12 bytes of HBM traffic per stored entry.  ndict == 0: absent.
+    mispec::DevBuf<uint8_t> codes;   // same padding as colind, padded with code 0
+    mispec::DevBuf<int32_t> dict;    // ndict distinct (col - global_row) values
+    int ndict = 0;
+    bool use_codes = true;           // mispec_csr_use_offset_codes: per-matrix switch (tests compare the two kernels)
     // staging for the host-pointer paths (allocated on first use)
     mutable mispec::DevBuf<double> stage_x, stage_y;
 
@@ -23,6 +30,12 @@ struct mispec_csr
     double algorithmic_bytes() const
     {
         return 12.0 * double(nnz) + 4.0 * double(local_rows() + 1) + 8.0 * double(n_cols) + 8.0 * double(local_rows());
+    }
+    // what the SpMV actually has to move with the index format in use (compulsory traffic, x counted once)
+    double stored_bytes() const
+    {
+        const double per_entry = ndict > 0 ? 9.0 : 12.0;
+        return per_entry * double(nnz) + 4.0 * double(local_rows() + 1) + 8.0 * double(n_cols) + 8.0 * double(local_rows());
     }
 };
 
@@ -39,6 +52,9 @@ struct SpmvEpilogue
     const int* status = nullptr;      // if set, the launch is a no-op unless *status == 0
     double* partials = nullptr;       // one double per block, deterministic second stage elsewhere
 };
+
+// MISPEC_SPMV_CODES=0 turns the offset-coded index format off (plain int32 column indices everywhere).
+bool spmv_codes_enabled();
 
 // Rows per SpMV workgroup (one thread per row in the reduction phase): 256, or 128 with MISPEC_SPMV_ROWS=128.
 int spmv_rows_per_block();

@@ -143,3 +143,94 @@ def test_spmv_linearity_at_full_size(ctx):
             if 0 <= j < n:
                 acc += O.lib().oracle_synth_value(sa.SYNTH_SEED, min(i, j), max(i, j)) * xh[j]
         assert Axh[i] == acc
+
+
+# ---- offset-coded index format (one byte per entry, col = row + dict[code]) -------------------------------------
+def _both_formats(op, x):
+    """Product with the offset-coded kernel and with the plain int32 kernel of the same matrix."""
+    assert op.offset_codes() > 0
+    y_codes = op.perform_op(x)
+    op.use_offset_codes(False)
+    assert op.offset_codes() == 0
+    y_plain = op.perform_op(x)
+    op.use_offset_codes(True)
+    return y_codes, y_plain
+
+
+def test_offset_codes_are_chosen_for_diagonal_structure_only(ctx):
+    n = 5000
+    band = sa.SparseSymMatProd.synth_band(n, offsets=(1, 2, 50), ctx=ctx)
+    assert band.offset_codes() == 7 and band.stored_bytes() < band.algorithmic_bytes()
+    A, _ = sparse_fixture(1000, 0.01)  # ~ 2000 distinct diagonals: stays on int32 indices
+    op = sa.SparseSymMatProd(A, ctx=ctx)
+    assert op.offset_codes() == 0 and op.stored_bytes() == op.algorithmic_bytes()
+
+
+@pytest.mark.parametrize("n", [3, 255, 256, 257, 1000, 4097, 300000])
+def test_offset_coded_kernel_is_bit_identical_on_band_matrices(ctx, n):
+    offs = tuple(o for o in (1, 2, 3, 1000, 1001, 100000, 100001) if o < n)
+    op = sa.SparseSymMatProd.synth_band(n, offsets=offs, ctx=ctx)
+    x = rand_x(n, 3)
+    y_codes, y_plain = _both_formats(op, x)
+    assert np.array_equal(y_codes, y_plain)
+    if n <= 5000:
+        rp, ci, v = O.synth_band_csr(n, offsets=offs)
+        assert np.array_equal(y_codes, O.Op.csr(n, n, rp, ci, v).perform_op(x))
+
+
+def test_offset_codes_from_host_uploads(ctx):
+    # banded matrices that arrive through the reference-compatible constructors (CSC lower triangle, general CSR / CSC)
+    n = 3001
+    rng = np.random.default_rng(5)
+    diags = [rng.uniform(-1, 1, n - abs(k)) for k in (0, 1, 4, 77)]
+    L = sp.diags(diags, [0, -1, -4, -77], format="csc")
+    S = (L + sp.tril(L, -1).T).tocsr()
+    S.sort_indices()
+    x = rand_x(n, 4)
+    ref = O.Op.csr(n, n, S.indptr, S.indices, S.data).perform_op(x)
+    op = sa.SparseSymMatProd(L, ctx=ctx)
+    assert op.offset_codes() == 7
+    y_codes, y_plain = _both_formats(op, x)
+    assert np.array_equal(y_codes, ref) and np.array_equal(y_plain, ref)
+    # rows with holes (entries removed at random keep the diagonal dictionary but make the rows ragged)
+    G = sp.diags([rng.uniform(-1, 1, n - abs(k)) for k in (-300, -2, 0, 1, 9)], [-300, -2, 0, 1, 9], format="coo")
+    keep = rng.uniform(size=G.nnz) < 0.6
+    G = sp.coo_matrix((G.data[keep], (G.row[keep], G.col[keep])), shape=(n, n))
+    for fmt in ("csr", "csc"):
+        M = G.asformat(fmt)
+        M.sort_indices()
+        gop = sa.SparseGenMatProd(M, ctx=ctx)
+        assert 0 < gop.offset_codes() <= 5
+        Mr = M.tocsr()
+        Mr.sort_indices()
+        yc, yp = _both_formats(gop, x)
+        assert np.array_equal(yc, yp)
+        assert np.array_equal(yc, O.Op.csr(n, n, Mr.indptr, Mr.indices, Mr.data).perform_op(x))
+
+
+def test_offset_codes_with_rows_longer_than_the_lds_chunk_and_rectangular_shapes(ctx):
+    # dense 120 x 120 stored as sparse: 239 diagonals, 14400 entries in one row block -> several LDS chunks
+    rng = np.random.default_rng(8)
+    D = sp.csr_matrix(rng.uniform(-1, 1, (120, 120)))
+    op = sa.SparseGenMatProd(D, ctx=ctx)
+    assert op.offset_codes() == 239
+    x = rand_x(120, 6)
+    yc, yp = _both_formats(op, x)
+    assert np.array_equal(yc, yp) and np.array_equal(yc, O.Op.csr(120, 120, D.indptr, D.indices, D.data).perform_op(x))
+    # 129 x 129 dense has 257 diagonals: one more than the dictionary holds
+    assert sa.SparseGenMatProd(sp.csr_matrix(rng.uniform(-1, 1, (129, 129))), ctx=ctx).offset_codes() == 0
+    # rectangular band (the SVD operators): 700 x 2000 and its transpose
+    R = sp.diags([rng.uniform(-1, 1, 700)] * 4, [0, 3, 650, 1299], shape=(700, 2000), format="csr")
+    R.sort_indices()
+    rop = sa.SparseGenMatProd(R, ctx=ctx)
+    assert rop.offset_codes() == 4
+    xr = rand_x(2000, 7)
+    yc, yp = _both_formats(rop, xr)
+    assert np.array_equal(yc, yp) and np.array_equal(yc, O.Op.csr(700, 2000, R.indptr, R.indices, R.data).perform_op(xr))
+    Rt = R.T.tocsr()
+    Rt.sort_indices()
+    top = sa.SparseGenMatProd(Rt, ctx=ctx)
+    assert top.offset_codes() == 4
+    xt = rand_x(700, 8)
+    yc, yp = _both_formats(top, xt)
+    assert np.array_equal(yc, yp) and np.array_equal(yc, O.Op.csr(2000, 700, Rt.indptr, Rt.indices, Rt.data).perform_op(xt))
