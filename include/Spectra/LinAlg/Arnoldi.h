@@ -71,6 +71,23 @@ struct has_device_geigs_shift : std::false_type
 template <typename T>
 struct has_device_geigs_shift<T, void_t<decltype(std::declval<const T&>().mispec_geigs_shift_solver())>> : std::true_type
 {};
+// dense matrix in HBM (DenseSymMatProd / DenseGenMatProd)
+template <typename T, typename = void>
+struct has_device_dense : std::false_type
+{};
+template <typename T>
+struct has_device_dense<T, void_t<decltype(std::declval<const T&>().mispec_dense_matrix())>> : std::true_type
+{};
+// user operator that works on device pointers:
+//   void perform_op_device(const Scalar* x_dev, Scalar* y_dev, void* hip_stream) const
+template <typename T, typename = void>
+struct has_device_perform_op : std::false_type
+{};
+template <typename T>
+struct has_device_perform_op<T, void_t<decltype(std::declval<const T&>().perform_op_device(
+                                    static_cast<const double*>(nullptr), static_cast<double*>(nullptr), static_cast<void*>(nullptr)))>>
+    : std::true_type
+{};
 template <typename T, typename = void>
 struct has_device_context : std::false_type
 {};
@@ -121,6 +138,39 @@ protected:
         }
     }
 
+    // perform_op_device of a user operator: device pointers, work enqueued on the factorisation's stream
+    static int call_user_device_op(void* user, const double* x_dev, double* y_dev, void* hip_stream)
+    {
+        try
+        {
+            static_cast<const OpType*>(user)->perform_op_device(x_dev, y_dev, hip_stream);
+            return 0;
+        }
+        catch (...)
+        {
+            return 1;
+        }
+    }
+
+    template <typename T = OpType>
+    typename std::enable_if<internal::has_device_dense<T>::value>::type bind(bool symmetric)
+    {
+        m_ctx = internal::borrow_context(m_op.mispec_context());
+        mispec_fac* raw = nullptr;
+        internal::check(mispec_fac_create_dense(m_ctx.get(), m_op.mispec_dense_matrix(), static_cast<int>(m_m), symmetric ? 1 : 0, &raw));
+        m_fac = std::shared_ptr<mispec_fac>(raw, [](mispec_fac* p) { (void) mispec_fac_destroy(p); });
+    }
+    template <typename T = OpType>
+    typename std::enable_if<internal::has_device_perform_op<T>::value && !internal::has_device_dense<T>::value &&
+                            !internal::has_device_matrix<T>::value && !internal::has_device_solver<T>::value>::type
+    bind(bool symmetric)
+    {
+        m_ctx = internal::context_of(m_op);
+        mispec_fac* raw = nullptr;
+        internal::check(mispec_fac_create_device_op(m_ctx.get(), &Arnoldi::call_user_device_op, const_cast<OpType*>(&m_op), m_n,
+                                                    static_cast<int>(m_m), symmetric ? 1 : 0, &raw));
+        m_fac = std::shared_ptr<mispec_fac>(raw, [](mispec_fac* p) { (void) mispec_fac_destroy(p); });
+    }
     template <typename T = OpType>
     typename std::enable_if<internal::has_device_matrix<T>::value>::type bind(bool symmetric)
     {
@@ -191,7 +241,8 @@ protected:
     template <typename T = OpType>
     typename std::enable_if<!internal::has_device_matrix<T>::value && !internal::has_device_solver<T>::value &&
                             !internal::has_device_product<T>::value && !internal::has_device_geigs<T>::value &&
-                            !internal::has_device_geigs_shift<T>::value && !internal::has_device_geigs_cholesky<T>::value>::type
+                            !internal::has_device_geigs_shift<T>::value && !internal::has_device_geigs_cholesky<T>::value &&
+                            !internal::has_device_dense<T>::value && !internal::has_device_perform_op<T>::value>::type
     bind(bool symmetric)
     {
         m_ctx = internal::context_of(m_op);

@@ -107,6 +107,22 @@ struct SparseView
     bool row_major = false;
 };
 
+// A borrowed view of a dense matrix in host memory: rows x cols with leading dimension ld, column-major
+// (Eigen's default) unless row_major.
+template <typename Scalar>
+struct DenseView
+{
+    Index rows = 0, cols = 0;
+    const Scalar* data = nullptr;
+    Index ld = 0;
+    bool row_major = false;
+
+    DenseView() {}
+    DenseView(Index r, Index c, const Scalar* d, Index ld_, bool rm = false) : rows(r), cols(c), data(d), ld(ld_), row_major(rm) {}
+    // the stand-in matrix type (column-major, contiguous)
+    DenseView(const internal::PlainMatrix<Scalar>& m) : rows(m.rows()), cols(m.cols()), data(m.data()), ld(m.rows()), row_major(false) {}
+};
+
 }  // namespace Spectra
 
 #endif

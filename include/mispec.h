@@ -185,6 +185,36 @@ typedef int (*mispec_op_fn)(void* user, const double* x_in_host, double* y_out_h
  * symmetric=0: Arnoldi (Arnoldi.h). */
 int mispec_fac_create(mispec_ctx* ctx, const mispec_csr* A, mispec_op_fn op, void* op_user, int64_t n, int ncv,
                       int symmetric, mispec_fac** out);
+/* User operator on DEVICE pointers: y_dev = Op(x_dev) for n doubles each, enqueued on hip_stream (a hipStream_t; the
+ * factorisation's own stream — do not synchronise it).  No staging: the Krylov vectors never leave HBM.  This is the
+ * perform_op contract of the reference (SymEigsSolver.h:43-51) with the two pointers in device memory; x_dev may be a
+ * column of V and must not be written.  Must return 0 on success. */
+typedef int (*mispec_device_op_fn)(void* user, const double* x_dev, double* y_dev, void* hip_stream);
+int mispec_fac_create_device_op(mispec_ctx* ctx, mispec_device_op_fn op, void* op_user, int64_t n, int ncv, int symmetric,
+                                mispec_fac** out);
+
+/* ---------------------------------------------------------------------------
+ * Dense operators — replace MatOp/DenseSymMatProd.h:28-105 and MatOp/DenseGenMatProd.h:27-102
+ * (y = mat.selfadjointView<Uplo>() * x and y = mat * x).  The matrix is copied to HBM once, row-major.
+ * uplo = 'L' / 'U': symmetric, only that triangle of the input is read (and mirrored); 0: general.
+ * data_host is rows x cols with leading dimension ld_host, column-major unless row_major != 0.
+ * ------------------------------------------------------------------------- */
+typedef struct mispec_dense mispec_dense;
+int mispec_dense_upload(mispec_ctx* ctx, int64_t rows, int64_t cols, const double* data_host, int64_t ld_host, int row_major,
+                        char uplo, mispec_dense** out);
+int mispec_dense_destroy(mispec_dense* D);
+int64_t mispec_dense_rows(const mispec_dense* D);
+int64_t mispec_dense_cols(const mispec_dense* D);
+int mispec_dense_gemv(const mispec_dense* D, const double* x_dev, double* y_dev);        /* device pointers */
+int mispec_dense_gemv_host(const mispec_dense* D, const double* x_host, double* y_host); /* literal perform_op */
+/* Y = D X for a host block of k columns (operator*, DenseSymMatProd.h:93-96) and D(i,j) (operator(), :101-104) */
+int mispec_dense_gemm_host(const mispec_dense* D, const double* X_host, int64_t ldx, int k, double* Y_host, int64_t ldy);
+int mispec_dense_coeff(const mispec_dense* D, int64_t i, int64_t j, double* out);
+/* average ms of `reps` back-to-back GEMV launches (benchmark helper, like mispec_spmv_time) */
+int mispec_dense_gemv_time(const mispec_dense* D, const double* x_dev, double* y_dev, int reps, float* ms_per_launch);
+/* Factorisation whose operator is the dense matrix (must be square). */
+int mispec_fac_create_dense(mispec_ctx* ctx, const mispec_dense* D, int ncv, int symmetric, mispec_fac** out);
+
 /* The same with the operator (A - sigma I)^{-1} of a device-resident shift solver (SymEigsShiftSolver path). */
 /* ---------------------------------------------------------------------------
  * Generalized symmetric problem A x = lambda B x, regular-inverse mode
@@ -310,6 +340,11 @@ typedef struct mispec_symeigs mispec_symeigs;
 int mispec_symeigs_create(mispec_ctx* ctx, const mispec_csr* A, int64_t nev, int64_t ncv, mispec_symeigs** out);
 int mispec_symeigs_create_op(mispec_ctx* ctx, mispec_op_fn op, void* op_user, int64_t n, int64_t nev, int64_t ncv,
                              mispec_symeigs** out);
+/* The same for a dense matrix in HBM (SymEigsSolver<DenseSymMatProd<double>>) and for a user operator on device
+ * pointers (see mispec_device_op_fn). */
+int mispec_symeigs_create_dense(mispec_ctx* ctx, const mispec_dense* D, int64_t nev, int64_t ncv, mispec_symeigs** out);
+int mispec_symeigs_create_device_op(mispec_ctx* ctx, mispec_device_op_fn op, void* op_user, int64_t n, int64_t nev, int64_t ncv,
+                                    mispec_symeigs** out);
 /* Spectra::SymEigsShiftSolver<Spectra::SparseSymShiftSolve<double>> (SymEigsShiftSolver.h:190-195): calls
  * set_shift(sigma) on S, iterates on (A - sigma I)^{-1} and maps the Ritz values back (lambda = 1/nu + sigma). */
 /* SymGEigsSolver<SparseSymMatProd, SparseRegularInverse, GEigsMode::RegularInverse>. */
@@ -351,6 +386,10 @@ typedef struct mispec_geneigs mispec_geneigs;
 int mispec_geneigs_create(mispec_ctx* ctx, const mispec_csr* A, int64_t nev, int64_t ncv, mispec_geneigs** out);
 int mispec_geneigs_create_op(mispec_ctx* ctx, mispec_op_fn op, void* op_user, int64_t n, int64_t nev, int64_t ncv,
                              mispec_geneigs** out);
+/* GenEigsSolver<DenseGenMatProd<double>> / a user operator on device pointers */
+int mispec_geneigs_create_dense(mispec_ctx* ctx, const mispec_dense* D, int64_t nev, int64_t ncv, mispec_geneigs** out);
+int mispec_geneigs_create_device_op(mispec_ctx* ctx, mispec_device_op_fn op, void* op_user, int64_t n, int64_t nev, int64_t ncv,
+                                    mispec_geneigs** out);
 /* GenEigsRealShiftSolver<SparseGenRealShiftSolve> (GenEigsRealShiftSolver.h:36-82): Arnoldi on (A - sigma I)^{-1},
  * eigenvalues mapped back by lambda = 1/nu + sigma.  Calls set_shift(sigma) on S. */
 int mispec_geneigs_create_shift(mispec_ctx* ctx, mispec_symshift* S, int64_t nev, int64_t ncv, double sigma, mispec_geneigs** out);

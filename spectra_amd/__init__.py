@@ -307,6 +307,120 @@ class SparseSymShiftSolve:
             pass
 
 
+class _DenseMatrix:
+    """A dense matrix in HBM (mispec_dense), row-major there."""
+
+    def __init__(self, mat, uplo, ctx):
+        self.ctx = ctx or default_context()
+        M = np.asarray(mat, dtype=np.float64)
+        if M.ndim != 2:
+            raise ValueError("dense operator: a 2-d array is expected")
+        row_major = M.flags.c_contiguous and not M.flags.f_contiguous
+        if not (M.flags.c_contiguous or M.flags.f_contiguous):
+            M = np.asfortranarray(M)
+        ld = M.shape[1] if row_major else M.shape[0]
+        h = C.c_void_p()
+        check(lib().mispec_dense_upload(self.ctx.h, M.shape[0], M.shape[1], _dp(M), max(int(ld), 1), int(row_major),
+                                        uplo.encode()[0:1] if uplo else b"\0", C.byref(h)))
+        self.h = h
+
+    def rows(self):
+        return lib().mispec_dense_rows(self.h)
+
+    def cols(self):
+        return lib().mispec_dense_cols(self.h)
+
+    def local_rows(self):
+        return self.rows()
+
+    def perform_op(self, x_in, y_out=None):
+        """y_out = A * x_in with HOST arrays (the reference's perform_op contract)."""
+        x = _f64(x_in)
+        if x.shape != (self.cols(),):
+            raise ValueError("perform_op: x_in must have cols() entries")
+        y = np.empty(self.rows()) if y_out is None else y_out
+        check(lib().mispec_dense_gemv_host(self.h, _dp(x), _dp(y)))
+        return y
+
+    def __matmul__(self, X):
+        X = np.asarray(X, dtype=np.float64)
+        if X.ndim == 1:
+            return self.perform_op(X)
+        Xf = np.asfortranarray(X)
+        Y = np.empty((self.rows(), X.shape[1]), order="F")
+        check(lib().mispec_dense_gemm_host(self.h, _dp(Xf), Xf.shape[0], X.shape[1], _dp(Y), Y.shape[0]))
+        return Y
+
+    def __call__(self, i, j):
+        v = C.c_double()
+        check(lib().mispec_dense_coeff(self.h, int(i), int(j), C.byref(v)))
+        return v.value
+
+    def gemv_device(self, x_ptr, y_ptr):
+        check(lib().mispec_dense_gemv(self.h, C.c_void_p(x_ptr), C.c_void_p(y_ptr)))
+
+    def gemv_time(self, x_ptr, y_ptr, reps):
+        ms = C.c_float()
+        check(lib().mispec_dense_gemv_time(self.h, C.c_void_p(x_ptr), C.c_void_p(y_ptr), reps, C.byref(ms)))
+        return ms.value
+
+    def algorithmic_bytes(self):
+        return 8.0 * self.rows() * self.cols() + 8.0 * self.cols() + 8.0 * self.rows()
+
+    def __del__(self):
+        try:
+            lib().mispec_dense_destroy(self.h)
+        except Exception:
+            pass
+
+
+class DenseSymMatProd(_DenseMatrix):
+    """MatOp/DenseSymMatProd.h: y = A x for a symmetric dense A, reading only the `uplo` triangle of the input."""
+
+    def __init__(self, mat, uplo="L", ctx=None):
+        M = np.asarray(mat)
+        if M.ndim != 2 or M.shape[0] != M.shape[1]:
+            raise ValueError("DenseSymMatProd: matrix must be square")
+        if uplo not in ("L", "U"):
+            raise ValueError("DenseSymMatProd: uplo must be 'L' or 'U'")
+        super().__init__(mat, uplo, ctx)
+
+
+class DenseGenMatProd(_DenseMatrix):
+    """MatOp/DenseGenMatProd.h: y = A x for a general dense A."""
+
+    def __init__(self, mat, ctx=None):
+        super().__init__(mat, None, ctx)
+
+
+class DeviceOp:
+    """A user operator on DEVICE pointers: fn(x_ptr, y_ptr, stream) must enqueue y = Op(x) (n doubles each) on the
+    given HIP stream.  The perform_op concept of the reference with both vectors in HBM: nothing is staged."""
+
+    def __init__(self, n, fn, ctx=None):
+        self.ctx = ctx or default_context()
+        self.n = int(n)
+        self.fn = fn
+
+        def tramp(user, x_ptr, y_ptr, stream):
+            try:
+                fn(int(x_ptr or 0), int(y_ptr or 0), int(stream or 0))
+                return 0
+            except Exception:  # noqa: BLE001 - reported through the return code
+                return 1
+
+        self.cb = _capi.device_op_fn(tramp)
+
+    def rows(self):
+        return self.n
+
+    def cols(self):
+        return self.n
+
+    def local_rows(self):
+        return self.n
+
+
 class _UserOp:
     """Adapter for a Python operator with rows(), cols(), perform_op(x_in) -> y (host numpy arrays)."""
 
@@ -564,6 +678,14 @@ class SymEigsSolver:
             self.ctx = op.ctx
             check(lib().mispec_symeigs_create_product(self.ctx.h, op.first.h, op.second.h, int(nev), int(ncv), C.byref(h)))
             self._user = None
+        elif isinstance(op, _DenseMatrix):  # dense GEMV on the device
+            self.ctx = op.ctx
+            check(lib().mispec_symeigs_create_dense(self.ctx.h, op.h, int(nev), int(ncv), C.byref(h)))
+            self._user = None
+        elif isinstance(op, DeviceOp):  # user operator on device pointers
+            self.ctx = op.ctx
+            check(lib().mispec_symeigs_create_device_op(self.ctx.h, op.cb, None, op.n, int(nev), int(ncv), C.byref(h)))
+            self._user = None
         else:  # any object with rows(), cols(), perform_op(x) -> y: the reference's OpType concept
             self.ctx = ctx or default_context()
             self._user = _UserOp(op)
@@ -599,7 +721,8 @@ class SymEigsSolver:
         return out[:cnt.value].copy()
 
     def local_rows(self):
-        return self.op.local_rows() if isinstance(self.op, (_DeviceMatrix, SVDMatOp, _GEigsRegInvOp, _GEigsShiftOp, _GEigsCholeskyOp)) else self.op.rows()
+        return self.op.local_rows() if isinstance(self.op, (_DeviceMatrix, SVDMatOp, _GEigsRegInvOp, _GEigsShiftOp, _GEigsCholeskyOp,
+                                                            _DenseMatrix, DeviceOp)) else self.op.rows()
 
     def eigenvectors(self, nvec=None, to_host=True):
         """n x nconv (this shard's rows).  to_host=False leaves the result in HBM and returns the column count."""
@@ -786,6 +909,14 @@ class GenEigsSolver:
             self.ctx = op.S.ctx
             check(lib().mispec_geneigs_create_shift(self.ctx.h, op.S.h, int(nev), int(ncv), float(op.sigma), C.byref(h)))
             self._user = None
+        elif isinstance(op, _DenseMatrix):
+            self.ctx = op.ctx
+            check(lib().mispec_geneigs_create_dense(self.ctx.h, op.h, int(nev), int(ncv), C.byref(h)))
+            self._user = None
+        elif isinstance(op, DeviceOp):
+            self.ctx = op.ctx
+            check(lib().mispec_geneigs_create_device_op(self.ctx.h, op.cb, None, op.n, int(nev), int(ncv), C.byref(h)))
+            self._user = None
         else:
             self.ctx = ctx or default_context()
             self._user = _UserOp(op)
@@ -907,6 +1038,16 @@ class Factorization:
             self.ctx = op.ctx
             self.n = op.rows()
             check(lib().mispec_fac_create(self.ctx.h, op.h, _capi.op_fn(), None, self.n, self.m, int(symmetric), C.byref(h)))
+            self._user = None
+        elif isinstance(op, _DenseMatrix):
+            self.ctx = op.ctx
+            self.n = op.rows()
+            check(lib().mispec_fac_create_dense(self.ctx.h, op.h, self.m, int(symmetric), C.byref(h)))
+            self._user = None
+        elif isinstance(op, DeviceOp):
+            self.ctx = op.ctx
+            self.n = op.n
+            check(lib().mispec_fac_create_device_op(self.ctx.h, op.cb, None, self.n, self.m, int(symmetric), C.byref(h)))
             self._user = None
         else:
             self.ctx = ctx or default_context()

@@ -30,6 +30,7 @@ def build_library(force=False, verbose=False):
 
 
 op_fn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))
+device_op_fn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 allgather_fn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 allreduce_fn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 exchange_fn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p,
@@ -97,6 +98,17 @@ SIGNATURES = {
     "mispec_symshift_solve_host": (C.c_int, [_vp, _dp, _dp]),
     "mispec_fac_create": (C.c_int, [_vp, _vp, op_fn, _vp, C.c_int64, C.c_int, C.c_int, _vpp]),
     "mispec_fac_create_shiftsolve": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vpp]),
+    "mispec_fac_create_device_op": (C.c_int, [_vp, device_op_fn, _vp, C.c_int64, C.c_int, C.c_int, _vpp]),
+    "mispec_fac_create_dense": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vpp]),
+    "mispec_dense_upload": (C.c_int, [_vp, C.c_int64, C.c_int64, _dp, C.c_int64, C.c_int, C.c_char, _vpp]),
+    "mispec_dense_destroy": (C.c_int, [_vp]),
+    "mispec_dense_rows": (C.c_int64, [_vp]),
+    "mispec_dense_cols": (C.c_int64, [_vp]),
+    "mispec_dense_gemv": (C.c_int, [_vp, _vp, _vp]),
+    "mispec_dense_gemv_host": (C.c_int, [_vp, _dp, _dp]),
+    "mispec_dense_gemm_host": (C.c_int, [_vp, _dp, C.c_int64, C.c_int, _dp, C.c_int64]),
+    "mispec_dense_coeff": (C.c_int, [_vp, C.c_int64, C.c_int64, C.POINTER(C.c_double)]),
+    "mispec_dense_gemv_time": (C.c_int, [_vp, _vp, _vp, C.c_int, C.POINTER(C.c_float)]),
     "mispec_fac_create_product": (C.c_int, [_vp, _vp, _vp, C.c_int, _vpp]),
     "mispec_fac_destroy": (C.c_int, [_vp]),
     "mispec_fac_init": (C.c_int, [_vp, _dp, _lp]),
@@ -124,6 +136,8 @@ SIGNATURES = {
     "mispec_symeigs_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vpp]),
     "mispec_symeigs_create_op": (C.c_int, [_vp, op_fn, _vp, C.c_int64, C.c_int64, C.c_int64, _vpp]),
     "mispec_symeigs_create_shift": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_double, _vpp]),
+    "mispec_symeigs_create_dense": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vpp]),
+    "mispec_symeigs_create_device_op": (C.c_int, [_vp, device_op_fn, _vp, C.c_int64, C.c_int64, C.c_int64, _vpp]),
     "mispec_symeigs_create_product": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int64, _vpp]),
     "mispec_symeigs_create_geigs_reginv": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int64, _vpp]),
     "mispec_symeigs_create_geigs_cholesky": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int64, _vpp]),
@@ -159,6 +173,8 @@ SIGNATURES = {
     "mispec_geneigs_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vpp]),
     "mispec_geneigs_create_op": (C.c_int, [_vp, op_fn, _vp, C.c_int64, C.c_int64, C.c_int64, _vpp]),
     "mispec_geneigs_create_shift": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_double, _vpp]),
+    "mispec_geneigs_create_dense": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vpp]),
+    "mispec_geneigs_create_device_op": (C.c_int, [_vp, device_op_fn, _vp, C.c_int64, C.c_int64, C.c_int64, _vpp]),
     "mispec_symshift_create_general": (C.c_int, [_vp, C.c_int64, _ip, _ip, _dp, C.c_int, _vpp]),
     "mispec_geneigs_destroy": (C.c_int, [_vp]),
     "mispec_geneigs_init": (C.c_int, [_vp, _dp]),

@@ -6,6 +6,7 @@
 // host, and the two triangular solves are dense GEMVs with the explicit L^{-1} / L^{-T} held in HBM — so the path
 // is limited to n <= 4096; larger sparse B go through the regular-inverse mode (conjugate gradient).
 #include "cholesky.hpp"
+#include "dense.hpp"
 
 #include <cmath>
 #include <memory>
@@ -13,36 +14,10 @@
 
 using namespace mispec;
 
-namespace {
-constexpr int kThreads = 256;
-
-// y = M x, M dense n x n row-major: one wavefront per row
-__global__ __launch_bounds__(kThreads) void k_row_gemv(int n, const double* __restrict__ M, const double* __restrict__ x,
-                                                        double* __restrict__ y)
-{
-    const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
-    if (r >= n)
-        return;
-    const double* a = M + size_t(r) * n;
-    double acc = 0.0;
-#pragma unroll 8
-    for (int c = lane; c < n; c += 64)
-        acc += a[c] * x[c];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-        acc += __shfl_down(acc, off, 64);
-    if (lane == 0)
-        y[r] = acc;
-}
-}  // namespace
-
 namespace mispec {
 void launch_cholesky_solve(const mispec_cholesky& C, bool upper, const double* x, double* y)
 {
-    hipLaunchKernelGGL(k_row_gemv, dim3(unsigned((C.n + 3) / 4)), dim3(kThreads), 0, C.ctx->stream, int(C.n),
-                       upper ? C.linvt.p : C.linv.p, x, y);
-    MISPEC_HIP(hipGetLastError());
+    launch_row_gemv(*C.ctx, upper ? C.linvt.p : C.linv.p, C.n, C.n, C.n, x, y);  // dense.hip: one wavefront per row
 }
 }  // namespace mispec
 

@@ -13,6 +13,7 @@
 //   * H is kept on the host (ncv x ncv, authoritative) — every rank of a row-sharded run holds the
 //     same H because all reductions end in an all-reduce.
 #include "csr.hpp"
+#include "dense.hpp"
 #include "krylov.hpp"
 #include "cholesky.hpp"
 #include "reginv.hpp"
@@ -64,6 +65,10 @@ struct mispec_fac
     bool bmode() const { return Bop != nullptr || Bcsr != nullptr; }
     mispec_op_fn op = nullptr;
     void* op_user = nullptr;
+    // dense operator in HBM (DenseSymMatProd / DenseGenMatProd), or a user operator that works on DEVICE pointers
+    const mispec_dense* D = nullptr;
+    mispec_device_op_fn dop = nullptr;
+    void* dop_user = nullptr;
     int64_t n = 0;     // global dimension
     int64_t nloc = 0;  // rows of this shard
     int64_t row_begin = 0;
@@ -434,6 +439,24 @@ void apply_op(mispec_fac& F, const double* x_loc, double* y_loc, bool lanczos_ep
     {
         Timed t(F, FAM_SPMV);
         launch_shiftsolve(*F.S, x_loc, y_loc);
+        if (lanczos_epi)
+            launch_lanczos_epilogue(*F.ctx, y_loc, x_loc, v_prev, h_prev, F.nloc, F.alpha_partials.p);
+    }
+    else if (F.D)
+    {
+        Timed t(F, FAM_SPMV);
+        launch_row_gemv(*F.ctx, F.D->a.p, F.D->ld, F.D->rows, F.D->cols, x_loc, y_loc);
+        if (lanczos_epi)
+            launch_lanczos_epilogue(*F.ctx, y_loc, x_loc, v_prev, h_prev, F.nloc, F.alpha_partials.p);
+    }
+    else if (F.dop)
+    {
+        // user operator on device pointers: it enqueues its work on the factorisation's stream, nothing is staged
+        {
+            Timed t(F, FAM_SPMV);
+            if (F.dop(F.dop_user, x_loc, y_loc, static_cast<void*>(F.stream())) != 0)
+                throw Error(MISPEC_ERUNTIME, "user device operator callback reported failure");
+        }
         if (lanczos_epi)
             launch_lanczos_epilogue(*F.ctx, y_loc, x_loc, v_prev, h_prev, F.nloc, F.alpha_partials.p);
     }
@@ -1079,11 +1102,15 @@ namespace {
 int fac_create_impl(mispec_ctx* ctx, const mispec_csr* A, const mispec_symshift* S, mispec_op_fn op, void* op_user, int64_t n,
                     int ncv, int symmetric, mispec_fac** out, const mispec_csr* A2 = nullptr, const mispec_reginv* Bop = nullptr,
                     const mispec_csr* Bcsr = nullptr, bool cayley = false, double cay_sigma = 0.0,
-                    const mispec_cholesky* Chol = nullptr)
+                    const mispec_cholesky* Chol = nullptr, const mispec_dense* D = nullptr, mispec_device_op_fn dop = nullptr,
+                    void* dop_user = nullptr)
 {
     return guarded([&] {
         MISPEC_REQUIRE(ctx && out, "mispec_fac_create: NULL argument");
-        MISPEC_REQUIRE(int(A != nullptr) + int(S != nullptr) + int(op != nullptr) == 1, "mispec_fac_create: give exactly one operator");
+        MISPEC_REQUIRE(int(A != nullptr) + int(S != nullptr) + int(op != nullptr) + int(D != nullptr) + int(dop != nullptr) == 1,
+                       "mispec_fac_create: give exactly one operator");
+        if (D)
+            MISPEC_REQUIRE(D->ctx == ctx && D->rows == n && D->cols == n, "mispec_fac_create_dense: matrix belongs to another context / is not n x n");
         MISPEC_REQUIRE(n >= 1, "mispec_fac_create: n must be positive");
         MISPEC_REQUIRE(ncv >= 1 && ncv <= n, "mispec_fac_create: need 1 <= ncv <= n");
         MISPEC_REQUIRE(ncv <= kMaxCols, "mispec_fac_create: the device factorisation holds at most 128 basis vectors (ncv <= 128)");
@@ -1150,6 +1177,9 @@ int fac_create_impl(mispec_ctx* ctx, const mispec_csr* A, const mispec_symshift*
             F->S = S;
             F->op = op;
             F->op_user = op_user;
+            F->D = D;
+            F->dop = dop;
+            F->dop_user = dop_user;
             F->n = n;
             F->m = ncv;
             F->symmetric = symmetric != 0;
@@ -1223,6 +1253,29 @@ extern "C" int mispec_fac_create(mispec_ctx* ctx, const mispec_csr* A, mispec_op
                                  int symmetric, mispec_fac** out)
 {
     return fac_create_impl(ctx, A, nullptr, op, op_user, n, ncv, symmetric, out);
+}
+
+extern "C" int mispec_fac_create_dense(mispec_ctx* ctx, const mispec_dense* D, int ncv, int symmetric, mispec_fac** out)
+{
+    if (!D)
+    {
+        set_last_error("mispec_fac_create_dense: NULL matrix");
+        return MISPEC_EINVAL;
+    }
+    return fac_create_impl(ctx, nullptr, nullptr, nullptr, nullptr, D->rows, ncv, symmetric, out, nullptr, nullptr, nullptr, false, 0.0,
+                           nullptr, D);
+}
+
+extern "C" int mispec_fac_create_device_op(mispec_ctx* ctx, mispec_device_op_fn op, void* op_user, int64_t n, int ncv, int symmetric,
+                                           mispec_fac** out)
+{
+    if (!op)
+    {
+        set_last_error("mispec_fac_create_device_op: NULL callback");
+        return MISPEC_EINVAL;
+    }
+    return fac_create_impl(ctx, nullptr, nullptr, nullptr, nullptr, n, ncv, symmetric, out, nullptr, nullptr, nullptr, false, 0.0,
+                           nullptr, nullptr, op, op_user);
 }
 
 extern "C" int mispec_fac_create_product(mispec_ctx* ctx, const mispec_csr* A, const mispec_csr* A2, int ncv, mispec_fac** out)
@@ -1665,6 +1718,7 @@ extern "C" int mispec_fac_get_profile(const mispec_fac* fac_c, mispec_profile* o
         out->ms_scale = F.ms_acc[FAM_SCALE];
         out->ms_compress = F.ms_acc[FAM_COMPRESS];
         out->ms_small = F.ms_acc[FAM_SMALL];
-        out->spmv_bytes = (F.A ? F.A->algorithmic_bytes() : 0.0) + (F.A2 ? F.A2->algorithmic_bytes() : 0.0);
+        out->spmv_bytes = (F.A ? F.A->algorithmic_bytes() : 0.0) + (F.A2 ? F.A2->algorithmic_bytes() : 0.0) +
+                          (F.D ? F.D->algorithmic_bytes() : 0.0);
     });
 }

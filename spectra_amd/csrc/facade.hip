@@ -69,7 +69,47 @@ public:
     }
 };
 
+// A dense matrix already in HBM (mispec_dense_upload) as an operator for C callers; the C++ classes
+// DenseSymMatProd / DenseGenMatProd own theirs.
+class DenseHandleOp
+{
+    mispec_ctx* m_ctx;
+    const mispec_dense* m_mat;
+
+public:
+    using Scalar = double;
+    DenseHandleOp(mispec_ctx* ctx, const mispec_dense* D) : m_ctx(ctx), m_mat(D) {}
+    mispec_ctx* mispec_context() const { return m_ctx; }
+    const mispec_dense* mispec_dense_matrix() const { return m_mat; }
+    Spectra::Index rows() const { return Spectra::Index(mispec_dense_rows(m_mat)); }
+    Spectra::Index cols() const { return Spectra::Index(mispec_dense_cols(m_mat)); }
+    void perform_op(const double* x_in, double* y_out) const { Spectra::internal::check(mispec_dense_gemv_host(m_mat, x_in, y_out)); }
+};
+
+// A user operator on device pointers supplied as a C function pointer.
+class DeviceCallbackOp
+{
+    mispec_ctx* m_ctx;
+    mispec_device_op_fn m_fn;
+    void* m_user;
+    Spectra::Index m_n;
+
+public:
+    using Scalar = double;
+    DeviceCallbackOp(mispec_ctx* ctx, mispec_device_op_fn fn, void* user, Spectra::Index n) : m_ctx(ctx), m_fn(fn), m_user(user), m_n(n) {}
+    mispec_ctx* mispec_context() const { return m_ctx; }
+    Spectra::Index rows() const { return m_n; }
+    Spectra::Index cols() const { return m_n; }
+    void perform_op_device(const double* x_dev, double* y_dev, void* hip_stream) const
+    {
+        if (m_fn(m_user, x_dev, y_dev, hip_stream) != 0)
+            throw std::runtime_error("user device operator callback reported failure");
+    }
+};
+
 using DevOp = Spectra::SparseSymMatProd<double>;
+using DenseSolver = Spectra::SymEigsSolver<DenseHandleOp>;
+using DevCbSolver = Spectra::SymEigsSolver<DeviceCallbackOp>;
 using DevSolver = Spectra::SymEigsSolver<DevOp>;
 using CbSolver = Spectra::SymEigsSolver<CallbackOp>;
 using ShiftOp = Spectra::SparseSymShiftSolve<double>;
@@ -102,6 +142,10 @@ struct mispec_symeigs
     std::unique_ptr<GShiftInvert> g_shift;
     std::unique_ptr<GBuckling> g_buckling;
     std::unique_ptr<GCayley> g_cayley;
+    std::unique_ptr<DenseHandleOp> dense_op;
+    std::unique_ptr<DenseSolver> dense;
+    std::unique_ptr<DeviceCallbackOp> devcb_op;
+    std::unique_ptr<DevCbSolver> devcb;
     std::unique_ptr<DevSolver> dev;
     std::unique_ptr<CbSolver> cb;
     std::unique_ptr<ShiftSolver> shift;
@@ -127,6 +171,10 @@ struct mispec_symeigs
             return f(*g_buckling);
         if (g_cayley)
             return f(*g_cayley);
+        if (dense)
+            return f(*dense);
+        if (devcb)
+            return f(*devcb);
         return f(*cb);
     }
     mispec_fac* fac() const
@@ -158,6 +206,33 @@ extern "C" int mispec_symeigs_create_op(mispec_ctx* ctx, mispec_op_fn op, void* 
         s->nev = nev;
         s->cb_op = std::make_unique<CallbackOp>(ctx, op, op_user, n);
         s->cb = std::make_unique<CbSolver>(*s->cb_op, nev, ncv);
+        *out = s.release();
+    });
+}
+
+extern "C" int mispec_symeigs_create_dense(mispec_ctx* ctx, const mispec_dense* D, int64_t nev, int64_t ncv, mispec_symeigs** out)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(ctx && D && out, "mispec_symeigs_create_dense: NULL argument");
+        auto s = std::make_unique<mispec_symeigs>();
+        s->ctx = ctx;
+        s->nev = nev;
+        s->dense_op = std::make_unique<DenseHandleOp>(ctx, D);
+        s->dense = std::make_unique<DenseSolver>(*s->dense_op, nev, ncv);
+        *out = s.release();
+    });
+}
+
+extern "C" int mispec_symeigs_create_device_op(mispec_ctx* ctx, mispec_device_op_fn op, void* op_user, int64_t n, int64_t nev,
+                                               int64_t ncv, mispec_symeigs** out)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(ctx && op && out, "mispec_symeigs_create_device_op: NULL argument");
+        auto s = std::make_unique<mispec_symeigs>();
+        s->ctx = ctx;
+        s->nev = nev;
+        s->devcb_op = std::make_unique<DeviceCallbackOp>(ctx, op, op_user, n);
+        s->devcb = std::make_unique<DevCbSolver>(*s->devcb_op, nev, ncv);
         *out = s.release();
     });
 }
@@ -358,6 +433,8 @@ namespace {
 using GenDevOp = Spectra::SparseGenMatProd<double>;
 using GenDevSolver = Spectra::GenEigsSolver<GenDevOp>;
 using GenCbSolver = Spectra::GenEigsSolver<CallbackOp>;
+using GenDenseSolver = Spectra::GenEigsSolver<DenseHandleOp>;
+using GenDevCbSolver = Spectra::GenEigsSolver<DeviceCallbackOp>;
 using GenShiftOp = Spectra::SparseGenRealShiftSolve<double>;
 using GenShiftSolver = Spectra::GenEigsRealShiftSolver<GenShiftOp>;
 }  // namespace
@@ -370,6 +447,10 @@ struct mispec_geneigs
     std::unique_ptr<GenDevSolver> dev;
     std::unique_ptr<GenCbSolver> cb;
     std::unique_ptr<GenShiftSolver> shift;
+    std::unique_ptr<DenseHandleOp> dense_op;
+    std::unique_ptr<GenDenseSolver> dense;
+    std::unique_ptr<DeviceCallbackOp> devcb_op;
+    std::unique_ptr<GenDevCbSolver> devcb;
     template <typename F>
     auto visit(F&& f) const
     {
@@ -377,6 +458,10 @@ struct mispec_geneigs
             return f(*dev);
         if (shift)
             return f(*shift);
+        if (dense)
+            return f(*dense);
+        if (devcb)
+            return f(*devcb);
         return f(*cb);
     }
     mispec_fac* fac() const
@@ -403,6 +488,27 @@ extern "C" int mispec_geneigs_create_op(mispec_ctx* ctx, mispec_op_fn op, void* 
         auto s = std::make_unique<mispec_geneigs>();
         s->cb_op = std::make_unique<CallbackOp>(ctx, op, op_user, n);
         s->cb = std::make_unique<GenCbSolver>(*s->cb_op, nev, ncv);
+        *out = s.release();
+    });
+}
+extern "C" int mispec_geneigs_create_dense(mispec_ctx* ctx, const mispec_dense* D, int64_t nev, int64_t ncv, mispec_geneigs** out)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(ctx && D && out, "mispec_geneigs_create_dense: NULL argument");
+        auto s = std::make_unique<mispec_geneigs>();
+        s->dense_op = std::make_unique<DenseHandleOp>(ctx, D);
+        s->dense = std::make_unique<GenDenseSolver>(*s->dense_op, nev, ncv);
+        *out = s.release();
+    });
+}
+extern "C" int mispec_geneigs_create_device_op(mispec_ctx* ctx, mispec_device_op_fn op, void* op_user, int64_t n, int64_t nev,
+                                               int64_t ncv, mispec_geneigs** out)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(ctx && op && out, "mispec_geneigs_create_device_op: NULL argument");
+        auto s = std::make_unique<mispec_geneigs>();
+        s->devcb_op = std::make_unique<DeviceCallbackOp>(ctx, op, op_user, n);
+        s->devcb = std::make_unique<GenDevCbSolver>(*s->devcb_op, nev, ncv);
         *out = s.release();
     });
 }

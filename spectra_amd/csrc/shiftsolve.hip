@@ -19,6 +19,7 @@
 //     pivoting of the dense A - sigma I on the host, explicit inverse, and a dense GEMV kernel per step.
 // Anything else (large n with large bandwidth) is rejected: a general sparse LU on the GPU is out of scope.
 #include "shiftsolve.hpp"
+#include "dense.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -393,28 +394,6 @@ __global__ __launch_bounds__(kChunkThreads) void k_chunk_factor(int64_t N, int b
     }
 }
 
-// y = Ainv * x, Ainv dense n x n stored ROW-major: one wavefront per row reads its row coalesced, x comes from
-// the L2, and a shuffle tree finishes the dot product — n waves in flight instead of n/256 workgroups that each
-// walk all the columns (the first version: 233 us at n = 1830, i.e. a third of a banded solve).
-__global__ __launch_bounds__(kThreads) void k_dense_gemv(int n, const double* __restrict__ Arow, const double* __restrict__ x,
-                                                          double* __restrict__ y)
-{
-    const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
-    if (r >= n)
-        return;
-    const double* a = Arow + size_t(r) * n;
-    double acc = 0.0;
-#pragma unroll 8
-    for (int c = lane; c < n; c += 64)
-        acc += a[c] * x[c];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-        acc += __shfl_down(acc, off, 64);
-    if (lane == 0)
-        y[r] = acc;
-}
-
 // column-major host inverse -> row-major device copy
 void upload_row_major(const std::vector<double>& inv, int64_t n, DevBuf<double>& dst)
 {
@@ -787,8 +766,9 @@ void solve_level(const mispec_ctx& ctx, const BandLevel& lev, const double* f, d
     {
         if (lev.inv.p)
         {
-            hipLaunchKernelGGL(k_dense_gemv, dim3(unsigned((lev.N + 3) / 4)), dim3(kThreads), 0, ctx.stream, int(lev.N), lev.inv.p, f, x);
-            MISPEC_HIP(hipGetLastError());
+            // explicit inverse, row-major: one wavefront per row (dense.hip) — n waves in flight instead of n/256
+            // workgroups that each walk all the columns (the first version: 233 us at n = 1830, a third of a banded solve)
+            launch_row_gemv(ctx, lev.inv.p, lev.N, lev.N, lev.N, f, x);
         }
         else
             launch_chunk_solve(ctx, lev, dim3(1), f, x);
@@ -875,11 +855,7 @@ void launch_shiftsolve(const mispec_symshift& S, const double* x_dev, double* y_
     if (!S.factored)
         throw Error(MISPEC_ELOGIC, "SparseSymShiftSolve: need to call set_shift() first");
     if (S.dense)
-    {
-        hipLaunchKernelGGL(k_dense_gemv, dim3(unsigned((S.n + 3) / 4)), dim3(kThreads), 0, S.ctx->stream, int(S.n),
-                           S.inverse.p, x_dev, y_dev);
-        MISPEC_HIP(hipGetLastError());
-    }
+        launch_row_gemv(*S.ctx, S.inverse.p, S.n, S.n, S.n, x_dev, y_dev);
     else
         solve_level(*S.ctx, *S.top, x_dev, y_dev);
 }

@@ -6,6 +6,8 @@
 // over as Spectra::SparseView and results come back as Spectra::DenseVector / DenseMatrix.
 #include <Spectra/GenEigsRealShiftSolver.h>
 #include <Spectra/GenEigsSolver.h>
+#include <Spectra/MatOp/DenseGenMatProd.h>
+#include <Spectra/MatOp/DenseSymMatProd.h>
 #include <Spectra/MatOp/SparseGenMatProd.h>
 #include <Spectra/MatOp/SparseSymMatProd.h>
 #include <Spectra/MatOp/SparseSymShiftSolve.h>
@@ -182,6 +184,86 @@ public:
             y_out[i] = x_in[i] * (i + 1);
     }
 };
+
+// test/SymEigs.cpp:100-131 on a dense matrix (README.md:150-180 is this program): only the lower triangle of the
+// column-major input is read.  The fixture is the sparse one scattered into a dense array, so `residual` applies.
+static void run_dense(const Csc& A, int k, int m)
+{
+    DenseMatrix<double> M(A.n, A.n);
+    for (int j = 0; j < A.n; j++)
+    {
+        for (int i = 0; i < A.n; i++)
+            M(i, j) = 0.0;
+        for (int p = A.colptr[j]; p < A.colptr[j + 1]; p++)
+            M(A.rowind[p], j) += A.val[p];
+    }
+    DenseSymMatProd<double> op{DenseView<double>(M)};
+    REQUIRE(op.rows() == A.n && op.cols() == A.n);
+    REQUIRE(op(A.n - 1, 0) == M(A.n - 1, 0) && op(0, A.n - 1) == M(A.n - 1, 0));  // the mirrored lower triangle
+    SymEigsSolver<DenseSymMatProd<double>> eigs(op, k, m);
+    eigs.init();
+    const int nconv = (int) eigs.compute(SortRule::LargestAlge);
+    REQUIRE(eigs.info() == CompInfo::Successful);
+    const double err = residual(A, eigs.eigenvalues(), eigs.eigenvectors());
+    std::printf("dense n=%d nconv=%d nops=%d ||AU-UD||_inf=%.3e\n", A.n, nconv, (int) eigs.num_operations(), err);
+    REQUIRE(nconv == k);
+    REQUIRE(err < 1e-9);
+
+    // general dense operator: the same matrix, all of it (test/GenEigs.cpp:110-146 shape)
+    DenseGenMatProd<double> gop{DenseView<double>(M)};
+    GenEigsSolver<DenseGenMatProd<double>> geigs(gop, k, m + 10);
+    geigs.init();
+    const int gconv = (int) geigs.compute(SortRule::LargestMagn);
+    REQUIRE(geigs.info() == CompInfo::Successful);
+    const auto ev = geigs.eigenvalues();
+    const auto U = geigs.eigenvectors();
+    double gerr = 0.0;
+    for (Index c = 0; c < U.cols(); c++)
+        for (int i = 0; i < A.n; i++)
+        {
+            std::complex<double> y = 0.0;
+            for (int j = 0; j < A.n; j++)
+                y += M(i, j) * U(j, c);
+            gerr = std::max(gerr, std::abs(y - ev[c] * U(i, c)));
+        }
+    std::printf("dense-gen n=%d nconv=%d nops=%d ||AU-UD||_inf=%.3e\n", A.n, gconv, (int) geigs.num_operations(), gerr);
+    REQUIRE(gconv >= k - 1);
+    REQUIRE(gerr < 1e-9);
+}
+
+// A user operator that works on DEVICE pointers: perform_op_device(x_dev, y_dev, stream) is the reference's
+// perform_op contract with the vectors left in HBM.  Here it forwards to the library's SpMV on a device matrix.
+class MyDeviceOperator
+{
+    SparseSymMatProd<double> m_mat;
+
+public:
+    using Scalar = double;
+    mutable int calls = 0;
+    explicit MyDeviceOperator(const Csc& A) : m_mat(A.view()) {}
+    Index rows() const { return m_mat.rows(); }
+    Index cols() const { return m_mat.cols(); }
+    mispec_ctx* mispec_context() const { return m_mat.mispec_context(); }
+    void perform_op_device(const double* x_dev, double* y_dev, void* /*hip_stream*/) const
+    {
+        calls++;
+        internal::check(mispec_spmv(m_mat.mispec_matrix(), x_dev, y_dev));  // enqueued on the context's stream
+    }
+};
+
+static void run_device_op(const Csc& A, int k, int m)
+{
+    MyDeviceOperator op(A);
+    SymEigsSolver<MyDeviceOperator> eigs(op, k, m);
+    eigs.init();
+    const int nconv = (int) eigs.compute(SortRule::LargestMagn);
+    REQUIRE(eigs.info() == CompInfo::Successful);
+    const double err = residual(A, eigs.eigenvalues(), eigs.eigenvectors());
+    std::printf("device-op n=%d nconv=%d nops=%d ||AU-UD||_inf=%.3e\n", A.n, nconv, (int) eigs.num_operations(), err);
+    REQUIRE(nconv == k);
+    REQUIRE(err < 1e-9);
+    REQUIRE(op.calls == (int) eigs.num_operations());
+}
 
 // test/SymGEigsRegInv.cpp:35-106: A = sprand(n, prob) (lower triangle used), B = A'A + 0.1 I, regular-inverse mode;
 // ||A U - B U D||_inf <= 1e-9 with the symmetric A the solver sees.
@@ -462,6 +544,8 @@ int main()
         run_geigs_shift<GEigsMode::Cayley>("cayley");
         run_svd(1000, 100, 5, 10);  // test/SVD.cpp:105-114 (tall sparse)
         run_svd(100, 1000, 5, 10);  // :116-125 (wide sparse)
+        run_dense(gen_sparse_data(100, 0.1), 10, 20);        // test/SymEigs.cpp:111-120 shape, dense operators
+        run_device_op(gen_sparse_data(1000, 0.01), 20, 50);  // user operator on device pointers
 
         // constructor argument checks throw std::invalid_argument like the reference (HermEigsBase.h:267-271)
         bool threw = false;
