@@ -212,8 +212,21 @@ __global__ __launch_bounds__(kThreads) void k_spmv_csr_stream(const int32_t* __r
         __syncthreads();
         // phase 4: thread r sums the part of row r that lies in [cs, ce), in storage order
         const int lo = max(rs, cs), hi = min(re, ce);
-        for (int k = lo; k < hi; k++)
-            acc += prod[k - a0];
+        {
+            // four LDS reads in flight, added in storage order: the serial read-add chain of a 15-entry row is
+            // otherwise 15 LDS round trips on the critical path of the workgroup
+            int k = lo;
+            for (; k + 4 <= hi; k += 4)
+            {
+                const double p0 = prod[k - a0], p1 = prod[k - a0 + 1], p2 = prod[k - a0 + 2], p3 = prod[k - a0 + 3];
+                acc += p0;
+                acc += p1;
+                acc += p2;
+                acc += p3;
+            }
+            for (; k < hi; k++)
+                acc += prod[k - a0];
+        }
         cs = ce;
         if (cs < be)
             __syncthreads();

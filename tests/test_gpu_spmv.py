@@ -234,3 +234,49 @@ def test_offset_codes_with_rows_longer_than_the_lds_chunk_and_rectangular_shapes
     xt = rand_x(700, 8)
     yc, yp = _both_formats(top, xt)
     assert np.array_equal(yc, yp) and np.array_equal(yc, O.Op.csr(2000, 700, Rt.indptr, Rt.indices, Rt.data).perform_op(xt))
+
+
+# ---- ragged rows, empty row-blocks -------------------------------------------------------------------------------
+def test_ragged_rows_and_empty_blocks_in_both_index_formats(ctx):
+    # random row lengths 0..14, a run of 600 empty rows (two empty 256-row blocks), empty first and last rows;
+    # general (non-symmetric) matrix with too many diagonals for offset codes -> int32 indices
+    n = 5000
+    rng = np.random.default_rng(12)
+    lens = rng.integers(0, 15, n)
+    lens[1500:2100] = 0
+    lens[0] = lens[-1] = 0
+    rows = np.repeat(np.arange(n), lens)
+    cols = rng.integers(0, n, rows.size)
+    A = sp.coo_matrix((rng.uniform(-1, 1, rows.size), (rows, cols)), shape=(n, n)).tocsr()
+    A.sum_duplicates()
+    A.sort_indices()
+    op = sa.SparseGenMatProd(A, ctx=ctx)
+    assert op.offset_codes() == 0
+    x = rand_x(n, 13)
+    assert np.array_equal(op.perform_op(x), O.Op.csr(n, n, A.indptr, A.indices, A.data).perform_op(x))
+    # the same on few diagonals -> offset codes, again with empty blocks
+    B = sp.diags([rng.uniform(-1, 1, n - abs(k)) for k in (-40, -1, 0, 2, 300)], [-40, -1, 0, 2, 300], format="lil")
+    B[1500:2100, :] = 0
+    B[0, :] = 0
+    B = B.tocsr()
+    B.eliminate_zeros()
+    B.sort_indices()
+    bop = sa.SparseGenMatProd(B, ctx=ctx)
+    assert 0 < bop.offset_codes() <= 5
+    yc, yp = _both_formats(bop, x)
+    assert np.array_equal(yc, yp)
+    assert np.array_equal(yc, O.Op.csr(n, n, B.indptr, B.indices, B.data).perform_op(x))
+
+
+def test_fused_epilogue_is_identical_in_both_index_formats():
+    # the Lanczos epilogue (w -= beta v_prev, alpha partials) rides on the SpMV: a full solve must not depend on the format
+    n = 200_000
+    res = []
+    for codes in (False, True):
+        op = sa.SparseSymMatProd.synth_band(n)
+        op.use_offset_codes(codes)
+        eigs = sa.SymEigsSolver(op, 6, 20)
+        eigs.init()
+        eigs.compute(sa.SortRule.LargestMagn, tol=1e-11)
+        res.append((eigs.eigenvalues(), eigs.num_operations()))
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
