@@ -92,6 +92,28 @@ std::vector<std::ptrdiff_t> argsort(SortRule selection, const T* values, std::pt
     return ind;
 }
 
+// The compile-time form of the reference (Util/SelectionRule.h:195-224): SortEigenvalue<T, Rule>(ptr, n).index() is
+// the permutation that sorts the n values by `Rule` (BothEnds sorts like LargestAlge here; the interleaving is
+// argsort's job, as upstream).  Kept for user code that names the class; the solvers use argsort.
+template <typename T, SortRule Rule>
+class SortEigenvalue
+{
+    std::vector<std::ptrdiff_t> m_index;
+
+public:
+    SortEigenvalue(const T* start, std::ptrdiff_t size) : m_index(static_cast<std::size_t>(size))
+    {
+        (void) internal::sort_key(Rule, T());
+        for (std::ptrdiff_t i = 0; i < size; i++)
+            m_index[static_cast<std::size_t>(i)] = i;
+        std::sort(m_index.begin(), m_index.end(), [start](std::ptrdiff_t a, std::ptrdiff_t b) {
+            return internal::sort_key(Rule, start[a]) < internal::sort_key(Rule, start[b]);
+        });
+    }
+    std::vector<std::ptrdiff_t> index() const { return m_index; }
+    void swap(std::vector<std::ptrdiff_t>& other) { m_index.swap(other); }
+};
+
 // Container forms (anything with data() and size(): Eigen vectors, std::vector, DenseVector)
 template <typename Vec, typename = decltype(std::declval<const Vec&>().data())>
 std::vector<std::ptrdiff_t> argsort(SortRule selection, const Vec& values, std::ptrdiff_t len)

@@ -7,6 +7,8 @@
 #include <Spectra/LinAlg/UpperHessenbergEigen.h>
 #include <Spectra/LinAlg/UpperHessenbergQR.h>
 #include <Spectra/LinAlg/UpperHessenbergSchur.h>
+#include <Spectra/Util/SelectionRule.h>
+#include <Spectra/Util/Version.h>
 
 #include <cmath>
 #include <complex>
@@ -222,6 +224,18 @@ int main()
                 err = std::fmax(err, std::abs(acc - ev[j] * X(i, j)));
             }
         REQUIRE(err <= 1e-10);
+    }
+    {
+        // Util/SelectionRule.h: the compile-time sorter and argsort agree; BothEnds interleaves (reference :265-284)
+        static_assert(SPECTRA_VERSION == 10200, "headers follow Spectra 1.2.0");
+        const double v[6] = {0.5, -3.0, 2.0, -0.1, 4.0, 1.0};
+        const std::vector<std::ptrdiff_t> lm = SortEigenvalue<double, SortRule::LargestMagn>(v, 6).index();
+        REQUIRE(lm == argsort(SortRule::LargestMagn, v, 6));
+        REQUIRE(lm[0] == 4 && lm[1] == 1 && lm[5] == 3);
+        const std::vector<std::ptrdiff_t> be = argsort(SortRule::BothEnds, v, 6);
+        REQUIRE(be[0] == 4 && be[1] == 1 && be[2] == 2 && be[3] == 3 && be[4] == 5 && be[5] == 0);
+        std::vector<double> vec(v, v + 6);
+        REQUIRE(argsort(SortRule::SmallestAlge, vec) == (SortEigenvalue<double, SortRule::SmallestAlge>(v, 6).index()));
     }
     std::printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);
     return failures ? 1 : 0;
