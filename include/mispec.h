@@ -331,6 +331,33 @@ int mispec_tridiag_qr(mispec_ctx* ctx, int n, const double* T_host, double shift
 int mispec_tridiag_eigen(mispec_ctx* ctx, int n, const double* T_host, double* evals_host, double* evecs_host);
 
 /* ---------------------------------------------------------------------------
+ * DavidsonSymEigsSolver — replaces DavidsonSymEigsSolver.h:18-90 + JDSymEigsBase.h:28-187 (block Davidson with the
+ * diagonal-preconditioned-residual correction).  The search space, its image under A and the Ritz vectors live in
+ * HBM; the projected eigenproblem (<= 128 x 128) is solved on the host.  nvec_max + correction size <= 128.
+ * Operators: a device CSR matrix, a dense device matrix, or a device-pointer callback plus diag(A).
+ * ------------------------------------------------------------------------- */
+typedef struct mispec_davidson mispec_davidson;
+int mispec_davidson_create(mispec_ctx* ctx, const mispec_csr* A, int64_t nev, int64_t nvec_init, int64_t nvec_max,
+                           mispec_davidson** out);
+int mispec_davidson_create_dense(mispec_ctx* ctx, const mispec_dense* D, int64_t nev, int64_t nvec_init, int64_t nvec_max,
+                                 mispec_davidson** out);
+int mispec_davidson_create_device_op(mispec_ctx* ctx, mispec_device_op_fn op, void* op_user, int64_t n, const double* diag_host,
+                                     int64_t nev, int64_t nvec_init, int64_t nvec_max, mispec_davidson** out);
+int mispec_davidson_destroy(mispec_davidson* S);
+/* set_initial_search_space_size / set_max_search_space_size / set_correction_size (JDSymEigsBase.h:86-105); negative = keep */
+int mispec_davidson_set_sizes(mispec_davidson* S, int64_t initial_search_space, int64_t max_search_space, int64_t correction);
+int mispec_davidson_get_sizes(const mispec_davidson* S, int64_t* initial_search_space, int64_t* max_search_space, int64_t* correction);
+/* compute(selection, maxit = 100, tol = 1e-10) (JDSymEigsBase.h:121-128); with guess_host != NULL compute_with_guess
+ * (:130-184) on an n x guess_cols column-major block.  *nconv = converged pairs among the first nev. */
+int mispec_davidson_compute(mispec_davidson* S, int selection, int64_t maxit, double tol, const double* guess_host,
+                            int64_t guess_cols, int64_t ldg, int64_t* nconv);
+int mispec_davidson_info(const mispec_davidson* S);               /* CompInfo as int */
+int64_t mispec_davidson_num_iterations(const mispec_davidson* S);
+int64_t mispec_davidson_num_operations(const mispec_davidson* S); /* matrix-vector products of the last compute() */
+int mispec_davidson_eigenvalues(const mispec_davidson* S, double* out_host);                 /* nev values */
+int mispec_davidson_eigenvectors(const mispec_davidson* S, double* out_host, int64_t ld);    /* n x nev, column-major */
+
+/* ---------------------------------------------------------------------------
  * Solver-level facade: Spectra::SymEigsSolver<Spectra::SparseSymMatProd<double>> (include/Spectra/)
  * instantiated inside the library, for bindings that cannot instantiate C++ templates (ctypes, cgo...).
  * Argument meaning and defaults as HermEigsBase.h:257-272, :309-342, :366-390, :395-478.

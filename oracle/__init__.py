@@ -51,6 +51,7 @@ def lib():
             "oracle_minstd_states": (None, [C.c_long, C.c_long, lp]),
             "oracle_gen_sparse_data": (C.c_long, [C.c_int, C.c_double, ip, ip, dp]),
             "oracle_gen_sparse_data_rect": (C.c_long, [C.c_int, C.c_int, C.c_double, ip, ip, dp]),
+            "oracle_gen_davidson_sparse": (C.c_long, [C.c_int, ip, ip, dp]),
             "oracle_synth_band_csr": (C.c_long, [C.c_long, C.c_ulonglong, lp, C.c_int, C.c_int, ip, ip, dp]),
             "oracle_synth_value": (C.c_double, [C.c_ulonglong, C.c_ulonglong, C.c_ulonglong]),
             "oracle_givens": (None, [C.c_double, C.c_double, dp, dp, dp]),
@@ -182,6 +183,16 @@ def gen_sparse_data_rect(m, n, prob):
     c = np.empty(cnt, dtype=np.int32)
     v = np.empty(cnt)
     lib().oracle_gen_sparse_data_rect(m, n, prob, _ip(r), _ip(c), _dp(v))
+    return r, c, v
+
+
+def gen_davidson_sparse(n):
+    """test/DavidsonSymEigs.cpp:46-67 gen_sym_data_sparse(n) as COO (rows, cols, vals) — NOT symmetric."""
+    cnt = lib().oracle_gen_davidson_sparse(n, None, None, None)
+    r = np.empty(cnt, dtype=np.int32)
+    c = np.empty(cnt, dtype=np.int32)
+    v = np.empty(cnt)
+    lib().oracle_gen_davidson_sparse(n, _ip(r), _ip(c), _dp(v))
     return r, c, v
 
 

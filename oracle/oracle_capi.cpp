@@ -115,6 +115,44 @@ long oracle_gen_sparse_data_rect(int m, int n, double prob, int* rows, int* cols
     return cnt;
 }
 
+// ---- test/DavidsonSymEigs.cpp:46-67 gen_sym_data_sparse(n): prob 0.5, entries 0.1*(u - 0.5), diagonal forced to i+1.
+// (The matrix is not symmetric; SparseSymMatProd reads its lower triangle.)  COO, row-major order, diagonal included once.
+long oracle_gen_davidson_sparse(int n, int* rows, int* cols, double* vals)
+{
+    const double prob = 0.5;
+    std::default_random_engine gen;
+    gen.seed(0);
+    std::uniform_real_distribution<double> distr(0.0, 1.0);
+    long cnt = 0;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++)
+        {
+            bool have = false;
+            double v = 0.0;
+            if (distr(gen) < prob)
+            {
+                v = 0.1 * (distr(gen) - 0.5);
+                have = true;
+            }
+            if (i == j)
+            {
+                v = i + 1;
+                have = true;
+            }
+            if (have)
+            {
+                if (rows)
+                {
+                    rows[cnt] = i;
+                    cols[cnt] = j;
+                    vals[cnt] = v;
+                }
+                cnt++;
+            }
+        }
+    return cnt;
+}
+
 // ---- synthetic benchmark matrices ------------------------------
 // Row i holds columns i+off for every signed offset in {0} U {+-offsets[k]} that lands in [0,n),
 // ascending.  rowptr may be NULL to just count.

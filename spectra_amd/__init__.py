@@ -763,6 +763,87 @@ class SymEigsSolver:
             pass
 
 
+class DavidsonSymEigsSolver:
+    """DavidsonSymEigsSolver.h:18-90 / JDSymEigsBase.h:28-187: block Davidson with the diagonal (DPR) correction.
+    op: SparseSymMatProd, DenseSymMatProd, or a DeviceOp together with `diagonal` (the solver needs op(i, i))."""
+
+    def __init__(self, op, nev, nvec_init=None, nvec_max=None, diagonal=None):
+        nev = int(nev)
+        nvec_init = 2 * nev if nvec_init is None else int(nvec_init)
+        nvec_max = 10 * nev if nvec_max is None else int(nvec_max)
+        self.op = op
+        self.ctx = op.ctx
+        self.nev = nev
+        h = C.c_void_p()
+        if isinstance(op, _DeviceMatrix):
+            check(lib().mispec_davidson_create(self.ctx.h, op.h, nev, nvec_init, nvec_max, C.byref(h)))
+        elif isinstance(op, _DenseMatrix):
+            check(lib().mispec_davidson_create_dense(self.ctx.h, op.h, nev, nvec_init, nvec_max, C.byref(h)))
+        elif isinstance(op, DeviceOp):
+            if diagonal is None:
+                raise ValueError("DavidsonSymEigsSolver: a device operator needs its diagonal")
+            d = _f64(diagonal)
+            if d.shape != (op.n,):
+                raise ValueError("DavidsonSymEigsSolver: diagonal must have n entries")
+            check(lib().mispec_davidson_create_device_op(self.ctx.h, op.cb, None, op.n, _dp(d), nev, nvec_init, nvec_max, C.byref(h)))
+        else:
+            raise TypeError("DavidsonSymEigsSolver: the operator must live on the device (SparseSymMatProd, DenseSymMatProd, DeviceOp)")
+        self.h = h
+
+    def set_max_search_space_size(self, m):
+        check(lib().mispec_davidson_set_sizes(self.h, -1, int(m), -1))
+
+    def set_correction_size(self, m):
+        check(lib().mispec_davidson_set_sizes(self.h, -1, -1, int(m)))
+
+    def set_initial_search_space_size(self, m):
+        check(lib().mispec_davidson_set_sizes(self.h, int(m), -1, -1))
+
+    def sizes(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        check(lib().mispec_davidson_get_sizes(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def compute(self, selection=SortRule.LargestMagn, maxit=100, tol=1e-10):
+        n = C.c_int64()
+        check(lib().mispec_davidson_compute(self.h, int(selection), int(maxit), float(tol), None, 0, 0, C.byref(n)))
+        return n.value
+
+    def compute_with_guess(self, initial_space, selection=SortRule.LargestMagn, maxit=100, tol=1e-10):
+        G = np.asfortranarray(initial_space, dtype=np.float64)
+        if G.ndim != 2 or G.shape[0] != self.op.rows():
+            raise ValueError("compute_with_guess: the initial space must have n rows")
+        n = C.c_int64()
+        check(lib().mispec_davidson_compute(self.h, int(selection), int(maxit), float(tol), _dp(G), G.shape[1], G.shape[0], C.byref(n)))
+        return n.value
+
+    def info(self):
+        return CompInfo(lib().mispec_davidson_info(self.h))
+
+    def num_iterations(self):
+        return lib().mispec_davidson_num_iterations(self.h)
+
+    def num_operations(self):
+        return lib().mispec_davidson_num_operations(self.h)
+
+    def eigenvalues(self):
+        out = np.empty(self.nev)
+        check(lib().mispec_davidson_eigenvalues(self.h, _dp(out)))
+        return out
+
+    def eigenvectors(self):
+        n = self.op.rows()
+        out = np.empty((n, self.nev), order="F")
+        check(lib().mispec_davidson_eigenvectors(self.h, _dp(out), n))
+        return out
+
+    def __del__(self):
+        try:
+            lib().mispec_davidson_destroy(self.h)
+        except Exception:
+            pass
+
+
 class _GEigsCholeskyOp:
     """MatOp/internal/SymGEigsCholeskyOp.h: y = L^{-1} A L^{-T} x."""
 

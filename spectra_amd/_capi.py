@@ -136,6 +136,18 @@ SIGNATURES = {
     "mispec_symeigs_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vpp]),
     "mispec_symeigs_create_op": (C.c_int, [_vp, op_fn, _vp, C.c_int64, C.c_int64, C.c_int64, _vpp]),
     "mispec_symeigs_create_shift": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_double, _vpp]),
+    "mispec_davidson_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, _vpp]),
+    "mispec_davidson_create_dense": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, _vpp]),
+    "mispec_davidson_create_device_op": (C.c_int, [_vp, device_op_fn, _vp, C.c_int64, _dp, C.c_int64, C.c_int64, C.c_int64, _vpp]),
+    "mispec_davidson_destroy": (C.c_int, [_vp]),
+    "mispec_davidson_set_sizes": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64]),
+    "mispec_davidson_get_sizes": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "mispec_davidson_compute": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_double, _dp, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),
+    "mispec_davidson_info": (C.c_int, [_vp]),
+    "mispec_davidson_num_iterations": (C.c_int64, [_vp]),
+    "mispec_davidson_num_operations": (C.c_int64, [_vp]),
+    "mispec_davidson_eigenvalues": (C.c_int, [_vp, _dp]),
+    "mispec_davidson_eigenvectors": (C.c_int, [_vp, _dp, C.c_int64]),
     "mispec_symeigs_create_dense": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vpp]),
     "mispec_symeigs_create_device_op": (C.c_int, [_vp, device_op_fn, _vp, C.c_int64, C.c_int64, C.c_int64, _vpp]),
     "mispec_symeigs_create_product": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int64, _vpp]),

@@ -4,6 +4,7 @@
 //     g++ -std=c++17 -I include tests/cpp/dropin_symeigs.cpp -L spectra_amd -lmispec -Wl,-rpath,$PWD/spectra_amd
 // It needs a GPU to run (tests/test_gpu_cpp_dropin.py).  Eigen is not available here, so matrices are handed
 // over as Spectra::SparseView and results come back as Spectra::DenseVector / DenseMatrix.
+#include <Spectra/DavidsonSymEigsSolver.h>
 #include <Spectra/GenEigsRealShiftSolver.h>
 #include <Spectra/GenEigsSolver.h>
 #include <Spectra/MatOp/DenseGenMatProd.h>
@@ -263,6 +264,64 @@ static void run_device_op(const Csc& A, int k, int m)
     REQUIRE(nconv == k);
     REQUIRE(err < 1e-9);
     REQUIRE(op.calls == (int) eigs.num_operations());
+}
+
+// test/DavidsonSymEigs.cpp:46-123: the sparse fixture (diagonal i + 1, off-diagonal 0.1 (u - 0.5) with probability 0.5),
+// nev = 10, largest and smallest eigenvalues, ||AU - UD||_inf < 1e-10
+static Csc gen_davidson_sparse(int n)
+{
+    std::default_random_engine gen;
+    gen.seed(0);
+    std::uniform_real_distribution<double> distr(0.0, 1.0);
+    std::vector<std::vector<std::pair<int, double>>> cols(n);
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++)
+        {
+            bool have = false;
+            double v = 0.0;
+            if (distr(gen) < 0.5)
+            {
+                v = 0.1 * (distr(gen) - 0.5);
+                have = true;
+            }
+            if (i == j)
+            {
+                v = i + 1;
+                have = true;
+            }
+            if (have)
+                cols[j].push_back(std::make_pair(i, v));
+        }
+    Csc A;
+    A.n = n;
+    A.colptr.push_back(0);
+    for (int j = 0; j < n; j++)
+    {
+        for (const auto& e : cols[j])
+        {
+            A.rowind.push_back(e.first);
+            A.val.push_back(e.second);
+        }
+        A.colptr.push_back((int) A.rowind.size());
+    }
+    return A;
+}
+
+static void run_davidson(int n, int k)
+{
+    const Csc A = gen_davidson_sparse(n);
+    SparseSymMatProd<double> op(A.view());
+    const SortRule rules[] = {SortRule::LargestAlge, SortRule::SmallestAlge};
+    for (SortRule rule : rules)
+    {
+        DavidsonSymEigsSolver<SparseSymMatProd<double>> eigs(op, k);
+        const int nconv = (int) eigs.compute(rule);
+        REQUIRE(eigs.info() == CompInfo::Successful);
+        const double err = residual(A, eigs.eigenvalues(), eigs.eigenvectors());
+        std::printf("davidson n=%d rule=%d nconv=%d niter=%d ||AU-UD||_inf=%.3e\n", n, (int) rule, nconv, (int) eigs.num_iterations(), err);
+        REQUIRE(nconv == k);
+        REQUIRE(err < 1e-10);  // test/DavidsonSymEigs.cpp:89
+    }
 }
 
 // test/SymGEigsRegInv.cpp:35-106: A = sprand(n, prob) (lower triangle used), B = A'A + 0.1 I, regular-inverse mode;
@@ -546,6 +605,7 @@ int main()
         run_svd(100, 1000, 5, 10);  // :116-125 (wide sparse)
         run_dense(gen_sparse_data(100, 0.1), 10, 20);        // test/SymEigs.cpp:111-120 shape, dense operators
         run_device_op(gen_sparse_data(1000, 0.01), 20, 50);  // user operator on device pointers
+        run_davidson(1000, 10);                              // test/DavidsonSymEigs.cpp:116-122
 
         // constructor argument checks throw std::invalid_argument like the reference (HermEigsBase.h:267-271)
         bool threw = false;

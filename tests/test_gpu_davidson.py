@@ -1,0 +1,120 @@
+"""DavidsonSymEigsSolver (block Davidson, DPR correction) through the C ABI against the numpy oracle and the reference's
+own test bar (test/DavidsonSymEigs.cpp:69-123: nconv == nev, Successful, ||AU - UD||_inf < 1e-10)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import spectra_amd as sa
+from oracle import davidson as OD
+from test_oracle_davidson import davidson_sparse_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def check(eigs, S, k, rule, ref):
+    nconv = eigs.compute(sa.SortRule[rule])
+    assert nconv == k and eigs.info() == sa.CompInfo.Successful
+    evals, evecs = eigs.eigenvalues(), eigs.eigenvectors()
+    assert np.abs(S @ evecs - evecs * evals).max() < 1e-10          # the reference's bar
+    assert np.abs(evecs.T @ evecs - np.eye(k)).max() < 1e-9
+    assert np.abs(evals - ref.eigenvalues()).max() < 1e-9           # oracle parity
+    # same algorithm, different orthogonalisation arithmetic: iteration counts equal or off by a few
+    assert abs(eigs.num_iterations() - ref.num_iterations()) <= 3
+
+
+@pytest.mark.parametrize("rule", ["LargestAlge", "SmallestAlge"])
+def test_reference_sparse_fixture(ctx, rule):
+    n, k = 1000, 10
+    A, S = davidson_sparse_fixture(n)
+    ref = OD.DavidsonSymEigsSolver(S, k)
+    assert ref.compute(getattr(OD, rule)) == k
+    check(sa.DavidsonSymEigsSolver(sa.SparseSymMatProd(A, ctx=ctx), k), S, k, rule, ref)
+
+
+@pytest.mark.parametrize("rule", ["LargestAlge", "SmallestAlge", "LargestMagn", "BothEnds"])
+def test_dense_matrix(ctx, rule):
+    # gen_sym_data_dense's recipe (test/DavidsonSymEigs.cpp:33-43), seeded numpy instead of Eigen's Random
+    n, k = 1000, 10
+    rng = np.random.default_rng(123)
+    M = 0.03 * rng.uniform(-1, 1, (n, n))
+    A = M + M.T + np.diag(np.arange(1, n + 1, dtype=float))
+    ref = OD.DavidsonSymEigsSolver(A, k)
+    assert ref.compute(getattr(OD, rule)) == k
+    check(sa.DavidsonSymEigsSolver(sa.DenseSymMatProd(A, ctx=ctx), k), A, k, rule, ref)
+
+
+@pytest.mark.parametrize("max_size", [16, 20])
+def test_sizes_restarts_and_guess(ctx, max_size):
+    # the reference fixture's recipe at n = 600 (dense coupling: with sparse coupling a start vector can be an exact
+    # eigenvector of the projected problem and the reference's correction divides 0 by 0).  max_size = 12 (a restart
+    # every other iteration, each dropping the block just added — JDSymEigsBase.h:148-153) is left out on purpose: in
+    # that regime the reference algorithm itself is chaotic — 1e-15 relative noise on the corrections moves the numpy
+    # oracle between 31 and 49 iterations and sometimes past maxit.
+    n, k = 600, 4
+    rng = np.random.default_rng(9)
+    M = 0.05 * rng.uniform(-1, 1, (n, n)) * (rng.uniform(size=(n, n)) < 0.5)
+    S = np.tril(M, -1)
+    S = S + S.T + np.diag(np.arange(1, n + 1, dtype=float))
+    op = sa.SparseSymMatProd(sp.csc_matrix(np.tril(S)), ctx=ctx)
+    eigs = sa.DavidsonSymEigsSolver(op, k)
+    assert eigs.sizes() == (2 * k, 10 * k, k)                       # JDSymEigsBase.h:70-82 defaults
+    eigs.set_max_search_space_size(max_size)                        # small space: forces restarts
+    eigs.set_initial_search_space_size(2 * k)
+    eigs.set_correction_size(k)
+    assert eigs.sizes() == (2 * k, max_size, k)
+    ref = OD.DavidsonSymEigsSolver(S, k)
+    ref.max_size = max_size
+    assert ref.compute(OD.LargestAlge) == k and ref.num_iterations() >= 6  # with restarts
+    nconv = eigs.compute(sa.SortRule.LargestAlge)
+    assert nconv == k and eigs.info() == sa.CompInfo.Successful
+    assert np.abs(eigs.eigenvalues() - ref.eigenvalues()).max() < 1e-9
+    assert abs(eigs.num_iterations() - ref.num_iterations()) <= max(3, ref.num_iterations() // 5)
+    assert eigs.num_operations() >= 2 * k
+    # compute_with_guess: a perturbed exact invariant subspace
+    w, U = np.linalg.eigh(S)
+    guess = U[:, -2 * k:] + 1e-4 * rng.uniform(-1, 1, (n, 2 * k))
+    assert eigs.compute_with_guess(guess, sa.SortRule.LargestAlge) == k
+    assert np.abs(eigs.eigenvalues() - w[::-1][:k]).max() < 1e-9
+    # too few iterations: NotConverging, like the reference (JDSymEigsBase.h:171-175)
+    few = sa.DavidsonSymEigsSolver(op, k)
+    assert few.compute(sa.SortRule.LargestAlge, maxit=2) < k and few.info() == sa.CompInfo.NotConverging
+
+
+def test_errors(ctx):
+    A = sp.diags(np.arange(1.0, 21.0)).tocsc()
+    op = sa.SparseSymMatProd(A, ctx=ctx)
+    with pytest.raises(ValueError):
+        sa.DavidsonSymEigsSolver(op, 20)                                # nev <= n - 1
+    big = sa.SparseSymMatProd(sp.diags(np.arange(1.0, 1001.0)).tocsc(), ctx=ctx)
+    with pytest.raises(ValueError):
+        sa.DavidsonSymEigsSolver(big, 20).compute()                     # 10 nev + nev > 128 device columns
+    with pytest.raises(ValueError):
+        sa.DavidsonSymEigsSolver(big, 3).compute(sa.SortRule.LargestReal)  # a complex-only rule
+
+
+def test_device_operator_with_diagonal(ctx):
+    n, k = 1000, 5
+    A, S = davidson_sparse_fixture(n)
+    mat = sa.SparseSymMatProd(A, ctx=ctx)
+    dop = sa.DeviceOp(n, lambda x, y, s: mat.spmv_device(x, y), ctx=ctx)
+    eigs = sa.DavidsonSymEigsSolver(dop, k, diagonal=S.diagonal())
+    assert eigs.compute(sa.SortRule.SmallestAlge) == k
+    evals, evecs = eigs.eigenvalues(), eigs.eigenvectors()
+    assert np.abs(S @ evecs - evecs * evals).max() < 1e-10
+    assert np.abs(evals - np.linalg.eigvalsh(S.toarray())[:k]).max() < 1e-9
+
+
+def test_at_scale_band_matrix(ctx):
+    # size-independent check at n = 4e5 (the oracle would need minutes): residuals and orthonormality on a banded
+    # matrix with the reference fixtures' diagonal ramp (a_ii = i + 1)
+    n, k = 400_000, 6
+    rng = np.random.default_rng(2)
+    diags = [0.01 * rng.uniform(-1, 1, n - o) for o in (1, 2, 1000)]
+    L = sp.diags([np.arange(1.0, n + 1.0)] + diags, [0, -1, -2, -1000], format="csc")
+    S = (L + sp.tril(L, -1).T).tocsr()
+    eigs = sa.DavidsonSymEigsSolver(sa.SparseSymMatProd(L, ctx=ctx), k)
+    nconv = eigs.compute(sa.SortRule.LargestAlge, maxit=200, tol=1e-8)
+    assert nconv == k and eigs.info() == sa.CompInfo.Successful
+    evals, evecs = eigs.eigenvalues(), eigs.eigenvectors()
+    assert np.linalg.norm(S @ evecs - evecs * evals, axis=0).max() < 1e-8
+    assert np.abs(evecs.T @ evecs - np.eye(k)).max() < 1e-9
