@@ -63,7 +63,7 @@ template <typename T, typename = void>
 struct has_device_geigs_cholesky : std::false_type
 {};
 template <typename T>
-struct has_device_geigs_cholesky<T, void_t<decltype(std::declval<const T&>().mispec_geigs_cholesky_factor())>> : std::true_type
+struct has_device_geigs_cholesky<T, void_t<decltype(std::declval<const T&>().mispec_geigs_cholesky_matrix())>> : std::true_type
 {};
 template <typename T, typename = void>
 struct has_device_geigs_shift : std::false_type

@@ -4,6 +4,7 @@
 #ifndef MISPEC_SPECTRA_SYM_GEIGS_CHOLESKY_OP_H
 #define MISPEC_SPECTRA_SYM_GEIGS_CHOLESKY_OP_H
 
+#include <utility>
 #include <vector>
 
 #include "../SparseCholesky.h"
@@ -37,9 +38,14 @@ public:
         m_Bop.lower_triangular_solve(m_cache.data(), y_out);
     }
 
-    // device hooks
+    // device hooks.  The matrix hook exists only when A is a device CSR operator (SparseSymMatProd): the factorisation
+    // then runs y = L^{-1} A L^{-T} x entirely in HBM; any other A (e.g. DenseSymMatProd) goes through perform_op above.
     mispec_ctx* mispec_context() const { return m_op.mispec_context(); }
-    const mispec_csr* mispec_geigs_cholesky_matrix() const { return m_op.mispec_matrix(); }
+    template <typename T = OpType>
+    auto mispec_geigs_cholesky_matrix() const -> decltype(std::declval<const T&>().mispec_matrix())
+    {
+        return m_op.mispec_matrix();
+    }
     const mispec_cholesky* mispec_geigs_cholesky_factor() const { return m_Bop.mispec_factor(); }
 };
 

@@ -1070,6 +1070,37 @@ class GenEigsRealShiftSolver(GenEigsSolver):
     def __init__(self, op, nev, ncv, sigma):
         super().__init__(_GenShiftBinding(op, sigma), nev, ncv)
 
+def _dense_as_csc(mat, name):
+    """The compressed form of a dense host matrix (exact zeros dropped): what the device factorisations ingest."""
+    import scipy.sparse as sp
+
+    M = np.asarray(mat, dtype=np.float64)
+    if M.ndim != 2 or M.shape[0] != M.shape[1]:
+        raise ValueError(f"{name}: matrix must be square")
+    return sp.csc_matrix(M)
+
+
+class DenseSymShiftSolve(SparseSymShiftSolve):
+    """MatOp/DenseSymShiftSolve.h: y = (A - sigma I)^{-1} x for a dense symmetric A (the `uplo` triangle is read)."""
+
+    def __init__(self, mat, uplo="L", ctx=None):
+        super().__init__(_dense_as_csc(mat, "DenseSymShiftSolve"), uplo, ctx)
+
+
+class DenseGenRealShiftSolve(SparseGenRealShiftSolve):
+    """MatOp/DenseGenRealShiftSolve.h: y = (A - sigma I)^{-1} x for a general dense A and a real shift (n <= 4096)."""
+
+    def __init__(self, mat, ctx=None):
+        super().__init__(_dense_as_csc(mat, "DenseGenRealShiftSolve"), ctx)
+
+
+class DenseCholesky(SparseCholesky):
+    """MatOp/DenseCholesky.h: B = L L' for a dense positive-definite B (n <= 4096)."""
+
+    def __init__(self, mat, uplo="L", ctx=None):
+        super().__init__(_dense_as_csc(mat, "DenseCholesky"), uplo, ctx)
+
+
 def hess_qr(H, shift):
     """UpperHessenbergQR on the host (the general restart's real-shift step): returns (Q, Q'HQ)."""
     H = np.asfortranarray(H, dtype=np.float64)

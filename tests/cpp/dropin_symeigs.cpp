@@ -7,7 +7,10 @@
 #include <Spectra/DavidsonSymEigsSolver.h>
 #include <Spectra/GenEigsRealShiftSolver.h>
 #include <Spectra/GenEigsSolver.h>
+#include <Spectra/MatOp/DenseCholesky.h>
 #include <Spectra/MatOp/DenseGenMatProd.h>
+#include <Spectra/MatOp/DenseGenRealShiftSolve.h>
+#include <Spectra/MatOp/DenseSymShiftSolve.h>
 #include <Spectra/MatOp/DenseSymMatProd.h>
 #include <Spectra/MatOp/SparseGenMatProd.h>
 #include <Spectra/MatOp/SparseSymMatProd.h>
@@ -230,6 +233,80 @@ static void run_dense(const Csc& A, int k, int m)
     std::printf("dense-gen n=%d nconv=%d nops=%d ||AU-UD||_inf=%.3e\n", A.n, gconv, (int) geigs.num_operations(), gerr);
     REQUIRE(gconv >= k - 1);
     REQUIRE(gerr < 1e-9);
+}
+
+// The dense forms of the shift-and-invert and Cholesky operators (MatOp/DenseSymShiftSolve.h, DenseGenRealShiftSolve.h,
+// DenseCholesky.h) on the sparse fixtures scattered into dense arrays — test/SymEigsShift.cpp:112-158,
+// test/GenEigsRealShift.cpp:110-146 and test/SymGEigsCholesky.cpp:120-170 use dense matrices of these shapes.
+static Csc gram_plus_ridge(const Csc& A);
+static double pencil_residual(const Csc& P, const Csc& Q, const DenseVector<double>& evals, const DenseMatrix<double>& U);
+
+static DenseMatrix<double> scatter(const Csc& A)
+{
+    DenseMatrix<double> M(A.n, A.n);
+    for (int j = 0; j < A.n; j++)
+    {
+        for (int i = 0; i < A.n; i++)
+            M(i, j) = 0.0;
+        for (int p = A.colptr[j]; p < A.colptr[j + 1]; p++)
+            M(A.rowind[p], j) += A.val[p];
+    }
+    return M;
+}
+
+static void run_dense_shift_and_cholesky(int n, double prob, int k, int m)
+{
+    const Csc A = gen_sparse_data(n, prob);
+    const DenseMatrix<double> M = scatter(A);
+    {
+        DenseSymShiftSolve<double> op{DenseView<double>(M)};
+        SymEigsShiftSolver<DenseSymShiftSolve<double>> eigs(op, k, m, 10.0);
+        eigs.init();
+        const int nconv = (int) eigs.compute(SortRule::LargestMagn, 500);
+        REQUIRE(eigs.info() == CompInfo::Successful);
+        const double err = residual(A, eigs.eigenvalues(), eigs.eigenvectors());
+        std::printf("dense-shift n=%d nconv=%d nops=%d ||AU-UD||_inf=%.3e\n", n, nconv, (int) eigs.num_operations(), err);
+        REQUIRE(nconv == k);
+        REQUIRE(err < 1e-9);
+    }
+    {
+        DenseGenRealShiftSolve<double> op{DenseView<double>(M)};
+        GenEigsRealShiftSolver<DenseGenRealShiftSolve<double>> eigs(op, k, m + 10, 10.0);
+        eigs.init();
+        const int nconv = (int) eigs.compute(SortRule::LargestMagn, 500);
+        REQUIRE(eigs.info() == CompInfo::Successful);
+        const auto evals = eigs.eigenvalues();
+        const auto U = eigs.eigenvectors();
+        double err = 0.0;
+        for (Index c = 0; c < U.cols(); c++)
+            for (int i = 0; i < n; i++)
+            {
+                std::complex<double> y = 0.0;
+                for (int j = 0; j < n; j++)
+                    y += M(i, j) * U(j, c);
+                err = std::fmax(err, std::abs(y - evals[c] * U(i, c)));
+            }
+        std::printf("dense-gen-realshift n=%d nconv=%d nops=%d ||AU-UD||_inf=%.3e\n", n, nconv, (int) eigs.num_operations(), err);
+        REQUIRE(nconv >= k - 1);
+        REQUIRE(err < 1e-8);
+    }
+    {
+        // dense A and dense B = A'A + 0.1 I in Cholesky mode: the operator falls back to the host-pointer path of
+        // SymGEigsCholeskyOp (three staged products per step), the Krylov basis stays in HBM
+        const Csc B = gram_plus_ridge(A);
+        const DenseMatrix<double> MB = scatter(B);
+        DenseSymMatProd<double> op{DenseView<double>(M)};
+        DenseCholesky<double> Bop{DenseView<double>(MB)};
+        REQUIRE(Bop.info() == CompInfo::Successful);
+        SymGEigsSolver<DenseSymMatProd<double>, DenseCholesky<double>, GEigsMode::Cholesky> eigs(op, Bop, k, m);
+        eigs.init();
+        const int nconv = (int) eigs.compute(SortRule::LargestAlge, 100);
+        REQUIRE(eigs.info() == CompInfo::Successful);
+        const double err = pencil_residual(A, B, eigs.eigenvalues(), eigs.eigenvectors());
+        std::printf("dense-geigs-cholesky n=%d nconv=%d nops=%d ||AU-BUD||_inf=%.3e\n", n, nconv, (int) eigs.num_operations(), err);
+        REQUIRE(nconv == k);
+        REQUIRE(err < 1e-9);
+    }
 }
 
 // A user operator that works on DEVICE pointers: perform_op_device(x_dev, y_dev, stream) is the reference's
@@ -606,6 +683,7 @@ int main()
         run_dense(gen_sparse_data(100, 0.1), 10, 20);        // test/SymEigs.cpp:111-120 shape, dense operators
         run_device_op(gen_sparse_data(1000, 0.01), 20, 50);  // user operator on device pointers
         run_davidson(1000, 10);                              // test/DavidsonSymEigs.cpp:116-122
+        run_dense_shift_and_cholesky(100, 0.1, 10, 20);      // dense shift-and-invert / Cholesky operators
 
         // constructor argument checks throw std::invalid_argument like the reference (HermEigsBase.h:267-271)
         bool threw = false;

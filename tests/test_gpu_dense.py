@@ -198,3 +198,43 @@ def test_dense_gemv_rate_at_scale(ctx):
     gbps = op.algorithmic_bytes() / (ms * 1e-3) / 1e9
     print(f"dense GEMV n={n}: {ms:.3f} ms, {gbps:.0f} GB/s")
     assert gbps > 1500  # HBM-bound kernel; anything far below means the row streaming broke
+
+
+def test_dense_shift_solve_and_cholesky_operators(ctx):
+    # MatOp/DenseSymShiftSolve.h, DenseGenRealShiftSolve.h, DenseCholesky.h: dense inputs through the device
+    # factorisations; shapes of test/SymEigsShift.cpp:112-158, test/GenEigsRealShift.cpp:110-146, test/SymGEigsCholesky.cpp
+    n, k, m = 100, 10, 30
+    M, S = sym_dense(n, 77)
+    sigma = 0.5
+    op = sa.DenseSymShiftSolve(M, ctx=ctx)
+    op.set_shift(sigma)
+    x = np.random.default_rng(3).uniform(-1, 1, n)
+    y = op.perform_op(x)
+    assert np.abs((S - sigma * np.eye(n)) @ y - x).max() < 1e-10
+    eigs = sa.SymEigsShiftSolver(sa.DenseSymShiftSolve(M, ctx=ctx), k, m, sigma)
+    eigs.init()
+    assert eigs.compute(sa.SortRule.LargestMagn) == k
+    evals, evecs = eigs.eigenvalues(), eigs.eigenvectors()
+    assert np.abs(S @ evecs - evecs * evals).max() < 1e-9
+    full = np.linalg.eigvalsh(S)
+    near = full[np.argsort(np.abs(full - sigma))[:k]]
+    assert np.abs(np.sort(evals) - np.sort(near)).max() < 1e-9
+    # general real shift
+    G = np.random.default_rng(5).uniform(-1, 1, (n, n))
+    ge = sa.GenEigsRealShiftSolver(sa.DenseGenRealShiftSolve(G, ctx=ctx), k, m, 1.0)
+    ge.init()
+    assert ge.compute(sa.SortRule.LargestMagn) >= k - 1
+    ev, U = ge.eigenvalues(), ge.eigenvectors()
+    assert np.abs(G @ U - U * ev).max() < 1e-8
+    # Cholesky mode with a sparse A and a dense B
+    A, Sa = sparse_fixture(n, 0.1)
+    Bd = (Sa.T @ Sa).toarray() + 0.1 * np.eye(n)
+    B = sa.DenseCholesky(Bd, ctx=ctx)
+    assert B.info() == sa.CompInfo.Successful
+    g = sa.SymGEigsSolver(sa.SparseSymMatProd(A, ctx=ctx), B, 10, 20, mode="Cholesky")
+    g.init()
+    assert g.compute(sa.SortRule.LargestAlge) == 10
+    lam, X = g.eigenvalues(), g.eigenvectors()
+    assert np.abs(Sa @ X - Bd @ X * lam).max() < 1e-9
+    with pytest.raises(ValueError):
+        sa.DenseCholesky(np.zeros((3, 4)), ctx=ctx)
