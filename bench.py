@@ -76,9 +76,9 @@ def cpu_baseline(args, gpu_nops, gpu_nconv):
     }
 
 
-def pmc_traffic(n, coded):
-    """HBM bytes per launch of the fused SpMV (offset-coded or int32-index instantiation, whichever the solve used) as
-    measured by the committed PMC passes (tools/pmc_summarize.py), or None."""
+def pmc_traffic(n, fmt):
+    """HBM bytes per launch of the fused SpMV (the instantiation the solve used: 0 int32 indices, 1 offset codes,
+    2 diagonal storage) as measured by the committed PMC passes (tools/pmc_summarize.py), or None."""
     import glob
 
     here = os.path.dirname(os.path.abspath(__file__))
@@ -91,7 +91,9 @@ def pmc_traffic(n, coded):
             for name, rec in d["kernels"].items():
                 args_ = name.split("<", 1)[1].rstrip(">").split(",") if "<" in name else []
                 is_coded = len(args_) >= 4 and args_[3].strip() == "true"
-                if name.startswith("k_spmv_csr_stream<true") and is_coded == bool(coded):
+                if fmt == 2 and name.startswith("k_spmv_dia<true"):
+                    return float(rec["hbm_bytes"])
+                if fmt != 2 and name.startswith("k_spmv_csr_stream<true") and is_coded == (fmt == 1):
                     return float(rec["hbm_bytes"])
         except Exception:  # noqa: BLE001 - a malformed summary just means "no PMC figure"
             continue
@@ -223,21 +225,22 @@ def main():
                 "parallelism": f"row-shard x{world}" + exchange_desc,
             },
             "roofline": {
-                "kernel": "k_spmv_csr_stream (CSR SpMV fused with w -= beta*v_prev and the alpha dot)",
+                "kernel": ("k_spmv_dia" if op.spmv_format() == 2 else "k_spmv_csr_stream") + " (SpMV fused with w -= beta*v_prev and the alpha dot)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": pmc_traffic(args.n, op.offset_codes() > 0) if world == 1 else None,
+                "traffic": pmc_traffic(args.n, op.spmv_format()) if world == 1 else None,
                 "traffic_source": "bytes per launch of the in-loop SpMV from the newest profiles/*pmc_traffic.json "
                                   "(rocprofv3 PMC passes need their own profiler run; see profiles/README.md)",
                 "bytes_per_launch": spmv_bytes,
                 "bytes_note": "algorithmic bytes of a CSR SpMV with int32 indices: 12 nnz + 4 (rows+1) + 8 cols + 8 rows (SURVEY.md 8d)",
                 # what this matrix's index format makes the kernel move at least (x once): with offset codes the column
                 # index costs 1 byte instead of 4, so `achieved` can exceed what the same time buys in raw HBM bytes
-                "index_format": (f"offset codes: 1 byte per entry into {op.offset_codes()} diagonals" if op.offset_codes() > 0
-                                 else "int32 column indices"),
+                "index_format": {0: "CSR, int32 column indices",
+                                 1: f"CSR, offset codes: 1 byte per entry into {op.offset_codes()} diagonals",
+                                 2: f"diagonal storage: {op.offset_codes()} diagonals, no index, no gather"}[op.spmv_format()],
                 "stored_bytes_per_launch": op.stored_bytes(),
                 "stored_gbps": op.stored_bytes() / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0,
                 "ms_per_launch": spmv_ms,

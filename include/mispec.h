@@ -123,6 +123,13 @@ int mispec_csr_offset_codes(const mispec_csr* A);
 /* Per-matrix switch between the two index formats (both give bit-identical products); no effect when the matrix
  * has no dictionary. */
 int mispec_csr_use_offset_codes(mispec_csr* A, int enable);
+/* Storage format the SpMV uses for this shard: 0 = CSR with int32 column indices, 1 = CSR with offset codes, 2 = diagonal
+ * storage (values kept diagonal-major, no index and no gather; chosen when the dictionary has <= 32 diagonals that are
+ * at least 3/4 full, rows sorted, no duplicate entries; MISPEC_SPMV_DIA=0 turns it off).  All three give bit-identical
+ * products for finite x (the diagonal format multiplies x by explicit zeros where the matrix has no entry).
+ * mispec_csr_set_spmv_format forces a format for this matrix (-1 = automatic; a format that was not built falls back). */
+int mispec_csr_spmv_format(const mispec_csr* A);
+int mispec_csr_set_spmv_format(mispec_csr* A, int format);
 /* Bytes one SpMV with this shard has to move, x counted once.  stored = 0: the CSR/int32 figure
  * 12 nnz + 4 (rows+1) + 8 cols + 8 rows that roofline numbers are quoted on; stored != 0: with the index format in use. */
 double mispec_csr_spmv_bytes(const mispec_csr* A, int stored);

@@ -190,6 +190,14 @@ class _DeviceMatrix:
     def use_offset_codes(self, enable=True):
         check(lib().mispec_csr_use_offset_codes(self.h, 1 if enable else 0))
 
+    def spmv_format(self):
+        """0: CSR with int32 column indices, 1: CSR with offset codes, 2: diagonal storage — what the SpMV uses."""
+        return int(lib().mispec_csr_spmv_format(self.h))
+
+    def set_spmv_format(self, fmt=-1):
+        """Force a storage format for this matrix (-1: automatic); all formats give bit-identical products."""
+        check(lib().mispec_csr_set_spmv_format(self.h, int(fmt)))
+
     def stored_bytes(self):
         """Compulsory SpMV traffic with the index format in use (9 instead of 12 bytes per entry with offset codes)."""
         return float(lib().mispec_csr_spmv_bytes(self.h, 1))

@@ -19,6 +19,11 @@
 //     The row of an entry is found through a byte table that the row-owning threads write into LDS
 //     while the streaming loads are in flight (it aliases the product buffer, which is not live yet);
 //     products and summation order are unchanged, so the result is bit-identical to the plain kernel.
+//   * diagonal variant (k_spmv_dia): when the dictionary has at most 32 diagonals and they are at least 3/4 full,
+//     the values are also kept diagonal-major (dia[k][row], zero where the matrix has no entry) and
+//     y[r] = sum_k dia[k][r] * x[r + off_k] in ascending offset order — no index, no gather, no LDS, every load
+//     coalesced, 8 bytes per stored slot.  Same products in the same order as the CSR row sum (absent entries add 0), so
+//     again bit-identical.
 // Bound: HBM.  Algorithmic bytes per launch: 12*nnz + 4*(rows+1) + 8*cols + 8*rows (CSR with int32
 // indices); the offset-coded variant's compulsory traffic is 9*nnz + ... .
 #include "csr.hpp"
@@ -256,6 +261,109 @@ __global__ __launch_bounds__(kThreads) void k_spmv_csr_stream(const int32_t* __r
         y[row0 + tid] = acc;
 }
 
+// ---- diagonal storage -----------------------------------------------------------------------------------------------
+constexpr int kMaxDia = 32;      // diagonals of the diagonal format
+constexpr int kDiaGroup = 8;     // loads issued together per thread: 8 values + 8 x entries
+
+// One thread per row: scatter the row's values into the diagonal-major array.  `pos_of_code` maps a dictionary code to the
+// rank of its offset.  Within a row the ranks must increase strictly (columns sorted, no duplicates), else the diagonal
+// sum would not be the CSR row sum bit for bit: such matrices raise *bad and keep the CSR kernels.
+__global__ __launch_bounds__(256) void k_build_dia(const int32_t* __restrict__ rowptr, const uint8_t* __restrict__ codes,
+                                                   const double* __restrict__ val, const int32_t* __restrict__ pos_of_code,
+                                                   int64_t nloc, int64_t ld, double* __restrict__ dia, int* __restrict__ bad)
+{
+    const int64_t r = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (r >= nloc)
+        return;
+    int last = -1;
+    for (int p = rowptr[r]; p < rowptr[r + 1]; p++)
+    {
+        const int pos = pos_of_code[codes[p]];
+        if (pos <= last)
+            *bad = 1;
+        last = pos;
+        dia[int64_t(pos) * ld + r] = val[p];
+    }
+}
+
+// acc + a*b with the product rounded before the sum, as the CSR kernels do it (their products pass through LDS)
+__device__ __forceinline__ double add_rounded_product(double acc, double a, double b)
+{
+#pragma clang fp contract(off)
+    const double p = a * b;
+    return acc + p;
+}
+
+struct DiaArgs
+{
+    const double* dia;
+    const int32_t* off;
+    int64_t ld;
+    int nd;
+    int col_max;
+    int64_t row_begin;
+};
+
+template <bool EPI>
+__global__ __launch_bounds__(256) void k_spmv_dia(DiaArgs da, const double* __restrict__ x, double* __restrict__ y, int64_t nrows,
+                                                  int nblocks, SpmvEpilogue epi)
+{
+    __shared__ int off_s[kMaxDia];
+    __shared__ double red[4];
+    // same XCD-aware row-block map and the same 256-row blocks as k_spmv_csr_stream: the alpha partials of the fused
+    // epilogue are identical records
+    const int per = (nblocks + 7) >> 3;
+    const int lb = (int(blockIdx.x) & 7) * per + (int(blockIdx.x) >> 3);
+    if (lb >= nblocks)
+        return;
+    if (EPI && epi.status && *epi.status != 0)
+        return;
+    const int tid = threadIdx.x;
+    if (tid < da.nd)
+        off_s[tid] = da.off[tid];
+    __syncthreads();
+    const int64_t row0 = int64_t(lb) * 256;
+    const int nr = int(min(int64_t(256), nrows - row0));
+    const int64_t r = row0 + min(tid, nr - 1);  // threads past the last row repeat it (their result is dropped)
+    const double* vrow = da.dia + r;
+    const int64_t grow = da.row_begin + r;
+    double acc = 0.0;
+    for (int g = 0; g < da.nd; g += kDiaGroup)
+    {
+        double v[kDiaGroup], xv[kDiaGroup];
+#pragma unroll
+        for (int u = 0; u < kDiaGroup; u++)
+        {
+            const int d = min(g + u, da.nd - 1);
+            v[u] = __builtin_nontemporal_load(vrow + int64_t(d) * da.ld);  // read once per SpMV
+            const int64_t c = grow + off_s[d];
+            xv[u] = x[min(max(c, int64_t(0)), int64_t(da.col_max))];  // out of range only where the value is a padding zero
+        }
+#pragma unroll
+        for (int u = 0; u < kDiaGroup; u++)
+            if (g + u < da.nd)
+                acc = add_rounded_product(acc, v[u], xv[u]);  // no FMA: bit-identical to the CSR row sum
+    }
+    if (EPI)
+    {
+        double contrib = 0.0;
+        if (tid < nr)
+        {
+            const int64_t row = row0 + tid;
+            double yv = acc;
+            if (epi.v_prev)
+                yv -= (epi.h_prev_dev ? *epi.h_prev_dev : epi.h_prev) * epi.v_prev[row];  // Lanczos.h:139
+            y[row] = yv;
+            contrib = epi.v_rows[row] * yv;  // Lanczos.h:142 partial <v, w>
+        }
+        const double total = block_reduce_sum(contrib, red);
+        if (tid == 0)
+            epi.partials[lb] = total;
+    }
+    else if (tid < nr)
+        y[row0 + tid] = acc;
+}
+
 // ---- synthetic band matrix, bit-identical to oracle/synth_matrix.h -------------
 __host__ __device__ inline uint64_t synth_mix64(uint64_t z)
 {
@@ -336,6 +444,51 @@ void alloc_codes(mispec_csr& A)
     const size_t cap = size_t(round_up(A.nnz, 4) + 8);
     A.codes.alloc(cap);
     MISPEC_HIP(hipMemsetAsync(A.codes.p, 0, cap, A.ctx->stream));
+}
+
+// Diagonal storage from the offset codes (device): only for small, well-filled dictionaries whose rows are sorted and free
+// of duplicates; anything else keeps the CSR kernels.  MISPEC_SPMV_DIA=0 turns the format off.
+void build_dia(mispec_csr& A, const std::vector<int32_t>& dict)
+{
+    static const bool on = getenv("MISPEC_SPMV_DIA") ? atoi(getenv("MISPEC_SPMV_DIA")) != 0 : true;
+    const int64_t nloc = A.local_rows();
+    const int nd = int(dict.size());
+    if (!on || nd == 0 || nd > kMaxDia || nloc == 0 || double(A.nnz) < 0.75 * double(nd) * double(nloc))
+        return;
+    std::vector<int32_t> order(static_cast<size_t>(nd)), pos(static_cast<size_t>(nd)), offs(static_cast<size_t>(nd));
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return dict[size_t(a)] < dict[size_t(b)]; });
+    for (int k = 0; k < nd; k++)
+    {
+        pos[size_t(order[size_t(k)])] = k;
+        offs[size_t(k)] = dict[size_t(order[size_t(k)])];
+    }
+    const int64_t ld = round_up(nloc, 2);
+    DevBuf<int32_t> d_pos;
+    DevBuf<int> d_bad;
+    d_pos.alloc(size_t(nd));
+    d_bad.alloc(1);
+    A.dia.alloc(size_t(ld) * size_t(nd));
+    A.dia_off.alloc(size_t(nd));
+    hipStream_t st = A.ctx->stream;
+    MISPEC_HIP(hipMemsetAsync(A.dia.p, 0, A.dia.n * sizeof(double), st));
+    MISPEC_HIP(hipMemsetAsync(d_bad.p, 0, sizeof(int), st));
+    MISPEC_HIP(hipMemcpyAsync(d_pos.p, pos.data(), pos.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    MISPEC_HIP(hipMemcpyAsync(A.dia_off.p, offs.data(), offs.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_build_dia, dim3(unsigned((nloc + 255) / 256)), dim3(256), 0, st, A.rowptr.p, A.codes.p, A.val.p, d_pos.p, nloc, ld,
+                       A.dia.p, d_bad.p);
+    MISPEC_HIP(hipGetLastError());
+    int bad = 0;
+    MISPEC_HIP(hipMemcpyAsync(&bad, d_bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    MISPEC_HIP(hipStreamSynchronize(st));
+    if (bad)
+    {
+        A.dia.release();
+        A.dia_off.release();
+        return;
+    }
+    A.dia_ld = ld;
+    A.ndia = nd;
 }
 
 // Host side of the offset-coded format: one byte per entry of rows [b, e) if the shard's entries lie on at most
@@ -425,6 +578,7 @@ mispec_csr* upload_rows(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const i
             MISPEC_HIP(hipMemcpyAsync(A->codes.p, codes.data(), codes.size(), hipMemcpyHostToDevice, ctx->stream));
             MISPEC_HIP(hipMemcpyAsync(A->dict.p, dict.data(), dict.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
             A->ndict = int(dict.size());
+            build_dia(*A, dict);
         }
         MISPEC_HIP(hipStreamSynchronize(ctx->stream));
     }
@@ -493,8 +647,26 @@ void launch_spmv(const mispec_csr& A, const double* x_dev, double* y_dev, const 
     const dim3 grid(unsigned(per * 8)), block(static_cast<unsigned>(threads));
     static const bool nt = getenv("MISPEC_SPMV_NT") ? atoi(getenv("MISPEC_SPMV_NT")) != 0 : false;
     const SpmvEpilogue e = epi ? *epi : SpmvEpilogue{};
-    const bool coded = A.ndict > 0 && A.use_codes && threads == 256 && spmv_codes_enabled();
+    const int format = A.spmv_format();
+    const bool coded = format == 1;
     const SpmvCodes cd{A.codes.p, A.dict.p, A.ndict, int(A.n_cols - 1), A.row_begin};
+    if (format == 2)
+    {
+        const DiaArgs da{A.dia.p, A.dia_off.p, A.dia_ld, A.ndia, int(A.n_cols - 1), A.row_begin};
+        if (ev_start && ev_stop)
+        {
+            if (epi)
+                hipExtLaunchKernelGGL(k_spmv_dia<true>, grid, block, 0, A.ctx->stream, ev_start, ev_stop, 0, da, x_dev, y_dev, nloc, nblocks, e);
+            else
+                hipExtLaunchKernelGGL(k_spmv_dia<false>, grid, block, 0, A.ctx->stream, ev_start, ev_stop, 0, da, x_dev, y_dev, nloc, nblocks, e);
+        }
+        else if (epi)
+            hipLaunchKernelGGL(k_spmv_dia<true>, grid, block, 0, A.ctx->stream, da, x_dev, y_dev, nloc, nblocks, e);
+        else
+            hipLaunchKernelGGL(k_spmv_dia<false>, grid, block, 0, A.ctx->stream, da, x_dev, y_dev, nloc, nblocks, e);
+        MISPEC_HIP(hipGetLastError());
+        return;
+    }
     // With an event pair the launch is timed through the dispatch's own completion signal (start/stop of the
     // kernel itself, as a profiler sees it) instead of marker packets around it.
 #define MISPEC_SPMV_LAUNCH(K)                                                                                          \
@@ -705,10 +877,11 @@ extern "C" int mispec_csr_synth_band(mispec_ctx* ctx, int64_t n, uint64_t seed, 
             const int64_t base = band_prefix(spec, n, b);
             alloc_entries(*A, band_prefix(spec, n, e) - base);
             A->rowptr.alloc(size_t(nloc) + 1);
+            std::vector<int32_t> dict;
             if (spmv_codes_enabled() && A->nnz > 0)
             {
                 alloc_codes(*A);
-                std::vector<int32_t> dict(offs.begin(), offs.end());
+                dict.assign(offs.begin(), offs.end());
                 A->dict.alloc(dict.size());
                 MISPEC_HIP(hipMemcpyAsync(A->dict.p, dict.data(), dict.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
                 MISPEC_HIP(hipStreamSynchronize(ctx->stream));  // dict is a local
@@ -720,6 +893,8 @@ extern "C" int mispec_csr_synth_band(mispec_ctx* ctx, int64_t n, uint64_t seed, 
                                symmetric, A->rowptr.p, A->colind.p, A->val.p, A->codes.p);
             MISPEC_HIP(hipGetLastError());
             MISPEC_HIP(hipStreamSynchronize(ctx->stream));
+            if (A->ndict > 0)
+                build_dia(*A, dict);
         }
         catch (...)
         {
@@ -744,9 +919,31 @@ extern "C" int64_t mispec_csr_rows(const mispec_csr* A) { return A ? A->n_rows :
 extern "C" int64_t mispec_csr_cols(const mispec_csr* A) { return A ? A->n_cols : 0; }
 extern "C" int64_t mispec_csr_local_rows(const mispec_csr* A) { return A ? A->local_rows() : 0; }
 extern "C" int64_t mispec_csr_local_nnz(const mispec_csr* A) { return A ? A->nnz : 0; }
+int mispec_csr::spmv_format() const
+{
+    const bool blocks256 = spmv_rows_per_block() == 256;
+    const bool can_codes = ndict > 0 && blocks256 && spmv_codes_enabled();
+    const bool can_dia = ndia > 0 && blocks256;
+    if (forced_format == 0 || !use_codes)
+        return 0;
+    if (forced_format == 1)
+        return can_codes ? 1 : 0;
+    if (forced_format == 2)
+        return can_dia ? 2 : (can_codes ? 1 : 0);
+    return can_dia ? 2 : (can_codes ? 1 : 0);
+}
+
 extern "C" int mispec_csr_offset_codes(const mispec_csr* A)
 {
-    return A && A->use_codes && spmv_codes_enabled() && spmv_rows_per_block() == 256 ? A->ndict : 0;
+    return A && A->use_codes && A->forced_format != 0 && spmv_codes_enabled() && spmv_rows_per_block() == 256 ? A->ndict : 0;
+}
+extern "C" int mispec_csr_spmv_format(const mispec_csr* A) { return A ? A->spmv_format() : 0; }
+extern "C" int mispec_csr_set_spmv_format(mispec_csr* A, int format)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(A && format >= -1 && format <= 2, "mispec_csr_set_spmv_format: format must be -1 (automatic), 0, 1 or 2");
+        A->forced_format = format;
+    });
 }
 extern "C" int mispec_csr_use_offset_codes(mispec_csr* A, int enable)
 {
@@ -759,7 +956,7 @@ extern "C" double mispec_csr_spmv_bytes(const mispec_csr* A, int stored)
 {
     if (!A)
         return 0.0;
-    return stored && mispec_csr_offset_codes(A) > 0 ? A->stored_bytes() : A->algorithmic_bytes();
+    return stored ? A->stored_bytes() : A->algorithmic_bytes();
 }
 
 extern "C" int mispec_csr_coeff(const mispec_csr* A, int64_t i, int64_t j, double* out)

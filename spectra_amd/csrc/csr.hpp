@@ -22,6 +22,14 @@ struct mispec_csr
     mispec::DevBuf<int32_t> dict;    // ndict distinct (col - global_row) values
     int ndict = 0;
     bool use_codes = true;           // mispec_csr_use_offset_codes: per-matrix switch (tests compare the two kernels)
+    // Diagonal storage (third format, built from the codes when the dictionary is small and the diagonals are well
+    // filled): dia[k * dia_ld + r] = A(r, r + dia_off[k]), diagonals sorted by offset, absent entries zero.  The SpMV
+    // then needs no index at all and no gather: 8 bytes per stored slot, every load coalesced.
+    mispec::DevBuf<double> dia;
+    mispec::DevBuf<int32_t> dia_off;
+    int64_t dia_ld = 0;
+    int ndia = 0;
+    int forced_format = -1;          // mispec_csr_set_spmv_format: -1 automatic, 0 int32 indices, 1 offset codes, 2 diagonals
     // staging for the host-pointer paths (allocated on first use)
     mutable mispec::DevBuf<double> stage_x, stage_y;
 
@@ -32,10 +40,18 @@ struct mispec_csr
         return 12.0 * double(nnz) + 4.0 * double(local_rows() + 1) + 8.0 * double(n_cols) + 8.0 * double(local_rows());
     }
     // what the SpMV actually has to move with the index format in use (compulsory traffic, x counted once)
+    // 0: int32 column indices, 1: offset codes, 2: diagonals — what launch_spmv will use for this matrix
+    int spmv_format() const;
+    double stored_bytes_for(int format) const
+    {
+        if (format == 2)
+            return 8.0 * double(ndia) * double(local_rows()) + 8.0 * double(n_cols) + 8.0 * double(local_rows());
+        const double per_entry = format == 1 ? 9.0 : 12.0;
+        return per_entry * double(nnz) + 4.0 * double(local_rows() + 1) + 8.0 * double(n_cols) + 8.0 * double(local_rows());
+    }
     double stored_bytes() const
     {
-        const double per_entry = ndict > 0 ? 9.0 : 12.0;
-        return per_entry * double(nnz) + 4.0 * double(local_rows() + 1) + 8.0 * double(n_cols) + 8.0 * double(local_rows());
+        return stored_bytes_for(spmv_format());
     }
 };
 

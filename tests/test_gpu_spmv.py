@@ -147,13 +147,20 @@ def test_spmv_linearity_at_full_size(ctx):
 
 # ---- offset-coded index format (one byte per entry, col = row + dict[code]) -------------------------------------
 def _both_formats(op, x):
-    """Product with the offset-coded kernel and with the plain int32 kernel of the same matrix."""
+    """The product in every storage format the matrix has: returns (offset-coded, int32); the diagonal format (when it
+    was built, it is the automatic choice) is asserted equal to the offset-coded one on the way."""
     assert op.offset_codes() > 0
+    auto = op.spmv_format()
+    y_auto = op.perform_op(x)
+    op.set_spmv_format(1)
+    assert op.spmv_format() == 1
     y_codes = op.perform_op(x)
-    op.use_offset_codes(False)
-    assert op.offset_codes() == 0
+    op.set_spmv_format(0)
+    assert op.spmv_format() == 0 and op.offset_codes() == 0
     y_plain = op.perform_op(x)
-    op.use_offset_codes(True)
+    op.set_spmv_format(-1)
+    assert op.spmv_format() == auto
+    assert np.array_equal(y_auto, y_codes)
     return y_codes, y_plain
 
 
@@ -161,9 +168,10 @@ def test_offset_codes_are_chosen_for_diagonal_structure_only(ctx):
     n = 5000
     band = sa.SparseSymMatProd.synth_band(n, offsets=(1, 2, 50), ctx=ctx)
     assert band.offset_codes() == 7 and band.stored_bytes() < band.algorithmic_bytes()
+    assert band.spmv_format() == 2  # few, full diagonals: diagonal storage
     A, _ = sparse_fixture(1000, 0.01)  # ~ 2000 distinct diagonals: stays on int32 indices
     op = sa.SparseSymMatProd(A, ctx=ctx)
-    assert op.offset_codes() == 0 and op.stored_bytes() == op.algorithmic_bytes()
+    assert op.offset_codes() == 0 and op.stored_bytes() == op.algorithmic_bytes() and op.spmv_format() == 0
 
 
 @pytest.mark.parametrize("n", [3, 255, 256, 257, 1000, 4097, 300000])
@@ -200,7 +208,7 @@ def test_offset_codes_from_host_uploads(ctx):
         M = G.asformat(fmt)
         M.sort_indices()
         gop = sa.SparseGenMatProd(M, ctx=ctx)
-        assert 0 < gop.offset_codes() <= 5
+        assert 0 < gop.offset_codes() <= 5 and gop.spmv_format() == 1  # 60 % filled diagonals: too sparse for diagonal storage
         Mr = M.tocsr()
         Mr.sort_indices()
         yc, yp = _both_formats(gop, x)
@@ -213,7 +221,7 @@ def test_offset_codes_with_rows_longer_than_the_lds_chunk_and_rectangular_shapes
     rng = np.random.default_rng(8)
     D = sp.csr_matrix(rng.uniform(-1, 1, (120, 120)))
     op = sa.SparseGenMatProd(D, ctx=ctx)
-    assert op.offset_codes() == 239
+    assert op.offset_codes() == 239 and op.spmv_format() == 1  # more than 32 diagonals
     x = rand_x(120, 6)
     yc, yp = _both_formats(op, x)
     assert np.array_equal(yc, yp) and np.array_equal(yc, O.Op.csr(120, 120, D.indptr, D.indices, D.data).perform_op(x))
@@ -223,14 +231,14 @@ def test_offset_codes_with_rows_longer_than_the_lds_chunk_and_rectangular_shapes
     R = sp.diags([rng.uniform(-1, 1, 700)] * 4, [0, 3, 650, 1299], shape=(700, 2000), format="csr")
     R.sort_indices()
     rop = sa.SparseGenMatProd(R, ctx=ctx)
-    assert rop.offset_codes() == 4
+    assert rop.offset_codes() == 4 and rop.spmv_format() == 2
     xr = rand_x(2000, 7)
     yc, yp = _both_formats(rop, xr)
     assert np.array_equal(yc, yp) and np.array_equal(yc, O.Op.csr(700, 2000, R.indptr, R.indices, R.data).perform_op(xr))
     Rt = R.T.tocsr()
     Rt.sort_indices()
     top = sa.SparseGenMatProd(Rt, ctx=ctx)
-    assert top.offset_codes() == 4
+    assert top.offset_codes() == 4 and top.spmv_format() == 1  # 2000 rows, 700 entries per diagonal: under 3/4 full
     xt = rand_x(700, 8)
     yc, yp = _both_formats(top, xt)
     assert np.array_equal(yc, yp) and np.array_equal(yc, O.Op.csr(2000, 700, Rt.indptr, Rt.indices, Rt.data).perform_op(xt))
@@ -268,15 +276,45 @@ def test_ragged_rows_and_empty_blocks_in_both_index_formats(ctx):
     assert np.array_equal(yc, O.Op.csr(n, n, B.indptr, B.indices, B.data).perform_op(x))
 
 
-def test_fused_epilogue_is_identical_in_both_index_formats():
+def test_fused_epilogue_is_identical_in_every_storage_format():
     # the Lanczos epilogue (w -= beta v_prev, alpha partials) rides on the SpMV: a full solve must not depend on the format
     n = 200_000
     res = []
-    for codes in (False, True):
+    for fmt in (0, 1, 2):
         op = sa.SparseSymMatProd.synth_band(n)
-        op.use_offset_codes(codes)
+        op.set_spmv_format(fmt)
+        assert op.spmv_format() == fmt
         eigs = sa.SymEigsSolver(op, 6, 20)
         eigs.init()
         eigs.compute(sa.SortRule.LargestMagn, tol=1e-11)
         res.append((eigs.eigenvalues(), eigs.num_operations()))
-    assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
+    for ev, nops in res[1:]:
+        assert np.array_equal(ev, res[0][0]) and nops == res[0][1]
+
+
+def test_diagonal_storage_needs_sorted_rows_without_duplicates(ctx):
+    # through the raw C ABI (the Python classes sort and merge): a row with a duplicated entry, or with its columns out
+    # of order, must keep the CSR kernels, whose storage-order sum is what the reference's row-major product does
+    import ctypes as C
+
+    n = 600
+    T = sp.diags([np.ones(n - 1), np.ones(n), np.ones(n - 1)], [-1, 0, 1], format="csr")
+    T.sort_indices()
+    rp = T.indptr.astype(np.int32)
+    vals = np.random.default_rng(1).uniform(-1, 1, T.nnz)
+    x = rand_x(n, 2)
+    ip, dp = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    for kind, want in (("sorted", 2), ("swapped", 1), ("duplicate", 1)):
+        ci = T.indices.astype(np.int32).copy()
+        p = rp[10]
+        if kind == "swapped":
+            ci[p], ci[p + 1] = ci[p + 1], ci[p]
+        if kind == "duplicate":
+            ci[p + 1] = ci[p]
+        h = C.c_void_p()
+        sa.check(sa.lib().mispec_csr_upload(ctx.h, n, n, rp.ctypes.data_as(ip), ci.ctypes.data_as(ip), vals.ctypes.data_as(dp), C.byref(h)))
+        assert sa.lib().mispec_csr_spmv_format(h) == want, kind
+        y = np.empty(n)
+        sa.check(sa.lib().mispec_spmv_host(h, x.ctypes.data_as(dp), y.ctypes.data_as(dp)))
+        assert np.array_equal(y, O.Op.csr(n, n, rp, ci, vals).perform_op(x)), kind
+        sa.check(sa.lib().mispec_csr_destroy(h))
