@@ -364,6 +364,62 @@ __global__ __launch_bounds__(256) void k_spmv_dia(DiaArgs da, const double* __re
         y[row0 + tid] = acc;
 }
 
+// The same product with the x entries of a row-block staged through LDS: the offsets cluster, so a block of 256 rows reads
+// a few contiguous windows of x (coalesced, once) instead of one 8-byte load per row and diagonal through the L1.
+// NG = groups of eight diagonals whose values a thread keeps in registers.
+template <bool EPI, int NG>
+__global__ __launch_bounds__(256) void k_spmv_dia_win(DiaArgs da, mispec_dia_windows w, const double* __restrict__ x,
+                                                      double* __restrict__ y, int64_t nrows, int nblocks, SpmvEpilogue epi)
+{
+    extern __shared__ double xs[];
+    __shared__ double red[4];
+    const int per = (nblocks + 7) >> 3;
+    const int lb = (int(blockIdx.x) & 7) * per + (int(blockIdx.x) >> 3);
+    if (lb >= nblocks)
+        return;
+    if (EPI && epi.status && *epi.status != 0)
+        return;
+    const int tid = threadIdx.x;
+    const int64_t row0 = int64_t(lb) * 256;
+    const int nr = int(min(int64_t(256), nrows - row0));
+    const double* vrow = da.dia + row0 + min(tid, nr - 1);
+    double v[NG * kDiaGroup];
+#pragma unroll
+    for (int k = 0; k < NG * kDiaGroup; k++)
+        v[k] = __builtin_nontemporal_load(vrow + int64_t(min(k, da.nd - 1)) * da.ld);
+    const int64_t g0 = da.row_begin + row0;
+    for (int c = 0; c < w.nc; c++)
+        for (int i = tid; i < w.len[c]; i += 256)
+        {
+            const int64_t col = g0 + w.start[c] + i;
+            xs[w.base[c] + i] = x[min(max(col, int64_t(0)), int64_t(da.col_max))];
+        }
+    __syncthreads();
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < NG * kDiaGroup; k++)
+        if (k < da.nd)
+            acc = add_rounded_product(acc, v[k], xs[w.idx[k] + tid]);
+    if (EPI)
+    {
+        double contrib = 0.0;
+        if (tid < nr)
+        {
+            const int64_t row = row0 + tid;
+            double yv = acc;
+            if (epi.v_prev)
+                yv -= (epi.h_prev_dev ? *epi.h_prev_dev : epi.h_prev) * epi.v_prev[row];  // Lanczos.h:139
+            y[row] = yv;
+            contrib = epi.v_rows[row] * yv;  // Lanczos.h:142 partial <v, w>
+        }
+        const double total = block_reduce_sum(contrib, red);
+        if (tid == 0)
+            epi.partials[lb] = total;
+    }
+    else if (tid < nr)
+        y[row0 + tid] = acc;
+}
+
 // ---- synthetic band matrix, bit-identical to oracle/synth_matrix.h -------------
 __host__ __device__ inline uint64_t synth_mix64(uint64_t z)
 {
@@ -489,6 +545,29 @@ void build_dia(mispec_csr& A, const std::vector<int32_t>& dict)
     }
     A.dia_ld = ld;
     A.ndia = nd;
+    // x windows: consecutive sorted offsets share a window while it stays within 256 + 256 entries
+    mispec_dia_windows w;
+    int first = 0;
+    bool ok = true;
+    for (int k = 0; k <= nd && ok; k++)
+        if (k == nd || int64_t(offs[size_t(k)]) - int64_t(offs[size_t(first)]) > 256)
+        {
+            if (w.nc == 8)
+            {
+                ok = false;
+                break;
+            }
+            const int c = w.nc++;
+            w.start[c] = offs[size_t(first)];
+            w.len[c] = 256 + (offs[size_t(k) - 1] - offs[size_t(first)]);
+            w.base[c] = w.total;
+            for (int d = first; d < k; d++)
+                w.idx[d] = w.total + (offs[size_t(d)] - offs[size_t(first)]);
+            w.total += w.len[c];
+            first = k;
+        }
+    if (ok)
+        A.dia_win = w;
 }
 
 // Host side of the offset-coded format: one byte per entry of rows [b, e) if the shard's entries lie on at most
@@ -653,6 +732,42 @@ void launch_spmv(const mispec_csr& A, const double* x_dev, double* y_dev, const 
     if (format == 2)
     {
         const DiaArgs da{A.dia.p, A.dia_off.p, A.dia_ld, A.ndia, int(A.n_cols - 1), A.row_begin};
+        // x staged through LDS windows (default when the offsets form at most 8 clusters; MISPEC_SPMV_DIA_WIN=0: direct loads)
+        static const bool win_on = getenv("MISPEC_SPMV_DIA_WIN") ? atoi(getenv("MISPEC_SPMV_DIA_WIN")) != 0 : true;
+        if (win_on && A.dia_win.nc > 0)
+        {
+            const size_t lds = size_t(A.dia_win.total) * sizeof(double);
+            const int ng = (A.ndia + kDiaGroup - 1) / kDiaGroup;
+#define MISPEC_DIA_WIN(E, G)                                                                                               \
+    do                                                                                                                     \
+    {                                                                                                                      \
+        if (ev_start && ev_stop)                                                                                           \
+            hipExtLaunchKernelGGL((k_spmv_dia_win<E, G>), grid, block, lds, A.ctx->stream, ev_start, ev_stop, 0, da, A.dia_win, x_dev, \
+                                  y_dev, nloc, nblocks, e);                                                                \
+        else                                                                                                               \
+            hipLaunchKernelGGL((k_spmv_dia_win<E, G>), grid, block, lds, A.ctx->stream, da, A.dia_win, x_dev, y_dev, nloc, nblocks, e); \
+    } while (0)
+#define MISPEC_DIA_WIN_G(E)          \
+    do                               \
+    {                                \
+        if (ng == 1)                 \
+            MISPEC_DIA_WIN(E, 1);    \
+        else if (ng == 2)            \
+            MISPEC_DIA_WIN(E, 2);    \
+        else if (ng == 3)            \
+            MISPEC_DIA_WIN(E, 3);    \
+        else                         \
+            MISPEC_DIA_WIN(E, 4);    \
+    } while (0)
+            if (epi)
+                MISPEC_DIA_WIN_G(true);
+            else
+                MISPEC_DIA_WIN_G(false);
+#undef MISPEC_DIA_WIN_G
+#undef MISPEC_DIA_WIN
+            MISPEC_HIP(hipGetLastError());
+            return;
+        }
         if (ev_start && ev_stop)
         {
             if (epi)

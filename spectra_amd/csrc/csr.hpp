@@ -4,6 +4,18 @@
 
 #include "common.hpp"
 
+// x windows of the diagonal format: the offsets of a matrix cluster (here: ±1..3, ±1000/1001, ±100000/100001), and a
+// 256-row block needs, per cluster, one contiguous piece of x of 256 + span entries.  Staged through LDS once per block.
+struct mispec_dia_windows
+{
+    int nc = 0;        // clusters (0: the windowed kernel is not used)
+    int total = 0;     // doubles of LDS
+    int start[8];      // first offset of the cluster
+    int len[8];        // 256 + span
+    int base[8];       // position of the window in LDS
+    int idx[32];       // per diagonal: base[c] + (offset - start[c]); thread t reads xs[idx[k] + t]
+};
+
 struct mispec_csr
 {
     mispec_ctx* ctx = nullptr;
@@ -29,6 +41,7 @@ struct mispec_csr
     mispec::DevBuf<int32_t> dia_off;
     int64_t dia_ld = 0;
     int ndia = 0;
+    mispec_dia_windows dia_win;
     int forced_format = -1;          // mispec_csr_set_spmv_format: -1 automatic, 0 int32 indices, 1 offset codes, 2 diagonals
     // staging for the host-pointer paths (allocated on first use)
     mutable mispec::DevBuf<double> stage_x, stage_y;
