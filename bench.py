@@ -91,7 +91,7 @@ def pmc_traffic(n, fmt):
             for name, rec in d["kernels"].items():
                 args_ = name.split("<", 1)[1].rstrip(">").split(",") if "<" in name else []
                 is_coded = len(args_) >= 4 and args_[3].strip() == "true"
-                if fmt == 2 and name.startswith("k_spmv_dia<true"):
+                if fmt == 2 and name.startswith("k_spmv_dia") and "<true" in name:
                     return float(rec["hbm_bytes"])
                 if fmt != 2 and name.startswith("k_spmv_csr_stream<true") and is_coded == (fmt == 1):
                     return float(rec["hbm_bytes"])
@@ -225,7 +225,7 @@ def main():
                 "parallelism": f"row-shard x{world}" + exchange_desc,
             },
             "roofline": {
-                "kernel": ("k_spmv_dia" if op.spmv_format() == 2 else "k_spmv_csr_stream") + " (SpMV fused with w -= beta*v_prev and the alpha dot)",
+                "kernel": ("k_spmv_dia_win / k_spmv_dia" if op.spmv_format() == 2 else "k_spmv_csr_stream") + " (SpMV fused with w -= beta*v_prev and the alpha dot)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
