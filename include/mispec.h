@@ -177,6 +177,9 @@ int mispec_symshift_destroy(mispec_symshift* S);
 int64_t mispec_symshift_rows(const mispec_symshift* S);
 /* set_shift(sigma) (SparseSymShiftSolve.h:85-95): MISPEC_EINVAL "factorization failed with the given shift" on breakdown */
 int mispec_symshift_set_shift(mispec_symshift* S, double sigma);
+/* Complex shift for the general operator (mispec_symshift_create_general): afterwards solve = Re((A - sigma I)^{-1} x), the
+ * operator of GenEigsComplexShiftSolver (MatOp/SparseGenComplexShiftSolve.h:74-113, DenseGenComplexShiftSolve.h).  n <= 4096. */
+int mispec_symshift_set_shift_complex(mispec_symshift* S, double sigmar, double sigmai);
 int mispec_symshift_solve(const mispec_symshift* S, const double* x_dev, double* y_dev);        /* device pointers */
 int mispec_symshift_solve_host(const mispec_symshift* S, const double* x_host, double* y_host); /* literal perform_op */
 
@@ -421,6 +424,10 @@ int mispec_geneigs_create(mispec_ctx* ctx, const mispec_csr* A, int64_t nev, int
 int mispec_geneigs_create_op(mispec_ctx* ctx, mispec_op_fn op, void* op_user, int64_t n, int64_t nev, int64_t ncv,
                              mispec_geneigs** out);
 /* GenEigsSolver<DenseGenMatProd<double>> / a user operator on device pointers */
+/* GenEigsComplexShiftSolver (GenEigsComplexShiftSolver.h:20-150): Arnoldi on x -> Re((A - sigma I)^{-1} x); S from
+ * mispec_symshift_create_general.  The solver leaves S at a real probe shift afterwards, like the reference. */
+int mispec_geneigs_create_complex_shift(mispec_ctx* ctx, mispec_symshift* S, int64_t nev, int64_t ncv, double sigmar, double sigmai,
+                                        mispec_geneigs** out);
 int mispec_geneigs_create_dense(mispec_ctx* ctx, const mispec_dense* D, int64_t nev, int64_t ncv, mispec_geneigs** out);
 int mispec_geneigs_create_device_op(mispec_ctx* ctx, mispec_device_op_fn op, void* op_user, int64_t n, int64_t nev, int64_t ncv,
                                     mispec_geneigs** out);

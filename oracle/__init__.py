@@ -87,6 +87,8 @@ def lib():
             "oracle_symeigs_free": (None, [vp]),
             "oracle_symeigs_set_shift_invert": (None, [vp, C.c_double]),
             "oracle_geneigs_set_shift_invert": (None, [vp, C.c_double]),
+            "oracle_geneigs_set_complex_shift": (None, [vp, C.c_double, C.c_double, vp]),
+            "oracle_complex_shift_probe": (C.c_double, [C.c_double]),
             "oracle_symeigs_create_b": (vp, [vp, vp, C.c_long, C.c_long, C.c_int, C.c_double]),
             "oracle_symeigs_init": (C.c_int, [vp, dp]),
             "oracle_symeigs_compute": (C.c_long, [vp, C.c_int, C.c_long, C.c_double, C.c_int]),
@@ -184,6 +186,11 @@ def gen_sparse_data_rect(m, n, prob):
     v = np.empty(cnt)
     lib().oracle_gen_sparse_data_rect(m, n, prob, _ip(r), _ip(c), _dp(v))
     return r, c, v
+
+
+def complex_shift_probe(sigmar):
+    """The real probe shift GenEigsComplexShiftSolver draws from SimpleRandom(0) (GenEigsComplexShiftSolver.h:69-72)."""
+    return float(lib().oracle_complex_shift_probe(float(sigmar)))
 
 
 def gen_davidson_sparse(n):
@@ -561,13 +568,19 @@ class GenEigsSolver:
     """GenEigsSolver.h / GenEigsBase.h on the oracle (real matrices, complex results).  sigma: the op is already
     (A - sigma I)^{-1} and the Ritz values are mapped back as in GenEigsRealShiftSolver.h:52-58."""
 
-    def __init__(self, op, nev, ncv, sigma=None):
+    def __init__(self, op, nev, ncv, sigma=None, complex_shift=None):
+        """complex_shift = (sigmar, sigmai, op_probe): GenEigsComplexShiftSolver.h — `op` is x -> Re((A - sigma I)^{-1} x) and
+        op_probe the same operator at the real probe shift complex_shift_probe(sigmar)."""
         self.op, self.nev, self.ncv, self.n = op, nev, min(ncv, op.n), op.n
         self.h = lib().oracle_geneigs_create(op.h, nev, ncv)
         if not self.h:
             raise ValueError(lib().oracle_last_error().decode())
         if sigma is not None:
             lib().oracle_geneigs_set_shift_invert(self.h, float(sigma))
+        if complex_shift is not None:
+            sr, si, probe = complex_shift
+            self._probe = probe  # keep the callback alive
+            lib().oracle_geneigs_set_complex_shift(self.h, float(sr), float(si), probe.h)
 
     def init(self, v0=None):
         v0 = None if v0 is None else _f64(v0)

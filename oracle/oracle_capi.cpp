@@ -538,6 +538,16 @@ void oracle_geneigs_set_shift_invert(void* s, double sigma)
     static_cast<GenEigs*>(s)->shift_invert = true;
     static_cast<GenEigs*>(s)->sigma = sigma;
 }
+// GenEigsComplexShiftSolver: op (given at creation) is Re((A - sigma I)^{-1} .), op_probe the operator at the real probe shift
+void oracle_geneigs_set_complex_shift(void* s, double sigmar, double sigmai, void* op_probe)
+{
+    auto* S = static_cast<GenEigs*>(s);
+    S->complex_shift = true;
+    S->sigmar = sigmar;
+    S->sigmai = sigmai;
+    S->op_probe = static_cast<Op*>(op_probe);
+}
+double oracle_complex_shift_probe(double sigmar) { return GenEigs::probe_shift(sigmar); }
 int oracle_geneigs_init(void* s, const double* v0)
 {
     auto* S = static_cast<GenEigs*>(s);

@@ -956,6 +956,18 @@ public:
     // GenEigsRealShiftSolver.h:52-58: lambda = 1 / nu + sigma before the final sort
     bool shift_invert = false;
     double sigma = 0.0;
+    // GenEigsComplexShiftSolver.h:20-150: `op` is x -> Re((A - sigma I)^{-1} x) with sigma = sigmar + i sigmai; op_probe is
+    // the same operator at the real probe shift the reference draws from SimpleRandom(0) (:69-72)
+    bool complex_shift = false;
+    double sigmar = 0.0, sigmai = 0.0;
+    const Op* op_probe = nullptr;
+    static double probe_shift(double sigmar_)
+    {
+        SimpleRandom rng(0);
+        const double a = rng.random();
+        const double b = rng.random();
+        return a * sigmar_ + b;
+    }
 
     static bool is_complex(const Complex& v) { return v.imag() != 0.0; }
     static bool is_conj(const Complex& a, const Complex& b) { return a == std::conj(b); }
@@ -1080,6 +1092,51 @@ public:
         if (shift_invert)
             for (Index i = 0; i < nev; i++)
                 ritz_val[i] = Complex(1.0, 0.0) / ritz_val[i] + sigma;
+        if (complex_shift)  // GenEigsComplexShiftSolver.h:39-123
+        {
+            const double shiftr = probe_shift(sigmar);
+            const Complex shift(shiftr, 0.0);
+            const double eps = std::numeric_limits<double>::epsilon();
+            std::vector<double> v_re(n), v_im(n), op_re(n), op_im(n);
+            for (Index i = 0; i < nev; i++)
+            {
+                std::fill(v_re.begin(), v_re.end(), 0.0);
+                std::fill(v_im.begin(), v_im.end(), 0.0);
+                for (Index c = 0; c < ncv; c++)  // v = V * ritz_vec.col(i)  (:80-81)
+                {
+                    const Complex y = ritz_vec[size_t(i) * ncv + c];
+                    const double* vc = &fac.V(0, c);
+                    for (Index r = 0; r < n; r++)
+                    {
+                        v_re[r] += vc[r] * y.real();
+                        v_im[r] += vc[r] * y.imag();
+                    }
+                }
+                op_probe->perform_op(v_re.data(), op_re.data());
+                op_probe->perform_op(v_im.data(), op_im.data());
+                const Complex nu = ritz_val[i];
+                const Complex part1 = sigmar + 0.5 / nu;  // :85-90
+                const Complex part2 = 0.5 * std::sqrt(1.0 - 4.0 * sigmai * sigmai * (nu * nu)) / nu;
+                const Complex root1 = part1 + part2, root2 = part1 - part2;
+                double err1 = 0.0, err2 = 0.0;
+                for (Index k = 0; k < n; k++)  // :93-101
+                {
+                    const Complex v(v_re[k], v_im[k]), opv(op_re[k], op_im[k]);
+                    err1 += std::norm(opv - v / (root1 - shift));
+                    err2 += std::norm(opv - v / (root2 - shift));
+                }
+                const Complex lambdaj = (err1 < err2) ? root1 : root2;
+                ritz_val[i] = lambdaj;
+                if (std::fabs(lambdaj.imag()) > eps)  // :106-114
+                {
+                    if (i + 1 < ncv)
+                        ritz_val[i + 1] = std::conj(lambdaj);
+                    i++;
+                }
+                else
+                    ritz_val[i] = Complex(lambdaj.real(), 0.0);
+            }
+        }
         std::vector<Index> ind;
         try
         {

@@ -971,6 +971,19 @@ class SparseGenRealShiftSolve:
             pass
 
 
+class _GenComplexShiftBinding:
+    def __init__(self, S, sigmar, sigmai):
+        if not isinstance(S, SparseGenRealShiftSolve):
+            raise TypeError("GenEigsComplexShiftSolver: needs a SparseGenComplexShiftSolve / DenseGenComplexShiftSolve operator")
+        self.S, self.sigmar, self.sigmai = S, float(sigmar), float(sigmai)
+
+    def rows(self):
+        return self.S.rows()
+
+    cols = rows
+    local_rows = rows
+
+
 class _GenShiftBinding:
     def __init__(self, S, sigma):
         if not isinstance(S, SparseGenRealShiftSolve):
@@ -993,6 +1006,11 @@ class GenEigsSolver:
         if isinstance(op, _DeviceMatrix):
             self.ctx = op.ctx
             check(lib().mispec_geneigs_create(self.ctx.h, op.h, int(nev), int(ncv), C.byref(h)))
+            self._user = None
+        elif isinstance(op, _GenComplexShiftBinding):  # Arnoldi on Re((A - sigma I)^{-1} .), complex sigma
+            self.ctx = op.S.ctx
+            check(lib().mispec_geneigs_create_complex_shift(self.ctx.h, op.S.h, int(nev), int(ncv), float(op.sigmar), float(op.sigmai),
+                                                            C.byref(h)))
             self._user = None
         elif isinstance(op, _GenShiftBinding):  # Arnoldi on (A - sigma I)^{-1}
             self.ctx = op.S.ctx
@@ -1078,6 +1096,20 @@ class GenEigsRealShiftSolver(GenEigsSolver):
     def __init__(self, op, nev, ncv, sigma):
         super().__init__(_GenShiftBinding(op, sigma), nev, ncv)
 
+class SparseGenComplexShiftSolve(SparseGenRealShiftSolve):
+    """MatOp/SparseGenComplexShiftSolve.h: y = Re((A - sigma I)^{-1} x) for a general sparse A and a complex shift (n <= 4096)."""
+
+    def set_shift(self, sigmar, sigmai=0.0):
+        check(lib().mispec_symshift_set_shift_complex(self.h, float(sigmar), float(sigmai)))
+
+
+class GenEigsComplexShiftSolver(GenEigsSolver):
+    """GenEigsComplexShiftSolver.h:20-150: eigenvalues of a general real A closest to the complex shift sigmar + i sigmai."""
+
+    def __init__(self, op, nev, ncv, sigmar, sigmai):
+        super().__init__(_GenComplexShiftBinding(op, sigmar, sigmai), nev, ncv)
+
+
 def _dense_as_csc(mat, name):
     """The compressed form of a dense host matrix (exact zeros dropped): what the device factorisations ingest."""
     import scipy.sparse as sp
@@ -1100,6 +1132,13 @@ class DenseGenRealShiftSolve(SparseGenRealShiftSolve):
 
     def __init__(self, mat, ctx=None):
         super().__init__(_dense_as_csc(mat, "DenseGenRealShiftSolve"), ctx)
+
+
+class DenseGenComplexShiftSolve(SparseGenComplexShiftSolve):
+    """MatOp/DenseGenComplexShiftSolve.h: the dense form of SparseGenComplexShiftSolve."""
+
+    def __init__(self, mat, ctx=None):
+        super().__init__(_dense_as_csc(mat, "DenseGenComplexShiftSolve"), ctx)
 
 
 class DenseCholesky(SparseCholesky):

@@ -187,6 +187,8 @@ SIGNATURES = {
     "mispec_geneigs_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vpp]),
     "mispec_geneigs_create_op": (C.c_int, [_vp, op_fn, _vp, C.c_int64, C.c_int64, C.c_int64, _vpp]),
     "mispec_geneigs_create_shift": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_double, _vpp]),
+    "mispec_geneigs_create_complex_shift": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_double, C.c_double, _vpp]),
+    "mispec_symshift_set_shift_complex": (C.c_int, [_vp, C.c_double, C.c_double]),
     "mispec_geneigs_create_dense": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vpp]),
     "mispec_geneigs_create_device_op": (C.c_int, [_vp, device_op_fn, _vp, C.c_int64, C.c_int64, C.c_int64, _vpp]),
     "mispec_symshift_create_general": (C.c_int, [_vp, C.c_int64, _ip, _ip, _dp, C.c_int, _vpp]),

@@ -2,6 +2,7 @@
 // library for bindings that cannot instantiate C++ templates (Python ctypes, cgo, JNI ...).
 // Nothing here adds arithmetic: it is Spectra::SymEigsSolver<Spectra::SparseSymMatProd<double>> (or a
 // callback operator with the reference's perform_op contract) behind opaque handles.
+#include <Spectra/GenEigsComplexShiftSolver.h>
 #include <Spectra/GenEigsRealShiftSolver.h>
 #include <Spectra/GenEigsSolver.h>
 #include <Spectra/LinAlg/DoubleShiftQR.h>
@@ -437,6 +438,8 @@ using GenDenseSolver = Spectra::GenEigsSolver<DenseHandleOp>;
 using GenDevCbSolver = Spectra::GenEigsSolver<DeviceCallbackOp>;
 using GenShiftOp = Spectra::SparseGenRealShiftSolve<double>;
 using GenShiftSolver = Spectra::GenEigsRealShiftSolver<GenShiftOp>;
+using GenCShiftOp = Spectra::SparseGenComplexShiftSolve<double>;
+using GenCShiftSolver = Spectra::GenEigsComplexShiftSolver<GenCShiftOp>;
 }  // namespace
 
 struct mispec_geneigs
@@ -447,6 +450,8 @@ struct mispec_geneigs
     std::unique_ptr<GenDevSolver> dev;
     std::unique_ptr<GenCbSolver> cb;
     std::unique_ptr<GenShiftSolver> shift;
+    std::unique_ptr<GenCShiftOp> cshift_op;
+    std::unique_ptr<GenCShiftSolver> cshift;
     std::unique_ptr<DenseHandleOp> dense_op;
     std::unique_ptr<GenDenseSolver> dense;
     std::unique_ptr<DeviceCallbackOp> devcb_op;
@@ -458,6 +463,8 @@ struct mispec_geneigs
             return f(*dev);
         if (shift)
             return f(*shift);
+        if (cshift)
+            return f(*cshift);
         if (dense)
             return f(*dense);
         if (devcb)
@@ -519,6 +526,17 @@ extern "C" int mispec_geneigs_create_shift(mispec_ctx* ctx, mispec_symshift* S, 
         auto s = std::make_unique<mispec_geneigs>();
         s->shift_op = std::make_unique<GenShiftOp>(ctx, S);
         s->shift = std::make_unique<GenShiftSolver>(*s->shift_op, nev, ncv, sigma);
+        *out = s.release();
+    });
+}
+extern "C" int mispec_geneigs_create_complex_shift(mispec_ctx* ctx, mispec_symshift* S, int64_t nev, int64_t ncv, double sigmar,
+                                                   double sigmai, mispec_geneigs** out)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(ctx && S && out, "mispec_geneigs_create_complex_shift: NULL argument");
+        auto s = std::make_unique<mispec_geneigs>();
+        s->cshift_op = std::make_unique<GenCShiftOp>(ctx, S);
+        s->cshift = std::make_unique<GenCShiftSolver>(*s->cshift_op, nev, ncv, sigmar, sigmai);
         *out = s.release();
     });
 }

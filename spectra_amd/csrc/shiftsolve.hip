@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <complex>
 #include <cstring>
 #include <string>
 
@@ -785,18 +786,19 @@ void solve_level(const mispec_ctx& ctx, const BandLevel& lev, const double* f, d
 }
 
 // dense LU with partial pivoting -> explicit inverse (column-major), host
-void dense_inverse(int n, std::vector<double>& A, std::vector<double>& inv)
+template <typename T>
+void dense_inverse(int n, std::vector<T>& A, std::vector<T>& inv)
 {
     std::vector<int> piv(static_cast<size_t>(n));
-    auto a = [&](int i, int j) -> double& { return A[size_t(j) * n + i]; };
+    auto a = [&](int i, int j) -> T& { return A[size_t(j) * n + i]; };
     for (int k = 0; k < n; k++)
     {
         int pr = k;
-        double best = std::fabs(a(k, k));
+        double best = std::abs(a(k, k));
         for (int i = k + 1; i < n; i++)
-            if (std::fabs(a(i, k)) > best)
+            if (std::abs(a(i, k)) > best)
             {
-                best = std::fabs(a(i, k));
+                best = std::abs(a(i, k));
                 pr = i;
             }
         if (!(best > 0.0))
@@ -805,40 +807,40 @@ void dense_inverse(int n, std::vector<double>& A, std::vector<double>& inv)
         if (pr != k)
             for (int j = 0; j < n; j++)
                 std::swap(a(k, j), a(pr, j));
-        const double d = a(k, k);
+        const T d = a(k, k);
         for (int i = k + 1; i < n; i++)
             a(i, k) /= d;
         for (int j = k + 1; j < n; j++)
         {
-            const double akj = a(k, j);
-            if (akj == 0.0)
+            const T akj = a(k, j);
+            if (akj == T(0))
                 continue;
-            double* col = &A[size_t(j) * n];
-            const double* lk = &A[size_t(k) * n];
+            T* col = &A[size_t(j) * n];
+            const T* lk = &A[size_t(k) * n];
             for (int i = k + 1; i < n; i++)
                 col[i] -= lk[i] * akj;
         }
     }
-    inv.assign(size_t(n) * n, 0.0);
-    std::vector<double> e(static_cast<size_t>(n));
+    inv.assign(size_t(n) * n, T(0));
+    std::vector<T> e(static_cast<size_t>(n));
     for (int c = 0; c < n; c++)
     {
-        std::fill(e.begin(), e.end(), 0.0);
-        e[size_t(c)] = 1.0;
+        std::fill(e.begin(), e.end(), T(0));
+        e[size_t(c)] = T(1);
         for (int k = 0; k < n; k++)
             std::swap(e[size_t(k)], e[size_t(piv[size_t(k)])]);
         for (int k = 0; k < n; k++)  // L y = P e
         {
-            const double ek = e[size_t(k)];
-            if (ek != 0.0)
+            const T ek = e[size_t(k)];
+            if (ek != T(0))
                 for (int i = k + 1; i < n; i++)
                     e[size_t(i)] -= a(i, k) * ek;
         }
         for (int k = n - 1; k >= 0; k--)  // U x = y
         {
             e[size_t(k)] /= a(k, k);
-            const double ek = e[size_t(k)];
-            if (ek != 0.0)
+            const T ek = e[size_t(k)];
+            if (ek != T(0))
                 for (int i = 0; i < k; i++)
                     e[size_t(i)] -= a(i, k) * ek;
         }
@@ -1091,7 +1093,7 @@ extern "C" int mispec_symshift_set_shift(mispec_symshift* S, double sigma)
             else
                 for (int64_t i = 0; i < n; i++)
                     A[size_t(i) * n + i] -= sigma;
-            dense_inverse(int(n), A, inv);
+            dense_inverse<double>(int(n), A, inv);
             upload_row_major(inv, n, S->inverse);
             S->dense = true;
         }
@@ -1099,6 +1101,37 @@ extern "C" int mispec_symshift_set_shift(mispec_symshift* S, double sigma)
             throw Error(MISPEC_EINVAL,
                         "SparseSymShiftSolve: only banded matrices (half-bandwidth <= 8) or n <= 4096 are supported on the GPU "
                         "(the reference uses a general sparse LU)");
+        S->factored = true;
+    });
+}
+
+// SparseGenComplexShiftSolve::set_shift(sigmar, sigmai) (MatOp/SparseGenComplexShiftSolve.h:74-99): the operator becomes
+// y = Re((A - sigma I)^{-1} x) for real x.  Dense path only: complex LU with partial pivoting on the host, the REAL PART of
+// the explicit inverse goes to HBM and is applied by the same GEMV kernel (Re(M x) = Re(M) x for real x).
+extern "C" int mispec_symshift_set_shift_complex(mispec_symshift* S, double sigmar, double sigmai)
+{
+    if (S && sigmai == 0.0)
+        return mispec_symshift_set_shift(S, sigmar);
+    return guarded([&] {
+        MISPEC_REQUIRE(S, "mispec_symshift_set_shift_complex: NULL argument");
+        MISPEC_REQUIRE(S->general && !S->pencil, "mispec_symshift_set_shift_complex: complex shifts are for the general (non-symmetric) operator");
+        S->ctx->make_current();
+        S->factored = false;
+        S->sigma = sigmar;
+        const int64_t n = S->n;
+        MISPEC_REQUIRE(n <= kMaxDense, "SparseGenComplexShiftSolve: only n <= 4096 is supported on the GPU");
+        typedef std::complex<double> Cx;
+        std::vector<Cx> A(size_t(n) * n, Cx(0.0, 0.0)), inv;
+        for (size_t e = 0; e < S->vals.size(); e++)
+            A[size_t(S->cols[e]) * n + S->rows[e]] += S->vals[e];
+        for (int64_t i = 0; i < n; i++)
+            A[size_t(i) * n + i] -= Cx(sigmar, sigmai);
+        dense_inverse<Cx>(int(n), A, inv);
+        std::vector<double> re(inv.size());
+        for (size_t e = 0; e < inv.size(); e++)
+            re[e] = inv[e].real();
+        upload_row_major(re, n, S->inverse);
+        S->dense = true;
         S->factored = true;
     });
 }

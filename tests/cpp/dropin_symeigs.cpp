@@ -5,9 +5,11 @@
 // It needs a GPU to run (tests/test_gpu_cpp_dropin.py).  Eigen is not available here, so matrices are handed
 // over as Spectra::SparseView and results come back as Spectra::DenseVector / DenseMatrix.
 #include <Spectra/DavidsonSymEigsSolver.h>
+#include <Spectra/GenEigsComplexShiftSolver.h>
 #include <Spectra/GenEigsRealShiftSolver.h>
 #include <Spectra/GenEigsSolver.h>
 #include <Spectra/MatOp/DenseCholesky.h>
+#include <Spectra/MatOp/DenseGenComplexShiftSolve.h>
 #include <Spectra/MatOp/DenseGenMatProd.h>
 #include <Spectra/MatOp/DenseGenRealShiftSolve.h>
 #include <Spectra/MatOp/DenseSymShiftSolve.h>
@@ -306,6 +308,36 @@ static void run_dense_shift_and_cholesky(int n, double prob, int k, int m)
         std::printf("dense-geigs-cholesky n=%d nconv=%d nops=%d ||AU-BUD||_inf=%.3e\n", n, nconv, (int) eigs.num_operations(), err);
         REQUIRE(nconv == k);
         REQUIRE(err < 1e-9);
+    }
+}
+
+// test/GenEigsComplexShift.cpp:163-173: sparse 100 x 100, k = 10, m = 30, sigma = 20 + 10i; ||AU - UD||_inf < 1e-8
+static void run_gen_complex_shift(int n, double prob, int k, int m, double sigmar, double sigmai)
+{
+    const Csc A = gen_sparse_data(n, prob);
+    SparseGenComplexShiftSolve<double> op(A.view());
+    const SortRule rules[] = {SortRule::LargestMagn, SortRule::LargestReal};
+    for (SortRule rule : rules)
+    {
+        GenEigsComplexShiftSolver<SparseGenComplexShiftSolve<double>> eigs(op, k, m, sigmar, sigmai);
+        eigs.init();
+        const int nconv = (int) eigs.compute(rule, 500);
+        REQUIRE(eigs.info() == CompInfo::Successful);
+        const auto evals = eigs.eigenvalues();
+        const auto U = eigs.eigenvectors();
+        double err = 0.0;
+        for (Index c = 0; c < U.cols(); c++)
+        {
+            std::vector<std::complex<double>> au(n, std::complex<double>(0.0, 0.0));
+            for (int j = 0; j < n; j++)
+                for (int p = A.colptr[j]; p < A.colptr[j + 1]; p++)
+                    au[A.rowind[p]] += A.val[p] * U(j, c);
+            for (int i = 0; i < n; i++)
+                err = std::fmax(err, std::abs(au[i] - evals[c] * U(i, c)));
+        }
+        std::printf("gen-complexshift n=%d rule=%d nconv=%d nops=%d ||AU-UD||_inf=%.3e\n", n, (int) rule, nconv, (int) eigs.num_operations(), err);
+        REQUIRE(nconv > 0);
+        REQUIRE(err < 1e-8);
     }
 }
 
@@ -684,6 +716,7 @@ int main()
         run_device_op(gen_sparse_data(1000, 0.01), 20, 50);  // user operator on device pointers
         run_davidson(1000, 10);                              // test/DavidsonSymEigs.cpp:116-122
         run_dense_shift_and_cholesky(100, 0.1, 10, 20);      // dense shift-and-invert / Cholesky operators
+        run_gen_complex_shift(100, 0.1, 10, 30, 20.0, 10.0); // test/GenEigsComplexShift.cpp:163-173
 
         // constructor argument checks throw std::invalid_argument like the reference (HermEigsBase.h:267-271)
         bool threw = false;

@@ -18,4 +18,4 @@ def test_cpp_dropin_program():
     out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     print(out.stdout)
     assert out.returncode == 0, out.stdout
-    assert "ALL PASSED" in out.stdout and out.stdout.count("||AU-UD||_inf") == 15 + 8 + 2 + 4 + 3 + 2 + 2
+    assert "ALL PASSED" in out.stdout and out.stdout.count("||AU-UD||_inf") == 15 + 8 + 2 + 4 + 3 + 2 + 2 + 2
