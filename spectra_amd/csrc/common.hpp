@@ -137,7 +137,7 @@ struct mispec_ctx
     bool own_stream = false;
     int num_cu = 256;
     // communicator (world == 1: no collectives are ever called)
-    mispec_comm comm{0, 1, nullptr, nullptr, nullptr};
+    mispec_comm comm{0, 1, nullptr, nullptr, nullptr, nullptr};
     void* comm_owner = nullptr;                 // built-in communicator state to free with the ctx
     void (*comm_owner_free)(void*) = nullptr;
 
