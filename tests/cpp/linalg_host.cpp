@@ -2,7 +2,9 @@
 // (/root/reference/test/QR.cpp:20-98, test/Eigen.cpp, test/Schur.cpp): Q orthogonal, R upper triangular,
 // H - sI = QR, Q'HQ, every apply_* against the explicit product, eigen / Schur residuals — all to 1e-12.
 // Plain C++11, no GPU, no library: g++ -std=c++11 -I include tests/cpp/linalg_host.cpp
+#include <Spectra/LinAlg/BKLDLT.h>
 #include <Spectra/LinAlg/DoubleShiftQR.h>
+#include <Spectra/LinAlg/Orthogonalization.h>
 #include <Spectra/LinAlg/TridiagEigen.h>
 #include <Spectra/LinAlg/UpperHessenbergEigen.h>
 #include <Spectra/LinAlg/UpperHessenbergQR.h>
@@ -224,6 +226,153 @@ int main()
                 err = std::fmax(err, std::abs(acc - ev[j] * X(i, j)));
             }
         REQUIRE(err <= 1e-10);
+    }
+    {
+        // LinAlg/BKLDLT.h — test/BKLDLT.cpp:14-74: (A - s I) x = b from either triangle, identical solutions, residual <= 1e-9
+        const Index sizes[] = {1, 2, 3, 10, 100, 300};
+        for (Index bn : sizes)
+        {
+            Matrix S = random_matrix(bn, bn);
+            for (Index j = 0; j < bn; j++)
+                for (Index i = 0; i < j; i++)
+                {
+                    const double sym = S(i, j) + S(j, i);
+                    S(i, j) = sym;
+                    S(j, i) = sym;
+                }
+            for (Index i = 0; i < bn; i++)
+                S(i, i) *= 2.0;  // A = M + M'
+            // the two triangles differ on purpose outside the one that is read
+            Matrix L = S, U = S;
+            for (Index j = 0; j < bn; j++)
+                for (Index i = 0; i < j; i++)
+                {
+                    L(i, j) = 1e3;
+                    U(j, i) = -1e3;
+                }
+            Vector b(bn);
+            for (Index i = 0; i < bn; i++)
+                b[i] = std::sin(1.0 + double(i));
+            const double shift = 1.0;
+            BKLDLT<double> dl(L, Lower, shift), du(U, Upper, shift);
+            REQUIRE(dl.info() == CompInfo::Successful);
+            REQUIRE(du.info() == CompInfo::Successful);
+            const Vector xl = dl.solve(b), xu = du.solve(b);
+            double diff = 0.0, resid = 0.0;
+            for (Index i = 0; i < bn; i++)
+            {
+                diff = std::max(diff, std::fabs(xl[i] - xu[i]));
+                double r = -shift * xl[i] - b[i];
+                for (Index j = 0; j < bn; j++)
+                    r += S(i, j) * xl[j];
+                resid = std::max(resid, std::fabs(r));
+            }
+            REQUIRE(diff == 0.0);
+            REQUIRE(resid < 1e-9);
+        }
+        // an indefinite matrix that needs 2x2 pivots (zero diagonal), and a singular one
+        Matrix Z(4, 4);
+        const double zv[16] = {0, 1, 2, 3, 1, 0, 4, 5, 2, 4, 0, 6, 3, 5, 6, 0};
+        for (Index j = 0; j < 4; j++)
+            for (Index i = 0; i < 4; i++)
+                Z(i, j) = zv[j * 4 + i];
+        BKLDLT<double> dz(Z);
+        REQUIRE(dz.info() == CompInfo::Successful);
+        Vector bz(4);
+        for (Index i = 0; i < 4; i++)
+            bz[i] = double(i) - 1.5;
+        const Vector xz = dz.solve(bz);
+        for (Index i = 0; i < 4; i++)
+        {
+            double r = -bz[i];
+            for (Index j = 0; j < 4; j++)
+                r += Z(i, j) * xz[j];
+            REQUIRE(std::fabs(r) < 1e-12);
+        }
+        Matrix O4(4, 4);
+        for (Index j = 0; j < 4; j++)
+            for (Index i = 0; i < 4; i++)
+                O4(i, j) = 0.0;
+        BKLDLT<double> dsing(O4);
+        REQUIRE(dsing.info() == CompInfo::NumericalIssue);
+        bool threw = false;
+        try
+        {
+            Vector t(4);
+            dsing.solve_inplace(t);
+        }
+        catch (const std::logic_error&)
+        {
+            threw = true;
+        }
+        REQUIRE(threw);
+    }
+    {
+        // LinAlg/Orthogonalization.h — test/Orthogonalization.cpp:13-99: basis' basis = I to 1e-12, complete (20 x 20) and
+        // partial (15 orthonormal columns kept, 5 random ones appended)
+        auto overlap_error = [](const Matrix& B) {
+            double err = 0.0;
+            for (Index a = 0; a < B.cols(); a++)
+                for (Index b = 0; b < B.cols(); b++)
+                {
+                    double s = 0.0;
+                    for (Index i = 0; i < B.rows(); i++)
+                        s += B(i, a) * B(i, b);
+                    err = std::max(err, std::fabs(s - (a == b ? 1.0 : 0.0)));
+                }
+            return err;
+        };
+        const Index on = 20, sub = 5, start = on - sub;
+        typedef void (*OrthFn)(Matrix&, Index);
+        const OrthFn fns[] = {&MGS_orthogonalisation<Matrix>, &GS_orthogonalisation<Matrix>, &twice_is_enough_orthogonalisation<Matrix>,
+                              &JensWehner_orthogonalisation<Matrix>};
+        for (OrthFn fn : fns)
+        {
+            Matrix full = random_matrix(on, on);
+            fn(full, 0);
+            REQUIRE(overlap_error(full) < 1e-12);
+            Matrix part = random_matrix(on, on);
+            Matrix head(on, start);
+            for (Index j = 0; j < start; j++)
+                for (Index i = 0; i < on; i++)
+                    head(i, j) = part(i, j);
+            QR_orthogonalisation(head);
+            REQUIRE(overlap_error(head) < 1e-12);
+            for (Index j = 0; j < start; j++)
+                for (Index i = 0; i < on; i++)
+                    part(i, j) = head(i, j);
+            const Matrix before = part;
+            fn(part, start);
+            REQUIRE(overlap_error(part) < 1e-12);
+            for (Index j = 0; j < start; j++)  // the leading block is left untouched
+                for (Index i = 0; i < on; i++)
+                    REQUIRE(part(i, j) == before(i, j));
+        }
+        Matrix q = random_matrix(on, on);
+        QR_orthogonalisation(q);
+        REQUIRE(overlap_error(q) < 1e-12);
+        Matrix tall = random_matrix(50, 7);  // thin Q of a tall matrix spans the same space
+        const Matrix tall0 = tall;
+        QR_orthogonalisation(tall);
+        REQUIRE(overlap_error(tall) < 1e-12);
+        for (Index j = 0; j < 7; j++)  // tall0(:, j) lies in span(Q): || (I - QQ') a_j || ~ 0
+        {
+            std::vector<double> res(50);
+            for (Index i = 0; i < 50; i++)
+                res[i] = tall0(i, j);
+            for (Index c = 0; c < 7; c++)
+            {
+                double s = 0.0;
+                for (Index i = 0; i < 50; i++)
+                    s += tall(i, c) * tall0(i, j);
+                for (Index i = 0; i < 50; i++)
+                    res[i] -= s * tall(i, c);
+            }
+            double nr = 0.0;
+            for (double x : res)
+                nr = std::max(nr, std::fabs(x));
+            REQUIRE(nr < 1e-12);
+        }
     }
     {
         // Util/SelectionRule.h: the compile-time sorter and argsort agree; BothEnds interleaves (reference :265-284)
