@@ -121,6 +121,13 @@ struct DenseView
     DenseView(Index r, Index c, const Scalar* d, Index ld_, bool rm = false) : rows(r), cols(c), data(d), ld(ld_), row_major(rm) {}
     // the stand-in matrix type (column-major, contiguous)
     DenseView(const internal::PlainMatrix<Scalar>& m) : rows(m.rows()), cols(m.cols()), data(m.data()), ld(m.rows()), row_major(false) {}
+#ifdef MISPEC_HAVE_EIGEN
+    // a plain (contiguous) Eigen matrix of either storage order
+    template <int Options>
+    DenseView(const Eigen::Matrix<Scalar, Eigen::Dynamic, Eigen::Dynamic, Options>& m) :
+        rows(m.rows()), cols(m.cols()), data(m.data()), ld(m.outerStride()), row_major((Options & Eigen::RowMajorBit) != 0)
+    {}
+#endif
 };
 
 }  // namespace Spectra

@@ -19,3 +19,15 @@ def test_cpp_dropin_program():
     print(out.stdout)
     assert out.returncode == 0, out.stdout
     assert "ALL PASSED" in out.stdout and out.stdout.count("||AU-UD||_inf") == 15 + 8 + 2 + 4 + 3 + 2 + 2 + 2
+
+
+def test_cpp_dropin_program_with_eigen_like_result_types():
+    # the same program compiled with tests/cpp/eigen_stub on the include path: DenseMatrix / DenseVector are then the
+    # Eigen-named types and the operators are constructed through the Eigen-facing code paths where the program uses them
+    exe = os.path.join(ROOT, "tests", "cpp", "dropin_symeigs_eigenapi.bin")
+    if not os.path.exists(exe):
+        import __graft_entry__ as g
+
+        g.build_eigen_api_checks()
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert out.returncode == 0 and "ALL PASSED" in out.stdout, out.stdout
