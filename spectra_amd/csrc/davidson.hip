@@ -232,12 +232,17 @@ bool orthonormalise_column(mispec_davidson& S, int j)
     return true;
 }
 
-void check_sizes(const mispec_davidson& S)
+void check_sizes(mispec_davidson& S)
 {
     MISPEC_REQUIRE(S.init_size >= 1 && S.corr_size >= 1 && S.max_size >= S.init_size,
                    "DavidsonSymEigsSolver: need 1 <= initial search space <= maximum search space and a positive correction size");
-    MISPEC_REQUIRE(S.max_size + S.corr_size <= kMaxCols,
-                   "DavidsonSymEigsSolver: the device search space holds at most 128 vectors (nvec_max + correction size <= 128)");
+    // The device search space holds 128 vectors.  A larger maximum (the reference's default is 10 * nev) is lowered to what
+    // fits — the solver then restarts earlier, which changes the iteration count, not the result; a space that cannot even
+    // hold the initial vectors plus one correction block is an error.
+    MISPEC_REQUIRE(S.init_size + S.corr_size <= kMaxCols,
+                   "DavidsonSymEigsSolver: the device search space holds at most 128 vectors (initial space + correction size <= 128)");
+    if (S.max_size + S.corr_size > kMaxCols)
+        S.max_size = kMaxCols - S.corr_size;
     MISPEC_REQUIRE(S.init_size >= S.nev && S.corr_size <= S.init_size,
                    "DavidsonSymEigsSolver: the initial search space must hold at least nev vectors and the correction block");
 }
