@@ -7,8 +7,8 @@
 // The search space, its image under A and the Ritz vectors live in HBM; this class is a thin owner of a
 // mispec_davidson handle (csrc/davidson.hip).  Operators: the device matrix classes (SparseSymMatProd,
 // DenseSymMatProd) or a user class with perform_op_device() plus operator()(i, i) for the diagonal.
-// Differences a user can observe: the device search space holds 128 vectors (a larger nvec_max is lowered to
-// 128 - correction size: earlier restarts, same results); new directions are orthonormalised by two
+// Differences a user can observe: the device search space holds 256 vectors (a larger nvec_max is lowered to
+// 256 - correction size: earlier restarts, same results); new directions are orthonormalised by two
 // Gram-Schmidt passes per vector instead of a block projection + Householder QR (same space, vectors equal up to
 // sign); the base class JDSymEigsBase is not exposed as a customisation point.
 #ifndef MISPEC_SPECTRA_DAVIDSON_SYM_EIGS_SOLVER_H

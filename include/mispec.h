@@ -343,8 +343,8 @@ int mispec_tridiag_eigen(mispec_ctx* ctx, int n, const double* T_host, double* e
 /* ---------------------------------------------------------------------------
  * DavidsonSymEigsSolver — replaces DavidsonSymEigsSolver.h:18-90 + JDSymEigsBase.h:28-187 (block Davidson with the
  * diagonal-preconditioned-residual correction).  The search space, its image under A and the Ritz vectors live in
- * HBM; the projected eigenproblem (<= 128 x 128) is solved on the host.  The search space holds 128 vectors: a larger
- * nvec_max is lowered to 128 - correction size (earlier restarts, same results).
+ * HBM; the projected eigenproblem (<= 256 x 256) is solved on the host.  The search space holds 256 vectors: a larger
+ * nvec_max is lowered to 256 - correction size (earlier restarts, same results).
  * Operators: a device CSR matrix, a dense device matrix, or a device-pointer callback plus diag(A).
  * ------------------------------------------------------------------------- */
 typedef struct mispec_davidson mispec_davidson;

@@ -240,7 +240,7 @@ void check_sizes(mispec_davidson& S)
     // fits — the solver then restarts earlier, which changes the iteration count, not the result; a space that cannot even
     // hold the initial vectors plus one correction block is an error.
     MISPEC_REQUIRE(S.init_size + S.corr_size <= kMaxCols,
-                   "DavidsonSymEigsSolver: the device search space holds at most 128 vectors (initial space + correction size <= 128)");
+                   "DavidsonSymEigsSolver: the device search space holds at most 128 vectors (initial space + correction size <= 256)");
     if (S.max_size + S.corr_size > kMaxCols)
         S.max_size = kMaxCols - S.corr_size;
     MISPEC_REQUIRE(S.init_size >= S.nev && S.corr_size <= S.init_size,

@@ -1113,7 +1113,7 @@ int fac_create_impl(mispec_ctx* ctx, const mispec_csr* A, const mispec_symshift*
             MISPEC_REQUIRE(D->ctx == ctx && D->rows == n && D->cols == n, "mispec_fac_create_dense: matrix belongs to another context / is not n x n");
         MISPEC_REQUIRE(n >= 1, "mispec_fac_create: n must be positive");
         MISPEC_REQUIRE(ncv >= 1 && ncv <= n, "mispec_fac_create: need 1 <= ncv <= n");
-        MISPEC_REQUIRE(ncv <= kMaxCols, "mispec_fac_create: the device factorisation holds at most 128 basis vectors (ncv <= 128)");
+        MISPEC_REQUIRE(ncv <= kMaxCols, "mispec_fac_create: the device factorisation holds at most 256 basis vectors (ncv <= 256)");
         if (Bop)
         {
             MISPEC_REQUIRE(A && !A2 && symmetric, "mispec_fac_create_geigs_reginv: needs a symmetric device matrix A");
@@ -1475,7 +1475,8 @@ extern "C" int mispec_fac_tridiag_eigen(mispec_fac* fac, double* evals_host, dou
         // host for the convergence test, so by default the m x m eigen-decomposition — a serial chain of rotations,
         // ~25 us on a host core against ~0.6 ms on one wavefront — runs where the data is.  MISPEC_SMALL=device
         // keeps it on the GPU (k_tridiag_eigen_w64 / k_tridiag_eigen; same routine, internal/SmallDense.h).
-        static const bool on_device = getenv("MISPEC_SMALL") && std::string(getenv("MISPEC_SMALL")) == "device";
+        static const bool on_device_env = getenv("MISPEC_SMALL") && std::string(getenv("MISPEC_SMALL")) == "device";
+        const bool on_device = on_device_env && m <= kMaxSmallDim;
         if (!on_device)
         {
             F.counts[FAM_SMALL]++;
@@ -1528,7 +1529,8 @@ extern "C" int mispec_fac_restart_sym(mispec_fac* fac, const double* shifts_host
         // shrinks with the rank count, so the sweeps run on the host core (same routine, internal/SmallDense.h,
         // ~40 us) and only Q (m x m) is uploaded.  MISPEC_RESTART=host|device overrides.
         static const char* where = getenv("MISPEC_RESTART");
-        const bool on_host = where ? std::string(where) == "host" : (F.sharded() && F.ctx->world() > 1);
+        // m > 128: the restart kernels keep the m x m Q in LDS and stop at 128 columns -> host
+        const bool on_host = m > kMaxSmallDim || (where ? std::string(where) == "host" : (F.sharded() && F.ctx->world() > 1));
         if (on_host)
         {
             F.counts[FAM_SMALL]++;

@@ -887,7 +887,7 @@ int launch_orth_panel(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a, i
 //                follow on the finished dst.  V is read 1.5 times instead of once — the price of ncv > 64.
 int launch_orth(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a)
 {
-    MISPEC_REQUIRE(a.ncol >= 0 && a.ncol <= kMaxCols, "orth kernel: more than 128 basis columns");
+    MISPEC_REQUIRE(a.ncol >= 0 && a.ncol <= kMaxCols, "orth kernel: more than 256 basis columns");
     if (a.ncol <= kPanelCols)
     {
         OrthArgs one = a;
@@ -1082,7 +1082,7 @@ void launch_vq_panel(const mispec_ctx& ctx, const double* V, int64_t ldv, int m,
 void launch_vq(const mispec_ctx& ctx, const double* V, int64_t ldv, int m, const double* Q, int ldq, int p, double* X,
                int64_t ldx, int64_t n)
 {
-    MISPEC_REQUIRE(m >= 1 && m <= kMaxCols && p >= 1 && p <= kMaxCols, "V*Q kernel: needs 1 <= m, p <= 128");
+    MISPEC_REQUIRE(m >= 1 && m <= kMaxCols && p >= 1 && p <= kMaxCols, "V*Q kernel: needs 1 <= m, p <= 256");
     if (m <= kPanelCols && p <= kPanelCols)
     {
         launch_vq_panel(ctx, V, ldv, m, Q, ldq, p, X, ldx, n, 0);

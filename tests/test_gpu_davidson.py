@@ -87,20 +87,20 @@ def test_errors(ctx):
         sa.DavidsonSymEigsSolver(op, 20)                                # nev <= n - 1
     big = sa.SparseSymMatProd(sp.diags(np.arange(1.0, 1001.0)).tocsc(), ctx=ctx)
     with pytest.raises(ValueError):
-        sa.DavidsonSymEigsSolver(big, 50).compute()                     # 2 nev + nev > 128 device columns
+        sa.DavidsonSymEigsSolver(big, 100).compute()                    # 2 nev + nev > 256 device columns
     with pytest.raises(ValueError):
         sa.DavidsonSymEigsSolver(big, 3).compute(sa.SortRule.LargestReal)  # a complex-only rule
 
 
 def test_search_space_larger_than_the_device_limit_is_lowered(ctx):
-    # nev = 20: the reference's default maximum (10 nev = 200) does not fit the 128 device columns; it is lowered to
-    # 128 - nev and the solve still meets the reference's bar
-    n, k = 1000, 20
+    # nev = 30: the reference's default maximum (10 nev = 300) does not fit the 256 device columns; it is lowered to
+    # 256 - nev and the solve still meets the reference's bar
+    n, k = 1000, 30
     A, S = davidson_sparse_fixture(n)
     eigs = sa.DavidsonSymEigsSolver(sa.SparseSymMatProd(A, ctx=ctx), k)
     assert eigs.sizes() == (2 * k, 10 * k, k)
     assert eigs.compute(sa.SortRule.LargestAlge) == k and eigs.info() == sa.CompInfo.Successful
-    assert eigs.sizes() == (2 * k, 128 - k, k)
+    assert eigs.sizes() == (2 * k, 256 - k, k)
     evals, evecs = eigs.eigenvalues(), eigs.eigenvectors()
     assert np.abs(S @ evecs - evecs * evals).max() < 1e-10
     assert np.abs(evals - np.linalg.eigvalsh(S.toarray())[::-1][:k]).max() < 1e-9

@@ -75,7 +75,7 @@ def test_arnoldi_cpp_identities_user_op(ctx, symmetric):
 
 
 @pytest.mark.parametrize("n,prob,m", [(100, 0.1, 20), (1000, 0.01, 50), (1000, 0.01, 64), (1000, 0.01, 65), (1000, 0.01, 100),
-                                      (1000, 0.01, 128)])  # more than 64 columns: column panels
+                                      (1000, 0.01, 128), (1000, 0.01, 200), (1000, 0.01, 256)])  # > 64 columns: column panels
 def test_lanczos_on_device_matrix_vs_oracle(ctx, n, prob, m):
     A, S = sparse_fixture(n, prob)
     op = sa.SparseSymMatProd(A, ctx=ctx)
@@ -188,8 +188,24 @@ def test_wide_basis_restart_and_limits(ctx):
     assert np.abs(resid).max() < 1e-10 and np.abs(V.T @ V - np.eye(k)).max() < 1e-11   # A V = V H + f e_k'
     fac.factorize_from(k, m)
     check_identities(fac, Sd, m, tol=1e-10)
-    with pytest.raises(ValueError, match="128"):
-        sa.Factorization(sa.SparseGenMatProd(S3, ctx=ctx), 129, True)
+    with pytest.raises(ValueError, match="256"):
+        sa.Factorization(sa.SparseGenMatProd(S3, ctx=ctx), 257, True)
+    # m = 200 > 128: the restart sweeps run on the host (the LDS-resident kernel stops at 128 columns)
+    m2, k2 = 200, 90
+    fac2 = sa.Factorization(sa.SparseGenMatProd(S3, ctx=ctx), m2, True)
+    fac2.init_random(0)
+    fac2.factorize_from(1, m2)
+    check_identities(fac2, Sd, m2, tol=1e-10)
+    ev2, _ = fac2.tridiag_eigen()
+    order2 = np.argsort(-np.abs(ev2))
+    fac2.restart_sym(ev2[order2][k2:])
+    assert fac2.subspace_dim() == k2
+    V2, H2, f2 = fac2.matrix_V(k2), fac2.matrix_H()[:k2, :k2], fac2.vector_f()
+    r2 = Sd @ V2 - V2 @ H2
+    r2[:, k2 - 1] -= f2
+    assert np.abs(r2).max() < 1e-10 and np.abs(V2.T @ V2 - np.eye(k2)).max() < 1e-11
+    fac2.factorize_from(k2, m2)
+    check_identities(fac2, Sd, m2, tol=1e-10)
 
 
 def test_vq_on_matrix_cores_matches_fma_kernel():

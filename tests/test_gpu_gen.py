@@ -142,6 +142,20 @@ def test_gen_wide_basis(ctx):
     assert np.abs(A @ U - U * ev).max() <= 1e-9
 
 
+def test_gen_very_wide_basis(ctx):
+    # ncv = 150 > 128 columns
+    from helpers import sparse_fixture
+
+    n, nev, ncv = 1000, 60, 150
+    A, _ = sparse_fixture(n, 0.01)
+    eigs = sa.GenEigsSolver(sa.SparseGenMatProd(A, ctx=ctx), nev, ncv)
+    eigs.init()
+    nconv = eigs.compute(sa.SortRule.LargestMagn, 1000, 1e-10)
+    assert nconv >= nev - 1
+    ev, U = eigs.eigenvalues(), eigs.eigenvectors()
+    assert np.abs(A @ U - U * ev).max() <= 1e-9
+
+
 # ---- GenEigsRealShiftSolver + SparseGenRealShiftSolve (GenEigsRealShiftSolver.h; test/GenEigsRealShift.cpp:146-180) -----
 REAL_SHIFT_CASES = [(10, 0.5, 3, 6, 1.0), (100, 0.1, 10, 30, 10.0), (1000, 0.01, 20, 50, 100.0)]
 

@@ -272,6 +272,26 @@ def test_many_eigenpairs_wide_basis(ctx, rule):
     assert eigs.num_operations() == pytest.approx(oe.num_operations(), rel=0.15)
 
 
+def test_very_wide_basis_beyond_the_restart_kernel(ctx):
+    # nev = 100, ncv = 220: more than the 128 columns the LDS-resident restart kernel holds -> host restart sweeps,
+    # four column panels in the orthogonalisation
+    n, nev, ncv = 1000, 100, 220
+    A, S = sparse_fixture(n, 0.01)
+    eigs = sa.SymEigsSolver(sa.SparseSymMatProd(A, ctx=ctx), nev, ncv)
+    eigs.init()
+    assert eigs.compute(sa.SortRule.LargestAlge, 1000, 1e-10) == nev
+    ev, U = eigs.eigenvalues(), eigs.eigenvectors()
+    assert np.abs(S @ U - U * ev).max() <= 1e-9
+    assert np.abs(ev - np.linalg.eigvalsh(S.toarray())[::-1][:nev]).max() <= 1e-9
+    oe = O.SymEigsSolver(O.Op.csr(n, n, S.indptr, S.indices, S.data), nev, ncv)
+    oe.init()
+    assert oe.compute(O.LargestAlge, 1000, 1e-10) == nev
+    assert np.abs(ev - oe.eigenvalues()).max() <= 1e-9
+    assert eigs.num_operations() == pytest.approx(oe.num_operations(), rel=0.15)
+    with pytest.raises(ValueError):
+        sa.SymEigsSolver(sa.SparseSymMatProd(A, ctx=ctx), 100, 257)
+
+
 def test_wide_basis_at_scale(ctx):
     n, nev, ncv = 300_000, 40, 96
     op = sa.SparseSymMatProd.synth_band(n, ctx=ctx)
