@@ -3,7 +3,7 @@
   C5  SymEigsShiftSolver on a 2M x 2M banded (half-bandwidth 3) definite matrix, sigma = 0, k = 6, ncv = 20
 Prints one JSON object per configuration (eigenpairs/s, per-kernel times, residuals).
 
-    python tools/bench_configs.py [c4] [c5] [g1]
+    python tools/bench_configs.py [c4] [c5] [g1] [d1]
 
   G1  SymGEigsSolver (regular-inverse mode) on a 2M x 2M pencil: A the M-band pattern, B a tridiagonal mass matrix;
       k = 6, ncv = 20 — not a BASELINE.json config, recorded as the measurement of SURVEY.md 8f row 4
@@ -98,3 +98,28 @@ if "g1" in which:
                       "seconds": dt, "eigenpairs_per_s": nconv / dt, "nconv": nconv, "num_operations": s.num_operations(),
                       "num_iterations": s.num_iterations(), "max_residual": float(res.max()),
                       "cg_iterations_last_solve": bop.last_iterations()}))
+
+if "d1" in which:
+    # DavidsonSymEigsSolver (not a BASELINE.json config): 2M x 2M banded matrix with the reference fixtures' diagonal ramp
+    # a_ii = i + 1 (test/DavidsonSymEigs.cpp:33-67) and weak off-diagonal bands, nev = 10, largest eigenvalues
+    n, nev = 2_000_000, 10
+    rng = np.random.default_rng(2)
+    L = sp.diags([np.arange(1.0, n + 1.0)] + [0.01 * rng.uniform(-1, 1, n - o) for o in (1, 2, 1000)], [0, -1, -2, -1000], format="csc")
+    op = sa.SparseSymMatProd(L, ctx=ctx)
+    best = None
+    for r in range(3):
+        s = sa.DavidsonSymEigsSolver(op, nev)
+        ctx.sync()
+        t0 = time.perf_counter()
+        nconv = s.compute(sa.SortRule.LargestAlge, 200, 1e-8)
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        if r > 0 and (best is None or dt < best[0]):
+            best = (dt, s, nconv)
+    dt, s, nconv = best
+    ev, U = s.eigenvalues(), s.eigenvectors()
+    S = (L + sp.tril(L, -1).T).tocsr()
+    print(json.dumps({"config": "D1 DavidsonSymEigsSolver 2M x 2M banded, diagonal ramp, nev=10, LargestAlge, tol 1e-8", "seconds": dt,
+                      "eigenpairs_per_s": nconv / dt, "nconv": nconv, "num_iterations": s.num_iterations(),
+                      "num_operations": s.num_operations(), "spmv_format": op.spmv_format(),
+                      "max_residual_norm": float(np.linalg.norm(S @ U - U * ev, axis=0).max())}))
