@@ -318,3 +318,20 @@ def test_diagonal_storage_needs_sorted_rows_without_duplicates(ctx):
         sa.check(sa.lib().mispec_spmv_host(h, x.ctypes.data_as(dp), y.ctypes.data_as(dp)))
         assert np.array_equal(y, O.Op.csr(n, n, rp, ci, vals).perform_op(x)), kind
         sa.check(sa.lib().mispec_csr_destroy(h))
+
+
+@pytest.mark.parametrize("offsets,fmt", [
+    (tuple(range(1, 4)) + tuple(range(500, 504)) + tuple(range(9000, 9003)), 2),   # 21 diagonals, 5 clusters: windows, 3 groups
+    (tuple(1000 * k for k in range(1, 16)), 2),                                    # 31 diagonals, 31 clusters: direct x loads, 4 groups
+    (tuple(range(1, 16)), 2),                                                      # 31 diagonals in one cluster: windows, 4 groups
+    (tuple(7 * k for k in range(1, 17)), 1),                                       # 33 diagonals: offset codes only
+])
+def test_diagonal_storage_with_many_diagonals(ctx, offsets, fmt):
+    n = 40_000
+    op = sa.SparseSymMatProd.synth_band(n, offsets=offsets, ctx=ctx)
+    assert op.offset_codes() == 2 * len(offsets) + 1 and op.spmv_format() == fmt
+    x = rand_x(n, 17)
+    y_codes, y_plain = _both_formats(op, x)
+    assert np.array_equal(y_codes, y_plain)
+    rp, ci, v = O.synth_band_csr(n, offsets=offsets)
+    assert np.array_equal(y_codes, O.Op.csr(n, n, rp, ci, v).perform_op(x))
