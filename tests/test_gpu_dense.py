@@ -238,3 +238,22 @@ def test_dense_shift_solve_and_cholesky_operators(ctx):
     assert np.abs(Sa @ X - Bd @ X * lam).max() < 1e-9
     with pytest.raises(ValueError):
         sa.DenseCholesky(np.zeros((3, 4)), ctx=ctx)
+
+
+@pytest.mark.parametrize("n", [61, 127])
+def test_odd_sized_dense_factor_paths(ctx, n):
+    # odd n: the explicit inverses have an odd row stride, which takes the GEMV kernel's scalar (non-16-byte) path
+    M, S = sym_dense(n, 5)
+    x = np.random.default_rng(6).uniform(-1, 1, n)
+    op = sa.DenseSymShiftSolve(M, ctx=ctx)
+    op.set_shift(0.25)
+    assert np.abs((S - 0.25 * np.eye(n)) @ op.perform_op(x) - x).max() < 1e-10
+    G = np.random.default_rng(7).uniform(-1, 1, (n, n))
+    g = sa.DenseGenComplexShiftSolve(G, ctx=ctx)
+    g.set_shift(0.1, 0.4)
+    assert np.abs(g.perform_op(x) - np.linalg.solve(G - (0.1 + 0.4j) * np.eye(n), x).real).max() < 1e-10
+    B = S @ S.T + np.eye(n)
+    chol = sa.DenseCholesky(B, ctx=ctx)
+    L = np.linalg.cholesky(B)
+    assert np.abs(chol.lower_triangular_solve(x) - np.linalg.solve(L, x)).max() < 1e-10
+    assert np.abs(chol.upper_triangular_solve(x) - np.linalg.solve(L.T, x)).max() < 1e-10
