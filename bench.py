@@ -186,6 +186,27 @@ def main():
     spmv_bytes = prof["spmv_bytes"]
     achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
 
+    # The timed region runs whatever storage format the library picked for this matrix (diagonal storage for the
+    # benchmark's band matrix).  BASELINE.json words its roofline target for a CSR SpMV, so the two CSR kernels of the same
+    # matrix are measured as well — one extra solve each, outside the timed region, same dispatch-bound events.
+    csr_kernels = None
+    if world == 1 and not args.no_profile and op.spmv_format() != 0:
+        csr_kernels = {}
+        try:
+            for fmt, name in ((1, "csr_offset_codes"), (0, "csr_int32")):
+                op.set_spmv_format(fmt)
+                if op.spmv_format() != fmt:
+                    continue
+                alt, alt_nconv, _ = solve(2)
+                pa = alt.get_profile()
+                ms = pa["ms_spmv"] / max(pa["n_spmv"], 1)
+                gbps = spmv_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+                csr_kernels[name] = {"ms_per_launch": ms, "achieved": gbps, "frac": gbps / HBM_PEAK_GBPS, "launches": int(pa["n_spmv"]),
+                                     "nconv": int(alt_nconv), "num_operations": int(alt.num_operations())}
+                del alt
+        finally:
+            op.set_spmv_format(-1)
+
     # stand-alone SpMV (same kernel, x resident) as a cross-check of the in-loop number
     x = torch.rand(args.n if world == 1 else int(sa.lib().mispec_shard_block(args.n, world)) * world, dtype=torch.float64,
                    device="cuda") - 0.5
@@ -249,6 +270,9 @@ def main():
                 # vector streams (v_prev, v) that the BASELINE.md formula above does not credit
                 "fused_epilogue_bytes_per_launch": spmv_bytes + 16.0 * op.local_rows(),
                 "fused_epilogue_frac": (spmv_bytes + 16.0 * op.local_rows()) / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if spmv_ms > 0 else 0.0,
+                "csr_kernels_same_matrix": csr_kernels,
+                "csr_kernels_note": "in-loop figures of the CSR SpMV kernels on the same matrix (one extra solve each, outside the timed region); "
+                                    "null when the timed region already ran the int32 CSR kernel",
                 "standalone_ms_per_launch": alone_ms,
                 "standalone_gbps": spmv_bytes / (alone_ms * 1e-3) / 1e9,
             },
