@@ -1,18 +1,25 @@
 #!/usr/bin/env python
 """Headline benchmark: BASELINE.json configs[1] — SymEigsSolver on a 10M x 10M, ~15 nnz/row fp64 symmetric CSR,
-k = 20, ncv = 40 — on N MI355X of one node (N > 1: the same matrix row-partitioned, RCCL all-gather of the
-Krylov vector per SpMV = configs[2], strong scaling).
+k = 20, ncv = 40 — on N MI355X of one node (N > 1: the same matrix row-partitioned, the Krylov vector exchanged over
+xGMI by RCCL before every SpMV = configs[2], strong scaling).
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus 8                      # spawns its 8 ranks itself (re-exec through torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
 
 A "step" is ONE complete solve: init() + compute(LargestMagn, tol) + eigenvectors() with the matrix already
-resident in HBM (generated there by the counter-hash generator of SURVEY.md §8d).  Rank 0 prints one JSON
-line: value = eigenpairs/s of the whole job; `roofline` = the per-iteration CSR SpMV kernel, algorithmic
-bytes / mean launch duration from HIP events recorded on the solver's stream inside the timed region;
-`cpu_baseline` = the CPU oracle (Eigen-free restatement of the reference, 1 thread like the reference) timed on
-a bounded sample of the same workload.
+resident in HBM (generated there by the counter-hash generator of SURVEY.md §8d).  Rank 0 prints one JSON line:
+  value      eigenpairs/s of the whole job;
+  roofline   the SpMV kernel that ran in the timed region, on the bytes THAT kernel has to move (its storage format's
+             values/indices + x + y + the fused epilogue's two vector reads) / its mean launch duration from HIP events
+             bound to the dispatches inside the timed region; `traffic` = the PMC-measured HBM bytes per launch of the same
+             instantiation (profiles/*pmc_traffic.json); the CSR-int32 byte count of SURVEY.md 8d over the same time is
+             reported separately as `csr_equivalent_gbps` (it is NOT an HBM rate when a compressed format ran);
+  secondary  driver-run figures of the other configurations: CSR kernels on the same matrix, M-rand (scattered columns,
+             stand-alone and inside a solver loop), C4 (GenEigsSolver 5M) and C5 (shift-and-invert 2M), all on true bytes;
+  cpu_baseline  the CPU oracle (Eigen-free restatement of the reference, 1 thread like the reference) timed on a bounded
+             sample of the same workload.
 """
 import argparse
 import json
@@ -38,6 +45,7 @@ def parse():
                    help="1e-11 so that ||Av - lv||/||v|| <= 1e-10 holds for |l| ~ 2.5 (the criterion is relative to |l|)")
     p.add_argument("--selection", default="LargestMagn")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations (M-rand, C4, C5, CSR kernels)")
     p.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     p.add_argument("--profile-level", type=int, default=2, choices=[1, 2],
                     help="HIP-event instrumentation of the timed solves: 2 = operator applications only (default), 1 = every kernel family")
@@ -46,10 +54,23 @@ def parse():
     return p.parse_args()
 
 
+def respawn_as_ranks(args):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks through torch.distributed.run on a free
+    local port and hand their output through (rank 0 prints the JSON line)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def cpu_baseline(args, gpu_nops, gpu_nconv):
     """The oracle (a 'port': Eigen is absent, see oracle/spectra_oracle.hpp) on the host, 1 thread."""
-    import numpy as np
-
     import oracle as O
 
     t0 = time.time()
@@ -61,7 +82,7 @@ def cpu_baseline(args, gpu_nops, gpu_nconv):
     t_spmv = op.time_op(x, 3)
     per_op = secs / nops
     est_total = per_op * gpu_nops
-    return {
+    out = {
         "value": gpu_nconv / est_total,
         "unit": "eigenpairs/s",
         "cores": 1,
@@ -74,6 +95,20 @@ def cpu_baseline(args, gpu_nops, gpu_nconv):
         "spmv_seconds": t_spmv,
         "spmv_gbps": (12.0 * len(v) + 20.0 * args.n + 4) / t_spmv / 1e9,
     }
+    # the oracle's COMPLETE solve of this configuration, run once on the build host (tests/golden/full_size_c2.json)
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "full_size_c2.json")) as f:
+            g = json.load(f)
+        if g["n"] == args.n and g["nev"] == args.nev and g["ncv"] == args.ncv:
+            out["complete_solve_on_build_host"] = {"seconds": g["oracle_seconds_one_thread"], "num_operations": g["num_operations"],
+                                                   "eigenpairs_per_s": g["nconv"] / g["oracle_seconds_one_thread"],
+                                                   "note": "not this box: recorded when the golden file was generated"}
+    except Exception:  # noqa: BLE001 - informational only
+        pass
+    return out
+
+
+KERNEL_OF_FORMAT = {0: "k_spmv_csr_stream<EPI, NT, 256, CODES=false>", 1: "k_spmv_csr_stream<EPI, NT, 256, CODES=true>", 2: "k_spmv_dia_win / k_spmv_dia"}
 
 
 def pmc_traffic(n, fmt):
@@ -81,8 +116,7 @@ def pmc_traffic(n, fmt):
     2 diagonal storage) as measured by the committed PMC passes (tools/pmc_summarize.py), or None."""
     import glob
 
-    here = os.path.dirname(os.path.abspath(__file__))
-    for path in sorted(glob.glob(os.path.join(here, "profiles", "*pmc_traffic.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
         try:
             with open(path) as f:
                 d = json.load(f)
@@ -92,16 +126,159 @@ def pmc_traffic(n, fmt):
                 args_ = name.split("<", 1)[1].rstrip(">").split(",") if "<" in name else []
                 is_coded = len(args_) >= 4 and args_[3].strip() == "true"
                 if fmt == 2 and name.startswith("k_spmv_dia") and "<true" in name:
-                    return float(rec["hbm_bytes"])
+                    return float(rec["hbm_bytes"]), os.path.basename(path)
                 if fmt != 2 and name.startswith("k_spmv_csr_stream<true") and is_coded == (fmt == 1):
-                    return float(rec["hbm_bytes"])
+                    return float(rec["hbm_bytes"]), os.path.basename(path)
         except Exception:  # noqa: BLE001 - a malformed summary just means "no PMC figure"
             continue
-    return None
+    return None, None
+
+
+def spmv_block(op, ms, launches, fused):
+    """Roofline figures of one SpMV instantiation on the bytes it has to move."""
+    fmt = op.spmv_format()
+    moved = op.stored_bytes() + (16.0 * op.local_rows() if fused else 0.0)
+    gbps = moved / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    return {"kernel": KERNEL_OF_FORMAT[fmt], "ms_per_launch": ms, "launches": int(launches), "bytes_per_launch": moved,
+            "achieved": gbps, "frac": gbps / HBM_PEAK_GBPS,
+            "csr_equivalent_gbps": op.algorithmic_bytes() / (ms * 1e-3) / 1e9 if ms > 0 else 0.0}
+
+
+def standalone_ms(op, ncols, reps):
+    import torch
+
+    x = torch.rand(ncols, dtype=torch.float64, device="cuda") - 0.5
+    y = torch.empty(op.local_rows() + 2, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    op.spmv_time(x.data_ptr(), y.data_ptr(), 5)
+    return op.spmv_time(x.data_ptr(), y.data_ptr(), reps)
+
+
+def m_rand_host(n, seed=20240607):
+    """M-rand of SURVEY.md 8d: every row has 7 partners at uniformly random columns, symmetrised (degrees vary around 15)."""
+    import numpy as np
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(seed)
+    rows = np.repeat(np.arange(n, dtype=np.int64), 7)
+    cols = rng.integers(0, n, size=rows.size, dtype=np.int64)
+    vals = rng.uniform(-0.5, 0.5, size=rows.size)
+    U = sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()
+    U.sum_duplicates()
+    A = (U + U.T + sp.diags(rng.uniform(-0.5, 0.5, n))).tocsr()
+    A.sort_indices()
+    return A
+
+
+def secondary_configs(args, ctx, op, sa):
+    """Driver-run figures of the other configurations (outside the timed region, one GPU)."""
+    import numpy as np
+    import scipy.sparse as sp
+
+    out = {}
+    rule = sa.SortRule[args.selection]
+
+    # (1) the CSR kernels on the headline matrix, inside a solver loop (BASELINE.json words its roofline target for a CSR SpMV)
+    csr = {}
+    try:
+        for fmt, name in ((0, "csr_int32"), (1, "csr_offset_codes")):
+            op.set_spmv_format(fmt)
+            if op.spmv_format() != fmt:
+                continue
+            e = sa.SymEigsSolver(op, args.nev, args.ncv)
+            e.profile(2)
+            e.init()
+            nconv = e.compute(rule, 1000, args.tol)
+            e.eigenvectors(to_host=False)
+            p = e.get_profile()
+            blk = spmv_block(op, p["ms_spmv"] / max(p["n_spmv"], 1), p["n_spmv"], True)
+            blk["traffic"], blk["traffic_source"] = pmc_traffic(args.n, fmt)
+            blk.update({"nconv": int(nconv), "num_operations": int(e.num_operations())})
+            csr[name] = blk
+            del e
+    finally:
+        op.set_spmv_format(-1)
+    out["csr_kernels_same_matrix"] = csr
+
+    # (2) M-rand at the headline size: scattered columns, the gather-bound case
+    t0 = time.perf_counter()
+    A = m_rand_host(args.n)
+    t_gen = time.perf_counter() - t0
+    rop = sa.SparseSymMatProd(sp.tril(A).tocsc(), ctx=ctx)
+    alone = standalone_ms(rop, args.n, 20)
+    e = sa.SymEigsSolver(rop, args.nev, args.ncv)
+    e.profile(2)
+    e.init()
+    t0 = time.perf_counter()
+    nconv = e.compute(rule, 12, args.tol)  # a bounded number of restarts: the in-loop SpMV time does not need convergence
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    p = e.get_profile()
+    inloop = spmv_block(rop, p["ms_spmv"] / max(p["n_spmv"], 1), p["n_spmv"], True)
+    out["m_rand"] = {"n": args.n, "nnz": rop.nnz(), "spmv_format": rop.spmv_format(), "reordering": rop.reordering() if hasattr(rop, "reordering") else "none",
+                     "standalone": spmv_block(rop, alone, 20, False), "in_loop": inloop,
+                     "solve_12_restarts": {"seconds": dt, "nconv": int(nconv), "num_operations": int(e.num_operations())},
+                     "host_generation_seconds": t_gen}
+    del e, rop, A
+
+    # (3) C4: GenEigsSolver on the 5M non-symmetric band matrix, k = 10, ncv = 30
+    gop = sa.SparseGenMatProd.synth_band(5_000_000, ctx=ctx)
+    best = None
+    for r in range(3):
+        g = sa.GenEigsSolver(gop, 10, 30)
+        g.profile(2)
+        ctx.sync()
+        t0 = time.perf_counter()
+        g.init()
+        nconv = g.compute(sa.SortRule.LargestMagn, 1000, 1e-11)
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        if r > 0 and (best is None or dt < best[0]):
+            best = (dt, g, nconv)
+    dt, g, nconv = best
+    p = g.get_profile()
+    out["c4"] = {"config": "GenEigsSolver 5M x 5M non-symmetric CSR, k=10, ncv=30, LargestMagn, tol 1e-11", "seconds": dt,
+                 "eigenpairs_per_s": nconv / dt, "nconv": int(nconv), "num_operations": int(g.num_operations()),
+                 "max_residual": float(g.residuals().max()), "spmv": spmv_block(gop, p["ms_spmv"] / max(p["n_spmv"], 1), p["n_spmv"], False)}
+    del g, gop, best
+
+    # (4) C5: shift-and-invert on the 2M banded matrix, sigma = 0, k = 6, ncv = 20
+    n5, b = 2_000_000, 3
+    rng = np.random.default_rng(5)
+    diags = [rng.uniform(-0.5, 0.5, n5 - d) for d in range(1, b + 1)]
+    A5 = sp.diags([rng.uniform(-0.5, 0.5, n5) + b + 0.5] + diags + diags, [0] + list(range(1, b + 1)) + [-d for d in range(1, b + 1)], format="csc")
+    sop = sa.SparseSymShiftSolve(sp.tril(A5).tocsc(), ctx=ctx)
+    sop.set_shift(0.0)
+    t0 = time.perf_counter()
+    sop.set_shift(0.0)
+    t_factor = time.perf_counter() - t0
+    best = None
+    for r in range(3):
+        s = sa.SymEigsShiftSolver(sop, 6, 20, 0.0)
+        s.profile(2)
+        ctx.sync()
+        t0 = time.perf_counter()
+        s.init()
+        nconv = s.compute(sa.SortRule.LargestMagn, 1000, 1e-11)
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        if r > 0 and (best is None or dt < best[0]):
+            best = (dt, s, nconv)
+    dt, s, nconv = best
+    p = s.get_profile()
+    solve_ms = p["ms_spmv"] / max(p["n_spmv"], 1)
+    solve_bytes = (2 * b + 1 + 2 * b) * 8.0 * n5  # factor bands + spikes + right-hand side / solution (DESIGN.md 3.5)
+    out["c5"] = {"config": "SymEigsShiftSolver 2M x 2M banded (half-bandwidth 3), sigma=0, k=6, ncv=20, tol 1e-11", "seconds": dt,
+                 "eigenpairs_per_s": nconv / dt, "nconv": int(nconv), "num_operations": int(s.num_operations()),
+                 "set_shift_seconds": t_factor, "solve_ms": solve_ms, "solve_bytes": solve_bytes,
+                 "solve_frac_of_hbm_peak": solve_bytes / (solve_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if solve_ms > 0 else None}
+    return out
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(respawn_as_ranks(args))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -140,6 +317,25 @@ def main():
         ncols = eigs.eigenvectors(to_host=False)  # V * Y formed in HBM (1.6 GB at n = 1e7; not pulled over PCIe)
         return eigs, nconv, ncols
 
+    def timed_steps(steps):
+        """`steps` solves between barriers; returns (max-over-ranks seconds, pairs, last solver, accumulated profile)."""
+        barrier()
+        t0 = time.perf_counter()
+        pairs, acc, eigs = 0, None, None
+        for _ in range(steps):
+            # level 2: HIP events bracket only the operator applications (the roofline figure is measured live in the
+            # timed region); the other families would cost ~10 more event records per Lanczos step
+            eigs, nconv, _ = solve(0 if args.no_profile else args.profile_level)
+            pairs += nconv
+            p = eigs.get_profile()
+            if acc is None:
+                acc = dict(p)
+            else:
+                for k, v in p.items():
+                    acc[k] = acc[k] + v if k != "spmv_bytes" else v
+        barrier()
+        return sdist.max_over_ranks(time.perf_counter() - t0), pairs, eigs, acc
+
     exchange_note = None
     if world > 1:
         # Self-check of the point-to-point neighbour exchange (outside the timed region): if the solve it drives
@@ -155,25 +351,26 @@ def main():
         del chk
     for _ in range(args.warmup):
         solve(False)
-    barrier()
-    t0 = time.perf_counter()
-    solvers = []
-    total_pairs = 0
-    for _ in range(args.steps):
-        # level 2: HIP events bracket only the operator applications (the roofline figure is measured live in the
-        # timed region); the other families would cost ~10 more event records per Lanczos step
-        eigs, nconv, ncols = solve(0 if args.no_profile else args.profile_level)
-        total_pairs += nconv
-        solvers.append(eigs)
-    barrier()
-    elapsed = sdist.max_over_ranks(time.perf_counter() - t0)
+    elapsed, total_pairs, eigs, prof = timed_steps(args.steps)
 
     # ---- everything below is outside the timed region -------------------------------------------------
-    eigs = solvers[-1]
-    prof = {k: 0.0 for k in eigs.get_profile()}
-    for s in solvers:
-        for k, v in s.get_profile().items():
-            prof[k] = prof[k] + v if k != "spmv_bytes" else v
+    halo, recv_doubles = eigs.exchange_info()
+    # north_star words the exchange as an all-gather of the Krylov vector: when the timed region used the neighbour
+    # exchange, the same number of steps is also run with the all-gather and reported next to it
+    allgather_run = None
+    if world > 1 and halo:
+        prev = os.environ.get("MISPEC_EXCHANGE")
+        os.environ["MISPEC_EXCHANGE"] = "allgather"
+        solve(False)
+        ag_elapsed, ag_pairs, ag_eigs, ag_prof = timed_steps(args.steps)
+        allgather_run = {"value": ag_pairs / ag_elapsed, "ms_per_step": 1e3 * ag_elapsed / args.steps,
+                         "spmv_ms_per_launch_incl_exchange_wait": ag_prof["ms_spmv"] / max(ag_prof["n_spmv"], 1),
+                         "moved_mb_per_product_per_rank": (world - 1) * int(sa.lib().mispec_shard_block(args.n, world)) * 8 / 1e6}
+        del ag_eigs
+        if prev is None:
+            del os.environ["MISPEC_EXCHANGE"]
+        else:
+            os.environ["MISPEC_EXCHANGE"] = prev
     # per-family kernel split: one more solve with every family instrumented, not part of `value`
     split = None
     if not args.no_profile:
@@ -183,48 +380,21 @@ def main():
     resid = eigs.residuals()
     evals = eigs.eigenvalues()
     spmv_ms = prof["ms_spmv"] / max(prof["n_spmv"], 1)
-    spmv_bytes = prof["spmv_bytes"]
-    achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
+    fmt = op.spmv_format()
+    head = spmv_block(op, spmv_ms, prof["n_spmv"], True)
+    alone_ms = standalone_ms(op, args.n if world == 1 else int(sa.lib().mispec_shard_block(args.n, world)) * world, args.spmv_reps)
 
-    # The timed region runs whatever storage format the library picked for this matrix (diagonal storage for the
-    # benchmark's band matrix).  BASELINE.json words its roofline target for a CSR SpMV, so the two CSR kernels of the same
-    # matrix are measured as well — one extra solve each, outside the timed region, same dispatch-bound events.
-    csr_kernels = None
-    if world == 1 and not args.no_profile and op.spmv_format() != 0:
-        csr_kernels = {}
-        try:
-            for fmt, name in ((1, "csr_offset_codes"), (0, "csr_int32")):
-                op.set_spmv_format(fmt)
-                if op.spmv_format() != fmt:
-                    continue
-                alt, alt_nconv, _ = solve(2)
-                pa = alt.get_profile()
-                ms = pa["ms_spmv"] / max(pa["n_spmv"], 1)
-                gbps = spmv_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-                csr_kernels[name] = {"ms_per_launch": ms, "achieved": gbps, "frac": gbps / HBM_PEAK_GBPS, "launches": int(pa["n_spmv"]),
-                                     "nconv": int(alt_nconv), "num_operations": int(alt.num_operations())}
-                del alt
-        finally:
-            op.set_spmv_format(-1)
-
-    # stand-alone SpMV (same kernel, x resident) as a cross-check of the in-loop number
-    x = torch.rand(args.n if world == 1 else int(sa.lib().mispec_shard_block(args.n, world)) * world, dtype=torch.float64,
-                   device="cuda") - 0.5
-    y = torch.empty(op.local_rows() + 2, dtype=torch.float64, device="cuda")
-    torch.cuda.synchronize()
-    op.spmv_time(x.data_ptr(), y.data_ptr(), 5)
-    alone_ms = op.spmv_time(x.data_ptr(), y.data_ptr(), args.spmv_reps)
-
-    halo, recv_doubles = eigs.exchange_info()
     if world == 1:
         exchange_desc = ""
     elif halo:
         exchange_desc = (f", RCCL point-to-point exchange of the referenced parts of the Krylov vector per SpMV "
                          f"({recv_doubles * 8 / 1e6:.2f} MB received by rank 0; the all-gather would move "
-                         f"{(world - 1) * int(sa.lib().mispec_shard_block(args.n, world)) * 8 / 1e6:.1f} MB)")
+                         f"{(world - 1) * int(sa.lib().mispec_shard_block(args.n, world)) * 8 / 1e6:.1f} MB; "
+                         f"the all-gather variant is timed as well: `allgather_variant`)")
     else:
         exchange_desc = ", RCCL all-gather of the Krylov vector per SpMV" + (f" ({exchange_note})" if exchange_note else "")
     if rank == 0:
+        traffic, traffic_file = pmc_traffic(args.n, fmt) if world == 1 else (None, None)
         out = {
             "metric": "eigenpairs_per_sec",
             "value": total_pairs / elapsed,
@@ -244,37 +414,36 @@ def main():
                 "n": args.n, "nnz_per_gpu": nnz_local, "nev": args.nev, "ncv": args.ncv, "selection": args.selection,
                 "tol": args.tol, "start_vector": "SimpleRandom(0) (reference default)",
                 "parallelism": f"row-shard x{world}" + exchange_desc,
+                "eigenvectors": ("X = V*Y is formed in HBM and left there (the reference's eigenvectors() returns a host matrix: "
+                                 f"the D2H copy of {8e-9 * args.n * args.nev:.1f} GB would add ~{8e-9 * args.n * args.nev / 55 * 1e3:.0f} ms per solve "
+                                 "at ~55 GB/s PCIe and is not part of `value`)"),
             },
             "roofline": {
-                "kernel": ("k_spmv_dia_win / k_spmv_dia" if op.spmv_format() == 2 else "k_spmv_csr_stream") + " (SpMV fused with w -= beta*v_prev and the alpha dot)",
+                "kernel": head["kernel"] + " (SpMV fused with w -= beta*v_prev and the alpha dot)",
                 "bound": "hbm",
-                "achieved": achieved,
+                "achieved": head["achieved"],
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": pmc_traffic(args.n, op.spmv_format()) if world == 1 else None,
-                "traffic_source": "bytes per launch of the in-loop SpMV from the newest profiles/*pmc_traffic.json "
-                                  "(rocprofv3 PMC passes need their own profiler run; see profiles/README.md)",
-                "bytes_per_launch": spmv_bytes,
-                "bytes_note": "algorithmic bytes of a CSR SpMV with int32 indices: 12 nnz + 4 (rows+1) + 8 cols + 8 rows (SURVEY.md 8d)",
-                # what this matrix's index format makes the kernel move at least (x once): with offset codes the column
-                # index costs 1 byte instead of 4, so `achieved` can exceed what the same time buys in raw HBM bytes
+                "frac": head["frac"],
+                "traffic": traffic,
+                "traffic_source": (f"profiles/{traffic_file}: " if traffic_file else "") +
+                                  "HBM bytes per launch of the in-loop SpMV instantiation from rocprofv3 PMC passes (FETCH_SIZE x calibration + "
+                                  "WRITE_SIZE, separate runs; see profiles/README.md)",
+                "bytes_per_launch": head["bytes_per_launch"],
+                "bytes_note": {0: "CSR int32: 12 nnz + 4 (rows+1) + 8 cols + 8 rows (SURVEY.md 8d) + 16 rows for the fused epilogue's v_prev / v reads",
+                               1: "offset-coded CSR: 9 nnz + 4 (rows+1) + 8 cols + 8 rows + 16 rows for the fused epilogue's v_prev / v reads",
+                               2: "diagonal storage: 8 ndia rows + 8 cols + 8 rows + 16 rows for the fused epilogue's v_prev / v reads — "
+                                  "the bytes this kernel has to move, not the CSR figure"}[fmt],
                 "index_format": {0: "CSR, int32 column indices",
                                  1: f"CSR, offset codes: 1 byte per entry into {op.offset_codes()} diagonals",
-                                 2: f"diagonal storage: {op.offset_codes()} diagonals, no index, no gather"}[op.spmv_format()],
-                "stored_bytes_per_launch": op.stored_bytes(),
-                "stored_gbps": op.stored_bytes() / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0,
+                                 2: f"diagonal storage: {op.offset_codes()} diagonals, no index, no gather"}[fmt],
                 "ms_per_launch": spmv_ms,
                 "launches": int(prof["n_spmv"]),
-                # the launch that is timed also does w -= beta*v_prev and the <v, w> partials (Lanczos.h:139,142): two more
-                # vector streams (v_prev, v) that the BASELINE.md formula above does not credit
-                "fused_epilogue_bytes_per_launch": spmv_bytes + 16.0 * op.local_rows(),
-                "fused_epilogue_frac": (spmv_bytes + 16.0 * op.local_rows()) / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if spmv_ms > 0 else 0.0,
-                "csr_kernels_same_matrix": csr_kernels,
-                "csr_kernels_note": "in-loop figures of the CSR SpMV kernels on the same matrix (one extra solve each, outside the timed region); "
-                                    "null when the timed region already ran the int32 CSR kernel",
+                "csr_equivalent_gbps": head["csr_equivalent_gbps"],
+                "csr_equivalent_note": "SURVEY.md 8d's CSR/int32 byte count (12 nnz + 20 n) over the same time: comparable across formats and "
+                                       "rounds, but not an HBM rate unless the int32 CSR kernel ran",
                 "standalone_ms_per_launch": alone_ms,
-                "standalone_gbps": spmv_bytes / (alone_ms * 1e-3) / 1e9,
+                "standalone_gbps": op.stored_bytes() / (alone_ms * 1e-3) / 1e9,
             },
             "solve": {
                 "nconv": int(total_pairs // args.steps), "num_operations": int(eigs.num_operations()),
@@ -286,6 +455,13 @@ def main():
             "kernels_ms_note": "from one additional solve with every kernel family bracketed by HIP events, outside the timed region",
             "kernels_launches_per_solve": {k[2:]: prof[k] / args.steps for k in prof if k.startswith("n_")},
         }
+        if allgather_run:
+            out["allgather_variant"] = allgather_run
+        if world == 1 and not args.no_secondary and not args.no_profile:
+            try:
+                out["secondary"] = secondary_configs(args, ctx, op, sa)
+            except Exception as e:  # noqa: BLE001 - the headline line must still be printed
+                out["secondary"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, int(eigs.num_operations()), int(total_pairs // args.steps))
         print(json.dumps(out), flush=True)

@@ -154,10 +154,11 @@ int mispec_spmv_time(const mispec_csr* A, const double* x_dev, double* y_dev, in
 /* ---------------------------------------------------------------------------
  * Shift-and-invert operator  y = (A - sigma I)^{-1} x  for symmetric A — replaces SparseSymShiftSolve
  * (MatOp/SparseSymShiftSolve.h:36-111, which delegates to Eigen::SparseLU).  The factorisation is redone
- * by set_shift (host, once per shift); every solve runs on the device: a recursive partitioned banded
- * LDL' when the half-bandwidth is <= 32, a dense inverse + GEMV when n <= 4096 (the reference's own test
- * fixtures); other sparsity patterns are rejected (MISPEC_EINVAL).  Input: one triangle of a compressed
- * matrix, as for mispec_csr_from_triangle.
+ * by set_shift (once per shift); every solve runs on the device: a recursive partitioned banded LDL' when the
+ * half-bandwidth is <= 8 (any n; sigma may lie inside the spectrum: tiny pivots are boosted and set_shift
+ * calibrates the iterative-refinement steps each solve then performs, mispec_symshift_refinement_info), a dense
+ * LU inverse + GEMV when n <= 4096 (the reference's own test fixtures); other sparsity patterns are rejected
+ * by set_shift (MISPEC_EINVAL).  Input: one triangle of a compressed matrix, as for mispec_csr_from_triangle.
  * ------------------------------------------------------------------------- */
 typedef struct mispec_symshift mispec_symshift;
 int mispec_symshift_create(mispec_ctx* ctx, int64_t n, const int32_t* outer_host, const int32_t* inner_host,
@@ -181,6 +182,11 @@ int mispec_symshift_set_shift(mispec_symshift* S, double sigma);
  * operator of GenEigsComplexShiftSolver (MatOp/SparseGenComplexShiftSolve.h:74-113, DenseGenComplexShiftSolve.h).  n <= 4096. */
 int mispec_symshift_set_shift_complex(mispec_symshift* S, double sigmar, double sigmai);
 int mispec_symshift_solve(const mispec_symshift* S, const double* x_dev, double* y_dev);        /* device pointers */
+/* What the last set_shift() of a banded operator found: iterative-refinement steps per solve (0 for a definite
+ * A - sigma I), pivots boosted, smallest |pivot| relative to the level's scale, backward error of the probe solve.
+ * Any output pointer may be NULL.  (No reference counterpart: Eigen::SparseLU pivots instead.) */
+int mispec_symshift_refinement_info(const mispec_symshift* S, int* refine_steps, int64_t* boosted_pivots,
+                                    double* min_pivot_ratio, double* probe_backward_error);
 int mispec_symshift_solve_host(const mispec_symshift* S, const double* x_host, double* y_host); /* literal perform_op */
 
 /* ---------------------------------------------------------------------------

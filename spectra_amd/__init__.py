@@ -95,11 +95,19 @@ class Context:
         check(lib().mispec_ctx_set_comm_rccl(self.h, rank, world, unique_id))
         self.rank, self.world = rank, world
 
-    def set_comm_callbacks(self, rank, world, allgather, allreduce_sum):
-        """allgather(send_ptr, recv_ptr, count_per_rank, stream) / allreduce_sum(buf_ptr, count, stream) -> 0 on success."""
+    def set_comm_callbacks(self, rank, world, allgather, allreduce_sum, exchange=None):
+        """allgather(send_ptr, recv_ptr, count_per_rank, stream) / allreduce_sum(buf_ptr, count, stream) -> 0 on success;
+        optional exchange(send_ptr, send_off[], send_count[], recv_ptr, recv_off[], recv_count[], stream) (mispec_comm.exchange)."""
         ag = _capi.allgather_fn(lambda user, s, r, cnt, st: int(allgather(s, r, cnt, st) or 0))
         ar = _capi.allreduce_fn(lambda user, b, cnt, st: int(allreduce_sum(b, cnt, st) or 0))
         comm = _capi.Comm(rank, world, ag, ar, None)
+        if exchange is not None:
+            def ex_tramp(user, s, so, sc, r, ro, rc, st):
+                lst = lambda a: [int(a[i]) for i in range(world)]
+                return int(exchange(int(s or 0), lst(so), lst(sc), int(r or 0), lst(ro), lst(rc), st) or 0)
+            ex = _capi.exchange_fn(ex_tramp)
+            comm.exchange = ex
+            self._keep.append(ex)
         self._keep += [ag, ar, comm]
         check(lib().mispec_ctx_set_comm(self.h, C.byref(comm)))
         self.rank, self.world = rank, world
@@ -299,6 +307,12 @@ class SparseSymShiftSolve:
 
     def set_shift(self, sigma):
         check(lib().mispec_symshift_set_shift(self.h, float(sigma)))
+
+    def refinement_info(self):
+        """Banded path: {refine_steps, boosted_pivots, min_pivot_ratio, probe_backward_error} of the last set_shift()."""
+        st, bo, mr, om = C.c_int(0), C.c_int64(0), C.c_double(0.0), C.c_double(0.0)
+        check(lib().mispec_symshift_refinement_info(self.h, C.byref(st), C.byref(bo), C.byref(mr), C.byref(om)))
+        return {"refine_steps": st.value, "boosted_pivots": bo.value, "min_pivot_ratio": mr.value, "probe_backward_error": om.value}
 
     def perform_op(self, x_in):
         x = _f64(x_in)

@@ -97,6 +97,7 @@ SIGNATURES = {
     "mispec_symshift_rows": (C.c_int64, [_vp]),
     "mispec_symshift_set_shift": (C.c_int, [_vp, C.c_double]),
     "mispec_symshift_solve": (C.c_int, [_vp, _vp, _vp]),
+    "mispec_symshift_refinement_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int64), _dp, _dp]),
     "mispec_symshift_solve_host": (C.c_int, [_vp, _dp, _dp]),
     "mispec_fac_create": (C.c_int, [_vp, _vp, op_fn, _vp, C.c_int64, C.c_int, C.c_int, _vpp]),
     "mispec_fac_create_shiftsolve": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vpp]),

@@ -12,8 +12,15 @@
 //                       (factors stored chunk-interleaved => coalesced across the threads of a wave)
 //        k_sep_rhs      g_S = f_S - M_SI y_I
 //        k_back_subst   x_I = y_I - W x_S   (one thread per row, fully parallel)
-//     The sequential depth per level is L rows instead of n.  No pivoting: stable when A - sigma I is
-//     definite (sigma outside the spectrum, config 5); a vanishing pivot is reported as a failed
+//     The sequential depth per level is L rows instead of n.  No pivoting inside the chunks: exact when A - sigma I
+//     is definite (sigma outside the spectrum, config 5).  For a shift INSIDE the spectrum (the usual use of
+//     shift-and-invert, test/SymEigsShift.cpp:119-184) a chunk's leading minors may be (nearly) singular although
+//     A - sigma I is not, so the factorisation is made robust the way partitioned band solvers are (SPIKE's "diagonal
+//     boosting"): a pivot below sqrt(eps) * scale is replaced by +-sqrt(eps) * scale (the factors are then those of a
+//     slightly perturbed matrix), the last level is a band LU with partial pivoting, and set_shift() CALIBRATES the
+//     number of iterative-refinement steps (r = x - (A - sigma I) y on the device from the resident band, y += solve(r))
+//     that bring the backward error of a probe solve to rounding level; every later solve runs that many steps
+//     (0 for a definite matrix).  A shift for which refinement does not converge is reported as a failed
 //     factorisation, like the reference does for a singular shift (SparseSymShiftSolve.h:93-94).
 //   * dense (n <= 4096, any sparsity — the reference's own test fixtures are of this kind): LU with partial
 //     pivoting of the dense A - sigma I on the host, explicit inverse, and a dense GEMV kernel per step.
@@ -218,12 +225,12 @@ __global__ __launch_bounds__(kThreads) void k_band_shift(int64_t total, int bw, 
 //   2. the 2b spikes  W = M_II^{-1} M_IS  (forward/backward substitution with the factor just written),
 //   3. the chunk's (2b x 2b) contribution  M_SI W  to the Schur complement of its two separators.
 // band: N x (b+1) row-major, band[i*(b+1)+d] = M(i, i-d).  W (N x 2b row-major) and C (P x 2b x 2b) must be
-// zero on entry.  *fail is set when a pivot vanishes.
+// zero on entry.  stats[0] counts boosted pivots (|d| <= tiny replaced by +-tiny), stats[1] is the smallest |pivot|.
 template <int B>
 __global__ __launch_bounds__(kChunkThreads) void k_chunk_factor(int64_t N, int b, int64_t L, int64_t P, double tiny,
                                                                  const double* __restrict__ band, double* __restrict__ Lf,
                                                                  double* __restrict__ Dinv, double* __restrict__ W,
-                                                                 double* __restrict__ C, int* __restrict__ fail)
+                                                                 double* __restrict__ C, unsigned long long* __restrict__ stats)
 {
     const int64_t p = int64_t(blockIdx.x) * kChunkThreads + threadIdx.x;
     if (p >= P)
@@ -233,6 +240,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_chunk_factor(int64_t N, int b
     const int bw = b + 1;
     // ---- 1. LDL' ---------------------------------------------------------------------------------------
     {
+        double minpiv = 1.7976931348623157e308;
         double Lw[B][B], Dw[B];  // Lw[i][d] = L(k-1-i, k-1-i-d-1), Dw[i] = D(k-1-i)
 #pragma unroll
         for (int i = 0; i < B; i++)
@@ -266,10 +274,12 @@ __global__ __launch_bounds__(kChunkThreads) void k_chunk_factor(int64_t N, int b
             for (int d = 0; d < B; d++)
                 if (d < dk)
                     dv -= lrow[d] * lrow[d] * Dw[d];
+            // stats[1]: smallest |pivot| seen (bit pattern of a non-negative double orders like an integer)
+            minpiv = fmin(minpiv, fabs(dv));
             if (!(fabs(dv) > tiny))
             {
-                *fail = 1;
-                dv = 1.0;
+                atomicAdd(&stats[0], 1ull);  // boosted pivots
+                dv = (dv < 0.0) ? -tiny : tiny;
             }
             Dinv[k * P + p] = 1.0 / dv;
 #pragma unroll
@@ -289,6 +299,8 @@ __global__ __launch_bounds__(kChunkThreads) void k_chunk_factor(int64_t N, int b
             for (int d = 0; d < B; d++)
                 Lw[0][d] = lrow[d];
         }
+        if (minpiv == minpiv)  // a NaN pivot was boosted and counted above
+            atomicMin(&stats[1], (unsigned long long) __double_as_longlong(minpiv));
     }
     if (P == 1)
         return;
@@ -411,6 +423,159 @@ void upload_row_major(const std::vector<double>& inv, int64_t n, DevBuf<double>&
 // ---------------------------------------------------------------------------------------------------
 // one level of the recursive factorisation
 // ---------------------------------------------------------------------------------------------------
+namespace {
+// Explicit inverse (column-major) of a symmetric band matrix by LU with PARTIAL PIVOTING within the band (row k is
+// exchanged with one of the rows k..k+b, U fills to width 2b): the dgbtrf scheme on a row-major window
+// R(i, j - i + b), i - b <= j <= i + 2b.  Throws when the matrix is singular to working precision.
+void band_lu_inverse(const HostBand& M, std::vector<double>& inv)
+{
+    const int64_t N = M.n;
+    const int b = M.b, w = 3 * b + 1;
+    std::vector<double> R(size_t(N) * w, 0.0);
+    auto at = [&](int64_t i, int64_t j) -> double& { return R[size_t(i) * w + size_t(j - i + b)]; };
+    double scale = 0.0;
+    for (int64_t i = 0; i < N; i++)
+        for (int64_t j = std::max<int64_t>(i - b, 0); j <= std::min<int64_t>(i + b, N - 1); j++)
+        {
+            at(i, j) = M.get(i, j);
+            scale = std::max(scale, std::fabs(at(i, j)));
+        }
+    std::vector<int64_t> piv(static_cast<size_t>(N));
+    for (int64_t k = 0; k < N; k++)
+    {
+        const int64_t rmax = std::min<int64_t>(k + b, N - 1), cmax = std::min<int64_t>(k + 2 * b, N - 1);
+        int64_t pr = k;
+        double best = std::fabs(at(k, k));
+        for (int64_t i = k + 1; i <= rmax; i++)
+            if (std::fabs(at(i, k)) > best)
+            {
+                best = std::fabs(at(i, k));
+                pr = i;
+            }
+        if (!(best > scale * 1e-15))
+            throw Error(MISPEC_EINVAL, "SparseSymShiftSolve: factorization failed with the given shift");
+        piv[size_t(k)] = pr;
+        if (pr != k)
+            for (int64_t j = k; j <= cmax; j++)
+                std::swap(at(k, j), at(pr, j));
+        const double d = at(k, k);
+        for (int64_t i = k + 1; i <= rmax; i++)
+        {
+            const double l = at(i, k) / d;
+            at(i, k) = l;
+            if (l != 0.0)
+                for (int64_t j = k + 1; j <= cmax; j++)
+                    at(i, j) -= l * at(k, j);
+        }
+    }
+    inv.assign(size_t(N) * N, 0.0);
+    std::vector<double> e(static_cast<size_t>(N));
+    for (int64_t c = 0; c < N; c++)
+    {
+        std::fill(e.begin(), e.end(), 0.0);
+        e[size_t(c)] = 1.0;
+        for (int64_t k = 0; k < N; k++)  // forward sweep with the interchanges interleaved (as dgbtrs)
+        {
+            if (piv[size_t(k)] != k)
+                std::swap(e[size_t(k)], e[size_t(piv[size_t(k)])]);
+            const double ek = e[size_t(k)];
+            if (ek != 0.0)
+                for (int64_t i = k + 1; i <= std::min<int64_t>(k + b, N - 1); i++)
+                    e[size_t(i)] -= at(i, k) * ek;
+        }
+        for (int64_t k = N - 1; k >= 0; k--)
+        {
+            double acc = e[size_t(k)];
+            for (int64_t j = k + 1; j <= std::min<int64_t>(k + 2 * b, N - 1); j++)
+                acc -= at(k, j) * e[size_t(j)];
+            e[size_t(k)] = acc / at(k, k);
+        }
+        std::copy(e.begin(), e.end(), inv.begin() + size_t(c) * N);
+    }
+}
+
+// ---- iterative refinement on the device ---------------------------------------------------------------------
+// r = x - (A - sigma B) y from the resident unshifted band(s) (n x (b+1) row-major, band[i*(b+1)+d] = A(i, i-d)); B = I
+// when bandB is null.  One thread per row.
+__global__ __launch_bounds__(kThreads) void k_band_resid(int64_t n, int b, double sigma, const double* __restrict__ band,
+                                                          const double* __restrict__ bandB, const double* __restrict__ x,
+                                                          const double* __restrict__ y, double* __restrict__ r)
+{
+    const int64_t i = int64_t(blockIdx.x) * kThreads + threadIdx.x;
+    if (i >= n)
+        return;
+    const int bw = b + 1;
+    double acc = x[i];
+    for (int d = b; d >= 1; d--)
+        if (i - d >= 0)
+        {
+            const double m = band[i * bw + d] - (bandB ? sigma * bandB[i * bw + d] : 0.0);
+            acc -= m * y[i - d];
+        }
+    acc -= (band[i * bw] - sigma * (bandB ? bandB[i * bw] : 1.0)) * y[i];
+    for (int d = 1; d <= b; d++)
+        if (i + d < n)
+        {
+            const double m = band[(i + d) * bw + d] - (bandB ? sigma * bandB[(i + d) * bw + d] : 0.0);
+            acc -= m * y[i + d];
+        }
+    r[i] = acc;
+}
+__global__ __launch_bounds__(kThreads) void k_add_inplace(int64_t n, double* __restrict__ y, const double* __restrict__ dy)
+{
+    const int64_t i = int64_t(blockIdx.x) * kThreads + threadIdx.x;
+    if (i < n)
+        y[i] += dy[i];
+}
+// out[slot] = max(out[slot], max_i |v_i|) through the integer order of non-negative doubles
+__global__ __launch_bounds__(kThreads) void k_absmax(int64_t n, const double* __restrict__ v, unsigned long long* __restrict__ out, int slot)
+{
+    __shared__ double red[kThreads];
+    double m = 0.0;
+    for (int64_t i = int64_t(blockIdx.x) * kThreads + threadIdx.x; i < n; i += int64_t(gridDim.x) * kThreads)
+    {
+        const double a = fabs(v[i]);
+        m = (a > m || a != a) ? a : m;  // a NaN wins
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = kThreads / 2; s > 0; s >>= 1)
+    {
+        if (int(threadIdx.x) < s)
+        {
+            const double o = red[threadIdx.x + s];
+            if (o > red[threadIdx.x] || o != o)
+                red[threadIdx.x] = o;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+    {
+        const double r = red[0];
+        atomicMax(&out[slot], r == r ? (unsigned long long) __double_as_longlong(r) : 0x7ff8000000000000ull);
+    }
+}
+// deterministic probe right-hand side in (-0.5, 0.5) (splitmix64 of the index)
+__global__ __launch_bounds__(kThreads) void k_probe_fill(int64_t n, double* __restrict__ v)
+{
+    const int64_t i = int64_t(blockIdx.x) * kThreads + threadIdx.x;
+    if (i >= n)
+        return;
+    unsigned long long z = (unsigned long long) i + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    v[i] = double(z >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+}
+}  // namespace
+
+// What the factorisation saw (all levels): decides whether set_shift() has to calibrate iterative refinement.
+struct FactorStats
+{
+    long long boosts = 0;          // pivots replaced by +-sqrt(eps)*scale
+    double min_pivot_ratio = 1.0;  // smallest |pivot| / scale of its level
+};
+
 struct mispec::BandLevel
 {
     int64_t N = 0, L = 0, P = 1;
@@ -453,7 +618,7 @@ bool factored_on_device(int64_t N, int b)
 }
 
 // Factor the band matrix M (destroyed) into `lev`, recursively.
-void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev)
+void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& stats)
 {
     const int64_t N = M.n;
     const int b = M.b;
@@ -468,7 +633,8 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev)
     double scale = 0.0;
     for (int64_t i = 0; i < N; i++)
         scale = std::max(scale, std::fabs(static_cast<const HostBand&>(M).at(i, 0)));
-    const double tiny = scale * 1e-14 + 1e-300;
+    // pivots at or below `tiny` are boosted to +-tiny (sqrt(eps) * scale): see the header comment
+    const double tiny = scale * 1.4901161193847656e-08 + 1e-300;
 
     const bool on_device = factored_on_device(N, b);
     MISPEC_REQUIRE(on_device || !M.view, "internal: a band view is only valid for a level factored on the device");
@@ -507,28 +673,39 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev)
         lev.W.alloc(w_size);
         DevBuf<double> Cdev;
         Cdev.alloc(size_t(P) * w2 * w2);
-        DevBuf<int> fail;
-        fail.alloc(1);
+        DevBuf<unsigned long long> dstats;
+        dstats.alloc(2);
         MISPEC_HIP(hipMemsetAsync(lev.Lf.p, 0, lf_size * sizeof(double), ctx->stream));
         MISPEC_HIP(hipMemsetAsync(lev.Dinv.p, 0, dinv_size * sizeof(double), ctx->stream));
         MISPEC_HIP(hipMemsetAsync(lev.W.p, 0, w_size * sizeof(double), ctx->stream));
         MISPEC_HIP(hipMemsetAsync(Cdev.p, 0, Cdev.n * sizeof(double), ctx->stream));
-        MISPEC_HIP(hipMemsetAsync(fail.p, 0, sizeof(int), ctx->stream));
+        {
+            const double huge = 1.7976931348623157e308;
+            unsigned long long init[2] = {0ull, 0ull};
+            std::memcpy(&init[1], &huge, sizeof(double));
+            MISPEC_HIP(hipMemcpyAsync(dstats.p, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+            MISPEC_HIP(hipStreamSynchronize(ctx->stream));  // init is a local
+        }
         const dim3 grid(unsigned((P + kChunkThreads - 1) / kChunkThreads));
         if (b <= 4)
             hipLaunchKernelGGL((k_chunk_factor<4>), grid, dim3(kChunkThreads), 0, ctx->stream, N, b, L, P, tiny, lev.band.p,
-                               lev.Lf.p, lev.Dinv.p, lev.W.p, Cdev.p, fail.p);
+                               lev.Lf.p, lev.Dinv.p, lev.W.p, Cdev.p, dstats.p);
         else
             hipLaunchKernelGGL((k_chunk_factor<8>), grid, dim3(kChunkThreads), 0, ctx->stream, N, b, L, P, tiny, lev.band.p,
-                               lev.Lf.p, lev.Dinv.p, lev.W.p, Cdev.p, fail.p);
+                               lev.Lf.p, lev.Dinv.p, lev.W.p, Cdev.p, dstats.p);
         MISPEC_HIP(hipGetLastError());
         std::vector<double> Cc(Cdev.n);
-        int failed = 0;
+        unsigned long long hstats[2] = {0ull, 0ull};
         MISPEC_HIP(hipMemcpyAsync(Cc.data(), Cdev.p, Cc.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        MISPEC_HIP(hipMemcpyAsync(&failed, fail.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        MISPEC_HIP(hipMemcpyAsync(hstats, dstats.p, sizeof(hstats), hipMemcpyDeviceToHost, ctx->stream));
         MISPEC_HIP(hipStreamSynchronize(ctx->stream));
-        if (failed)
-            throw_singular();
+        {
+            double minpiv;
+            std::memcpy(&minpiv, &hstats[1], sizeof(double));
+            stats.boosts += (long long) hstats[0];
+            if (scale > 0.0)
+                stats.min_pivot_ratio = std::min(stats.min_pivot_ratio, minpiv / scale);
+        }
         for (int64_t p = 0; p < P; p++)
             for (int side1 = 0; side1 < 2; side1++)
             {
@@ -558,6 +735,20 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev)
             }
     }
 
+    if (P == 1)
+    {
+        // last level: band LU with partial pivoting (this is where an indefinite matrix needs it most: the Schur
+        // complement of all separators), explicit inverse applied as a GEMV
+        std::vector<double> inv;
+        band_lu_inverse(M, inv);
+        ctx->make_current();
+        upload_row_major(inv, N, lev.inv);
+        lev.y.alloc(size_t(N));
+        MISPEC_HIP(hipStreamSynchronize(ctx->stream));
+        M.a.clear();
+        M.a.shrink_to_fit();
+        return;
+    }
     std::vector<double> D, Lc, rhs, sol;
     for (int64_t p = 0; p < (on_device ? 0 : P); p++)
     {
@@ -583,8 +774,13 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev)
             double dv = M.at(row0 + k, 0);
             for (int d = 0; d < dk; d++)
                 dv -= Lc[size_t(k) * b + d] * Lc[size_t(k) * b + d] * D[size_t(k - d - 1)];
+            if (scale > 0.0)
+                stats.min_pivot_ratio = std::min(stats.min_pivot_ratio, std::fabs(dv) / scale);
             if (!(std::fabs(dv) > tiny))
-                throw_singular();
+            {
+                stats.boosts++;
+                dv = (dv < 0.0) ? -tiny : tiny;
+            }
             D[size_t(k)] = dv;
         }
         for (int64_t k = 0; k < m; k++)
@@ -592,36 +788,6 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev)
             Dinv[size_t(k) * P + p] = 1.0 / D[size_t(k)];
             for (int d = 0; d < b; d++)
                 Lf[(size_t(k) * b + d) * P + p] = Lc[size_t(k) * b + d];
-        }
-        if (P == 1)
-        {
-            // last level: explicit inverse, column by column
-            std::vector<double> inv(size_t(N) * N, 0.0), e(static_cast<size_t>(N));
-            for (int64_t c = 0; c < N; c++)
-            {
-                std::fill(e.begin(), e.end(), 0.0);
-                e[size_t(c)] = 1.0;
-                for (int64_t k = c; k < m; k++)  // forward (zero above c)
-                {
-                    double acc = e[size_t(k)];
-                    const int dk2 = int(std::min<int64_t>(k, b));
-                    for (int d = dk2 - 1; d >= 0; d--)
-                        acc -= Lc[size_t(k) * b + d] * e[size_t(k - d - 1)];
-                    e[size_t(k)] = acc;
-                }
-                for (int64_t k = m - 1; k >= 0; k--)
-                {
-                    double acc = e[size_t(k)] / D[size_t(k)];
-                    const int dk2 = int(std::min<int64_t>(m - 1 - k, b));
-                    for (int d = dk2 - 1; d >= 0; d--)
-                        acc -= Lc[size_t(k + d + 1) * b + d] * e[size_t(k + d + 1)];
-                    e[size_t(k)] = acc;
-                }
-                std::copy(e.begin(), e.end(), inv.begin() + size_t(c) * N);
-            }
-            ctx->make_current();
-            upload_row_major(inv, N, lev.inv);
-            break;
         }
         // ---- spikes W = M_II^{-1} M_IS and their contribution to the Schur complement -------------------
         auto solve_block = [&](std::vector<double>& v) {
@@ -737,7 +903,7 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev)
     if (P > 1)
     {
         lev.next = std::make_unique<BandLevel>();
-        factor_level(ctx, S, *lev.next);
+        factor_level(ctx, S, *lev.next, stats);
     }
 }
 
@@ -850,6 +1016,115 @@ void dense_inverse(int n, std::vector<T>& A, std::vector<T>& inv)
 
 }  // namespace
 
+namespace {
+inline dim3 row_blocks(int64_t n) { return dim3(unsigned((n + kThreads - 1) / kThreads)); }
+
+// y += (A - sigma B)^{-1}_approx (x - (A - sigma B) y): one step of iterative refinement with the factorisation at hand
+void refine_once(const mispec_symshift& S, const double* x_dev, double* y_dev)
+{
+    hipStream_t st = S.ctx->stream;
+    hipLaunchKernelGGL(k_band_resid, row_blocks(S.n), dim3(kThreads), 0, st, S.n, S.band_b, S.sigma, S.band0_dev.p,
+                       S.pencil ? S.bandB0_dev.p : nullptr, x_dev, y_dev, S.ref_r.p);
+    MISPEC_HIP(hipGetLastError());
+    solve_level(*S.ctx, *S.top, S.ref_r.p, S.ref_dy.p);
+    hipLaunchKernelGGL(k_add_inplace, row_blocks(S.n), dim3(kThreads), 0, st, S.n, y_dev, S.ref_dy.p);
+    MISPEC_HIP(hipGetLastError());
+}
+
+// After a banded factorisation: solve a probe system, measure the backward error
+//   omega = |x - M y|_inf / (|M|_inf |y|_inf + |x|_inf)
+// and add refinement steps until it reaches rounding level.  A definite matrix passes at once (no step, no cost per
+// solve); an indefinite one with boosted / small pivots typically needs 1-2; no convergence = singular shift.
+void calibrate_refinement(mispec_symshift& S, const FactorStats& fs)
+{
+    S.boosted_pivots = fs.boosts;
+    S.min_pivot_ratio = fs.min_pivot_ratio;
+    S.refine_steps = 0;
+    S.probe_backward_error = 0.0;
+    const int64_t n = S.n;
+    const int bw = S.band_b + 1;
+    hipStream_t st = S.ctx->stream;
+    if (!S.band0_dev.p)
+    {
+        S.band0_dev.alloc(S.band0.size());
+        MISPEC_HIP(hipMemcpyAsync(S.band0_dev.p, S.band0.data(), S.band0.size() * sizeof(double), hipMemcpyHostToDevice, st));
+        if (S.pencil)
+        {
+            S.bandB0_dev.alloc(S.bandB0.size());
+            MISPEC_HIP(hipMemcpyAsync(S.bandB0_dev.p, S.bandB0.data(), S.bandB0.size() * sizeof(double), hipMemcpyHostToDevice, st));
+        }
+    }
+    if (S.ref_r.n < size_t(n))
+    {
+        S.ref_r.alloc(size_t(n));
+        S.ref_dy.alloc(size_t(n));
+    }
+    // |M|_inf from the host band (rows of the symmetric matrix: |M(i, i-d)| counts for rows i and i-d)
+    double mnorm = 0.0;
+    {
+        std::vector<double> rs(static_cast<size_t>(n), 0.0);
+        for (int64_t i = 0; i < n; i++)
+            for (int d = 0; d < bw; d++)
+            {
+                if (i - d < 0)
+                    continue;
+                const double a = S.band0[size_t(i) * bw + d] - S.sigma * (S.pencil ? S.bandB0[size_t(i) * bw + d] : (d == 0 ? 1.0 : 0.0));
+                rs[size_t(i)] += std::fabs(a);
+                if (d > 0)
+                    rs[size_t(i - d)] += std::fabs(a);
+            }
+        for (double v : rs)
+            mnorm = std::max(mnorm, v);
+    }
+    DevBuf<double> px, py;
+    DevBuf<unsigned long long> norms;
+    px.alloc(size_t(n));
+    py.alloc(size_t(n));
+    norms.alloc(3);
+    hipLaunchKernelGGL(k_probe_fill, row_blocks(n), dim3(kThreads), 0, st, n, px.p);
+    MISPEC_HIP(hipGetLastError());
+    solve_level(*S.ctx, *S.top, px.p, py.p);
+    const unsigned grid = unsigned(std::min<int64_t>((n + kThreads - 1) / kThreads, 1024));
+    constexpr int kMaxRefine = 8;
+    constexpr double kTarget = 4.0e-15;  // a few eps: what a backward-stable solve of a band matrix gives
+    double omega = 0.0, prev = 1e300;
+    for (int it = 0;; it++)
+    {
+        MISPEC_HIP(hipMemsetAsync(norms.p, 0, 3 * sizeof(unsigned long long), st));
+        hipLaunchKernelGGL(k_band_resid, row_blocks(n), dim3(kThreads), 0, st, n, S.band_b, S.sigma, S.band0_dev.p,
+                           S.pencil ? S.bandB0_dev.p : nullptr, px.p, py.p, S.ref_r.p);
+        hipLaunchKernelGGL(k_absmax, dim3(grid), dim3(kThreads), 0, st, n, S.ref_r.p, norms.p, 0);
+        hipLaunchKernelGGL(k_absmax, dim3(grid), dim3(kThreads), 0, st, n, py.p, norms.p, 1);
+        hipLaunchKernelGGL(k_absmax, dim3(grid), dim3(kThreads), 0, st, n, px.p, norms.p, 2);
+        MISPEC_HIP(hipGetLastError());
+        unsigned long long hb[3];
+        MISPEC_HIP(hipMemcpyAsync(hb, norms.p, sizeof(hb), hipMemcpyDeviceToHost, st));
+        MISPEC_HIP(hipStreamSynchronize(st));
+        double nr, ny, nx;
+        std::memcpy(&nr, &hb[0], 8);
+        std::memcpy(&ny, &hb[1], 8);
+        std::memcpy(&nx, &hb[2], 8);
+        omega = nr / (mnorm * ny + nx);
+        if (!(omega == omega) || !(ny == ny))
+            throw_singular();
+        if (omega <= kTarget)
+            break;
+        if (it == kMaxRefine || (it >= 2 && omega > 0.5 * prev))
+        {
+            // stagnation: accept when the probe is still solved to 1e-12 (the error then sits below the eigensolver's
+            // tolerances), otherwise the shift is (numerically) singular for this factorisation
+            if (omega <= 1e-12)
+                break;
+            throw_singular();
+        }
+        prev = omega;
+        S.refine_steps = it + 1;
+        refine_once(S, px.p, py.p);
+    }
+    S.probe_backward_error = omega;
+}
+}  // namespace
+
 namespace mispec {
 
 void launch_shiftsolve(const mispec_symshift& S, const double* x_dev, double* y_dev)
@@ -859,7 +1134,11 @@ void launch_shiftsolve(const mispec_symshift& S, const double* x_dev, double* y_
     if (S.dense)
         launch_row_gemv(*S.ctx, S.inverse.p, S.n, S.n, S.n, x_dev, y_dev);
     else
+    {
         solve_level(*S.ctx, *S.top, x_dev, y_dev);
+        for (int it = 0; it < S.refine_steps; it++)
+            refine_once(S, x_dev, y_dev);
+    }
 }
 
 }  // namespace mispec
@@ -1071,8 +1350,10 @@ extern "C" int mispec_symshift_set_shift(mispec_symshift* S, double sigma)
                         M.at(i, 0) -= sigma;
             }
             S->top = std::make_unique<BandLevel>();
-            factor_level(S->ctx, M, *S->top);
+            FactorStats fs;
+            factor_level(S->ctx, M, *S->top, fs);
             S->dense = false;
+            calibrate_refinement(*S, fs);
         }
         else if (n <= kMaxDense)
         {
@@ -1133,6 +1414,22 @@ extern "C" int mispec_symshift_set_shift_complex(mispec_symshift* S, double sigm
         upload_row_major(re, n, S->inverse);
         S->dense = true;
         S->factored = true;
+    });
+}
+
+extern "C" int mispec_symshift_refinement_info(const mispec_symshift* S, int* refine_steps, int64_t* boosted_pivots,
+                                               double* min_pivot_ratio, double* probe_backward_error)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(S, "mispec_symshift_refinement_info: NULL argument");
+        if (refine_steps)
+            *refine_steps = S->refine_steps;
+        if (boosted_pivots)
+            *boosted_pivots = S->boosted_pivots;
+        if (min_pivot_ratio)
+            *min_pivot_ratio = S->min_pivot_ratio;
+        if (probe_backward_error)
+            *probe_backward_error = S->probe_backward_error;
     });
 }
 

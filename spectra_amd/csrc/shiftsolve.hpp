@@ -38,6 +38,13 @@ struct mispec_symshift
     std::unique_ptr<mispec::BandLevel> top;  // banded path
     mispec::DevBuf<double> inverse;          // dense path: (A - sigma I)^{-1}, n x n column-major
     mutable mispec::DevBuf<double> stage_x, stage_y;
+    // Robustness for indefinite A - sigma I (banded path): what the last factorisation saw and the number of iterative
+    // refinement steps every solve performs (calibrated by set_shift on a probe right-hand side; 0 for definite matrices)
+    long long boosted_pivots = 0;
+    double min_pivot_ratio = 1.0;
+    int refine_steps = 0;
+    double probe_backward_error = 0.0;  // of the calibrated solve
+    mutable mispec::DevBuf<double> ref_r, ref_dy;
     ~mispec_symshift();
 };
 

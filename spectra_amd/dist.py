@@ -7,6 +7,8 @@ transports are offered, both ending in RCCL:
   * "rccl"  (default) — the library's own RCCL communicator (`mispec_ctx_set_comm_rccl`): rank 0 creates an
     ncclUniqueId, `torch.distributed` broadcasts it, every rank calls ncclCommInitRank.  Collectives are
     enqueued by C++ on the solver's stream, no Python in the loop.
+  * "gloo-staged" — for tests: N processes that may SHARE a device, collectives staged through host memory over gloo
+    (HostStagedComm); exercises the real multi-process SPMD path where RCCL cannot build a communicator.
   * "torch" — Python callbacks that run `dist.all_gather_into_tensor` / `dist.all_reduce` (backend "nccl" is
     RCCL on ROCm; "gloo" works for CPU tensors in the tests) on tensors aliasing the library's device buffers.
     The context must then run on torch's current stream so that torch orders the collectives with the kernels.
@@ -82,6 +84,82 @@ class TorchComm:
         return 0
 
 
+class HostStagedComm:
+    """The collectives for DEVICE buffers over a CPU process group (gloo): every call drains the solver's stream, stages the
+    operands through host memory, runs the gloo collective and copies the result back.  Slow by construction — it exists so
+    that the product's SPMD code (row shards, exchange plan, batched all-reduces, identical H on every rank) can run as N
+    real processes on a box with fewer GPUs than ranks (the ranks then share a device), where RCCL refuses to build a
+    communicator.  Includes the personalised exchange, so the neighbour-exchange plan is exercised as well."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    @staticmethod
+    def _view(ptr, count):
+        import torch
+
+        return torch.as_tensor(_DeviceArray(ptr, count), device="cuda")
+
+    def _sync(self, stream):
+        import torch
+
+        torch.cuda.ExternalStream(int(stream)).synchronize() if stream else torch.cuda.synchronize()
+
+    def allgather_ptr(self, send_ptr, recv_ptr, count, stream):
+        import torch
+
+        self._sync(stream)
+        send = self._view(send_ptr, count).cpu()
+        recv = torch.empty(count * self.world, dtype=torch.float64)
+        self.dist.all_gather_into_tensor(recv, send, group=self.group)
+        self._view(recv_ptr, count * self.world).copy_(recv)
+        torch.cuda.synchronize()
+        return 0
+
+    def allreduce_ptr(self, buf_ptr, count, stream):
+        import torch
+
+        self._sync(stream)
+        dev = self._view(buf_ptr, count)
+        # fixed rank order => the same bits on every rank (gloo's ring order depends on the rank)
+        parts = torch.empty(count * self.world, dtype=torch.float64)
+        self.dist.all_gather_into_tensor(parts, dev.cpu(), group=self.group)
+        acc = torch.zeros(count, dtype=torch.float64)
+        for r in range(self.world):
+            acc += parts[r * count:(r + 1) * count]
+        dev.copy_(acc)
+        torch.cuda.synchronize()
+        return 0
+
+    def exchange_ptr(self, send_ptr, send_off, send_count, recv_ptr, recv_off, recv_count, stream):
+        import torch
+
+        self._sync(stream)
+        ops, landing = [], []
+        for p in range(self.world):
+            if p == self.rank:
+                continue
+            if send_count[p] > 0:
+                buf = self._view(send_ptr + 8 * send_off[p], send_count[p]).cpu()
+                ops.append(self.dist.P2POp(self.dist.isend, buf, p, group=self.group))
+            if recv_count[p] > 0:
+                buf = torch.empty(recv_count[p], dtype=torch.float64)
+                landing.append((recv_off[p], recv_count[p], buf))
+                ops.append(self.dist.P2POp(self.dist.irecv, buf, p, group=self.group))
+        if ops:
+            for req in self.dist.batch_isend_irecv(ops):
+                req.wait()
+        for off, cnt, buf in landing:
+            self._view(recv_ptr + 8 * off, cnt).copy_(buf)
+        torch.cuda.synchronize()
+        return 0
+
+
 def make_context(device=None, transport=None):
     """Context for this rank's GPU with the communicator attached (no-op communicator when world == 1).
 
@@ -98,7 +176,12 @@ def make_context(device=None, transport=None):
     # transports can be smoke-tested on a 1-GPU box (collectives over one rank are copies / no-ops).
     force = os.environ.get("MISPEC_FORCE_COMM", "0") == "1" and dist.is_initialized()
     torch.cuda.set_device(device)
-    if (world > 1 or force) and transport == "torch":
+    if (world > 1 or force) and transport == "gloo-staged":
+        ctx = Context(device)
+        comm = HostStagedComm()
+        ctx.set_comm_callbacks(rank, world, comm.allgather_ptr, comm.allreduce_ptr, comm.exchange_ptr)
+        ctx._comm = comm
+    elif (world > 1 or force) and transport == "torch":
         # a dedicated (non-default) torch stream: the solver's kernels and torch's collectives are both ordered
         # against it (the default stream's handle is 0, which the C ABI reads as "create your own stream")
         stream = torch.cuda.Stream(device=device)

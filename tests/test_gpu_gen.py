@@ -84,6 +84,10 @@ def test_gen_user_operator_and_errors(ctx):
 @pytest.mark.parametrize("n", [200_000, 5_000_000])
 def test_config4_nonsymmetric_band(ctx, n):
     # BASELINE.json configs[3]: GenEigsSolver on a 5M x 5M non-symmetric CSR (~15 nnz/row), k = 10, ncv = 30.
+    if n == 5_000_000:  # full size: against the oracle's complete solve (tests/golden/full_size_c4.json)
+        from test_gpu_fullsize import check_c4_solve
+
+        return check_c4_solve(ctx)
     op = sa.SparseGenMatProd.synth_band(n, ctx=ctx)
     eigs = sa.GenEigsSolver(op, 10, 30)
     eigs.init()

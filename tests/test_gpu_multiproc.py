@@ -1,0 +1,65 @@
+"""The product's row-sharded SPMD path as TWO REAL PROCESSES: started through
+torch.distributed.run, each process owns a context, a row shard and a solver; the collectives go over a real
+multi-process transport.  The GPU box of the test tier has one device, and RCCL refuses a communicator with two ranks
+on one device, so the ranks share device 0 and the transport is `gloo-staged` (device buffers staged through host
+memory over gloo, spectra_amd.dist.HostStagedComm, including the personalised neighbour exchange).  The result must
+equal — bit for bit — what the in-process loopback communicator gives for the same partition, and the unsharded solve
+to tolerance."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import spectra_amd as sa
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_processes(world, tmp_path, exchange=None, **cfg):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MP_OUT=str(tmp_path), MP_TRANSPORT="gloo-staged", MP_DEVICE="shared", **{k: str(v) for k, v in cfg.items()})
+    env.pop("MISPEC_EXCHANGE", None)
+    if exchange:
+        env["MISPEC_EXCHANGE"] = exchange
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "mp_worker.py")]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-4000:]
+    out = []
+    for rank in range(world):
+        d = dict(np.load(os.path.join(str(tmp_path), f"rank{rank}.npz")))
+        with open(os.path.join(str(tmp_path), f"rank{rank}.json")) as f:
+            d["meta"] = json.load(f)
+        out.append(d)
+    return out
+
+
+@pytest.mark.parametrize("exchange", [None, "allgather"])
+def test_two_processes_equal_the_loopback_run(ctx, tmp_path, exchange):
+    from test_gpu_sharded import run_sharded
+
+    n, offsets, nev, ncv = 40_003, (1, 2, 3, 50, 51, 1500, 1501), 6, 20
+    procs = run_processes(2, tmp_path, exchange=exchange, MP_N=n, MP_OFFSETS=",".join(map(str, offsets)), MP_NEV=nev, MP_NCV=ncv)
+    assert len({p["meta"]["pid"] for p in procs}) == 2  # two operating-system processes
+    loop = run_sharded(2, n, offsets, nev, ncv, sa.SortRule.LargestMagn, 1e-11, exchange=exchange)
+    for p, l in zip(procs, loop):
+        assert int(p["nconv"]) == l["nconv"] == nev and int(p["info"]) == 0
+        assert bool(p["exchange"][0]) == l["exchange"][0] == (exchange is None)  # the plan picks the neighbour exchange
+        assert int(p["exchange"][1]) == l["exchange"][1]
+        assert np.array_equal(p["evals"], l["evals"]) and np.array_equal(p["X"], l["X"])  # bit for bit
+        assert (int(p["nops"]), int(p["niter"])) == (l["nops"], l["niter"])
+        assert p["res"].max() <= 1e-10
+    assert np.array_equal(procs[0]["evals"], procs[1]["evals"])  # every rank holds the same H
+    single = sa.SymEigsSolver(sa.SparseSymMatProd.synth_band(n, offsets=offsets, ctx=ctx), nev, ncv)
+    single.init()
+    assert single.compute(sa.SortRule.LargestMagn, 1000, 1e-11) == nev
+    assert np.abs(single.eigenvalues() - procs[0]["evals"]).max() < 1e-10
+    X = np.vstack([p["X"] for p in procs])
+    assert np.abs(np.abs(np.sum(X * single.eigenvectors(), axis=0)) - 1.0).max() < 1e-8

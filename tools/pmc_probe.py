@@ -3,7 +3,7 @@
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d OUT -o fetch -- python tools/pmc_probe.py
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d OUT -o write -- python tools/pmc_probe.py
 
-Launches, in order: 3 x k_scale on an n-vector (calibration: exactly 8n bytes read + 8n written with the same
+For each storage format of the matrix (diagonal, offset-coded CSR, int32 CSR), in order: k_scale_step launches on an n-vector (calibration: exactly 8n bytes read + 8n written with the same
 16-byte-per-lane access pattern the guide's FETCH_SIZE correction is about), 5 x stand-alone SpMV, then
 init() + one full Lanczos factorisation (39 steps: fused SpMV, RESID_VTF, CORRECT_VTF) and one restart
 (shifted-QR kernel + V*Q).  tools/pmc_summarize.py turns the two CSVs into per-kernel bytes per launch.
@@ -23,15 +23,21 @@ op = sa.SparseSymMatProd.synth_band(n, ctx=ctx)
 x = torch.rand(n, dtype=torch.float64, device="cuda") - 0.5
 y = torch.empty(n, dtype=torch.float64, device="cuda")
 torch.cuda.synchronize()
-for _ in range(5):
-    op.spmv_device(x.data_ptr(), y.data_ptr())
-ctx.sync()
-fac = sa.Factorization(op, 40, True)
-fac.init_random(0)
-fac.factorize_from(1, 40)
-ev, U = fac.tridiag_eigen()
-order = np.argsort(-np.abs(ev))
-fac.restart_sym(ev[order][25:])
-fac.factorize_from(25, 40)
-ctx.sync()
-print("probe done: k =", fac.subspace_dim(), "nops =", fac.num_operations())
+# every storage format of the matrix in one process, so that one pair of --pmc passes covers every SpMV instantiation
+# (PROBE_FORMATS=2,1,0: diagonal storage, offset-coded CSR, int32 CSR)
+for fmt in [int(f) for f in os.environ.get("PROBE_FORMATS", "2,1,0").split(",")]:
+    op.set_spmv_format(fmt)
+    for _ in range(5):
+        op.spmv_device(x.data_ptr(), y.data_ptr())
+    ctx.sync()
+    fac = sa.Factorization(op, 40, True)
+    fac.init_random(0)
+    fac.factorize_from(1, 40)
+    ev, U = fac.tridiag_eigen()
+    order = np.argsort(-np.abs(ev))
+    fac.restart_sym(ev[order][25:])
+    fac.factorize_from(25, 40)
+    ctx.sync()
+    print("probe done: format", op.spmv_format(), "k =", fac.subspace_dim(), "nops =", fac.num_operations())
+    del fac
+op.set_spmv_format(-1)
