@@ -16,6 +16,8 @@
 #include <algorithm>
 #include <cmath>
 #include <complex>
+#include <cstdlib>
+#include <string>
 #include <stdexcept>
 #include <vector>
 
@@ -132,6 +134,39 @@ private:
         if (k >= m_ncv)
             return;
         const int m = static_cast<int>(m_ncv);
+        // Where the ncv x ncv sweeps run: MISPEC_SMALL_GEN=device applies the whole shift list in one LDS-resident kernel
+        // (ncv <= 96, spectra_amd/csrc/small.hip k_hess_restart; H and Q never leave the device between the sweeps and
+        // V <- V Q); the default is the host (same arithmetic, internal/SmallDenseGen.h) because one wavefront stepping
+        // through a serial chain of reflectors is slower than one host core at these sizes (DESIGN.md 3.4 has the numbers).
+        static const char* where = std::getenv("MISPEC_SMALL_GEN");
+        if (where && std::string(where) == "device" && m <= 96)
+        {
+            std::vector<int> kind;
+            std::vector<double> sa, sb;
+            Index kk = m_ncv;
+            for (Index i = k; i < m_ncv; i++)
+            {
+                if (is_complex(m_ritz_val[i]) && i + 1 < m_ncv && is_conj(m_ritz_val[i], m_ritz_val[i + 1]))
+                {
+                    kind.push_back(1);
+                    sa.push_back(RealScalar(2) * m_ritz_val[i].real());
+                    sb.push_back(std::norm(m_ritz_val[i]));
+                    kk -= 2;
+                    i++;
+                }
+                else
+                {
+                    kind.push_back(0);
+                    sa.push_back(m_ritz_val[i].real());
+                    sb.push_back(0.0);
+                    kk -= 1;
+                }
+            }
+            m_fac.restart_gen(kind, sa, sb, kk);
+            m_fac.factorize_from(k, m_ncv, m_nmatop);
+            retrieve_ritzpair(selection);
+            return;
+        }
         Matrix H = m_fac.matrix_H();
         Matrix Q(m_ncv, m_ncv);
         for (Index j = 0; j < m_ncv; j++)

@@ -316,6 +316,13 @@ public:
         internal::check(mispec_fac_compress_V(m_fac.get(), Q.data(), H_compressed.data(), static_cast<int>(new_k)));
     }
 
+    // The shift list of one general restart applied on the device (k_hess_restart), then V <- V Q and the update of f.
+    void restart_gen(const std::vector<int>& kind, const std::vector<double>& a, const std::vector<double>& b, Index new_k)
+    {
+        internal::check(mispec_fac_restart_gen(m_fac.get(), kind.data(), a.data(), b.data(), static_cast<int>(kind.size()),
+                                               static_cast<int>(new_k)));
+    }
+
     // X = V * Y, Y is m x ncols (HermEigsBase.h:467 / GenEigsBase.h:600); returned on the host.
     Matrix ritz_vectors(const Matrix& Y) const
     {

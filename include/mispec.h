@@ -148,6 +148,22 @@ int mispec_spmv(const mispec_csr* A, const double* x_dev, double* y_dev);
 int mispec_spmv_host(const mispec_csr* A, const double* x_host, double* y_host);
 /* Y = A X for a column-major n x k block: operator* (SparseSymMatProd.h:93-96). Host pointers. */
 int mispec_spmm_host(const mispec_csr* A, const double* X_host, int64_t ldx, int k, double* Y_host, int64_t ldy);
+/* Symmetric reordering of an unsharded square matrix (no reference counterpart: on a CPU the ordering of the rows costs
+ * little; on the GPU scattered x gathers cost an order of magnitude).  The stored matrix becomes P A P' with P from reverse
+ * Cuthill-McKee on the pattern of A + A' (host, once).  Everything the C ABI hands out keeps the CALLER's index order:
+ * mispec_spmv / _host / mispec_csr_coeff / _download un-permute, the eigensolvers work in the permuted order and return
+ * eigenvectors in the caller's order; eigenvalues are those of A.  method 1: always reorder; -1: only if more than a
+ * quarter of the entries lie further than 131072 columns from the diagonal and the ordering at least halves that
+ * fraction (this is also what ingest does by itself unless MISPEC_REORDER=none; MISPEC_REORDER=rcm forces it).
+ * *applied = 1 when the matrix is reordered on return.  mispec_csr_reordering returns 0 (none) or 1 (RCM) and the
+ * fraction of far entries before / after; mispec_csr_permutation writes perm[new] = old (identity when not reordered). */
+int mispec_csr_reorder(mispec_csr* A, int method, int* applied);
+int mispec_csr_reordering(const mispec_csr* A, double* far_before, double* far_after);
+int mispec_csr_permutation(const mispec_csr* A, int32_t* perm_out);
+/* The ordering alone, on host arrays (no device needed): perm_out[new] = old for the pattern of an n x n CSR matrix;
+ * *gave_up = 1 (identity returned) when the first breadth-first level structure is too wide for any ordering to help. */
+int mispec_rcm_order(int64_t n, const int32_t* rowptr, const int32_t* colind, int symmetric_pattern, int32_t* perm_out,
+                     int* gave_up, int64_t* widest_level);
 /* Duration (ms, HIP events on the context stream) of the last `reps` back-to-back SpMV launches. */
 int mispec_spmv_time(const mispec_csr* A, const double* x_dev, double* y_dev, int reps, float* ms_per_launch);
 
@@ -314,6 +330,11 @@ int mispec_fac_restart_sym(mispec_fac* fac, const double* shifts_host, int nshif
 /* Host-side variant: the caller ran the shifted QR itself and hands over Q (ncv x ncv col-major) and the
  * compressed H / new k (compress_H already applied): only compress_V runs on the device. */
 int mispec_fac_compress_V(mispec_fac* fac, const double* Q_host, const double* H_host, int new_k);
+/* One implicit restart of a GENERAL factorisation entirely on the device (GenEigsBase.h:204-222, RestartArnoldi): the
+ * shifts in order — kind[i] = 0: real shift a[i] (UpperHessenbergQR); kind[i] = 1: conjugate pair as the double shift
+ * (s, t) = (a[i], b[i]) = (2 Re mu, |mu|^2) (DoubleShiftQR) — are applied to H by one LDS-resident kernel that also
+ * accumulates Q; then V[:, :new_k+1] <- V Q and the update of f as in mispec_fac_compress_V.  ncv <= 96. */
+int mispec_fac_restart_gen(mispec_fac* fac, const int* kind, const double* a, const double* b, int nshift, int new_k);
 /* X = V * Y  (HermEigsBase.h:467, GenEigsBase.h:600).  Y_host: ncv x ncols col-major.
  * X_host (local_rows x ncols, may be NULL) and/or *X_dev (device buffer owned by fac, valid until the next call). */
 int mispec_fac_ritz_vectors(mispec_fac* fac, const double* Y_host, int ncols, double* X_host, const double** X_dev);
@@ -464,6 +485,14 @@ int mispec_geneigs_profile(mispec_geneigs* s, int enable);
  *   mispec_hess_eigen_host       UpperHessenbergEigen: complex eigenpairs, interleaved  (UpperHessenbergEigen.h:231-327)
  * ------------------------------------------------------------------------- */
 int mispec_hess_qr_host(int n, const double* H, double shift, double* Q, double* QtHQ);
+/* The two sweeps of the general restart as HIP kernels (one wavefront, H and Q in LDS, 3 <= n <= 96): the device
+ * counterparts of mispec_hess_qr_host / mispec_double_shift_qr_host (UpperHessenbergQR.h:136-255, DoubleShiftQR.h:334-467);
+ * host arrays in and out.  The *_lanes_host forms run the kernels' source (internal/SmallDenseGenLanes.h) with one lane on
+ * the host.  Inside a solve the whole shift list of a restart is one launch: mispec_fac_restart_gen. */
+int mispec_hess_qr(mispec_ctx* ctx, int n, const double* H_host, double shift, double* Q_host, double* QtHQ_host);
+int mispec_double_shift_qr(mispec_ctx* ctx, int n, const double* H_host, double s, double t, double* Q_host, double* QtHQ_host);
+int mispec_hess_qr_lanes_host(int n, const double* H, double shift, double* Q, double* QtHQ);
+int mispec_double_shift_qr_lanes_host(int n, const double* H, double s, double t, double* Q, double* QtHQ);
 int mispec_double_shift_qr_host(int n, const double* H, double s, double t, double* Q, double* QtHQ);
 int mispec_hess_schur_host(int n, const double* H, double* T, double* U);
 int mispec_hess_eigen_host(int n, const double* H, double* evals, double* evecs);

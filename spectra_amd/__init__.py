@@ -10,6 +10,7 @@ There is NO CPU fallback: constructing a `Context` without a visible HIP device 
 """
 import ctypes as C
 import enum
+import os
 
 import numpy as np
 
@@ -59,6 +60,17 @@ def _dp(a):
 
 def _ip(a):
     return a.ctypes.data_as(C.POINTER(C.c_int32)) if a is not None else None
+
+
+def rcm_order(rowptr, colind, symmetric_pattern=True):
+    """Reverse Cuthill-McKee ordering of an n x n CSR pattern on the host (mispec_rcm_order; no device needed).
+    Returns (perm with perm[new] = old, gave_up, widest_level)."""
+    rp, ci = _i32(rowptr), _i32(colind)
+    n = len(rp) - 1
+    perm = np.empty(n, dtype=np.int32)
+    gave_up, widest = C.c_int(0), C.c_int64(0)
+    check(lib().mispec_rcm_order(n, _ip(rp), _ip(ci), int(symmetric_pattern), _ip(perm), C.byref(gave_up), C.byref(widest)))
+    return perm, bool(gave_up.value), int(widest.value)
 
 
 def shard_block(n, world):
@@ -210,6 +222,28 @@ class _DeviceMatrix:
         """Compulsory SpMV traffic with the index format in use (9 instead of 12 bytes per entry with offset codes)."""
         return float(lib().mispec_csr_spmv_bytes(self.h, 1))
 
+    def reorder(self, method="rcm"):
+        """Symmetric reordering of the stored matrix (mispec_csr_reorder): "rcm" always, "auto" only when it pays.  Returns
+        True when the matrix is reordered afterwards.  Products and results keep the caller's index order."""
+        applied = C.c_int(0)
+        check(lib().mispec_csr_reorder(self.h, {"rcm": 1, "auto": -1}[method], C.byref(applied)))
+        return bool(applied.value)
+
+    def reordering(self):
+        """"none" or "rcm"."""
+        return {0: "none", 1: "rcm"}[int(lib().mispec_csr_reordering(self.h, None, None))]
+
+    def reordering_info(self):
+        fb, fa = C.c_double(0.0), C.c_double(0.0)
+        m = int(lib().mispec_csr_reordering(self.h, C.byref(fb), C.byref(fa)))
+        return {"method": {0: "none", 1: "rcm"}[m], "far_fraction_before": fb.value, "far_fraction_after": fa.value}
+
+    def permutation(self):
+        """perm[new] = old (identity when the matrix is not reordered)."""
+        out = np.empty(self.rows(), dtype=np.int32)
+        check(lib().mispec_csr_permutation(self.h, _ip(out)))
+        return out
+
     def to_host_csr(self):
         nl, nnz = self.local_rows(), self.nnz()
         rp = np.empty(nl + 1, dtype=np.int32)
@@ -236,17 +270,39 @@ def _compressed(mat):
     return m.shape[0], m.shape[1], _i32(m.indptr), _i32(m.indices), _f64(m.data), fmt == "csr"
 
 
+class _reorder_env:
+    """reorder=None keeps the library default (MISPEC_REORDER or "auto"); "none" / "rcm" / "auto" override it for one ingest."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.old = os.environ.get("MISPEC_REORDER")
+        if self.mode is not None:
+            if self.mode not in ("none", "rcm", "auto"):
+                raise ValueError("reorder must be None, 'none', 'rcm' or 'auto'")
+            os.environ["MISPEC_REORDER"] = self.mode
+
+    def __exit__(self, *exc):
+        if self.mode is not None:
+            if self.old is None:
+                os.environ.pop("MISPEC_REORDER", None)
+            else:
+                os.environ["MISPEC_REORDER"] = self.old
+
+
 class SparseSymMatProd(_DeviceMatrix):
     """MatOp/SparseSymMatProd.h: y = selfadjointView<Uplo>(A) * x; only the `uplo` triangle of A is read."""
 
-    def __init__(self, mat, uplo="L", ctx=None):
+    def __init__(self, mat, uplo="L", ctx=None, reorder=None):
         ctx = ctx or default_context()
         n, nc, outer, inner, val, row_major = _compressed(mat)
         if n != nc:
             raise ValueError("SparseSymMatProd: matrix must be square")
         h = C.c_void_p()
-        check(lib().mispec_csr_from_triangle(ctx.h, n, _ip(outer), _ip(inner), _dp(val), uplo.encode()[0:1], int(row_major),
-                                             C.byref(h)))
+        with _reorder_env(reorder):
+            check(lib().mispec_csr_from_triangle(ctx.h, n, _ip(outer), _ip(inner), _dp(val), uplo.encode()[0:1], int(row_major),
+                                                 C.byref(h)))
         super().__init__(ctx, h)
 
     @classmethod
@@ -258,12 +314,13 @@ class SparseSymMatProd(_DeviceMatrix):
 class SparseGenMatProd(_DeviceMatrix):
     """MatOp/SparseGenMatProd.h: y = A * x for a general sparse A (CSR or CSC input)."""
 
-    def __init__(self, mat, ctx=None):
+    def __init__(self, mat, ctx=None, reorder=None):
         ctx = ctx or default_context()
         nr, nc, outer, inner, val, row_major = _compressed(mat)
         h = C.c_void_p()
         fn = lib().mispec_csr_upload if row_major else lib().mispec_csr_from_csc
-        check(fn(ctx.h, nr, nc, _ip(outer), _ip(inner), _dp(val), C.byref(h)))
+        with _reorder_env(reorder):
+            check(fn(ctx.h, nr, nc, _ip(outer), _ip(inner), _dp(val), C.byref(h)))
         super().__init__(ctx, h)
 
     @classmethod
@@ -1178,6 +1235,35 @@ def double_shift_qr(H, s, t):
     Q, D = np.empty((n, n), order="F"), np.empty((n, n), order="F")
     check(lib().mispec_double_shift_qr_host(n, _dp(H), float(s), float(t), _dp(Q), _dp(D)))
     return Q, D
+
+
+def _sweep(fn, H, *args):
+    H = np.asfortranarray(H, dtype=np.float64)
+    n = H.shape[0]
+    Q, D = np.empty((n, n), order="F"), np.empty((n, n), order="F")
+    check(fn(*args[:1], n, _dp(H), *args[1:], _dp(Q), _dp(D)) if args and hasattr(args[0], "value") else fn(n, _dp(H), *args, _dp(Q), _dp(D)))
+    return Q, D
+
+
+def hess_qr_device(H, shift, ctx=None):
+    """UpperHessenbergQR as a HIP kernel (k_hess_restart, one real shift): returns (Q, Q'HQ).  3 <= n <= 96."""
+    ctx = ctx or default_context()
+    return _sweep(lib().mispec_hess_qr, H, ctx.h, float(shift))
+
+
+def double_shift_qr_device(H, s, t, ctx=None):
+    """DoubleShiftQR (one Francis step) as a HIP kernel: returns (Q, Q'HQ).  3 <= n <= 96."""
+    ctx = ctx or default_context()
+    return _sweep(lib().mispec_double_shift_qr, H, ctx.h, float(s), float(t))
+
+
+def hess_qr_lanes_host(H, shift):
+    """The kernel's source (internal/SmallDenseGenLanes.h) run with one lane on the host."""
+    return _sweep(lib().mispec_hess_qr_lanes_host, H, float(shift))
+
+
+def double_shift_qr_lanes_host(H, s, t):
+    return _sweep(lib().mispec_double_shift_qr_lanes_host, H, float(s), float(t))
 
 
 def hess_schur(H):

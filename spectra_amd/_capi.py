@@ -95,6 +95,10 @@ SIGNATURES = {
     "mispec_symshift_create": (C.c_int, [_vp, C.c_int64, _ip, _ip, _dp, C.c_char, C.c_int, _vpp]),
     "mispec_symshift_destroy": (C.c_int, [_vp]),
     "mispec_symshift_rows": (C.c_int64, [_vp]),
+    "mispec_csr_reorder": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
+    "mispec_csr_reordering": (C.c_int, [_vp, _dp, _dp]),
+    "mispec_csr_permutation": (C.c_int, [_vp, _ip]),
+    "mispec_rcm_order": (C.c_int, [C.c_int64, _ip, _ip, C.c_int, _ip, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "mispec_symshift_set_shift": (C.c_int, [_vp, C.c_double]),
     "mispec_symshift_solve": (C.c_int, [_vp, _vp, _vp]),
     "mispec_symshift_refinement_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int64), _dp, _dp]),
@@ -129,6 +133,7 @@ SIGNATURES = {
     "mispec_fac_tridiag_eigen": (C.c_int, [_vp, _dp, _dp]),
     "mispec_fac_restart_sym": (C.c_int, [_vp, _dp, C.c_int]),
     "mispec_fac_compress_V": (C.c_int, [_vp, _dp, _dp, C.c_int]),
+    "mispec_fac_restart_gen": (C.c_int, [_vp, C.POINTER(C.c_int), _dp, _dp, C.c_int, C.c_int]),
     "mispec_fac_ritz_vectors": (C.c_int, [_vp, _dp, C.c_int, _dp, _vpp]),
     "mispec_fac_residuals": (C.c_int, [_vp, _dp, C.c_int, _dp]),
     "mispec_fac_residuals_complex": (C.c_int, [_vp, _dp, _dp, _dp, C.c_int, _dp]),
@@ -205,6 +210,10 @@ SIGNATURES = {
     "mispec_geneigs_get_profile": (C.c_int, [_vp, C.POINTER(Profile)]),
     "mispec_geneigs_profile": (C.c_int, [_vp, C.c_int]),
     "mispec_hess_qr_host": (C.c_int, [C.c_int, _dp, C.c_double, _dp, _dp]),
+    "mispec_hess_qr_lanes_host": (C.c_int, [C.c_int, _dp, C.c_double, _dp, _dp]),
+    "mispec_double_shift_qr_lanes_host": (C.c_int, [C.c_int, _dp, C.c_double, C.c_double, _dp, _dp]),
+    "mispec_hess_qr": (C.c_int, [_vp, C.c_int, _dp, C.c_double, _dp, _dp]),
+    "mispec_double_shift_qr": (C.c_int, [_vp, C.c_int, _dp, C.c_double, C.c_double, _dp, _dp]),
     "mispec_double_shift_qr_host": (C.c_int, [C.c_int, _dp, C.c_double, C.c_double, _dp, _dp]),
     "mispec_hess_schur_host": (C.c_int, [C.c_int, _dp, _dp, _dp]),
     "mispec_hess_eigen_host": (C.c_int, [C.c_int, _dp, _dp, _dp]),

@@ -6,6 +6,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <utility>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -98,6 +99,11 @@ struct DevBuf
             (void) hipFree(p);
         p = nullptr;
         n = 0;
+    }
+    void swap(DevBuf& o)
+    {
+        std::swap(p, o.p);
+        std::swap(n, o.n);
     }
 };
 

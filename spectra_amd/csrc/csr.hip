@@ -27,12 +27,14 @@
 // Bound: HBM.  Algorithmic bytes per launch: 12*nnz + 4*(rows+1) + 8*cols + 8*rows (CSR with int32
 // indices); the offset-coded variant's compulsory traffic is 9*nnz + ... .
 #include "csr.hpp"
+#include "reorder.hpp"
 
 #include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <numeric>
 
 using namespace mispec;
@@ -420,6 +422,49 @@ __global__ __launch_bounds__(256) void k_spmv_dia_win(DiaArgs da, mispec_dia_win
         y[row0 + tid] = acc;
 }
 
+// ---- reordered matrices: vector permutations and the un-fused epilogue ----------------------------------------------
+__global__ __launch_bounds__(256) void k_perm_gather(int64_t n, const int32_t* __restrict__ perm, const double* __restrict__ src,
+                                                     double* __restrict__ dst)
+{
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n)
+        dst[i] = src[perm[i]];
+}
+__global__ __launch_bounds__(256) void k_perm_scatter(int64_t n, const int32_t* __restrict__ perm, const double* __restrict__ src,
+                                                      double* __restrict__ dst)
+{
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n)
+        dst[perm[i]] = src[i];
+}
+// The Lanczos epilogue of the SpMV kernels as its own pass, on the same 256-row blocks (so the alpha partials are the same
+// records): y -= h_prev * v_prev, partials[block] = sum v * y  (Lanczos.h:139,142)
+__global__ __launch_bounds__(256) void k_epilogue_blocks(double* __restrict__ y, int64_t nrows, SpmvEpilogue epi)
+{
+    __shared__ double red[4];
+    if (epi.status && *epi.status != 0)
+        return;
+    if (blockDim.x < 256)  // 128-row blocks (MISPEC_SPMV_ROWS=128): two of the four wave slots stay zero
+    {
+        if (threadIdx.x < 4)
+            red[threadIdx.x] = 0.0;
+        __syncthreads();
+    }
+    const int64_t row = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    double contrib = 0.0;
+    if (row < nrows)
+    {
+        double yv = y[row];
+        if (epi.v_prev)
+            yv -= (epi.h_prev_dev ? *epi.h_prev_dev : epi.h_prev) * epi.v_prev[row];
+        y[row] = yv;
+        contrib = epi.v_rows[row] * yv;
+    }
+    const double total = block_reduce_sum(contrib, red);
+    if (threadIdx.x == 0)
+        epi.partials[blockIdx.x] = total;
+}
+
 // ---- synthetic band matrix, bit-identical to oracle/synth_matrix.h -------------
 __host__ __device__ inline uint64_t synth_mix64(uint64_t z)
 {
@@ -610,8 +655,10 @@ bool build_offset_codes(int64_t b, int64_t e, const int32_t* rowptr, const int32
 }
 
 // Upload host CSR rows [begin,end) of a global matrix.
+bool reorder_matrix(mispec_csr& A, const int32_t* rowptr, const int32_t* colind, const double* val, bool forced);
+
 mispec_csr* upload_rows(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const int32_t* rowptr, const int32_t* colind,
-                        const double* val)
+                        const double* val, bool allow_reorder = true, bool structurally_symmetric = false)
 {
     MISPEC_REQUIRE(ctx && rowptr && n_rows >= 0 && n_cols >= 0, "csr upload: bad argument");
     MISPEC_REQUIRE(n_cols < (int64_t(1) << 31), "csr upload: column count exceeds int32");
@@ -660,6 +707,19 @@ mispec_csr* upload_rows(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const i
             build_dia(*A, dict);
         }
         MISPEC_HIP(hipStreamSynchronize(ctx->stream));
+        A->structurally_symmetric = structurally_symmetric;
+        // MISPEC_REORDER = auto (default) | rcm | none: an unsharded square matrix whose gathers are scattered (more than a
+        // quarter of the entries further than kFarWindow from the diagonal, and x larger than an L2 slice) is reordered
+        // at ingest when reverse Cuthill-McKee localises them (reorder.hip)
+        const char* mode = getenv("MISPEC_REORDER");
+        const bool off = mode && std::strcmp(mode, "none") == 0;
+        const bool force = mode && std::strcmp(mode, "rcm") == 0;
+        if (allow_reorder && !off && ctx->world() == 1 && ctx->comm.allgather == nullptr && n_rows == n_cols && p1 > p0)
+        {
+            A->far_before = far_fraction(n_rows, rowptr, colind, nullptr, kFarWindow);
+            if (force || (n_rows >= 2 * kFarWindow && A->far_before > 0.25))
+                reorder_matrix(*A, rowptr, colind, val, force);
+        }
     }
     catch (...)
     {
@@ -667,6 +727,51 @@ mispec_csr* upload_rows(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const i
         throw;
     }
     return A;
+}
+
+// Replace the stored matrix by P A P' (reverse Cuthill-McKee).  Host arrays of the FULL matrix in the caller's order.
+// Automatic mode adopts the ordering only when it at least halves the fraction of far gathers; `forced` always does.
+bool reorder_matrix(mispec_csr& A, const int32_t* rowptr, const int32_t* colind, const double* val, bool forced)
+{
+    const int64_t n = A.n_rows;
+    MISPEC_REQUIRE(A.n_rows == A.n_cols && A.ctx->world() == 1 && A.ctx->comm.allgather == nullptr,
+                   "reordering needs an unsharded square matrix");
+    MISPEC_REQUIRE(!A.reordered(), "the matrix is already reordered");
+    std::vector<int32_t> perm;
+    ReorderStats st;
+    if (!rcm_order(n, rowptr, colind, A.structurally_symmetric, forced ? 0.0 : 0.125, perm, &st))
+        return false;
+    std::vector<int32_t> inv(static_cast<size_t>(n));
+    for (int64_t i = 0; i < n; i++)
+        inv[size_t(perm[size_t(i)])] = int32_t(i);
+    const double before = far_fraction(n, rowptr, colind, nullptr, kFarWindow);
+    const double after = far_fraction(n, rowptr, colind, inv.data(), kFarWindow);
+    if (!forced && !(after <= 0.5 * before))
+        return false;
+    std::vector<int32_t> rp, ci;
+    std::vector<double> v;
+    permute_csr(n, rowptr, colind, val, perm, rp, ci, v);
+    std::unique_ptr<mispec_csr> B(upload_rows(A.ctx, n, n, rp.data(), ci.data(), v.data(), false, A.structurally_symmetric));
+    A.rowptr.swap(B->rowptr);
+    A.colind.swap(B->colind);
+    A.val.swap(B->val);
+    A.codes.swap(B->codes);
+    A.dict.swap(B->dict);
+    A.dia.swap(B->dia);
+    A.dia_off.swap(B->dia_off);
+    std::swap(A.ndict, B->ndict);
+    std::swap(A.dia_ld, B->dia_ld);
+    std::swap(A.ndia, B->ndia);
+    std::swap(A.dia_win, B->dia_win);
+    A.nnz = B->nnz;
+    A.perm.alloc(size_t(n));
+    MISPEC_HIP(hipMemcpy(A.perm.p, perm.data(), size_t(n) * sizeof(int32_t), hipMemcpyHostToDevice));
+    A.perm_host.swap(perm);
+    A.inv_host.swap(inv);
+    A.reorder_method = 1;
+    A.far_before = before;
+    A.far_after = after;
+    return true;
 }
 
 // Smallest / largest column referenced inside every rank's row block (block = rows per rank): which part of
@@ -714,8 +819,51 @@ int spmv_rows_per_block()
     return rows;
 }
 
+void launch_to_stored_order(const mispec_csr& A, const double* src, double* dst)
+{
+    const int64_t n = A.local_rows();
+    hipLaunchKernelGGL(k_perm_gather, dim3(unsigned((n + 255) / 256)), dim3(256), 0, A.ctx->stream, n, A.perm.p, src, dst);
+    MISPEC_HIP(hipGetLastError());
+}
+void launch_from_stored_order(const mispec_csr& A, const double* src, double* dst)
+{
+    const int64_t n = A.local_rows();
+    hipLaunchKernelGGL(k_perm_scatter, dim3(unsigned((n + 255) / 256)), dim3(256), 0, A.ctx->stream, n, A.perm.p, src, dst);
+    MISPEC_HIP(hipGetLastError());
+}
+
 void launch_spmv(const mispec_csr& A, const double* x_dev, double* y_dev, const SpmvEpilogue* epi, hipEvent_t ev_start,
                  hipEvent_t ev_stop)
+{
+    if (!A.reordered())
+    {
+        launch_spmv_raw(A, x_dev, y_dev, epi, ev_start, ev_stop);
+        return;
+    }
+    // the caller's index order is kept: x -> stored order, product with P A P', y back, then the epilogue as its own pass
+    // over the same 256-row blocks (identical partial records)
+    const int64_t n = A.local_rows();
+    if (n == 0)
+        return;
+    if (A.perm_x.n < size_t(n) + 2)
+    {
+        A.perm_x.alloc(size_t(n) + 2);
+        A.perm_y.alloc(size_t(n) + 2);
+    }
+    launch_to_stored_order(A, x_dev, A.perm_x.p);
+    launch_spmv_raw(A, A.perm_x.p, A.perm_y.p, nullptr, ev_start, ev_stop);
+    launch_from_stored_order(A, A.perm_y.p, y_dev);
+    if (epi)
+    {
+        const int nblocks = spmv_num_blocks(n);
+        hipLaunchKernelGGL(k_epilogue_blocks, dim3(unsigned(nblocks)), dim3(unsigned(spmv_rows_per_block())), 0, A.ctx->stream, y_dev, n,
+                           *epi);
+        MISPEC_HIP(hipGetLastError());
+    }
+}
+
+void launch_spmv_raw(const mispec_csr& A, const double* x_dev, double* y_dev, const SpmvEpilogue* epi, hipEvent_t ev_start,
+                     hipEvent_t ev_stop)
 {
     const int64_t nloc = A.local_rows();
     if (nloc == 0)
@@ -953,7 +1101,7 @@ extern "C" int mispec_csr_from_triangle(mispec_ctx* ctx, int64_t n, const int32_
                 v[size_t(s + k)] = tv[size_t(perm[size_t(k)])];
             }
         }
-        *out = upload_rows(ctx, n, n, rp.data(), ci.data(), v.data());
+        *out = upload_rows(ctx, n, n, rp.data(), ci.data(), v.data(), true, true);
     });
 }
 
@@ -1074,12 +1222,74 @@ extern "C" double mispec_csr_spmv_bytes(const mispec_csr* A, int stored)
     return stored ? A->stored_bytes() : A->algorithmic_bytes();
 }
 
+extern "C" int mispec_csr_reorder(mispec_csr* A, int method, int* applied)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(A && (method == 1 || method == -1), "mispec_csr_reorder: method must be 1 (reverse Cuthill-McKee) or -1 (automatic)");
+        if (applied)
+            *applied = 0;
+        if (A->reordered())
+        {
+            if (applied)
+                *applied = 1;
+            return;
+        }
+        MISPEC_REQUIRE(A->n_rows == A->n_cols && A->ctx->world() == 1 && A->ctx->comm.allgather == nullptr,
+                       "mispec_csr_reorder: needs an unsharded square matrix");
+        A->ctx->make_current();
+        MISPEC_HIP(hipStreamSynchronize(A->ctx->stream));
+        const int64_t n = A->n_rows;
+        std::vector<int32_t> rp(size_t(n) + 1), ci(size_t(A->nnz));
+        std::vector<double> v(size_t(A->nnz));
+        MISPEC_HIP(hipMemcpy(rp.data(), A->rowptr.p, rp.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (A->nnz)
+        {
+            MISPEC_HIP(hipMemcpy(ci.data(), A->colind.p, ci.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+            MISPEC_HIP(hipMemcpy(v.data(), A->val.p, v.size() * sizeof(double), hipMemcpyDeviceToHost));
+        }
+        if (method == -1)
+        {
+            A->far_before = far_fraction(n, rp.data(), ci.data(), nullptr, kFarWindow);
+            if (!(n >= 2 * kFarWindow && A->far_before > 0.25))
+                return;
+        }
+        const bool done = reorder_matrix(*A, rp.data(), ci.data(), v.data(), method == 1);
+        if (applied)
+            *applied = done ? 1 : 0;
+    });
+}
+
+extern "C" int mispec_csr_reordering(const mispec_csr* A, double* far_before, double* far_after)
+{
+    if (!A)
+        return 0;
+    if (far_before)
+        *far_before = A->far_before;
+    if (far_after)
+        *far_after = A->reordered() ? A->far_after : A->far_before;
+    return A->reorder_method;
+}
+
+extern "C" int mispec_csr_permutation(const mispec_csr* A, int32_t* perm_out)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(A && perm_out, "mispec_csr_permutation: NULL argument");
+        for (int64_t i = 0; i < A->n_rows; i++)
+            perm_out[i] = A->reordered() ? A->perm_host[size_t(i)] : int32_t(i);
+    });
+}
+
 extern "C" int mispec_csr_coeff(const mispec_csr* A, int64_t i, int64_t j, double* out)
 {
     return guarded([&] {
         MISPEC_REQUIRE(A && out, "mispec_csr_coeff: NULL argument");
         MISPEC_REQUIRE(i >= A->row_begin && i < A->row_end && j >= 0 && j < A->n_cols, "mispec_csr_coeff: index outside this shard");
         A->ctx->make_current();
+        if (A->reordered())  // stored: B(inv[i], inv[j]) = A(i, j)
+        {
+            i = A->inv_host[size_t(i)];
+            j = A->inv_host[size_t(j)];
+        }
         int32_t rp[2];
         MISPEC_HIP(hipMemcpy(rp, A->rowptr.p + (i - A->row_begin), sizeof(rp), hipMemcpyDeviceToHost));
         const int len = rp[1] - rp[0];
@@ -1102,6 +1312,29 @@ extern "C" int mispec_csr_download(const mispec_csr* A, int32_t* rowptr_host, in
         MISPEC_REQUIRE(A, "mispec_csr_download: NULL argument");
         A->ctx->make_current();
         MISPEC_HIP(hipStreamSynchronize(A->ctx->stream));
+        if (A->reordered())
+        {
+            // hand back the matrix in the caller's order: A = P' B P
+            const int64_t n = A->n_rows;
+            std::vector<int32_t> rp(size_t(n) + 1), ci(size_t(A->nnz));
+            std::vector<double> v(size_t(A->nnz));
+            MISPEC_HIP(hipMemcpy(rp.data(), A->rowptr.p, rp.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+            if (A->nnz)
+            {
+                MISPEC_HIP(hipMemcpy(ci.data(), A->colind.p, ci.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+                MISPEC_HIP(hipMemcpy(v.data(), A->val.p, v.size() * sizeof(double), hipMemcpyDeviceToHost));
+            }
+            std::vector<int32_t> orp, oci;
+            std::vector<double> ov;
+            permute_csr(n, rp.data(), ci.data(), v.data(), A->inv_host, orp, oci, ov);  // the inverse permutation undoes it
+            if (rowptr_host)
+                std::memcpy(rowptr_host, orp.data(), orp.size() * sizeof(int32_t));
+            if (colind_host && A->nnz)
+                std::memcpy(colind_host, oci.data(), oci.size() * sizeof(int32_t));
+            if (val_host && A->nnz)
+                std::memcpy(val_host, ov.data(), ov.size() * sizeof(double));
+            return;
+        }
         if (rowptr_host)
             MISPEC_HIP(hipMemcpy(rowptr_host, A->rowptr.p, size_t(A->local_rows() + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
         if (colind_host && A->nnz)
@@ -1159,7 +1392,7 @@ extern "C" int mispec_spmv_time(const mispec_csr* A, const double* x_dev, double
         MISPEC_HIP(hipEventCreate(&e1));
         MISPEC_HIP(hipEventRecord(e0, A->ctx->stream));
         for (int i = 0; i < reps; i++)
-            launch_spmv(*A, x_dev, y_dev, nullptr);
+            launch_spmv_raw(*A, x_dev, y_dev, nullptr);  // the kernel itself (the stored, possibly reordered matrix)
         MISPEC_HIP(hipEventRecord(e1, A->ctx->stream));
         MISPEC_HIP(hipEventSynchronize(e1));
         float ms = 0.f;

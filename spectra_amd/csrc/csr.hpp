@@ -43,6 +43,16 @@ struct mispec_csr
     int ndia = 0;
     mispec_dia_windows dia_win;
     int forced_format = -1;          // mispec_csr_set_spmv_format: -1 automatic, 0 int32 indices, 1 offset codes, 2 diagonals
+    // Symmetric reordering (reorder.hip): when perm is set, the arrays above hold B = P A P', B(i, j) = A(perm[i], perm[j]).
+    // The public products (mispec_spmv*, operator(), downloads) keep the ORIGINAL index order (gather x, product, scatter
+    // y); the eigensolvers work in the permuted order and un-permute what they return.  Unsharded square matrices only.
+    mispec::DevBuf<int32_t> perm;          // new -> old, local_rows entries
+    std::vector<int32_t> perm_host, inv_host;  // and old -> new
+    int reorder_method = 0;                // 0 none, 1 reverse Cuthill-McKee
+    double far_before = 0.0, far_after = 0.0;  // fraction of entries further than kFarWindow from the diagonal
+    bool structurally_symmetric = false;   // set by the symmetric ingest paths (the ordering then skips A + A')
+    mutable mispec::DevBuf<double> perm_x, perm_y;  // scratch of the order-preserving public product
+    bool reordered() const { return perm.p != nullptr; }
     // staging for the host-pointer paths (allocated on first use)
     mutable mispec::DevBuf<double> stage_x, stage_y;
 
@@ -94,8 +104,17 @@ inline int spmv_num_blocks(int64_t local_rows)
 }
 
 // ev_start / ev_stop (both or none): HIP events bound to this dispatch's start and completion.
+// launch_spmv keeps the caller's index order: for a reordered matrix it gathers x, runs the product on P A P', scatters y
+// and applies the epilogue as a separate pass.  launch_spmv_raw is the product with the STORED matrix (the permuted one
+// when reordered): what a solver that works in the permuted order calls.
 void launch_spmv(const mispec_csr& A, const double* x_dev, double* y_dev, const SpmvEpilogue* epi, hipEvent_t ev_start = nullptr,
                  hipEvent_t ev_stop = nullptr);
+void launch_spmv_raw(const mispec_csr& A, const double* x_dev, double* y_dev, const SpmvEpilogue* epi, hipEvent_t ev_start = nullptr,
+                     hipEvent_t ev_stop = nullptr);
+// dst[i] = src[perm[i]] (to the stored order) / dst[perm[i]] = src[i] (back to the caller's order), i < local_rows
+void launch_to_stored_order(const mispec_csr& A, const double* src, double* dst);
+void launch_from_stored_order(const mispec_csr& A, const double* src, double* dst);
+constexpr int64_t kFarWindow = 131072;  // |col - row| beyond which an x gather is counted as "far" (1 MiB of x)
 
 // For every rank p of a `world`-way row partition with `block` rows per rank: the smallest (lo[p]) and largest
 // (hi[p]) column index this shard references inside p's rows; hi[p] = -1 when it references none.  Returns

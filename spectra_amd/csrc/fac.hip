@@ -96,6 +96,12 @@ struct mispec_fac
     bool halo = false;
     std::vector<int64_t> send_off, send_count, recv_off, recv_count;
     int64_t halo_recv = 0;  // doubles received per exchange
+    // The matrix is stored reordered (P A P', reorder.hip) and this factorisation works in that order: start vectors are
+    // permuted on the way in, V / f / Ritz vectors on the way out; plain operators only (product, generalized and
+    // Cholesky operators use the order-preserving product instead)
+    bool perm_mode = false;
+    bool x_original = false;  // the columns of X have been put back into the caller's order
+    DevBuf<double> pscratch;
     int red_cur = 0;   // which half of `red` holds the latest reduced record
     int x_cols = 0;    // columns currently held in X
 
@@ -195,6 +201,31 @@ void comm_check(int rc, const char* what)
 {
     if (rc != MISPEC_OK)
         throw Error(MISPEC_ERUNTIME, std::string(what) + " failed: " + mispec_last_error());
+}
+
+// vec (nloc entries, caller's order) -> stored order, in place; and back
+void to_stored_order(mispec_fac& F, double* vec)
+{
+    if (!F.perm_mode)
+        return;
+    launch_to_stored_order(*F.A, vec, F.pscratch.p);
+    MISPEC_HIP(hipMemcpyAsync(vec, F.pscratch.p, size_t(F.nloc) * sizeof(double), hipMemcpyDeviceToDevice, F.stream()));
+}
+void from_stored_order(mispec_fac& F, double* vec)
+{
+    if (!F.perm_mode)
+        return;
+    launch_from_stored_order(*F.A, vec, F.pscratch.p);
+    MISPEC_HIP(hipMemcpyAsync(vec, F.pscratch.p, size_t(F.nloc) * sizeof(double), hipMemcpyDeviceToDevice, F.stream()));
+}
+// the product with the stored matrix when this factorisation works in its order, else the order-preserving one
+void spmv_of(mispec_fac& F, const mispec_csr& M, const double* x, double* y, const SpmvEpilogue* epi, hipEvent_t e0 = nullptr,
+             hipEvent_t e1 = nullptr)
+{
+    if (F.perm_mode)
+        launch_spmv_raw(M, x, y, epi, e0, e1);
+    else
+        launch_spmv(M, x, y, epi, e0, e1);
 }
 
 void allreduce(mispec_fac& F, double* buf, int64_t count)
@@ -411,10 +442,10 @@ void apply_op(mispec_fac& F, const double* x_loc, double* y_loc, bool lanczos_ep
             epi.h_prev_dev = h_prev_dev;
             epi.status = status;
             epi.partials = F.alpha_partials.p;
-            launch_spmv(*last, x, y_loc, &epi, e0, e1);
+            spmv_of(F, *last, x, y_loc, &epi, e0, e1);
         }
         else
-            launch_spmv(*last, x, y_loc, nullptr, e0, e1);
+            spmv_of(F, *last, x, y_loc, nullptr, e0, e1);
     }
     else if (F.S && F.Bcsr)
     {
@@ -605,11 +636,15 @@ void expand_basis(mispec_fac& F, int ncol, int64_t seed, int64_t* nmatop)
         if (iter == 0)
         {
             launch_simple_random(*F.ctx, F.tmp.p, F.row_begin, F.nloc, s);  // :76
+            to_stored_order(F, F.tmp.p);
             apply_op(F, F.tmp.p, F.f.p, false, nullptr, 0.0);               // :79  f = A * rand
             (*nmatop)++;
         }
         else
+        {
             launch_simple_random(*F.ctx, F.f.p, F.row_begin, F.nloc, s);  // :84
+            to_stored_order(F, F.f.p);
+        }
         vtf(F, F.f.p, ncol, 0);                                         // :87
         correct_vtf(F, F.f.p, F.f.p, ncol);                             // :88-93 (f -= V Vf ; |f| ; V'f)
         double fnorm = F.h_red.p[kSlotBeta];
@@ -1236,6 +1271,9 @@ int fac_create_impl(mispec_ctx* ctx, const mispec_csr* A, const mispec_symshift*
                 F->h_x.alloc(size_t(n));
                 F->h_y.alloc(size_t(n));
             }
+            F->perm_mode = A && A->reordered() && !A2 && !Bop && !Chol && !F->sharded();
+            if (F->perm_mode)
+                F->pscratch.alloc(size_t(F->ldv));
             MISPEC_HIP(hipStreamSynchronize(ctx->stream));
             plan_exchange(*F);
         }
@@ -1352,6 +1390,7 @@ extern "C" int mispec_fac_init(mispec_fac* fac, const double* v0_host, int64_t* 
             MISPEC_HIP(hipMemcpyAsync(F.tmp.p, v0_host + F.row_begin, size_t(F.nloc) * sizeof(double), hipMemcpyHostToDevice,
                                       F.stream()));
         sync_stream(F);  // v0_host may be pageable memory that the caller frees right after
+        to_stored_order(F, F.tmp.p);
         init_from_tmp(F, nmatop);
     });
 }
@@ -1364,6 +1403,7 @@ extern "C" int mispec_fac_init_random(mispec_fac* fac, uint64_t seed, int64_t* n
         F.ctx->make_current();
         zero_vector(F, F.tmp.p);
         launch_simple_random(*F.ctx, F.tmp.p, F.row_begin, F.nloc, seed);
+        to_stored_order(F, F.tmp.p);  // the reference's start vector, entry i belonging to row i of the caller's matrix
         init_from_tmp(F, nmatop);
     });
 }
@@ -1431,6 +1471,17 @@ extern "C" int mispec_fac_get_V(const mispec_fac* fac, int ncols, double* V_host
         MISPEC_REQUIRE(fac && V_host && ncols >= 0 && ncols <= fac->m, "mispec_fac_get_V: bad argument");
         fac->ctx->make_current();
         MISPEC_HIP(hipStreamSynchronize(fac->ctx->stream));
+        if (fac->perm_mode)
+        {
+            for (int j = 0; j < ncols; j++)  // column by column through the scratch vector, back in the caller's row order
+            {
+                launch_from_stored_order(*fac->A, fac->V.p + int64_t(j) * fac->ldv, fac->pscratch.p);
+                MISPEC_HIP(hipMemcpyAsync(V_host + int64_t(j) * fac->nloc, fac->pscratch.p, size_t(fac->nloc) * sizeof(double),
+                                          hipMemcpyDeviceToHost, fac->ctx->stream));
+                MISPEC_HIP(hipStreamSynchronize(fac->ctx->stream));
+            }
+            return;
+        }
         if (ncols && fac->nloc)
             MISPEC_HIP(hipMemcpy2D(V_host, size_t(fac->nloc) * sizeof(double), fac->V.p, size_t(fac->ldv) * sizeof(double),
                                    size_t(fac->nloc) * sizeof(double), size_t(ncols), hipMemcpyDeviceToHost));
@@ -1443,6 +1494,13 @@ extern "C" int mispec_fac_get_f(const mispec_fac* fac, double* f_host)
         MISPEC_REQUIRE(fac && f_host, "mispec_fac_get_f: NULL argument");
         fac->ctx->make_current();
         MISPEC_HIP(hipStreamSynchronize(fac->ctx->stream));
+        if (fac->perm_mode)
+        {
+            launch_from_stored_order(*fac->A, fac->f.p, fac->pscratch.p);
+            MISPEC_HIP(hipMemcpyAsync(f_host, fac->pscratch.p, size_t(fac->nloc) * sizeof(double), hipMemcpyDeviceToHost, fac->ctx->stream));
+            MISPEC_HIP(hipStreamSynchronize(fac->ctx->stream));
+            return;
+        }
         if (fac->nloc)
             MISPEC_HIP(hipMemcpy(f_host, fac->f.p, size_t(fac->nloc) * sizeof(double), hipMemcpyDeviceToHost));
     });
@@ -1601,6 +1659,48 @@ extern "C" int mispec_fac_compress_V(mispec_fac* fac, const double* Q_host, cons
     });
 }
 
+// The whole shift list of one general (Arnoldi) restart on the device: H and Q stay there, Q is consumed by V <- V Q
+// straight from HBM; only H comes back (it is authoritative on the host).  GenEigsBase.h:204-222 / RestartArnoldi.
+extern "C" int mispec_fac_restart_gen(mispec_fac* fac, const int* kind, const double* a, const double* b, int nshift, int new_k)
+{
+    return guarded([&] {
+        require_init(fac, "mispec_fac_restart_gen");
+        mispec_fac& F = *fac;
+        MISPEC_REQUIRE(!F.symmetric, "mispec_fac_restart_gen: general (Arnoldi) factorisations only");
+        MISPEC_REQUIRE(kind && a && b && nshift >= 1 && nshift <= kMaxShifts && new_k >= 1 && new_k < F.m, "mispec_fac_restart_gen: bad argument");
+        MISPEC_REQUIRE(F.m <= kMaxGenDim, "mispec_fac_restart_gen: the device kernel holds at most 96 basis columns");
+        MISPEC_REQUIRE(F.k == F.m, "mispec_fac_restart_gen: the factorisation must be complete (k == ncv)");
+        F.ctx->make_current();
+        const int m = F.m;
+        GenShiftList sl;
+        sl.count = nshift;
+        for (int i = 0; i < nshift; i++)
+        {
+            MISPEC_REQUIRE(kind[i] == 0 || kind[i] == 1, "mispec_fac_restart_gen: kind must be 0 (real shift) or 1 (double shift)");
+            sl.kind[i] = kind[i];
+            sl.a[i] = a[i];
+            sl.b[i] = b[i];
+        }
+        std::memcpy(F.h_H.p, F.H.data(), size_t(m) * m * sizeof(double));
+        MISPEC_HIP(hipMemcpyAsync(F.d_H.p, F.h_H.p, size_t(m) * m * 8, hipMemcpyHostToDevice, F.stream()));
+        {
+            Timed t(F, FAM_SMALL);
+            launch_restart_gen(*F.ctx, m, F.d_H.p, sl, F.Qdev.p);
+        }
+        F.k = new_k;
+        {
+            Timed t(F, FAM_COMPRESS);
+            compress_basis(F, new_k + 1);
+        }
+        double* hs = F.h_small.p;
+        MISPEC_HIP(hipMemcpyAsync(F.h_H.p, F.d_H.p, size_t(m) * m * 8, hipMemcpyDeviceToHost, F.stream()));
+        MISPEC_HIP(hipMemcpyAsync(hs, F.Qdev.p + size_t(new_k - 1) * m + (m - 1), sizeof(double), hipMemcpyDeviceToHost, F.stream()));
+        sync_stream(F);
+        std::memcpy(F.H.data(), F.h_H.p, size_t(m) * m * sizeof(double));
+        update_f_after_compress(F, hs[0], F.Hat(new_k, new_k - 1));
+    });
+}
+
 extern "C" int mispec_fac_ritz_vectors(mispec_fac* fac, const double* Y_host, int ncols, double* X_host, const double** X_dev)
 {
     return guarded([&] {
@@ -1619,6 +1719,10 @@ extern "C" int mispec_fac_ritz_vectors(mispec_fac* fac, const double* Y_host, in
             launch_vq(*F.ctx, F.V.p, F.ldv, m, F.d_Y.p, m, ncols, F.X.p, F.ldv, F.nloc);  // HermEigsBase.h:467
         }
         F.x_cols = ncols;
+        F.x_original = F.perm_mode;
+        if (F.perm_mode)
+            for (int j = 0; j < ncols; j++)
+                from_stored_order(F, F.X.p + int64_t(j) * F.ldv);  // rows back in the caller's order
         if (X_host && F.nloc)
             MISPEC_HIP(hipMemcpy2DAsync(X_host, size_t(F.nloc) * sizeof(double), F.X.p, size_t(F.ldv) * sizeof(double),
                                         size_t(F.nloc) * sizeof(double), size_t(ncols), hipMemcpyDeviceToHost, F.stream()));
@@ -1646,6 +1750,8 @@ extern "C" int mispec_fac_residuals(mispec_fac* fac, const double* lambda_host, 
                 b_apply(F, x);
                 x = F.bx.p;
             }
+            else if (F.perm_mode && F.x_original)
+                launch_spmv(*F.A, x, F.tmp.p, nullptr);  // X is in the caller's order: the order-preserving product
             else
                 apply_op(F, x, F.tmp.p, false, nullptr, 0.0);
             const int nrec = launch_resid_norms(*F.ctx, F.tmp.p, x, lambda_host[j], F.nloc, F.partials.p, F.pstride);

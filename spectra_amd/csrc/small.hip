@@ -5,8 +5,11 @@
 #include "small.hpp"
 
 #include <Spectra/internal/SmallDense.h>
+#include <Spectra/internal/SmallDenseGenLanes.h>
 
+#include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 using namespace mispec;
 
@@ -71,6 +74,42 @@ __global__ __launch_bounds__(64) void k_restart_sym(int m, double* __restrict__ 
         Qout[idx] = Q[idx];
 }
 
+// General restart (a19): the shifts of one implicit restart of the Arnoldi process applied to the m x m upper Hessenberg
+// H — a real shift is UpperHessenbergQR::compute + matrix_QtHQ (UpperHessenbergQR.h:136-255), a conjugate pair one Francis
+// double-shift step (DoubleShiftQR.h:334-438) — with Q <- Q * Q_i accumulated (apply_YQ) for the V*Q kernel.  One
+// wavefront; H, Q (leading dimension m|1: row walks hit distinct banks) and the work arrays in LDS; the arithmetic is
+// internal/SmallDenseGenLanes.h, the same source the host compiles.
+__global__ __launch_bounds__(64) void k_hess_restart(int m, int ld, double* __restrict__ H_io, GenShiftList shifts, double* __restrict__ Qout)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* H = sm;
+    double* Q = sm + size_t(m) * ld;
+    double* work = Q + size_t(m) * ld;  // 3m
+    int* iwork = reinterpret_cast<int*>(work + 3 * m);  // 2m + 2
+    const int lane = threadIdx.x;
+    for (int idx = lane; idx < m * m; idx += 64)
+    {
+        const int i = idx % m, j = idx / m;
+        H[size_t(j) * ld + i] = H_io[idx];
+        Q[size_t(j) * ld + i] = (i == j) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    const small::Lanes lanes{lane, 64};
+    for (int s = 0; s < shifts.count; s++)
+    {
+        if (shifts.kind[s] == 0)
+            small::hess_shifted_qr_lanes(m, H, ld, shifts.a[s], Q, ld, m, work, lanes);
+        else
+            small::double_shift_qr_lanes(m, H, ld, shifts.a[s], shifts.b[s], Q, ld, m, work, iwork, lanes);
+    }
+    __syncthreads();
+    for (int idx = lane; idx < m * m; idx += 64)
+    {
+        const int i = idx % m, j = idx / m;
+        H_io[idx] = H[size_t(j) * ld + i];
+        Qout[idx] = Q[size_t(j) * ld + i];
+    }
+}
 
 // ===================================================================================================
 // Register-resident variants for m <= 64 (one wavefront, lane i <-> row/entry i).
@@ -398,7 +437,86 @@ void launch_restart_sym(const mispec_ctx& ctx, int m, double* diag, double* subd
     MISPEC_HIP(hipGetLastError());
 }
 
+void launch_restart_gen(const mispec_ctx& ctx, int m, double* H, const GenShiftList& shifts, double* Q)
+{
+    MISPEC_REQUIRE(m >= 3 && m <= kMaxGenDim, "general restart kernel: dimension out of range (3 <= ncv <= 96)");
+    MISPEC_REQUIRE(shifts.count >= 0 && shifts.count <= kMaxShifts, "general restart kernel: too many shifts");
+    const int ld = m | 1;
+    const size_t lds = (size_t(2) * m * ld + size_t(3) * m) * sizeof(double) + (size_t(2) * m + 2) * sizeof(int);
+    MISPEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hess_restart), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    hipLaunchKernelGGL(k_hess_restart, dim3(1), dim3(64), lds, ctx.stream, m, ld, H, shifts, Q);
+    MISPEC_HIP(hipGetLastError());
+}
+
 }  // namespace mispec
+
+// ---- the general sweeps as stand-alone entry points: on the device (one shift per launch) and — the same source with one
+// ---- lane — on the host (mirror test/QR.cpp "QR of upper Hessenberg matrix" / "QR decomposition with double shift")
+namespace {
+void gen_sweep_device(mispec_ctx* ctx, int n, const double* H_host, int kind, double a, double b, double* Q_host, double* QtHQ_host)
+{
+    ctx->make_current();
+    DevBuf<double> H, Q;
+    H.alloc(size_t(n) * n);
+    Q.alloc(size_t(n) * n);
+    MISPEC_HIP(hipMemcpyAsync(H.p, H_host, size_t(n) * n * 8, hipMemcpyHostToDevice, ctx->stream));
+    GenShiftList sl;
+    sl.count = 1;
+    sl.kind[0] = kind;
+    sl.a[0] = a;
+    sl.b[0] = b;
+    launch_restart_gen(*ctx, n, H.p, sl, Q.p);
+    if (Q_host)
+        MISPEC_HIP(hipMemcpyAsync(Q_host, Q.p, size_t(n) * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (QtHQ_host)
+        MISPEC_HIP(hipMemcpyAsync(QtHQ_host, H.p, size_t(n) * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    MISPEC_HIP(hipStreamSynchronize(ctx->stream));
+}
+void gen_sweep_host_lanes(int n, const double* H_in, int kind, double a, double b, double* Q_out, double* QtHQ_out)
+{
+    std::vector<double> H(H_in, H_in + size_t(n) * n), Q(size_t(n) * n, 0.0), work(size_t(3) * n);
+    std::vector<int> iwork(size_t(2) * n + 2);
+    for (int i = 0; i < n; i++)
+        Q[size_t(i) * n + i] = 1.0;
+    if (kind == 0)
+        small::hess_shifted_qr_lanes(n, H.data(), n, a, Q.data(), n, n, work.data(), small::Lanes{0, 1});
+    else
+        small::double_shift_qr_lanes(n, H.data(), n, a, b, Q.data(), n, n, work.data(), iwork.data(), small::Lanes{0, 1});
+    if (Q_out)
+        std::copy(Q.begin(), Q.end(), Q_out);
+    if (QtHQ_out)
+        std::copy(H.begin(), H.end(), QtHQ_out);
+}
+}  // namespace
+
+extern "C" int mispec_hess_qr(mispec_ctx* ctx, int n, const double* H_host, double shift, double* Q_host, double* QtHQ_host)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(ctx && H_host && n >= 3, "mispec_hess_qr: bad argument");
+        gen_sweep_device(ctx, n, H_host, 0, shift, 0.0, Q_host, QtHQ_host);
+    });
+}
+extern "C" int mispec_double_shift_qr(mispec_ctx* ctx, int n, const double* H_host, double s, double t, double* Q_host, double* QtHQ_host)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(ctx && H_host && n >= 3, "mispec_double_shift_qr: bad argument");
+        gen_sweep_device(ctx, n, H_host, 1, s, t, Q_host, QtHQ_host);
+    });
+}
+extern "C" int mispec_hess_qr_lanes_host(int n, const double* H, double shift, double* Q, double* QtHQ)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(H && n >= 2, "mispec_hess_qr_lanes_host: bad argument");
+        gen_sweep_host_lanes(n, H, 0, shift, 0.0, Q, QtHQ);
+    });
+}
+extern "C" int mispec_double_shift_qr_lanes_host(int n, const double* H, double s, double t, double* Q, double* QtHQ)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(H && n >= 3, "mispec_double_shift_qr_lanes_host: bad argument");
+        gen_sweep_host_lanes(n, H, 1, s, t, Q, QtHQ);
+    });
+}
 
 // ---- stand-alone unit-test entry points (mirror test/QR.cpp "QR of real tridiagonal matrix" and
 // ---- test/Eigen.cpp "Eigen decomposition of symmetric real tridiagonal matrix") ---------------------

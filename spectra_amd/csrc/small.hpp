@@ -18,4 +18,16 @@ void launch_tridiag_eigen(const mispec_ctx& ctx, int n, const double* diag, cons
 void launch_restart_sym(const mispec_ctx& ctx, int m, double* diag, double* subd, const double* shifts_host, int nshift,
                         double* Q);
 
+// General (Hessenberg) restart on the device (a19): a list of shifts applied to the m x m Hessenberg H (device, in/out,
+// leading dimension m), accumulating Q (m x m, written).  kind 0: one real shift `a` (UpperHessenbergQR); kind 1: a
+// conjugate pair as the double shift (s, t) = (a, b) (DoubleShiftQR).  One wavefront, H and Q resident in LDS: m <= kMaxGenDim.
+constexpr int kMaxGenDim = 96;  // LDS: 2 m (m|1) + 3 m doubles + (2m+2) ints <= 160 KiB
+struct GenShiftList
+{
+    int count;
+    int kind[kMaxShifts];
+    double a[kMaxShifts], b[kMaxShifts];
+};
+void launch_restart_gen(const mispec_ctx& ctx, int m, double* H, const GenShiftList& shifts, double* Q);
+
 }  // namespace mispec

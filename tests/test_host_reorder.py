@@ -1,0 +1,64 @@
+"""Host logic of the symmetric reordering (spectra_amd/csrc/reorder.hip) through the C ABI — no device needed.
+
+Integer work: the ordering is checked exactly (a permutation; deterministic), its effect through the bandwidth it yields."""
+import numpy as np
+import scipy.sparse as sp
+
+import spectra_amd as sa
+
+
+def stencil7(m):
+    I = sp.identity(m, format="csr")
+    T = sp.diags([np.ones(m - 1), np.ones(m - 1)], [-1, 1], format="csr")
+    A = sp.kron(sp.kron(T, I), I) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(I, I), T) + 6 * sp.identity(m ** 3)
+    return A.tocsr()
+
+
+def bandwidth(M):
+    c = M.tocoo()
+    return int(np.abs(c.row - c.col).max())
+
+
+def test_rcm_recovers_the_band_of_a_shuffled_stencil():
+    m = 24
+    A = stencil7(m)
+    n = A.shape[0]
+    p = np.random.default_rng(0).permutation(n)
+    B = A[p][:, p].tocsr()
+    B.sort_indices()
+    assert bandwidth(B) > n // 2
+    perm, gave_up, widest = sa.rcm_order(B.indptr, B.indices, True)
+    assert not gave_up and sorted(perm.tolist()) == list(range(n))
+    C = B[perm][:, perm]
+    assert bandwidth(C) <= 2 * m * m          # a plane of the grid (natural order: m*m)
+    assert widest <= 2 * m * m
+    # deterministic, and the general-pattern path (A + A') gives the same ordering for a symmetric pattern
+    perm2, _, _ = sa.rcm_order(B.indptr, B.indices, False)
+    assert np.array_equal(perm, perm2)
+    perm3, _, _ = sa.rcm_order(B.indptr, B.indices, True)
+    assert np.array_equal(perm, perm3)
+
+
+def test_rcm_handles_components_empty_rows_and_nonsymmetric_patterns():
+    # two disconnected paths, an isolated vertex, one-directional edges
+    rows = [0, 1, 2, 5, 6, 7]
+    cols = [1, 2, 3, 6, 7, 8]
+    n = 10
+    A = sp.coo_matrix((np.ones(6), (rows, cols)), shape=(n, n)).tocsr()
+    perm, gave_up, _ = sa.rcm_order(A.indptr, A.indices, False)
+    assert not gave_up and sorted(perm.tolist()) == list(range(n))
+    S = (A + A.T).tocsr()
+    assert bandwidth(S[perm][:, perm]) == 1
+    perm0, _, _ = sa.rcm_order(np.zeros(1, dtype=np.int32), np.zeros(0, dtype=np.int32), True)
+    assert len(perm0) == 0
+
+
+def test_rcm_gives_up_on_an_expander():
+    n = 20000
+    rng = np.random.default_rng(3)
+    r = np.repeat(np.arange(n), 7)
+    c = rng.integers(0, n, r.size)
+    U = sp.coo_matrix((np.ones(r.size), (r, c)), shape=(n, n)).tocsr()
+    S = (U + U.T).tocsr()
+    perm, gave_up, widest = sa.rcm_order(S.indptr, S.indices, True)
+    assert gave_up and np.array_equal(perm, np.arange(n)) and widest > n // 8
