@@ -108,7 +108,8 @@ def cpu_baseline(args, gpu_nops, gpu_nconv):
     return out
 
 
-KERNEL_OF_FORMAT = {0: "k_spmv_csr_stream<EPI, NT, 256, CODES=false>", 1: "k_spmv_csr_stream<EPI, NT, 256, CODES=true>", 2: "k_spmv_dia_win / k_spmv_dia"}
+KERNEL_OF_FORMAT = {0: "k_spmv_csr_stream<EPI, NT, 256, CODES=false>", 1: "k_spmv_csr_stream<EPI, NT, 256, CODES=true>", 2: "k_spmv_dia_win / k_spmv_dia",
+                    3: "k_spmv_tiles (column-blocked tiles, segment sums in LDS)"}
 
 
 def pmc_traffic(n, fmt):
@@ -204,7 +205,9 @@ def secondary_configs(args, ctx, op, sa):
     t0 = time.perf_counter()
     A = m_rand_host(args.n)
     t_gen = time.perf_counter() - t0
+    t0 = time.perf_counter()
     rop = sa.SparseSymMatProd(sp.tril(A).tocsc(), ctx=ctx)
+    t_ingest = time.perf_counter() - t0
     alone = standalone_ms(rop, args.n, 20)
     e = sa.SymEigsSolver(rop, args.nev, args.ncv)
     e.profile(2)
@@ -215,8 +218,12 @@ def secondary_configs(args, ctx, op, sa):
     dt = time.perf_counter() - t0
     p = e.get_profile()
     inloop = spmv_block(rop, p["ms_spmv"] / max(p["n_spmv"], 1), p["n_spmv"], True)
-    out["m_rand"] = {"n": args.n, "nnz": rop.nnz(), "spmv_format": rop.spmv_format(), "reordering": rop.reordering() if hasattr(rop, "reordering") else "none",
-                     "standalone": spmv_block(rop, alone, 20, False), "in_loop": inloop,
+    rop.set_spmv_format(0)
+    csr_alone = spmv_block(rop, standalone_ms(rop, args.n, 10), 10, False)
+    rop.set_spmv_format(-1)
+    out["m_rand"] = {"n": args.n, "nnz": rop.nnz(), "spmv_format": rop.spmv_format(), "reordering": rop.reordering(),
+                     "standalone": spmv_block(rop, alone, 20, False), "in_loop": inloop, "standalone_csr_int32_kernel": csr_alone,
+                     "ingest_seconds": t_ingest,
                      "solve_12_restarts": {"seconds": dt, "nconv": int(nconv), "num_operations": int(e.num_operations())},
                      "host_generation_seconds": t_gen}
     del e, rop, A

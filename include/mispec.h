@@ -125,8 +125,11 @@ int mispec_csr_offset_codes(const mispec_csr* A);
 int mispec_csr_use_offset_codes(mispec_csr* A, int enable);
 /* Storage format the SpMV uses for this shard: 0 = CSR with int32 column indices, 1 = CSR with offset codes, 2 = diagonal
  * storage (values kept diagonal-major, no index and no gather; chosen when the dictionary has <= 32 diagonals that are
- * at least 3/4 full, rows sorted, no duplicate entries; MISPEC_SPMV_DIA=0 turns it off).  All three give bit-identical
- * products for finite x (the diagonal format multiplies x by explicit zeros where the matrix has no entry).
+ * at least 3/4 full, rows sorted, no duplicate entries; MISPEC_SPMV_DIA=0 turns it off), 3 = column-blocked tiles (built at
+ * ingest for unsharded matrices with more than a quarter of their entries further than 131072 columns from the diagonal
+ * that reordering did not localise: 4096-row segments x 131072-column blocks, the segment's sums in LDS, x reused through
+ * the L2; MISPEC_SPMV_TILES=0 turns it off, =1 builds it for any matrix).  All give bit-identical products for finite x
+ * (the diagonal format multiplies x by explicit zeros where the matrix has no entry).
  * mispec_csr_set_spmv_format forces a format for this matrix (-1 = automatic; a format that was not built falls back). */
 int mispec_csr_spmv_format(const mispec_csr* A);
 int mispec_csr_set_spmv_format(mispec_csr* A, int format);
@@ -160,6 +163,11 @@ int mispec_spmm_host(const mispec_csr* A, const double* X_host, int64_t ldx, int
 int mispec_csr_reorder(mispec_csr* A, int method, int* applied);
 int mispec_csr_reordering(const mispec_csr* A, double* far_before, double* far_after);
 int mispec_csr_permutation(const mispec_csr* A, int32_t* perm_out);
+/* Host image of the tile format and its summation order, for tests (no device needed): y = A x through the tiles of an
+ * nrows x ncols CSR matrix; *built = 0 when the format does not apply (a row with more than 7 entries inside one column
+ * block, unsorted rows).  stats (optional): entries incl. padding, padding entries, chunks. */
+int mispec_tiles_spmv_host(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* colind, const double* val,
+                           const double* x, double* y, int* built, int64_t* stats);
 /* The ordering alone, on host arrays (no device needed): perm_out[new] = old for the pattern of an n x n CSR matrix;
  * *gave_up = 1 (identity returned) when the first breadth-first level structure is too wide for any ordering to help. */
 int mispec_rcm_order(int64_t n, const int32_t* rowptr, const int32_t* colind, int symmetric_pattern, int32_t* perm_out,

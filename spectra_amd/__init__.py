@@ -62,6 +62,18 @@ def _ip(a):
     return a.ctypes.data_as(C.POINTER(C.c_int32)) if a is not None else None
 
 
+def tiles_spmv_host(mat, x):
+    """y = A x through the HOST image of the column-blocked tile format, in the kernel's summation order (mispec_tiles_spmv_host;
+    no device needed).  mat: scipy CSR with sorted rows.  Returns (y or None when the format does not apply, stats dict)."""
+    rp, ci, v = _i32(mat.indptr), _i32(mat.indices), _f64(mat.data)
+    x = _f64(x)
+    y = np.zeros(mat.shape[0])
+    built = C.c_int(0)
+    st = (C.c_int64 * 3)()
+    check(lib().mispec_tiles_spmv_host(mat.shape[0], mat.shape[1], _ip(rp), _ip(ci), _dp(v), _dp(x), _dp(y), C.byref(built), st))
+    return (y if built.value else None), {"entries": st[0], "padding": st[1], "chunks": st[2]}
+
+
 def rcm_order(rowptr, colind, symmetric_pattern=True):
     """Reverse Cuthill-McKee ordering of an n x n CSR pattern on the host (mispec_rcm_order; no device needed).
     Returns (perm with perm[new] = old, gave_up, widest_level)."""

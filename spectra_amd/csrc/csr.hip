@@ -272,7 +272,7 @@ constexpr int kDiaGroup = 8;     // loads issued together per thread: 8 values +
 // sum would not be the CSR row sum bit for bit: such matrices raise *bad and keep the CSR kernels.
 __global__ __launch_bounds__(256) void k_build_dia(const int32_t* __restrict__ rowptr, const uint8_t* __restrict__ codes,
                                                    const double* __restrict__ val, const int32_t* __restrict__ pos_of_code,
-                                                   int64_t nloc, int64_t ld, double* __restrict__ dia, int* __restrict__ bad)
+                                                   int64_t nloc, int64_t ld, double* __restrict__ dia, int* __restrict__ bad, int nd_blocked)
 {
     const int64_t r = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (r >= nloc)
@@ -284,7 +284,11 @@ __global__ __launch_bounds__(256) void k_build_dia(const int32_t* __restrict__ r
         if (pos <= last)
             *bad = 1;
         last = pos;
-        dia[int64_t(pos) * ld + r] = val[p];
+        // nd_blocked > 0: the values of a 256-row block are one contiguous [nd][256] piece (one stream per workgroup)
+        if (nd_blocked)
+            dia[(int64_t(blockIdx.x) * nd_blocked + pos) * 256 + threadIdx.x] = val[p];
+        else
+            dia[int64_t(pos) * ld + r] = val[p];
     }
 }
 
@@ -300,11 +304,22 @@ struct DiaArgs
 {
     const double* dia;
     const int32_t* off;
-    int64_t ld;
+    int64_t ld;       // diagonal-major layout: dia[k * ld + r]; 0: block layout dia[(block * nd + k) * 256 + r % 256]
     int nd;
     int col_max;
     int64_t row_begin;
 };
+// start of thread t's column of values in row-block lb and the stride between consecutive diagonals
+__device__ __forceinline__ const double* dia_row(const DiaArgs& da, int lb, int t, int64_t& stride)
+{
+    if (da.ld == 0)
+    {
+        stride = 256;
+        return da.dia + int64_t(lb) * da.nd * 256 + t;
+    }
+    stride = da.ld;
+    return da.dia + int64_t(lb) * 256 + t;
+}
 
 template <bool EPI>
 __global__ __launch_bounds__(256) void k_spmv_dia(DiaArgs da, const double* __restrict__ x, double* __restrict__ y, int64_t nrows,
@@ -327,7 +342,8 @@ __global__ __launch_bounds__(256) void k_spmv_dia(DiaArgs da, const double* __re
     const int64_t row0 = int64_t(lb) * 256;
     const int nr = int(min(int64_t(256), nrows - row0));
     const int64_t r = row0 + min(tid, nr - 1);  // threads past the last row repeat it (their result is dropped)
-    const double* vrow = da.dia + r;
+    int64_t vstride;
+    const double* vrow = dia_row(da, lb, min(tid, nr - 1), vstride);
     const int64_t grow = da.row_begin + r;
     double acc = 0.0;
     for (int g = 0; g < da.nd; g += kDiaGroup)
@@ -337,7 +353,7 @@ __global__ __launch_bounds__(256) void k_spmv_dia(DiaArgs da, const double* __re
         for (int u = 0; u < kDiaGroup; u++)
         {
             const int d = min(g + u, da.nd - 1);
-            v[u] = __builtin_nontemporal_load(vrow + int64_t(d) * da.ld);  // read once per SpMV
+            v[u] = __builtin_nontemporal_load(vrow + int64_t(d) * vstride);  // read once per SpMV
             const int64_t c = grow + off_s[d];
             xv[u] = x[min(max(c, int64_t(0)), int64_t(da.col_max))];  // out of range only where the value is a padding zero
         }
@@ -384,11 +400,12 @@ __global__ __launch_bounds__(256) void k_spmv_dia_win(DiaArgs da, mispec_dia_win
     const int tid = threadIdx.x;
     const int64_t row0 = int64_t(lb) * 256;
     const int nr = int(min(int64_t(256), nrows - row0));
-    const double* vrow = da.dia + row0 + min(tid, nr - 1);
+    int64_t vstride;
+    const double* vrow = dia_row(da, lb, min(tid, nr - 1), vstride);
     double v[NG * kDiaGroup];
 #pragma unroll
     for (int k = 0; k < NG * kDiaGroup; k++)
-        v[k] = __builtin_nontemporal_load(vrow + int64_t(min(k, da.nd - 1)) * da.ld);
+        v[k] = __builtin_nontemporal_load(vrow + int64_t(min(k, da.nd - 1)) * vstride);
     const int64_t g0 = da.row_begin + row0;
     for (int c = 0; c < w.nc; c++)
         for (int i = tid; i < w.len[c]; i += 256)
@@ -564,7 +581,10 @@ void build_dia(mispec_csr& A, const std::vector<int32_t>& dict)
         pos[size_t(order[size_t(k)])] = k;
         offs[size_t(k)] = dict[size_t(order[size_t(k)])];
     }
-    const int64_t ld = round_up(nloc, 2);
+    // MISPEC_DIA_LAYOUT=block (default): the values of a 256-row block are stored as one contiguous [nd][256] piece, so a
+    // workgroup streams ONE 30 KB run instead of nd runs of 2 KB that are 80 MB apart; =diagonal keeps dia[k][row]
+    static const bool blocked = !(getenv("MISPEC_DIA_LAYOUT") && std::strcmp(getenv("MISPEC_DIA_LAYOUT"), "diagonal") == 0);
+    const int64_t ld = blocked ? round_up(nloc, 256) : round_up(nloc, 2);
     DevBuf<int32_t> d_pos;
     DevBuf<int> d_bad;
     d_pos.alloc(size_t(nd));
@@ -577,7 +597,7 @@ void build_dia(mispec_csr& A, const std::vector<int32_t>& dict)
     MISPEC_HIP(hipMemcpyAsync(d_pos.p, pos.data(), pos.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     MISPEC_HIP(hipMemcpyAsync(A.dia_off.p, offs.data(), offs.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_build_dia, dim3(unsigned((nloc + 255) / 256)), dim3(256), 0, st, A.rowptr.p, A.codes.p, A.val.p, d_pos.p, nloc, ld,
-                       A.dia.p, d_bad.p);
+                       A.dia.p, d_bad.p, blocked ? nd : 0);
     MISPEC_HIP(hipGetLastError());
     int bad = 0;
     MISPEC_HIP(hipMemcpyAsync(&bad, d_bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -588,7 +608,7 @@ void build_dia(mispec_csr& A, const std::vector<int32_t>& dict)
         A.dia_off.release();
         return;
     }
-    A.dia_ld = ld;
+    A.dia_ld = blocked ? 0 : ld;
     A.ndia = nd;
     // x windows: consecutive sorted offsets share a window while it stays within 256 + 256 entries
     mispec_dia_windows w;
@@ -711,6 +731,10 @@ mispec_csr* upload_rows(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const i
         // MISPEC_REORDER = auto (default) | rcm | none: an unsharded square matrix whose gathers are scattered (more than a
         // quarter of the entries further than kFarWindow from the diagonal, and x larger than an L2 slice) is reordered
         // at ingest when reverse Cuthill-McKee localises them (reorder.hip)
+        // MISPEC_SPMV_TILES = auto (default) | 0 | 1: the column-blocked tile format for scattered patterns that stay
+        // scattered (decided below, after the reordering attempt)
+        const char* tmode = getenv("MISPEC_SPMV_TILES");
+        const bool tiles_off = tmode && std::strcmp(tmode, "0") == 0, tiles_force = tmode && std::strcmp(tmode, "1") == 0;
         const char* mode = getenv("MISPEC_REORDER");
         const bool off = mode && std::strcmp(mode, "none") == 0;
         const bool force = mode && std::strcmp(mode, "rcm") == 0;
@@ -719,6 +743,17 @@ mispec_csr* upload_rows(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const i
             A->far_before = far_fraction(n_rows, rowptr, colind, nullptr, kFarWindow);
             if (force || (n_rows >= 2 * kFarWindow && A->far_before > 0.25))
                 reorder_matrix(*A, rowptr, colind, val, force);
+        }
+        if (!A->reordered() && !tiles_off && ctx->world() == 1 && ctx->comm.allgather == nullptr && p1 > p0 && spmv_rows_per_block() == 256)
+        {
+            const double far = (allow_reorder && !off && n_rows == n_cols) ? A->far_before : far_fraction(n_rows, rowptr, colind, nullptr, kFarWindow);
+            A->far_before = far;
+            if (tiles_force || (n_cols >= 2 * kFarWindow && far > 0.25))
+            {
+                HostTiles H;
+                if (build_tiles(n_rows, n_cols, rowptr, colind, val, H))
+                    upload_tiles(H, ctx->stream, A->tiles);
+            }
         }
     }
     catch (...)
@@ -763,6 +798,7 @@ bool reorder_matrix(mispec_csr& A, const int32_t* rowptr, const int32_t* colind,
     std::swap(A.dia_ld, B->dia_ld);
     std::swap(A.ndia, B->ndia);
     std::swap(A.dia_win, B->dia_win);
+    A.tiles.swap(B->tiles);
     A.nnz = B->nnz;
     A.perm.alloc(size_t(n));
     MISPEC_HIP(hipMemcpy(A.perm.p, perm.data(), size_t(n) * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -877,6 +913,11 @@ void launch_spmv_raw(const mispec_csr& A, const double* x_dev, double* y_dev, co
     const int format = A.spmv_format();
     const bool coded = format == 1;
     const SpmvCodes cd{A.codes.p, A.dict.p, A.ndict, int(A.n_cols - 1), A.row_begin};
+    if (format == 3)
+    {
+        launch_spmv_tiles(A.tiles, A.ctx->stream, x_dev, y_dev, nloc, nblocks, epi, ev_start, ev_stop);
+        return;
+    }
     if (format == 2)
     {
         const DiaArgs da{A.dia.p, A.dia_off.p, A.dia_ld, A.ndia, int(A.n_cols - 1), A.row_begin};
@@ -1187,7 +1228,14 @@ int mispec_csr::spmv_format() const
     const bool blocks256 = spmv_rows_per_block() == 256;
     const bool can_codes = ndict > 0 && blocks256 && spmv_codes_enabled();
     const bool can_dia = ndia > 0 && blocks256;
-    if (forced_format == 0 || !use_codes)
+    const bool can_tiles = tiles.present() && blocks256;
+    if (forced_format == 3)
+        return can_tiles ? 3 : 0;
+    if (forced_format == 0)
+        return 0;
+    if (forced_format == -1 && can_tiles)
+        return 3;  // built only when the pattern asked for it
+    if (!use_codes)
         return 0;
     if (forced_format == 1)
         return can_codes ? 1 : 0;
@@ -1204,7 +1252,7 @@ extern "C" int mispec_csr_spmv_format(const mispec_csr* A) { return A ? A->spmv_
 extern "C" int mispec_csr_set_spmv_format(mispec_csr* A, int format)
 {
     return guarded([&] {
-        MISPEC_REQUIRE(A && format >= -1 && format <= 2, "mispec_csr_set_spmv_format: format must be -1 (automatic), 0, 1 or 2");
+        MISPEC_REQUIRE(A && format >= -1 && format <= 3, "mispec_csr_set_spmv_format: format must be -1 (automatic), 0, 1, 2 or 3");
         A->forced_format = format;
     });
 }

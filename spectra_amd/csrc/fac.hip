@@ -82,6 +82,7 @@ struct mispec_fac
 
     DevBuf<double> mid;  // product operator: A x
     DevBuf<double> bx;
+    DevBuf<double> V2;   // second basis buffer of the out-of-place V <- V Q (MISPEC_VQ_OOP=1)
     DevBuf<double> V, f, w, tmp, xfull, X, partials, alpha_partials, red, Qdev, d_diag, d_subd, d_evals, d_evecs, d_Y, gmax;
     DevBuf<int> d_info;
     DevBuf<StepState> d_state;     // device-driven step bookkeeping (krylov.hpp)
@@ -1101,6 +1102,20 @@ void compress_basis(mispec_fac& F, int p)
     const int m = F.m;
     if (m <= kPanelCols)
     {
+        // MISPEC_VQ_OOP=1: write V Q into a second basis buffer and swap the two (the columns beyond p are rewritten by the
+        // factorisation before anything reads them) instead of updating V in place — reads and writes then never share a line
+        static const bool oop = getenv("MISPEC_VQ_OOP") && atoi(getenv("MISPEC_VQ_OOP")) != 0;
+        if (oop)
+        {
+            if (F.V2.n != F.V.n)
+            {
+                F.V2.alloc(F.V.n);
+                MISPEC_HIP(hipMemsetAsync(F.V2.p, 0, F.V2.n * sizeof(double), F.stream()));
+            }
+            launch_vq(*F.ctx, F.V.p, F.ldv, m, F.Qdev.p, m, p, F.V2.p, F.ldv, F.nloc);
+            F.V.swap(F.V2);
+            return;
+        }
         launch_vq(*F.ctx, F.V.p, F.ldv, m, F.Qdev.p, m, p, F.V.p, F.ldv, F.nloc);
         return;
     }

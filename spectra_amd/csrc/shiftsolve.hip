@@ -274,12 +274,20 @@ __global__ __launch_bounds__(kChunkThreads) void k_chunk_factor(int64_t N, int b
             for (int d = 0; d < B; d++)
                 if (d < dk)
                     dv -= lrow[d] * lrow[d] * Dw[d];
-            // stats[1]: smallest |pivot| seen (bit pattern of a non-negative double orders like an integer)
-            minpiv = fmin(minpiv, fabs(dv));
-            if (!(fabs(dv) > tiny))
+            // A pivot that is tiny RELATIVE TO ITS OWN ROW of the matrix (levels below the first mix magnitudes: Schur
+            // complements next to an ill-conditioned chunk are huge) is boosted; `tiny` is the relative threshold.
+            double rowmax = fabs(mrow[0]);
+#pragma unroll
+            for (int d = 0; d < B; d++)
+                if (d < dk)
+                    rowmax = fmax(rowmax, fabs(mrow[d + 1]));
+            // stats[1]: smallest |pivot| / row scale seen (bit pattern of a non-negative double orders like an integer)
+            const double thr = tiny * rowmax + 1e-300;
+            minpiv = fmin(minpiv, rowmax > 0.0 ? fabs(dv) / rowmax : 0.0);
+            if (!(fabs(dv) > thr))
             {
                 atomicAdd(&stats[0], 1ull);  // boosted pivots
-                dv = (dv < 0.0) ? -tiny : tiny;
+                dv = (dv < 0.0) ? -thr : thr;
             }
             Dinv[k * P + p] = 1.0 / dv;
 #pragma unroll
@@ -452,7 +460,7 @@ void band_lu_inverse(const HostBand& M, std::vector<double>& inv)
                 best = std::fabs(at(i, k));
                 pr = i;
             }
-        if (!(best > scale * 1e-15))
+        if (!(best > 0.0))  // exactly singular (or NaN); anything else is judged by the calibration of the refinement
             throw Error(MISPEC_EINVAL, "SparseSymShiftSolve: factorization failed with the given shift");
         piv[size_t(k)] = pr;
         if (pr != k)
@@ -633,8 +641,9 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
     double scale = 0.0;
     for (int64_t i = 0; i < N; i++)
         scale = std::max(scale, std::fabs(static_cast<const HostBand&>(M).at(i, 0)));
-    // pivots at or below `tiny` are boosted to +-tiny (sqrt(eps) * scale): see the header comment
-    const double tiny = scale * 1.4901161193847656e-08 + 1e-300;
+    // pivots at or below tiny * (largest entry of their matrix row) are boosted to that magnitude: see the header comment
+    const double tiny = 1.4901161193847656e-08;  // sqrt(eps)
+    (void) scale;
 
     const bool on_device = factored_on_device(N, b);
     MISPEC_REQUIRE(on_device || !M.view, "internal: a band view is only valid for a level factored on the device");
@@ -703,8 +712,7 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
             double minpiv;
             std::memcpy(&minpiv, &hstats[1], sizeof(double));
             stats.boosts += (long long) hstats[0];
-            if (scale > 0.0)
-                stats.min_pivot_ratio = std::min(stats.min_pivot_ratio, minpiv / scale);
+            stats.min_pivot_ratio = std::min(stats.min_pivot_ratio, minpiv);
         }
         for (int64_t p = 0; p < P; p++)
             for (int side1 = 0; side1 < 2; side1++)
@@ -774,12 +782,15 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
             double dv = M.at(row0 + k, 0);
             for (int d = 0; d < dk; d++)
                 dv -= Lc[size_t(k) * b + d] * Lc[size_t(k) * b + d] * D[size_t(k - d - 1)];
-            if (scale > 0.0)
-                stats.min_pivot_ratio = std::min(stats.min_pivot_ratio, std::fabs(dv) / scale);
-            if (!(std::fabs(dv) > tiny))
+            double rowmax = std::fabs(M.at(row0 + k, 0));
+            for (int d = 0; d < dk; d++)
+                rowmax = std::max(rowmax, std::fabs(M.at(row0 + k, d + 1)));
+            const double thr = tiny * rowmax + 1e-300;
+            stats.min_pivot_ratio = std::min(stats.min_pivot_ratio, rowmax > 0.0 ? std::fabs(dv) / rowmax : 0.0);
+            if (!(std::fabs(dv) > thr))
             {
                 stats.boosts++;
-                dv = (dv < 0.0) ? -tiny : tiny;
+                dv = (dv < 0.0) ? -thr : thr;
             }
             D[size_t(k)] = dv;
         }
@@ -1085,7 +1096,7 @@ void calibrate_refinement(mispec_symshift& S, const FactorStats& fs)
     MISPEC_HIP(hipGetLastError());
     solve_level(*S.ctx, *S.top, px.p, py.p);
     const unsigned grid = unsigned(std::min<int64_t>((n + kThreads - 1) / kThreads, 1024));
-    constexpr int kMaxRefine = 8;
+    constexpr int kMaxRefine = 12;
     constexpr double kTarget = 4.0e-15;  // a few eps: what a backward-stable solve of a band matrix gives
     double omega = 0.0, prev = 1e300;
     for (int it = 0;; it++)
@@ -1111,9 +1122,9 @@ void calibrate_refinement(mispec_symshift& S, const FactorStats& fs)
             break;
         if (it == kMaxRefine || (it >= 2 && omega > 0.5 * prev))
         {
-            // stagnation: accept when the probe is still solved to 1e-12 (the error then sits below the eigensolver's
+            // stagnation: accept when the probe is still solved to 1e-13 (the error then sits below the eigensolver's
             // tolerances), otherwise the shift is (numerically) singular for this factorisation
-            if (omega <= 1e-12)
+            if (omega <= 1e-13)
                 break;
             throw_singular();
         }

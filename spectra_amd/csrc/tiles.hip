@@ -1,0 +1,391 @@
+// Column-blocked SpMV for scattered sparsity patterns (SURVEY.md 8d "M-rand"; north_star's CSR SpMV must hold up on any
+// pattern the reference's operators accept: MatOp/SparseSymMatProd.h:83-88, SparseGenMatProd.h:82-87).
+//
+// Why.  A CSR row sweep over a matrix with uniformly scattered columns issues one 8-byte gather per entry into an 80 MB
+// vector; every gather misses the 4 MiB per-XCD L2 and drags a 128-byte line through the fabric: 16x read amplification,
+// 0.10 of the HBM roofline (profiles/r01g_spmv_patterns.jsonl).  No symmetric reordering helps an expander.
+//
+// Layout.  The rows are cut into SEGMENTS of 4096 rows, the columns into BLOCKS of 131072 columns (1 MiB of x).  A TILE is
+// the part of a segment inside one column block; a segment stores its tiles one after the other (ascending block), every
+// entry as (fp64 value, 32-bit index) = 12 bytes like CSR with int32 indices, the index packing the row inside the segment
+// (12 bits), the column inside the block (17 bits) and the length of the row's run inside the tile (3 bits).
+//
+// Kernel.  One workgroup (256 threads) per segment, the segment's 4096 partial sums in LDS.  It walks its tiles in block
+// order, so that at any moment all the workgroups resident on an XCD gather from the same one or two 1 MiB pieces of x,
+// which stay in that XCD's L2: x is read from HBM / Infinity Cache once per XCD and generation of workgroups instead of
+// once per entry.  Inside a tile the entries are sorted by row, every row's entries (ascending column) are consecutive and
+// never straddle a wavefront; the lane holding the first entry of a run collects the products of the run from its
+// neighbours (shuffles) and adds them to the row's LDS accumulator one after the other.  A row's products are therefore
+// added in ascending column order — the CSR storage order — and, rounded individually, the result is BIT-IDENTICAL to the
+// CSR kernels and to the oracle's row-dot.  One barrier per <= 1024 entries; the next chunk's entries are in flight while
+// the current one is gathered and accumulated.
+// Bound: HBM for the 12 nnz bytes of the stream + L2 for the gathers.
+#include "tiles.hpp"
+#include "csr.hpp"
+
+#include <hip/hip_ext.h>
+
+#include <algorithm>
+#include <cstring>
+
+namespace mispec {
+
+bool build_tiles(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* colind, const double* val, HostTiles& T)
+{
+    T = HostTiles{};
+    const int64_t ncb = (ncols + kTileCols - 1) / kTileCols;
+    if (ncb > 65535 || nrows <= 0)
+        return false;
+    const int64_t nseg = (nrows + kTileRows - 1) / kTileRows;
+    T.seg_entry.assign(size_t(nseg) + 1, 0);
+    T.seg_chunk.assign(size_t(nseg) + 1, 0);
+    const int64_t nnz = rowptr[nrows] - rowptr[0];
+    T.val.reserve(size_t(nnz + nnz / 32));
+    T.idx.reserve(size_t(nnz + nnz / 32));
+    std::vector<int64_t> count(static_cast<size_t>(ncb)), start(size_t(ncb) + 1);
+    std::vector<uint32_t> tidx;  // entries of the segment, bucketed by tile (row-major inside a tile)
+    std::vector<double> tval;
+    std::vector<std::pair<int64_t, int64_t>> groups;  // (first entry, length) of every row's run inside the current tile
+    for (int64_t s = 0; s < nseg; s++)
+    {
+        const int64_t r0 = s * kTileRows, r1 = std::min<int64_t>(r0 + kTileRows, nrows);
+        std::fill(count.begin(), count.end(), 0);
+        for (int64_t r = r0; r < r1; r++)
+            for (int32_t p = rowptr[r]; p < rowptr[r + 1]; p++)
+            {
+                if (p > rowptr[r] && colind[p] <= colind[p - 1])
+                    return false;  // unsorted row or duplicate entry: the run order would not be the CSR order
+                count[size_t(colind[p] >> kTileColBits)]++;
+            }
+        start[0] = 0;
+        for (int64_t c = 0; c < ncb; c++)
+            start[size_t(c) + 1] = start[size_t(c)] + count[size_t(c)];
+        const int64_t seg_nnz = start[size_t(ncb)];
+        tidx.resize(size_t(seg_nnz));
+        tval.resize(size_t(seg_nnz));
+        std::vector<int64_t> fill(start.begin(), start.end() - 1);
+        for (int64_t r = r0; r < r1; r++)
+        {
+            int32_t p = rowptr[r];
+            while (p < rowptr[r + 1])
+            {
+                const int64_t c = colind[p] >> kTileColBits;
+                int32_t q = p + 1;
+                while (q < rowptr[r + 1] && (colind[q] >> kTileColBits) == c)
+                    q++;
+                const int run = q - p;
+                for (int k = 0; k < run; k++)
+                {
+                    const int64_t dst = fill[size_t(c)]++;
+                    tidx[size_t(dst)] = (uint32_t(r - r0) << (kTileColBits + kTileRunBits)) |
+                                        (uint32_t(colind[p + k] & (kTileCols - 1)) << kTileRunBits);  // run bits set at emission
+                    tval[size_t(dst)] = val[p + k];
+                }
+                p = q;
+            }
+        }
+        // emit: chunks of at most kTileChunk entries of one tile; a run never straddles a 64-entry group of its chunk
+        const int64_t seg_first = int64_t(T.val.size());
+        T.seg_entry[size_t(s)] = seg_first;
+        T.seg_chunk[size_t(s)] = int32_t(T.chunks.size());
+        for (int64_t c = 0; c < ncb; c++)
+        {
+            // A row's entries inside the tile are consecutive.  Pass 0 emits the first (up to) 7 of every row, pass 1 the next
+            // 7 of the rows that have more, ... — every pass in chunks of its own, so that the barrier between chunks keeps a
+            // row's additions in column order and no two run heads of one row ever share a chunk.
+            groups.clear();
+            for (int64_t e = start[size_t(c)]; e < start[size_t(c) + 1];)
+            {
+                int64_t q = e + 1;
+                const uint32_t row = tidx[size_t(e)] >> (kTileColBits + kTileRunBits);
+                while (q < start[size_t(c) + 1] && (tidx[size_t(q)] >> (kTileColBits + kTileRunBits)) == row)
+                    q++;
+                groups.emplace_back(e, q - e);
+                e = q;
+            }
+            for (int pass = 0; !groups.empty(); pass++)
+            {
+                size_t gi = 0;
+                while (gi < groups.size())
+                {
+                    TileChunk ch;
+                    ch.offset = int32_t(int64_t(T.val.size()) - seg_first);
+                    ch.colblock = uint16_t(c);
+                    int cnt = 0;
+                    while (gi < groups.size())
+                    {
+                        const int64_t e = groups[gi].first + int64_t(pass) * kTileMaxRun;
+                        const int run = int(std::min<int64_t>(groups[gi].second - int64_t(pass) * kTileMaxRun, kTileMaxRun));
+                        const int room = 64 - (cnt & 63);
+                        int pad = 0;
+                        if (run > room)
+                        {
+                            if (cnt + room >= kTileChunk)
+                                break;  // the chunk ends here; the run opens the next one
+                            pad = room;
+                        }
+                        if (cnt + pad + run > kTileChunk)
+                            break;
+                        for (int k = 0; k < pad; k++)
+                        {
+                            T.val.push_back(0.0);
+                            T.idx.push_back(kTileSkip);
+                        }
+                        T.padding += pad;
+                        for (int k = 0; k < run; k++)
+                        {
+                            T.val.push_back(tval[size_t(e + k)]);
+                            T.idx.push_back(tidx[size_t(e + k)] | uint32_t(k == 0 ? run : 0));
+                        }
+                        cnt += pad + run;
+                        gi++;
+                    }
+                    ch.count = uint16_t(cnt);
+                    T.chunks.push_back(ch);
+                }
+                // rows with more entries than the passes so far have emitted stay for the next pass
+                size_t keep = 0;
+                for (size_t g = 0; g < groups.size(); g++)
+                    if (groups[g].second > int64_t(pass + 1) * kTileMaxRun)
+                        groups[keep++] = groups[g];
+                groups.resize(keep);
+            }
+        }
+    }
+    T.seg_entry[size_t(nseg)] = int64_t(T.val.size());
+    T.seg_chunk[size_t(nseg)] = int32_t(T.chunks.size());
+    // slack so that the kernel's unconditional 4-entry loads never leave the arrays
+    for (int k = 0; k < kTileChunk; k++)
+    {
+        T.val.push_back(0.0);
+        T.idx.push_back(kTileSkip);
+    }
+    return true;
+}
+
+void tiles_spmv_host(const HostTiles& T, int64_t nrows, const double* x, double* y)
+{
+    const int64_t nseg = int64_t(T.seg_entry.size()) - 1;
+    std::vector<double> acc(kTileRows);
+    for (int64_t s = 0; s < nseg; s++)
+    {
+        std::fill(acc.begin(), acc.end(), 0.0);
+        for (int32_t ci = T.seg_chunk[size_t(s)]; ci < T.seg_chunk[size_t(s) + 1]; ci++)
+        {
+            const TileChunk& ch = T.chunks[size_t(ci)];
+            const int64_t base = T.seg_entry[size_t(s)] + ch.offset;
+            for (int k = 0; k < ch.count; k++)
+            {
+                const uint32_t id = T.idx[size_t(base + k)];
+                if (id == kTileSkip)
+                    continue;
+                const int64_t col = int64_t(ch.colblock) * kTileCols + ((id >> kTileRunBits) & uint32_t(kTileCols - 1));
+                // continuation entries follow their head: adding in storage order IS the run order
+                const volatile double p = T.val[size_t(base + k)] * x[col];
+                acc[size_t(id >> (kTileColBits + kTileRunBits))] += p;
+            }
+        }
+        const int64_t r0 = s * kTileRows;
+        for (int64_t r = r0; r < std::min<int64_t>(r0 + kTileRows, nrows); r++)
+            y[r] = acc[size_t(r - r0)];
+    }
+}
+
+namespace {
+__device__ __forceinline__ double tile_wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_down(v, off, 64);
+    return v;
+}
+// product rounded on its own (no FMA with the accumulation): the sums are those of the CSR kernels, bit for bit
+__device__ __forceinline__ double rounded_product(double a, double b)
+{
+#pragma clang fp contract(off)
+    const double p = a * b;
+    return p;
+}
+__device__ __forceinline__ double rounded_add(double a, double b)
+{
+#pragma clang fp contract(off)
+    const double s = a + b;
+    return s;
+}
+
+template <bool EPI>
+__global__ __launch_bounds__(256) void k_spmv_tiles(const int64_t* __restrict__ seg_entry, const int32_t* __restrict__ seg_chunk,
+                                                    const TileChunk* __restrict__ chunks, const double* __restrict__ val,
+                                                    const uint32_t* __restrict__ idx, const double* __restrict__ x, double* __restrict__ y,
+                                                    int64_t nrows, int nblocks256, SpmvEpilogue epi)
+{
+    __shared__ double acc[kTileRows];  // exactly 32 KiB: five workgroups per CU
+    if (EPI && epi.status && *epi.status != 0)
+        return;
+    const int seg = blockIdx.x;
+    const int tid = threadIdx.x;
+    for (int r = tid; r < kTileRows; r += 256)
+        acc[r] = 0.0;
+    const int c0 = seg_chunk[seg], c1 = seg_chunk[seg + 1];
+    const int64_t base = seg_entry[seg];
+    constexpr int kPer = kTileChunk / 256;  // entries per thread and chunk
+    double v[kPer], nv[kPer];
+    uint32_t id[kPer], nid[kPer];
+    int off = (c0 < c1) ? chunks[c0].offset : 0;
+#pragma unroll
+    for (int k = 0; k < kPer; k++)
+    {
+        v[k] = __builtin_nontemporal_load(val + base + off + k * 256 + tid);  // streamed once: keep x in the L2
+        id[k] = __builtin_nontemporal_load(idx + base + off + k * 256 + tid);
+    }
+    __syncthreads();
+    for (int ci = c0; ci < c1; ci++)
+    {
+        const TileChunk ch = chunks[ci];
+        const int count = ch.count;
+        // the next chunk's entries follow this chunk's: issue their loads now (the arrays end with a chunk of slack)
+        const int noff = off + count;
+#pragma unroll
+        for (int k = 0; k < kPer; k++)
+        {
+            nv[k] = __builtin_nontemporal_load(val + base + noff + k * 256 + tid);
+            nid[k] = __builtin_nontemporal_load(idx + base + noff + k * 256 + tid);
+        }
+        const int64_t col0 = int64_t(ch.colblock) << kTileColBits;
+        double p[kPer];
+        int run[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; k++)
+        {
+            const bool live = (k * 256 + tid < count) && id[k] != kTileSkip;
+            run[k] = live ? int(id[k] & uint32_t(kTileMaxRun)) : 0;
+            const int64_t col = live ? col0 + int64_t((id[k] >> kTileRunBits) & uint32_t(kTileCols - 1)) : col0;
+            p[k] = live ? rounded_product(v[k], x[col]) : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < kPer; k++)
+        {
+            // head lanes add the products of their run in order: own, then the next lanes' (a run never leaves its wavefront)
+            const int row = int(id[k] >> (kTileColBits + kTileRunBits)) & (kTileRows - 1);
+            double a = (run[k] > 0) ? acc[row] : 0.0;
+            a = rounded_add(a, p[k]);
+            for (int j = 1; j < kTileMaxRun; j++)
+            {
+                if (__ballot(run[k] > j) == 0ull)
+                    break;
+                const double pj = __shfl_down(p[k], j, 64);
+                if (run[k] > j)
+                    a = rounded_add(a, pj);
+            }
+            if (run[k] > 0)
+                acc[row] = a;
+        }
+        __syncthreads();  // the next chunk may address the same rows from other lanes
+        off = noff;
+#pragma unroll
+        for (int k = 0; k < kPer; k++)
+        {
+            v[k] = nv[k];
+            id[k] = nid[k];
+        }
+    }
+    // rows of the segment -> y, in the 256-row blocks of the CSR kernels (identical alpha partial records)
+    const int64_t row0 = int64_t(seg) * kTileRows;
+#pragma unroll 1
+    for (int j = 0; j < kTileRows / 256; j++)
+    {
+        const int64_t row = row0 + j * 256 + tid;
+        const int64_t blk = row0 / 256 + j;
+        if (blk >= nblocks256)
+            break;
+        double contrib = 0.0;
+        if (row < nrows)
+        {
+            double yv = acc[j * 256 + tid];
+            if (EPI)
+            {
+                if (epi.v_prev)
+                    yv -= (epi.h_prev_dev ? *epi.h_prev_dev : epi.h_prev) * epi.v_prev[row];  // Lanczos.h:139
+                contrib = epi.v_rows[row] * yv;                                                 // Lanczos.h:142
+            }
+            y[row] = yv;
+        }
+        if (EPI)
+        {
+            // cross-wave sum through the accumulator slots of this block, which every thread has read by now
+            const double t = tile_wave_sum(contrib);
+            __syncthreads();
+            double* red = acc + j * 256;
+            if ((tid & 63) == 0)
+                red[tid >> 6] = t;
+            __syncthreads();
+            if (tid == 0)
+                epi.partials[blk] = (red[0] + red[1]) + (red[2] + red[3]);
+        }
+    }
+}
+}  // namespace
+
+void upload_tiles(const HostTiles& H, hipStream_t stream, DevTiles& D)
+{
+    auto up = [&](auto& dst, const auto& src) {
+        dst.alloc(src.size());
+        MISPEC_HIP(hipMemcpyAsync(dst.p, src.data(), src.size() * sizeof(src[0]), hipMemcpyHostToDevice, stream));
+    };
+    up(D.seg_entry, H.seg_entry);
+    up(D.seg_chunk, H.seg_chunk);
+    up(D.chunks, H.chunks);
+    up(D.val, H.val);
+    up(D.idx, H.idx);
+    MISPEC_HIP(hipStreamSynchronize(stream));
+    D.nseg = int64_t(H.seg_entry.size()) - 1;
+    D.entries = int64_t(H.val.size()) - kTileChunk;
+    D.nchunks = int64_t(H.chunks.size());
+    D.padding = H.padding;
+}
+
+void launch_spmv_tiles(const DevTiles& T, hipStream_t stream, const double* x, double* y, int64_t nrows, int nblocks256,
+                       const SpmvEpilogue* epi, hipEvent_t ev_start, hipEvent_t ev_stop)
+{
+    const dim3 grid(static_cast<unsigned>(T.nseg)), block(256);
+    const SpmvEpilogue e = epi ? *epi : SpmvEpilogue{};
+#define MISPEC_TILES(E)                                                                                                     \
+    do                                                                                                                      \
+    {                                                                                                                       \
+        if (ev_start && ev_stop)                                                                                            \
+            hipExtLaunchKernelGGL((k_spmv_tiles<E>), grid, block, 0, stream, ev_start, ev_stop, 0, T.seg_entry.p, T.seg_chunk.p, \
+                                  T.chunks.p, T.val.p, T.idx.p, x, y, nrows, nblocks256, e);                               \
+        else                                                                                                                \
+            hipLaunchKernelGGL((k_spmv_tiles<E>), grid, block, 0, stream, T.seg_entry.p, T.seg_chunk.p, T.chunks.p, T.val.p, \
+                               T.idx.p, x, y, nrows, nblocks256, e);                                                       \
+    } while (0)
+    if (epi)
+        MISPEC_TILES(true);
+    else
+        MISPEC_TILES(false);
+#undef MISPEC_TILES
+    MISPEC_HIP(hipGetLastError());
+}
+
+}  // namespace mispec
+
+// Host-only test hook (no device): builds the tiles of a CSR matrix and multiplies with them on the host in the kernel's
+// summation order.  *built = 0 when the format does not apply to this matrix.  stats: [entries incl. padding, padding, chunks]
+extern "C" int mispec_tiles_spmv_host(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* colind, const double* val,
+                                      const double* x, double* y, int* built, int64_t* stats)
+{
+    return mispec::guarded([&] {
+        MISPEC_REQUIRE(rowptr && x && y && built, "mispec_tiles_spmv_host: NULL argument");
+        mispec::HostTiles T;
+        *built = mispec::build_tiles(nrows, ncols, rowptr, colind, val, T) ? 1 : 0;
+        if (!*built)
+            return;
+        mispec::tiles_spmv_host(T, nrows, x, y);
+        if (stats)
+        {
+            stats[0] = int64_t(T.val.size()) - mispec::kTileChunk;
+            stats[1] = T.padding;
+            stats[2] = int64_t(T.chunks.size());
+        }
+    });
+}

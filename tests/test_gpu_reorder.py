@@ -125,15 +125,15 @@ def test_reordered_general_matrix(ctx):
 
 
 def test_automatic_reordering_at_ingest(ctx):
-    # 64^3 = 262144 rows = 2 * the far window: a shuffled stencil is reordered without being asked, a banded matrix and an
-    # expander are left alone
-    B = shuffled_stencil(64, seed=2)
+    # 80^3 = 512000 rows: a shuffled stencil (half of its gathers further than the far window) is reordered without being
+    # asked, a banded matrix and an expander are left alone
+    B = shuffled_stencil(80, seed=2)
     op = sa.SparseSymMatProd(sp.tril(B).tocsc(), ctx=ctx)
     info = op.reordering_info()
     assert info["method"] == "rcm" and info["far_fraction_before"] > 0.25 and info["far_fraction_after"] == 0.0
     x = np.random.default_rng(0).uniform(-1, 1, B.shape[0])
     assert np.abs(op.perform_op(x) - B @ x).max() <= 1e-13
-    band = sa.SparseSymMatProd(sp.tril(stencil7(64)).tocsc(), ctx=ctx)
+    band = sa.SparseSymMatProd(sp.tril(stencil7(80)).tocsc(), ctx=ctx)
     assert band.reordering() == "none"
     n = 300_000
     rng = np.random.default_rng(1)
