@@ -67,6 +67,9 @@ private:
     static bool is_complex(const Complex& v) { return v.imag() != RealScalar(0); }
     static bool is_conj(const Complex& a, const Complex& b) { return a == std::conj(b); }
 
+    // LIMIT of this implementation (not of the reference): the device factorisation holds at most 256 basis vectors, so a
+    // solver constructed with ncv > 256 throws std::invalid_argument from the factorisation's constructor
+    // (mispec_fac_create: "ncv <= 256"); the reference accepts any nev < ncv <= n.
     static Index check_args(Index n, Index nev, Index ncv)
     {
         if (nev < 1 || nev > n - 2)

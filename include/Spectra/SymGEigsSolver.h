@@ -10,7 +10,8 @@
 // The Lanczos process runs on y = B^{-1}(A x) with every inner product taken as x'By, so the Ritz vectors are
 // B-orthonormal eigenvectors of the pencil and need no back-transformation (SymGEigsSolver.h:224-238).
 // The **Cholesky** mode (SymGEigsSolver.h:142-208) solves the standard problem L^{-1} A L^{-T} y = lambda y with
-// B = L L' and returns x = L^{-T} y; its device B operator holds a dense factor (n <= 4096):
+// B = L L' and returns x = L^{-T} y; its device B operator holds a dense factor (n <= 4096) or, for a banded B of any
+// size, the partitioned band factor:
 //
 //     SparseCholesky<double> Bop(B);
 //     SymGEigsSolver<SparseSymMatProd<double>, SparseCholesky<double>, GEigsMode::Cholesky> geigs(op, Bop, nev, ncv);

@@ -276,9 +276,11 @@ int64_t mispec_reginv_last_iterations(const mispec_reginv* B);                  
  * ArnoldiOp.h:68-101): every dot product / norm / V'f of Lanczos.h is taken as x'By.  Single GPU. */
 int mispec_fac_create_geigs_reginv(mispec_ctx* ctx, const mispec_csr* A, const mispec_reginv* B, int ncv, mispec_fac** out);
 
-/* Cholesky mode (SymGEigsSolver.h:142-208 with MatOp/SparseCholesky.h:36-128): B = L L' factored once (dense factor,
- * n <= 4096), the triangular solves y = L^{-1} x / y = L^{-T} x as GEMVs with the explicit inverse factor in HBM;
- * the operator of the standard problem is L^{-1} A L^{-T}.  mispec_cholesky_info: 0 = Successful, 3 = NumericalIssue
+/* Cholesky mode (SymGEigsSolver.h:142-208 with MatOp/SparseCholesky.h:36-128): B = G G' factored once — n <= 4096: dense
+ * Cholesky factor, the triangular solves y = G^{-1} x / y = G^{-T} x as GEMVs with the explicit inverse factor in HBM;
+ * n > 4096: B must be banded (half-bandwidth <= 8) and G is the factor of the partitioned band factorisation in its nested
+ * order, the two solves being the two halves of the device band solve; other large patterns are rejected (MISPEC_EINVAL:
+ * use the regular-inverse mode).  The operator of the standard problem is G^{-1} A G^{-T}.  mispec_cholesky_info: 0 = Successful, 3 = NumericalIssue
  * (B not positive definite), as SparseCholesky::info(). */
 typedef struct mispec_cholesky mispec_cholesky;
 int mispec_cholesky_create(mispec_ctx* ctx, int64_t n, const int32_t* outer_host, const int32_t* inner_host,
@@ -317,6 +319,10 @@ int mispec_fac_f_norm(const mispec_fac* fac, double* beta);  /* f_norm() */
  * parts of the other ranks' slices are exchanged point-to-point (recv_doubles of them per product), 0 if the
  * full all-gather is used (or the context is not sharded). */
 int mispec_fac_exchange_info(const mispec_fac* fac, int* halo, int64_t* recv_doubles);
+/* Overlap of the exchange with the product on a row shard: the 256-row blocks [first_block, first_block + block_count) read
+ * only the rank's own slice of the vector and are multiplied while the exchange is in flight on a second stream; the
+ * others follow when it has landed.  block_count = 0: no overlap (unsharded, MISPEC_OVERLAP=0, or too few such blocks). */
+int mispec_fac_overlap_info(const mispec_fac* fac, int* first_block, int* block_count, int* total_blocks);
 int mispec_fac_get_H(const mispec_fac* fac, double* H_host); /* matrix_H(), ncv x ncv col-major */
 int mispec_fac_set_H(mispec_fac* fac, const double* H_host, int k); /* after a host-side compress_H */
 /* matrix_V().leftCols(ncols) / vector_f() of this shard to host (ld = local_rows). */
@@ -448,6 +454,7 @@ int mispec_symeigs_eigenvectors(mispec_symeigs* s, int64_t nvec, double* out_hos
 int mispec_symeigs_residuals(mispec_symeigs* s, double* resid_host, int64_t* count);
 int mispec_symeigs_get_profile(const mispec_symeigs* s, mispec_profile* out);
 int mispec_symeigs_exchange_info(const mispec_symeigs* s, int* halo, int64_t* recv_doubles); /* see mispec_fac_exchange_info */
+int mispec_symeigs_overlap_info(const mispec_symeigs* s, int* first_block, int* block_count, int* total_blocks);
 int mispec_symeigs_profile(mispec_symeigs* s, int enable);
 
 /* ---------------------------------------------------------------------------

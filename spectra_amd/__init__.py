@@ -532,8 +532,9 @@ class _UserOp:
 
 
 class SparseCholesky:
-    """MatOp/SparseCholesky.h: B = L L' (dense factor on the GPU, n <= 4096); lower_triangular_solve = L^{-1} x,
-    upper_triangular_solve = L^{-T} x; info() like the reference (NumericalIssue when B is not positive definite)."""
+    """MatOp/SparseCholesky.h: B = G G' (dense factor on the GPU for n <= 4096, the partitioned band factorisation for a
+    larger banded B); lower_triangular_solve = G^{-1} x, upper_triangular_solve = G^{-T} x; info() like the reference
+    (NumericalIssue when B is not positive definite)."""
 
     def __init__(self, mat, uplo="L", ctx=None):
         self.ctx = ctx or default_context()
@@ -840,6 +841,12 @@ class SymEigsSolver:
         p = Profile()
         check(lib().mispec_symeigs_get_profile(self.h, C.byref(p)))
         return p.as_dict()
+
+    def overlap_info(self):
+        """(first interior 256-row block, interior blocks, all blocks): what is multiplied while the exchange is in flight."""
+        a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+        check(lib().mispec_symeigs_overlap_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def exchange_info(self):
         """(halo, doubles received per product): how a sharded matrix moves the Krylov vector (mispec_fac_exchange_info)."""

@@ -190,6 +190,8 @@ SIGNATURES = {
     "mispec_symeigs_residuals": (C.c_int, [_vp, _dp, _lp]),
     "mispec_symeigs_get_profile": (C.c_int, [_vp, C.POINTER(Profile)]),
     "mispec_symeigs_exchange_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    "mispec_symeigs_overlap_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mispec_fac_overlap_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mispec_symeigs_profile": (C.c_int, [_vp, C.c_int]),
     "mispec_geneigs_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vpp]),
     "mispec_geneigs_create_op": (C.c_int, [_vp, op_fn, _vp, C.c_int64, C.c_int64, C.c_int64, _vpp]),

@@ -3,8 +3,11 @@
 // The generalized problem A x = lambda B x becomes the standard one L^{-1} A L^{-T} y = lambda y, x = L^{-T} y
 // (SymGEigsSolver.h:142-208, MatOp/internal/SymGEigsCholeskyOp.h:63-71).  Any factor G with G G' = B gives the
 // same eigenpairs; here G = L is the dense Cholesky factor (no fill-reducing permutation), computed once on the
-// host, and the two triangular solves are dense GEMVs with the explicit L^{-1} / L^{-T} held in HBM — so the path
-// is limited to n <= 4096; larger sparse B go through the regular-inverse mode (conjugate gradient).
+// host, and the two triangular solves are dense GEMVs with the explicit L^{-1} / L^{-T} held in HBM (n <= 4096).
+// Larger B must be BANDED (half-bandwidth <= 8, the usual mass / stiffness matrices of 1-D and structured problems): the
+// factor is then the one of the partitioned band factorisation of shiftsolve.hip in its nested order (chunk interiors, then
+// separators, recursively) — G = [L_II D^{1/2} 0; M_SI L_II^{-T} D^{-1/2} G_S] — and G^{-1} x / G^{-T} x are the two halves of
+// the band solve, on the device (launch_band_cholesky_solve).  Other large patterns: regular-inverse mode (conjugate gradient).
 #include "cholesky.hpp"
 #include "dense.hpp"
 
@@ -17,6 +20,11 @@ using namespace mispec;
 namespace mispec {
 void launch_cholesky_solve(const mispec_cholesky& C, bool upper, const double* x, double* y)
 {
+    if (C.band)
+    {
+        launch_band_cholesky_solve(*C.band, upper, x, y);
+        return;
+    }
     launch_row_gemv(*C.ctx, upper ? C.linvt.p : C.linv.p, C.n, C.n, C.n, x, y);  // dense.hip: one wavefront per row
 }
 }  // namespace mispec
@@ -27,13 +35,27 @@ extern "C" int mispec_cholesky_create(mispec_ctx* ctx, int64_t n, const int32_t*
     return guarded([&] {
         MISPEC_REQUIRE(ctx && out && outer && n >= 1, "mispec_cholesky_create: bad argument");
         MISPEC_REQUIRE(uplo == 'L' || uplo == 'U' || uplo == 'l' || uplo == 'u', "mispec_cholesky_create: uplo must be 'L' or 'U'");
-        MISPEC_REQUIRE(n <= kMaxCholesky,
-                       "SparseCholesky: the dense device factor is limited to n <= 4096 (use the regular-inverse mode for larger B)");
         MISPEC_REQUIRE(ctx->comm.allgather == nullptr, "mispec_cholesky_create: the B operator cannot be row-sharded");
         const bool lower = (uplo == 'L' || uplo == 'l');
         auto C = std::make_unique<mispec_cholesky>();
         C->ctx = ctx;
         C->n = n;
+        if (n > kMaxCholesky)
+        {
+            // banded B: the partitioned band factorisation with sigma = 0, keeping the triangular halves
+            mispec_symshift* S = nullptr;
+            if (mispec_symshift_create(ctx, n, outer, inner, val, uplo, row_major, &S) != MISPEC_OK)
+                throw Error(MISPEC_EINVAL, mispec_last_error());
+            C->band = S;
+            MISPEC_REQUIRE(S->half_bandwidth <= kMaxBandwidth,
+                           "SparseCholesky: for n > 4096 the matrix must be banded (half-bandwidth <= 8); use the regular-inverse mode "
+                           "for other large B");
+            S->want_cholesky = true;
+            const int rc = mispec_symshift_set_shift(S, 0.0);
+            C->info = (rc == MISPEC_OK && S->cholesky_ready) ? 0 : 3;  // CompInfo::NumericalIssue: B is not positive definite
+            *out = C.release();
+            return;
+        }
         // dense symmetric B from the selected triangle (column-major, both triangles filled)
         std::vector<double> B(size_t(n) * n, 0.0);
         for (int64_t o = 0; o < n; o++)
@@ -100,6 +122,12 @@ extern "C" int mispec_cholesky_create(mispec_ctx* ctx, int64_t n, const int32_t*
         }
         *out = C.release();
     });
+}
+
+mispec_cholesky::~mispec_cholesky()
+{
+    if (band)
+        (void) mispec_symshift_destroy(band);
 }
 
 extern "C" int mispec_cholesky_destroy(mispec_cholesky* C)

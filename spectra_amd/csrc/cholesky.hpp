@@ -2,13 +2,16 @@
 #pragma once
 #include "common.hpp"
 #include "csr.hpp"
+#include "shiftsolve.hpp"
 
 struct mispec_cholesky
 {
     mispec_ctx* ctx = nullptr;
     int64_t n = 0;
     int info = 0;                       // CompInfo: 0 Successful, 3 NumericalIssue (B not positive definite)
-    mispec::DevBuf<double> linv, linvt; // L^{-1} and its transpose, dense n x n row-major
+    mispec::DevBuf<double> linv, linvt; // L^{-1} and its transpose, dense n x n row-major (n <= 4096)
+    mispec_symshift* band = nullptr;    // n > 4096, half-bandwidth <= 8: the partitioned band factorisation of B (shiftsolve.hip)
+    ~mispec_cholesky();
     mutable mispec::DevBuf<double> stage_x, stage_y;
 };
 

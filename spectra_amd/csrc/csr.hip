@@ -93,9 +93,10 @@ __global__ __launch_bounds__(kThreads) void k_spmv_csr_stream(const int32_t* __r
     // XCD-aware map: gridDim.x == 8 * per; block b runs on XCD b % 8 and takes the (b/8)-th
     // row-block of that XCD's contiguous range.
     const int per = (nblocks + 7) >> 3;
-    const int lb = (int(blockIdx.x) & 7) * per + (int(blockIdx.x) >> 3);
-    if (lb >= nblocks)
+    const int lmap = (int(blockIdx.x) & 7) * per + (int(blockIdx.x) >> 3);
+    if (lmap >= nblocks)
         return;
+    const int lb = epi.first_block + lmap;  // a launch may cover a sub-range of the row-blocks (comm / compute overlap)
     if (EPI && epi.status && *epi.status != 0)
         return;
 
@@ -330,9 +331,10 @@ __global__ __launch_bounds__(256) void k_spmv_dia(DiaArgs da, const double* __re
     // same XCD-aware row-block map and the same 256-row blocks as k_spmv_csr_stream: the alpha partials of the fused
     // epilogue are identical records
     const int per = (nblocks + 7) >> 3;
-    const int lb = (int(blockIdx.x) & 7) * per + (int(blockIdx.x) >> 3);
-    if (lb >= nblocks)
+    const int lmap = (int(blockIdx.x) & 7) * per + (int(blockIdx.x) >> 3);
+    if (lmap >= nblocks)
         return;
+    const int lb = epi.first_block + lmap;  // a launch may cover a sub-range of the row-blocks (comm / compute overlap)
     if (EPI && epi.status && *epi.status != 0)
         return;
     const int tid = threadIdx.x;
@@ -392,9 +394,10 @@ __global__ __launch_bounds__(256) void k_spmv_dia_win(DiaArgs da, mispec_dia_win
     extern __shared__ double xs[];
     __shared__ double red[4];
     const int per = (nblocks + 7) >> 3;
-    const int lb = (int(blockIdx.x) & 7) * per + (int(blockIdx.x) >> 3);
-    if (lb >= nblocks)
+    const int lmap = (int(blockIdx.x) & 7) * per + (int(blockIdx.x) >> 3);
+    if (lmap >= nblocks)
         return;
+    const int lb = epi.first_block + lmap;  // a launch may cover a sub-range of the row-blocks (comm / compute overlap)
     if (EPI && epi.status && *epi.status != 0)
         return;
     const int tid = threadIdx.x;
@@ -839,9 +842,68 @@ __global__ __launch_bounds__(256) void k_col_ranges(const int32_t* __restrict__ 
         }
 }
 
+// flag[b] = 1 when every entry of 256-row block b has its column in [lo, hi)
+__global__ __launch_bounds__(256) void k_block_local(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind, int64_t nrows,
+                                                      int rows_per_block, int lo, int hi, int* __restrict__ flag)
+{
+    __shared__ int outside;
+    if (threadIdx.x == 0)
+        outside = 0;
+    __syncthreads();
+    const int64_t r0 = int64_t(blockIdx.x) * rows_per_block;
+    const int64_t r1 = min(r0 + rows_per_block, nrows);
+    int bad = 0;
+    for (int p = rowptr[r0] + int(threadIdx.x); p < rowptr[r1]; p += 256)
+    {
+        const int c = colind[p];
+        bad |= (c < lo || c >= hi);
+    }
+    if (bad)
+        outside = 1;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        flag[blockIdx.x] = outside ? 0 : 1;
+}
+
 }  // namespace
 
 namespace mispec {
+
+void interior_blocks(const mispec_csr& A, int64_t col_lo, int64_t col_hi, int& first, int& count)
+{
+    first = 0;
+    count = 0;
+    const int64_t nloc = A.local_rows();
+    if (nloc == 0 || A.nnz == 0)
+        return;
+    const int nblocks = spmv_num_blocks(nloc);
+    DevBuf<int> d;
+    d.alloc(size_t(nblocks));
+    hipLaunchKernelGGL(k_block_local, dim3(unsigned(nblocks)), dim3(256), 0, A.ctx->stream, A.rowptr.p, A.colind.p, nloc,
+                       spmv_rows_per_block(), int(col_lo), int(col_hi), d.p);
+    MISPEC_HIP(hipGetLastError());
+    std::vector<int> h(static_cast<size_t>(nblocks));
+    MISPEC_HIP(hipMemcpyAsync(h.data(), d.p, h.size() * sizeof(int), hipMemcpyDeviceToHost, A.ctx->stream));
+    MISPEC_HIP(hipStreamSynchronize(A.ctx->stream));
+    int best_first = 0, best = 0, run_first = 0, run = 0;
+    for (int b = 0; b < nblocks; b++)
+    {
+        if (h[size_t(b)])
+        {
+            if (run == 0)
+                run_first = b;
+            if (++run > best)
+            {
+                best = run;
+                best_first = run_first;
+            }
+        }
+        else
+            run = 0;
+    }
+    first = best_first;
+    count = best;
+}
 
 bool spmv_codes_enabled()
 {
@@ -899,23 +961,34 @@ void launch_spmv(const mispec_csr& A, const double* x_dev, double* y_dev, const 
 }
 
 void launch_spmv_raw(const mispec_csr& A, const double* x_dev, double* y_dev, const SpmvEpilogue* epi, hipEvent_t ev_start,
-                     hipEvent_t ev_stop)
+                     hipEvent_t ev_stop, int block_first, int block_count)
 {
     const int64_t nloc = A.local_rows();
     if (nloc == 0)
         return;
-    const int nblocks = spmv_num_blocks(nloc);
+    const int all_blocks = spmv_num_blocks(nloc);
+    if (block_count < 0)
+    {
+        block_first = 0;
+        block_count = all_blocks;
+    }
+    if (block_count == 0)
+        return;
+    MISPEC_REQUIRE(block_first >= 0 && block_first + block_count <= all_blocks, "SpMV: row-block range out of bounds");
+    const int nblocks = block_count;  // the kernels map blockIdx onto [first_block, first_block + nblocks)
     const int per = (nblocks + 7) >> 3;
     const int threads = spmv_rows_per_block();
     const dim3 grid(unsigned(per * 8)), block(static_cast<unsigned>(threads));
     static const bool nt = getenv("MISPEC_SPMV_NT") ? atoi(getenv("MISPEC_SPMV_NT")) != 0 : false;
-    const SpmvEpilogue e = epi ? *epi : SpmvEpilogue{};
+    SpmvEpilogue e = epi ? *epi : SpmvEpilogue{};
+    e.first_block = block_first;
     const int format = A.spmv_format();
     const bool coded = format == 1;
     const SpmvCodes cd{A.codes.p, A.dict.p, A.ndict, int(A.n_cols - 1), A.row_begin};
     if (format == 3)
     {
-        launch_spmv_tiles(A.tiles, A.ctx->stream, x_dev, y_dev, nloc, nblocks, epi, ev_start, ev_stop);
+        MISPEC_REQUIRE(block_count == all_blocks, "SpMV: the tile format does not take row-block sub-ranges");
+        launch_spmv_tiles(A.tiles, A.ctx->stream, x_dev, y_dev, nloc, all_blocks, epi, ev_start, ev_stop);
         return;
     }
     if (format == 2)

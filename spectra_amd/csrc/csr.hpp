@@ -97,6 +97,7 @@ struct SpmvEpilogue
     const double* h_prev_dev = nullptr;  // if set, H(i,i-1) is read from device memory instead (device-driven steps)
     const int* status = nullptr;      // if set, the launch is a no-op unless *status == 0
     double* partials = nullptr;       // one double per block, deterministic second stage elsewhere
+    int first_block = 0;              // set by the launcher: first 256-row block this launch covers
 };
 
 // MISPEC_SPMV_CODES=0 turns the offset-coded index format off (plain int32 column indices everywhere).
@@ -116,8 +117,12 @@ inline int spmv_num_blocks(int64_t local_rows)
 // when reordered): what a solver that works in the permuted order calls.
 void launch_spmv(const mispec_csr& A, const double* x_dev, double* y_dev, const SpmvEpilogue* epi, hipEvent_t ev_start = nullptr,
                  hipEvent_t ev_stop = nullptr);
+// block_count >= 0: only the 256-row blocks [block_first, block_first + block_count) (their rows of y, their partial records)
 void launch_spmv_raw(const mispec_csr& A, const double* x_dev, double* y_dev, const SpmvEpilogue* epi, hipEvent_t ev_start = nullptr,
-                     hipEvent_t ev_stop = nullptr);
+                     hipEvent_t ev_stop = nullptr, int block_first = 0, int block_count = -1);
+// For a row shard: the longest run of 256-row blocks whose entries reference only columns in [col_lo, col_hi) (the shard's own
+// slice of x): rows that can be multiplied before the other ranks' parts of x have arrived.  Synchronises the stream.
+void interior_blocks(const mispec_csr& A, int64_t col_lo, int64_t col_hi, int& first, int& count);
 // dst[i] = src[perm[i]] (to the stored order) / dst[perm[i]] = src[i] (back to the caller's order), i < local_rows
 void launch_to_stored_order(const mispec_csr& A, const double* src, double* dst);
 void launch_from_stored_order(const mispec_csr& A, const double* src, double* dst);

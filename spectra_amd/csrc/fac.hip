@@ -97,6 +97,12 @@ struct mispec_fac
     bool halo = false;
     std::vector<int64_t> send_off, send_count, recv_off, recv_count;
     int64_t halo_recv = 0;  // doubles received per exchange
+    // Overlap of the exchange with the product: the longest run of 256-row blocks that reference only this
+    // rank's own slice of x is multiplied on the solver's stream while the exchange runs on a second stream; the remaining
+    // blocks follow when it has landed.  interior_count == 0: no overlap (everything after the exchange).
+    int interior_first = 0, interior_count = 0;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_x_ready = nullptr, ev_x_landed = nullptr;
     // The matrix is stored reordered (P A P', reorder.hip) and this factorisation works in that order: start vectors are
     // permuted on the way in, V / f / Ritz vectors on the way out; plain operators only (product, generalized and
     // Cholesky operators use the order-preserving product instead)
@@ -132,6 +138,12 @@ struct mispec_fac
             }
         for (auto e : ev_pool)
             (void) hipEventDestroy(e);
+        if (ev_x_ready)
+            (void) hipEventDestroy(ev_x_ready);
+        if (ev_x_landed)
+            (void) hipEventDestroy(ev_x_landed);
+        if (comm_stream)
+            (void) hipStreamDestroy(comm_stream);
     }
 };
 
@@ -254,6 +266,31 @@ void allreduce_max_scalar(mispec_fac& F, double* dev_scalar)
     sync_stream(F);
 }
 
+// Which row-blocks can be multiplied before the exchange has landed (collective-free: a local property of the shard).
+// MISPEC_OVERLAP=0 turns the overlap off.
+void plan_overlap(mispec_fac& F)
+{
+    F.interior_first = F.interior_count = 0;
+    if (!F.A || !F.sharded() || F.ctx->world() < 2 || F.A2 || F.Bop || F.Chol || F.A->spmv_format() == 3)
+        return;
+    const char* e = getenv("MISPEC_OVERLAP");
+    if (e && atoi(e) == 0)
+        return;
+    int first = 0, count = 0;
+    interior_blocks(*F.A, F.row_begin, F.row_begin + F.nloc, first, count);
+    const int nblocks = spmv_num_blocks(F.nloc);
+    if (count < nblocks / 4 || count == nblocks)  // too little to hide anything behind / nothing to wait for
+        return;
+    F.interior_first = first;
+    F.interior_count = count;
+    if (!F.comm_stream)
+    {
+        MISPEC_HIP(hipStreamCreateWithFlags(&F.comm_stream, hipStreamNonBlocking));
+        MISPEC_HIP(hipEventCreateWithFlags(&F.ev_x_ready, hipEventDisableTiming));
+        MISPEC_HIP(hipEventCreateWithFlags(&F.ev_x_landed, hipEventDisableTiming));
+    }
+}
+
 // Decide between the all-gather and the neighbour exchange for this matrix (collective: every rank calls it and
 // every rank reaches the same decision, because the decision is a function of the all-gathered table).
 void plan_exchange(mispec_fac& F)
@@ -353,6 +390,23 @@ void b_norm_slots(mispec_fac& F, const double* x, int nrec)
     launch_dot_record(*F.ctx, x, F.bx.p, F.nloc, F.partials.p, F.pstride, nrec);
 }
 
+// The product of a row shard while its exchange is still in flight on the communication stream: first the row-blocks that
+// read only this rank's slice of x, then — once the other slices have landed — the blocks before and after them.  Same
+// kernels on the same blocks as the single launch, so the same y and the same alpha records.
+void overlapped_spmv(mispec_fac& F, const mispec_csr& M, const double* x, double* y, const SpmvEpilogue* epi, hipEvent_t e0, hipEvent_t e1)
+{
+    const int nblocks = spmv_num_blocks(F.nloc);
+    const int i0 = F.interior_first, i1 = F.interior_first + F.interior_count;
+    if (e0)
+        MISPEC_HIP(hipEventRecord(e0, F.stream()));
+    launch_spmv_raw(M, x, y, epi, nullptr, nullptr, i0, i1 - i0);
+    MISPEC_HIP(hipStreamWaitEvent(F.stream(), F.ev_x_landed, 0));
+    launch_spmv_raw(M, x, y, epi, nullptr, nullptr, 0, i0);
+    launch_spmv_raw(M, x, y, epi, nullptr, nullptr, i1, nblocks - i1);
+    if (e1)
+        MISPEC_HIP(hipEventRecord(e1, F.stream()));
+}
+
 // y = Op(x).  x_loc / y_loc: this shard's rows (device).  With `lanczos_epi`, additionally
 // y -= h_prev * v_prev (when v_prev != nullptr) and alpha = <x, y> is left in red_buf(0)[kSlotAlpha]
 // (device) — Lanczos.h:131-142.
@@ -363,20 +417,29 @@ void apply_op(mispec_fac& F, const double* x_loc, double* y_loc, bool lanczos_ep
     if (F.A)
     {
         const double* x = x_loc;
+        const bool overlap = F.sharded() && F.interior_count > 0;
+        hipStream_t xs = overlap ? F.comm_stream : F.stream();  // the stream the exchange is enqueued on
         if (F.sharded())
         {
-            if (F.halo)
+            // own slice by a local copy (the interior row-blocks read nothing else); the collective then runs in place /
+            // on the referenced parts only
+            MISPEC_HIP(hipMemcpyAsync(F.xfull.p + F.row_begin, x_loc, size_t(F.nloc) * sizeof(double), hipMemcpyDeviceToDevice,
+                                      F.stream()));
+            if (overlap)
             {
-                // the matrix references only parts of the other slices: own slice by a local copy, the referenced
-                // parts by concurrent point-to-point transfers
-                MISPEC_HIP(hipMemcpyAsync(F.xfull.p + F.row_begin, x_loc, size_t(F.nloc) * sizeof(double),
-                                          hipMemcpyDeviceToDevice, F.stream()));
-                comm_check(F.ctx->comm.exchange(F.ctx->comm.user, x_loc, F.send_off.data(), F.send_count.data(), F.xfull.p,
-                                                F.recv_off.data(), F.recv_count.data(), F.stream()),
-                           "neighbour exchange");
+                MISPEC_HIP(hipEventRecord(F.ev_x_ready, F.stream()));
+                MISPEC_HIP(hipStreamWaitEvent(F.comm_stream, F.ev_x_ready, 0));
             }
-            else  // all-gather of the Krylov vector over xGMI; blocks are equal-sized and padded
-                comm_check(F.ctx->comm.allgather(F.ctx->comm.user, x_loc, F.xfull.p, F.block, F.stream()), "all-gather");
+            if (F.halo)
+                // the matrix references only parts of the other slices: concurrent point-to-point transfers of exactly those
+                comm_check(F.ctx->comm.exchange(F.ctx->comm.user, F.xfull.p + F.row_begin, F.send_off.data(), F.send_count.data(), F.xfull.p,
+                                                F.recv_off.data(), F.recv_count.data(), xs),
+                           "neighbour exchange");
+            else  // all-gather of the Krylov vector over xGMI, in place: blocks are equal-sized and padded
+                comm_check(F.ctx->comm.allgather(F.ctx->comm.user, F.xfull.p + int64_t(F.ctx->rank()) * F.block, F.xfull.p, F.block, xs),
+                           "all-gather");
+            if (overlap)
+                MISPEC_HIP(hipEventRecord(F.ev_x_landed, F.comm_stream));
             x = F.xfull.p;
         }
         // A single SpMV is timed through its own dispatch (start/stop of the kernel, no marker packets in the
@@ -443,8 +506,13 @@ void apply_op(mispec_fac& F, const double* x_loc, double* y_loc, bool lanczos_ep
             epi.h_prev_dev = h_prev_dev;
             epi.status = status;
             epi.partials = F.alpha_partials.p;
-            spmv_of(F, *last, x, y_loc, &epi, e0, e1);
+            if (overlap)
+                overlapped_spmv(F, *last, x, y_loc, &epi, e0, e1);
+            else
+                spmv_of(F, *last, x, y_loc, &epi, e0, e1);
         }
+        else if (overlap)
+            overlapped_spmv(F, *last, x, y_loc, nullptr, e0, e1);
         else
             spmv_of(F, *last, x, y_loc, nullptr, e0, e1);
     }
@@ -1291,6 +1359,7 @@ int fac_create_impl(mispec_ctx* ctx, const mispec_csr* A, const mispec_symshift*
                 F->pscratch.alloc(size_t(F->ldv));
             MISPEC_HIP(hipStreamSynchronize(ctx->stream));
             plan_exchange(*F);
+            plan_overlap(*F);
         }
         catch (...)
         {
@@ -1445,6 +1514,19 @@ extern "C" int mispec_fac_factorize(mispec_fac* fac, int from_k, int to_m, int64
 
 extern "C" int mispec_fac_subspace_dim(const mispec_fac* fac) { return fac ? fac->k : 0; }
 extern "C" int64_t mispec_fac_local_rows(const mispec_fac* fac) { return fac ? fac->nloc : 0; }
+
+extern "C" int mispec_fac_overlap_info(const mispec_fac* fac, int* first_block, int* block_count, int* total_blocks)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(fac, "mispec_fac_overlap_info: NULL argument");
+        if (first_block)
+            *first_block = fac->interior_first;
+        if (block_count)
+            *block_count = fac->interior_count;
+        if (total_blocks)
+            *total_blocks = fac->A ? spmv_num_blocks(fac->nloc) : 0;
+    });
+}
 
 extern "C" int mispec_fac_exchange_info(const mispec_fac* fac, int* halo, int64_t* recv_doubles)
 {

@@ -422,6 +422,10 @@ extern "C" int mispec_symeigs_get_profile(const mispec_symeigs* s, mispec_profil
 {
     return s ? mispec_fac_get_profile(s->fac(), out) : MISPEC_EINVAL;
 }
+extern "C" int mispec_symeigs_overlap_info(const mispec_symeigs* s, int* first_block, int* block_count, int* total_blocks)
+{
+    return s ? mispec_fac_overlap_info(s->fac(), first_block, block_count, total_blocks) : MISPEC_EINVAL;
+}
 extern "C" int mispec_symeigs_exchange_info(const mispec_symeigs* s, int* halo, int64_t* recv_doubles)
 {
     return s ? mispec_fac_exchange_info(s->fac(), halo, recv_doubles) : MISPEC_EINVAL;

@@ -31,6 +31,8 @@
 #include <algorithm>
 #include <cmath>
 #include <complex>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -79,10 +81,13 @@ struct HostBand
 // path is the FMA chain itself: the last B unknowns live in registers (never re-read from memory), and the
 // factor entries / right-hand sides of the next U rows are loaded as one batch before they are needed.
 constexpr int kChunkThreads = 64;  // one wavefront per workgroup: the chunks spread over all CUs, 512 VGPRs per lane
+// mode 0: y = M_II^{-1} f (forward, diagonal, backward); with u_out also u = D^{-1/2} L^{-1} f from the forward sweep — the
+//         interior part of G^{-1} f for the Cholesky-like factor G of a positive definite band (cholesky.hip);
+// mode 2: y = L^{-T} D^{-1/2} f (backward sweep only): the interior part of G^{-T}.
 template <int B, int U>
 __global__ __launch_bounds__(kChunkThreads) void k_chunk_solve(int64_t N, int b, int64_t L, int64_t P, const double* __restrict__ Lf,
                                                            const double* __restrict__ Dinv, const double* __restrict__ f,
-                                                           double* __restrict__ y)
+                                                           double* __restrict__ y, int mode, double* __restrict__ u_out)
 {
     const int64_t p = int64_t(blockIdx.x) * kChunkThreads + threadIdx.x;
     if (p >= P)
@@ -94,14 +99,15 @@ __global__ __launch_bounds__(kChunkThreads) void k_chunk_solve(int64_t N, int b,
     for (int d = 0; d < B; d++)
         hist[d] = 0.0;
     // forward: z_k = f_k - sum_d Lf(k,d) z_{k-d-1}
-    for (int64_t k0 = 0; k0 < m; k0 += U)
+    for (int64_t k0 = 0; k0 < (mode == 2 ? 0 : m); k0 += U)
     {
-        double fk[U], lf[U][B];
+        double fk[U], lf[U][B], ds[U];
 #pragma unroll
         for (int u = 0; u < U; u++)
         {
             const int64_t k = (k0 + u < m) ? k0 + u : m - 1;
             fk[u] = f[row0 + k];
+            ds[u] = u_out ? sqrt(fabs(Dinv[k * P + p])) : 0.0;
 #pragma unroll
             for (int d = 0; d < B; d++)
                 lf[u][d] = (d < b) ? Lf[(k * b + d) * P + p] : 0.0;  // rows k < b hold zeros for the missing neighbours
@@ -120,10 +126,12 @@ __global__ __launch_bounds__(kChunkThreads) void k_chunk_solve(int64_t N, int b,
                     hist[d] = hist[d - 1];
                 hist[0] = acc;
                 y[row0 + k0 + u] = acc;
+                if (u_out)
+                    u_out[row0 + k0 + u] = acc * ds[u];
             }
         }
     }
-    // diagonal and backward: y_k = z_k / D_k - sum_d Lf(k+d+1, d) y_{k+d+1}
+    // diagonal and backward: y_k = z_k / D_k - sum_d Lf(k+d+1, d) y_{k+d+1}   (mode 2: z_k |D_k|^{-1/2} from f instead)
 #pragma unroll
     for (int d = 0; d < B; d++)
         hist[d] = 0.0;
@@ -134,8 +142,8 @@ __global__ __launch_bounds__(kChunkThreads) void k_chunk_solve(int64_t N, int b,
         for (int u = 0; u < U; u++)
         {
             const int64_t k = (k0 - u >= 0) ? k0 - u : 0;
-            zk[u] = y[row0 + k];
-            di[u] = Dinv[k * P + p];
+            zk[u] = (mode == 2) ? f[row0 + k] : y[row0 + k];
+            di[u] = (mode == 2) ? sqrt(fabs(Dinv[k * P + p])) : Dinv[k * P + p];
 #pragma unroll
             for (int d = 0; d < B; d++)
                 lf[u][d] = (d < b && k + d + 1 < m) ? Lf[((k + d + 1) * b + d) * P + p] : 0.0;
@@ -241,6 +249,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_chunk_factor(int64_t N, int b
     // ---- 1. LDL' ---------------------------------------------------------------------------------------
     {
         double minpiv = 1.7976931348623157e308;
+        unsigned long long negs = 0;
         double Lw[B][B], Dw[B];  // Lw[i][d] = L(k-1-i, k-1-i-d-1), Dw[i] = D(k-1-i)
 #pragma unroll
         for (int i = 0; i < B; i++)
@@ -289,6 +298,8 @@ __global__ __launch_bounds__(kChunkThreads) void k_chunk_factor(int64_t N, int b
                 atomicAdd(&stats[0], 1ull);  // boosted pivots
                 dv = (dv < 0.0) ? -thr : thr;
             }
+            if (dv < 0.0)
+                negs++;
             Dinv[k * P + p] = 1.0 / dv;
 #pragma unroll
             for (int d = 0; d < B; d++)
@@ -309,6 +320,8 @@ __global__ __launch_bounds__(kChunkThreads) void k_chunk_factor(int64_t N, int b
         }
         if (minpiv == minpiv)  // a NaN pivot was boosted and counted above
             atomicMin(&stats[1], (unsigned long long) __double_as_longlong(minpiv));
+        if (negs)
+            atomicAdd(&stats[2], negs);
     }
     if (P == 1)
         return;
@@ -461,7 +474,8 @@ void band_lu_inverse(const HostBand& M, std::vector<double>& inv)
                 pr = i;
             }
         if (!(best > 0.0))  // exactly singular (or NaN); anything else is judged by the calibration of the refinement
-            throw Error(MISPEC_EINVAL, "SparseSymShiftSolve: factorization failed with the given shift");
+            throw Error(MISPEC_EINVAL, "SparseSymShiftSolve: factorization failed with the given shift (singular last level: column " +
+                                           std::to_string(k) + " of " + std::to_string(N) + ")");
         piv[size_t(k)] = pr;
         if (pr != k)
             for (int64_t j = k; j <= cmax; j++)
@@ -582,6 +596,8 @@ struct FactorStats
 {
     long long boosts = 0;          // pivots replaced by +-sqrt(eps)*scale
     double min_pivot_ratio = 1.0;  // smallest |pivot| / scale of its level
+    long long negative = 0;        // negative pivots (a positive definite matrix has none at any level)
+    bool want_cholesky = false;    // also keep the triangular factor of the last level (G G' = M for SparseCholesky)
 };
 
 struct mispec::BandLevel
@@ -590,25 +606,64 @@ struct mispec::BandLevel
     int b = 0;
     DevBuf<double> Lf, Dinv, W, band, y, g, xs;
     DevBuf<double> inv;  // last level only: explicit inverse (N x N), applied by a dense GEMV
+    DevBuf<double> linv, linvt;  // last level, Cholesky use only: C^{-1} and C^{-T} of the level's M = C C' (row-major)
     std::unique_ptr<BandLevel> next;
 };
 
 namespace {
 
-constexpr int64_t kChunk = 128;         // rows per chunk
-constexpr int64_t kSingleChunk = 2048;  // a level this small is not partitioned any further: its inverse is formed
-                                        // explicitly (banded LDL' solves of the unit vectors) and applied as a GEMV
+// defaults of ChunkPlan below: 128 rows per chunk; a level of at most 2048 rows is not partitioned any further: its inverse
+// is formed explicitly (band LU solves of the unit vectors) and applied as a GEMV
 
 void throw_singular()
 {
     throw Error(MISPEC_EINVAL, "SparseSymShiftSolve: factorization failed with the given shift");
 }
 
+// Chunk-length bias of the factorisation attempt in progress (set_shift): when an attempt meets chunk interiors that are
+// singular although the matrix is not — tridiag(-1, 0, -1) cut into odd pieces is the textbook case — the next attempt
+// moves every separator by using chunks one row longer.
+thread_local int g_chunk_bias = 0;
+// Last resort of set_shift for a matrix of at most kPivotedLimit rows whose chunk interiors stay singular wherever the
+// separators are put (tridiag(-1, 0, -1) is one): no partition at all, one band LU with partial pivoting + explicit inverse.
+thread_local bool g_single_chunk = false;
+constexpr int64_t kPivotedLimit = 8192;
+
 // chunk length and chunk count of a level
+// MISPEC_SHIFT_CHUNK="L_big,L_small,N_switch,N_dense": chunk length for levels with more than N_switch rows / for smaller
+// levels, and the size below which a level is inverted densely.  The solve kernels run one lane per chunk, so a level needs
+// many chunks to pull bandwidth: short chunks, paid for with more separator rows (the next level) — measured in profiles/.
+struct ChunkPlan
+{
+    int64_t big = 128, small = 128, n_switch = 0, n_dense = 2048;
+};
+const ChunkPlan& chunk_plan()
+{
+    static const ChunkPlan plan = [] {
+        ChunkPlan c;
+        if (const char* e = getenv("MISPEC_SHIFT_CHUNK"))
+        {
+            long long a = 0, b2 = 0, c2 = 0, d = 0;
+            const int got = sscanf(e, "%lld,%lld,%lld,%lld", &a, &b2, &c2, &d);
+            if (got >= 1 && a >= 8)
+                c.big = c.small = a;
+            if (got >= 2 && b2 >= 8)
+                c.small = b2;
+            if (got >= 3 && c2 >= 0)
+                c.n_switch = c2;
+            if (got >= 4 && d >= 64 && d <= 8192)
+                c.n_dense = d;
+        }
+        return c;
+    }();
+    return plan;
+}
+
 void plan_level(int64_t N, int b, int64_t& L, int64_t& P)
 {
-    L = std::max<int64_t>(kChunk, 4 * int64_t(b));
-    P = (N <= std::max<int64_t>(kSingleChunk, 8 * int64_t(b))) ? 1 : N / L;
+    const ChunkPlan& cp = chunk_plan();
+    L = std::max<int64_t>((N > cp.n_switch ? cp.big : cp.small) + g_chunk_bias, 4 * int64_t(b));
+    P = (N <= std::max<int64_t>(cp.n_dense, 8 * int64_t(b)) || (g_single_chunk && N <= kPivotedLimit)) ? 1 : N / L;
     if (P < 2)
     {
         P = 1;
@@ -683,14 +738,14 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
         DevBuf<double> Cdev;
         Cdev.alloc(size_t(P) * w2 * w2);
         DevBuf<unsigned long long> dstats;
-        dstats.alloc(2);
+        dstats.alloc(3);
         MISPEC_HIP(hipMemsetAsync(lev.Lf.p, 0, lf_size * sizeof(double), ctx->stream));
         MISPEC_HIP(hipMemsetAsync(lev.Dinv.p, 0, dinv_size * sizeof(double), ctx->stream));
         MISPEC_HIP(hipMemsetAsync(lev.W.p, 0, w_size * sizeof(double), ctx->stream));
         MISPEC_HIP(hipMemsetAsync(Cdev.p, 0, Cdev.n * sizeof(double), ctx->stream));
         {
             const double huge = 1.7976931348623157e308;
-            unsigned long long init[2] = {0ull, 0ull};
+            unsigned long long init[3] = {0ull, 0ull, 0ull};
             std::memcpy(&init[1], &huge, sizeof(double));
             MISPEC_HIP(hipMemcpyAsync(dstats.p, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
             MISPEC_HIP(hipStreamSynchronize(ctx->stream));  // init is a local
@@ -704,7 +759,7 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
                                lev.Lf.p, lev.Dinv.p, lev.W.p, Cdev.p, dstats.p);
         MISPEC_HIP(hipGetLastError());
         std::vector<double> Cc(Cdev.n);
-        unsigned long long hstats[2] = {0ull, 0ull};
+        unsigned long long hstats[3] = {0ull, 0ull, 0ull};
         MISPEC_HIP(hipMemcpyAsync(Cc.data(), Cdev.p, Cc.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         MISPEC_HIP(hipMemcpyAsync(hstats, dstats.p, sizeof(hstats), hipMemcpyDeviceToHost, ctx->stream));
         MISPEC_HIP(hipStreamSynchronize(ctx->stream));
@@ -712,6 +767,7 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
             double minpiv;
             std::memcpy(&minpiv, &hstats[1], sizeof(double));
             stats.boosts += (long long) hstats[0];
+            stats.negative += (long long) hstats[2];
             stats.min_pivot_ratio = std::min(stats.min_pivot_ratio, minpiv);
         }
         for (int64_t p = 0; p < P; p++)
@@ -751,6 +807,54 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
         band_lu_inverse(M, inv);
         ctx->make_current();
         upload_row_major(inv, N, lev.inv);
+        if (stats.want_cholesky)
+        {
+            // M = C C' (banded Cholesky), C^{-1} by forward substitution on the unit vectors; both C^{-1} and C^{-T} row-major
+            std::vector<double> Cb(size_t(N) * (b + 1), 0.0);  // Cb[i*(b+1)+d] = C(i, i-d)
+            bool spd = true;
+            for (int64_t i = 0; i < N && spd; i++)
+                for (int d = std::min<int64_t>(b, i); d >= 0; d--)
+                {
+                    const int64_t j = i - d;
+                    double v = static_cast<const HostBand&>(M).at(i, d);
+                    for (int64_t t = std::max<int64_t>(std::max<int64_t>(i - b, j - b), 0); t < j; t++)
+                        v -= Cb[size_t(i) * (b + 1) + (i - t)] * Cb[size_t(j) * (b + 1) + (j - t)];
+                    if (d == 0)
+                    {
+                        if (!(v > 0.0))
+                        {
+                            spd = false;
+                            break;
+                        }
+                        Cb[size_t(i) * (b + 1)] = std::sqrt(v);
+                    }
+                    else
+                        Cb[size_t(i) * (b + 1) + d] = v / Cb[size_t(j) * (b + 1)];
+                }
+            if (!spd)
+                stats.negative++;
+            else
+            {
+                std::vector<double> X(size_t(N) * N, 0.0), Xt(size_t(N) * N, 0.0), col(static_cast<size_t>(N));
+                for (int64_t c = 0; c < N; c++)
+                {
+                    std::fill(col.begin(), col.end(), 0.0);
+                    for (int64_t i = c; i < N; i++)
+                    {
+                        double acc = (i == c) ? 1.0 : 0.0;
+                        for (int64_t t = std::max<int64_t>(std::max<int64_t>(i - b, c), 0); t < i; t++)
+                            acc -= Cb[size_t(i) * (b + 1) + (i - t)] * col[size_t(t)];
+                        col[size_t(i)] = acc / Cb[size_t(i) * (b + 1)];
+                        X[size_t(i) * N + c] = col[size_t(i)];
+                        Xt[size_t(c) * N + i] = col[size_t(i)];
+                    }
+                }
+                lev.linv.alloc(X.size());
+                lev.linvt.alloc(Xt.size());
+                MISPEC_HIP(hipMemcpy(lev.linv.p, X.data(), X.size() * sizeof(double), hipMemcpyHostToDevice));
+                MISPEC_HIP(hipMemcpy(lev.linvt.p, Xt.data(), Xt.size() * sizeof(double), hipMemcpyHostToDevice));
+            }
+        }
         lev.y.alloc(size_t(N));
         MISPEC_HIP(hipStreamSynchronize(ctx->stream));
         M.a.clear();
@@ -792,6 +896,8 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
                 stats.boosts++;
                 dv = (dv < 0.0) ? -thr : thr;
             }
+            if (dv < 0.0)
+                stats.negative++;
             D[size_t(k)] = dv;
         }
         for (int64_t k = 0; k < m; k++)
@@ -918,11 +1024,12 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
     }
 }
 
-void launch_chunk_solve(const mispec_ctx& ctx, const BandLevel& lev, dim3 grid, const double* f, double* y)
+void launch_chunk_solve(const mispec_ctx& ctx, const BandLevel& lev, dim3 grid, const double* f, double* y, int mode = 0,
+                        double* u_out = nullptr)
 {
 #define MISPEC_CHUNK(B, U)                                                                                                  \
     hipLaunchKernelGGL((k_chunk_solve<B, U>), grid, dim3(kChunkThreads), 0, ctx.stream, lev.N, lev.b, lev.L, lev.P, lev.Lf.p, \
-                       lev.Dinv.p, f, y)
+                       lev.Dinv.p, f, y, mode, u_out)
     // U rows of factor entries are in flight per lane and batch ((B + 2) * U doubles): as deep as the register
     // file allows, because with one lane per chunk nothing else hides the load latency
     if (lev.b <= 4)
@@ -931,6 +1038,8 @@ void launch_chunk_solve(const mispec_ctx& ctx, const BandLevel& lev, dim3 grid, 
         MISPEC_CHUNK(8, 16);
     else if (lev.b <= 16)
         MISPEC_CHUNK(16, 8);
+    else if (lev.b <= 32)
+        MISPEC_CHUNK(32, 4);
     else
         MISPEC_CHUNK(64, 1);
 #undef MISPEC_CHUNK
@@ -959,6 +1068,59 @@ void solve_level(const mispec_ctx& ctx, const BandLevel& lev, const double* f, d
     solve_level(ctx, *lev.next, lev.g.p, lev.xs.p);
     hipLaunchKernelGGL(k_back_subst, blocks(lev.N), dim3(kThreads), 0, ctx.stream, lev.N, lev.b, lev.L, lev.P, lev.W.p, lev.y.p,
                        lev.xs.p, x);
+    MISPEC_HIP(hipGetLastError());
+}
+
+// ---- G^{-1} and G^{-T} for the factor G G' = M of a positive definite band (SparseCholesky beyond the dense limit) -------
+// In the nested order (chunk interiors, then separators, recursively) M = G G' with
+//   G = [ L_II D^{1/2}  0 ; M_SI L_II^{-T} D^{-1/2}  G_S ],   G_S G_S' = Schur complement of the separators,
+// so   u = G^{-1} f :  u_I = D^{-1/2} L_II^{-1} f_I ,  u_S = G_S^{-1} (f_S - M_SI M_II^{-1} f_I)
+//      x = G^{-T} u :  x_S = G_S^{-T} u_S ,            x_I = L_II^{-T} D^{-1/2} u_I - W x_S     (W = M_II^{-1} M_IS)
+// — the same kernels and factors as the solve, split in two halves.
+__global__ __launch_bounds__(kThreads) void k_sep_move(int64_t nsep, int b, int64_t L, const double* __restrict__ src, double* __restrict__ dst,
+                                                        int to_rows)
+{
+    const int64_t s = int64_t(blockIdx.x) * kThreads + threadIdx.x;
+    if (s >= nsep)
+        return;
+    const int64_t row = (s / b + 1) * L - b + (s % b);
+    if (to_rows)
+        dst[row] = src[s];
+    else
+        dst[s] = src[row];
+}
+
+void chol_forward(const mispec_ctx& ctx, const BandLevel& lev, const double* f, double* u)
+{
+    const auto blocks = [](int64_t n) { return dim3(unsigned((n + kThreads - 1) / kThreads)); };
+    if (lev.P == 1)
+    {
+        launch_row_gemv(ctx, lev.linv.p, lev.N, lev.N, lev.N, f, u);
+        return;
+    }
+    const int64_t nsep = (lev.P - 1) * lev.b;
+    launch_chunk_solve(ctx, lev, dim3(unsigned((lev.P + kChunkThreads - 1) / kChunkThreads)), f, lev.y.p, 0, u);
+    hipLaunchKernelGGL(k_sep_rhs, blocks(nsep), dim3(kThreads), 0, ctx.stream, lev.N, lev.b, lev.L, lev.P, lev.band.p, f, lev.y.p, lev.g.p);
+    MISPEC_HIP(hipGetLastError());
+    chol_forward(ctx, *lev.next, lev.g.p, lev.xs.p);
+    hipLaunchKernelGGL(k_sep_move, blocks(nsep), dim3(kThreads), 0, ctx.stream, nsep, lev.b, lev.L, lev.xs.p, u, 1);
+    MISPEC_HIP(hipGetLastError());
+}
+
+void chol_backward(const mispec_ctx& ctx, const BandLevel& lev, const double* u, double* x)
+{
+    const auto blocks = [](int64_t n) { return dim3(unsigned((n + kThreads - 1) / kThreads)); };
+    if (lev.P == 1)
+    {
+        launch_row_gemv(ctx, lev.linvt.p, lev.N, lev.N, lev.N, u, x);
+        return;
+    }
+    const int64_t nsep = (lev.P - 1) * lev.b;
+    hipLaunchKernelGGL(k_sep_move, blocks(nsep), dim3(kThreads), 0, ctx.stream, nsep, lev.b, lev.L, u, lev.g.p, 0);
+    MISPEC_HIP(hipGetLastError());
+    chol_backward(ctx, *lev.next, lev.g.p, lev.xs.p);
+    launch_chunk_solve(ctx, lev, dim3(unsigned((lev.P + kChunkThreads - 1) / kChunkThreads)), u, lev.y.p, 2, nullptr);
+    hipLaunchKernelGGL(k_back_subst, blocks(lev.N), dim3(kThreads), 0, ctx.stream, lev.N, lev.b, lev.L, lev.P, lev.W.p, lev.y.p, lev.xs.p, x);
     MISPEC_HIP(hipGetLastError());
 }
 
@@ -1117,16 +1279,19 @@ void calibrate_refinement(mispec_symshift& S, const FactorStats& fs)
         std::memcpy(&nx, &hb[2], 8);
         omega = nr / (mnorm * ny + nx);
         if (!(omega == omega) || !(ny == ny))
-            throw_singular();
+            throw Error(MISPEC_EINVAL, "SparseSymShiftSolve: factorization failed with the given shift (the probe solve is not finite; " +
+                                           std::to_string(fs.boosts) + " boosted pivots)");
         if (omega <= kTarget)
             break;
-        if (it == kMaxRefine || (it >= 2 && omega > 0.5 * prev))
+        if (it == kMaxRefine || (it >= 2 && omega > 0.9 * prev))
         {
             // stagnation: accept when the probe is still solved to 1e-13 (the error then sits below the eigensolver's
             // tolerances), otherwise the shift is (numerically) singular for this factorisation
             if (omega <= 1e-13)
                 break;
-            throw_singular();
+            throw Error(MISPEC_EINVAL, "SparseSymShiftSolve: factorization failed with the given shift (iterative refinement stalls at backward error " +
+                                           std::to_string(omega) + " after " + std::to_string(it) + " steps; " + std::to_string(fs.boosts) +
+                                           " boosted pivots, smallest pivot ratio " + std::to_string(fs.min_pivot_ratio) + ")");
         }
         prev = omega;
         S.refine_steps = it + 1;
@@ -1152,6 +1317,18 @@ void launch_shiftsolve(const mispec_symshift& S, const double* x_dev, double* y_
     }
 }
 
+}  // namespace mispec
+
+namespace mispec {
+void launch_band_cholesky_solve(const mispec_symshift& S, bool upper, const double* x_dev, double* y_dev)
+{
+    if (!S.factored || S.dense || !S.cholesky_ready)
+        throw Error(MISPEC_ELOGIC, "SparseCholesky (banded): the factorisation is not available");
+    if (upper)
+        chol_backward(*S.ctx, *S.top, x_dev, y_dev);
+    else
+        chol_forward(*S.ctx, *S.top, x_dev, y_dev);
+}
 }  // namespace mispec
 
 mispec_symshift::~mispec_symshift() {}
@@ -1360,11 +1537,46 @@ extern "C" int mispec_symshift_set_shift(mispec_symshift* S, double sigma)
                     for (int64_t i = 0; i < n; i++)
                         M.at(i, 0) -= sigma;
             }
-            S->top = std::make_unique<BandLevel>();
-            FactorStats fs;
-            factor_level(S->ctx, M, *S->top, fs);
+            // Up to four attempts with the separators moved by one row each time: an attempt fails when the calibration
+            // of the iterative refinement does not converge (singular chunk interiors of a nonsingular matrix)
             S->dense = false;
-            calibrate_refinement(*S, fs);
+            for (int attempt = 0;; attempt++)
+            {
+                g_chunk_bias = attempt < 4 ? attempt : 0;
+                g_single_chunk = attempt == 4;
+                try
+                {
+                    HostBand Mt = M;  // factor_level consumes its argument
+                    if (Mt.view && !factored_on_device(n, Mt.b))
+                    {
+                        // the attempt factors this level on the host: it needs the shifted band itself, not the device view
+                        Mt.a.resize(S->band0.size());
+                        for (size_t e = 0; e < Mt.a.size(); e++)
+                            Mt.a[e] = S->band0[e] - sigma * (S->pencil ? S->bandB0[e] : ((e % size_t(Mt.b + 1)) == 0 ? 1.0 : 0.0));
+                        Mt.view = nullptr;
+                        Mt.view_dev = nullptr;
+                        Mt.viewB = nullptr;
+                        Mt.viewB_dev = nullptr;
+                    }
+                    S->top = std::make_unique<BandLevel>();
+                    FactorStats fs;
+                    fs.want_cholesky = S->want_cholesky;
+                    factor_level(S->ctx, Mt, *S->top, fs);
+                    calibrate_refinement(*S, fs);
+                    S->negative_pivots = fs.negative;
+                    S->cholesky_ready = S->want_cholesky && fs.negative == 0 && fs.boosts == 0;
+                    g_chunk_bias = 0;
+                    g_single_chunk = false;
+                    break;
+                }
+                catch (const Error& e)
+                {
+                    g_chunk_bias = 0;
+                    g_single_chunk = false;
+                    if (attempt == 4 || (attempt == 3 && n > kPivotedLimit))
+                        throw Error(e.code, std::string(e.what()) + " [n = " + std::to_string(n) + ", " + std::to_string(attempt + 1) + " attempts]");
+                }
+            }
         }
         else if (n <= kMaxDense)
         {

@@ -43,6 +43,10 @@ struct mispec_symshift
     long long boosted_pivots = 0;
     double min_pivot_ratio = 1.0;
     int refine_steps = 0;
+    // SparseCholesky beyond the dense limit (cholesky.hip): factor the band itself (sigma = 0) and keep what G^{-1} / G^{-T}
+    // need; cholesky_ready only when every pivot of every level was positive (the matrix is positive definite)
+    bool want_cholesky = false, cholesky_ready = false;
+    long long negative_pivots = 0;
     double probe_backward_error = 0.0;  // of the calibrated solve
     mutable mispec::DevBuf<double> ref_r, ref_dy;
     ~mispec_symshift();
@@ -51,4 +55,7 @@ struct mispec_symshift
 namespace mispec {
 // y = (A - sigma I)^{-1} x, device pointers of n doubles, enqueued on the context stream
 void launch_shiftsolve(const mispec_symshift& S, const double* x_dev, double* y_dev);
+// y = G^{-1} x (upper == false) / y = G^{-T} x (upper == true) for the factor G G' = A of a positive definite banded A that
+// was factored with want_cholesky and sigma = 0
+void launch_band_cholesky_solve(const mispec_symshift& S, bool upper, const double* x_dev, double* y_dev);
 }  // namespace mispec

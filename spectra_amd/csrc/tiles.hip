@@ -26,6 +26,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace mispec {
@@ -37,6 +38,7 @@ bool build_tiles(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int3
     if (ncb > 65535 || nrows <= 0)
         return false;
     const int64_t nseg = (nrows + kTileRows - 1) / kTileRows;
+    T.ncb = ncb;
     T.seg_entry.assign(size_t(nseg) + 1, 0);
     T.seg_chunk.assign(size_t(nseg) + 1, 0);
     const int64_t nnz = rowptr[nrows] - rowptr[0];
@@ -213,115 +215,196 @@ __device__ __forceinline__ double rounded_add(double a, double b)
     return s;
 }
 
-template <bool EPI>
+// Loose barrier among the workgroups of one group (the ~160 workgroups an XCD holds: blockIdx % 8): keeps the sweeps over
+// the column blocks in step, so that the group's gathers stay inside the 1-3 MiB of x its L2 holds.  Thread 0 arrives on a
+// monotonic counter and polls it; a wait that outlasts `spin_cap` polls gives up for the rest of the launch (a workgroup
+// that is not resident can therefore never hang the others — only the locality is lost).
+struct TileSync
+{
+    unsigned int* counter;  // 8 counters (one per XCD, 128 bytes apart), zero at launch
+    int period;             // barrier every `period` column blocks; 0: no synchronisation (one segment per workgroup)
+    int group_size;         // workgroups per group
+    int sweeps;             // segments per workgroup (idle sweeps only pass the barriers)
+    int ncb;                // column blocks
+    int spin_cap;
+    unsigned int zero;      // 0 (a value the compiler cannot fold)
+    int xload;              // how x is gathered: 0 plain loads, 1 non-temporal, 2 system scope (L2 bypass) — MISPEC_TILES_XLOAD
+};
+
+// The counter lives in the L2 of the group's own XCD: read-modify-writes without the agent-scope cache-bypass bits are
+// executed there (atomics never run in the per-CU L1), so arriving and polling cost an L2 round trip instead of a trip to
+// memory; the XCDs' L2s are not coherent with each other, which is why every XCD has its own counter and only its own
+// workgroups (hardware register XCC_ID) touch it.
+__device__ __forceinline__ void tile_group_barrier(const TileSync& ts, int xcd, unsigned int target, bool& give_up)
+{
+    if (threadIdx.x == 0 && !give_up)
+    {
+        unsigned int* c = ts.counter + xcd * 32;  // one 128-byte line per counter
+        __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        int spins = 0;
+        // polled with a read-modify-write of a run-time zero: a plain (even atomic) load could be served by this CU's L1 forever
+        while (__hip_atomic_fetch_add(c, ts.zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target)
+        {
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > ts.spin_cap)
+            {
+                give_up = true;
+                break;
+            }
+        }
+    }
+}
+
+template <int XL>
+__device__ __forceinline__ double tile_load_x(const double* p)
+{
+    if (XL == 1)
+        return __builtin_nontemporal_load(p);
+    if (XL == 2)
+        return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return *p;
+}
+
+template <bool EPI, int XL>
 __global__ __launch_bounds__(256) void k_spmv_tiles(const int64_t* __restrict__ seg_entry, const int32_t* __restrict__ seg_chunk,
                                                     const TileChunk* __restrict__ chunks, const double* __restrict__ val,
                                                     const uint32_t* __restrict__ idx, const double* __restrict__ x, double* __restrict__ y,
-                                                    int64_t nrows, int nblocks256, SpmvEpilogue epi)
+                                                    int64_t nrows, int nblocks256, int nseg, SpmvEpilogue epi, TileSync ts)
 {
     __shared__ double acc[kTileRows];  // exactly 32 KiB: five workgroups per CU
     if (EPI && epi.status && *epi.status != 0)
         return;
-    const int seg = blockIdx.x;
     const int tid = threadIdx.x;
-    for (int r = tid; r < kTileRows; r += 256)
-        acc[r] = 0.0;
-    const int c0 = seg_chunk[seg], c1 = seg_chunk[seg + 1];
-    const int64_t base = seg_entry[seg];
     constexpr int kPer = kTileChunk / 256;  // entries per thread and chunk
-    double v[kPer], nv[kPer];
-    uint32_t id[kPer], nid[kPer];
-    int off = (c0 < c1) ? chunks[c0].offset : 0;
-#pragma unroll
-    for (int k = 0; k < kPer; k++)
+    bool give_up = false;         // thread 0 only
+    unsigned int arrivals = 0;    // barriers passed so far (all sweeps)
+    // XCC_ID: the XCD this workgroup runs on (hwreg 20, bits 3:0); workgroups are dealt round-robin, gridDim.x / 8 per XCD
+    const int xcd = ts.period > 0 ? int(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) : 0;
+    const int nsweep = ts.period > 0 ? ts.sweeps : 1;
+    for (int sweep = 0; sweep < nsweep; sweep++)
     {
-        v[k] = __builtin_nontemporal_load(val + base + off + k * 256 + tid);  // streamed once: keep x in the L2
-        id[k] = __builtin_nontemporal_load(idx + base + off + k * 256 + tid);
-    }
-    __syncthreads();
-    for (int ci = c0; ci < c1; ci++)
-    {
-        const TileChunk ch = chunks[ci];
-        const int count = ch.count;
-        // the next chunk's entries follow this chunk's: issue their loads now (the arrays end with a chunk of slack)
-        const int noff = off + count;
-#pragma unroll
-        for (int k = 0; k < kPer; k++)
+        const int seg = int(blockIdx.x) + sweep * int(gridDim.x);
+        int next_sync = ts.period;  // first column block that lies behind the next barrier
+        if (seg < nseg)
         {
-            nv[k] = __builtin_nontemporal_load(val + base + noff + k * 256 + tid);
-            nid[k] = __builtin_nontemporal_load(idx + base + noff + k * 256 + tid);
-        }
-        const int64_t col0 = int64_t(ch.colblock) << kTileColBits;
-        double p[kPer];
-        int run[kPer];
+            for (int r = tid; r < kTileRows; r += 256)
+                acc[r] = 0.0;
+            const int c0 = seg_chunk[seg], c1 = seg_chunk[seg + 1];
+            const int64_t base = seg_entry[seg];
+            double v[kPer], nv[kPer];
+            uint32_t id[kPer], nid[kPer];
+            int off = (c0 < c1) ? chunks[c0].offset : 0;
 #pragma unroll
-        for (int k = 0; k < kPer; k++)
-        {
-            const bool live = (k * 256 + tid < count) && id[k] != kTileSkip;
-            run[k] = live ? int(id[k] & uint32_t(kTileMaxRun)) : 0;
-            const int64_t col = live ? col0 + int64_t((id[k] >> kTileRunBits) & uint32_t(kTileCols - 1)) : col0;
-            p[k] = live ? rounded_product(v[k], x[col]) : 0.0;
-        }
-#pragma unroll
-        for (int k = 0; k < kPer; k++)
-        {
-            // head lanes add the products of their run in order: own, then the next lanes' (a run never leaves its wavefront)
-            const int row = int(id[k] >> (kTileColBits + kTileRunBits)) & (kTileRows - 1);
-            double a = (run[k] > 0) ? acc[row] : 0.0;
-            a = rounded_add(a, p[k]);
-            for (int j = 1; j < kTileMaxRun; j++)
+            for (int k = 0; k < kPer; k++)
             {
-                if (__ballot(run[k] > j) == 0ull)
-                    break;
-                const double pj = __shfl_down(p[k], j, 64);
-                if (run[k] > j)
-                    a = rounded_add(a, pj);
+                v[k] = __builtin_nontemporal_load(val + base + off + k * 256 + tid);  // streamed once: keep x in the L2
+                id[k] = __builtin_nontemporal_load(idx + base + off + k * 256 + tid);
             }
-            if (run[k] > 0)
-                acc[row] = a;
-        }
-        __syncthreads();  // the next chunk may address the same rows from other lanes
-        off = noff;
+            __syncthreads();
+            for (int ci = c0; ci < c1; ci++)
+            {
+                const TileChunk ch = chunks[ci];
+                const int count = ch.count;
+                // the next chunk's entries follow this chunk's: issue their loads now (the arrays end with a chunk of slack)
+                const int noff = off + count;
 #pragma unroll
-        for (int k = 0; k < kPer; k++)
-        {
-            v[k] = nv[k];
-            id[k] = nid[k];
-        }
-    }
-    // rows of the segment -> y, in the 256-row blocks of the CSR kernels (identical alpha partial records)
-    const int64_t row0 = int64_t(seg) * kTileRows;
+                for (int k = 0; k < kPer; k++)
+                {
+                    nv[k] = __builtin_nontemporal_load(val + base + noff + k * 256 + tid);
+                    nid[k] = __builtin_nontemporal_load(idx + base + noff + k * 256 + tid);
+                }
+                if (ts.period > 0 && next_sync <= int(ch.colblock))
+                {
+                    while (next_sync <= int(ch.colblock))  // do not run ahead of the group into the next piece of x
+                    {
+                        arrivals++;
+                        tile_group_barrier(ts, xcd, arrivals * unsigned(ts.group_size), give_up);
+                        next_sync += ts.period;
+                    }
+                    __syncthreads();  // the whole workgroup waits for thread 0's wait
+                }
+                const int64_t col0 = int64_t(ch.colblock) << kTileColBits;
+                double p[kPer];
+                int run[kPer];
+#pragma unroll
+                for (int k = 0; k < kPer; k++)
+                {
+                    const bool live = (k * 256 + tid < count) && id[k] != kTileSkip;
+                    run[k] = live ? int(id[k] & uint32_t(kTileMaxRun)) : 0;
+                    const int64_t col = live ? col0 + int64_t((id[k] >> kTileRunBits) & uint32_t(kTileCols - 1)) : col0;
+                    p[k] = live ? rounded_product(v[k], tile_load_x<XL>(x + col)) : 0.0;
+                }
+#pragma unroll
+                for (int k = 0; k < kPer; k++)
+                {
+                    // head lanes add the products of their run in order: own, then the next lanes' (a run never leaves its wavefront)
+                    const int row = int(id[k] >> (kTileColBits + kTileRunBits)) & (kTileRows - 1);
+                    double a = (run[k] > 0) ? acc[row] : 0.0;
+                    a = rounded_add(a, p[k]);
+                    for (int j = 1; j < kTileMaxRun; j++)
+                    {
+                        if (__ballot(run[k] > j) == 0ull)
+                            break;
+                        const double pj = __shfl_down(p[k], j, 64);
+                        if (run[k] > j)
+                            a = rounded_add(a, pj);
+                    }
+                    if (run[k] > 0)
+                        acc[row] = a;
+                }
+                __syncthreads();  // the next chunk may address the same rows from other lanes
+                off = noff;
+#pragma unroll
+                for (int k = 0; k < kPer; k++)
+                {
+                    v[k] = nv[k];
+                    id[k] = nid[k];
+                }
+            }
+            // rows of the segment -> y, in the 256-row blocks of the CSR kernels (identical alpha partial records)
+            const int64_t row0 = int64_t(seg) * kTileRows;
 #pragma unroll 1
-    for (int j = 0; j < kTileRows / 256; j++)
-    {
-        const int64_t row = row0 + j * 256 + tid;
-        const int64_t blk = row0 / 256 + j;
-        if (blk >= nblocks256)
-            break;
-        double contrib = 0.0;
-        if (row < nrows)
-        {
-            double yv = acc[j * 256 + tid];
-            if (EPI)
+            for (int j = 0; j < kTileRows / 256; j++)
             {
-                if (epi.v_prev)
-                    yv -= (epi.h_prev_dev ? *epi.h_prev_dev : epi.h_prev) * epi.v_prev[row];  // Lanczos.h:139
-                contrib = epi.v_rows[row] * yv;                                                 // Lanczos.h:142
+                const int64_t row = row0 + j * 256 + tid;
+                const int64_t blk = row0 / 256 + j;
+                if (blk >= nblocks256)
+                    break;
+                double contrib = 0.0;
+                if (row < nrows)
+                {
+                    double yv = acc[j * 256 + tid];
+                    if (EPI)
+                    {
+                        if (epi.v_prev)
+                            yv -= (epi.h_prev_dev ? *epi.h_prev_dev : epi.h_prev) * epi.v_prev[row];  // Lanczos.h:139
+                        contrib = epi.v_rows[row] * yv;                                                 // Lanczos.h:142
+                    }
+                    y[row] = yv;
+                }
+                if (EPI)
+                {
+                    // cross-wave sum through the accumulator slots of this block, which every thread has read by now
+                    const double t = tile_wave_sum(contrib);
+                    __syncthreads();
+                    double* red = acc + j * 256;
+                    if ((tid & 63) == 0)
+                        red[tid >> 6] = t;
+                    __syncthreads();
+                    if (tid == 0)
+                        epi.partials[blk] = (red[0] + red[1]) + (red[2] + red[3]);
+                }
             }
-            y[row] = yv;
+            __syncthreads();  // acc is reused by the next sweep
         }
-        if (EPI)
-        {
-            // cross-wave sum through the accumulator slots of this block, which every thread has read by now
-            const double t = tile_wave_sum(contrib);
-            __syncthreads();
-            double* red = acc + j * 256;
-            if ((tid & 63) == 0)
-                red[tid >> 6] = t;
-            __syncthreads();
-            if (tid == 0)
-                epi.partials[blk] = (red[0] + red[1]) + (red[2] + red[3]);
-        }
+        // the barriers of this sweep that the segment's chunks did not reach (empty trailing tiles, idle sweep)
+        if (ts.period > 0)
+            while (next_sync < ts.ncb + ts.period)
+            {
+                arrivals++;
+                tile_group_barrier(ts, xcd, arrivals * unsigned(ts.group_size), give_up);
+                next_sync += ts.period;
+            }
     }
 }
 }  // namespace
@@ -342,27 +425,75 @@ void upload_tiles(const HostTiles& H, hipStream_t stream, DevTiles& D)
     D.entries = int64_t(H.val.size()) - kTileChunk;
     D.nchunks = int64_t(H.chunks.size());
     D.padding = H.padding;
+    D.ncb = H.ncb;
+    D.sync_counters.alloc(8 * 32);
+    MISPEC_HIP(hipMemset(D.sync_counters.p, 0, 8 * 32 * sizeof(unsigned int)));
 }
 
 void launch_spmv_tiles(const DevTiles& T, hipStream_t stream, const double* x, double* y, int64_t nrows, int nblocks256,
                        const SpmvEpilogue* epi, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
-    const dim3 grid(static_cast<unsigned>(T.nseg)), block(256);
     const SpmvEpilogue e = epi ? *epi : SpmvEpilogue{};
-#define MISPEC_TILES(E)                                                                                                     \
+    // MISPEC_TILES_SYNC=k: persistent workgroups (as many as are resident at once), each sweeping several segments, with a
+    // loose barrier per XCD group every k column blocks so that the sweeps stay in step and the gathers stay in the L2;
+    // 0: one workgroup per segment, free-running.
+    static const int period = getenv("MISPEC_TILES_SYNC") ? atoi(getenv("MISPEC_TILES_SYNC")) : 0;
+    static const int xload = getenv("MISPEC_TILES_XLOAD") ? atoi(getenv("MISPEC_TILES_XLOAD")) : 0;
+    TileSync ts{nullptr, 0, 0, 1, int(T.ncb), 0, 0u, xload};
+    dim3 grid(static_cast<unsigned>(T.nseg)), block(256);
+    if (period > 0 && T.sync_counters.p)
+    {
+        static int resident = 0;
+        if (!resident)
+        {
+            int per_cu = 0, dev = 0;
+            hipDeviceProp_t prop;
+            MISPEC_HIP(hipGetDevice(&dev));
+            MISPEC_HIP(hipGetDeviceProperties(&prop, dev));
+            int per_cu2 = 0;
+            MISPEC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_spmv_tiles<true, 0>), 256, 0));
+            MISPEC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, reinterpret_cast<const void*>(&k_spmv_tiles<false, 0>), 256, 0));
+            // one below what the occupancy calculator allows (5 x 32 KiB is the whole LDS of a CU: measured, the fifth
+            // workgroup is not resident), overridable for experiments
+            per_cu = std::max(1, std::min(per_cu, per_cu2) - 1);
+            if (getenv("MISPEC_TILES_WG_PER_CU"))
+                per_cu = std::max(1, atoi(getenv("MISPEC_TILES_WG_PER_CU")));
+            resident = std::max(8, per_cu * prop.multiProcessorCount / 8 * 8);
+        }
+        const int g = int(std::min<int64_t>(resident, (T.nseg + 7) / 8 * 8));
+        grid = dim3(static_cast<unsigned>(g));
+        ts.counter = T.sync_counters.p;
+        ts.period = period;
+        ts.group_size = g / 8;
+        ts.sweeps = int((T.nseg + g - 1) / g);
+        ts.spin_cap = 20000;  // ~ a few ms of polling: far beyond any healthy wait
+        MISPEC_HIP(hipMemsetAsync(T.sync_counters.p, 0, 8 * 32 * sizeof(unsigned int), stream));
+    }
+#define MISPEC_TILES(E, X)                                                                                                  \
     do                                                                                                                      \
     {                                                                                                                       \
         if (ev_start && ev_stop)                                                                                            \
-            hipExtLaunchKernelGGL((k_spmv_tiles<E>), grid, block, 0, stream, ev_start, ev_stop, 0, T.seg_entry.p, T.seg_chunk.p, \
-                                  T.chunks.p, T.val.p, T.idx.p, x, y, nrows, nblocks256, e);                               \
+            hipExtLaunchKernelGGL((k_spmv_tiles<E, X>), grid, block, 0, stream, ev_start, ev_stop, 0, T.seg_entry.p, T.seg_chunk.p, \
+                                  T.chunks.p, T.val.p, T.idx.p, x, y, nrows, nblocks256, int(T.nseg), e, ts);              \
         else                                                                                                                \
-            hipLaunchKernelGGL((k_spmv_tiles<E>), grid, block, 0, stream, T.seg_entry.p, T.seg_chunk.p, T.chunks.p, T.val.p, \
-                               T.idx.p, x, y, nrows, nblocks256, e);                                                       \
+            hipLaunchKernelGGL((k_spmv_tiles<E, X>), grid, block, 0, stream, T.seg_entry.p, T.seg_chunk.p, T.chunks.p, T.val.p, \
+                               T.idx.p, x, y, nrows, nblocks256, int(T.nseg), e, ts);                                      \
+    } while (0)
+#define MISPEC_TILES_X(E)        \
+    do                           \
+    {                            \
+        if (xload == 1)          \
+            MISPEC_TILES(E, 1);  \
+        else if (xload == 2)     \
+            MISPEC_TILES(E, 2);  \
+        else                     \
+            MISPEC_TILES(E, 0);  \
     } while (0)
     if (epi)
-        MISPEC_TILES(true);
+        MISPEC_TILES_X(true);
     else
-        MISPEC_TILES(false);
+        MISPEC_TILES_X(false);
+#undef MISPEC_TILES_X
 #undef MISPEC_TILES
     MISPEC_HIP(hipGetLastError());
 }

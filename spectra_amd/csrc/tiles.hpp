@@ -33,6 +33,7 @@ struct HostTiles
     std::vector<double> val;          // padded entries carry 0.0
     std::vector<uint32_t> idx;
     int64_t padding = 0;              // padding entries inserted
+    int64_t ncb = 0;                  // column blocks
 };
 
 // Build the tiles of rows [0, nrows) of a CSR matrix (rows sorted by column, no duplicates).  Returns false (nothing
@@ -48,7 +49,8 @@ struct DevTiles
     DevBuf<TileChunk> chunks;
     DevBuf<double> val;
     DevBuf<uint32_t> idx;
-    int64_t nseg = 0, entries = 0, nchunks = 0, padding = 0;
+    DevBuf<unsigned int> sync_counters;  // the loose per-XCD barrier of the persistent variant (MISPEC_TILES_SYNC)
+    int64_t nseg = 0, entries = 0, nchunks = 0, padding = 0, ncb = 0;
     bool present() const { return nseg > 0; }
     void swap(DevTiles& o)
     {
@@ -57,6 +59,8 @@ struct DevTiles
         chunks.swap(o.chunks);
         val.swap(o.val);
         idx.swap(o.idx);
+        sync_counters.swap(o.sync_counters);
+        std::swap(ncb, o.ncb);
         std::swap(nseg, o.nseg);
         std::swap(entries, o.entries);
         std::swap(nchunks, o.nchunks);

@@ -146,8 +146,60 @@ def test_sparse_cholesky_operator(ctx):
     assert bad.info() == sa.CompInfo.NumericalIssue
     with pytest.raises(ValueError, match="positive definite"):
         sa.SymGEigsSolver(sa.SparseSymMatProd(sp.identity(3, format="csc"), ctx=ctx), bad, 1, 2, "Cholesky")
-    with pytest.raises(ValueError, match="4096"):
-        sa.SparseCholesky(sp.identity(5000, format="csc"), ctx=ctx)
+    with pytest.raises(ValueError, match="banded"):          # large and not banded: regular-inverse mode is the way
+        sa.SparseCholesky(sp.random(5000, 5000, density=2e-3, random_state=0, format="csc") + 10 * sp.identity(5000, format="csc"), ctx=ctx)
+
+
+def banded_pd(n, b, seed):
+    rng = np.random.default_rng(seed)
+    diags = [rng.uniform(-0.5, 0.5, n - d) for d in range(1, b + 1)]
+    return sp.diags([rng.uniform(0.0, 1.0, n) + b + 0.5] + diags + diags, [0] + list(range(1, b + 1)) + [-d for d in range(1, b + 1)], format="csc")
+
+
+@pytest.mark.parametrize("n,b", [(5000, 1), (20_000, 3), (300_001, 2), (1_000_000, 4)])
+def test_banded_cholesky_beyond_the_dense_limit(ctx, n, b):
+    # SparseCholesky for n > 4096: a banded B is factored by the partitioned band factorisation;
+    # lower_triangular_solve / upper_triangular_solve are G^{-1} x and G^{-T} x of a factor with G G' = B (any such factor
+    # gives the same generalized eigenpairs — the reference's own L is that of a fill-reducing permutation)
+    import scipy.sparse.linalg as spla
+
+    B = banded_pd(n, b, seed=n)
+    Bop = sa.SparseCholesky(sp.tril(B).tocsc(), ctx=ctx)
+    assert Bop.info() == sa.CompInfo.Successful
+    x = np.random.default_rng(1).uniform(-1, 1, n)
+    u = Bop.lower_triangular_solve(x)                 # G^{-1} x
+    z = Bop.upper_triangular_solve(u)                 # G^{-T} G^{-1} x = B^{-1} x
+    ref = spla.splu(B).solve(x)
+    assert np.abs(z - ref).max() <= 1e-11 * np.abs(ref).max()
+    # G^{-1} B G^{-T} = I  on a probe vector, and |G^{-1} x|^2 = x' B^{-1} x
+    w = Bop.lower_triangular_solve(B @ Bop.upper_triangular_solve(x))
+    assert np.abs(w - x).max() <= 1e-11
+    assert abs(u @ u - x @ ref) <= 1e-11 * abs(x @ ref)
+    notpd = B - (b + 1.0) * sp.identity(n, format="csc")
+    assert sa.SparseCholesky(sp.tril(notpd).tocsc(), ctx=ctx).info() == sa.CompInfo.NumericalIssue
+
+
+def test_cholesky_mode_on_a_large_banded_pencil(ctx):
+    # SymGEigsSolver<SparseSymMatProd, SparseCholesky, GEigsMode::Cholesky> at n = 200 000 (was limited to 4096): against
+    # the regular-inverse mode of the same pencil (another algorithm: B^{-1} A with B-inner products) and scipy
+    import scipy.sparse.linalg as spla
+
+    n = 200_000
+    rp, ci, v = O.synth_band_csr(n, offsets=(1, 2, 3, 50, 51))
+    A = sp.csr_matrix((v, ci, rp), shape=(n, n))
+    B = sp.diags([np.full(n - 1, 1.0 / 6.0), np.full(n, 4.0 / 6.0), np.full(n - 1, 1.0 / 6.0)], [-1, 0, 1], format="csc")
+    aop = sa.SparseSymMatProd(sp.tril(A).tocsc(), ctx=ctx)
+    eigs = sa.SymGEigsSolver(aop, sa.SparseCholesky(B, ctx=ctx), 6, 24, "Cholesky")
+    eigs.init()
+    assert eigs.compute(sa.SortRule.LargestAlge, 1000, 1e-10) == 6
+    ev, U = eigs.eigenvalues(), eigs.eigenvectors()
+    res = np.linalg.norm(A @ U - (B @ U) * ev, axis=0) / np.linalg.norm(B @ U, axis=0)
+    assert res.max() <= 1e-8
+    assert np.abs(U.T @ (B @ U) - np.eye(6)).max() <= 1e-9            # B-orthonormal (SymGEigsSolver.h:196-207)
+    ri = sa.SymGEigsSolver(aop, sa.SparseRegularInverse(B, ctx=ctx), 6, 24)
+    ri.init()
+    assert ri.compute(sa.SortRule.LargestAlge, 1000, 1e-10) == 6
+    assert np.abs(ri.eigenvalues() - ev).max() <= 1e-8
 
 
 @pytest.mark.parametrize("n,prob,k,m", GEIGS_CASES)

@@ -37,7 +37,8 @@ def run_sharded(world, n, offsets, nev, ncv, rule, tol, exchange=None):
             nconv = eigs.compute(rule, 1000, tol)
             results[rank] = dict(nconv=nconv, info=eigs.info(), evals=eigs.eigenvalues(), X=eigs.eigenvectors(),
                                  nops=eigs.num_operations(), niter=eigs.num_iterations(), res=eigs.residuals(),
-                                 rows=sa.shard_range(n, world, rank), local=op.local_rows(), exchange=eigs.exchange_info())
+                                 rows=sa.shard_range(n, world, rank), local=op.local_rows(), exchange=eigs.exchange_info(),
+                                 overlap=eigs.overlap_info())
         except Exception as e:  # noqa: BLE001
             errors.append((rank, repr(e)))
 
@@ -120,3 +121,26 @@ def test_sharded_wide_basis(ctx):
         assert r["nconv"] == nev and np.array_equal(r["evals"], res[0]["evals"])
         assert r["res"].max() <= 1e-10
     assert np.abs(res[0]["evals"] - single.eigenvalues()).max() < 1e-10
+
+
+@pytest.mark.parametrize("world,exchange", [(2, None), (3, None), (2, "allgather")])
+def test_exchange_overlapped_with_the_local_rows_changes_nothing(world, exchange):
+    # The row-blocks that read only the rank's own slice are multiplied while the exchange runs on a second stream
+    # (SURVEY.md 8e); same kernels on the same blocks => bit-identical to the run without overlap (MISPEC_OVERLAP=0).
+    import os
+
+    n, offsets, nev, ncv = 120_001, (1, 2, 3, 50, 51, 1500, 1501), 6, 20
+    with_overlap = run_sharded(world, n, offsets, nev, ncv, sa.SortRule.LargestMagn, 1e-11, exchange=exchange)
+    os.environ["MISPEC_OVERLAP"] = "0"
+    try:
+        without = run_sharded(world, n, offsets, nev, ncv, sa.SortRule.LargestMagn, 1e-11, exchange=exchange)
+    finally:
+        del os.environ["MISPEC_OVERLAP"]
+    for a, b in zip(with_overlap, without):
+        first, count, total = a["overlap"]
+        assert count >= total - 2 * 7 and count < total       # all but the blocks within 1501 rows of a shard boundary
+        assert b["overlap"][1] == 0
+        assert a["nconv"] == b["nconv"] == nev
+        assert np.array_equal(a["evals"], b["evals"]) and np.array_equal(a["X"], b["X"])
+        assert (a["nops"], a["niter"]) == (b["nops"], b["niter"])
+        assert a["res"].max() <= 1e-10
