@@ -27,6 +27,7 @@
 // Bound: HBM.  Algorithmic bytes per launch: 12*nnz + 4*(rows+1) + 8*cols + 8*rows (CSR with int32
 // indices); the offset-coded variant's compulsory traffic is 9*nnz + ... .
 #include "csr.hpp"
+#include "krylov.hpp"
 #include "reorder.hpp"
 
 #include <hip/hip_ext.h>
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(256) void k_spmv_dia(DiaArgs da, const double* __re
 // The same product with the x entries of a row-block staged through LDS: the offsets cluster, so a block of 256 rows reads
 // a few contiguous windows of x (coalesced, once) instead of one 8-byte load per row and diagonal through the L1.
 // NG = groups of eight diagonals whose values a thread keeps in registers.
-template <bool EPI, int NG>
+template <bool EPI, int NG, bool FUSE = false>
 __global__ __launch_bounds__(256) void k_spmv_dia_win(DiaArgs da, mispec_dia_windows w, const double* __restrict__ x,
                                                       double* __restrict__ y, int64_t nrows, int nblocks, SpmvEpilogue epi)
 {
@@ -401,6 +402,27 @@ __global__ __launch_bounds__(256) void k_spmv_dia_win(DiaArgs da, mispec_dia_win
     if (EPI && epi.status && *epi.status != 0)
         return;
     const int tid = threadIdx.x;
+    double beta = 1.0;
+    if (FUSE)
+    {
+        // the start of the Lanczos step that k_scale_step otherwise does (Lanczos.h:99-128 without the restart branch):
+        // every block takes the same decision from the same beta; one thread records it
+        StepState* st = static_cast<StepState*>(epi.scale_state);
+        beta = st->beta;
+        const bool first = (blockIdx.x == 0 && tid == 0);
+        if (beta < epi.scale_eps_sqrt)
+        {
+            if (first)
+            {
+                st->status = kStepSmallBeta;
+                st->stop_step = epi.scale_step;
+                st->stop_count = 0;
+            }
+            return;
+        }
+        if (first)
+            st->subd[epi.scale_step - 1] = beta;  // Lanczos.h:127-128
+    }
     const int64_t row0 = int64_t(lb) * 256;
     const int nr = int(min(int64_t(256), nrows - row0));
     int64_t vstride;
@@ -414,8 +436,12 @@ __global__ __launch_bounds__(256) void k_spmv_dia_win(DiaArgs da, mispec_dia_win
         for (int i = tid; i < w.len[c]; i += 256)
         {
             const int64_t col = g0 + w.start[c] + i;
-            xs[w.base[c] + i] = x[min(max(col, int64_t(0)), int64_t(da.col_max))];
+            const double xv = x[min(max(col, int64_t(0)), int64_t(da.col_max))];
+            xs[w.base[c] + i] = FUSE ? xv / beta : xv;  // the same true division as k_scale_step: the same v, bit for bit
         }
+    double vown = 0.0;
+    if (FUSE)
+        vown = x[da.row_begin + row0 + min(tid, nr - 1)] / beta;
     __syncthreads();
     double acc = 0.0;
 #pragma unroll
@@ -430,9 +456,15 @@ __global__ __launch_bounds__(256) void k_spmv_dia_win(DiaArgs da, mispec_dia_win
             const int64_t row = row0 + tid;
             double yv = acc;
             if (epi.v_prev)
-                yv -= (epi.h_prev_dev ? *epi.h_prev_dev : epi.h_prev) * epi.v_prev[row];  // Lanczos.h:139
+                yv -= (FUSE ? beta : (epi.h_prev_dev ? *epi.h_prev_dev : epi.h_prev)) * epi.v_prev[row];  // Lanczos.h:139
             y[row] = yv;
-            contrib = epi.v_rows[row] * yv;  // Lanczos.h:142 partial <v, w>
+            if (FUSE)
+            {
+                epi.v_out[row] = vown;  // Lanczos.h:106
+                contrib = vown * yv;
+            }
+            else
+                contrib = epi.v_rows[row] * yv;  // Lanczos.h:142 partial <v, w>
         }
         const double total = block_reduce_sum(contrib, red);
         if (tid == 0)
@@ -905,6 +937,15 @@ void interior_blocks(const mispec_csr& A, int64_t col_lo, int64_t col_hi, int& f
     count = best;
 }
 
+bool spmv_can_fuse_scale(const mispec_csr& A)
+{
+    static const bool win_on = getenv("MISPEC_SPMV_DIA_WIN") ? atoi(getenv("MISPEC_SPMV_DIA_WIN")) != 0 : true;
+    // opt-in: measured (profiles/r02n_ab_fuse_scale.jsonl) the fused launch saves the 29 us scaling pass but the divisions in
+    // the window fill cost the SpMV 16 us — 1707.7 vs 1707.3 ms per solve, no gain, and a lower fraction for the timed kernel
+    static const bool fuse_on = getenv("MISPEC_FUSE_SCALE") ? atoi(getenv("MISPEC_FUSE_SCALE")) != 0 : false;
+    return fuse_on && win_on && !A.reordered() && A.row_begin == 0 && A.n_rows == A.n_cols && A.spmv_format() == 2 && A.dia_win.nc > 0;
+}
+
 bool spmv_codes_enabled()
 {
     static const bool on = getenv("MISPEC_SPMV_CODES") ? atoi(getenv("MISPEC_SPMV_CODES")) != 0 : true;
@@ -976,6 +1017,8 @@ void launch_spmv_raw(const mispec_csr& A, const double* x_dev, double* y_dev, co
         return;
     MISPEC_REQUIRE(block_first >= 0 && block_first + block_count <= all_blocks, "SpMV: row-block range out of bounds");
     const int nblocks = block_count;  // the kernels map blockIdx onto [first_block, first_block + nblocks)
+    MISPEC_REQUIRE(!(epi && epi->scale_state) || (spmv_can_fuse_scale(A) && block_count == all_blocks),
+                   "SpMV: a fused step start was requested for a matrix / launch that cannot take it");
     const int per = (nblocks + 7) >> 3;
     const int threads = spmv_rows_per_block();
     const dim3 grid(unsigned(per * 8)), block(static_cast<unsigned>(threads));
@@ -1021,7 +1064,30 @@ void launch_spmv_raw(const mispec_csr& A, const double* x_dev, double* y_dev, co
         else                         \
             MISPEC_DIA_WIN(E, 4);    \
     } while (0)
-            if (epi)
+            if (epi && e.scale_state)
+            {
+                MISPEC_REQUIRE(block_count == all_blocks && A.row_begin == 0, "SpMV: the fused step start needs the whole unsharded matrix");
+#define MISPEC_DIA_WIN_FUSED(G)                                                                                                       \
+    do                                                                                                                                \
+    {                                                                                                                                 \
+        if (ev_start && ev_stop)                                                                                                      \
+            hipExtLaunchKernelGGL((k_spmv_dia_win<true, G, true>), grid, block, lds, A.ctx->stream, ev_start, ev_stop, 0, da, A.dia_win, \
+                                  x_dev, y_dev, nloc, nblocks, e);                                                                    \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((k_spmv_dia_win<true, G, true>), grid, block, lds, A.ctx->stream, da, A.dia_win, x_dev, y_dev, nloc,   \
+                               nblocks, e);                                                                                           \
+    } while (0)
+                if (ng == 1)
+                    MISPEC_DIA_WIN_FUSED(1);
+                else if (ng == 2)
+                    MISPEC_DIA_WIN_FUSED(2);
+                else if (ng == 3)
+                    MISPEC_DIA_WIN_FUSED(3);
+                else
+                    MISPEC_DIA_WIN_FUSED(4);
+#undef MISPEC_DIA_WIN_FUSED
+            }
+            else if (epi)
                 MISPEC_DIA_WIN_G(true);
             else
                 MISPEC_DIA_WIN_G(false);

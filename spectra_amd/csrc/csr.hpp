@@ -98,7 +98,18 @@ struct SpmvEpilogue
     const int* status = nullptr;      // if set, the launch is a no-op unless *status == 0
     double* partials = nullptr;       // one double per block, deterministic second stage elsewhere
     int first_block = 0;              // set by the launcher: first 256-row block this launch covers
+    // Fused start of a device-driven Lanczos step (diagonal storage with x windows only; fac.hip decides): the input of the
+    // product is f / beta with beta read from the step state — x_dev points to f —, the normalised vector is written to
+    // v_out (the new basis column, Lanczos.h:106), H(i,i-1) = beta (:127-128) and the beta < sqrt(eps) stop of
+    // k_scale_step are taken here, and the <v, w> partials use the same f / beta.  Saves the separate scaling pass and the
+    // second read of v (2 x 8n bytes per step).
+    void* scale_state = nullptr;      // StepState* (krylov.hpp)
+    double* v_out = nullptr;
+    int scale_step = 0;
+    double scale_eps_sqrt = 0.0;
 };
+// true when launch_spmv_raw(A, ...) with an epilogue that carries scale_state would be honoured (else the caller must scale itself)
+bool spmv_can_fuse_scale(const ::mispec_csr& A);
 
 // MISPEC_SPMV_CODES=0 turns the offset-coded index format off (plain int32 column indices everywhere).
 bool spmv_codes_enabled();

@@ -106,6 +106,7 @@ struct mispec_fac
     // The matrix is stored reordered (P A P', reorder.hip) and this factorisation works in that order: start vectors are
     // permuted on the way in, V / f / Ritz vectors on the way out; plain operators only (product, generalized and
     // Cholesky operators use the order-preserving product instead)
+    int fuse_scale_step = 0;  // > 0 while apply_op is to fuse the start of that Lanczos step into the SpMV (csr.hpp SpmvEpilogue)
     bool perm_mode = false;
     bool x_original = false;  // the columns of X have been put back into the caller's order
     DevBuf<double> pscratch;
@@ -506,6 +507,13 @@ void apply_op(mispec_fac& F, const double* x_loc, double* y_loc, bool lanczos_ep
             epi.h_prev_dev = h_prev_dev;
             epi.status = status;
             epi.partials = F.alpha_partials.p;
+            if (F.fuse_scale_step > 0)
+            {
+                epi.scale_state = F.d_state.p;
+                epi.v_out = F.col(F.fuse_scale_step);
+                epi.scale_step = F.fuse_scale_step;
+                epi.scale_eps_sqrt = std::sqrt(kEps);
+            }
             if (overlap)
                 overlapped_spmv(F, *last, x, y_loc, &epi, e0, e1);
             else
@@ -900,11 +908,17 @@ void lanczos_step_device(mispec_fac& F, int i)
     const int kSpeculativeCorrections = speculative_corrections(F);
     StepState* st = F.d_state.p;
     double* v = F.col(i);
+    // With the diagonal-storage SpMV the start of the step (v = f / beta, H(i,i-1) = beta, the small-beta stop) can ride on the
+    // product itself when MISPEC_FUSE_SCALE=1: x is read as f / beta, v is written by the same launch (default: k_scale_step)
+    const bool fuse = F.A && !F.A2 && !F.Bop && !F.Chol && !F.sharded() && !F.perm_mode && spmv_can_fuse_scale(*F.A);
+    if (!fuse)
     {
         Timed t(F, FAM_SCALE);
         launch_scale_step(*F.ctx, F.f.p, v, F.ldv, st, i, std::sqrt(kEps));
     }
-    apply_op(F, v, F.w.p, true, F.col(i - 1), 0.0, &st->subd[i - 1], &st->status);
+    F.fuse_scale_step = fuse ? i : 0;
+    apply_op(F, fuse ? F.f.p : v, F.w.p, true, F.col(i - 1), 0.0, &st->subd[i - 1], &st->status);
+    F.fuse_scale_step = 0;
 
     const int i1 = i + 1;
     FinishArgs fin;

@@ -290,3 +290,29 @@ def test_wide_basis_at_scale(ctx):
     assert eigs.residuals().max() <= 1e-10
     ev = eigs.eigenvalues()
     assert np.all(np.diff(ev) <= 0)
+
+
+def test_step_start_fused_into_the_spmv_changes_nothing():
+    # Diagonal-storage matrices, MISPEC_FUSE_SCALE=1 (opt-in; measured: no gain): v = f / beta, H(i,i-1) = beta and the
+    # small-beta stop ride on the SpMV launch (csr.hip k_spmv_dia_win<.., FUSE>) instead of a separate k_scale_step pass; same
+    # division, same products => the same solve to the last bit as the default.
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); import spectra_amd as sa\n"
+        "op = sa.SparseSymMatProd.synth_band(300001)\n"
+        "assert op.spmv_format() == 2\n"
+        "e = sa.SymEigsSolver(op, 12, 30); e.init(); n = e.compute(sa.SortRule.LargestMagn, 1000, 1e-11)\n"
+        "X = e.eigenvectors()\n"
+        "p = e.get_profile()\n"
+        "print(n, e.num_operations(), e.num_iterations(), e.eigenvalues().tobytes().hex(), __import__('zlib').crc32(X.tobytes()), p['n_scale'])\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for fuse in ("1", "0"):
+        env = dict(os.environ, MISPEC_FUSE_SCALE=fuse)
+        r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        outs.append(r.stdout.split())
+    assert outs[0][:5] == outs[1][:5]
+    assert int(outs[0][5]) < int(outs[1][5]) // 4       # the separate scaling launches are gone
