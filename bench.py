@@ -295,13 +295,16 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 or args.gpus > 1 or os.environ.get("MISPEC_FORCE_COMM") == "1":
-        rank, world = sdist.init_process_group("nccl")
+        # MISPEC_COMM=gloo-staged (tests on a box with fewer GPUs than ranks): gloo process group, collectives staged through
+        # host memory, ranks beyond the device count share the last device — exercises this file's N > 1 path end to end
+        staged = os.environ.get("MISPEC_COMM") == "gloo-staged"
+        rank, world = sdist.init_process_group("gloo" if staged else "nccl")
         assert world == args.gpus, f"launched {world} ranks for --gpus {args.gpus}"
         using_dist = True
     else:
         rank, world = 0, 1
         using_dist = False
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = min(int(os.environ.get("LOCAL_RANK", "0")), torch.cuda.device_count() - 1)
     torch.cuda.set_device(local)
     ctx = sdist.make_context(local)
 
@@ -350,7 +353,7 @@ def main():
         chk, nconv_chk, _ = solve(False)
         r = chk.residuals()
         bad = int(nconv_chk < args.nev or not np.all(np.isfinite(r)) or float(r.max()) > 1e-8)
-        flag = torch.tensor([bad], dtype=torch.int32, device="cuda")
+        flag = torch.tensor([bad], dtype=torch.int32, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         if int(flag.item()) and chk.exchange_info()[0]:
             os.environ["MISPEC_EXCHANGE"] = "allgather"
@@ -391,15 +394,16 @@ def main():
     head = spmv_block(op, spmv_ms, prof["n_spmv"], True)
     alone_ms = standalone_ms(op, args.n if world == 1 else int(sa.lib().mispec_shard_block(args.n, world)) * world, args.spmv_reps)
 
+    transport_name = {"gloo-staged": "gloo (host-staged)", "torch": "torch.distributed (RCCL)"}.get(os.environ.get("MISPEC_COMM", "rccl"), "RCCL")
     if world == 1:
         exchange_desc = ""
     elif halo:
-        exchange_desc = (f", RCCL point-to-point exchange of the referenced parts of the Krylov vector per SpMV "
+        exchange_desc = (f", {transport_name} point-to-point exchange of the referenced parts of the Krylov vector per SpMV "
                          f"({recv_doubles * 8 / 1e6:.2f} MB received by rank 0; the all-gather would move "
                          f"{(world - 1) * int(sa.lib().mispec_shard_block(args.n, world)) * 8 / 1e6:.1f} MB; "
                          f"the all-gather variant is timed as well: `allgather_variant`)")
     else:
-        exchange_desc = ", RCCL all-gather of the Krylov vector per SpMV" + (f" ({exchange_note})" if exchange_note else "")
+        exchange_desc = f", {transport_name} all-gather of the Krylov vector per SpMV" + (f" ({exchange_note})" if exchange_note else "")
     if rank == 0:
         traffic, traffic_file = pmc_traffic(args.n, fmt) if world == 1 else (None, None)
         out = {

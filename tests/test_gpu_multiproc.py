@@ -63,3 +63,24 @@ def test_two_processes_equal_the_loopback_run(ctx, tmp_path, exchange):
     assert np.abs(single.eigenvalues() - procs[0]["evals"]).max() < 1e-10
     X = np.vstack([p["X"] for p in procs])
     assert np.abs(np.abs(np.sum(X * single.eigenvectors(), axis=0)) - 1.0).max() < 1e-8
+
+
+def test_bench_with_two_ranks_end_to_end(tmp_path):
+    # `python bench.py --gpus 2` as the driver starts it (a plain process): it must spawn its two ranks itself, run the
+    # self-check of the neighbour exchange, time the steps with both exchange modes and print ONE JSON line.  On this 1-GPU
+    # box the ranks share the device over the gloo-staged transport (MISPEC_COMM); the code path of the file is the same.
+    env = dict(os.environ, MISPEC_COMM="gloo-staged")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--size", "1000000",
+                        "--nev", "6", "--ncv", "20", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["solve"]["nconv"] == 6
+    assert d["solve"]["max_residual"] <= 1e-10
+    assert "point-to-point exchange" in d["config"]["parallelism"] and "allgather_variant" in d
+    assert d["allgather_variant"]["value"] > 0
+    assert d["roofline"]["traffic"] is None and "cpu_baseline" not in d and "secondary" not in d
