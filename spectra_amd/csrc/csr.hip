@@ -45,7 +45,7 @@ namespace {
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-constexpr int kLoadIters = 4;  // THREADS * 4 entries * 4 steps = 16 * THREADS >= cap + 3
+// THREADS * 4 entries * 4 load steps = 16 * THREADS >= cap + 3 (k_spmv_csr_stream's ITERS = 4)
 // products per LDS chunk for a THREADS-row workgroup: 256 -> (4080+4)*8 B + 32 B <= 32 KiB -> 5 workgroups / CU
 constexpr int chunk_cap(int threads) { return threads * 16 - 16; }
 // offset-coded variant: 1 KiB of the 32 KiB goes to the dictionary -> (3952+4)*8 + 1024 + 32 B, still 5 workgroups / CU
@@ -79,14 +79,18 @@ __device__ __forceinline__ double block_reduce_sum(double v, double* red)
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-template <bool EPI, bool NT, int kThreads, bool CODES>
+// ITERS: 16-byte load groups per thread and chunk (4: chunks of ~4080 entries, 32 KiB of LDS, 5 workgroups per CU; 2: chunks of
+// ~2032 entries, 16 KiB, 8 workgroups per CU — for matrices with few entries per row, whose 256-row blocks would leave half of
+// the large chunk unused while the LDS it reserves caps the occupancy)
+template <bool EPI, bool NT, int kThreads, bool CODES, int ITERS = 4>
 __global__ __launch_bounds__(kThreads) void k_spmv_csr_stream(const int32_t* __restrict__ rowptr,
                                                                const int32_t* __restrict__ colind,
                                                                const double* __restrict__ val,
                                                                const double* __restrict__ x, double* __restrict__ y,
                                                                int64_t nrows, int nblocks, SpmvEpilogue epi, SpmvCodes cd)
 {
-    constexpr int kCap = CODES ? chunk_cap_codes(kThreads) : chunk_cap(kThreads);
+    constexpr int kLoadIters = ITERS;
+    constexpr int kCap = (CODES ? chunk_cap_codes(kThreads) : chunk_cap(kThreads)) - (4 - ITERS) * kThreads * 4;
     __shared__ __attribute__((aligned(16))) double prod[kCap + 4];
     __shared__ double red[4];
     __shared__ int dict_s[CODES ? kMaxDict : 1];
@@ -1122,10 +1126,16 @@ void launch_spmv_raw(const mispec_csr& A, const double* x_dev, double* y_dev, co
             hipLaunchKernelGGL((K), grid, block, 0, A.ctx->stream, A.rowptr.p, A.colind.p, A.val.p, x_dev, y_dev,    \
                                nloc, nblocks, e, cd);                                                                  \
     } while (0)
+    // few entries per row (<= 8 on average): the 16 KiB-chunk instantiation (MISPEC_SPMV_SMALL_CHUNK=0/1 overrides)
+    static const int small_knob = getenv("MISPEC_SPMV_SMALL_CHUNK") ? atoi(getenv("MISPEC_SPMV_SMALL_CHUNK")) : -1;
+    const bool small_chunk = !coded && threads == 256 && !nt &&
+                             (small_knob >= 0 ? small_knob != 0 : (double(A.nnz) <= 8.0 * double(nloc)));
 #define MISPEC_SPMV(E, N)                                          \
     do                                                             \
     {                                                              \
-        if (coded)                                                        \
+        if (small_chunk)                                                  \
+            MISPEC_SPMV_LAUNCH((k_spmv_csr_stream<E, false, 256, false, 2>)); \
+        else if (coded)                                                   \
             MISPEC_SPMV_LAUNCH((k_spmv_csr_stream<E, N, 256, true>));     \
         else if (threads == 128)                                          \
             MISPEC_SPMV_LAUNCH((k_spmv_csr_stream<E, N, 128, false>));    \
