@@ -1045,7 +1045,9 @@ void launch_spmv_raw(const mispec_csr& A, const double* x_dev, double* y_dev, co
         static const bool win_on = getenv("MISPEC_SPMV_DIA_WIN") ? atoi(getenv("MISPEC_SPMV_DIA_WIN")) != 0 : true;
         if (win_on && A.dia_win.nc > 0)
         {
-            const size_t lds = size_t(A.dia_win.total) * sizeof(double);
+            // MISPEC_DIA_LDS_PAD=bytes: extra dynamic LDS per workgroup, i.e. fewer resident workgroups per CU (an occupancy experiment)
+            static const size_t lds_pad = getenv("MISPEC_DIA_LDS_PAD") ? size_t(atol(getenv("MISPEC_DIA_LDS_PAD"))) : 0;
+            const size_t lds = size_t(A.dia_win.total) * sizeof(double) + lds_pad;
             const int ng = (A.ndia + kDiaGroup - 1) / kDiaGroup;
 #define MISPEC_DIA_WIN(E, G)                                                                                               \
     do                                                                                                                     \
