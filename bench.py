@@ -221,7 +221,7 @@ def secondary_configs(args, ctx, op, sa):
     rop.set_spmv_format(0)
     csr_alone = spmv_block(rop, standalone_ms(rop, args.n, 10), 10, False)
     rop.set_spmv_format(-1)
-    out["m_rand"] = {"n": args.n, "nnz": rop.nnz(), "spmv_format": rop.spmv_format(), "reordering": rop.reordering(),
+    out["m_rand"] = {"n": args.n, "nnz": rop.nnz(), "spmv_format": rop.spmv_format(), "reordering": rop.reordering(), "tiles": rop.tiles_info(),
                      "standalone": spmv_block(rop, alone, 20, False), "in_loop": inloop, "standalone_csr_int32_kernel": csr_alone,
                      "ingest_seconds": t_ingest,
                      "solve_12_restarts": {"seconds": dt, "nconv": int(nconv), "num_operations": int(e.num_operations())},

@@ -163,6 +163,10 @@ int mispec_spmm_host(const mispec_csr* A, const double* X_host, int64_t ldx, int
 int mispec_csr_reorder(mispec_csr* A, int method, int* applied);
 int mispec_csr_reordering(const mispec_csr* A, double* far_before, double* far_after);
 int mispec_csr_permutation(const mispec_csr* A, int32_t* perm_out);
+/* What the tile format of this matrix looks like (segments = 0: not built): stored entries incl. padding, padding entries,
+ * and the launch variant picked by measurement at ingest (0: one free-running workgroup per segment; k: persistent
+ * workgroups that meet every k column blocks). */
+int mispec_csr_tiles_info(const mispec_csr* A, int64_t* segments, int64_t* entries, int64_t* padding, int* sync_period);
 /* Host image of the tile format and its summation order, for tests (no device needed): y = A x through the tiles of an
  * nrows x ncols CSR matrix; *built = 0 when the format does not apply (a row with more than 7 entries inside one column
  * block, unsorted rows).  stats (optional): entries incl. padding, padding entries, chunks. */

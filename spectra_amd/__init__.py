@@ -234,6 +234,12 @@ class _DeviceMatrix:
         """Compulsory SpMV traffic with the index format in use (9 instead of 12 bytes per entry with offset codes)."""
         return float(lib().mispec_csr_spmv_bytes(self.h, 1))
 
+    def tiles_info(self):
+        """{segments, entries, padding, sync_period} of the column-blocked tile format (segments = 0: not built)."""
+        a, b, c, d = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int(0)
+        check(lib().mispec_csr_tiles_info(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return {"segments": a.value, "entries": b.value, "padding": c.value, "sync_period": d.value}
+
     def reorder(self, method="rcm"):
         """Symmetric reordering of the stored matrix (mispec_csr_reorder): "rcm" always, "auto" only when it pays.  Returns
         True when the matrix is reordered afterwards.  Products and results keep the caller's index order."""

@@ -791,7 +791,10 @@ mispec_csr* upload_rows(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const i
             {
                 HostTiles H;
                 if (build_tiles(n_rows, n_cols, rowptr, colind, val, H))
+                {
                     upload_tiles(H, ctx->stream, A->tiles);
+                    calibrate_tiles(A->tiles, ctx->stream, nloc, n_cols, spmv_num_blocks(nloc));
+                }
             }
         }
     }
@@ -1420,6 +1423,21 @@ extern "C" double mispec_csr_spmv_bytes(const mispec_csr* A, int stored)
     if (!A)
         return 0.0;
     return stored ? A->stored_bytes() : A->algorithmic_bytes();
+}
+
+extern "C" int mispec_csr_tiles_info(const mispec_csr* A, int64_t* segments, int64_t* entries, int64_t* padding, int* sync_period)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(A, "mispec_csr_tiles_info: NULL argument");
+        if (segments)
+            *segments = A->tiles.nseg;
+        if (entries)
+            *entries = A->tiles.entries;
+        if (padding)
+            *padding = A->tiles.padding;
+        if (sync_period)
+            *sync_period = A->tiles.sync_period;
+    });
 }
 
 extern "C" int mispec_csr_reorder(mispec_csr* A, int method, int* applied)

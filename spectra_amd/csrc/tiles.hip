@@ -434,10 +434,11 @@ void launch_spmv_tiles(const DevTiles& T, hipStream_t stream, const double* x, d
                        const SpmvEpilogue* epi, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     const SpmvEpilogue e = epi ? *epi : SpmvEpilogue{};
-    // MISPEC_TILES_SYNC=k: persistent workgroups (as many as are resident at once), each sweeping several segments, with a
+    // sync_period = k > 0: persistent workgroups (as many as are resident at once), each sweeping several segments, with a
     // loose barrier per XCD group every k column blocks so that the sweeps stay in step and the gathers stay in the L2;
     // 0: one workgroup per segment, free-running.
-    static const int period = getenv("MISPEC_TILES_SYNC") ? atoi(getenv("MISPEC_TILES_SYNC")) : 0;
+    // sync_period: per matrix, chosen by calibrate_tiles() at ingest (or forced by MISPEC_TILES_SYNC=k)
+    const int period = T.sync_period;
     static const int xload = getenv("MISPEC_TILES_XLOAD") ? atoi(getenv("MISPEC_TILES_XLOAD")) : 0;
     TileSync ts{nullptr, 0, 0, 1, int(T.ncb), 0, 0u, xload};
     dim3 grid(static_cast<unsigned>(T.nseg)), block(256);
@@ -496,6 +497,52 @@ void launch_spmv_tiles(const DevTiles& T, hipStream_t stream, const double* x, d
 #undef MISPEC_TILES_X
 #undef MISPEC_TILES
     MISPEC_HIP(hipGetLastError());
+}
+
+// Pick the launch variant of this matrix by measurement: free-running workgroups against persistent ones that meet every
+// quarter of the column sweep (measured at n = 1e7: 1.87 vs 1.73-1.76 ms; frequent barriers lose, profiles/r02_mrand_variants.jsonl).
+// The persistent variant relies on every workgroup of its grid being resident; if that ever fails its barriers time out and
+// the timing here says so — the free-running kernel is then kept.  MISPEC_TILES_SYNC=k forces a period (0: free-running).
+void calibrate_tiles(DevTiles& T, hipStream_t stream, int64_t nrows, int64_t ncols, int nblocks256)
+{
+    T.sync_period = 0;
+    if (const char* e = getenv("MISPEC_TILES_SYNC"))
+    {
+        T.sync_period = std::max(0, atoi(e));
+        return;
+    }
+    if (T.nseg < 2048 || T.ncb < 16)  // fewer segments than two generations of resident workgroups: nothing to keep in step
+        return;
+    DevBuf<double> x, y;
+    x.alloc(size_t(ncols) + 2);
+    y.alloc(size_t(nrows) + 2);
+    MISPEC_HIP(hipMemsetAsync(x.p, 0, x.n * sizeof(double), stream));
+    hipEvent_t e0, e1;
+    MISPEC_HIP(hipEventCreate(&e0));
+    MISPEC_HIP(hipEventCreate(&e1));
+    const int candidate = int(std::max<int64_t>(1, T.ncb / 4));
+    float best_ms = 0.f;
+    int best = 0;
+    for (int variant = 0; variant < 2; variant++)
+    {
+        T.sync_period = variant ? candidate : 0;
+        launch_spmv_tiles(T, stream, x.p, y.p, nrows, nblocks256, nullptr, nullptr, nullptr);  // warm-up
+        MISPEC_HIP(hipEventRecord(e0, stream));
+        for (int r = 0; r < 3; r++)
+            launch_spmv_tiles(T, stream, x.p, y.p, nrows, nblocks256, nullptr, nullptr, nullptr);
+        MISPEC_HIP(hipEventRecord(e1, stream));
+        MISPEC_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        MISPEC_HIP(hipEventElapsedTime(&ms, e0, e1));
+        if (variant == 0 || ms < 0.97f * best_ms)
+        {
+            best_ms = ms;
+            best = T.sync_period;
+        }
+    }
+    T.sync_period = best;
+    (void) hipEventDestroy(e0);
+    (void) hipEventDestroy(e1);
 }
 
 }  // namespace mispec

@@ -51,6 +51,7 @@ struct DevTiles
     DevBuf<uint32_t> idx;
     DevBuf<unsigned int> sync_counters;  // the loose per-XCD barrier of the persistent variant (MISPEC_TILES_SYNC)
     int64_t nseg = 0, entries = 0, nchunks = 0, padding = 0, ncb = 0;
+    int sync_period = 0;                 // 0: free-running workgroups; k: persistent workgroups meeting every k column blocks
     bool present() const { return nseg > 0; }
     void swap(DevTiles& o)
     {
@@ -61,6 +62,7 @@ struct DevTiles
         idx.swap(o.idx);
         sync_counters.swap(o.sync_counters);
         std::swap(ncb, o.ncb);
+        std::swap(sync_period, o.sync_period);
         std::swap(nseg, o.nseg);
         std::swap(entries, o.entries);
         std::swap(nchunks, o.nchunks);
@@ -68,6 +70,7 @@ struct DevTiles
     }
 };
 void upload_tiles(const HostTiles& H, hipStream_t stream, DevTiles& D);
+void calibrate_tiles(DevTiles& T, hipStream_t stream, int64_t nrows, int64_t ncols, int nblocks256);
 struct SpmvEpilogue;
 void launch_spmv_tiles(const DevTiles& T, hipStream_t stream, const double* x, double* y, int64_t nrows, int nblocks256,
                        const SpmvEpilogue* epi, hipEvent_t ev_start, hipEvent_t ev_stop);

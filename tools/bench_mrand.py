@@ -23,7 +23,7 @@ x = torch.rand(n, dtype=torch.float64, device="cuda") - 0.5
 y3 = torch.empty(n + 2, dtype=torch.float64, device="cuda")
 y0 = torch.empty(n + 2, dtype=torch.float64, device="cuda")
 torch.cuda.synchronize()
-out = {"n": n, "nnz": op.nnz(), "ingest_s": round(ingest, 2), "TILES_SYNC": os.environ.get("MISPEC_TILES_SYNC", "0")}
+out = {"n": n, "nnz": op.nnz(), "ingest_s": round(ingest, 2), "TILES_SYNC": os.environ.get("MISPEC_TILES_SYNC", "auto"), "tiles": op.tiles_info()}
 for fmt, yy in ((3, y3), (0, y0)):
     op.set_spmv_format(fmt)
     op.spmv_time(x.data_ptr(), yy.data_ptr(), 3)

@@ -1,0 +1,3 @@
+OUT=gpurun_out/r02t; mkdir -p $OUT
+timeout 300 python tools/bench_mrand.py 1e7 > $OUT/mrand_auto.jsonl 2> $OUT/err.log; cat $OUT/mrand_auto.jsonl
+timeout 600 python -m pytest tests/test_gpu_tiles.py -m gpu -q > $OUT/pytest_tiles.log 2>&1; tail -2 $OUT/pytest_tiles.log
