@@ -5,14 +5,15 @@
 // vector; every gather misses the 4 MiB per-XCD L2 and drags a 128-byte line through the fabric: 16x read amplification,
 // 0.10 of the HBM roofline (profiles/r01g_spmv_patterns.jsonl).  No symmetric reordering helps an expander.
 //
-// Layout.  The rows are cut into SEGMENTS of 4096 rows, the columns into BLOCKS of 131072 columns (1 MiB of x).  A TILE is
+// Layout.  The rows are cut into SEGMENTS of 8192 rows, the columns into BLOCKS of 65536 columns (512 KiB of x).  A TILE is
 // the part of a segment inside one column block; a segment stores its tiles one after the other (ascending block), every
 // entry as (fp64 value, 32-bit index) = 12 bytes like CSR with int32 indices, the index packing the row inside the segment
-// (12 bits), the column inside the block (17 bits) and the length of the row's run inside the tile (3 bits).
+// (13 bits), the column inside the block (16 bits) and the length of the row's run inside the tile (3 bits).  (The geometry
+// is a set of compile-time constants, tiles.hpp; the sweep that chose it is recorded there.)
 //
-// Kernel.  One workgroup (256 threads) per segment, the segment's 4096 partial sums in LDS.  It walks its tiles in block
+// Kernel.  One workgroup (512 threads) per segment, the segment's 8192 partial sums in LDS.  It walks its tiles in block
 // order, so that at any moment all the workgroups resident on an XCD gather from the same one or two 1 MiB pieces of x,
-// which stay in that XCD's L2: x is read from HBM / Infinity Cache once per XCD and generation of workgroups instead of
+// which stay in that XCD's L2 (fewer, larger workgroups drift apart less: 64 per XCD): x is read from HBM / Infinity Cache once per XCD and generation of workgroups instead of
 // once per entry.  Inside a tile the entries are sorted by row, every row's entries (ascending column) are consecutive and
 // never straddle a wavefront; the lane holding the first entry of a run collects the products of the run from its
 // neighbours (shuffles) and adds them to the row's LDS accumulator one after the other.  A row's products are therefore
@@ -266,16 +267,16 @@ __device__ __forceinline__ double tile_load_x(const double* p)
 }
 
 template <bool EPI, int XL>
-__global__ __launch_bounds__(256) void k_spmv_tiles(const int64_t* __restrict__ seg_entry, const int32_t* __restrict__ seg_chunk,
+__global__ __launch_bounds__(kTileThreads) void k_spmv_tiles(const int64_t* __restrict__ seg_entry, const int32_t* __restrict__ seg_chunk,
                                                     const TileChunk* __restrict__ chunks, const double* __restrict__ val,
                                                     const uint32_t* __restrict__ idx, const double* __restrict__ x, double* __restrict__ y,
                                                     int64_t nrows, int nblocks256, int nseg, SpmvEpilogue epi, TileSync ts)
 {
-    __shared__ double acc[kTileRows];  // exactly 32 KiB: five workgroups per CU
+    __shared__ double acc[kTileRows];  // 64 KiB with the default geometry: two workgroups per CU
     if (EPI && epi.status && *epi.status != 0)
         return;
     const int tid = threadIdx.x;
-    constexpr int kPer = kTileChunk / 256;  // entries per thread and chunk
+    constexpr int kPer = kTileChunk / kTileThreads;  // entries per thread and chunk
     bool give_up = false;         // thread 0 only
     unsigned int arrivals = 0;    // barriers passed so far (all sweeps)
     // XCC_ID: the XCD this workgroup runs on (hwreg 20, bits 3:0); workgroups are dealt round-robin, gridDim.x / 8 per XCD
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256) void k_spmv_tiles(const int64_t* __restrict__ 
         int next_sync = ts.period;  // first column block that lies behind the next barrier
         if (seg < nseg)
         {
-            for (int r = tid; r < kTileRows; r += 256)
+            for (int r = tid; r < kTileRows; r += kTileThreads)
                 acc[r] = 0.0;
             const int c0 = seg_chunk[seg], c1 = seg_chunk[seg + 1];
             const int64_t base = seg_entry[seg];
@@ -297,8 +298,8 @@ __global__ __launch_bounds__(256) void k_spmv_tiles(const int64_t* __restrict__ 
 #pragma unroll
             for (int k = 0; k < kPer; k++)
             {
-                v[k] = __builtin_nontemporal_load(val + base + off + k * 256 + tid);  // streamed once: keep x in the L2
-                id[k] = __builtin_nontemporal_load(idx + base + off + k * 256 + tid);
+                v[k] = __builtin_nontemporal_load(val + base + off + k * kTileThreads + tid);  // streamed once: keep x in the L2
+                id[k] = __builtin_nontemporal_load(idx + base + off + k * kTileThreads + tid);
             }
             __syncthreads();
             for (int ci = c0; ci < c1; ci++)
@@ -310,8 +311,8 @@ __global__ __launch_bounds__(256) void k_spmv_tiles(const int64_t* __restrict__ 
 #pragma unroll
                 for (int k = 0; k < kPer; k++)
                 {
-                    nv[k] = __builtin_nontemporal_load(val + base + noff + k * 256 + tid);
-                    nid[k] = __builtin_nontemporal_load(idx + base + noff + k * 256 + tid);
+                    nv[k] = __builtin_nontemporal_load(val + base + noff + k * kTileThreads + tid);
+                    nid[k] = __builtin_nontemporal_load(idx + base + noff + k * kTileThreads + tid);
                 }
                 if (ts.period > 0 && next_sync <= int(ch.colblock))
                 {
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(256) void k_spmv_tiles(const int64_t* __restrict__ 
 #pragma unroll
                 for (int k = 0; k < kPer; k++)
                 {
-                    const bool live = (k * 256 + tid < count) && id[k] != kTileSkip;
+                    const bool live = (k * kTileThreads + tid < count) && id[k] != kTileSkip;
                     run[k] = live ? int(id[k] & uint32_t(kTileMaxRun)) : 0;
                     const int64_t col = live ? col0 + int64_t((id[k] >> kTileRunBits) & uint32_t(kTileCols - 1)) : col0;
                     p[k] = live ? rounded_product(v[k], tile_load_x<XL>(x + col)) : 0.0;
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(256) void k_spmv_tiles(const int64_t* __restrict__ 
                 if (blk >= nblocks256)
                     break;
                 double contrib = 0.0;
-                if (row < nrows)
+                if (tid < 256 && row < nrows)
                 {
                     double yv = acc[j * 256 + tid];
                     if (EPI)
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(256) void k_spmv_tiles(const int64_t* __restrict__ 
                     const double t = tile_wave_sum(contrib);
                     __syncthreads();
                     double* red = acc + j * 256;
-                    if ((tid & 63) == 0)
+                    if ((tid & 63) == 0 && tid < 256)
                         red[tid >> 6] = t;
                     __syncthreads();
                     if (tid == 0)
@@ -441,7 +442,7 @@ void launch_spmv_tiles(const DevTiles& T, hipStream_t stream, const double* x, d
     const int period = T.sync_period;
     static const int xload = getenv("MISPEC_TILES_XLOAD") ? atoi(getenv("MISPEC_TILES_XLOAD")) : 0;
     TileSync ts{nullptr, 0, 0, 1, int(T.ncb), 0, 0u, xload};
-    dim3 grid(static_cast<unsigned>(T.nseg)), block(256);
+    dim3 grid(static_cast<unsigned>(T.nseg)), block(kTileThreads);
     if (period > 0 && T.sync_counters.p)
     {
         static int resident = 0;
@@ -452,8 +453,8 @@ void launch_spmv_tiles(const DevTiles& T, hipStream_t stream, const double* x, d
             MISPEC_HIP(hipGetDevice(&dev));
             MISPEC_HIP(hipGetDeviceProperties(&prop, dev));
             int per_cu2 = 0;
-            MISPEC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_spmv_tiles<true, 0>), 256, 0));
-            MISPEC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, reinterpret_cast<const void*>(&k_spmv_tiles<false, 0>), 256, 0));
+            MISPEC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_spmv_tiles<true, 0>), kTileThreads, 0));
+            MISPEC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, reinterpret_cast<const void*>(&k_spmv_tiles<false, 0>), kTileThreads, 0));
             // one below what the occupancy calculator allows (5 x 32 KiB is the whole LDS of a CU: measured, the fifth
             // workgroup is not resident), overridable for experiments
             per_cu = std::max(1, std::min(per_cu, per_cu2) - 1);

@@ -7,16 +7,35 @@
 
 namespace mispec {
 
-constexpr int kTileRowBits = 12;                 // rows per segment: 4096 (32 KiB of fp64 accumulators in LDS)
+// Geometry (compile-time; the defaults are the measured best of profiles/r02_mrand_tile_geometry_sweep.jsonl, M-rand n = 1e7):
+//   segments of 8192 rows (64 KiB of accumulators: two workgroups per CU), column blocks of 65536 columns (512 KiB of x),
+//   512 threads per workgroup, chunks of 1024 entries.  4096 x 131072 x 256 threads: 1.87 ms; 8192 x 65536 x 256: 1.50;
+//   8192 x 65536 x 512: 1.29-1.32; 8192 x 65536 x 1024: 1.40; 8192 x 131072 (2-bit runs): 1.65-1.70; 16384 x 32768: 1.60-1.99;
+//   2048 x 131072: 2.27 (int32 CSR kernel on the same matrix: 2.67).
+#ifndef MISPEC_TILE_ROW_BITS
+#define MISPEC_TILE_ROW_BITS 13
+#endif
+#ifndef MISPEC_TILE_COL_BITS
+#define MISPEC_TILE_COL_BITS 16
+#endif
+#ifndef MISPEC_TILE_THREADS
+#define MISPEC_TILE_THREADS 512
+#endif
+constexpr int kTileRowBits = MISPEC_TILE_ROW_BITS;  // rows per segment: 8192 (64 KiB of fp64 accumulators in LDS)
 constexpr int kTileRows = 1 << kTileRowBits;
-constexpr int kTileColBits = 17;                 // columns per block: 131072 (1 MiB of x: a quarter of an XCD's L2)
+constexpr int kTileColBits = MISPEC_TILE_COL_BITS;  // columns per block: 65536 (512 KiB of x)
+constexpr int kTileThreads = MISPEC_TILE_THREADS;   // threads of the workgroup that owns a segment
 constexpr int kTileCols = 1 << kTileColBits;
-constexpr int kTileRunBits = 3;                  // entries of one row inside one tile: at most 7
+constexpr int kTileRunBits = 32 - MISPEC_TILE_ROW_BITS - MISPEC_TILE_COL_BITS;  // run length of a head entry: the bits that are left
 constexpr int kTileMaxRun = (1 << kTileRunBits) - 1;
-constexpr int kTileChunk = 1024;                 // entries handled between two barriers (4 per thread, 256 threads)
+#ifndef MISPEC_TILE_CHUNK
+#define MISPEC_TILE_CHUNK 1024
+#endif
+constexpr int kTileChunk = MISPEC_TILE_CHUNK;       // entries handled between two barriers (kTileChunk / kTileThreads per thread)
+static_assert(kTileRunBits >= 2 && kTileRunBits <= 8, "tile index packing: row + column bits must leave 2..8 bits for the run length");
 constexpr uint32_t kTileSkip = 0xFFFFFFFFu;      // padding entry
 
-// idx = row_local << 20 | col_local << 3 | run      run = 0: continuation of the run started by an earlier entry;
+// idx = row_local << (col bits + 3) | col_local << 3 | run      run = 0: continuation of the run started by an earlier entry;
 //                                                   run = k >= 1: first of k consecutive entries of this row in this tile
 struct TileChunk
 {
