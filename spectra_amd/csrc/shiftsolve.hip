@@ -89,7 +89,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_chunk_solve(int64_t N, int b,
                                                            const double* __restrict__ Dinv, const double* __restrict__ f,
                                                            double* __restrict__ y, int mode, double* __restrict__ u_out)
 {
-    const int64_t p = int64_t(blockIdx.x) * kChunkThreads + threadIdx.x;
+    const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;  // blockDim.x = chunks per wavefront (solve_lanes())
     if (p >= P)
         return;
     const int64_t row0 = p * L;
@@ -1024,11 +1024,28 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
     }
 }
 
-void launch_chunk_solve(const mispec_ctx& ctx, const BandLevel& lev, dim3 grid, const double* f, double* y, int mode = 0,
+// Chunks per wavefront of the solve kernels (MISPEC_SHIFT_LANES = 64 | 32 | 16 | 8).  One lane per chunk makes a level with P
+// chunks run P / 64 wavefronts — 244 at the top level of C5, 6 at the second; fewer chunks per wavefront (the other lanes idle)
+// means more wavefronts in flight, but measured (profiles/r03a_*) 0.265 / 0.276 / 0.278 / 0.464 ms per solve at 64 / 32 / 16 / 8:
+// the sweeps are bound by their dependency chain, not by the number of wavefronts.  A software-pipelined variant (next batch of
+// rows in flight during the recurrence) measured 0.281 against 0.265 ms (profiles/r03b_*) and was removed again.
+int solve_lanes(int64_t P)
+{
+    static const int knob = getenv("MISPEC_SHIFT_LANES") ? atoi(getenv("MISPEC_SHIFT_LANES")) : 0;
+    if (knob == 64 || knob == 32 || knob == 16 || knob == 8)
+        return knob;
+    (void) P;
+    return kChunkThreads;
+}
+
+void launch_chunk_solve(const mispec_ctx& ctx, const BandLevel& lev, dim3 grid_unused, const double* f, double* y, int mode = 0,
                         double* u_out = nullptr)
 {
+    (void) grid_unused;
+    const int lanes = lev.P == 1 ? 1 : solve_lanes(lev.P);
+    const dim3 grid(unsigned((lev.P + lanes - 1) / lanes));
 #define MISPEC_CHUNK(B, U)                                                                                                  \
-    hipLaunchKernelGGL((k_chunk_solve<B, U>), grid, dim3(kChunkThreads), 0, ctx.stream, lev.N, lev.b, lev.L, lev.P, lev.Lf.p, \
+    hipLaunchKernelGGL((k_chunk_solve<B, U>), grid, dim3(unsigned(lanes)), 0, ctx.stream, lev.N, lev.b, lev.L, lev.P, lev.Lf.p, \
                        lev.Dinv.p, f, y, mode, u_out)
     // U rows of factor entries are in flight per lane and batch ((B + 2) * U doubles): as deep as the register
     // file allows, because with one lane per chunk nothing else hides the load latency
