@@ -73,44 +73,98 @@ struct HostBand
     }
 };
 
+// Where the factor of chunk p, row k lives.  Chunks are stored in groups of 64 — one wavefront of the solve kernels — and
+// lane-interleaved inside a group: entries (2j, d) and (2j + 1, d) of the 64 chunks of group g are one 1024-byte line at
+// ((g * R0 / 2 + j) * b + d) * 128, so a wavefront's loads are coalesced and consecutive (j, d) are a compile-time stride apart.
+// The last chunk (no separator; it also takes the remainder of N / L and may be almost twice as long) is lane 0 of a final
+// group with Rt rows.  R0 / Rt are the interior lengths rounded up to the batch length of the sweeps plus a margin, and the
+// padding is ZERO: a sweep may run whole batches past the end of a chunk (z = 0 there) and read L(k + d + 1, d) without a test.
+struct ChunkStore
+{
+    int64_t P = 1, R0 = 0, Rt = 0, groups = 0;  // groups: full-length groups, = ceil((P - 1) / 64)
+    int b = 0;
+    __host__ __device__ int64_t row_base(int64_t p) const { return (p == P - 1 ? groups : (p >> 6)) * R0; }  // R0, Rt even
+    __host__ __device__ int lane(int64_t p) const { return p == P - 1 ? 0 : int(p & 63); }
+    // rows are stored in PAIRS: a lane's entries of rows 2j and 2j + 1 are adjacent, one 16-byte load (see k_chunk_solve_lds)
+    __host__ __device__ size_t lf(int64_t p, int64_t k, int d) const
+    {
+        return (size_t((row_base(p) + k) >> 1) * b + d) * 128 + size_t(lane(p)) * 2 + size_t(k & 1);
+    }
+    __host__ __device__ size_t dinv(int64_t p, int64_t k) const
+    {
+        return size_t((row_base(p) + k) >> 1) * 128 + size_t(lane(p)) * 2 + size_t(k & 1);
+    }
+    __host__ __device__ size_t rows() const { return size_t(groups) * R0 + Rt; }
+    __host__ __device__ size_t lf_size() const { return rows() * (b > 0 ? b : 1) * 64; }
+    __host__ __device__ size_t dinv_size() const { return rows() * 64; }
+};
+constexpr int kSweepBatch = 32;  // longest batch of the sweep kernels: the row padding of ChunkStore
+inline ChunkStore make_chunk_store(int64_t N, int b, int64_t L, int64_t P)
+{
+    ChunkStore cs;
+    cs.P = P;
+    cs.b = b;
+    cs.groups = (P - 1 + 63) / 64;
+    const auto padded = [](int64_t m) { return (m + kSweepBatch - 1) / kSweepBatch * kSweepBatch + 16; };
+    cs.R0 = P > 1 ? padded(L - b) : 0;
+    cs.Rt = padded(N - (P - 1) * L);
+    return cs;
+}
+
 // ---- kernels ------------------------------------------------------------------------------------------
 // Chunk p owns rows [p*L, min((p+1)*L, N)); its interior is the chunk minus the last b rows (the last chunk
-// has no separator).  Lf(k, d, p) multiplies z_{k-d-1}; everything chunk-interleaved: index (k*b + d)*P + p.
+// has no separator).  Lf(k, d, p) multiplies z_{k-d-1}; everything chunk-interleaved: ChunkStore above.
 //
 // One thread per chunk.  The recurrence is sequential in k, so the only latency that may sit on the critical
 // path is the FMA chain itself: the last B unknowns live in registers (never re-read from memory), and the
 // factor entries / right-hand sides of the next U rows are loaded as one batch before they are needed.
+//
+// Every wavefront runs chunks of ONE interior length: the last chunk has a workgroup of its own.  Row counters and trip counts
+// are therefore wave-uniform, and the factor addresses are `per-lane base + compile-time stride` (ChunkStore).
+//
+// What bounds these kernels (measured, profiles/r03e-r03g): with one wavefront per SIMD nothing overlaps the instruction
+// stream, so the time is the NUMBER OF INSTRUCTIONS per row.  The first version (per-lane interior length in the loop bounds,
+// factor index (k*b + d)*P + p) needed five 64-bit vector integer instructions and a branch per load — 540 cycles per row,
+// unchanged by deeper batches, more wavefronts, or staging the vector in LDS.
 constexpr int kChunkThreads = 64;  // one wavefront per workgroup: the chunks spread over all CUs, 512 VGPRs per lane
+// General kernel (any b <= B, Cholesky halves):
 // mode 0: y = M_II^{-1} f (forward, diagonal, backward); with u_out also u = D^{-1/2} L^{-1} f from the forward sweep — the
 //         interior part of G^{-1} f for the Cholesky-like factor G of a positive definite band (cholesky.hip);
 // mode 2: y = L^{-T} D^{-1/2} f (backward sweep only): the interior part of G^{-T}.
 template <int B, int U>
-__global__ __launch_bounds__(kChunkThreads) void k_chunk_solve(int64_t N, int b, int64_t L, int64_t P, const double* __restrict__ Lf,
+__global__ __launch_bounds__(kChunkThreads) void k_chunk_solve(int64_t N, int64_t L, ChunkStore cs, const double* __restrict__ Lf,
                                                            const double* __restrict__ Dinv, const double* __restrict__ f,
                                                            double* __restrict__ y, int mode, double* __restrict__ u_out)
 {
-    const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;  // blockDim.x = chunks per wavefront (solve_lanes())
-    if (p >= P)
+    const int64_t P = cs.P;
+    const int b = cs.b;
+    const bool tail_block = blockIdx.x == gridDim.x - 1;  // the last chunk alone
+    const int64_t p = tail_block ? P - 1 : int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (tail_block ? threadIdx.x != 0 : p >= P - 1)
         return;
-    const int64_t row0 = p * L;
-    const int64_t m = ((p == P - 1) ? N : (row0 + L - b)) - row0;  // interior rows
-    double hist[B];                                                // hist[d] = unknown k-d-1 (forward) / k+d+1 (backward)
+    const int m = int(tail_block ? N - (P - 1) * L : L - b);  // interior rows of this wavefront's chunks
+    const double* const fp = f + p * L;
+    double* const yp = y + p * L;
+    double* const up = u_out ? u_out + p * L : nullptr;
+    const double* const lfw = Lf + cs.lf(p, 0, 0);    // entry (k, d): lfw[((k >> 1) * b + d) * 128 + (k & 1)]
+    const double* const dvw = Dinv + cs.dinv(p, 0);  // row k: dvw[(k >> 1) * 128 + (k & 1)]
+    double hist[B];  // hist[d] = unknown k-d-1 (forward) / k+d+1 (backward)
 #pragma unroll
     for (int d = 0; d < B; d++)
         hist[d] = 0.0;
     // forward: z_k = f_k - sum_d Lf(k,d) z_{k-d-1}
-    for (int64_t k0 = 0; k0 < (mode == 2 ? 0 : m); k0 += U)
+    for (int k0 = 0; k0 < (mode == 2 ? 0 : m); k0 += U)
     {
         double fk[U], lf[U][B], ds[U];
 #pragma unroll
         for (int u = 0; u < U; u++)
         {
-            const int64_t k = (k0 + u < m) ? k0 + u : m - 1;
-            fk[u] = f[row0 + k];
-            ds[u] = u_out ? sqrt(fabs(Dinv[k * P + p])) : 0.0;
+            const int k = (k0 + u < m) ? k0 + u : m - 1;
+            fk[u] = fp[k];
+            ds[u] = u_out ? sqrt(fabs(dvw[int64_t(k >> 1) * 128 + (k & 1)])) : 0.0;
 #pragma unroll
             for (int d = 0; d < B; d++)
-                lf[u][d] = (d < b) ? Lf[(k * b + d) * P + p] : 0.0;  // rows k < b hold zeros for the missing neighbours
+                lf[u][d] = (d < b) ? lfw[(int64_t(k >> 1) * b + d) * 128 + (k & 1)] : 0.0;  // rows k < b: zeros for the missing neighbours
         }
 #pragma unroll
         for (int u = 0; u < U; u++)
@@ -120,14 +174,14 @@ __global__ __launch_bounds__(kChunkThreads) void k_chunk_solve(int64_t N, int b,
                 double acc = fk[u];
 #pragma unroll
                 for (int d = B - 1; d >= 0; d--)  // the most recent unknown (d = 0) enters last
-                    acc -= lf[u][d] * hist[d];
+                    acc = fma(-lf[u][d], hist[d], acc);  // explicit: both solve kernels round identically
 #pragma unroll
                 for (int d = B - 1; d > 0; d--)
                     hist[d] = hist[d - 1];
                 hist[0] = acc;
-                y[row0 + k0 + u] = acc;
+                yp[k0 + u] = acc;
                 if (u_out)
-                    u_out[row0 + k0 + u] = acc * ds[u];
+                    up[k0 + u] = acc * ds[u];
             }
         }
     }
@@ -135,39 +189,312 @@ __global__ __launch_bounds__(kChunkThreads) void k_chunk_solve(int64_t N, int b,
 #pragma unroll
     for (int d = 0; d < B; d++)
         hist[d] = 0.0;
-    for (int64_t k0 = m - 1; k0 >= 0; k0 -= U)
+    for (int k0 = m - 1; k0 >= 0; k0 -= U)
     {
         double zk[U], di[U], lf[U][B];
 #pragma unroll
         for (int u = 0; u < U; u++)
         {
-            const int64_t k = (k0 - u >= 0) ? k0 - u : 0;
-            zk[u] = (mode == 2) ? f[row0 + k] : y[row0 + k];
-            di[u] = (mode == 2) ? sqrt(fabs(Dinv[k * P + p])) : Dinv[k * P + p];
+            const int k = (k0 - u >= 0) ? k0 - u : 0;
+            zk[u] = (mode == 2) ? fp[k] : yp[k];
+            di[u] = (mode == 2) ? sqrt(fabs(dvw[int64_t(k >> 1) * 128 + (k & 1)])) : dvw[int64_t(k >> 1) * 128 + (k & 1)];
 #pragma unroll
             for (int d = 0; d < B; d++)
-                lf[u][d] = (d < b && k + d + 1 < m) ? Lf[((k + d + 1) * b + d) * P + p] : 0.0;
+                lf[u][d] = (d < b && k + d + 1 < m) ? lfw[(int64_t((k + d + 1) >> 1) * b + d) * 128 + ((k + d + 1) & 1)] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < U; u++)
         {
             if (k0 - u >= 0)
             {
-                double acc = zk[u] * di[u];
+                double acc = __dmul_rn(zk[u], di[u]);
 #pragma unroll
                 for (int d = B - 1; d >= 0; d--)
-                    acc -= lf[u][d] * hist[d];
+                    acc = fma(-lf[u][d], hist[d], acc);  // explicit: both solve kernels round identically
 #pragma unroll
                 for (int d = B - 1; d > 0; d--)
                     hist[d] = hist[d - 1];
                 hist[0] = acc;
-                y[row0 + k0 - u] = acc;
+                yp[k0 - u] = acc;
             }
         }
     }
 }
 
+// The plain solve of a level (the hot one), half-bandwidth exactly B: as few instructions per row as the recurrence allows.
+//  * the wavefront's piece of the vector is staged in LDS: its chunks are contiguous rows, copied in and out with coalesced
+//    accesses (one lane per chunk would make every access to f / y a 64-line gather); row stride in LDS odd, no bank conflicts.
+//    The copies are done by four wavefronts (one alone has 32 x 512 bytes in flight per round trip to HBM: 14.6 of the
+//    kernel's 39.7 us, measured by skipping it), the sweeps by the first;
+//  * every batch is a full one: the sweeps run to the interior length rounded up to U over the zero padding of ChunkStore
+//    (z = 0, y = 0 there), so there is no clamp, no guard and no branch between the loads;
+//  * B is a template parameter: no `d < b` tests, and consecutive factor entries are 512 bytes apart at compile time.
+//  * a scheduling barrier separates the loads of a batch from its recurrence: left alone, the compiler sinks each load next to
+//    its use to save registers and keeps five or six in flight (s_waitcnt vmcnt(5) between the FMAs in the ISA), which makes
+//    every row wait for half a memory latency — that, not bandwidth or address arithmetic, was the 540 cycles per row.
+// Same operations in the same order as k_chunk_solve: bit-identical results.
+constexpr int kStageThreads = 256;  // the workgroup: the sweeps run on its first wavefront, all four copy the vector in and out
+template <int B, int U>
+__global__ __launch_bounds__(kStageThreads) void k_chunk_solve_lds(int64_t N, int64_t L, ChunkStore cs, int ldl, int chunks_per_block,
+                                                                   const double* __restrict__ Lf, const double* __restrict__ Dinv,
+                                                                   const double* __restrict__ f, double* __restrict__ y)
+{
+    extern __shared__ double seg[];  // chunks_per_block chunks x ldl
+    const int64_t P = cs.P;
+    const bool tail_block = blockIdx.x == gridDim.x - 1;  // the last chunk alone
+    const int64_t first = tail_block ? P - 1 : int64_t(blockIdx.x) * chunks_per_block;
+    const int nch = tail_block ? 1 : int(min(int64_t(chunks_per_block), P - 1 - first));
+    const int m = int(tail_block ? N - (P - 1) * L : L - B);  // interior rows of this wavefront's chunks
+    const int mr = (m + U - 1) / U * U;                        // ... in whole batches
+    const int lane = threadIdx.x, nl = blockDim.x;
+    {
+        // copy in: the wavefront's rows are one contiguous piece of f; 32 loads per lane in flight, then the LDS writes
+        // (row i of the piece is row k = i mod L of chunk c = i div L, followed incrementally; separator rows are skipped)
+        const double* src = f + first * L;
+        const int64_t total = tail_block ? m : int64_t(nch) * L;
+        constexpr int kInFlight = 32;
+        int c = 0;
+        int64_t k = lane;
+        while (k >= L && !tail_block)
+        {
+            k -= L;
+            c++;
+        }
+        for (int64_t i0 = lane; i0 < total; i0 += int64_t(kInFlight) * nl)
+        {
+            double t[kInFlight];
+#pragma unroll
+            for (int q = 0; q < kInFlight; q++)
+                t[q] = (i0 + int64_t(q) * nl < total) ? src[i0 + int64_t(q) * nl] : 0.0;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < kInFlight; q++)
+            {
+                if (i0 + int64_t(q) * nl < total && k < m)
+                    seg[c * ldl + k] = t[q];
+                k += nl;
+                while (k >= L && !tail_block)
+                {
+                    k -= L;
+                    c++;
+                }
+            }
+        }
+        for (int kz = m + lane; kz < mr; kz += nl)
+            for (int cz = 0; cz < nch; cz++)
+                seg[cz * ldl + kz] = 0.0;
+    }
+    __syncthreads();
+    if (lane < nch)
+    {
+        const int64_t p = first + lane;
+        double* const zp = seg + lane * ldl;
+        const double* const lfw = Lf + cs.lf(p, 0, 0);
+        const double* const dvw = Dinv + cs.dinv(p, 0);
+        double hist[B];
+        // one batch of the forward / backward recurrence on factor entries already in registers
+        const auto forward = [&](const double (&lf)[U][B], int k0) {
+#pragma unroll
+            for (int u = 0; u < U; u++)
+            {
+                double acc = zp[k0 + u];
+#pragma unroll
+                for (int d = B - 1; d >= 0; d--)
+                    acc = fma(-lf[u][d], hist[d], acc);  // explicit: both solve kernels round identically
+#pragma unroll
+                for (int d = B - 1; d > 0; d--)
+                    hist[d] = hist[d - 1];
+                hist[0] = acc;
+                zp[k0 + u] = acc;
+            }
+        };
+        const auto backward = [&](const double (&lf)[U][B], const double (&di)[U], int k0) {  // rows k0 + U - 1 down to k0
+#pragma unroll
+            for (int u = U - 1; u >= 0; u--)
+            {
+                double acc = __dmul_rn(zp[k0 + u], di[u]);
+#pragma unroll
+                for (int d = B - 1; d >= 0; d--)
+                    acc = fma(-lf[u][d], hist[d], acc);  // explicit: both solve kernels round identically
+#pragma unroll
+                for (int d = B - 1; d > 0; d--)
+                    hist[d] = hist[d - 1];
+                hist[0] = acc;
+                zp[k0 + u] = acc;
+            }
+        };
+        // 16-byte loads: rows 2j and 2j + 1 of one entry (k0 and U are even).  A wavefront may have 63 loads outstanding,
+        // whatever their width, and with one wavefront per CU that count times the bytes per load is all the memory
+        // parallelism there is: 8-byte loads ran these sweeps at 4 TB/s.
+        const auto load_forward = [&](double (&lf)[U][B], int k0) {
+            const double* const lfk = lfw + int64_t(k0 >> 1) * (B * 128);
+#pragma unroll
+            for (int j = 0; j < U / 2; j++)
+#pragma unroll
+                for (int d = 0; d < B; d++)
+                {
+                    const double2 v = *reinterpret_cast<const double2*>(lfk + (j * B + d) * 128);
+                    lf[2 * j][d] = v.x;
+                    lf[2 * j + 1][d] = v.y;
+                }
+        };
+        const auto load_backward = [&](double (&lf)[U][B], double (&di)[U], int k0) {  // entry d of row k0 + u + d + 1
+            const double* const lfk = lfw + int64_t(k0 >> 1) * (B * 128);
+            const double* const dvk = dvw + int64_t(k0 >> 1) * 128;
+#pragma unroll
+            for (int j = U / 2 - 1; j >= 0; j--)
+            {
+                const double2 v = *reinterpret_cast<const double2*>(dvk + j * 128);
+                di[2 * j] = v.x;
+                di[2 * j + 1] = v.y;
+            }
+#pragma unroll
+            for (int d = 0; d < B; d++)
+#pragma unroll
+                for (int j = (U + d) / 2; j >= (d + 1) / 2; j--)
+                {
+                    const double2 v = *reinterpret_cast<const double2*>(lfk + (j * B + d) * 128);
+                    if (2 * j - d - 1 >= 0 && 2 * j - d - 1 < U)
+                        lf[2 * j - d - 1][d] = v.x;
+                    if (2 * j - d >= 0 && 2 * j - d < U)
+                        lf[2 * j - d][d] = v.y;
+                }
+        };
+#pragma unroll
+        for (int d = 0; d < B; d++)
+            hist[d] = 0.0;
+        for (int k0 = 0; k0 < mr; k0 += U)
+        {
+            double lf[U][B];
+            load_forward(lf, k0);
+            __builtin_amdgcn_sched_barrier(0);  // all loads of the batch are issued before the first use
+            forward(lf, k0);
+        }
+#pragma unroll
+        for (int d = 0; d < B; d++)
+            hist[d] = 0.0;
+        for (int k0 = mr - U; k0 >= 0; k0 -= U)
+        {
+            double di[U], lf[U][B];
+            load_backward(lf, di, k0);
+            __builtin_amdgcn_sched_barrier(0);
+            backward(lf, di, k0);
+        }
+    }
+    __syncthreads();
+    {
+        double* dst = y + first * L;
+        for (int k = lane; k < m; k += nl)
+        {
+#pragma unroll 8
+            for (int c = 0; c < nch; c++)
+                dst[int64_t(c) * L + k] = seg[c * ldl + k];
+        }
+    }
+}
+
+// ---- explicit inverses of the chunk interiors (levels below the top one) ------------------------------------------------
+// A lower level has few chunks (C5: 366 at the second level = 6 wavefronts of k_chunk_solve), so its two sequential sweeps are
+// pure latency: 116 us for 47 000 rows.  Its interiors are small enough to invert explicitly (m x m each, 48 MB together):
+// M_II^{-1} f becomes a batched GEMV that reads every inverse once with all lanes busy.
+//
+// k_chunk_inverse: lane (p, j) solves M_II(p) c = e_j with the chunk's banded factor and stores c as COLUMN j of the row-major
+// m x m block (ld = longest interior) — coalesced over j; the inverse is symmetric, so the GEMV below may read it either way.
+template <int B>
+__global__ __launch_bounds__(64) void k_chunk_inverse(int64_t N, int64_t L, ChunkStore cs, int64_t ld, const double* __restrict__ Lf,
+                                                      const double* __restrict__ Dinv, double* __restrict__ inv)
+{
+    const int64_t P = cs.P;
+    const int b = cs.b;
+    const int64_t p = blockIdx.y;
+    const int64_t j = int64_t(blockIdx.x) * 64 + threadIdx.x;
+    const int64_t row0 = p * L;
+    const int64_t m = ((p == P - 1) ? N : (row0 + L - b)) - row0;
+    if (j >= m)
+        return;
+    double* col = inv + size_t(p) * ld * ld + j;  // element k of the column: col[k * ld]
+    double hist[B];
+#pragma unroll
+    for (int d = 0; d < B; d++)
+        hist[d] = 0.0;
+    for (int64_t k = 0; k < m; k++)  // every lane walks all rows (zeros above row j): the factor loads are wave-uniform
+    {
+        double acc = (k == j) ? 1.0 : 0.0;
+#pragma unroll
+        for (int d = B - 1; d >= 0; d--)
+            acc -= ((d < b) ? Lf[cs.lf(p, k, d)] : 0.0) * hist[d];
+#pragma unroll
+        for (int d = B - 1; d > 0; d--)
+            hist[d] = hist[d - 1];
+        hist[0] = acc;
+        col[k * ld] = acc;
+    }
+#pragma unroll
+    for (int d = 0; d < B; d++)
+        hist[d] = 0.0;
+    for (int64_t k = m - 1; k >= 0; k--)
+    {
+        double acc = col[k * ld] * Dinv[cs.dinv(p, k)];
+#pragma unroll
+        for (int d = B - 1; d >= 0; d--)
+            acc -= ((d < b && k + d + 1 < m) ? Lf[cs.lf(p, k + d + 1, d)] : 0.0) * hist[d];
+#pragma unroll
+        for (int d = B - 1; d > 0; d--)
+            hist[d] = hist[d - 1];
+        hist[0] = acc;
+        col[k * ld] = acc;
+    }
+}
+
+// y_I(p) = inv(p) f_I(p): workgroup (p, column tile of 64), four wavefronts that each take every fourth row k of the block
+// (lane j reads inv[k][j]: 512 contiguous bytes per wavefront and row); partial sums meet in LDS in a fixed order.
+constexpr int kBlockGemvWaves = 4;
+__global__ __launch_bounds__(64 * kBlockGemvWaves) void k_block_gemv(int64_t N, int b, int64_t L, int64_t P, int64_t ld,
+                                                                      const double* __restrict__ inv, const double* __restrict__ f,
+                                                                      double* __restrict__ y)
+{
+    __shared__ double fs[256];
+    __shared__ double part[kBlockGemvWaves][64];
+    const int64_t p = blockIdx.y;
+    const int64_t row0 = p * L;
+    const int64_t m = ((p == P - 1) ? N : (row0 + L - b)) - row0;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t j = int64_t(blockIdx.x) * 64 + lane;
+    for (int64_t k = threadIdx.x; k < m; k += 64 * kBlockGemvWaves)
+        fs[k] = f[row0 + k];
+    __syncthreads();
+    const double* blk = inv + size_t(p) * ld * ld;
+    double acc = 0.0;
+    if (j < m)
+    {
+        int64_t k = w;
+        for (; k + 3 * kBlockGemvWaves < m; k += 4 * kBlockGemvWaves)
+        {
+            const double a0 = blk[k * ld + j], a1 = blk[(k + kBlockGemvWaves) * ld + j], a2 = blk[(k + 2 * kBlockGemvWaves) * ld + j],
+                         a3 = blk[(k + 3 * kBlockGemvWaves) * ld + j];
+            acc += a0 * fs[k];
+            acc += a1 * fs[k + kBlockGemvWaves];
+            acc += a2 * fs[k + 2 * kBlockGemvWaves];
+            acc += a3 * fs[k + 3 * kBlockGemvWaves];
+        }
+        for (; k < m; k += kBlockGemvWaves)
+            acc += blk[k * ld + j] * fs[k];
+    }
+    part[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && j < m)
+    {
+        double s = part[0][lane];
+#pragma unroll
+        for (int q = 1; q < kBlockGemvWaves; q++)
+            s += part[q][lane];
+        y[row0 + j] = s;
+    }
+}
+
 // separator rows: s = p*b + c  <->  global row (p+1)*L - b + c.  g[s] = f[r] - sum over interior neighbours M(r,j) y[j]
+// (all 4b operands are loaded before the first product: the kernel is a few thousand threads of pure latency)
+template <int B>
 __global__ __launch_bounds__(kThreads) void k_sep_rhs(int64_t N, int b, int64_t L, int64_t P, const double* __restrict__ band,
                                                        const double* __restrict__ f, const double* __restrict__ y,
                                                        double* __restrict__ g)
@@ -177,45 +504,76 @@ __global__ __launch_bounds__(kThreads) void k_sep_rhs(int64_t N, int b, int64_t 
         return;
     const int64_t p = s / b;
     const int64_t sep0 = (p + 1) * L - b, r = sep0 + (s % b);
-    double acc = f[r];
-    for (int d = 1; d <= b; d++)
+    double mu[B], yu[B], ml[B], yl[B];
+#pragma unroll
+    for (int d = 1; d <= B; d++)
     {
         const int64_t ju = r - d;  // above: interior of chunk p unless still inside this separator
-        if (ju >= 0 && ju < sep0)
-            acc -= band[r * (b + 1) + d] * y[ju];
+        const bool up = d <= b && ju >= 0 && ju < sep0;
+        mu[d - 1] = up ? band[r * (b + 1) + d] : 0.0;
+        yu[d - 1] = up ? y[ju] : 0.0;
         const int64_t jl = r + d;  // below: interior of chunk p+1 unless still inside this separator
-        if (jl < N && jl >= sep0 + b)
-            acc -= band[jl * (b + 1) + d] * y[jl];
+        const bool lo = d <= b && jl < N && jl >= sep0 + b;
+        ml[d - 1] = lo ? band[jl * (b + 1) + d] : 0.0;
+        yl[d - 1] = lo ? y[jl] : 0.0;
+    }
+    double acc = f[r];
+#pragma unroll
+    for (int d = 1; d <= B; d++)
+    {
+        if (d <= b && r - d >= 0 && r - d < sep0)
+            acc -= mu[d - 1] * yu[d - 1];
+        if (d <= b && r + d < N && r + d >= sep0 + b)
+            acc -= ml[d - 1] * yl[d - 1];
     }
     g[s] = acc;
 }
 
-// x_I = y_I - W [x_S(p-1); x_S(p)], x_S copied into place.  W: N x 2b row-major (zero rows for separators)
-__global__ __launch_bounds__(kThreads) void k_back_subst(int64_t N, int b, int64_t L, int64_t P, const double* __restrict__ W,
-                                                          const double* __restrict__ y, const double* __restrict__ xs,
-                                                          double* __restrict__ x)
+void launch_sep_rhs(hipStream_t stream, int64_t N, int b, int64_t L, int64_t P, const double* band, const double* f, const double* y,
+                    double* g)
 {
-    const int64_t r = int64_t(blockIdx.x) * kThreads + threadIdx.x;
-    if (r >= N)
-        return;
-    int64_t p = r / L;
-    if (p > P - 1)
-        p = P - 1;
-    const int64_t sep0 = (p + 1) * L - b;
-    if (p < P - 1 && r >= sep0)
+    const dim3 grid(unsigned(((P - 1) * b + kThreads - 1) / kThreads));
+    if (b <= 4)
+        hipLaunchKernelGGL(k_sep_rhs<4>, grid, dim3(kThreads), 0, stream, N, b, L, P, band, f, y, g);
+    else if (b <= 8)
+        hipLaunchKernelGGL(k_sep_rhs<8>, grid, dim3(kThreads), 0, stream, N, b, L, P, band, f, y, g);
+    else if (b <= 16)
+        hipLaunchKernelGGL(k_sep_rhs<16>, grid, dim3(kThreads), 0, stream, N, b, L, P, band, f, y, g);
+    else
+        hipLaunchKernelGGL(k_sep_rhs<64>, grid, dim3(kThreads), 0, stream, N, b, L, P, band, f, y, g);
+}
+
+// x_I = y_I - W [x_S(p-1); x_S(p)], x_S copied into place.  W: 2b columns of N (column c of row r at c*N + r; zero in
+// separator rows): one workgroup per chunk, so the 2b separator unknowns are wave-uniform (scalar loads) and every W / y / x
+// access is a coalesced line.  (The first version — one thread per row over a row-major W, chunk number by a 64-bit division —
+// ran at 3.6 TB/s.)
+constexpr int kBackThreads = 128;
+__global__ __launch_bounds__(kBackThreads) void k_back_subst(int64_t N, int b, int64_t L, int64_t P, const double* __restrict__ W,
+                                                             const double* __restrict__ y, const double* __restrict__ xs,
+                                                             double* __restrict__ x)
+{
+    const int64_t p = blockIdx.x;
+    const int64_t row0 = p * L;
+    const int64_t end = (p == P - 1) ? N : row0 + L;
+    const int64_t sep0 = (p == P - 1) ? N : row0 + L - b;
+    const double* const xprev = xs + (p - 1) * b;  // p > 0
+    const double* const xnext = xs + p * b;        // p < P - 1
+    for (int64_t r = row0 + threadIdx.x; r < end; r += kBackThreads)
     {
-        x[r] = xs[p * b + (r - sep0)];
-        return;
+        if (r >= sep0)
+        {
+            x[r] = xnext[r - sep0];
+            continue;
+        }
+        double acc = y[r];
+        if (p > 0)
+            for (int c = 0; c < b; c++)
+                acc -= W[int64_t(c) * N + r] * xprev[c];
+        if (p < P - 1)
+            for (int c = 0; c < b; c++)
+                acc -= W[int64_t(b + c) * N + r] * xnext[c];
+        x[r] = acc;
     }
-    double acc = y[r];
-    const double* w = W + r * (2 * b);
-    if (p > 0)
-        for (int c = 0; c < b; c++)
-            acc -= w[c] * xs[(p - 1) * b + c];
-    if (p < P - 1)
-        for (int c = 0; c < b; c++)
-            acc -= w[b + c] * xs[p * b + c];
-    x[r] = acc;
 }
 
 // dst = src with sigma subtracted from the diagonal entries (column 0 of the n x (b+1) row-major band)
@@ -232,14 +590,16 @@ __global__ __launch_bounds__(kThreads) void k_band_shift(int64_t total, int bw, 
 //   1. banded LDL' of the chunk's interior block (the last B rows of L and D kept in registers),
 //   2. the 2b spikes  W = M_II^{-1} M_IS  (forward/backward substitution with the factor just written),
 //   3. the chunk's (2b x 2b) contribution  M_SI W  to the Schur complement of its two separators.
-// band: N x (b+1) row-major, band[i*(b+1)+d] = M(i, i-d).  W (N x 2b row-major) and C (P x 2b x 2b) must be
+// band: N x (b+1) row-major, band[i*(b+1)+d] = M(i, i-d).  W (2b columns of N: column c of row r at c*N + r) and C (P x 2b x 2b) must be
 // zero on entry.  stats[0] counts boosted pivots (|d| <= tiny replaced by +-tiny), stats[1] is the smallest |pivot|.
 template <int B>
-__global__ __launch_bounds__(kChunkThreads) void k_chunk_factor(int64_t N, int b, int64_t L, int64_t P, double tiny,
+__global__ __launch_bounds__(kChunkThreads) void k_chunk_factor(int64_t N, int64_t L, ChunkStore cs, double tiny,
                                                                  const double* __restrict__ band, double* __restrict__ Lf,
                                                                  double* __restrict__ Dinv, double* __restrict__ W,
                                                                  double* __restrict__ C, unsigned long long* __restrict__ stats)
 {
+    const int64_t P = cs.P;
+    const int b = cs.b;
     const int64_t p = int64_t(blockIdx.x) * kChunkThreads + threadIdx.x;
     if (p >= P)
         return;
@@ -300,11 +660,11 @@ __global__ __launch_bounds__(kChunkThreads) void k_chunk_factor(int64_t N, int b
             }
             if (dv < 0.0)
                 negs++;
-            Dinv[k * P + p] = 1.0 / dv;
+            Dinv[cs.dinv(p, k)] = 1.0 / dv;
 #pragma unroll
             for (int d = 0; d < B; d++)
                 if (d < b)
-                    Lf[(k * b + d) * P + p] = lrow[d];
+                    Lf[cs.lf(p, k, d)] = lrow[d];
 #pragma unroll
             for (int i = B - 1; i > 0; i--)
             {
@@ -342,7 +702,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_chunk_factor(int64_t N, int b
             double lf[B];
 #pragma unroll
             for (int d = 0; d < B; d++)
-                lf[d] = (d < b) ? Lf[(k * b + d) * P + p] : 0.0;
+                lf[d] = (d < b) ? Lf[cs.lf(p, k, d)] : 0.0;
             const int dk = int(k < b ? k : b);
 #pragma unroll
             for (int c = 0; c < B; c++)
@@ -365,7 +725,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_chunk_factor(int64_t N, int b
                 for (int d = B - 1; d > 0; d--)
                     hist[c][d] = hist[c][d - 1];
                 hist[c][0] = acc;
-                W[(row0 + k) * w2 + side * b + c] = acc;
+                W[int64_t(side * b + c) * N + row0 + k] = acc;
             }
         }
 #pragma unroll
@@ -375,17 +735,17 @@ __global__ __launch_bounds__(kChunkThreads) void k_chunk_factor(int64_t N, int b
                 hist[c][d] = 0.0;
         for (int64_t k = m - 1; k >= 0; k--)
         {
-            const double di = Dinv[k * P + p];
+            const double di = Dinv[cs.dinv(p, k)];
             double lf[B];
 #pragma unroll
             for (int d = 0; d < B; d++)
-                lf[d] = (d < b && k + d + 1 < m) ? Lf[((k + d + 1) * b + d) * P + p] : 0.0;
+                lf[d] = (d < b && k + d + 1 < m) ? Lf[cs.lf(p, k + d + 1, d)] : 0.0;
 #pragma unroll
             for (int c = 0; c < B; c++)
             {
                 if (c >= b)
                     continue;
-                double acc = W[(row0 + k) * w2 + side * b + c] * di;
+                double acc = W[int64_t(side * b + c) * N + row0 + k] * di;
 #pragma unroll
                 for (int d = B - 1; d >= 0; d--)
                     acc -= lf[d] * hist[c][d];
@@ -393,7 +753,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_chunk_factor(int64_t N, int b
                 for (int d = B - 1; d > 0; d--)
                     hist[c][d] = hist[c][d - 1];
                 hist[c][0] = acc;
-                W[(row0 + k) * w2 + side * b + c] = acc;
+                W[int64_t(side * b + c) * N + row0 + k] = acc;
             }
         }
     }
@@ -415,13 +775,13 @@ __global__ __launch_bounds__(kChunkThreads) void k_chunk_factor(int64_t N, int b
                     const int64_t kend = (b < m) ? b : m;
                     for (int64_t k = 0; k < kend; k++)
                         if (k <= c1)
-                            acc += band[(row0 + k) * bw + (k + b - c1)] * W[(row0 + k) * w2 + s2];
+                            acc += band[(row0 + k) * bw + (k + b - c1)] * W[int64_t(s2) * N + row0 + k];
                 }
                 else
                 {
                     for (int64_t k = (m - b > 0 ? m - b : 0); k < m; k++)
                         if (k >= m + c1 - b)
-                            acc += band[(row0 + m + c1) * bw + (m + c1 - k)] * W[(row0 + k) * w2 + s2];
+                            acc += band[(row0 + m + c1) * bw + (m + c1 - k)] * W[int64_t(s2) * N + row0 + k];
                 }
                 Cp[(side1 * b + c1) * w2 + s2] = acc;
             }
@@ -604,8 +964,11 @@ struct mispec::BandLevel
 {
     int64_t N = 0, L = 0, P = 1;
     int b = 0;
+    ChunkStore cs;  // layout of Lf / Dinv
     DevBuf<double> Lf, Dinv, W, band, y, g, xs;
     DevBuf<double> inv;  // last level only: explicit inverse (N x N), applied by a dense GEMV
+    DevBuf<double> binv;  // partitioned level with few chunks: explicit inverses of the interiors, P blocks of binv_ld x binv_ld
+    int64_t binv_ld = 0;
     DevBuf<double> linv, linvt;  // last level, Cholesky use only: C^{-1} and C^{-T} of the level's M = C C' (row-major)
     std::unique_ptr<BandLevel> next;
 };
@@ -680,6 +1043,36 @@ bool factored_on_device(int64_t N, int b)
     return P > 1 && b <= 8 && !host_only;
 }
 
+// Whether the chunk interiors of a partitioned level are also inverted explicitly (k_chunk_inverse / k_block_gemv): levels
+// whose chunks would not fill the device with one lane each, as long as the blocks stay small next to the matrix
+// (MISPEC_SHIFT_BLOCK_INVERSE=0 keeps the sweeps; =<MiB> moves the size limit, default 256 MiB per level).
+bool wants_block_inverse(int64_t P, int64_t mmax, int b)
+{
+    static const long long limit_mib = getenv("MISPEC_SHIFT_BLOCK_INVERSE") ? atoll(getenv("MISPEC_SHIFT_BLOCK_INVERSE")) : 256;
+    if (limit_mib <= 0 || mmax > 256 || b > 16)
+        return false;
+    const double bytes = double(P) * double(mmax) * double(mmax) * 8.0;
+    return P <= 65535 && bytes <= double(limit_mib) * 1048576.0;  // P: grid.y of the two kernels
+}
+
+void build_block_inverses(const mispec_ctx& ctx, BandLevel& lev, int64_t mmax)
+{
+    lev.binv_ld = mmax;
+    lev.binv.alloc(size_t(lev.P) * mmax * mmax);
+    MISPEC_HIP(hipMemsetAsync(lev.binv.p, 0, lev.binv.n * sizeof(double), ctx.stream));
+    const dim3 grid(unsigned((mmax + 63) / 64), unsigned(lev.P));
+    if (lev.b <= 4)
+        hipLaunchKernelGGL((k_chunk_inverse<4>), grid, dim3(64), 0, ctx.stream, lev.N, lev.L, lev.cs, mmax, lev.Lf.p, lev.Dinv.p,
+                           lev.binv.p);
+    else if (lev.b <= 8)
+        hipLaunchKernelGGL((k_chunk_inverse<8>), grid, dim3(64), 0, ctx.stream, lev.N, lev.L, lev.cs, mmax, lev.Lf.p, lev.Dinv.p,
+                           lev.binv.p);
+    else
+        hipLaunchKernelGGL((k_chunk_inverse<16>), grid, dim3(64), 0, ctx.stream, lev.N, lev.L, lev.cs, mmax, lev.Lf.p, lev.Dinv.p,
+                           lev.binv.p);
+    MISPEC_HIP(hipGetLastError());
+}
+
 // Factor the band matrix M (destroyed) into `lev`, recursively.
 void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& stats)
 {
@@ -702,7 +1095,9 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
 
     const bool on_device = factored_on_device(N, b);
     MISPEC_REQUIRE(on_device || !M.view, "internal: a band view is only valid for a level factored on the device");
-    const size_t lf_size = size_t(mmax) * std::max(b, 1) * P, dinv_size = size_t(mmax) * P, w_size = size_t(N) * 2 * std::max(b, 1);
+    const ChunkStore cs = make_chunk_store(N, b, L, P);
+    lev.cs = cs;
+    const size_t lf_size = cs.lf_size(), dinv_size = cs.dinv_size(), w_size = size_t(N) * 2 * std::max(b, 1);
     std::vector<double> Lf, Dinv, W;  // host images of the factor (host path only)
     if (!on_device)
     {
@@ -752,10 +1147,10 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
         }
         const dim3 grid(unsigned((P + kChunkThreads - 1) / kChunkThreads));
         if (b <= 4)
-            hipLaunchKernelGGL((k_chunk_factor<4>), grid, dim3(kChunkThreads), 0, ctx->stream, N, b, L, P, tiny, lev.band.p,
+            hipLaunchKernelGGL((k_chunk_factor<4>), grid, dim3(kChunkThreads), 0, ctx->stream, N, L, cs, tiny, lev.band.p,
                                lev.Lf.p, lev.Dinv.p, lev.W.p, Cdev.p, dstats.p);
         else
-            hipLaunchKernelGGL((k_chunk_factor<8>), grid, dim3(kChunkThreads), 0, ctx->stream, N, b, L, P, tiny, lev.band.p,
+            hipLaunchKernelGGL((k_chunk_factor<8>), grid, dim3(kChunkThreads), 0, ctx->stream, N, L, cs, tiny, lev.band.p,
                                lev.Lf.p, lev.Dinv.p, lev.W.p, Cdev.p, dstats.p);
         MISPEC_HIP(hipGetLastError());
         std::vector<double> Cc(Cdev.n);
@@ -902,9 +1297,9 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
         }
         for (int64_t k = 0; k < m; k++)
         {
-            Dinv[size_t(k) * P + p] = 1.0 / D[size_t(k)];
+            Dinv[cs.dinv(p, k)] = 1.0 / D[size_t(k)];
             for (int d = 0; d < b; d++)
-                Lf[(size_t(k) * b + d) * P + p] = Lc[size_t(k) * b + d];
+                Lf[cs.lf(p, k, d)] = Lc[size_t(k) * b + d];
         }
         // ---- spikes W = M_II^{-1} M_IS and their contribution to the Schur complement -------------------
         auto solve_block = [&](std::vector<double>& v) {
@@ -946,7 +1341,7 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
                     solve_block(rhs);
                 spike[size_t(side * b + c)] = rhs;
                 for (int64_t k = 0; k < m; k++)
-                    W[size_t(row0 + k) * 2 * b + side * b + c] = rhs[size_t(k)];
+                    W[size_t(side * b + c) * N + size_t(row0 + k)] = rhs[size_t(k)];
             }
         }
         // S(s1, s2) -= sum_k M(sep row s1, interior k) * spike_s2[k]
@@ -1014,6 +1409,8 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
         lev.g.alloc(size_t(nsep));
         lev.xs.alloc(size_t(nsep));
     }
+    if (P > 1 && !stats.want_cholesky && wants_block_inverse(P, mmax, b))
+        build_block_inverses(*ctx, lev, mmax);
     MISPEC_HIP(hipStreamSynchronize(ctx->stream));
     M.a.clear();
     M.a.shrink_to_fit();
@@ -1042,13 +1439,56 @@ void launch_chunk_solve(const mispec_ctx& ctx, const BandLevel& lev, dim3 grid_u
                         double* u_out = nullptr)
 {
     (void) grid_unused;
-    const int lanes = lev.P == 1 ? 1 : solve_lanes(lev.P);
-    const dim3 grid(unsigned((lev.P + lanes - 1) / lanes));
-#define MISPEC_CHUNK(B, U)                                                                                                  \
-    hipLaunchKernelGGL((k_chunk_solve<B, U>), grid, dim3(unsigned(lanes)), 0, ctx.stream, lev.N, lev.b, lev.L, lev.P, lev.Lf.p, \
-                       lev.Dinv.p, f, y, mode, u_out)
-    // U rows of factor entries are in flight per lane and batch ((B + 2) * U doubles): as deep as the register
-    // file allows, because with one lane per chunk nothing else hides the load latency
+    const int lanes = solve_lanes(lev.P);
+    const dim3 grid(unsigned((lev.P - 1 + lanes - 1) / lanes) + 1);  // + the last chunk's own workgroup
+    const bool chol = mode != 0 || u_out != nullptr;
+    // plain solves of a level whose wavefront segments fit the LDS: the staged kernel (MISPEC_SHIFT_LDS=0: always the general one)
+    static const bool lds_off = getenv("MISPEC_SHIFT_LDS") && atoi(getenv("MISPEC_SHIFT_LDS")) == 0;
+    static const int batch = getenv("MISPEC_SHIFT_BATCH") ? atoi(getenv("MISPEC_SHIFT_BATCH")) : 0;
+    if (!chol && !lds_off && lev.P > 1 && lev.b >= 1 && lev.b <= 8)
+    {
+        const int U = (batch == 8 || batch == 16 || batch == 32) ? batch : (lev.b <= 4 ? 32 : 16);
+        const auto whole = [U](int64_t m) { return (m + U - 1) / U * U; };
+        // LDS row stride of a chunk: the padded interior; the last chunk's (its workgroup holds it alone) may spread over all rows
+        const int64_t ldl = std::max<int64_t>(whole(lev.L - lev.b), (whole(lev.N - (lev.P - 1) * lev.L) + lanes - 1) / lanes) | 1;
+        const size_t lds_bytes = size_t(lanes) * size_t(ldl) * sizeof(double);
+        if (lds_bytes <= 160 * 1024)
+        {
+            const auto launch = [&](auto kernel) {
+                MISPEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               int(lds_bytes)));
+                hipLaunchKernelGGL(kernel, grid, dim3(kStageThreads), lds_bytes, ctx.stream, lev.N, lev.L, lev.cs, int(ldl), lanes, lev.Lf.p,
+                                   lev.Dinv.p, f, y);
+            };
+#define MISPEC_LDS_CASE(B)                       \
+    case B:                                      \
+        if (U == 32)                             \
+            launch(&k_chunk_solve_lds<B, 32>);   \
+        else if (U == 16)                        \
+            launch(&k_chunk_solve_lds<B, 16>);   \
+        else                                     \
+            launch(&k_chunk_solve_lds<B, 8>);    \
+        break
+            switch (lev.b)
+            {
+                MISPEC_LDS_CASE(1);
+                MISPEC_LDS_CASE(2);
+                MISPEC_LDS_CASE(3);
+                MISPEC_LDS_CASE(4);
+                MISPEC_LDS_CASE(5);
+                MISPEC_LDS_CASE(6);
+                MISPEC_LDS_CASE(7);
+                MISPEC_LDS_CASE(8);
+            }
+#undef MISPEC_LDS_CASE
+            MISPEC_HIP(hipGetLastError());
+            return;
+        }
+    }
+    (void) chol;
+#define MISPEC_CHUNK(B, U) \
+    hipLaunchKernelGGL((k_chunk_solve<B, U>), grid, dim3(unsigned(lanes)), 0, ctx.stream, lev.N, lev.L, lev.cs, lev.Lf.p, lev.Dinv.p, f, y, mode, u_out)
+    // U rows of factor entries are in flight per lane and batch ((B + 2) * U doubles): as deep as the register file allows
     if (lev.b <= 4)
         MISPEC_CHUNK(4, 32);
     else if (lev.b <= 8)
@@ -1065,7 +1505,6 @@ void launch_chunk_solve(const mispec_ctx& ctx, const BandLevel& lev, dim3 grid_u
 
 void solve_level(const mispec_ctx& ctx, const BandLevel& lev, const double* f, double* x)
 {
-    const auto blocks = [](int64_t n) { return dim3(unsigned((n + kThreads - 1) / kThreads)); };
     if (lev.P == 1)
     {
         if (lev.inv.p)
@@ -1078,12 +1517,18 @@ void solve_level(const mispec_ctx& ctx, const BandLevel& lev, const double* f, d
             launch_chunk_solve(ctx, lev, dim3(1), f, x);
         return;
     }
-    launch_chunk_solve(ctx, lev, dim3(unsigned((lev.P + kChunkThreads - 1) / kChunkThreads)), f, lev.y.p);
-    hipLaunchKernelGGL(k_sep_rhs, blocks((lev.P - 1) * lev.b), dim3(kThreads), 0, ctx.stream, lev.N, lev.b, lev.L, lev.P,
-                       lev.band.p, f, lev.y.p, lev.g.p);
+    if (lev.binv.p)
+    {
+        hipLaunchKernelGGL(k_block_gemv, dim3(unsigned((lev.binv_ld + 63) / 64), unsigned(lev.P)), dim3(64 * kBlockGemvWaves), 0,
+                           ctx.stream, lev.N, lev.b, lev.L, lev.P, lev.binv_ld, lev.binv.p, f, lev.y.p);
+        MISPEC_HIP(hipGetLastError());
+    }
+    else
+        launch_chunk_solve(ctx, lev, dim3(unsigned((lev.P + kChunkThreads - 1) / kChunkThreads)), f, lev.y.p);
+    launch_sep_rhs(ctx.stream, lev.N, lev.b, lev.L, lev.P, lev.band.p, f, lev.y.p, lev.g.p);
     MISPEC_HIP(hipGetLastError());
     solve_level(ctx, *lev.next, lev.g.p, lev.xs.p);
-    hipLaunchKernelGGL(k_back_subst, blocks(lev.N), dim3(kThreads), 0, ctx.stream, lev.N, lev.b, lev.L, lev.P, lev.W.p, lev.y.p,
+    hipLaunchKernelGGL(k_back_subst, dim3(unsigned(lev.P)), dim3(kBackThreads), 0, ctx.stream, lev.N, lev.b, lev.L, lev.P, lev.W.p, lev.y.p,
                        lev.xs.p, x);
     MISPEC_HIP(hipGetLastError());
 }
@@ -1117,7 +1562,7 @@ void chol_forward(const mispec_ctx& ctx, const BandLevel& lev, const double* f, 
     }
     const int64_t nsep = (lev.P - 1) * lev.b;
     launch_chunk_solve(ctx, lev, dim3(unsigned((lev.P + kChunkThreads - 1) / kChunkThreads)), f, lev.y.p, 0, u);
-    hipLaunchKernelGGL(k_sep_rhs, blocks(nsep), dim3(kThreads), 0, ctx.stream, lev.N, lev.b, lev.L, lev.P, lev.band.p, f, lev.y.p, lev.g.p);
+    launch_sep_rhs(ctx.stream, lev.N, lev.b, lev.L, lev.P, lev.band.p, f, lev.y.p, lev.g.p);
     MISPEC_HIP(hipGetLastError());
     chol_forward(ctx, *lev.next, lev.g.p, lev.xs.p);
     hipLaunchKernelGGL(k_sep_move, blocks(nsep), dim3(kThreads), 0, ctx.stream, nsep, lev.b, lev.L, lev.xs.p, u, 1);
@@ -1137,7 +1582,7 @@ void chol_backward(const mispec_ctx& ctx, const BandLevel& lev, const double* u,
     MISPEC_HIP(hipGetLastError());
     chol_backward(ctx, *lev.next, lev.g.p, lev.xs.p);
     launch_chunk_solve(ctx, lev, dim3(unsigned((lev.P + kChunkThreads - 1) / kChunkThreads)), u, lev.y.p, 2, nullptr);
-    hipLaunchKernelGGL(k_back_subst, blocks(lev.N), dim3(kThreads), 0, ctx.stream, lev.N, lev.b, lev.L, lev.P, lev.W.p, lev.y.p, lev.xs.p, x);
+    hipLaunchKernelGGL(k_back_subst, dim3(unsigned(lev.P)), dim3(kBackThreads), 0, ctx.stream, lev.N, lev.b, lev.L, lev.P, lev.W.p, lev.y.p, lev.xs.p, x);
     MISPEC_HIP(hipGetLastError());
 }
 

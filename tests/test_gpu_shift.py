@@ -230,3 +230,47 @@ def test_definite_matrices_need_no_refinement(ctx):
     op.set_shift(0.0)
     info = op.refinement_info()
     assert info["refine_steps"] == 0 and info["boosted_pivots"] == 0 and info["probe_backward_error"] <= 4e-15, info
+
+
+def _solve_in_subprocess(env_extra, cases):
+    """One process per setting of the kernel switches (they are read once per process): crc32 of the solution for every case."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, zlib, numpy as np, scipy.sparse as sp; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import spectra_amd as sa\n"
+        "from test_gpu_shift import banded_spd, banded_indefinite\n"
+        "for n, b, sigma, indef in %r:\n"
+        "    A = (banded_indefinite if indef else banded_spd)(n, b, seed=n)\n"
+        "    op = sa.SparseSymShiftSolve(sp.tril(A).tocsc()); op.set_shift(sigma)\n"
+        "    x = np.random.default_rng(1).uniform(-1, 1, n); y = op.perform_op(x)\n"
+        "    r = (A - sigma * sp.identity(n)) @ y - x\n"
+        "    print(zlib.crc32(y.tobytes()), float(np.linalg.norm(r) / np.linalg.norm(x)), op.refinement_info()['refine_steps'])\n"
+    ) % (root, os.path.join(root, "tests"), cases)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env_extra), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return [line.split() for line in r.stdout.strip().splitlines()]
+
+
+def test_solve_kernel_variants_agree():
+    # (i) the LDS-staged sweeps (k_chunk_solve_lds: 16-byte loads, whole batches over the zero padding, vector in LDS) against the
+    # general kernel (MISPEC_SHIFT_LDS=0), any batch length and chunks per wavefront: the same operations in the same order, so
+    # the SAME BITS; (ii) the explicit inverses of the lower levels' chunk interiors (k_chunk_inverse / k_block_gemv) against the
+    # sweeps there (MISPEC_SHIFT_BLOCK_INVERSE=0): a different but equally stable evaluation — residual at the same level.
+    # Sizes: two / three levels, a last chunk longer than the others (n not a multiple of 128), every instantiated bandwidth.
+    cases = [(300_001, 1, 0.0, 0), (300_077, 2, -1.0, 0), (1_000_003, 3, 0.0, 0), (200_050, 4, 0.0, 0), (150_001, 5, -0.5, 0),
+             (100_003, 7, 0.0, 0), (100_000, 8, 0.0, 0), (400_000, 3, 0.3, 1)]
+    base = _solve_in_subprocess({}, cases)
+    for env in ({"MISPEC_SHIFT_LDS": "0"}, {"MISPEC_SHIFT_BATCH": "16"}, {"MISPEC_SHIFT_BATCH": "8"}, {"MISPEC_SHIFT_LANES": "32"},
+                {"MISPEC_SHIFT_LANES": "16", "MISPEC_SHIFT_BATCH": "16"}):
+        other = _solve_in_subprocess(env, cases)
+        assert [o[0] for o in other] == [o[0] for o in base], (env, other, base)
+    sweeps = _solve_in_subprocess({"MISPEC_SHIFT_BLOCK_INVERSE": "0"}, cases)
+    for (crc_a, res_a, steps_a), (crc_b, res_b, steps_b), case in zip(base, sweeps, cases):
+        tol = 1e-10 if case[3] else 1e-12   # interior shift: the matrix is indefinite and worse conditioned
+        assert float(res_a) <= tol and float(res_b) <= tol, (case, res_a, res_b)
+        assert steps_a == steps_b, (case, steps_a, steps_b)

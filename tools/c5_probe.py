@@ -1,5 +1,5 @@
 import sys, time, json, os, numpy as np, scipy.sparse as sp
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import spectra_amd as sa
 from test_gpu_fullsize import banded_spd
 n = 2_000_000
@@ -14,4 +14,4 @@ for r in range(3):
     p = s.get_profile()
     if r and (best is None or dt < best[0]): best = (dt, p["ms_spmv"] / p["n_spmv"], nc, s.num_operations())
 x = np.random.default_rng(0).uniform(-1, 1, n); y = op.perform_op(x)
-print(json.dumps({"lanes": os.environ.get("MISPEC_SHIFT_LANES", "default"), "chunks": os.environ.get("MISPEC_SHIFT_CHUNK", "default"), "set_shift_s": round(tf, 4), "solve_ms": round(best[1], 4), "solve_s": round(best[0], 4), "nconv": best[2], "nops": best[3], "resid": float(np.abs(A @ y - x).max())}))
+print(json.dumps({"lanes": os.environ.get("MISPEC_SHIFT_LANES", "default"), "block_inverse": os.environ.get("MISPEC_SHIFT_BLOCK_INVERSE", "default"), "batch": os.environ.get("MISPEC_SHIFT_BATCH", "default"), "lds": os.environ.get("MISPEC_SHIFT_LDS", "default"), "chunks": os.environ.get("MISPEC_SHIFT_CHUNK", "default"), "set_shift_s": round(tf, 4), "solve_ms": round(best[1], 4), "solve_s": round(best[0], 4), "nconv": best[2], "nops": best[3], "resid": float(np.abs(A @ y - x).max())}))

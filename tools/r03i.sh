@@ -1,0 +1,10 @@
+OUT=gpurun_out/r03i; mkdir -p $OUT
+timeout 900 python -m pytest tests/test_gpu_shift.py tests/test_gpu_geigs.py -m gpu -q > $OUT/pytest_subset.log 2>&1; tail -4 $OUT/pytest_subset.log
+sed -i 's/"lds": os.environ.get("MISPEC_SHIFT_LDS", "default"),/"lds": os.environ.get("MISPEC_SHIFT_LDS", "default"), "prefetch": os.environ.get("MISPEC_SHIFT_PREFETCH", "0"),/' tools/c5_probe.py
+for bt in 32 16; do MISPEC_SHIFT_BATCH=$bt timeout 280 python tools/c5_probe.py >> $OUT/c5.jsonl 2>> $OUT/err.log; done
+for bt in 16 8; do MISPEC_SHIFT_PREFETCH=1 MISPEC_SHIFT_BATCH=$bt timeout 280 python tools/c5_probe.py >> $OUT/c5.jsonl 2>> $OUT/err.log; done
+MISPEC_SHIFT_PREFETCH=1 MISPEC_SHIFT_BATCH=16 MISPEC_SHIFT_LANES=32 timeout 280 python tools/c5_probe.py >> $OUT/c5.jsonl 2>> $OUT/err.log
+MISPEC_SHIFT_LANES=32 timeout 280 python tools/c5_probe.py >> $OUT/c5.jsonl 2>> $OUT/err.log
+cat $OUT/c5.jsonl
+(cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o c5 -- python $GRAFT_REPO_ROOT/tools/c5_probe.py > /dev/null 2> $GRAFT_REPO_ROOT/$OUT/rocprof.err)
+f=$(find $OUT/prof -name '*kernel_stats.csv' | head -1); cp $f $OUT/c5_kernel_stats.csv; rm -rf $OUT/prof; grep -E "chunk_solve|back_subst|block_gemv|sep_rhs|row_gemv" $OUT/c5_kernel_stats.csv | cut -c1-60,150-260
