@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void k_spmv_dia(DiaArgs da, const double* __re
 // The same product with the x entries of a row-block staged through LDS: the offsets cluster, so a block of 256 rows reads
 // a few contiguous windows of x (coalesced, once) instead of one 8-byte load per row and diagonal through the L1.
 // NG = groups of eight diagonals whose values a thread keeps in registers.
-template <bool EPI, int NG, bool FUSE = false>
+template <bool EPI, int NG, bool FUSE = false, int NCW = 8>  // NCW: registers for window entries (>= number of windows)
 __global__ __launch_bounds__(256) void k_spmv_dia_win(DiaArgs da, mispec_dia_windows w, const double* __restrict__ x,
                                                       double* __restrict__ y, int64_t nrows, int nblocks, SpmvEpilogue epi)
 {
@@ -435,14 +435,73 @@ __global__ __launch_bounds__(256) void k_spmv_dia_win(DiaArgs da, mispec_dia_win
 #pragma unroll
     for (int k = 0; k < NG * kDiaGroup; k++)
         v[k] = __builtin_nontemporal_load(vrow + int64_t(min(k, da.nd - 1)) * vstride);
-    const int64_t g0 = da.row_begin + row0;
-    for (int c = 0; c < w.nc; c++)
-        for (int i = tid; i < w.len[c]; i += 256)
+    // The epilogue's operands travel with the matrix values: issued here, they are in flight during the window staging and
+    // the barrier instead of costing the block a second round trip to HBM after its row sums (the kernel is bound by the
+    // number of resident blocks, i.e. by latency per block: profiles/r02r_*, r03q_*).
+    double vprev_early = 0.0, vrow_early = 0.0, hprev_early = 0.0;
+    const bool early = EPI && !epi.late_loads && tid < nr;
+    if (early)
+    {
+        if (epi.v_prev)
         {
-            const int64_t col = g0 + w.start[c] + i;
-            const double xv = x[min(max(col, int64_t(0)), int64_t(da.col_max))];
-            xs[w.base[c] + i] = FUSE ? xv / beta : xv;  // the same true division as k_scale_step: the same v, bit for bit
+            vprev_early = epi.v_prev[row0 + tid];
+            if (!FUSE)
+                hprev_early = epi.h_prev_dev ? *epi.h_prev_dev : epi.h_prev;
         }
+        if (!FUSE)
+            vrow_early = epi.v_rows[row0 + tid];
+    }
+    const int64_t g0 = da.row_begin + row0;
+    // x windows -> LDS.  A window is 256 + span entries: two per thread, ALL loaded before the first LDS write.  (Written as
+    // a loop over windows and pieces, each piece was a load, a wait and a write: ten dependent round trips per block on the
+    // five clusters of M-band, the latency the occupancy experiments of profiles/r02r_* were measuring.)
+    const auto xat = [&](int64_t col) { return x[min(max(col, int64_t(0)), int64_t(da.col_max))]; };
+    // entry tid of every window in a register of its own; the entries past 256 (the spans: 10 in all for M-band) one per
+    // thread, thread t taking the t-th of them — 64 VGPRs in total, i.e. eight workgroups per CU as before
+    double xw[NCW], xtail = 0.0;
+    int tail_pos = -1;  // LDS slot of this thread's tail entry
+    const int tails = w.total - 256 * w.nc;
+    {
+        int before = 0;
+#pragma unroll
+        for (int c = 0; c < NCW; c++)
+        {
+            xw[c] = 0.0;
+            if (c < w.nc)
+            {
+                xw[c] = xat(g0 + w.start[c] + tid);
+                const int span = w.len[c] - 256;
+                if (tid >= before && tid < before + span)
+                {
+                    tail_pos = w.base[c] + 256 + (tid - before);
+                    xtail = xat(g0 + w.start[c] + 256 + (tid - before));
+                }
+                before += span;
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < NCW; c++)
+        if (c < w.nc)
+            xs[w.base[c] + tid] = FUSE ? xw[c] / beta : xw[c];  // the same true division as k_scale_step: the same v, bit for bit
+    if (tail_pos >= 0)
+        xs[tail_pos] = FUSE ? xtail / beta : xtail;
+    if (tails > 256)  // more tail entries than threads (very wide clusters): the rest the slow way
+    {
+        int before = 0;
+        for (int c = 0; c < w.nc; c++)
+        {
+            const int span = w.len[c] - 256;
+            for (int t = tid + 256; t < before + span; t += 256)
+                if (t >= before)
+                {
+                    const double xv = xat(g0 + w.start[c] + 256 + (t - before));
+                    xs[w.base[c] + 256 + (t - before)] = FUSE ? xv / beta : xv;
+                }
+            before += span;
+        }
+    }
     double vown = 0.0;
     if (FUSE)
         vown = x[da.row_begin + row0 + min(tid, nr - 1)] / beta;
@@ -460,7 +519,8 @@ __global__ __launch_bounds__(256) void k_spmv_dia_win(DiaArgs da, mispec_dia_win
             const int64_t row = row0 + tid;
             double yv = acc;
             if (epi.v_prev)
-                yv -= (FUSE ? beta : (epi.h_prev_dev ? *epi.h_prev_dev : epi.h_prev)) * epi.v_prev[row];  // Lanczos.h:139
+                yv -= (FUSE ? beta : (early ? hprev_early : (epi.h_prev_dev ? *epi.h_prev_dev : epi.h_prev))) *
+                      (early ? vprev_early : epi.v_prev[row]);  // Lanczos.h:139
             y[row] = yv;
             if (FUSE)
             {
@@ -468,7 +528,7 @@ __global__ __launch_bounds__(256) void k_spmv_dia_win(DiaArgs da, mispec_dia_win
                 contrib = vown * yv;
             }
             else
-                contrib = epi.v_rows[row] * yv;  // Lanczos.h:142 partial <v, w>
+                contrib = (early ? vrow_early : epi.v_rows[row]) * yv;  // Lanczos.h:142 partial <v, w>
         }
         const double total = block_reduce_sum(contrib, red);
         if (tid == 0)
@@ -1032,6 +1092,8 @@ void launch_spmv_raw(const mispec_csr& A, const double* x_dev, double* y_dev, co
     static const bool nt = getenv("MISPEC_SPMV_NT") ? atoi(getenv("MISPEC_SPMV_NT")) != 0 : false;
     SpmvEpilogue e = epi ? *epi : SpmvEpilogue{};
     e.first_block = block_first;
+    static const bool late_epilogue = getenv("MISPEC_DIA_LATE_EPILOGUE") && atoi(getenv("MISPEC_DIA_LATE_EPILOGUE")) != 0;
+    e.late_loads = late_epilogue ? 1 : 0;
     const int format = A.spmv_format();
     const bool coded = format == 1;
     const SpmvCodes cd{A.codes.p, A.dict.p, A.ndict, int(A.n_cols - 1), A.row_begin};
@@ -1052,14 +1114,24 @@ void launch_spmv_raw(const mispec_csr& A, const double* x_dev, double* y_dev, co
             static const size_t lds_pad = getenv("MISPEC_DIA_LDS_PAD") ? size_t(atol(getenv("MISPEC_DIA_LDS_PAD"))) : 0;
             const size_t lds = size_t(A.dia_win.total) * sizeof(double) + lds_pad;
             const int ng = (A.ndia + kDiaGroup - 1) / kDiaGroup;
-#define MISPEC_DIA_WIN(E, G)                                                                                               \
+#define MISPEC_DIA_WIN_W(E, G, W)                                                                                             \
     do                                                                                                                     \
     {                                                                                                                      \
         if (ev_start && ev_stop)                                                                                           \
-            hipExtLaunchKernelGGL((k_spmv_dia_win<E, G>), grid, block, lds, A.ctx->stream, ev_start, ev_stop, 0, da, A.dia_win, x_dev, \
+            hipExtLaunchKernelGGL((k_spmv_dia_win<E, G, false, W>), grid, block, lds, A.ctx->stream, ev_start, ev_stop, 0, da, A.dia_win, x_dev, \
                                   y_dev, nloc, nblocks, e);                                                                \
         else                                                                                                               \
-            hipLaunchKernelGGL((k_spmv_dia_win<E, G>), grid, block, lds, A.ctx->stream, da, A.dia_win, x_dev, y_dev, nloc, nblocks, e); \
+            hipLaunchKernelGGL((k_spmv_dia_win<E, G, false, W>), grid, block, lds, A.ctx->stream, da, A.dia_win, x_dev, y_dev, nloc, nblocks, e); \
+    } while (0)
+#define MISPEC_DIA_WIN(E, G)              \
+    do                                    \
+    {                                     \
+        if (A.dia_win.nc <= 4)            \
+            MISPEC_DIA_WIN_W(E, G, 4);    \
+        else if (A.dia_win.nc <= 6)       \
+            MISPEC_DIA_WIN_W(E, G, 6);    \
+        else                              \
+            MISPEC_DIA_WIN_W(E, G, 8);    \
     } while (0)
 #define MISPEC_DIA_WIN_G(E)          \
     do                               \
@@ -1102,6 +1174,7 @@ void launch_spmv_raw(const mispec_csr& A, const double* x_dev, double* y_dev, co
                 MISPEC_DIA_WIN_G(false);
 #undef MISPEC_DIA_WIN_G
 #undef MISPEC_DIA_WIN
+#undef MISPEC_DIA_WIN_W
             MISPEC_HIP(hipGetLastError());
             return;
         }

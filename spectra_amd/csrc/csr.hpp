@@ -107,6 +107,7 @@ struct SpmvEpilogue
     double* v_out = nullptr;
     int scale_step = 0;
     double scale_eps_sqrt = 0.0;
+    int late_loads = 0;               // set by the launcher (MISPEC_DIA_LATE_EPILOGUE=1): read v_prev / v only after the row sums
 };
 // true when launch_spmv_raw(A, ...) with an epilogue that carries scale_state would be honoured (else the caller must scale itself)
 bool spmv_can_fuse_scale(const ::mispec_csr& A);
