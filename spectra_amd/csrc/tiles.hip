@@ -157,8 +157,8 @@ bool build_tiles(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int3
     }
     T.seg_entry[size_t(nseg)] = int64_t(T.val.size());
     T.seg_chunk[size_t(nseg)] = int32_t(T.chunks.size());
-    // slack so that the kernel's unconditional 4-entry loads never leave the arrays
-    for (int k = 0; k < kTileChunk; k++)
+    // slack so that the kernel's unconditional loads (two chunks ahead) never leave the arrays
+    for (int k = 0; k < kTileSlack; k++)
     {
         T.val.push_back(0.0);
         T.idx.push_back(kTileSkip);
@@ -306,7 +306,9 @@ __global__ __launch_bounds__(kTileThreads) void k_spmv_tiles(const int64_t* __re
             {
                 const TileChunk ch = chunks[ci];
                 const int count = ch.count;
-                // the next chunk's entries follow this chunk's: issue their loads now (the arrays end with a chunk of slack)
+                // the next chunk's entries follow this chunk's: issue their loads now (the arrays end with slack).  Also issuing
+                // the NEXT chunk's x gathers here (three chunks in flight per thread) measured 1.46 against 1.33 ms on M-rand
+                // (profiles/r03t_*): the gathers are bound by the fabric, more of them in flight only evict each other
                 const int noff = off + count;
 #pragma unroll
                 for (int k = 0; k < kPer; k++)
@@ -423,7 +425,7 @@ void upload_tiles(const HostTiles& H, hipStream_t stream, DevTiles& D)
     up(D.idx, H.idx);
     MISPEC_HIP(hipStreamSynchronize(stream));
     D.nseg = int64_t(H.seg_entry.size()) - 1;
-    D.entries = int64_t(H.val.size()) - kTileChunk;
+    D.entries = int64_t(H.val.size()) - kTileSlack;
     D.nchunks = int64_t(H.chunks.size());
     D.padding = H.padding;
     D.ncb = H.ncb;
@@ -562,7 +564,7 @@ extern "C" int mispec_tiles_spmv_host(int64_t nrows, int64_t ncols, const int32_
         mispec::tiles_spmv_host(T, nrows, x, y);
         if (stats)
         {
-            stats[0] = int64_t(T.val.size()) - mispec::kTileChunk;
+            stats[0] = int64_t(T.val.size()) - mispec::kTileSlack;
             stats[1] = T.padding;
             stats[2] = int64_t(T.chunks.size());
         }

@@ -34,6 +34,7 @@ constexpr int kTileMaxRun = (1 << kTileRunBits) - 1;
 constexpr int kTileChunk = MISPEC_TILE_CHUNK;       // entries handled between two barriers (kTileChunk / kTileThreads per thread)
 static_assert(kTileRunBits >= 2 && kTileRunBits <= 8, "tile index packing: row + column bits must leave 2..8 bits for the run length");
 constexpr uint32_t kTileSkip = 0xFFFFFFFFu;      // padding entry
+constexpr int kTileSlack = 2 * kTileChunk;        // padding entries behind the last segment: the kernel prefetches two chunks ahead
 
 // idx = row_local << (col bits + 3) | col_local << 3 | run      run = 0: continuation of the run started by an earlier entry;
 //                                                   run = k >= 1: first of k consecutive entries of this row in this tile
