@@ -8,7 +8,6 @@
 #include <Spectra/GenEigsComplexShiftSolver.h>
 #include <Spectra/GenEigsRealShiftSolver.h>
 #include <Spectra/GenEigsSolver.h>
-#include <Spectra/HermEigsSolver.h>
 #include <Spectra/MatOp/DenseCholesky.h>
 #include <Spectra/MatOp/DenseGenComplexShiftSolve.h>
 #include <Spectra/MatOp/DenseGenMatProd.h>
@@ -692,14 +691,6 @@ int main()
         const auto ev = eigs.eigenvalues();
         REQUIRE(ev.size() == 3);
         REQUIRE(std::fabs(ev[0] - 10.0) < 1e-10 && std::fabs(ev[1] - 9.0) < 1e-10 && std::fabs(ev[2] - 8.0) < 1e-10);
-        {
-            // HermEigsSolver with a real operator is the same solver (the complex Hermitian case is not built)
-            HermEigsSolver<MyDiagonalTen> heigs(op, 3, 6);
-            heigs.init();
-            heigs.compute(SortRule::LargestAlge);
-            const auto hv = heigs.eigenvalues();
-            REQUIRE(heigs.info() == CompInfo::Successful && hv.size() == 3 && std::fabs(hv[0] - ev[0]) == 0.0);
-        }
         std::printf("diag(1..10): %.12f %.12f %.12f\n", ev[0], ev[1], ev[2]);
 
         run_test_sets(gen_sparse_data(10, 0.5), 3, 6);      // test/SymEigs.cpp:133-143
