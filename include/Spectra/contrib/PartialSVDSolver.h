@@ -66,6 +66,65 @@ SparseView<double, int> svd_view(const Eigen::SparseMatrix<double, Flags, int>& 
 }
 #endif
 
+// A dense matrix (the reference's PartialSVDSolver<Eigen::MatrixXd>, test/SVD.cpp:72-103): the device operators are sparse
+// ones, so every entry is stored — a compressed column-major image built here and uploaded like any other sparse matrix.
+struct DenseAsCsc
+{
+    std::vector<int> outer, inner;
+    std::vector<double> values;
+    Index rows = 0, cols = 0;
+    DenseAsCsc(const DenseView<double>& m) : rows(m.rows), cols(m.cols)
+    {
+        outer.resize(static_cast<std::size_t>(cols) + 1);
+        inner.reserve(static_cast<std::size_t>(rows * cols));
+        values.reserve(static_cast<std::size_t>(rows * cols));
+        for (Index j = 0; j < cols; j++)
+        {
+            outer[static_cast<std::size_t>(j)] = static_cast<int>(values.size());
+            for (Index i = 0; i < rows; i++)
+            {
+                inner.push_back(static_cast<int>(i));
+                values.push_back(m.row_major ? m.data[i * m.ld + j] : m.data[j * m.ld + i]);
+            }
+        }
+        outer[static_cast<std::size_t>(cols)] = static_cast<int>(values.size());
+    }
+    SparseView<double, int> view() const
+    {
+        SparseView<double, int> v;
+        v.rows = rows;
+        v.cols = cols;
+        v.outer = outer.data();
+        v.inner = inner.data();
+        v.values = values.data();
+        v.row_major = false;
+        return v;
+    }
+};
+
+// host matrix of any supported kind -> the device pair
+template <typename MatrixType>
+std::shared_ptr<DeviceCsrPair> make_device_pair(const MatrixType& mat, CtxPtr ctx)
+{
+    return std::make_shared<DeviceCsrPair>(svd_view(mat), ctx);
+}
+inline std::shared_ptr<DeviceCsrPair> make_device_pair(const DenseView<double>& mat, CtxPtr ctx)
+{
+    const DenseAsCsc image(mat);
+    return std::make_shared<DeviceCsrPair>(image.view(), ctx);
+}
+inline std::shared_ptr<DeviceCsrPair> make_device_pair(const PlainMatrix<double>& mat, CtxPtr ctx)
+{
+    return make_device_pair(DenseView<double>(mat), ctx);
+}
+#ifdef MISPEC_HAVE_EIGEN
+template <int Options>
+std::shared_ptr<DeviceCsrPair> make_device_pair(const Eigen::Matrix<double, Eigen::Dynamic, Eigen::Dynamic, Options>& mat, CtxPtr ctx)
+{
+    return make_device_pair(DenseView<double>(mat), ctx);
+}
+#endif
+
 }  // namespace internal
 
 // Common interface of the two operators (reference: contrib/PartialSVDSolver.h:16-34) plus the hooks through which the
@@ -99,7 +158,7 @@ class SVDTallMatOp : public SVDMatOp<Scalar>
 
 public:
     SVDTallMatOp(const MatrixType& mat, internal::CtxPtr ctx = internal::CtxPtr()) :
-        SVDTallMatOp(std::make_shared<internal::DeviceCsrPair>(internal::svd_view(mat), ctx))
+        SVDTallMatOp(internal::make_device_pair(mat, ctx))
     {}
     explicit SVDTallMatOp(std::shared_ptr<internal::DeviceCsrPair> dev) :
         m_dev(dev),
@@ -133,7 +192,7 @@ class SVDWideMatOp : public SVDMatOp<Scalar>
 
 public:
     SVDWideMatOp(const MatrixType& mat, internal::CtxPtr ctx = internal::CtxPtr()) :
-        SVDWideMatOp(std::make_shared<internal::DeviceCsrPair>(internal::svd_view(mat), ctx))
+        SVDWideMatOp(internal::make_device_pair(mat, ctx))
     {}
     explicit SVDWideMatOp(std::shared_ptr<internal::DeviceCsrPair> dev) :
         m_dev(dev),
@@ -195,7 +254,7 @@ private:
 public:
     // Constructor
     PartialSVDSolver(const MatrixType& mat, Index ncomp, Index ncv, internal::CtxPtr ctx = internal::CtxPtr()) :
-        m_dev(std::make_shared<internal::DeviceCsrPair>(internal::svd_view(mat), ctx)),
+        m_dev(internal::make_device_pair(mat, ctx)),
         m_m(static_cast<Index>(mispec_csr_rows(m_dev->mat.get()))),
         m_n(static_cast<Index>(mispec_csr_cols(m_dev->mat.get())))
     {

@@ -1,5 +1,5 @@
 // Compile-and-link check of the Eigen-facing constructors of include/Spectra (the MISPEC_HAVE_EIGEN blocks), built against
-// tests/cpp/eigen_stub — a stand-in for Eigen's API, NOT Eigen (this image has no Eigen).  The program
+// tests/cpp/eigen_lite — a stand-in for Eigen's API, NOT Eigen (this image has no Eigen).  The program
 // is never run by the CPU tests: constructing the operators needs a GPU.  It is the source a Spectra user would write.
 #include <Eigen/Core>
 #include <Eigen/SparseCore>

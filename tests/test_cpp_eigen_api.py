@@ -1,5 +1,5 @@
 """The Eigen-facing constructors and result types of include/Spectra (the MISPEC_HAVE_EIGEN blocks) compile and link against
-tests/cpp/eigen_stub, a minimal stand-in for Eigen's API (Eigen is not in this image — SURVEY.md 8f row 2).  The host-only
+tests/cpp/eigen_lite, a small stand-in for Eigen's API (Eigen is not in this image — SURVEY.md 8f row 2).  The host-only
 LinAlg program is also RUN with the Eigen-like container types; the programs that need a GPU are run by the GPU tests."""
 import os
 import subprocess

@@ -22,7 +22,7 @@ def test_cpp_dropin_program():
 
 
 def test_cpp_dropin_program_with_eigen_like_result_types():
-    # the same program compiled with tests/cpp/eigen_stub on the include path: DenseMatrix / DenseVector are then the
+    # the same program compiled with tests/cpp/eigen_lite on the include path: DenseMatrix / DenseVector are then the
     # Eigen-named types and the operators are constructed through the Eigen-facing code paths where the program uses them
     exe = os.path.join(ROOT, "tests", "cpp", "dropin_symeigs_eigenapi.bin")
     if not os.path.exists(exe):
