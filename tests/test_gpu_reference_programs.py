@@ -35,7 +35,11 @@ def test_reference_test_program(name):
         # the second copies are found (the reference's run; ours with the sparse operator: tests/test_gpu_solver.py
         # test_example1_cycle_laplacian); below it the basis is complete after one restart with the distinct values only.  The
         # dense device GEMV's summation order lands below.  Accept exactly that outcome, nothing else.
+        import re
+
         failed = out.count("FAILED:")
-        assert failed == 0 or (failed == 1 and "(n, k, m) = (20, 5, 12)" in out and "test cases: 3 | 2 passed | 1 failed" in out), out[-3000:]
+        only_the_degenerate_case = (failed == 1 and "(n, k, m) = (20, 5, 12)" in out and
+                                    re.search(r"test cases:\s+3\s+\|\s+2 passed\s+\|\s+1 failed", out) is not None)
+        assert failed == 0 or only_the_degenerate_case, out[-3000:]
         return
     assert r.returncode == 0 and "All tests passed" in out, out[-3000:]
