@@ -29,12 +29,16 @@ def test_reference_test_program(name):
     r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     out = r.stdout
     if name == "Example1":
-        # test/Example1.cpp, case (n, k, m) = (20, 5, 12): the cycle Laplacian has DOUBLE eigenvalues and the basis (12) is
-        # longer than the number of distinct ones (11), so the 12th Lanczos residual is pure rounding noise of size ~1e-15 —
-        # right at the reference's clamp (Lanczos.h:163-168, beta < eps*sqrt(n) => f = 0).  Above it the noise is normalised and
-        # the second copies are found (the reference's run; ours with the sparse operator: tests/test_gpu_solver.py
-        # test_example1_cycle_laplacian); below it the basis is complete after one restart with the distinct values only.  The
-        # dense device GEMV's summation order lands below.  Accept exactly that outcome, nothing else.
+        # test/Example1.cpp, case (n, k, m) = (20, 5, 12): the cycle Laplacian has DOUBLE eigenvalues, the start vector A v0 has
+        # no component along the constant vector, so the Krylov space is exhausted after 10 steps and the residual there is pure
+        # rounding noise of size ~1e-15 — right at the reference's clamp (Lanczos.h:163-168, beta < eps * sqrt(n) => f = 0).
+        # Which side it falls on depends on the summation order of A x: the CPU oracle (the reference's algorithm restated)
+        # measures 9.887e-16 with row sums in storage order (no clamp, done after 9 restarts) and exactly 0 after the clamp with
+        # numpy's or a 64-lane tree order (new random direction, 239 restarts) — three runs, two paths, all of which happen to
+        # reach the second copies; the device's dense GEMV takes a third path (noise survives one more step, the clamp comes at
+        # the last step, every Ritz estimate is then exactly 0) and returns the five largest DISTINCT eigenvalues after one
+        # restart, with residual 1.7e-15.  With the sparse device operator the same case passes
+        # (tests/test_gpu_solver.py::test_example1_cycle_laplacian).  Accept exactly that outcome, nothing else.
         import re
 
         failed = out.count("FAILED:")
