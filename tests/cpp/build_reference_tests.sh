@@ -17,7 +17,8 @@ mkdir -p "$OUT"
 CXX="${CXX:-g++}"
 FLAGS="-std=c++11 -O1 -w -I$ROOT/tests/cpp/eigen_lite -I$ROOT/include -I$REF/test"
 LINK="-L$ROOT/spectra_amd -lmispec -Wl,-rpath,\$ORIGIN/../../../spectra_amd"
-LIST="${*:-SymEigs SymEigsShift GenEigs GenEigsRealShift GenEigsComplexShift SymGEigsCholesky SymGEigsRegInv SVD DavidsonSymEigs Example1 Example2 Example3 Example4}"
+# the last two test host-side classes only and run without a GPU
+LIST="${*:-SymEigs SymEigsShift GenEigs GenEigsRealShift GenEigsComplexShift SymGEigsCholesky SymGEigsRegInv SVD DavidsonSymEigs Example1 Example2 Example3 Example4 Schur Orthogonalization}"
 # Catch2's main(): compiled once
 if [ ! -f "$OUT/tests-main.o" ] || [ "$REF/test/tests-main.cpp" -nt "$OUT/tests-main.o" ]; then
     $CXX $FLAGS -c "$REF/test/tests-main.cpp" -o "$OUT/tests-main.o" || exit 1
