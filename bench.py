@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+ORTH_DEFAULT = "reference"
 
 
 def parse():
@@ -51,6 +52,9 @@ def parse():
                     help="HIP-event instrumentation of the timed solves: 2 = operator applications only (default), 1 = every kernel family")
     p.add_argument("--cpu-steps", type=int, default=20, help="Lanczos steps of the CPU sample (about 10 s of one host core at n = 1e7)")
     p.add_argument("--spmv-reps", type=int, default=50, help="stand-alone SpMV launches timed after the solves")
+    p.add_argument("--orth", default=ORTH_DEFAULT, choices=["reference", "onesweep"],
+                   help="orthogonalisation of the Lanczos steps in the timed region (include/mispec.h mispec_fac_set_orth_mode); the other "
+                        "mode is timed as well, outside the timed region, and reported as `other_orth_mode`")
     return p.parse_args()
 
 
@@ -187,14 +191,24 @@ def secondary_configs(args, ctx, op, sa):
             if op.spmv_format() != fmt:
                 continue
             e = sa.SymEigsSolver(op, args.nev, args.ncv)
+            e.set_orth_mode(args.orth)
             e.profile(2)
-            e.init()
-            nconv = e.compute(rule, 1000, args.tol)
-            e.eigenvectors(to_host=False)
-            p = e.get_profile()
-            blk = spmv_block(op, p["ms_spmv"] / max(p["n_spmv"], 1), p["n_spmv"], True)
+            secs = None
+            for rep in range(2):  # the second solve is the timed one (buffers allocated, code paths warm)
+                p0 = e.get_profile()
+                ctx.sync()
+                t0 = time.perf_counter()
+                e.init()
+                nconv = e.compute(rule, 1000, args.tol)
+                e.eigenvectors(to_host=False)
+                ctx.sync()
+                secs = time.perf_counter() - t0
+            p1 = e.get_profile()
+            n_spmv = p1["n_spmv"] - p0["n_spmv"]
+            blk = spmv_block(op, (p1["ms_spmv"] - p0["ms_spmv"]) / max(n_spmv, 1), n_spmv, True)
             blk["traffic"], blk["traffic_source"] = pmc_traffic(args.n, fmt)
-            blk.update({"nconv": int(nconv), "num_operations": int(e.num_operations())})
+            blk.update({"nconv": int(nconv), "num_operations": int(e.num_operations()), "seconds": secs,
+                        "eigenpairs_per_s": nconv / secs, "orth": args.orth})
             csr[name] = blk
             del e
     finally:
@@ -327,50 +341,55 @@ def main():
     nnz_local = op.nnz()
     rule = sa.SortRule[args.selection]
 
-    def solve(profile):
+    def new_solver(profile, orth=None):
+        """One solver object = one set of device buffers (V 3.2 GB, X 1.6 GB at n = 1e7): created OUTSIDE the timed region and
+        re-used by every step, as a caller of the reference would re-use its SymEigsSolver (init() starts a new solve)."""
         eigs = sa.SymEigsSolver(op, args.nev, args.ncv)
+        eigs.set_orth_mode(orth or args.orth)
         if profile:
             eigs.profile(profile)
+        return eigs
+
+    def solve(eigs):
         eigs.init()
         nconv = eigs.compute(rule, 1000, args.tol)
         ncols = eigs.eigenvectors(to_host=False)  # V * Y formed in HBM (1.6 GB at n = 1e7; not pulled over PCIe)
-        return eigs, nconv, ncols
+        return nconv, ncols
 
-    def timed_steps(steps):
-        """`steps` solves between barriers; returns (max-over-ranks seconds, pairs, last solver, accumulated profile)."""
+    def timed_steps(eigs, steps):
+        """`steps` solves between barriers; returns (max-over-ranks seconds, pairs, profile of exactly these steps)."""
+        before = eigs.get_profile()
         barrier()
         t0 = time.perf_counter()
-        pairs, acc, eigs = 0, None, None
+        pairs = 0
         for _ in range(steps):
-            # level 2: HIP events bracket only the operator applications (the roofline figure is measured live in the
-            # timed region); the other families would cost ~10 more event records per Lanczos step
-            eigs, nconv, _ = solve(0 if args.no_profile else args.profile_level)
+            nconv, _ = solve(eigs)
             pairs += nconv
-            p = eigs.get_profile()
-            if acc is None:
-                acc = dict(p)
-            else:
-                for k, v in p.items():
-                    acc[k] = acc[k] + v if k != "spmv_bytes" else v
         barrier()
-        return sdist.max_over_ranks(time.perf_counter() - t0), pairs, eigs, acc
+        dt = sdist.max_over_ranks(time.perf_counter() - t0)
+        after = eigs.get_profile()
+        return dt, pairs, {k: (after[k] - before[k] if k != "spmv_bytes" else after[k]) for k in after}
 
     exchange_note = None
+    # level 2: HIP events bracket only the operator applications (the roofline figure is measured live in the timed region); the
+    # other families would cost ~10 more event records per Lanczos step
+    eigs = new_solver(0 if args.no_profile else args.profile_level)
     if world > 1:
         # Self-check of the point-to-point neighbour exchange (outside the timed region): if the solve it drives
         # does not reach the residual bar on every rank, every rank falls back to the plain all-gather.
-        chk, nconv_chk, _ = solve(False)
-        r = chk.residuals()
+        nconv_chk, _ = solve(eigs)
+        r = eigs.residuals()
         bad = int(nconv_chk < args.nev or not np.all(np.isfinite(r)) or float(r.max()) > 1e-8)
         flag = torch.tensor([bad], dtype=torch.int32, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if int(flag.item()) and chk.exchange_info()[0]:
+        if int(flag.item()) and eigs.exchange_info()[0]:
             os.environ["MISPEC_EXCHANGE"] = "allgather"
             exchange_note = "neighbour exchange failed its residual self-check; all-gather used"
-        del chk
+            del eigs
+            eigs = new_solver(0 if args.no_profile else args.profile_level)  # the exchange is planned at construction
     for _ in range(args.warmup):
-        solve(False)
-    elapsed, total_pairs, eigs, prof = timed_steps(args.steps)
+        solve(eigs)
+    elapsed, total_pairs, prof = timed_steps(eigs, args.steps)
 
     # ---- everything below is outside the timed region -------------------------------------------------
     halo, recv_doubles = eigs.exchange_info()
@@ -380,20 +399,48 @@ def main():
     if world > 1 and halo:
         prev = os.environ.get("MISPEC_EXCHANGE")
         os.environ["MISPEC_EXCHANGE"] = "allgather"
-        solve(False)
-        ag_elapsed, ag_pairs, ag_eigs, ag_prof = timed_steps(args.steps)
+        ag = new_solver(2)
+        solve(ag)
+        ag_elapsed, ag_pairs, ag_prof = timed_steps(ag, args.steps)
         allgather_run = {"value": ag_pairs / ag_elapsed, "ms_per_step": 1e3 * ag_elapsed / args.steps,
                          "spmv_ms_per_launch_incl_exchange_wait": ag_prof["ms_spmv"] / max(ag_prof["n_spmv"], 1),
                          "moved_mb_per_product_per_rank": (world - 1) * int(sa.lib().mispec_shard_block(args.n, world)) * 8 / 1e6}
-        del ag_eigs
+        del ag
         if prev is None:
             del os.environ["MISPEC_EXCHANGE"]
         else:
             os.environ["MISPEC_EXCHANGE"] = prev
+    # the other orthogonalisation mode on the same matrix, same number of steps (not part of `value`)
+    other_mode = None
+    if not args.no_profile:
+        other = "reference" if args.orth == "onesweep" else "onesweep"
+        oe = new_solver(0, other)
+        solve(oe)
+        o_elapsed, o_pairs, _ = timed_steps(oe, args.steps)
+        o_res = oe.residuals()
+        other_mode = {"orth": other, "value": o_pairs / o_elapsed, "ms_per_step": 1e3 * o_elapsed / args.steps,
+                      "num_operations": int(oe.num_operations()), "num_iterations": int(oe.num_iterations()),
+                      "max_residual": float(o_res.max()) if len(o_res) else None, "orth_info": oe.orth_info()}
+        del oe
+    # the reference's eigenvectors() hands back a HOST matrix: the same steps with that copy inside the timed loop
+    with_host = None
+    if world == 1 and not args.no_profile:
+        barrier()
+        t0 = time.perf_counter()
+        hp = 0
+        for _ in range(args.steps):
+            eigs.init()
+            hp += eigs.compute(rule, 1000, args.tol)
+            Xh = eigs.eigenvectors()
+        barrier()
+        with_host = {"value": hp / (time.perf_counter() - t0), "note": f"eigenvectors() returned as a {Xh.shape[0]} x {Xh.shape[1]} host matrix "
+                     "(pageable numpy array, D2H inside the timed loop) as the reference's API does"}
+        del Xh
     # per-family kernel split: one more solve with every family instrumented, not part of `value`
     split = None
     if not args.no_profile:
-        full, _, _ = solve(1)
+        full = new_solver(1)
+        solve(full)
         split = full.get_profile()
         del full
     resid = eigs.residuals()
@@ -434,6 +481,13 @@ def main():
                 "n": args.n, "nnz_per_gpu": nnz_local, "nev": args.nev, "ncv": args.ncv, "selection": args.selection,
                 "tol": args.tol, "start_vector": "SimpleRandom(0) (reference default)",
                 "parallelism": f"row-shard x{world}" + exchange_desc,
+                "orthogonalisation": ({"reference": "reference control flow (Lanczos.h:145-181): V'f, then f -= Vc with |f| and the V'f check — "
+                                                    "two passes over V per step",
+                                       "onesweep": "opt-in one-sweep variant (mispec_fac_set_orth_mode, DESIGN.md 3.2.1): the correction of a step "
+                                                   "rides on the next step's pass over V; same decisions and fixed points, parity-gated by "
+                                                   "tests/test_gpu_onesweep.py and the full-size golden; the reference-flow figure of the same "
+                                                   "run is `other_orth_mode`"}[args.orth]),
+                "solver_object": "one SymEigsSolver (V, X, work vectors) allocated before the timed region and re-used by every step",
                 "eigenvectors": ("X = V*Y is formed in HBM and left there (the reference's eigenvectors() returns a host matrix: "
                                  f"the D2H copy of {8e-9 * args.n * args.nev:.1f} GB would add ~{8e-9 * args.n * args.nev / 55 * 1e3:.0f} ms per solve "
                                  "at ~55 GB/s PCIe and is not part of `value`)"),
@@ -470,7 +524,10 @@ def main():
                 "num_iterations": int(eigs.num_iterations()), "max_residual": float(resid.max()) if len(resid) else None,
                 "lambda_max": float(evals.max()) if len(evals) else None, "lambda_min": float(evals.min()) if len(evals) else None,
                 "host_syncs_per_solve": prof["n_host_sync"] / args.steps,
+                "orth_info": eigs.orth_info(),
             },
+            "other_orth_mode": other_mode,
+            "value_with_host_eigenvectors": with_host,
             "kernels_ms_per_solve": ({k[3:]: split[k] for k in split if k.startswith("ms_")} if split else None),
             "kernels_ms_note": "from one additional solve with every kernel family bracketed by HIP events, outside the timed region",
             "kernels_launches_per_solve": {k[2:]: prof[k] / args.steps for k in prof if k.startswith("n_")},

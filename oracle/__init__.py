@@ -26,7 +26,7 @@ def build(force=False):
     """Compile oracle/liboracle.so with the committed Makefile (g++ -O2)."""
     if force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-        for f in ("oracle_capi.cpp", "spectra_oracle.hpp", "spectra_oracle_gen.hpp", "synth_matrix.h")
+        for f in ("oracle_capi.cpp", "spectra_oracle.hpp", "spectra_oracle_gen.hpp", "synth_matrix.h", "onesweep_variant.hpp")
     ):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _LIB_PATH
@@ -86,6 +86,8 @@ def lib():
             "oracle_symeigs_create": (vp, [vp, C.c_long, C.c_long]),
             "oracle_symeigs_free": (None, [vp]),
             "oracle_symeigs_set_shift_invert": (None, [vp, C.c_double]),
+            "oracle_symeigs_set_onesweep": (None, [vp, C.c_int]),
+            "oracle_symeigs_onesweep_stats": (None, [vp, dp]),
             "oracle_geneigs_set_shift_invert": (None, [vp, C.c_double]),
             "oracle_geneigs_set_complex_shift": (None, [vp, C.c_double, C.c_double, vp]),
             "oracle_complex_shift_probe": (C.c_double, [C.c_double]),
@@ -399,6 +401,17 @@ class SymEigsSolver:
             raise ValueError(lib().oracle_last_error().decode())
         if sigma is not None:  # SymEigsShiftSolver.h:190-195 (the op must already be shift-inverted)
             lib().oracle_symeigs_set_shift_invert(self.h, sigma)
+
+    def set_onesweep(self, on=True):
+        """NOT the reference: switch the factorisation to the CPU restatement of this repository's opt-in one-sweep
+        variant (oracle/onesweep_variant.hpp), for variant-vs-reference comparisons under the same driver."""
+        lib().oracle_symeigs_set_onesweep(self.h, int(bool(on)))
+
+    def onesweep_stats(self):
+        out = np.zeros(7)
+        lib().oracle_symeigs_onesweep_stats(self.h, _dp(out))
+        keys = ("lagged_steps", "faithful_steps", "fallbacks_check", "fallbacks_state", "final_passes", "max_rel_c", "max_chk")
+        return dict(zip(keys, out.tolist()))
 
     def init(self, v0=None):
         v0 = None if v0 is None else _f64(v0)

@@ -1,0 +1,275 @@
+// =============================================================================
+//  TEST INFRASTRUCTURE — NOT the reference's algorithm.
+//
+//  CPU restatement of THIS REPOSITORY's opt-in "one sweep of V per step" Lanczos
+//  factorisation (spectra_amd/csrc/fac.hip lanczos_step_lagged, MISPEC_ORTH=onesweep),
+//  written against the oracle's Factorization so that the variant can be compared
+//  with the reference-faithful restatement (spectra_oracle.hpp, Lanczos.h:62-187) on
+//  the CPU: same solver driver, same restart code, only the factorisation differs.
+//
+//  What the variant changes.  The reference makes, per step i,
+//      w = A v_i - beta v_{i-1};  alpha = <v_i, w>;  f = w - alpha v_i;
+//      c = V' f            (one sweep over V)
+//      f -= V c ; |f| ; V' f   (a second sweep; the loop practically always runs once)
+//  The variant applies the operator to the NOT YET corrected vector and folds the correction into the
+//  next step's sweep ("delayed re-orthogonalisation", cf. Swirydowicz et al. 2020, Bielich et al. 2022):
+//      col_i <- f~ / beta           with  beta = sqrt(|f~|^2 - |c|^2)  (the norm the corrected vector will have)
+//      w = A col_i - beta v_{i-1};  alpha~ = <col_i, w>
+//      ONE sweep:  v_i = (f~ - V c)/beta -> col_i ;  chk = V' v_i ;  f~' = w - alpha~ v_i ;  c' = [V, v_i]' f~' ; |f~'|^2
+//  Everything the operator was applied to "too early" lies in span(V, v_i) and is removed by the measured c' of the
+//  same sweep (A V c = V H c + beta v_i c_last), so v_{i+1} is the reference's vector up to rounding, and
+//      H(i,i)   = alpha~ - c[i-1] + c'[i]
+//      H(i,i-1) = beta + c'[i-1] - (H(i-1,i-2) c[i-2] + H(i-1,i-1) c[i-1]) / beta
+//  are exact consequences of the Lanczos relation of the previous step (derivation: DESIGN.md 3.2.1).
+//  The reference's decisions are kept: no correction when max|c| <= eps |f~| ; the breakdown clamp, a second
+//  correction (chk fails), tiny or small beta and large |c| all leave the lagged path and continue with the
+//  reference's own loop from the same state.
+// =============================================================================
+#pragma once
+#include "spectra_oracle.hpp"
+
+namespace oracle {
+
+struct OneSweepStats
+{
+    long lagged_steps = 0, faithful_steps = 0, fallbacks_check = 0, fallbacks_state = 0, final_passes = 0;
+    double max_rel_c = 0.0;  // max |c| / |f~| over the accepted lagged corrections
+    double max_chk = 0.0;    // max |V' v_i| after a lagged correction
+};
+
+namespace onesweep_detail {
+
+// Dot products of the lagged sweep the way the device forms them: short sequential runs, then a pairwise tree — the
+// rounding error stays near eps instead of growing with n as the oracle's sequential sum does (which makes the reference
+// restatement itself take a second correction in most steps at n >= 1e5: a property of that sum, not of the algorithm).
+inline double dot_tree(const double* x, const double* y, Index n)
+{
+    constexpr Index kRun = 64;
+    std::vector<double> part((n + kRun - 1) / kRun + 1, 0.0);
+    Index np = 0;
+    for (Index b = 0; b < n; b += kRun)
+    {
+        const Index e = std::min(n, b + kRun);
+        double s = 0.0;
+        for (Index i = b; i < e; i++)
+            s += x[i] * y[i];
+        part[np++] = s;
+    }
+    while (np > 1)
+    {
+        const Index half = (np + 1) / 2;
+        for (Index i = 0; i + half < np; i++)
+            part[i] += part[i + half];
+        np = half;
+    }
+    return np ? part[0] : 0.0;
+}
+inline void adjoint_tree(const Mat& V, Index n, Index ncol, const double* y, double* res)
+{
+    for (Index j = 0; j < ncol; j++)
+        res[j] = dot_tree(V.col(j), y, n);
+}
+
+// the while loop of Lanczos.h:156-182 for step i, entered with `count` corrections applied, F.f / F.beta current and
+// Vf = V[:, :i+1]' f
+inline void corrections(Factorization& F, Index i, int count, std::vector<double>& Vf)
+{
+    const double beta_thresh = kEps * std::sqrt(double(F.n));
+    const Index i1 = i + 1;
+    double ortho_err = max_abs(Vf.data(), i1);
+    while (count < 5 && ortho_err > kEps * F.beta)
+    {
+        if (F.beta < beta_thresh)
+        {
+            std::fill(F.f.begin(), F.f.end(), 0.0);
+            F.beta = 0.0;
+            break;
+        }
+        F.axpy_V(i1, Vf.data());
+        F.H(i - 1, i) += Vf[i - 1];
+        F.H(i, i - 1) = F.H(i - 1, i);
+        F.H(i, i) += Vf[i];
+        F.beta = F.nrm(F.f.data());
+        F.adj(i1, F.f.data(), Vf.data());
+        ortho_err = max_abs(Vf.data(), i1);
+        count++;
+    }
+}
+
+// one step of Lanczos.h:88-183, literally
+inline void faithful_step(Factorization& F, Index i, Index& op_counter, std::vector<double>& w, std::vector<double>& Vf)
+{
+    const Index n = F.n;
+    const double eps_sqrt = std::sqrt(kEps);
+    bool restart = (F.beta < kNear0);
+    double* v = F.V.col(i);
+    if (!restart)
+    {
+        for (Index r = 0; r < n; r++)
+            v[r] = F.f[r] / F.beta;
+        if (F.beta < eps_sqrt)
+        {
+            const double Viv = F.ip(F.V.col(i - 1), v);
+            restart = (std::fabs(Viv) > eps_sqrt);
+        }
+    }
+    if (restart)
+    {
+        F.expand_basis(i, 2 * i, F.f, F.beta, op_counter);
+        for (Index r = 0; r < n; r++)
+            v[r] = F.f[r] / F.beta;
+    }
+    F.H(i, i - 1) = restart ? 0.0 : F.beta;
+    F.H(i - 1, i) = F.H(i, i - 1);
+    F.op.perform_op(v, w.data());
+    op_counter++;
+    if (!restart)
+    {
+        const double h = F.H(i, i - 1);
+        const double* vp = F.V.col(i - 1);
+        for (Index r = 0; r < n; r++)
+            w[r] -= h * vp[r];
+    }
+    F.H(i, i) = F.ip(v, w.data());
+    const double hii = F.H(i, i);
+    for (Index r = 0; r < n; r++)
+        F.f[r] = w[r] - hii * v[r];
+    F.beta = F.nrm(F.f.data());
+    F.adj(i + 1, F.f.data(), Vf.data());
+    corrections(F, i, 0, Vf);
+}
+
+}  // namespace onesweep_detail
+
+// Drop-in for Factorization::factorize_from_lanczos (standard problems only: plain inner products).
+inline void factorize_from_lanczos_onesweep(Factorization& F, Index from_k, Index to_m, Index& op_counter, OneSweepStats* stats)
+{
+    using namespace onesweep_detail;
+    if (to_m <= from_k)
+        return;
+    if (from_k > F.k)
+        throw std::invalid_argument("Lanczos: from_k (= " + std::to_string(from_k) +
+                                    ") is larger than the current subspace dimension (= " + std::to_string(F.k) + ")");
+    if (F.bop)
+        throw std::invalid_argument("one-sweep variant: standard problems only");
+    const Index n = F.n;
+    const double beta_thresh = kEps * std::sqrt(double(n));
+    const double eps_sqrt = std::sqrt(kEps);
+    OneSweepStats local;
+    OneSweepStats& S = stats ? *stats : local;
+    std::vector<double> Vf(to_m + 1), c(to_m + 1, 0.0), chk(to_m + 1), w(n), vi(n);
+    F.zero_outside_leading(from_k);
+
+    // pending == true: F.f is the UNCORRECTED residual f~ of step i-1, c = V[:, :i]' f~ (accepted), F.beta the norm the
+    // corrected residual will have; pending == false: F.f / F.beta are final (the reference's state between steps)
+    bool pending = false;
+    Index i = from_k;
+    while (i <= to_m - 1)
+    {
+        if (F.beta < eps_sqrt)  // covers beta < near_0: the restart heuristics of Lanczos.h:99-119 need a finished f
+        {
+            if (pending)
+                throw std::logic_error("one-sweep variant: a pending correction with beta < sqrt(eps)");  // excluded below
+            faithful_step(F, i, op_counter, w, Vf);
+            S.faithful_steps++;
+            // the reference's step leaves a finished f: pending stays false
+            i++;
+            continue;
+        }
+        // ---- lagged step i ---------------------------------------------------------------------------------------
+        const double beta = F.beta;
+        double* v = F.V.col(i);
+        for (Index r = 0; r < n; r++)
+            v[r] = F.f[r] / beta;  // what the operator is applied to
+        F.op.perform_op(v, w.data());
+        {
+            const double* vp = F.V.col(i - 1);
+            for (Index r = 0; r < n; r++)
+                w[r] -= beta * vp[r];
+        }
+        const double alpha_t = dot_tree(v, w.data(), n);
+        // the sweep: finish column i, check it, form the next uncorrected residual and measure it
+        if (pending)
+        {
+            for (Index r = 0; r < n; r++)
+                vi[r] = F.f[r];
+            for (Index j = 0; j < i; j++)
+            {
+                const double cj = c[j];
+                const double* vj = F.V.col(j);
+                for (Index r = 0; r < n; r++)
+                    vi[r] -= vj[r] * cj;
+            }
+            for (Index r = 0; r < n; r++)
+                v[r] = vi[r] / beta;
+            adjoint_tree(F.V, n, i, v, chk.data());
+            const double cerr = max_abs(chk.data(), i);
+            S.max_chk = std::max(S.max_chk, cerr);
+            if (cerr > kEps)  // Lanczos.h:156 after the first correction, in units of beta: a second one is needed
+            {
+                // leave the lagged path: f = once-corrected residual of step i-1, count = 1, then the reference's loop
+                S.fallbacks_check++;
+                for (Index r = 0; r < n; r++)
+                    F.f[r] = vi[r];
+                for (Index j = 0; j < i; j++)
+                    Vf[j] = chk[j] * beta;
+                corrections(F, i - 1, 1, Vf);
+                pending = false;
+                continue;  // step i again from the finished state (the speculative product is not counted)
+            }
+        }
+        op_counter++;
+        S.lagged_steps++;
+        for (Index r = 0; r < n; r++)
+            F.f[r] = w[r] - alpha_t * v[r];
+        const Index i1 = i + 1;
+        adjoint_tree(F.V, n, i1, F.f.data(), Vf.data());
+        const double gamma2 = dot_tree(F.f.data(), F.f.data(), n);
+        const double gamma = std::sqrt(gamma2);
+        // H of this step before its own correction
+        F.H(i, i) = alpha_t - (pending ? c[i - 1] : 0.0);
+        {
+            double sub = beta;
+            if (pending)
+                sub -= ((i >= 2 ? F.H(i - 1, i - 2) * c[i - 2] : 0.0) + F.H(i - 1, i - 1) * c[i - 1]) / beta;
+            F.H(i, i - 1) = sub;
+            F.H(i - 1, i) = sub;
+        }
+        const double err = max_abs(Vf.data(), i1);
+        F.beta = gamma;
+        pending = false;
+        if (err > kEps * gamma)  // Lanczos.h:156: a correction is needed
+        {
+            double c2 = 0.0;
+            for (Index j = 0; j < i1; j++)
+                c2 += Vf[j] * Vf[j];
+            const double b2 = gamma2 - c2;
+            const bool can_lag = (gamma >= beta_thresh) && (c2 <= 1e-6 * gamma2) && (b2 > 0.0) && (std::sqrt(b2) >= eps_sqrt) &&
+                                 (i < to_m - 1);
+            if (can_lag)
+            {
+                F.H(i - 1, i) += Vf[i - 1];  // Lanczos.h:173-175
+                F.H(i, i - 1) = F.H(i - 1, i);
+                F.H(i, i) += Vf[i];
+                for (Index j = 0; j < i1; j++)
+                    c[j] = Vf[j];
+                F.beta = std::sqrt(b2);
+                pending = true;
+                S.max_rel_c = std::max(S.max_rel_c, std::sqrt(c2) / gamma);
+            }
+            else
+            {
+                // the reference's loop from here (the last step of a sweep always ends this way: f must be finished)
+                if (i == to_m - 1)
+                    S.final_passes++;
+                else
+                    S.fallbacks_state++;
+                corrections(F, i, 0, Vf);
+            }
+        }
+        i++;
+    }
+    F.k = to_m;
+}
+
+}  // namespace oracle

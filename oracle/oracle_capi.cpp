@@ -6,6 +6,7 @@
 #include "spectra_oracle.hpp"
 #include "spectra_oracle_gen.hpp"
 #include "synth_matrix.h"
+#include "onesweep_variant.hpp"
 
 #include <chrono>
 #include <cstring>
@@ -393,6 +394,39 @@ long oracle_geigs_cg_solve(void* h, const double* rhs, double* x)
     return ok ? long(H->binv.last_iterations) : -1;
 }
 void oracle_geigs_bprod(void* h, const double* x, double* y) { static_cast<GEigsHolder*>(h)->B.perform_op(x, y); }
+// NON-reference variant (oracle/onesweep_variant.hpp): the repository's opt-in one-sweep Lanczos factorisation under the
+// reference's driver.  on == 0 restores the reference's algorithm.
+void oracle_symeigs_set_onesweep(void* s, int on)
+{
+    auto* S = static_cast<SymEigs*>(s);
+    if (!on)
+    {
+        S->fac.lanczos_variant = nullptr;
+        S->fac.variant_user.reset();
+        return;
+    }
+    S->fac.variant_user = std::make_shared<OneSweepStats>();
+    S->fac.lanczos_variant = [](Factorization& F, Index from_k, Index to_m, Index& ops, void* user) {
+        factorize_from_lanczos_onesweep(F, from_k, to_m, ops, static_cast<OneSweepStats*>(user));
+    };
+}
+// out[0..7): lagged steps, faithful steps, check fallbacks, state fallbacks, final passes, max |c|/|f~|, max |V'v| after a lagged correction
+void oracle_symeigs_onesweep_stats(void* s, double* out)
+{
+    auto* S = static_cast<SymEigs*>(s);
+    const auto* st = static_cast<const OneSweepStats*>(S->fac.variant_user.get());
+    for (int i = 0; i < 7; i++)
+        out[i] = 0.0;
+    if (!st)
+        return;
+    out[0] = double(st->lagged_steps);
+    out[1] = double(st->faithful_steps);
+    out[2] = double(st->fallbacks_check);
+    out[3] = double(st->fallbacks_state);
+    out[4] = double(st->final_passes);
+    out[5] = st->max_rel_c;
+    out[6] = st->max_chk;
+}
 void oracle_symeigs_set_shift_invert(void* s, double sigma)
 {
     static_cast<SymEigs*>(s)->shift_invert = true;

@@ -32,6 +32,7 @@
 #include <stdexcept>
 #include <string>
 #include <limits>
+#include <memory>
 #include <vector>
 
 namespace oracle {
@@ -857,6 +858,12 @@ public:
     const Op* bop = nullptr;
     mutable std::vector<double> bcache;
 
+    // Test hook, unset by default: a NON-reference factorisation variant that replaces factorize_from_lanczos
+    // (oracle/onesweep_variant.hpp restates this repository's opt-in one-sweep variant so that it can be compared with the
+    // reference-faithful code below under the same driver).  nullptr = the reference's algorithm.
+    void (*lanczos_variant)(Factorization&, Index, Index, Index&, void*) = nullptr;
+    std::shared_ptr<void> variant_user;
+
     Factorization(const Op& op_, Index m_, const Op* bop_ = nullptr) : op(op_), n(op_.rows()), m(m_), bop(bop_) {}
 
     double ip(const double* x, const double* y) const  // ArnoldiOp::inner_product
@@ -985,6 +992,11 @@ public:
     // Lanczos.h:62-187
     void factorize_from_lanczos(Index from_k, Index to_m, Index& op_counter)
     {
+        if (lanczos_variant)  // test hook (see the member): not the reference's algorithm
+        {
+            lanczos_variant(*this, from_k, to_m, op_counter, variant_user.get());
+            return;
+        }
         if (to_m <= from_k)
             return;
         if (from_k > k)

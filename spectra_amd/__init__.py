@@ -848,6 +848,19 @@ class SymEigsSolver:
         check(lib().mispec_symeigs_get_profile(self.h, C.byref(p)))
         return p.as_dict()
 
+    def set_orth_mode(self, mode):
+        """'reference' (default: Lanczos.h:145-181, two passes over V per step) or 'onesweep' (opt-in: the correction of a
+        step rides on the next step's pass, include/mispec.h mispec_fac_set_orth_mode).  Call before init()."""
+        modes = {"reference": 0, "onesweep": 1, 0: 0, 1: 1}
+        check(lib().mispec_symeigs_set_orth_mode(self.h, modes[mode]))
+
+    def orth_info(self):
+        mode, a, b, c = C.c_int(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        r, k = C.c_double(0.0), C.c_double(0.0)
+        check(lib().mispec_symeigs_orth_info(self.h, C.byref(mode), C.byref(a), C.byref(b), C.byref(c), C.byref(r), C.byref(k)))
+        return {"mode": "onesweep" if mode.value else "reference", "lagged_steps": a.value, "check_stops": b.value,
+                "state_stops": c.value, "max_rel_c": r.value, "max_chk": k.value}
+
     def overlap_info(self):
         """(first interior 256-row block, interior blocks, all blocks): what is multiplied while the exchange is in flight."""
         a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)

@@ -194,6 +194,10 @@ SIGNATURES = {
     "mispec_symeigs_overlap_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mispec_fac_overlap_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mispec_symeigs_profile": (C.c_int, [_vp, C.c_int]),
+    "mispec_symeigs_set_orth_mode": (C.c_int, [_vp, C.c_int]),
+    "mispec_symeigs_orth_info": (C.c_int, [_vp, C.POINTER(C.c_int), _lp, _lp, _lp, _dp, _dp]),
+    "mispec_fac_set_orth_mode": (C.c_int, [_vp, C.c_int]),
+    "mispec_fac_orth_info": (C.c_int, [_vp, C.POINTER(C.c_int), _lp, _lp, _lp, _dp, _dp]),
     "mispec_geneigs_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vpp]),
     "mispec_geneigs_create_op": (C.c_int, [_vp, op_fn, _vp, C.c_int64, C.c_int64, C.c_int64, _vpp]),
     "mispec_geneigs_create_shift": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_double, _vpp]),

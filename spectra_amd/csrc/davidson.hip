@@ -163,7 +163,7 @@ struct mispec_davidson
         if (A)
             launch_spmv(*A, x, y, nullptr);
         else if (D)
-            launch_row_gemv(*ctx, D->a.p, D->ld, D->rows, D->cols, x, y);
+            launch_row_gemv(*ctx, D->a.p, D->ld, D->rows, D->cols, x, y, true);
         else if (dop(dop_user, x, y, static_cast<void*>(stream())) != 0)
             throw Error(MISPEC_ERUNTIME, "user device operator callback reported failure");
         nops++;
@@ -319,6 +319,16 @@ extern "C" int mispec_davidson_create(mispec_ctx* ctx, const mispec_csr* A, int6
         hipLaunchKernelGGL(k_csr_diag, blocks_for(S->n), dim3(kThreads), 0, ctx->stream, A->rowptr.p, A->colind.p, A->val.p, A->row_begin,
                            S->n, S->diag.p);
         MISPEC_HIP(hipGetLastError());
+        if (A->reordered())
+        {
+            // the stored matrix is P A P' (reorder.hip): its i-th diagonal entry is A(perm[i], perm[i]), while the operator of this
+            // solver (launch_spmv) keeps the caller's order — the preconditioner and the unit start vectors must use that order too
+            DevBuf<double> tmp;
+            tmp.alloc(size_t(S->n) + 2);
+            launch_from_stored_order(*A, S->diag.p, tmp.p);
+            MISPEC_HIP(hipMemcpyAsync(S->diag.p, tmp.p, size_t(S->n) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+            MISPEC_HIP(hipStreamSynchronize(ctx->stream));
+        }
         fetch_diag(*S);
         *out = S.release();
     });

@@ -16,5 +16,8 @@ struct mispec_dense
 namespace mispec {
 // y[rows] = M x, M row-major with row stride ld (device pointers, enqueued on the context's stream).  One wavefront per
 // row, fixed summation order: deterministic, independent of the launch geometry.
-void launch_row_gemv(const mispec_ctx& ctx, const double* M, int64_t ld, int64_t rows, int64_t cols, const double* x, double* y);
+// storage_order_if_small: matrices of at most 128 x 128 entries are multiplied with one lane per row, each row summed in storage
+// order like a CPU row-dot and the sparse kernels (the dense product operators ask for it; see k_row_gemv_serial)
+void launch_row_gemv(const mispec_ctx& ctx, const double* M, int64_t ld, int64_t rows, int64_t cols, const double* x, double* y,
+                     bool storage_order_if_small = false);
 }  // namespace mispec

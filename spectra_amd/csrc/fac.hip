@@ -91,6 +91,12 @@ struct mispec_fac
     PinnedBuf<StepState> h_state;  // its pinned host mirror
     PinnedBuf<double> h_red, h_small, h_x, h_y;
     bool device_steps = true;      // MISPEC_HOST_STEPS=1 forces the host-synchronous path
+    // Opt-in one-sweep variant of the Lanczos steps (mispec_fac_set_orth_mode / MISPEC_ORTH=onesweep): the
+    // correction of a step rides on the next step's pass over V.  Default off = the reference's control flow.
+    bool onesweep = false;
+    double lag_limit = 1e-6;
+    int64_t lag_steps = 0, lag_check_stops = 0, lag_state_stops = 0;
+    double lag_rel_c_max = 0.0, lag_chk_max = 0.0;
     int64_t pstride = 0;  // stride between slots of the partial records
     // Neighbour exchange plan (sharded device matrices): per peer, which part of my slice it reads and which
     // part of its slice I read.  halo == false: the full all-gather is used.
@@ -124,6 +130,9 @@ struct mispec_fac
     double& Hat(int i, int j) { return H[size_t(j) * m + i]; }
     double* col(int j) { return V.p + int64_t(j) * ldv; }
     double* red_buf(int which) { return red.p + which * kPartialLd; }
+    // <v, w> of the fused SpMV epilogue: a device scalar of its own behind the two record halves (a reduction rewrites every
+    // slot of the half it targets, and the one-sweep steps let records land in either half while alpha is still needed)
+    double* alpha_slot() { return red.p + 2 * kPartialLd; }
     hipStream_t stream() const { return ctx->stream; }
     // a communicator is attached (world may be 1: the collectives are then still issued, which is how the
     // RCCL / torch transports are smoke-tested on a single GPU)
@@ -409,12 +418,12 @@ void overlapped_spmv(mispec_fac& F, const mispec_csr& M, const double* x, double
 }
 
 // y = Op(x).  x_loc / y_loc: this shard's rows (device).  With `lanczos_epi`, additionally
-// y -= h_prev * v_prev (when v_prev != nullptr) and alpha = <x, y> is left in red_buf(0)[kSlotAlpha]
+// y -= h_prev * v_prev (when v_prev != nullptr) and alpha = <x, y> is left in F.alpha_slot()
 // (device) — Lanczos.h:131-142.
 void apply_op(mispec_fac& F, const double* x_loc, double* y_loc, bool lanczos_epi, const double* v_prev, double h_prev,
               const double* h_prev_dev = nullptr, const int* status = nullptr)
 {
-    double* alpha_dev = F.red_buf(0) + kSlotAlpha;
+    double* alpha_dev = F.alpha_slot();
     if (F.A)
     {
         const double* x = x_loc;
@@ -553,7 +562,7 @@ void apply_op(mispec_fac& F, const double* x_loc, double* y_loc, bool lanczos_ep
     else if (F.D)
     {
         Timed t(F, FAM_SPMV);
-        launch_row_gemv(*F.ctx, F.D->a.p, F.D->ld, F.D->rows, F.D->cols, x_loc, y_loc);
+        launch_row_gemv(*F.ctx, F.D->a.p, F.D->ld, F.D->rows, F.D->cols, x_loc, y_loc, true);
         if (lanczos_epi)
             launch_lanczos_epilogue(*F.ctx, y_loc, x_loc, v_prev, h_prev, F.nloc, F.alpha_partials.p);
     }
@@ -774,8 +783,8 @@ void init_from_tmp(mispec_fac& F, int64_t* nmatop)
     (*nmatop)++;
 
     // f = w - v H(0,0)  (:177) ; the V'f by-product is not used here
-    const int nrec = resid_vtf(F, F.w.p, v, F.red_buf(0) + kSlotAlpha, F.f.p, 1);
-    MISPEC_HIP(hipMemcpyAsync(F.h_red.p + kPartialLd, F.red_buf(0) + kSlotAlpha, sizeof(double), hipMemcpyDeviceToHost,
+    const int nrec = resid_vtf(F, F.w.p, v, F.alpha_slot(), F.f.p, 1);
+    MISPEC_HIP(hipMemcpyAsync(F.h_red.p + kPartialLd, F.alpha_slot(), sizeof(double), hipMemcpyDeviceToHost,
                               F.stream()));
     reduce_to_host(F, nrec, 1, 1);
     const double alpha = F.h_red.p[kPartialLd];
@@ -881,8 +890,8 @@ void lanczos_step_host(mispec_fac& F, int i, int64_t* nmatop)
 
     // f = w - alpha v ; beta = |f| ; Vf = V[:, :i+1]' f   (:145-153) — one pass over V
     const int i1 = i + 1;
-    const int nrec = resid_vtf(F, F.w.p, v, F.red_buf(0) + kSlotAlpha, F.f.p, i1);
-    MISPEC_HIP(hipMemcpyAsync(F.h_red.p + kPartialLd, F.red_buf(0) + kSlotAlpha, sizeof(double), hipMemcpyDeviceToHost,
+    const int nrec = resid_vtf(F, F.w.p, v, F.alpha_slot(), F.f.p, i1);
+    MISPEC_HIP(hipMemcpyAsync(F.h_red.p + kPartialLd, F.alpha_slot(), sizeof(double), hipMemcpyDeviceToHost,
                               F.stream()));
     reduce_to_host(F, nrec, i1, 1);
     F.Hat(i, i) = F.h_red.p[kPartialLd];
@@ -932,15 +941,77 @@ void lanczos_step_device(mispec_fac& F, int i)
         a.src = F.w.p;
         a.dst = F.f.p;
         a.vi = v;
-        a.alpha_dev = F.red_buf(0) + kSlotAlpha;
+        a.alpha_dev = F.alpha_slot();
         a.status = &st->status;
         Timed t(F, FAM_VTF);
         const int nrec = launch_orth(*F.ctx, ORTH_RESID_VTF, a);
         fin.mode = kFinishStepFirst;
-        fin.alpha_src = F.red_buf(0) + kSlotAlpha;
+        fin.alpha_src = F.alpha_slot();
         reduce_record(F, nrec, i1, 1, fin);
     }
     for (int c = 0; c < kSpeculativeCorrections; c++)
+    {
+        OrthArgs a = orth_args(F, i1);
+        a.src = F.f.p;
+        a.dst = F.f.p;
+        a.c_in = F.red_buf(F.red_cur);
+        a.status = &st->status;
+        a.need_corr = &st->need_corr;
+        Timed t(F, FAM_GEMV);
+        const int nrec = launch_orth(*F.ctx, ORTH_CORRECT_VTF, a);
+        fin.mode = kFinishStepCorr;
+        fin.prev_red = F.red_buf(F.red_cur);
+        reduce_record(F, nrec, i1, F.red_cur ^ 1, fin);
+    }
+}
+
+// One step of the opt-in one-sweep variant (CPU restatement: oracle/onesweep_variant.hpp).  The operator is
+// applied to the not yet corrected column i; the pass that follows finishes column i with the correction measured in the
+// previous step, forms the next residual and measures its V'f — one sweep over V per step instead of two.  Records
+// alternate between the two halves of `red`: step i writes half (i & 1) and takes its coefficients from the other one.
+// `last`: the sweep ends here, so the residual is finished the reference's way by the CORRECT_VTF launches that follow.
+void lanczos_step_lagged(mispec_fac& F, int i, bool last)
+{
+    StepState* st = F.d_state.p;
+    double* v = F.col(i);
+    {
+        Timed t(F, FAM_SCALE);
+        launch_scale_step(*F.ctx, F.f.p, v, F.ldv, st, i, std::sqrt(kEps));
+    }
+    apply_op(F, v, F.w.p, true, F.col(i - 1), 0.0, &st->subd[i - 1], &st->status);
+
+    const int cur = i & 1;
+    FinishArgs fin;
+    fin.st = st;
+    fin.step = i;
+    fin.eps = kEps;
+    fin.beta_thresh = kEps * std::sqrt(double(F.n));
+    fin.eps_sqrt = std::sqrt(kEps);
+    fin.lag_limit = F.lag_limit;
+    fin.lag_last = last ? 1 : 0;
+    fin.max_spec = speculative_corrections(F);
+    {
+        OrthArgs a = orth_args(F, i);
+        a.src = F.w.p;
+        a.vi = F.f.p;
+        a.dst = F.f.p;
+        a.vout = v;
+        a.c_in = F.red_buf(cur ^ 1);
+        a.alpha_dev = F.alpha_slot();
+        a.beta_dev = &st->beta;
+        a.pending = &st->lag_pending;
+        a.status = &st->status;
+        Timed t(F, FAM_VTF);
+        const int nrec = launch_orth(*F.ctx, ORTH_LAGGED, a);
+        fin.mode = kFinishLagged;
+        fin.alpha_src = F.alpha_slot();
+        fin.prev_red = F.red_buf(cur ^ 1);
+        reduce_record(F, nrec, 2 * i + 1, cur, fin);
+    }
+    if (!last)
+        return;
+    const int i1 = i + 1;
+    for (int c = 0; c < fin.max_spec; c++)
     {
         OrthArgs a = orth_args(F, i1);
         a.src = F.f.p;
@@ -961,6 +1032,7 @@ void factorize_lanczos(mispec_fac& F, int from_k, int to_m, int64_t* nmatop)
 {
     zero_H_outside(F, from_k);
     const bool fast = F.device_steps && F.A != nullptr && !F.bmode() && F.Chol == nullptr;
+    const bool lagged = fast && F.onesweep && F.m <= kPanelCols;
     int i = from_k;
     while (i <= to_m - 1)
     {
@@ -982,13 +1054,24 @@ void factorize_lanczos(mispec_fac& F, int from_k, int to_m, int64_t* nmatop)
         }
         MISPEC_HIP(hipMemcpyAsync(F.d_state.p, &hs, sizeof(StepState), hipMemcpyHostToDevice, F.stream()));
         for (int s = i; s <= to_m - 1; s++)
-            lanczos_step_device(F, s);
+        {
+            if (lagged)
+                lanczos_step_lagged(F, s, s == to_m - 1);
+            else
+                lanczos_step_device(F, s);
+        }
         MISPEC_HIP(hipMemcpyAsync(&hs, F.d_state.p, sizeof(StepState), hipMemcpyDeviceToHost, F.stream()));
         sync_stream(F);
 
         const int status = hs.status;
         const int stop = (status == kStepOk) ? to_m : hs.stop_step;
-        const int last_done = (status == kStepOk) ? to_m - 1 : (status == kStepSmallBeta ? stop - 1 : stop);
+        const int last_done = (status == kStepOk) ? to_m - 1 : ((status == kStepSmallBeta || status == kStepLagCheck) ? stop - 1 : stop);
+        if (lagged)
+        {
+            F.lag_steps += hs.lag_steps;
+            F.lag_rel_c_max = std::max(F.lag_rel_c_max, hs.lag_rel_c_max);
+            F.lag_chk_max = std::max(F.lag_chk_max, hs.lag_chk_max);
+        }
         for (int j = i; j <= last_done; j++)  // bring H of the executed steps home
         {
             F.Hat(j, j) = hs.diag[j];
@@ -999,11 +1082,42 @@ void factorize_lanczos(mispec_fac& F, int from_k, int to_m, int64_t* nmatop)
         if (status == kStepOk)
             break;
         // ---- the rare branches continue on the host path, then the device path resumes ---------------
+        if (status == kStepLagCheck)
+        {
+            // one-sweep variant: column `stop` (once corrected) fails the reference's test for a second correction.  Back to
+            // the state of the reference's loop for step stop-1 after its first correction: f = beta * column, V'f = beta *
+            // the measured V'v, count = 1; the step `stop` itself is then repeated (its speculative product is not counted)
+            F.lag_check_stops++;
+            const int rec = stop & 1;
+            MISPEC_HIP(hipMemcpyAsync(F.h_red.p, F.red_buf(rec), kPartialLd * sizeof(double), hipMemcpyDeviceToHost, F.stream()));
+            sync_stream(F);
+            double err = 0.0;
+            for (int j = 0; j < stop; j++)
+            {
+                F.h_red.p[j] = F.h_red.p[stop + 1 + j] * F.beta;
+                err = std::max(err, std::fabs(F.h_red.p[j]));
+            }
+            F.h_red.p[kSlotErr] = err;
+            F.h_red.p[kSlotBeta] = F.beta;
+            MISPEC_HIP(hipMemcpyAsync(F.red_buf(rec), F.h_red.p, size_t(stop) * sizeof(double), hipMemcpyHostToDevice, F.stream()));
+            {
+                Timed t(F, FAM_SCALE);
+                launch_scale(*F.ctx, F.col(stop), F.f.p, F.ldv, 1.0 / F.beta);
+            }
+            F.red_cur = rec;
+            lanczos_corrections_host(F, stop - 1, 1);
+            i = stop;
+            continue;
+        }
         if (status == kStepSmallBeta)
             lanczos_step_host(F, stop, nmatop);
         else
         {
+            if (lagged)
+                F.lag_state_stops++;
             F.red_cur = (hs.stop_count % 2 == 0) ? 1 : 0;  // RESID -> red[1], then the corrections alternate
+            if (lagged)  // the lagged record of step `stop` sits in half (stop & 1), corrections alternate from there
+                F.red_cur = (stop & 1) ^ (hs.stop_count & 1);
             MISPEC_HIP(hipMemcpyAsync(F.h_red.p, F.red_buf(F.red_cur), kPartialLd * sizeof(double), hipMemcpyDeviceToHost,
                                       F.stream()));
             sync_stream(F);
@@ -1344,7 +1458,7 @@ int fac_create_impl(mispec_ctx* ctx, const mispec_csr* A, const mispec_symshift*
             F->partials.alloc(size_t(max_rec) * kPartialLd);
             const int64_t nparts = std::max<int64_t>(A ? spmv_num_blocks(F->nloc) : 0, lanczos_epilogue_records(*ctx, F->nloc));
             F->alpha_partials.alloc(size_t(std::max<int64_t>(nparts, 1)));
-            F->red.alloc(2 * kPartialLd);
+            F->red.alloc(2 * kPartialLd + 8);
             MISPEC_HIP(hipMemsetAsync(F->red.p, 0, F->red.n * sizeof(double), ctx->stream));
             F->Qdev.alloc(size_t(ncv) * ncv);
             F->d_diag.alloc(size_t(ncv));
@@ -1361,6 +1475,7 @@ int fac_create_impl(mispec_ctx* ctx, const mispec_csr* A, const mispec_symshift*
             }
             F->h_state.alloc(1);
             F->device_steps = !(getenv("MISPEC_HOST_STEPS") && atoi(getenv("MISPEC_HOST_STEPS")) != 0);
+            F->onesweep = getenv("MISPEC_ORTH") && std::string(getenv("MISPEC_ORTH")) == "onesweep";
             F->h_red.alloc(kPartialLd + 8);
             F->h_small.alloc(size_t(ncv) * ncv + 4 * size_t(ncv) + 8);
             if (op)
@@ -1539,6 +1654,37 @@ extern "C" int mispec_fac_overlap_info(const mispec_fac* fac, int* first_block, 
             *block_count = fac->interior_count;
         if (total_blocks)
             *total_blocks = fac->A ? spmv_num_blocks(fac->nloc) : 0;
+    });
+}
+
+extern "C" int mispec_fac_set_orth_mode(mispec_fac* fac, int mode)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(fac, "mispec_fac_set_orth_mode: NULL argument");
+        MISPEC_REQUIRE(mode == MISPEC_ORTH_REFERENCE || mode == MISPEC_ORTH_ONESWEEP, "mispec_fac_set_orth_mode: unknown mode");
+        fac->onesweep = (mode == MISPEC_ORTH_ONESWEEP);
+    });
+}
+
+extern "C" int mispec_fac_orth_info(const mispec_fac* fac, int* mode, int64_t* lagged_steps, int64_t* check_stops,
+                                    int64_t* state_stops, double* max_rel_c, double* max_chk)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(fac, "mispec_fac_orth_info: NULL argument");
+        const bool active = fac->onesweep && fac->device_steps && fac->symmetric && fac->A && !fac->bmode() && !fac->Chol &&
+                            fac->m <= kPanelCols;
+        if (mode)
+            *mode = active ? MISPEC_ORTH_ONESWEEP : MISPEC_ORTH_REFERENCE;
+        if (lagged_steps)
+            *lagged_steps = fac->lag_steps;
+        if (check_stops)
+            *check_stops = fac->lag_check_stops;
+        if (state_stops)
+            *state_stops = fac->lag_state_stops;
+        if (max_rel_c)
+            *max_rel_c = fac->lag_rel_c_max;
+        if (max_chk)
+            *max_chk = fac->lag_chk_max;
     });
 }
 

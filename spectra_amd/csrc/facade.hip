@@ -426,6 +426,15 @@ extern "C" int mispec_symeigs_overlap_info(const mispec_symeigs* s, int* first_b
 {
     return s ? mispec_fac_overlap_info(s->fac(), first_block, block_count, total_blocks) : MISPEC_EINVAL;
 }
+extern "C" int mispec_symeigs_set_orth_mode(mispec_symeigs* s, int mode)
+{
+    return s ? mispec_fac_set_orth_mode(s->fac(), mode) : MISPEC_EINVAL;
+}
+extern "C" int mispec_symeigs_orth_info(const mispec_symeigs* s, int* mode, int64_t* lagged_steps, int64_t* check_stops,
+                                        int64_t* state_stops, double* max_rel_c, double* max_chk)
+{
+    return s ? mispec_fac_orth_info(s->fac(), mode, lagged_steps, check_stops, state_stops, max_rel_c, max_chk) : MISPEC_EINVAL;
+}
 extern "C" int mispec_symeigs_exchange_info(const mispec_symeigs* s, int* halo, int64_t* recv_doubles)
 {
     return s ? mispec_fac_exchange_info(s->fac(), halo, recv_doubles) : MISPEC_EINVAL;

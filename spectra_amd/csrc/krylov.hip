@@ -215,11 +215,257 @@ __global__ __launch_bounds__(kThreads) void k_orth(OrthArgs a)
     }
 }
 
+// ---- one-sweep variant (ORTH_LAGGED; opt-in, see krylov.hpp and DESIGN.md 3.2.1) -------------------------------------
+// The correction of step i-1 and the projection of step i share one pass over V[:, :i]:
+//   p = V c_in (cross-wave row sums through LDS, as in CORRECT) ;  v_i = (f - p) / beta -> column i
+//   chk_j = <V_j, v_i> ;  dst = w - alpha v_i -> f ;  c_j = <V_j, dst>, c_i = <v_i, dst>, |dst|^2
+// Same tiling, load pattern and record layout as k_orth; with c_in = 0 (no pending correction) column i is rewritten
+// with the bits k_scale_step gave it.
+template <int MAXS, int R>
+__global__ __launch_bounds__(kThreads) void k_orth_lagged(OrthArgs a)
+{
+    constexpr int kRows = kTileRows * R;
+    __shared__ double cs[kPanelCols];
+    __shared__ __attribute__((aligned(16))) double psum[2][4][kRows];
+
+    if (a.status && *a.status != kStepOk)
+        return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool pending = *a.pending != 0;
+    if (tid < kPanelCols)
+        cs[tid] = (pending && tid < a.ncol) ? a.c_in[tid] : 0.0;
+    __syncthreads();
+    const double alpha = *a.alpha_dev;
+    const double beta = *a.beta_dev;
+
+    const double* colp[MAXS];
+    double cw[MAXS], acc[MAXS], chk[MAXS];
+#pragma unroll
+    for (int jj = 0; jj < MAXS; jj++)
+    {
+        const int j = w + 4 * jj;
+        colp[jj] = a.V + int64_t(j < a.ncol ? j : 0) * a.ldv;
+        cw[jj] = (j < kPanelCols) ? cs[j] : 0.0;
+        acc[jj] = 0.0;
+        chk[jj] = 0.0;
+    }
+    double b2 = 0.0, mx = 0.0, dvi = 0.0;
+
+    const int64_t ntiles = (a.n + kRows - 1) / kRows;
+    int buf = 0;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x)
+    {
+        int64_t r[R], rc[R];
+        bool valid[R];
+#pragma unroll
+        for (int q = 0; q < R; q++)
+        {
+            r[q] = t * kRows + q * kTileRows + 2 * lane;
+            valid[q] = r[q] < a.n;
+            rc[q] = valid[q] ? r[q] : 0;
+        }
+        double2 vv[MAXS][R];
+#pragma unroll
+        for (int jj = 0; jj < MAXS; jj++)
+#pragma unroll
+            for (int q = 0; q < R; q++)
+                vv[jj][q] = *reinterpret_cast<const double2*>(colp[jj] + rc[q]);
+        double2 fv[R], wv[R];
+#pragma unroll
+        for (int q = 0; q < R; q++)
+        {
+            fv[q] = *reinterpret_cast<const double2*>(a.vi + rc[q]);
+            wv[q] = *reinterpret_cast<const double2*>(a.src + rc[q]);
+            if (!valid[q])
+            {
+                fv[q].x = fv[q].y = 0.0;
+                wv[q].x = wv[q].y = 0.0;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R; q++)
+        {
+            double2 p;
+            p.x = 0.0;
+            p.y = 0.0;
+#pragma unroll
+            for (int jj = 0; jj < MAXS; jj++)
+            {
+                p.x += vv[jj][q].x * cw[jj];
+                p.y += vv[jj][q].y * cw[jj];
+            }
+            *reinterpret_cast<double2*>(&psum[buf][w][q * kTileRows + 2 * lane]) = p;
+        }
+        __syncthreads();
+        double2 vi[R], fn[R];
+#pragma unroll
+        for (int q = 0; q < R; q++)
+        {
+            const int o = q * kTileRows + 2 * lane;
+            const double2 p0 = *reinterpret_cast<const double2*>(&psum[buf][0][o]);
+            const double2 p1 = *reinterpret_cast<const double2*>(&psum[buf][1][o]);
+            const double2 p2 = *reinterpret_cast<const double2*>(&psum[buf][2][o]);
+            const double2 p3 = *reinterpret_cast<const double2*>(&psum[buf][3][o]);
+            vi[q].x = (fv[q].x - ((p0.x + p1.x) + (p2.x + p3.x))) / beta;  // Lanczos.h:171 then :106 (true division)
+            vi[q].y = (fv[q].y - ((p0.y + p1.y) + (p2.y + p3.y))) / beta;
+            if (!valid[q])  // rows past the end were loaded from row 0 (clamped address): they must not reach the sums
+            {
+                vi[q].x = 0.0;
+                vi[q].y = 0.0;
+            }
+            fn[q].x = wv[q].x - alpha * vi[q].x;  // Lanczos.h:145
+            fn[q].y = wv[q].y - alpha * vi[q].y;
+        }
+        buf ^= 1;
+        if (w == 0)
+        {
+#pragma unroll
+            for (int q = 0; q < R; q++)
+            {
+                if (valid[q])
+                {
+                    *reinterpret_cast<double2*>(a.vout + r[q]) = vi[q];
+                    *reinterpret_cast<double2*>(a.dst + r[q]) = fn[q];
+                }
+                b2 += fn[q].x * fn[q].x + fn[q].y * fn[q].y;
+                dvi += vi[q].x * fn[q].x + vi[q].y * fn[q].y;
+                mx = fmax(mx, fmax(fabs(fn[q].x), fabs(fn[q].y)));
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < MAXS; jj++)
+#pragma unroll
+            for (int q = 0; q < R; q++)
+            {
+                acc[jj] += vv[jj][q].x * fn[q].x + vv[jj][q].y * fn[q].y;
+                chk[jj] += vv[jj][q].x * vi[q].x + vv[jj][q].y * vi[q].y;
+            }
+    }
+
+    double* rec = a.partials + blockIdx.x;
+#pragma unroll
+    for (int jj = 0; jj < MAXS; jj++)
+    {
+        const double s = wave_reduce_sum(acc[jj]);
+        const double c = wave_reduce_sum(chk[jj]);
+        const int j = w + 4 * jj;
+        if (lane == 0 && j < a.ncol)
+        {
+            rec[int64_t(j) * a.pstride] = s;
+            rec[int64_t(a.ncol + 1 + j) * a.pstride] = c;
+        }
+    }
+    if (w == 0)
+    {
+        b2 = wave_reduce_sum(b2);
+        dvi = wave_reduce_sum(dvi);
+        mx = wave_reduce_max(mx);
+        if (lane == 0)
+        {
+            rec[int64_t(a.ncol) * a.pstride] = dvi;
+            rec[kSlotBeta2 * a.pstride] = b2;
+            rec[kSlotMaxAbs * a.pstride] = mx;
+        }
+    }
+}
+
+// Executed by ONE thread after the reduction of an ORTH_LAGGED record (layout above, i = fa.step columns were final).
+// H of step i follows from the Lanczos relation of step i-1; the decisions are the reference's
+// (Lanczos.h:156-168) with "apply the correction now" replaced by "carry it into the next sweep" whenever that is safe.
+__device__ void finish_lagged(double* red, const FinishArgs& fa)
+{
+    StepState* st = fa.st;
+    const int i = fa.step;
+    if (st->status != kStepOk)
+        return;
+    const bool pend = st->lag_pending != 0;
+    const double bprev = st->beta;  // the divisor column i was formed with
+    if (pend)
+    {
+        double cerr = 0.0;
+        for (int j = 0; j < i; j++)
+            cerr = fmax(cerr, fabs(red[i + 1 + j]));
+        st->lag_chk_max = fmax(st->lag_chk_max, cerr);
+        if (cerr > fa.eps)  // Lanczos.h:156 after the first correction, in units of beta
+        {
+            st->status = kStepLagCheck;
+            st->stop_step = i;
+            st->stop_count = 1;
+            return;
+        }
+    }
+    const double* cp = fa.prev_red;  // the accepted V'f of step i-1 (valid when pend)
+    const double alpha = *fa.alpha_src;
+    double d = alpha, sub = bprev;
+    if (pend)
+    {
+        d -= cp[i - 1];
+        sub -= ((i >= 2 ? st->subd[i - 2] * cp[i - 2] : 0.0) + st->diag[i - 1] * cp[i - 1]) / bprev;
+    }
+    const double gamma2 = red[kSlotBeta2];
+    const double gamma = sqrt(gamma2);
+    double err = 0.0, c2 = 0.0;
+    for (int j = 0; j <= i; j++)
+    {
+        err = fmax(err, fabs(red[j]));
+        c2 += red[j] * red[j];
+    }
+    red[kSlotBeta] = gamma;
+    red[kSlotErr] = err;
+    st->diag[i] = d;
+    st->subd[i - 1] = sub;
+    st->alpha = alpha;
+    st->beta = gamma;
+    st->err = err;
+    st->count = 0;
+    st->lag_pending = 0;
+    st->need_corr = 0;
+    st->lag_steps++;
+    const int need = err > fa.eps * gamma;  // Lanczos.h:156
+    if (need && gamma < fa.beta_thresh)     // Lanczos.h:163
+    {
+        st->status = kStepTinyF;
+        st->stop_step = i;
+        st->stop_count = 0;
+        return;
+    }
+    if (fa.lag_last)  // the CORRECT_VTF launches that follow finish f the reference's way
+    {
+        st->need_corr = need;
+        return;
+    }
+    if (!need)
+        return;
+    const double b2 = gamma2 - c2;
+    if (c2 <= fa.lag_limit * gamma2 && b2 > 0.0 && sqrt(b2) >= fa.eps_sqrt)
+    {
+        st->subd[i - 1] += red[i - 1];  // Lanczos.h:173-175
+        st->diag[i] += red[i];
+        st->beta = sqrt(b2);            // |f - V c| for V'V = I, f'V = c'
+        st->lag_pending = 1;
+        st->count = 1;
+        st->lag_rel_c_max = fmax(st->lag_rel_c_max, sqrt(c2) / gamma);
+    }
+    else  // the reference's loop on the host, from the uncorrected state
+    {
+        st->status = kStepMoreCorr;
+        st->stop_step = i;
+        st->stop_count = 0;
+    }
+}
+
 // Executed by ONE thread after a reduction: the scalar tail of a Lanczos step.
 __device__ void finish_record(double* red, int ncol, const FinishArgs& fa)
 {
     if (fa.mode == kFinishNone)
         return;
+    if (fa.mode == kFinishLagged)
+    {
+        finish_lagged(red, fa);
+        return;
+    }
     const double beta = sqrt(red[kSlotBeta2]);  // ArnoldiOp.h:152-155: plain sqrt(sum x^2)
     double err = 0.0;
     for (int j = 0; j < ncol; j++)
@@ -836,6 +1082,44 @@ void launch_orth_mode(const mispec_ctx& ctx, const OrthArgs& a, int grid)
     }
 }
 
+void launch_orth_lagged(const mispec_ctx& ctx, const OrthArgs& a, int grid)
+{
+    const int slots = (a.ncol + 3) / 4;
+    static const int rknob = env_int("MISPEC_ORTH_R");
+    const bool two = (rknob != 1) && slots <= 10;
+    const dim3 g(static_cast<unsigned>(grid)), b(kThreads);
+    switch (slots)
+    {
+#define MISPEC_LAG_CASE(S)                                                  \
+    case S:                                                                 \
+        if (two)                                                            \
+            hipLaunchKernelGGL((k_orth_lagged<S, 2>), g, b, 0, ctx.stream, a); \
+        else                                                                \
+            hipLaunchKernelGGL((k_orth_lagged<S, 1>), g, b, 0, ctx.stream, a); \
+        break;
+        case 0:
+            MISPEC_LAG_CASE(1)
+            MISPEC_LAG_CASE(2)
+            MISPEC_LAG_CASE(3)
+            MISPEC_LAG_CASE(4)
+            MISPEC_LAG_CASE(5)
+            MISPEC_LAG_CASE(6)
+            MISPEC_LAG_CASE(7)
+            MISPEC_LAG_CASE(8)
+            MISPEC_LAG_CASE(9)
+            MISPEC_LAG_CASE(10)
+            MISPEC_LAG_CASE(11)
+            MISPEC_LAG_CASE(12)
+            MISPEC_LAG_CASE(13)
+            MISPEC_LAG_CASE(14)
+            MISPEC_LAG_CASE(15)
+        default:
+            hipLaunchKernelGGL((k_orth_lagged<16, 1>), g, b, 0, ctx.stream, a);
+            break;
+#undef MISPEC_LAG_CASE
+    }
+}
+
 }  // namespace
 
 namespace mispec {
@@ -872,6 +1156,9 @@ int launch_orth_panel(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a, i
         case ORTH_CORRECT_ONLY:
             launch_orth_mode<ORTH_CORRECT_ONLY>(ctx, a, grid);
             break;
+        case ORTH_LAGGED:
+            launch_orth_lagged(ctx, a, grid);
+            break;
     }
     MISPEC_HIP(hipGetLastError());
     return grid;
@@ -888,6 +1175,7 @@ int launch_orth_panel(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a, i
 int launch_orth(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a)
 {
     MISPEC_REQUIRE(a.ncol >= 0 && a.ncol <= kMaxCols, "orth kernel: more than 256 basis columns");
+    MISPEC_REQUIRE(mode != ORTH_LAGGED || (a.ncol >= 1 && a.ncol < kPanelCols), "one-sweep orth kernel: needs 1 <= columns <= 63");
     if (a.ncol <= kPanelCols)
     {
         OrthArgs one = a;
@@ -946,6 +1234,8 @@ int launch_orth(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a)
                     b.src = a.dst;
                     launch_orth_panel(ctx, ORTH_VTF, b, grid);
                 }
+            break;
+        case ORTH_LAGGED:  // single panel only (checked above)
             break;
     }
     return grid;

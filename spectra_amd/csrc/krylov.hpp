@@ -13,14 +13,18 @@ constexpr int kSlotBeta2 = kMaxCols;       // sum f^2
 constexpr int kSlotMaxAbs = kMaxCols + 1;  // max |f|
 constexpr int kSlotBeta = kMaxCols + 2;    // sqrt(sum f^2)            (filled by the finish step)
 constexpr int kSlotErr = kMaxCols + 3;     // max_j |(V'f)_j|          (filled by the finish step)
-constexpr int kSlotAlpha = kMaxCols + 4;   // <v, w> of the SpMV epilogue
 
 enum OrthMode
 {
     ORTH_VTF = 0,          // c = V'f                                   (ArnoldiOp.h:145-148)
     ORTH_RESID_VTF = 1,    // f = w - alpha*v_i ; |f|^2 ; c = V'f       (Lanczos.h:145-152 fused)
     ORTH_CORRECT_VTF = 2,  // dst = src - V c_in ; |dst|^2 ; c = V'dst  (Lanczos.h:171-179 fused)
-    ORTH_CORRECT_ONLY = 3  // dst = src - V c_in ; |dst|^2              (Arnoldi.h:254-255)
+    ORTH_CORRECT_ONLY = 3, // dst = src - V c_in ; |dst|^2              (Arnoldi.h:254-255)
+    // One-sweep variant (opt-in, fac.hip lanczos_step_lagged; NOT the reference's control flow):
+    //   v_i = (f - V c_in)/beta -> vout ;  chk = V' v_i ;  dst = w - alpha v_i ;  c = [V, v_i]' dst ; |dst|^2
+    // i.e. the correction of step i-1 and the projection of step i in ONE pass over V[:, :ncol], ncol = i <= 63.
+    // Record slots: [0, i) c ; i <v_i, dst> ; [i+1, 2i+1) chk ; kSlotBeta2 / kSlotMaxAbs of dst.
+    ORTH_LAGGED = 4
 };
 
 // Device-resident bookkeeping of the Lanczos recurrence, so that a whole factorize_from(k, m) can be
@@ -36,16 +40,23 @@ struct StepState
     int status;    // kStepOk or the reason the device path stopped
     int stop_step; // step at which it stopped
     int stop_count;
-    int pad_;
+    int lag_pending;  // one-sweep variant: the residual in f is not yet corrected, its accepted V'f is the latest record
     double diag[kMaxCols];  // H(i,i)
     double subd[kMaxCols];  // H(i+1,i)
+    // one-sweep variant, diagnostics of a device run: largest accepted |c|/|f|, largest |V'v_i| after a lagged correction,
+    // lagged steps executed
+    double lag_rel_c_max;
+    double lag_chk_max;
+    int64_t lag_steps;
 };
 enum
 {
     kStepOk = 0,
     kStepSmallBeta = 1,  // beta < sqrt(eps) at the start of a step: the reference's restart heuristics run on the host path
     kStepMoreCorr = 2,   // a third correction is needed: continue the loop on the host path
-    kStepTinyF = 3       // beta < eps*sqrt(n) inside the loop (Lanczos.h:163-168): host zeroes f
+    kStepTinyF = 3,      // beta < eps*sqrt(n) inside the loop (Lanczos.h:163-168): host zeroes f
+    kStepLagCheck = 4    // one-sweep variant: column stop_step needs a second correction (Lanczos.h:156 after the first one);
+                         // the host finishes step stop_step-1 with the reference's loop and repeats step stop_step
 };
 enum
 {
@@ -54,7 +65,8 @@ enum
     kFinishStepFirst = 2,  // + bookkeeping after f = w - alpha v (Lanczos.h:142-153)
     kFinishStepCorr = 3,   // + bookkeeping after one correction (Lanczos.h:171-180)
     kFinishArnoldiH = 4,   // Arnoldi: red[0..ncol) is h = V'w -> H(:, step), |h| (Arnoldi.h:251)
-    kFinishArnoldiF = 5    // Arnoldi: after f = w - Vh: beta, the 0.717 test and the need for corrections (Arnoldi.h:255-266)
+    kFinishArnoldiF = 5,   // Arnoldi: after f = w - Vh: beta, the 0.717 test and the need for corrections (Arnoldi.h:255-266)
+    kFinishLagged = 6      // one-sweep variant: bookkeeping after an ORTH_LAGGED pass
 };
 struct FinishArgs
 {
@@ -67,6 +79,9 @@ struct FinishArgs
     double beta_thresh = 0.0;
     int max_spec = 2;  // corrections that are enqueued speculatively per step
     double* hcol = nullptr;  // Arnoldi: device column `step` of H
+    int lag_last = 0;        // kFinishLagged: last step of the sweep — the following CORRECT_VTF launches finish f the reference's way
+    double lag_limit = 1e-6; // kFinishLagged: a correction is lagged only while |c|^2 <= lag_limit |f|^2
+    double eps_sqrt = 0.0;   // kFinishLagged: ... and the corrected norm stays >= sqrt(eps) (Lanczos.h:107 needs a finished f)
 };
 
 struct OrthArgs
@@ -86,6 +101,11 @@ struct OrthArgs
     int64_t pstride = 0;                // >= number of workgroups of any launch
     const int* status = nullptr;        // optional predicate: run only while *status == kStepOk ...
     const int* need_corr = nullptr;     // ... and (if given) *need_corr != 0
+    // ORTH_LAGGED: src = w, vi = f (the uncorrected residual of the previous step), dst = f (next residual), vout = column i,
+    // alpha_dev = <col_i, w>, beta_dev = the divisor column i was formed with, pending = use c_in (else c_in is taken as 0)
+    double* vout = nullptr;
+    const double* beta_dev = nullptr;
+    const int* pending = nullptr;
 };
 
 // All launchers enqueue on ctx.stream and return immediately.

@@ -291,6 +291,13 @@ extern "C" int mispec_reginv_create(mispec_ctx* ctx, int64_t n, const int32_t* o
         hipLaunchKernelGGL(k_inv_diag, dim3(unsigned((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream, R->B->rowptr.p,
                            R->B->colind.p, R->B->val.p, n, R->invdiag.p);
         MISPEC_HIP(hipGetLastError());
+        if (R->B->reordered())
+        {
+            // stored matrix = P B P': entry i of what was just computed belongs to row perm[i]; the CG iteration works in the
+            // caller's order (launch_spmv), so the Jacobi preconditioner has to as well
+            launch_from_stored_order(*R->B, R->invdiag.p, R->z.p);
+            MISPEC_HIP(hipMemcpyAsync(R->invdiag.p, R->z.p, size_t(n) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        }
         MISPEC_HIP(hipStreamSynchronize(ctx->stream));
         *out = R.release();
     });

@@ -87,7 +87,7 @@ def test_full_size_spmv_bit_exact_in_every_format(ctx, name, symmetric, n):
     dev.set_spmv_format(-1)
 
 
-def check_c2_solve(ctx):  # run by tests/test_gpu_solver.py::test_full_size_c2_residuals
+def check_c2_solve(ctx, orth="reference"):  # run by tests/test_gpu_solver.py::test_full_size_c2_residuals
     # BASELINE.json configs[1]: 10M x 10M, ~15 nnz/row, k = 20, ncv = 40 on one MI355X (test/SymEigs.cpp:44-65's checks)
     g = golden("c2")
     n, nev, ncv = g["n"], g["nev"], g["ncv"]
@@ -95,9 +95,11 @@ def check_c2_solve(ctx):  # run by tests/test_gpu_solver.py::test_full_size_c2_r
     out = []
     for _ in range(2):
         eigs = sa.SymEigsSolver(op, nev, ncv)
+        eigs.set_orth_mode(orth)  # "onesweep": the opt-in variant must hold the same golden (tests/test_gpu_onesweep.py)
         eigs.init()
         nconv = eigs.compute(sa.SortRule.LargestMagn, 1000, g["tol"])
         assert nconv == g["nconv"] == nev and eigs.info() == sa.CompInfo.Successful and g["info"] == 0
+        assert eigs.orth_info()["mode"] == orth
         out.append((eigs.eigenvalues(), eigs.num_operations(), eigs.num_iterations()))
     assert np.array_equal(out[0][0], out[1][0]) and out[0][1:] == out[1][1:]  # deterministic reductions
     ev = out[0][0]
@@ -159,3 +161,93 @@ def check_c5_solve(ctx):  # run by tests/test_gpu_shift.py::test_config5_banded[
     assert abs(eigs.num_operations() - g["num_operations"]) <= (ncv - nev)
     res = np.linalg.norm(A @ X - X * ev, axis=0) / np.linalg.norm(X, axis=0)
     assert res.max() <= 1e-10, res
+
+
+_C2_MATRIX = {}
+
+
+def c2_matrix_on_host():
+    """BASELINE's 10M matrix as scipy CSR from the oracle's generator (built once per session: ~4 s, 1.9 GB)."""
+    if "A" not in _C2_MATRIX:
+        g = golden("c2")
+        rp, ci, v = O.synth_band_csr(g["n"])
+        _C2_MATRIX["A"] = sp.csr_matrix((v, ci, rp), shape=(g["n"], g["n"]))
+    return _C2_MATRIX["A"]
+
+
+def check_c3_run(res, world, g, expect_halo, expect_overlap):
+    nev, ncv, n = g["nev"], g["ncv"], g["n"]
+    ref = np.array(g["eigenvalues"])
+    block = sa.shard_block(n, world)
+    for rank, r in enumerate(res):
+        assert r["nconv"] == g["nconv"] == nev and r["info"] == sa.CompInfo.Successful
+        assert np.array_equal(r["evals"], res[0]["evals"])                   # every rank holds the same H
+        assert (r["nops"], r["niter"]) == (res[0]["nops"], res[0]["niter"])
+        assert r["rows"] == (rank * block, min(n, (rank + 1) * block)) and r["local"] == r["rows"][1] - r["rows"][0]
+        assert r["res"].max() <= 1e-10                                        # the library's own (all-reduced) residuals
+        neighbours = (rank > 0) + (rank < world - 1)
+        if expect_halo:                                                       # +-100001 rows across every shard boundary
+            assert r["exchange"] == (True, 100001 * neighbours)
+        else:
+            assert r["exchange"] == (False, block * (world - 1))
+        first, count, total = r["overlap"]
+        if expect_overlap:  # all 256-row blocks but those within 100001 rows of a neighbour's slice
+            assert total - count <= neighbours * (100001 // 256 + 2) and count < total
+        else:
+            assert count == 0
+    ev = res[0]["evals"]
+    assert np.all(np.abs(ev - ref) <= 1e-9 * np.maximum(1.0, np.abs(ref))), np.abs(ev - ref).max()
+    assert abs(res[0]["nops"] - g["num_operations"]) <= (ncv - nev)           # within one restart cycle of the oracle's solve
+    assert abs(res[0]["niter"] - g["num_iterations"]) <= 1
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_full_size_c3_sharded(world):
+    """BASELINE.json configs[2]: the SAME 10M x 10M matrix row-partitioned `world` ways, k = 20, ncv = 40 — run on one GPU
+    through the loopback transport (world host threads, one context / stream / row shard each; the SPMD code and every kernel
+    launch are those of a multi-GPU run, only the wire differs), pinned to the oracle's complete C2 solve exactly as
+    check_c2_solve pins the unsharded run.  Exercises what the small sharded tests cannot: shard offsets >= 1.25M rows, the
+    +-100001 halo across up to seven boundaries, interior-block overlap at 84-96 %, int32 / int64 index arithmetic at scale.
+    Matches /root/reference/include/Spectra/LinAlg/Lanczos.h:131-181 (one exchange + three reductions per step)."""
+    import os
+
+    from test_gpu_sharded import run_sharded
+
+    g = golden("c2")
+    n, nev, ncv = g["n"], g["nev"], g["ncv"]
+    res = run_sharded(world, n, None, nev, ncv, sa.SortRule.LargestMagn, g["tol"])
+    check_c3_run(res, world, g, expect_halo=True, expect_overlap=True)
+    # the assembled eigenvectors against an INDEPENDENT product: scipy's SpMV on the host with the oracle's matrix
+    X = np.vstack([r["X"] for r in res])
+    assert X.shape == (n, nev)
+    ev = res[0]["evals"]
+    A = c2_matrix_on_host()
+    resid = np.linalg.norm(A @ X - X * ev, axis=0) / np.linalg.norm(X, axis=0)
+    assert resid.max() <= 1e-10, resid
+    assert np.abs(X.T @ X - np.eye(nev)).max() <= 1e-10
+    del X
+    # north_star's wording — the all-gather of the whole Krylov vector — and the exchange without overlap must give the SAME
+    # BITS: the same x values reach the same kernels on the same row-blocks
+    variants = [("allgather", None)] if world != 8 else [("allgather", None), (None, "0"), ("allgather", "0")]
+    for exchange, overlap in variants:
+        if overlap is not None:
+            os.environ["MISPEC_OVERLAP"] = overlap
+        try:
+            alt = run_sharded(world, n, None, nev, ncv, sa.SortRule.LargestMagn, g["tol"], exchange=exchange, keep_vectors=False)
+        finally:
+            os.environ.pop("MISPEC_OVERLAP", None)
+        check_c3_run(alt, world, g, expect_halo=(exchange is None), expect_overlap=(overlap is None))
+        for a, b in zip(alt, res):
+            assert np.array_equal(a["evals"], b["evals"]) and (a["nops"], a["niter"]) == (b["nops"], b["niter"])
+            assert np.array_equal(a["res"], b["res"])
+
+
+def test_full_size_c3_sharded_onesweep():
+    """The same partition (8 ways) with the opt-in one-sweep orthogonalisation: one all-reduced record per step instead of two."""
+    from test_gpu_sharded import run_sharded
+
+    g = golden("c2")
+    res = run_sharded(8, g["n"], None, g["nev"], g["ncv"], sa.SortRule.LargestMagn, g["tol"], orth="onesweep", keep_vectors=False)
+    check_c3_run(res, 8, g, expect_halo=True, expect_overlap=True)
+    for r in res:
+        assert r["orth"]["mode"] == "onesweep" and r["orth"]["lagged_steps"] >= 0.9 * r["nops"]

@@ -28,22 +28,8 @@ def test_reference_test_program(name):
         pytest.skip("tests/cpp/_ref/%s.bin not built (needs /root/reference at build time)" % name)
     r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     out = r.stdout
-    if name == "Example1":
-        # test/Example1.cpp, case (n, k, m) = (20, 5, 12): the cycle Laplacian has DOUBLE eigenvalues, the start vector A v0 has
-        # no component along the constant vector, so the Krylov space is exhausted after 10 steps and the residual there is pure
-        # rounding noise of size ~1e-15 — right at the reference's clamp (Lanczos.h:163-168, beta < eps * sqrt(n) => f = 0).
-        # Which side it falls on depends on the summation order of A x: the CPU oracle (the reference's algorithm restated)
-        # measures 9.887e-16 with row sums in storage order (no clamp, done after 9 restarts) and exactly 0 after the clamp with
-        # numpy's or a 64-lane tree order (new random direction, 239 restarts) — three runs, two paths, all of which happen to
-        # reach the second copies; the device's dense GEMV takes a third path (noise survives one more step, the clamp comes at
-        # the last step, every Ritz estimate is then exactly 0) and returns the five largest DISTINCT eigenvalues after one
-        # restart, with residual 1.7e-15.  With the sparse device operator the same case passes
-        # (tests/test_gpu_solver.py::test_example1_cycle_laplacian).  Accept exactly that outcome, nothing else.
-        import re
-
-        failed = out.count("FAILED:")
-        only_the_degenerate_case = (failed == 1 and "(n, k, m) = (20, 5, 12)" in out and
-                                    re.search(r"test cases:\s+3\s+\|\s+2 passed\s+\|\s+1 failed", out) is not None)
-        assert failed == 0 or only_the_degenerate_case, out[-3000:]
-        return
+    # Example1 (20, 5, 12) exhausts its Krylov space after 10 steps; whether the surviving 1e-15 of noise trips the breakdown clamp
+    # (Lanczos.h:163-168) at a step where the solver can still recover depends on the summation order of A x.  The dense product
+    # operators therefore sum small matrices row by row in storage order (dense.hip k_row_gemv_serial) — the order of a CPU
+    # row-dot, of the sparse kernels and of the oracle, all of which pass this case; no outcome is whitelisted any more.
     assert r.returncode == 0 and "All tests passed" in out, out[-3000:]

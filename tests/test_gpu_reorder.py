@@ -143,3 +143,40 @@ def test_automatic_reordering_at_ingest(ctx):
     rnd = sa.SparseSymMatProd(sp.tril(S).tocsc(), ctx=ctx)
     assert rnd.reordering() == "none" and rnd.reordering_info()["far_fraction_before"] > 0.25
     assert rnd.reorder("auto") is False
+
+
+def test_davidson_and_regular_inverse_use_the_callers_diagonal_on_a_reordered_matrix(ctx, monkeypatch):
+    # the stored matrix of a reordered operator is P A P', so its i-th diagonal entry is A(perm[i], perm[i]); the
+    # Davidson preconditioner / unit start vectors and the Jacobi preconditioner of the CG solve work in the CALLER's order and
+    # must not read that diagonal unpermuted.  A diagonal ramp makes the difference decisive: with the permuted diagonal the
+    # Davidson start vectors point at the wrong rows and the iteration counts blow up.
+    B = shuffled_stencil(24, seed=3).tolil()
+    n = B.shape[0]
+    ramp = np.random.default_rng(9).permutation(n) + 1.0
+    B.setdiag(ramp)
+    B = B.tocsr()
+    k = 5
+    out = {}
+    for mode in ("none", "rcm"):
+        op = sa.SparseSymMatProd(sp.tril(B).tocsc(), ctx=ctx, reorder=mode)
+        assert op.reordering() == mode
+        eigs = sa.DavidsonSymEigsSolver(op, k)
+        nconv = eigs.compute(sa.SortRule.LargestAlge, maxit=100, tol=1e-10)
+        assert nconv == k and eigs.info() == sa.CompInfo.Successful
+        ev, X = eigs.eigenvalues(), eigs.eigenvectors()
+        assert np.abs(B @ X - X * ev).max() < 1e-8
+        out[mode] = (ev, eigs.num_iterations())
+    assert np.abs(out["none"][0] - out["rcm"][0]).max() < 1e-9
+    assert abs(out["none"][1] - out["rcm"][1]) <= 2, out          # same preconditioner => same convergence history
+    # regular inverse: B^{-1} x by CG with the Jacobi preconditioner, reordering forced through the environment
+    M = (B + sp.diags(np.full(n, 8.0))).tocsc()                    # diagonally dominant => positive definite
+    x = np.random.default_rng(4).uniform(-1, 1, n)
+    its = {}
+    for mode in ("none", "rcm"):
+        monkeypatch.setenv("MISPEC_REORDER", mode)
+        R = sa.SparseRegularInverse(sp.tril(M).tocsc(), ctx=ctx)
+        y = R.solve(x)
+        assert np.abs(M @ y - x).max() <= 1e-10 * np.abs(x).max() * 100
+        its[mode] = R.last_iterations()
+    monkeypatch.delenv("MISPEC_REORDER")
+    assert abs(its["none"] - its["rcm"]) <= 1, its

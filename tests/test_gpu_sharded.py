@@ -15,7 +15,7 @@ from spectra_amd import _capi
 pytestmark = pytest.mark.gpu
 
 
-def run_sharded(world, n, offsets, nev, ncv, rule, tol, exchange=None):
+def run_sharded(world, n, offsets, nev, ncv, rule, tol, exchange=None, orth="reference", keep_vectors=True, profile=False):
     import os
 
     lib = sa.lib()
@@ -31,14 +31,20 @@ def run_sharded(world, n, offsets, nev, ncv, rule, tol, exchange=None):
             ctx = sa.Context(0)
             _capi.check(lib.mispec_loopback_attach(grp, ctx.h, rank))
             ctx.rank, ctx.world = rank, world
-            op = sa.SparseSymMatProd.synth_band(n, offsets=offsets, ctx=ctx)
+            op = sa.SparseSymMatProd.synth_band(n, offsets=offsets, ctx=ctx) if offsets is not None else \
+                sa.SparseSymMatProd.synth_band(n, ctx=ctx)
             eigs = sa.SymEigsSolver(op, nev, ncv)
+            eigs.set_orth_mode(orth)
+            if profile:
+                eigs.profile(1)
             eigs.init()
             nconv = eigs.compute(rule, 1000, tol)
-            results[rank] = dict(nconv=nconv, info=eigs.info(), evals=eigs.eigenvalues(), X=eigs.eigenvectors(),
+            results[rank] = dict(nconv=nconv, info=eigs.info(), evals=eigs.eigenvalues(),
+                                 X=eigs.eigenvectors() if keep_vectors else None,
                                  nops=eigs.num_operations(), niter=eigs.num_iterations(), res=eigs.residuals(),
                                  rows=sa.shard_range(n, world, rank), local=op.local_rows(), exchange=eigs.exchange_info(),
-                                 overlap=eigs.overlap_info())
+                                 overlap=eigs.overlap_info(), orth=eigs.orth_info(),
+                                 profile=eigs.get_profile() if profile else None)
         except Exception as e:  # noqa: BLE001
             errors.append((rank, repr(e)))
 
@@ -46,7 +52,7 @@ def run_sharded(world, n, offsets, nev, ncv, rule, tol, exchange=None):
     for t in threads:
         t.start()
     for t in threads:
-        t.join(timeout=600)
+        t.join(timeout=1200)
     os.environ.pop("MISPEC_EXCHANGE", None)
     if old_env is not None:
         os.environ["MISPEC_EXCHANGE"] = old_env

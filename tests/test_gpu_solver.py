@@ -187,13 +187,14 @@ def test_benchmark_matrix_vs_oracle_and_residuals(ctx, n):
         assert np.abs(fac.matrix_H() - ofac.matrices()[1]).max() < 1e-10
 
 
-def test_full_size_c2_residuals(ctx):
+@pytest.mark.parametrize("orth", ["reference", "onesweep"])
+def test_full_size_c2_residuals(ctx, orth):
     # BASELINE.json configs[1]: 10M x 10M, ~15 nnz/row, k = 20, ncv = 40 on one MI355X, against the oracle's complete solve
     # (tests/golden/full_size_c2.json): same nconv, |d lambda| <= 1e-9, operation count within one restart, residuals <= 1e-10
     # from scipy's SpMV on the host, run-to-run bit reproducibility.
     from test_gpu_fullsize import check_c2_solve
 
-    check_c2_solve(ctx)
+    check_c2_solve(ctx, orth)
 
 
 def test_device_driven_steps_equal_host_driven_steps():
