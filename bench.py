@@ -215,13 +215,44 @@ def secondary_configs(args, ctx, op, sa):
         op.set_spmv_format(-1)
     out["csr_kernels_same_matrix"] = csr
 
+    # (1b) ingest of the headline matrix from HOST arrays (the reference's operators take a host matrix and have no ingest cost):
+    # the device-generated matrix is downloaded, then uploaded again as a full CSR matrix and as a lower triangle (CSC, the
+    # reference's SparseSymMatProd<double, Lower> input).  Timed: the library call only (scipy conversions are done before).
+    try:
+        rp, ci, v = op.to_host_csr()
+        full = sp.csr_matrix((v, ci, rp), shape=(args.n, args.n))
+        t0 = time.perf_counter()
+        up = sa.SparseGenMatProd(full, ctx=ctx)
+        t_full = time.perf_counter() - t0
+        st_full = sa.last_ingest_info()
+        fmt_full = up.spmv_format()
+        del up
+        tri = sp.tril(full).tocsc()
+        del full
+        t0 = time.perf_counter()
+        up = sa.SparseSymMatProd(tri, ctx=ctx)
+        t_tri = time.perf_counter() - t0
+        st_tri = sa.last_ingest_info()
+        out["ingest_headline_matrix_from_host"] = {
+            "full_csr": {"seconds": t_full, "stages": st_full, "spmv_format": fmt_full},
+            "lower_triangle_csc": {"seconds": t_tri, "stages": st_tri, "spmv_format": up.spmv_format()},
+            "host_threads": int(sa.lib().mispec_ingest_threads()), "nnz": int(len(v)),
+            "note": "seconds = wall clock of the SparseGenMatProd / SparseSymMatProd constructor (Python marshalling + mispec_csr_upload / "
+                    "mispec_csr_from_triangle); stages = the library's own breakdown (include/mispec.h mispec_last_ingest_info)"}
+        del up, tri, rp, ci, v
+    except Exception as e:  # noqa: BLE001
+        out["ingest_headline_matrix_from_host"] = {"error": repr(e)}
+
     # (2) M-rand at the headline size: scattered columns, the gather-bound case
     t0 = time.perf_counter()
     A = m_rand_host(args.n)
     t_gen = time.perf_counter() - t0
+    tri = sp.tril(A).tocsc()
     t0 = time.perf_counter()
-    rop = sa.SparseSymMatProd(sp.tril(A).tocsc(), ctx=ctx)
+    rop = sa.SparseSymMatProd(tri, ctx=ctx)
     t_ingest = time.perf_counter() - t0
+    ingest_stages = sa.last_ingest_info()
+    del tri
     alone = standalone_ms(rop, args.n, 20)
     e = sa.SymEigsSolver(rop, args.nev, args.ncv)
     e.profile(2)
@@ -237,7 +268,7 @@ def secondary_configs(args, ctx, op, sa):
     rop.set_spmv_format(-1)
     out["m_rand"] = {"n": args.n, "nnz": rop.nnz(), "spmv_format": rop.spmv_format(), "reordering": rop.reordering(), "tiles": rop.tiles_info(),
                      "standalone": spmv_block(rop, alone, 20, False), "in_loop": inloop, "standalone_csr_int32_kernel": csr_alone,
-                     "ingest_seconds": t_ingest,
+                     "ingest_seconds": t_ingest, "ingest_stages": ingest_stages, "ingest_host_threads": int(sa.lib().mispec_ingest_threads()),
                      "solve_12_restarts": {"seconds": dt, "nconv": int(nconv), "num_operations": int(e.num_operations())},
                      "host_generation_seconds": t_gen}
     del e, rop, A
@@ -532,6 +563,15 @@ def main():
             "kernels_ms_note": "from one additional solve with every kernel family bracketed by HIP events, outside the timed region",
             "kernels_launches_per_solve": {k[2:]: prof[k] / args.steps for k in prof if k.startswith("n_")},
         }
+        if world > 1:
+            block_mb = int(sa.lib().mispec_shard_block(args.n, world)) * 8 / 1e6
+            out["collectives_per_step"] = {
+                "exchange": {"count": 1, "kind": "neighbour send/recv" if halo else "all-gather",
+                             "megabytes_received_per_rank": recv_doubles * 8 / 1e6 if halo else (world - 1) * block_mb},
+                "all_reduce_sum": [{"what": "alpha = <v, w>", "bytes": 8}] +
+                                  [{"what": "record: V'f (<= ncv slots used), |f|^2", "bytes": 8 * 1025}] * (1 if args.orth == "onesweep" else 2),
+                "note": "per Lanczos step and rank; one-sweep: one record per step (+ one finishing pass per restart cycle), reference flow: "
+                        "V'f and the correction's V'f check"}
         if allgather_run:
             out["allgather_variant"] = allgather_run
         if world == 1 and not args.no_secondary and not args.no_profile:

@@ -67,9 +67,9 @@ private:
     static bool is_complex(const Complex& v) { return v.imag() != RealScalar(0); }
     static bool is_conj(const Complex& a, const Complex& b) { return a == std::conj(b); }
 
-    // LIMIT of this implementation (not of the reference): the device factorisation holds at most 256 basis vectors, so a
-    // solver constructed with ncv > 256 throws std::invalid_argument from the factorisation's constructor
-    // (mispec_fac_create: "ncv <= 256"); the reference accepts any nev < ncv <= n.
+    // LIMIT of this implementation (not of the reference): the device factorisation holds at most 1024 basis vectors, so a
+    // solver constructed with ncv > 1024 throws std::invalid_argument from the factorisation's constructor
+    // (mispec_fac_create: "ncv <= 1024"); the reference accepts any nev < ncv <= n.
     static Index check_args(Index n, Index nev, Index ncv)
     {
         if (nev < 1 || nev > n - 2)
@@ -137,11 +137,11 @@ private:
         if (k >= m_ncv)
             return;
         const int m = static_cast<int>(m_ncv);
-        // Where the ncv x ncv sweeps run: MISPEC_SMALL_GEN=device applies the whole shift list in one LDS-resident kernel
+        // Where the ncv x ncv sweeps run: MISPEC_SMALL=device applies the whole shift list in one LDS-resident kernel
         // (ncv <= 96, spectra_amd/csrc/small.hip k_hess_restart; H and Q never leave the device between the sweeps and
         // V <- V Q); the default is the host (same arithmetic, internal/SmallDenseGen.h) because one wavefront stepping
         // through a serial chain of reflectors is slower than one host core at these sizes (DESIGN.md 3.4 has the numbers).
-        static const char* where = std::getenv("MISPEC_SMALL_GEN");
+        static const char* where = std::getenv("MISPEC_SMALL");
         if (where && std::string(where) == "device" && m <= 96)
         {
             std::vector<int> kind;

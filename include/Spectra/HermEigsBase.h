@@ -64,9 +64,9 @@ private:
     std::vector<char> m_ritz_conv;  // convergence flags of the wanted values
     CompInfo m_info;
 
-    // LIMIT of this implementation (not of the reference): the device factorisation holds at most 256 basis vectors, so a
-    // solver constructed with ncv > 256 throws std::invalid_argument from the factorisation's constructor
-    // (mispec_fac_create: "ncv <= 256"); the reference accepts any nev < ncv <= n.
+    // LIMIT of this implementation (not of the reference): the device factorisation holds at most 1024 basis vectors, so a
+    // solver constructed with ncv > 1024 throws std::invalid_argument from the factorisation's constructor
+    // (mispec_fac_create: "ncv <= 1024"); the reference accepts any nev < ncv <= n.
     static Index check_ncv(Index ncv, Index n) { return ncv > n ? n : ncv; }
     static std::vector<OpType> create_op_container(OpType&& rval)
     {

@@ -118,17 +118,19 @@ int64_t mispec_csr_local_rows(const mispec_csr* A); /* rows held by this shard *
 int64_t mispec_csr_local_nnz(const mispec_csr* A);
 /* Index format the SpMV uses for this shard: 0 = plain int32 column indices (12 bytes per stored entry), d > 0 =
  * offset codes, one byte per entry into a dictionary of d <= 256 distinct diagonals col - row (9 bytes per entry).
- * Chosen at construction whenever the dictionary fits; MISPEC_SPMV_CODES=0 in the environment turns it off. */
+ * Built at construction whenever the dictionary fits; mispec_csr_set_spmv_format / mispec_csr_use_offset_codes select. */
 int mispec_csr_offset_codes(const mispec_csr* A);
 /* Per-matrix switch between the two index formats (both give bit-identical products); no effect when the matrix
  * has no dictionary. */
 int mispec_csr_use_offset_codes(mispec_csr* A, int enable);
 /* Storage format the SpMV uses for this shard: 0 = CSR with int32 column indices, 1 = CSR with offset codes, 2 = diagonal
  * storage (values kept diagonal-major, no index and no gather; chosen when the dictionary has <= 32 diagonals that are
- * at least 3/4 full, rows sorted, no duplicate entries; MISPEC_SPMV_DIA=0 turns it off), 3 = column-blocked tiles (built at
+ * at least 3/4 full, rows sorted, no duplicate entries), 3 = column-blocked tiles (built at
  * ingest for unsharded matrices with more than a quarter of their entries further than 131072 columns from the diagonal
- * that reordering did not localise: 4096-row segments x 131072-column blocks, the segment's sums in LDS, x reused through
- * the L2; MISPEC_SPMV_TILES=0 turns it off, =1 builds it for any matrix).  All give bit-identical products for finite x
+ * that reordering did not localise: 8192-row segments x 65536-column blocks; two-phase product — phase 1 forms all products
+ * chunk by chunk in column-block order, so that the whole device gathers from the same 0.5-1 MiB of x at any moment, phase 2
+ * sums them per segment in LDS; MISPEC_SPMV_TILES=0 turns the format off, =1 builds it for any matrix, =onephase builds it with
+ * the older kernel that gathers x during the segment sweep).  All give bit-identical products for finite x
  * (the diagonal format multiplies x by explicit zeros where the matrix has no entry).
  * mispec_csr_set_spmv_format forces a format for this matrix (-1 = automatic; a format that was not built falls back). */
 int mispec_csr_spmv_format(const mispec_csr* A);
@@ -164,12 +166,23 @@ int mispec_csr_reorder(mispec_csr* A, int method, int* applied);
 int mispec_csr_reordering(const mispec_csr* A, double* far_before, double* far_after);
 int mispec_csr_permutation(const mispec_csr* A, int32_t* perm_out);
 /* What the tile format of this matrix looks like (segments = 0: not built): stored entries incl. padding, padding entries,
- * and the launch variant picked by measurement at ingest (0: one free-running workgroup per segment; k: persistent
- * workgroups that meet every k column blocks). */
-int mispec_csr_tiles_info(const mispec_csr* A, int64_t* segments, int64_t* entries, int64_t* padding, int* sync_period);
+ * and whether the two-phase product is in use (1: products in column-block order, then segment sums — tiles.hpp; 0: the
+ * one-phase kernel that gathers x per entry, MISPEC_SPMV_TILES=onephase). */
+int mispec_csr_tiles_info(const mispec_csr* A, int64_t* segments, int64_t* entries, int64_t* padding, int* two_phase);
+/* Wall-clock seconds of the host stages of the last mispec_csr_upload / mispec_csr_from_triangle on the calling thread:
+ * [0] the whole call, [1] triangle -> full matrix, [2] validation + local row pointers, [3] index formats (offset codes, diagonal
+ * storage) incl. the H2D copies of the CSR arrays, [4] far-gather statistics + reordering, [5] tile image on the host, [6] its
+ * upload and split.  count <= 8 values are written. */
+int mispec_last_ingest_info(double* seconds_out, int count);
+int mispec_ingest_threads(void); /* host threads the ingest stages use: the machine's hardware threads, at most 64 */
+/* Host-only test hook (no device needed): the full symmetric CSR matrix (rows sorted by column) that mispec_csr_from_triangle
+ * derives from one stored triangle — built by the library's host threads, the same bytes whatever their number.  rowptr_out has
+ * n + 1 entries, colind_out / val_out `capacity` entries (twice the input's entries always suffice); *nnz_out = entries written. */
+int mispec_mirror_triangle_host(int64_t n, const int32_t* outer, const int32_t* inner, const double* val, char uplo, int row_major,
+                                int32_t* rowptr_out, int32_t* colind_out, double* val_out, int64_t capacity, int64_t* nnz_out);
 /* Host image of the tile format and its summation order, for tests (no device needed): y = A x through the tiles of an
- * nrows x ncols CSR matrix; *built = 0 when the format does not apply (a row with more than 7 entries inside one column
- * block, unsorted rows).  stats (optional): entries incl. padding, padding entries, chunks. */
+ * nrows x ncols CSR matrix; *built = 0 when the format does not apply (unsorted rows or duplicate entries, more than 65535
+ * column blocks; a row with more than 7 entries inside one column block is emitted in several passes).  stats (optional): entries incl. padding, padding entries, chunks. */
 int mispec_tiles_spmv_host(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* colind, const double* val,
                            const double* x, double* y, int* built, int64_t* stats);
 /* The ordering alone, on host arrays (no device needed): perm_out[new] = old for the pattern of an n x n CSR matrix;

@@ -74,6 +74,30 @@ def tiles_spmv_host(mat, x):
     return (y if built.value else None), {"entries": st[0], "padding": st[1], "chunks": st[2]}
 
 
+def last_ingest_info():
+    """Seconds the host stages of the last matrix ingest on this thread took (mispec_last_ingest_info)."""
+    out = np.zeros(8)
+    check(lib().mispec_last_ingest_info(_dp(out), 7))
+    keys = ("total", "mirror_triangle", "validate", "index_formats_and_h2d", "far_statistics_and_reordering", "tiles_build", "tiles_upload")
+    return dict(zip(keys, out[:7].tolist()))
+
+
+def mirror_triangle_host(mat, uplo="L"):
+    """The full symmetric CSR matrix that mispec_csr_from_triangle derives from the `uplo` triangle of a compressed scipy matrix
+    (CSC or CSR; the other triangle is ignored) — host only, no device needed (mispec_mirror_triangle_host)."""
+    import scipy.sparse as sp
+
+    n, nc, outer, inner, val, row_major = _compressed(mat)
+    cap = 2 * len(val) + 1
+    rp = np.zeros(n + 1, dtype=np.int32)
+    ci = np.zeros(cap, dtype=np.int32)
+    v = np.zeros(cap)
+    nnz = C.c_int64(0)
+    check(lib().mispec_mirror_triangle_host(n, _ip(outer), _ip(inner), _dp(val), uplo.encode()[0:1], int(row_major), _ip(rp), _ip(ci), _dp(v),
+                                           cap, C.byref(nnz)))
+    return sp.csr_matrix((v[:nnz.value], ci[:nnz.value], rp), shape=(n, n))
+
+
 def rcm_order(rowptr, colind, symmetric_pattern=True):
     """Reverse Cuthill-McKee ordering of an n x n CSR pattern on the host (mispec_rcm_order; no device needed).
     Returns (perm with perm[new] = old, gave_up, widest_level)."""
@@ -235,10 +259,10 @@ class _DeviceMatrix:
         return float(lib().mispec_csr_spmv_bytes(self.h, 1))
 
     def tiles_info(self):
-        """{segments, entries, padding, sync_period} of the column-blocked tile format (segments = 0: not built)."""
+        """{segments, entries, padding, two_phase} of the column-blocked tile format (segments = 0: not built)."""
         a, b, c, d = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int(0)
         check(lib().mispec_csr_tiles_info(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
-        return {"segments": a.value, "entries": b.value, "padding": c.value, "sync_period": d.value}
+        return {"segments": a.value, "entries": b.value, "padding": c.value, "two_phase": bool(d.value)}
 
     def reorder(self, method="rcm"):
         """Symmetric reordering of the stored matrix (mispec_csr_reorder): "rcm" always, "auto" only when it pays.  Returns

@@ -193,6 +193,9 @@ SIGNATURES = {
     "mispec_symeigs_exchange_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "mispec_symeigs_overlap_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mispec_fac_overlap_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mispec_last_ingest_info": (C.c_int, [_dp, C.c_int]),
+    "mispec_ingest_threads": (C.c_int, []),
+    "mispec_mirror_triangle_host": (C.c_int, [C.c_int64, _ip, _ip, _dp, C.c_char, C.c_int, _ip, _ip, _dp, C.c_int64, _lp]),
     "mispec_symeigs_profile": (C.c_int, [_vp, C.c_int]),
     "mispec_symeigs_set_orth_mode": (C.c_int, [_vp, C.c_int]),
     "mispec_symeigs_orth_info": (C.c_int, [_vp, C.POINTER(C.c_int), _lp, _lp, _lp, _dp, _dp]),

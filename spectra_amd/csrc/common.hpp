@@ -6,6 +6,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <utility>
 #include <stdexcept>
 #include <string>
@@ -132,6 +133,13 @@ struct PinnedBuf
 };
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// Host threads of the ingest stages (format builders, triangle mirroring, validation passes): the machine's hardware threads,
+// at most 64.  Every parallel stage produces the bytes the serial loop would.
+int ingest_threads();
+// fn(t, begin, end) over `parts` contiguous, nearly equal pieces of [0, n), one std::thread each (inline when parts <= 1);
+// an exception thrown by a piece is rethrown on the calling thread.
+void parallel_ranges(int64_t n, int parts, const std::function<void(int, int64_t, int64_t)>& fn);
 
 }  // namespace mispec
 

@@ -32,6 +32,8 @@
 
 #include <hip/hip_ext.h>
 
+#include <chrono>
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(256) void k_spmv_dia(DiaArgs da, const double* __re
 // The same product with the x entries of a row-block staged through LDS: the offsets cluster, so a block of 256 rows reads
 // a few contiguous windows of x (coalesced, once) instead of one 8-byte load per row and diagonal through the L1.
 // NG = groups of eight diagonals whose values a thread keeps in registers.
-template <bool EPI, int NG, bool FUSE = false, int NCW = 8>  // NCW: registers for window entries (>= number of windows)
+template <bool EPI, int NG, int NCW = 8>  // NCW: registers for window entries (>= number of windows)
 __global__ __launch_bounds__(256) void k_spmv_dia_win(DiaArgs da, mispec_dia_windows w, const double* __restrict__ x,
                                                       double* __restrict__ y, int64_t nrows, int nblocks, SpmvEpilogue epi)
 {
@@ -406,27 +408,6 @@ __global__ __launch_bounds__(256) void k_spmv_dia_win(DiaArgs da, mispec_dia_win
     if (EPI && epi.status && *epi.status != 0)
         return;
     const int tid = threadIdx.x;
-    double beta = 1.0;
-    if (FUSE)
-    {
-        // the start of the Lanczos step that k_scale_step otherwise does (Lanczos.h:99-128 without the restart branch):
-        // every block takes the same decision from the same beta; one thread records it
-        StepState* st = static_cast<StepState*>(epi.scale_state);
-        beta = st->beta;
-        const bool first = (blockIdx.x == 0 && tid == 0);
-        if (beta < epi.scale_eps_sqrt)
-        {
-            if (first)
-            {
-                st->status = kStepSmallBeta;
-                st->stop_step = epi.scale_step;
-                st->stop_count = 0;
-            }
-            return;
-        }
-        if (first)
-            st->subd[epi.scale_step - 1] = beta;  // Lanczos.h:127-128
-    }
     const int64_t row0 = int64_t(lb) * 256;
     const int nr = int(min(int64_t(256), nrows - row0));
     int64_t vstride;
@@ -439,17 +420,15 @@ __global__ __launch_bounds__(256) void k_spmv_dia_win(DiaArgs da, mispec_dia_win
     // the barrier instead of costing the block a second round trip to HBM after its row sums (the kernel is bound by the
     // number of resident blocks, i.e. by latency per block: profiles/r02r_*, r03q_*).
     double vprev_early = 0.0, vrow_early = 0.0, hprev_early = 0.0;
-    const bool early = EPI && !epi.late_loads && tid < nr;
+    const bool early = EPI && tid < nr;
     if (early)
     {
         if (epi.v_prev)
         {
             vprev_early = epi.v_prev[row0 + tid];
-            if (!FUSE)
-                hprev_early = epi.h_prev_dev ? *epi.h_prev_dev : epi.h_prev;
+            hprev_early = epi.h_prev_dev ? *epi.h_prev_dev : epi.h_prev;
         }
-        if (!FUSE)
-            vrow_early = epi.v_rows[row0 + tid];
+        vrow_early = epi.v_rows[row0 + tid];
     }
     const int64_t g0 = da.row_begin + row0;
     // x windows -> LDS.  A window is 256 + span entries: two per thread, ALL loaded before the first LDS write.  (Written as
@@ -484,9 +463,9 @@ __global__ __launch_bounds__(256) void k_spmv_dia_win(DiaArgs da, mispec_dia_win
 #pragma unroll
     for (int c = 0; c < NCW; c++)
         if (c < w.nc)
-            xs[w.base[c] + tid] = FUSE ? xw[c] / beta : xw[c];  // the same true division as k_scale_step: the same v, bit for bit
+            xs[w.base[c] + tid] = xw[c];
     if (tail_pos >= 0)
-        xs[tail_pos] = FUSE ? xtail / beta : xtail;
+        xs[tail_pos] = xtail;
     if (tails > 256)  // more tail entries than threads (very wide clusters): the rest the slow way
     {
         int before = 0;
@@ -497,14 +476,11 @@ __global__ __launch_bounds__(256) void k_spmv_dia_win(DiaArgs da, mispec_dia_win
                 if (t >= before)
                 {
                     const double xv = xat(g0 + w.start[c] + 256 + (t - before));
-                    xs[w.base[c] + 256 + (t - before)] = FUSE ? xv / beta : xv;
+                    xs[w.base[c] + 256 + (t - before)] = xv;
                 }
             before += span;
         }
     }
-    double vown = 0.0;
-    if (FUSE)
-        vown = x[da.row_begin + row0 + min(tid, nr - 1)] / beta;
     __syncthreads();
     double acc = 0.0;
 #pragma unroll
@@ -519,16 +495,10 @@ __global__ __launch_bounds__(256) void k_spmv_dia_win(DiaArgs da, mispec_dia_win
             const int64_t row = row0 + tid;
             double yv = acc;
             if (epi.v_prev)
-                yv -= (FUSE ? beta : (early ? hprev_early : (epi.h_prev_dev ? *epi.h_prev_dev : epi.h_prev))) *
+                yv -= (early ? hprev_early : (epi.h_prev_dev ? *epi.h_prev_dev : epi.h_prev)) *
                       (early ? vprev_early : epi.v_prev[row]);  // Lanczos.h:139
             y[row] = yv;
-            if (FUSE)
-            {
-                epi.v_out[row] = vown;  // Lanczos.h:106
-                contrib = vown * yv;
-            }
-            else
-                contrib = (early ? vrow_early : epi.v_rows[row]) * yv;  // Lanczos.h:142 partial <v, w>
+            contrib = (early ? vrow_early : epi.v_rows[row]) * yv;  // Lanczos.h:142 partial <v, w>
         }
         const double total = block_reduce_sum(contrib, red);
         if (tid == 0)
@@ -560,7 +530,7 @@ __global__ __launch_bounds__(256) void k_epilogue_blocks(double* __restrict__ y,
     __shared__ double red[4];
     if (epi.status && *epi.status != 0)
         return;
-    if (blockDim.x < 256)  // 128-row blocks (MISPEC_SPMV_ROWS=128): two of the four wave slots stay zero
+    if (blockDim.x < 256)  // fewer than four waves: the unused wave slots stay zero
     {
         if (threadIdx.x < 4)
             red[threadIdx.x] = 0.0;
@@ -664,13 +634,12 @@ void alloc_codes(mispec_csr& A)
 }
 
 // Diagonal storage from the offset codes (device): only for small, well-filled dictionaries whose rows are sorted and free
-// of duplicates; anything else keeps the CSR kernels.  MISPEC_SPMV_DIA=0 turns the format off.
+// of duplicates; anything else keeps the CSR kernels (mispec_csr_set_spmv_format selects among the formats a matrix has).
 void build_dia(mispec_csr& A, const std::vector<int32_t>& dict)
 {
-    static const bool on = getenv("MISPEC_SPMV_DIA") ? atoi(getenv("MISPEC_SPMV_DIA")) != 0 : true;
     const int64_t nloc = A.local_rows();
     const int nd = int(dict.size());
-    if (!on || nd == 0 || nd > kMaxDia || nloc == 0 || double(A.nnz) < 0.75 * double(nd) * double(nloc))
+    if (nd == 0 || nd > kMaxDia || nloc == 0 || double(A.nnz) < 0.75 * double(nd) * double(nloc))
         return;
     std::vector<int32_t> order(static_cast<size_t>(nd)), pos(static_cast<size_t>(nd)), offs(static_cast<size_t>(nd));
     std::iota(order.begin(), order.end(), 0);
@@ -680,10 +649,10 @@ void build_dia(mispec_csr& A, const std::vector<int32_t>& dict)
         pos[size_t(order[size_t(k)])] = k;
         offs[size_t(k)] = dict[size_t(order[size_t(k)])];
     }
-    // MISPEC_DIA_LAYOUT=block (default): the values of a 256-row block are stored as one contiguous [nd][256] piece, so a
-    // workgroup streams ONE 30 KB run instead of nd runs of 2 KB that are 80 MB apart; =diagonal keeps dia[k][row]
-    static const bool blocked = !(getenv("MISPEC_DIA_LAYOUT") && std::strcmp(getenv("MISPEC_DIA_LAYOUT"), "diagonal") == 0);
-    const int64_t ld = blocked ? round_up(nloc, 256) : round_up(nloc, 2);
+    // the values of a 256-row block are stored as one contiguous [nd][256] piece, so a workgroup streams ONE 30 KB run instead
+    // of nd runs of 2 KB that are 80 MB apart (the diagonal-major layout dia[k][row] of round 1 measured 1.5 % slower and is gone)
+    constexpr bool blocked = true;
+    const int64_t ld = round_up(nloc, 256);
     DevBuf<int32_t> d_pos;
     DevBuf<int> d_bad;
     d_pos.alloc(size_t(nd));
@@ -740,38 +709,103 @@ bool build_offset_codes(int64_t b, int64_t e, const int32_t* rowptr, const int32
                         std::vector<uint8_t>& codes)
 {
     constexpr int kSlots = 1024;  // open addressing, <= 25 % full
-    int64_t key[kSlots];
-    int code_of[kSlots];
-    std::fill(key, key + kSlots, INT64_MIN);
-    dict.clear();
-    codes.resize(size_t(rowptr[e] - rowptr[b]));
-    const int64_t p0 = rowptr[b];
-    int64_t last_d = INT64_MIN;
-    int last_code = 0;
-    for (int64_t i = b; i < e; i++)
-        for (int64_t p = rowptr[i]; p < rowptr[i + 1]; p++)
+    struct Table
+    {
+        int64_t key[kSlots];
+        int code_of[kSlots];
+        std::vector<int64_t> order;  // distinct diagonals in the order of their first appearance
+        Table() { std::fill(key, key + kSlots, INT64_MIN); }
+        static unsigned slot(int64_t d) { return unsigned(uint64_t(d) * 0x9E3779B97F4A7C15ULL >> 54) & (kSlots - 1); }
+        int find(int64_t d) const
         {
-            const int64_t d = int64_t(colind[p]) - i;
-            if (d != last_d)
-            {
-                unsigned h = unsigned(uint64_t(d) * 0x9E3779B97F4A7C15ULL >> 54) & (kSlots - 1);
-                while (key[h] != INT64_MIN && key[h] != d)
-                    h = (h + 1) & (kSlots - 1);
-                if (key[h] == INT64_MIN)
-                {
-                    if (int(dict.size()) == kMaxDict)
-                        return false;
-                    key[h] = d;
-                    code_of[h] = int(dict.size());
-                    dict.push_back(int32_t(d));
-                }
-                last_d = d;
-                last_code = code_of[h];
-            }
-            codes[size_t(p - p0)] = uint8_t(last_code);
+            unsigned h = slot(d);
+            while (key[h] != INT64_MIN && key[h] != d)
+                h = (h + 1) & (kSlots - 1);
+            return key[h] == INT64_MIN ? -1 : code_of[h];
         }
-    return !dict.empty();
+        bool insert(int64_t d)  // false: the dictionary is full
+        {
+            unsigned h = slot(d);
+            while (key[h] != INT64_MIN && key[h] != d)
+                h = (h + 1) & (kSlots - 1);
+            if (key[h] == d)
+                return true;
+            if (int(order.size()) == kMaxDict)
+                return false;
+            key[h] = d;
+            code_of[h] = int(order.size());
+            order.push_back(d);
+            return true;
+        }
+    };
+    dict.clear();
+    const int64_t p0 = rowptr[b], nnz = rowptr[e] - rowptr[b];
+    // pass 1 (host threads over contiguous row ranges): the distinct diagonals of every range in order of first appearance;
+    // merged in range order they give the dictionary a single scan would build
+    const int nt = int(std::max<int64_t>(1, std::min<int64_t>(ingest_threads(), nnz / 1048576)));
+    std::vector<Table> local(static_cast<size_t>(nt));
+    std::vector<char> full(static_cast<size_t>(nt), 0);
+    parallel_ranges(e - b, nt, [&](int t, int64_t rb, int64_t re) {
+        Table& T = local[size_t(t)];
+        int64_t last_d = INT64_MIN;
+        for (int64_t i = b + rb; i < b + re && !full[size_t(t)]; i++)
+            for (int64_t p = rowptr[i]; p < rowptr[i + 1]; p++)
+            {
+                const int64_t d = int64_t(colind[p]) - i;
+                if (d == last_d)
+                    continue;
+                last_d = d;
+                if (!T.insert(d))
+                {
+                    full[size_t(t)] = 1;
+                    break;
+                }
+            }
+    });
+    Table G;
+    for (int t = 0; t < nt; t++)
+    {
+        if (full[size_t(t)])
+            return false;
+        for (int64_t d : local[size_t(t)].order)
+            if (!G.insert(d))
+                return false;
+    }
+    if (G.order.empty())
+        return false;
+    for (int64_t d : G.order)
+        dict.push_back(int32_t(d));
+    // pass 2: encode
+    codes.resize(size_t(nnz));
+    parallel_ranges(e - b, nt, [&](int, int64_t rb, int64_t re) {
+        int64_t last_d = INT64_MIN;
+        int last_code = 0;
+        for (int64_t i = b + rb; i < b + re; i++)
+            for (int64_t p = rowptr[i]; p < rowptr[i + 1]; p++)
+            {
+                const int64_t d = int64_t(colind[p]) - i;
+                if (d != last_d)
+                {
+                    last_d = d;
+                    last_code = G.find(d);
+                }
+                codes[size_t(p - p0)] = uint8_t(last_code);
+            }
+    });
+    return true;
 }
+
+// Wall-clock seconds of the host stages of the last ingest on this thread (mispec_last_ingest_info): [0] the whole library call,
+// [1] triangle -> full matrix, [2] validation + local row pointers, [3] index formats (offset codes, diagonal storage) incl. the
+// H2D copies of the CSR arrays, [4] far-gather statistics + reordering, [5] tile image on the host, [6] its upload and split.
+thread_local double g_ingest[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+struct IngestTimer
+{
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    int slot;
+    explicit IngestTimer(int s) : slot(s) {}
+    ~IngestTimer() { g_ingest[slot] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
 
 // Upload host CSR rows [begin,end) of a global matrix.
 bool reorder_matrix(mispec_csr& A, const int32_t* rowptr, const int32_t* colind, const double* val, bool forced);
@@ -798,13 +832,31 @@ mispec_csr* upload_rows(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const i
         MISPEC_REQUIRE(p1 >= p0, "csr upload: row pointers must be non-decreasing");
         alloc_entries(*A, p1 - p0);
         std::vector<int32_t> rp(size_t(nloc) + 1);
-        for (int64_t i = 0; i <= nloc; i++)
         {
-            MISPEC_REQUIRE(rowptr[b + i] >= rowptr[b + (i ? i - 1 : 0)], "csr upload: row pointers must be non-decreasing");
-            rp[size_t(i)] = int32_t(rowptr[b + i] - p0);
+            IngestTimer timer(2);
+            const int nt = int(std::max<int64_t>(1, std::min<int64_t>(ingest_threads(), (p1 - p0) / 1048576)));
+            std::vector<char> bad_rp(static_cast<size_t>(nt), 0), bad_col(static_cast<size_t>(nt), 0);
+            parallel_ranges(nloc + 1, nt, [&](int t, int64_t ib, int64_t ie) {
+                for (int64_t i = ib; i < ie; i++)
+                {
+                    if (rowptr[b + i] < rowptr[b + (i ? i - 1 : 0)])
+                        bad_rp[size_t(t)] = 1;
+                    rp[size_t(i)] = int32_t(rowptr[b + i] - p0);
+                }
+            });
+            parallel_ranges(p1 - p0, nt, [&](int t, int64_t pb, int64_t pe) {
+                char bad = 0;
+                for (int64_t p = p0 + pb; p < p0 + pe; p++)
+                    bad |= char(colind[p] < 0 || colind[p] >= n_cols);
+                bad_col[size_t(t)] = bad;
+            });
+            for (int t = 0; t < nt; t++)
+            {
+                MISPEC_REQUIRE(!bad_rp[size_t(t)], "csr upload: row pointers must be non-decreasing");
+                MISPEC_REQUIRE(!bad_col[size_t(t)], "csr upload: column index out of range");
+            }
         }
-        for (int64_t p = p0; p < p1; p++)
-            MISPEC_REQUIRE(colind[p] >= 0 && colind[p] < n_cols, "csr upload: column index out of range");
+        std::unique_ptr<IngestTimer> formats(new IngestTimer(3));
         A->rowptr.alloc(size_t(nloc) + 1);
         MISPEC_HIP(hipMemcpyAsync(A->rowptr.p, rp.data(), rp.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
         if (p1 > p0)
@@ -816,7 +868,7 @@ mispec_csr* upload_rows(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const i
         }
         std::vector<int32_t> dict;
         std::vector<uint8_t> codes;
-        if (p1 > p0 && spmv_codes_enabled() && build_offset_codes(b, e, rowptr, colind, dict, codes))
+        if (p1 > p0 && build_offset_codes(b, e, rowptr, colind, dict, codes))
         {
             alloc_codes(*A);
             A->dict.alloc(dict.size());
@@ -826,19 +878,22 @@ mispec_csr* upload_rows(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const i
             build_dia(*A, dict);
         }
         MISPEC_HIP(hipStreamSynchronize(ctx->stream));
+        formats.reset();
         A->structurally_symmetric = structurally_symmetric;
         // MISPEC_REORDER = auto (default) | rcm | none: an unsharded square matrix whose gathers are scattered (more than a
         // quarter of the entries further than kFarWindow from the diagonal, and x larger than an L2 slice) is reordered
         // at ingest when reverse Cuthill-McKee localises them (reorder.hip)
-        // MISPEC_SPMV_TILES = auto (default) | 0 | 1: the column-blocked tile format for scattered patterns that stay
-        // scattered (decided below, after the reordering attempt)
+        // MISPEC_SPMV_TILES = auto (default) | 0 | 1 | onephase: the column-blocked tile format for scattered patterns that stay
+        // scattered (decided below, after the reordering attempt; "onephase" = forced, with the gathering one-phase kernel)
         const char* tmode = getenv("MISPEC_SPMV_TILES");
-        const bool tiles_off = tmode && std::strcmp(tmode, "0") == 0, tiles_force = tmode && std::strcmp(tmode, "1") == 0;
+        const bool tiles_off = tmode && std::strcmp(tmode, "0") == 0;
+        const bool tiles_force = tmode && (std::strcmp(tmode, "1") == 0 || std::strcmp(tmode, "onephase") == 0);
         const char* mode = getenv("MISPEC_REORDER");
         const bool off = mode && std::strcmp(mode, "none") == 0;
         const bool force = mode && std::strcmp(mode, "rcm") == 0;
         if (allow_reorder && !off && ctx->world() == 1 && ctx->comm.allgather == nullptr && n_rows == n_cols && p1 > p0)
         {
+            IngestTimer timer(4);
             A->far_before = far_fraction(n_rows, rowptr, colind, nullptr, kFarWindow);
             if (force || (n_rows >= 2 * kFarWindow && A->far_before > 0.25))
                 reorder_matrix(*A, rowptr, colind, val, force);
@@ -850,10 +905,15 @@ mispec_csr* upload_rows(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const i
             if (tiles_force || (n_cols >= 2 * kFarWindow && far > 0.25))
             {
                 HostTiles H;
-                if (build_tiles(n_rows, n_cols, rowptr, colind, val, H))
+                bool built;
                 {
+                    IngestTimer timer(5);
+                    built = build_tiles(n_rows, n_cols, rowptr, colind, val, H);
+                }
+                if (built)
+                {
+                    IngestTimer timer(6);
                     upload_tiles(H, ctx->stream, A->tiles);
-                    calibrate_tiles(A->tiles, ctx->stream, nloc, n_cols, spmv_num_blocks(nloc));
                 }
             }
         }
@@ -1004,26 +1064,7 @@ void interior_blocks(const mispec_csr& A, int64_t col_lo, int64_t col_hi, int& f
     count = best;
 }
 
-bool spmv_can_fuse_scale(const mispec_csr& A)
-{
-    static const bool win_on = getenv("MISPEC_SPMV_DIA_WIN") ? atoi(getenv("MISPEC_SPMV_DIA_WIN")) != 0 : true;
-    // opt-in: measured (profiles/r02n_ab_fuse_scale.jsonl) the fused launch saves the 29 us scaling pass but the divisions in
-    // the window fill cost the SpMV 16 us — 1707.7 vs 1707.3 ms per solve, no gain, and a lower fraction for the timed kernel
-    static const bool fuse_on = getenv("MISPEC_FUSE_SCALE") ? atoi(getenv("MISPEC_FUSE_SCALE")) != 0 : false;
-    return fuse_on && win_on && !A.reordered() && A.row_begin == 0 && A.n_rows == A.n_cols && A.spmv_format() == 2 && A.dia_win.nc > 0;
-}
-
-bool spmv_codes_enabled()
-{
-    static const bool on = getenv("MISPEC_SPMV_CODES") ? atoi(getenv("MISPEC_SPMV_CODES")) != 0 : true;
-    return on;
-}
-
-int spmv_rows_per_block()
-{
-    static const int rows = (getenv("MISPEC_SPMV_ROWS") && atoi(getenv("MISPEC_SPMV_ROWS")) == 128) ? 128 : 256;
-    return rows;
-}
+int spmv_rows_per_block() { return 256; }
 
 void launch_to_stored_order(const mispec_csr& A, const double* src, double* dst)
 {
@@ -1084,16 +1125,11 @@ void launch_spmv_raw(const mispec_csr& A, const double* x_dev, double* y_dev, co
         return;
     MISPEC_REQUIRE(block_first >= 0 && block_first + block_count <= all_blocks, "SpMV: row-block range out of bounds");
     const int nblocks = block_count;  // the kernels map blockIdx onto [first_block, first_block + nblocks)
-    MISPEC_REQUIRE(!(epi && epi->scale_state) || (spmv_can_fuse_scale(A) && block_count == all_blocks),
-                   "SpMV: a fused step start was requested for a matrix / launch that cannot take it");
     const int per = (nblocks + 7) >> 3;
     const int threads = spmv_rows_per_block();
     const dim3 grid(unsigned(per * 8)), block(static_cast<unsigned>(threads));
-    static const bool nt = getenv("MISPEC_SPMV_NT") ? atoi(getenv("MISPEC_SPMV_NT")) != 0 : false;
     SpmvEpilogue e = epi ? *epi : SpmvEpilogue{};
     e.first_block = block_first;
-    static const bool late_epilogue = getenv("MISPEC_DIA_LATE_EPILOGUE") && atoi(getenv("MISPEC_DIA_LATE_EPILOGUE")) != 0;
-    e.late_loads = late_epilogue ? 1 : 0;
     const int format = A.spmv_format();
     const bool coded = format == 1;
     const SpmvCodes cd{A.codes.p, A.dict.p, A.ndict, int(A.n_cols - 1), A.row_begin};
@@ -1106,22 +1142,19 @@ void launch_spmv_raw(const mispec_csr& A, const double* x_dev, double* y_dev, co
     if (format == 2)
     {
         const DiaArgs da{A.dia.p, A.dia_off.p, A.dia_ld, A.ndia, int(A.n_cols - 1), A.row_begin};
-        // x staged through LDS windows (default when the offsets form at most 8 clusters; MISPEC_SPMV_DIA_WIN=0: direct loads)
-        static const bool win_on = getenv("MISPEC_SPMV_DIA_WIN") ? atoi(getenv("MISPEC_SPMV_DIA_WIN")) != 0 : true;
-        if (win_on && A.dia_win.nc > 0)
+        // x staged through LDS windows when the offsets form at most 8 clusters, else direct loads (k_spmv_dia)
+        if (A.dia_win.nc > 0)
         {
-            // MISPEC_DIA_LDS_PAD=bytes: extra dynamic LDS per workgroup, i.e. fewer resident workgroups per CU (an occupancy experiment)
-            static const size_t lds_pad = getenv("MISPEC_DIA_LDS_PAD") ? size_t(atol(getenv("MISPEC_DIA_LDS_PAD"))) : 0;
-            const size_t lds = size_t(A.dia_win.total) * sizeof(double) + lds_pad;
+            const size_t lds = size_t(A.dia_win.total) * sizeof(double);
             const int ng = (A.ndia + kDiaGroup - 1) / kDiaGroup;
 #define MISPEC_DIA_WIN_W(E, G, W)                                                                                             \
     do                                                                                                                     \
     {                                                                                                                      \
         if (ev_start && ev_stop)                                                                                           \
-            hipExtLaunchKernelGGL((k_spmv_dia_win<E, G, false, W>), grid, block, lds, A.ctx->stream, ev_start, ev_stop, 0, da, A.dia_win, x_dev, \
+            hipExtLaunchKernelGGL((k_spmv_dia_win<E, G, W>), grid, block, lds, A.ctx->stream, ev_start, ev_stop, 0, da, A.dia_win, x_dev, \
                                   y_dev, nloc, nblocks, e);                                                                \
         else                                                                                                               \
-            hipLaunchKernelGGL((k_spmv_dia_win<E, G, false, W>), grid, block, lds, A.ctx->stream, da, A.dia_win, x_dev, y_dev, nloc, nblocks, e); \
+            hipLaunchKernelGGL((k_spmv_dia_win<E, G, W>), grid, block, lds, A.ctx->stream, da, A.dia_win, x_dev, y_dev, nloc, nblocks, e); \
     } while (0)
 #define MISPEC_DIA_WIN(E, G)              \
     do                                    \
@@ -1145,30 +1178,7 @@ void launch_spmv_raw(const mispec_csr& A, const double* x_dev, double* y_dev, co
         else                         \
             MISPEC_DIA_WIN(E, 4);    \
     } while (0)
-            if (epi && e.scale_state)
-            {
-                MISPEC_REQUIRE(block_count == all_blocks && A.row_begin == 0, "SpMV: the fused step start needs the whole unsharded matrix");
-#define MISPEC_DIA_WIN_FUSED(G)                                                                                                       \
-    do                                                                                                                                \
-    {                                                                                                                                 \
-        if (ev_start && ev_stop)                                                                                                      \
-            hipExtLaunchKernelGGL((k_spmv_dia_win<true, G, true>), grid, block, lds, A.ctx->stream, ev_start, ev_stop, 0, da, A.dia_win, \
-                                  x_dev, y_dev, nloc, nblocks, e);                                                                    \
-        else                                                                                                                          \
-            hipLaunchKernelGGL((k_spmv_dia_win<true, G, true>), grid, block, lds, A.ctx->stream, da, A.dia_win, x_dev, y_dev, nloc,   \
-                               nblocks, e);                                                                                           \
-    } while (0)
-                if (ng == 1)
-                    MISPEC_DIA_WIN_FUSED(1);
-                else if (ng == 2)
-                    MISPEC_DIA_WIN_FUSED(2);
-                else if (ng == 3)
-                    MISPEC_DIA_WIN_FUSED(3);
-                else
-                    MISPEC_DIA_WIN_FUSED(4);
-#undef MISPEC_DIA_WIN_FUSED
-            }
-            else if (epi)
+            if (epi)
                 MISPEC_DIA_WIN_G(true);
             else
                 MISPEC_DIA_WIN_G(false);
@@ -1204,31 +1214,23 @@ void launch_spmv_raw(const mispec_csr& A, const double* x_dev, double* y_dev, co
             hipLaunchKernelGGL((K), grid, block, 0, A.ctx->stream, A.rowptr.p, A.colind.p, A.val.p, x_dev, y_dev,    \
                                nloc, nblocks, e, cd);                                                                  \
     } while (0)
-    // up to 16 entries per row on average: the 16 KiB-chunk instantiation (MISPEC_SPMV_SMALL_CHUNK=0/1 overrides).  Measured
-    // in the solver loop: 7 per row (reordered stencil) 0.258 -> 0.215 ms, 15 per row (M-band) 0.413 -> 0.394 ms, stand-alone equal
-    static const int small_knob = getenv("MISPEC_SPMV_SMALL_CHUNK") ? atoi(getenv("MISPEC_SPMV_SMALL_CHUNK")) : -1;
-    const bool small_chunk = !coded && threads == 256 && !nt &&
-                             (small_knob >= 0 ? small_knob != 0 : (double(A.nnz) <= 16.0 * double(nloc)));
-#define MISPEC_SPMV(E, N)                                          \
-    do                                                             \
-    {                                                              \
+    // up to 16 entries per row on average: the 16 KiB-chunk instantiation.  Measured in the solver loop: 7 per row (reordered
+    // stencil) 0.258 -> 0.215 ms, 15 per row (M-band) 0.413 -> 0.394 ms, stand-alone equal
+    const bool small_chunk = !coded && double(A.nnz) <= 16.0 * double(nloc);
+#define MISPEC_SPMV(E)                                                    \
+    do                                                                    \
+    {                                                                     \
         if (small_chunk)                                                  \
             MISPEC_SPMV_LAUNCH((k_spmv_csr_stream<E, false, 256, false, 2>)); \
         else if (coded)                                                   \
-            MISPEC_SPMV_LAUNCH((k_spmv_csr_stream<E, N, 256, true>));     \
-        else if (threads == 128)                                          \
-            MISPEC_SPMV_LAUNCH((k_spmv_csr_stream<E, N, 128, false>));    \
+            MISPEC_SPMV_LAUNCH((k_spmv_csr_stream<E, false, 256, true>)); \
         else                                                              \
-            MISPEC_SPMV_LAUNCH((k_spmv_csr_stream<E, N, 256, false>));    \
+            MISPEC_SPMV_LAUNCH((k_spmv_csr_stream<E, false, 256, false>)); \
     } while (0)
-    if (epi && nt)
-        MISPEC_SPMV(true, true);
-    else if (epi)
-        MISPEC_SPMV(true, false);
-    else if (nt)
-        MISPEC_SPMV(false, true);
+    if (epi)
+        MISPEC_SPMV(true);
     else
-        MISPEC_SPMV(false, false);
+        MISPEC_SPMV(false);
 #undef MISPEC_SPMV
 #undef MISPEC_SPMV_LAUNCH
     MISPEC_HIP(hipGetLastError());
@@ -1276,7 +1278,20 @@ extern "C" int mispec_csr_upload(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols
     return guarded([&] {
         MISPEC_REQUIRE(ctx && out && rowptr_host, "mispec_csr_upload: NULL argument");
         MISPEC_REQUIRE((colind_host && val_host) || rowptr_host[n_rows] == 0, "mispec_csr_upload: NULL arrays");
+        std::fill(g_ingest, g_ingest + 8, 0.0);
+        IngestTimer total(0);
         *out = upload_rows(ctx, n_rows, n_cols, rowptr_host, colind_host, val_host);
+    });
+}
+
+extern "C" int mispec_ingest_threads(void) { return mispec::ingest_threads(); }
+
+extern "C" int mispec_last_ingest_info(double* seconds_out, int count)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(seconds_out && count >= 1 && count <= 8, "mispec_last_ingest_info: bad argument");
+        for (int i = 0; i < count; i++)
+            seconds_out[i] = g_ingest[i];
     });
 }
 
@@ -1307,6 +1322,117 @@ extern "C" int mispec_csr_from_csc(mispec_ctx* ctx, int64_t n_rows, int64_t n_co
     });
 }
 
+namespace {
+// The full symmetric matrix (CSR, rows sorted by column) that one stored triangle defines: what mispec_csr_from_triangle uploads.
+// ci / v are left uninitialised by the allocation (a std::vector would zero-fill 12 bytes per entry on one thread, and fault
+// every page in there): the threads that own the rows touch them first.
+struct MirroredCsr
+{
+    std::vector<int32_t> rp;
+    std::unique_ptr<int32_t[]> ci;
+    std::unique_ptr<double[]> v;
+    int64_t nnz = 0;
+};
+void mirror_triangle(int64_t n, const int32_t* outer, const int32_t* inner, const double* val, bool lower, bool row_major, MirroredCsr& M)
+{
+    std::vector<int32_t>& rp = M.rp;
+        // (r, c) is the matrix position of an entry whatever the storage order; an entry is kept iff it lies in the requested
+        // triangle (selfadjointView<Uplo> ignores the rest).  Row r of the full matrix receives column c, row c column r.
+        //
+        // Host threads: thread t owns the rows [b, e) of the OUTPUT and walks the whole input in storage order, acting only on
+        // entries that land in its rows — so every row is filled in input order (for a sorted triangle that IS ascending column
+        // order: the columns below the diagonal arrive outer by outer, then the diagonal and the mirrored run), with no atomics and
+        // the same bytes whatever the thread count.  The index array is read once per thread (4 B per entry, streamed), a value
+        // only by the owners of its two rows.
+        const int64_t nnz_in = outer[n] - outer[0];
+        const int nt = int(std::max<int64_t>(1, std::min<int64_t>(std::min(ingest_threads(), 32), nnz_in / 262144)));
+        std::vector<char> bad(static_cast<size_t>(nt), 0);
+        rp.assign(size_t(n) + 1, 0);
+        auto walk = [&](int64_t b, int64_t e, char& flag, auto&& fn) {
+            for (int64_t o = 0; o < n; o++)
+                for (int32_t p = outer[o]; p < outer[o + 1]; p++)
+                {
+                    const int64_t in = inner[p];
+                    if (in < 0 || in >= n)
+                    {
+                        flag = 1;
+                        continue;
+                    }
+                    const int64_t r = row_major ? o : in, c = row_major ? in : o;
+                    if (!(lower ? (r >= c) : (r <= c)))
+                        continue;
+                    if (r >= b && r < e)
+                        fn(r, c, p);
+                    if (r != c && c >= b && c < e)
+                        fn(c, r, p);
+                }
+        };
+        parallel_ranges(n, nt, [&](int t, int64_t b, int64_t e) {
+            walk(b, e, bad[size_t(t)], [&](int64_t row, int64_t, int32_t) { rp[size_t(row) + 1]++; });
+        });
+        for (char f : bad)
+            MISPEC_REQUIRE(!f, "mispec_csr_from_triangle: index out of range");
+        for (int64_t i = 0; i < n; i++)
+        {
+            MISPEC_REQUIRE(int64_t(rp[size_t(i) + 1]) + rp[size_t(i)] <= INT32_MAX, "mispec_csr_from_triangle: more than 2^31 - 1 entries");
+            rp[size_t(i) + 1] += rp[size_t(i)];
+        }
+        const int64_t nnz = rp[size_t(n)];
+        M.nnz = nnz;
+        M.ci.reset(new int32_t[size_t(std::max<int64_t>(nnz, 1))]);
+        M.v.reset(new double[size_t(std::max<int64_t>(nnz, 1))]);
+        int32_t* const ci = M.ci.get();
+        double* const v = M.v.get();
+        parallel_ranges(n, nt, [&](int t, int64_t b, int64_t e) {
+            std::vector<int32_t> fill(rp.begin() + b, rp.begin() + e);
+            walk(b, e, bad[size_t(t)], [&](int64_t row, int64_t col, int32_t p) {
+                const int32_t q = fill[size_t(row - b)]++;
+                ci[size_t(q)] = int32_t(col);
+                v[size_t(q)] = val[p];
+            });
+        });
+        // sort every row by column (the SpMV sums in storage order); rows of a sorted triangle are sorted already
+        parallel_ranges(n, ingest_threads(), [&](int, int64_t b, int64_t e) {
+            std::vector<int32_t> perm, tc;
+            std::vector<double> tv;
+            for (int64_t i = b; i < e; i++)
+            {
+                const int32_t s0 = rp[size_t(i)], e0 = rp[size_t(i) + 1];
+                if (e0 - s0 < 2 || std::is_sorted(ci + s0, ci + e0))
+                    continue;
+                perm.resize(size_t(e0 - s0));
+                std::iota(perm.begin(), perm.end(), 0);
+                std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t c) { return ci[size_t(s0 + a)] < ci[size_t(s0 + c)]; });
+                tc.assign(ci + s0, ci + e0);
+                tv.assign(v + s0, v + e0);
+                for (int32_t k = 0; k < e0 - s0; k++)
+                {
+                    ci[size_t(s0 + k)] = tc[size_t(perm[size_t(k)])];
+                    v[size_t(s0 + k)] = tv[size_t(perm[size_t(k)])];
+                }
+            }
+        });
+}
+}  // namespace
+
+// Host-only test hook (no device): the mirrored matrix of a triangle.  rowptr_out: n + 1 entries; colind_out / val_out: capacity
+// entries (2 nnz of the input is always enough); *nnz_out = entries written.
+extern "C" int mispec_mirror_triangle_host(int64_t n, const int32_t* outer, const int32_t* inner, const double* val, char uplo, int row_major,
+                                           int32_t* rowptr_out, int32_t* colind_out, double* val_out, int64_t capacity, int64_t* nnz_out)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(outer && rowptr_out && nnz_out, "mispec_mirror_triangle_host: NULL argument");
+        MISPEC_REQUIRE(uplo == 'L' || uplo == 'U' || uplo == 'l' || uplo == 'u', "mispec_mirror_triangle_host: uplo must be 'L' or 'U'");
+        MirroredCsr M;
+        mirror_triangle(n, outer, inner, val, uplo == 'L' || uplo == 'l', row_major != 0, M);
+        MISPEC_REQUIRE(M.nnz <= capacity, "mispec_mirror_triangle_host: output capacity too small");
+        std::copy(M.rp.begin(), M.rp.end(), rowptr_out);
+        std::copy(M.ci.get(), M.ci.get() + M.nnz, colind_out);
+        std::copy(M.v.get(), M.v.get() + M.nnz, val_out);
+        *nnz_out = M.nnz;
+    });
+}
+
 extern "C" int mispec_csr_from_triangle(mispec_ctx* ctx, int64_t n, const int32_t* outer, const int32_t* inner,
                                         const double* val, char uplo, int row_major, mispec_csr** out)
 {
@@ -1314,63 +1440,14 @@ extern "C" int mispec_csr_from_triangle(mispec_ctx* ctx, int64_t n, const int32_
         MISPEC_REQUIRE(ctx && out && outer, "mispec_csr_from_triangle: NULL argument");
         MISPEC_REQUIRE(uplo == 'L' || uplo == 'U' || uplo == 'l' || uplo == 'u', "mispec_csr_from_triangle: uplo must be 'L' or 'U'");
         const bool lower = (uplo == 'L' || uplo == 'l');
-        // Walk the compressed input; (r, c) is the matrix position whatever the storage order.
-        // Keep the entry iff it lies in the requested triangle (selfadjointView<Uplo> ignores the rest).
-        auto for_each_kept = [&](auto&& fn) {
-            for (int64_t o = 0; o < n; o++)
-                for (int32_t p = outer[o]; p < outer[o + 1]; p++)
-                {
-                    const int64_t in = inner[p];
-                    MISPEC_REQUIRE(in >= 0 && in < n, "mispec_csr_from_triangle: index out of range");
-                    const int64_t r = row_major ? o : in, c = row_major ? in : o;
-                    if (lower ? (r >= c) : (r <= c))
-                        fn(r, c, val[p]);
-                }
-        };
-        std::vector<int32_t> rp(size_t(n) + 1, 0);
-        for_each_kept([&](int64_t r, int64_t c, double) {
-            rp[size_t(r) + 1]++;
-            if (r != c)
-                rp[size_t(c) + 1]++;
-        });
-        for (int64_t i = 0; i < n; i++)
-            rp[size_t(i) + 1] += rp[size_t(i)];
-        const int64_t nnz = rp[size_t(n)];
-        std::vector<int32_t> ci(static_cast<size_t>(nnz));
-        std::vector<double> v(static_cast<size_t>(nnz));
-        std::vector<int32_t> fill(rp.begin(), rp.end() - 1);
-        for_each_kept([&](int64_t r, int64_t c, double a) {
-            int32_t q = fill[size_t(r)]++;
-            ci[size_t(q)] = int32_t(c);
-            v[size_t(q)] = a;
-            if (r != c)
-            {
-                q = fill[size_t(c)]++;
-                ci[size_t(q)] = int32_t(r);
-                v[size_t(q)] = a;
-            }
-        });
-        // sort every row by column (the SpMV sums in storage order)
-        std::vector<int32_t> perm;
-        std::vector<int32_t> tc;
-        std::vector<double> tv;
-        for (int64_t i = 0; i < n; i++)
+        std::fill(g_ingest, g_ingest + 8, 0.0);
+        IngestTimer total(0);
+        MirroredCsr M;
         {
-            const int32_t s = rp[size_t(i)], e = rp[size_t(i) + 1];
-            if (e - s < 2 || std::is_sorted(ci.begin() + s, ci.begin() + e))
-                continue;
-            perm.resize(size_t(e - s));
-            std::iota(perm.begin(), perm.end(), 0);
-            std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) { return ci[size_t(s + a)] < ci[size_t(s + b)]; });
-            tc.assign(ci.begin() + s, ci.begin() + e);
-            tv.assign(v.begin() + s, v.begin() + e);
-            for (int32_t k = 0; k < e - s; k++)
-            {
-                ci[size_t(s + k)] = tc[size_t(perm[size_t(k)])];
-                v[size_t(s + k)] = tv[size_t(perm[size_t(k)])];
-            }
+            IngestTimer timer(1);
+            mirror_triangle(n, outer, inner, val, lower, row_major != 0, M);
         }
-        *out = upload_rows(ctx, n, n, rp.data(), ci.data(), v.data(), true, true);
+        *out = upload_rows(ctx, n, n, M.rp.data(), M.ci.get(), M.v.get(), true, true);
     });
 }
 
@@ -1410,7 +1487,7 @@ extern "C" int mispec_csr_synth_band(mispec_ctx* ctx, int64_t n, uint64_t seed, 
             alloc_entries(*A, band_prefix(spec, n, e) - base);
             A->rowptr.alloc(size_t(nloc) + 1);
             std::vector<int32_t> dict;
-            if (spmv_codes_enabled() && A->nnz > 0)
+            if (A->nnz > 0)
             {
                 alloc_codes(*A);
                 dict.assign(offs.begin(), offs.end());
@@ -1454,7 +1531,7 @@ extern "C" int64_t mispec_csr_local_nnz(const mispec_csr* A) { return A ? A->nnz
 int mispec_csr::spmv_format() const
 {
     const bool blocks256 = spmv_rows_per_block() == 256;
-    const bool can_codes = ndict > 0 && blocks256 && spmv_codes_enabled();
+    const bool can_codes = ndict > 0 && blocks256;
     const bool can_dia = ndia > 0 && blocks256;
     const bool can_tiles = tiles.present() && blocks256;
     if (forced_format == 3)
@@ -1474,7 +1551,7 @@ int mispec_csr::spmv_format() const
 
 extern "C" int mispec_csr_offset_codes(const mispec_csr* A)
 {
-    return A && A->use_codes && A->forced_format != 0 && spmv_codes_enabled() && spmv_rows_per_block() == 256 ? A->ndict : 0;
+    return A && A->use_codes && A->forced_format != 0 ? A->ndict : 0;
 }
 extern "C" int mispec_csr_spmv_format(const mispec_csr* A) { return A ? A->spmv_format() : 0; }
 extern "C" int mispec_csr_set_spmv_format(mispec_csr* A, int format)
@@ -1498,7 +1575,7 @@ extern "C" double mispec_csr_spmv_bytes(const mispec_csr* A, int stored)
     return stored ? A->stored_bytes() : A->algorithmic_bytes();
 }
 
-extern "C" int mispec_csr_tiles_info(const mispec_csr* A, int64_t* segments, int64_t* entries, int64_t* padding, int* sync_period)
+extern "C" int mispec_csr_tiles_info(const mispec_csr* A, int64_t* segments, int64_t* entries, int64_t* padding, int* two_phase)
 {
     return guarded([&] {
         MISPEC_REQUIRE(A, "mispec_csr_tiles_info: NULL argument");
@@ -1508,8 +1585,8 @@ extern "C" int mispec_csr_tiles_info(const mispec_csr* A, int64_t* segments, int
             *entries = A->tiles.entries;
         if (padding)
             *padding = A->tiles.padding;
-        if (sync_period)
-            *sync_period = A->tiles.sync_period;
+        if (two_phase)
+            *two_phase = A->tiles.two_phase ? 1 : 0;
     });
 }
 

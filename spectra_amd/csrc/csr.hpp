@@ -73,9 +73,16 @@ struct mispec_csr
     {
         if (format == 2)
             return 8.0 * double(ndia) * double(local_rows()) + 8.0 * double(n_cols) + 8.0 * double(local_rows());
-        if (format == 3)  // 12 bytes per stored entry (padding included) + the chunk table; x counted once like everywhere
-            return 12.0 * double(tiles.entries) + 8.0 * double(tiles.nchunks) + 12.0 * double(tiles.nseg) + 8.0 * double(n_cols) +
+        if (format == 3)
+        {
+            // one-phase: 12 bytes per stored entry (padding included) + the chunk table; x counted once like everywhere.
+            // two-phase: value 8 + column 2 read and product 8 written by phase 1, product 8 + row/run 2 read by phase 2 = 28 per
+            // entry, the chunk table read by both (+ 12 bytes per chunk for phase 1's order and absolute offsets)
+            const double per_entry = tiles.two_phase ? 28.0 : 12.0;
+            const double per_chunk = tiles.two_phase ? 28.0 : 8.0;
+            return per_entry * double(tiles.entries) + per_chunk * double(tiles.nchunks) + 12.0 * double(tiles.nseg) + 8.0 * double(n_cols) +
                    8.0 * double(local_rows());
+        }
         const double per_entry = format == 1 ? 9.0 : 12.0;
         return per_entry * double(nnz) + 4.0 * double(local_rows() + 1) + 8.0 * double(n_cols) + 8.0 * double(local_rows());
     }
@@ -98,24 +105,8 @@ struct SpmvEpilogue
     const int* status = nullptr;      // if set, the launch is a no-op unless *status == 0
     double* partials = nullptr;       // one double per block, deterministic second stage elsewhere
     int first_block = 0;              // set by the launcher: first 256-row block this launch covers
-    // Fused start of a device-driven Lanczos step (diagonal storage with x windows only; fac.hip decides): the input of the
-    // product is f / beta with beta read from the step state — x_dev points to f —, the normalised vector is written to
-    // v_out (the new basis column, Lanczos.h:106), H(i,i-1) = beta (:127-128) and the beta < sqrt(eps) stop of
-    // k_scale_step are taken here, and the <v, w> partials use the same f / beta.  Saves the separate scaling pass and the
-    // second read of v (2 x 8n bytes per step).
-    void* scale_state = nullptr;      // StepState* (krylov.hpp)
-    double* v_out = nullptr;
-    int scale_step = 0;
-    double scale_eps_sqrt = 0.0;
-    int late_loads = 0;               // set by the launcher (MISPEC_DIA_LATE_EPILOGUE=1): read v_prev / v only after the row sums
 };
-// true when launch_spmv_raw(A, ...) with an epilogue that carries scale_state would be honoured (else the caller must scale itself)
-bool spmv_can_fuse_scale(const ::mispec_csr& A);
-
-// MISPEC_SPMV_CODES=0 turns the offset-coded index format off (plain int32 column indices everywhere).
-bool spmv_codes_enabled();
-
-// Rows per SpMV workgroup (one thread per row in the reduction phase): 256, or 128 with MISPEC_SPMV_ROWS=128.
+// Rows per SpMV workgroup (one thread per row in the reduction phase)
 int spmv_rows_per_block();
 inline int spmv_num_blocks(int64_t local_rows)
 {

@@ -12,13 +12,59 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <condition_variable>
+#include <exception>
+#include <thread>
 #include <cstring>
 #include <mutex>
 
 namespace mispec {
 static thread_local std::string g_last_error;
 void set_last_error(const std::string& msg) { g_last_error = msg; }
+
+int ingest_threads()
+{
+    static const int n = [] {
+        const unsigned hw = std::thread::hardware_concurrency();
+        return int(std::min(64u, std::max(1u, hw)));
+    }();
+    return n;
+}
+
+void parallel_ranges(int64_t n, int parts, const std::function<void(int, int64_t, int64_t)>& fn)
+{
+    if (n <= 0)
+        return;
+    parts = int(std::max<int64_t>(1, std::min<int64_t>(parts, n)));
+    if (parts == 1)
+    {
+        fn(0, 0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    std::vector<std::exception_ptr> err(static_cast<size_t>(parts));
+    th.reserve(static_cast<size_t>(parts));
+    for (int t = 0; t < parts; t++)
+    {
+        const int64_t b = n * t / parts, e = n * (t + 1) / parts;
+        th.emplace_back([&, t, b, e] {
+            try
+            {
+                fn(t, b, e);
+            }
+            catch (...)
+            {
+                err[size_t(t)] = std::current_exception();
+            }
+        });
+    }
+    for (auto& t : th)
+        t.join();
+    for (auto& e : err)
+        if (e)
+            std::rethrow_exception(e);
+}
 }  // namespace mispec
 
 using namespace mispec;

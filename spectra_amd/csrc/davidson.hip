@@ -25,6 +25,7 @@
 using namespace mispec;
 
 namespace {
+constexpr int kDavidsonMaxCols = 256;  // search-space columns held on the device (the projected problem is solved densely on the host)
 
 constexpr int kThreads = 256;
 
@@ -239,10 +240,10 @@ void check_sizes(mispec_davidson& S)
     // The device search space holds 128 vectors.  A larger maximum (the reference's default is 10 * nev) is lowered to what
     // fits — the solver then restarts earlier, which changes the iteration count, not the result; a space that cannot even
     // hold the initial vectors plus one correction block is an error.
-    MISPEC_REQUIRE(S.init_size + S.corr_size <= kMaxCols,
+    MISPEC_REQUIRE(S.init_size + S.corr_size <= kDavidsonMaxCols,
                    "DavidsonSymEigsSolver: the device search space holds at most 128 vectors (initial space + correction size <= 256)");
-    if (S.max_size + S.corr_size > kMaxCols)
-        S.max_size = kMaxCols - S.corr_size;
+    if (S.max_size + S.corr_size > kDavidsonMaxCols)
+        S.max_size = kDavidsonMaxCols - S.corr_size;
     MISPEC_REQUIRE(S.init_size >= S.nev && S.corr_size <= S.init_size,
                    "DavidsonSymEigsSolver: the initial search space must hold at least nev vectors and the correction block");
 }

@@ -82,7 +82,6 @@ struct mispec_fac
 
     DevBuf<double> mid;  // product operator: A x
     DevBuf<double> bx;
-    DevBuf<double> V2;   // second basis buffer of the out-of-place V <- V Q (MISPEC_VQ_OOP=1)
     DevBuf<double> V, f, w, tmp, xfull, X, partials, alpha_partials, red, Qdev, d_diag, d_subd, d_evals, d_evecs, d_Y, gmax;
     DevBuf<int> d_info;
     DevBuf<StepState> d_state;     // device-driven step bookkeeping (krylov.hpp)
@@ -112,7 +111,6 @@ struct mispec_fac
     // The matrix is stored reordered (P A P', reorder.hip) and this factorisation works in that order: start vectors are
     // permuted on the way in, V / f / Ritz vectors on the way out; plain operators only (product, generalized and
     // Cholesky operators use the order-preserving product instead)
-    int fuse_scale_step = 0;  // > 0 while apply_op is to fuse the start of that Lanczos step into the SpMV (csr.hpp SpmvEpilogue)
     bool perm_mode = false;
     bool x_original = false;  // the columns of X have been put back into the caller's order
     DevBuf<double> pscratch;
@@ -516,13 +514,6 @@ void apply_op(mispec_fac& F, const double* x_loc, double* y_loc, bool lanczos_ep
             epi.h_prev_dev = h_prev_dev;
             epi.status = status;
             epi.partials = F.alpha_partials.p;
-            if (F.fuse_scale_step > 0)
-            {
-                epi.scale_state = F.d_state.p;
-                epi.v_out = F.col(F.fuse_scale_step);
-                epi.scale_step = F.fuse_scale_step;
-                epi.scale_eps_sqrt = std::sqrt(kEps);
-            }
             if (overlap)
                 overlapped_spmv(F, *last, x, y_loc, &epi, e0, e1);
             else
@@ -917,17 +908,11 @@ void lanczos_step_device(mispec_fac& F, int i)
     const int kSpeculativeCorrections = speculative_corrections(F);
     StepState* st = F.d_state.p;
     double* v = F.col(i);
-    // With the diagonal-storage SpMV the start of the step (v = f / beta, H(i,i-1) = beta, the small-beta stop) can ride on the
-    // product itself when MISPEC_FUSE_SCALE=1: x is read as f / beta, v is written by the same launch (default: k_scale_step)
-    const bool fuse = F.A && !F.A2 && !F.Bop && !F.Chol && !F.sharded() && !F.perm_mode && spmv_can_fuse_scale(*F.A);
-    if (!fuse)
     {
         Timed t(F, FAM_SCALE);
         launch_scale_step(*F.ctx, F.f.p, v, F.ldv, st, i, std::sqrt(kEps));
     }
-    F.fuse_scale_step = fuse ? i : 0;
-    apply_op(F, fuse ? F.f.p : v, F.w.p, true, F.col(i - 1), 0.0, &st->subd[i - 1], &st->status);
-    F.fuse_scale_step = 0;
+    apply_op(F, v, F.w.p, true, F.col(i - 1), 0.0, &st->subd[i - 1], &st->status);
 
     const int i1 = i + 1;
     FinishArgs fin;
@@ -1298,20 +1283,6 @@ void compress_basis(mispec_fac& F, int p)
     const int m = F.m;
     if (m <= kPanelCols)
     {
-        // MISPEC_VQ_OOP=1: write V Q into a second basis buffer and swap the two (the columns beyond p are rewritten by the
-        // factorisation before anything reads them) instead of updating V in place — reads and writes then never share a line
-        static const bool oop = getenv("MISPEC_VQ_OOP") && atoi(getenv("MISPEC_VQ_OOP")) != 0;
-        if (oop)
-        {
-            if (F.V2.n != F.V.n)
-            {
-                F.V2.alloc(F.V.n);
-                MISPEC_HIP(hipMemsetAsync(F.V2.p, 0, F.V2.n * sizeof(double), F.stream()));
-            }
-            launch_vq(*F.ctx, F.V.p, F.ldv, m, F.Qdev.p, m, p, F.V2.p, F.ldv, F.nloc);
-            F.V.swap(F.V2);
-            return;
-        }
         launch_vq(*F.ctx, F.V.p, F.ldv, m, F.Qdev.p, m, p, F.V.p, F.ldv, F.nloc);
         return;
     }
@@ -1359,7 +1330,7 @@ int fac_create_impl(mispec_ctx* ctx, const mispec_csr* A, const mispec_symshift*
             MISPEC_REQUIRE(D->ctx == ctx && D->rows == n && D->cols == n, "mispec_fac_create_dense: matrix belongs to another context / is not n x n");
         MISPEC_REQUIRE(n >= 1, "mispec_fac_create: n must be positive");
         MISPEC_REQUIRE(ncv >= 1 && ncv <= n, "mispec_fac_create: need 1 <= ncv <= n");
-        MISPEC_REQUIRE(ncv <= kMaxCols, "mispec_fac_create: the device factorisation holds at most 256 basis vectors (ncv <= 256)");
+        MISPEC_REQUIRE(ncv <= kMaxCols, "mispec_fac_create: the device factorisation holds at most 1024 basis vectors (ncv <= 1024)");
         if (Bop)
         {
             MISPEC_REQUIRE(A && !A2 && symmetric, "mispec_fac_create_geigs_reginv: needs a symmetric device matrix A");
@@ -1842,8 +1813,8 @@ extern "C" int mispec_fac_restart_sym(mispec_fac* fac, const double* shifts_host
         // Where the (m-k) shifted QR sweeps run.  One GPU: on the device (k_restart_sym*, 0.24 ms, < 1 % of a restart
         // cycle).  Row-sharded: every rank would repeat the same serial 0.24 ms while its share of the n-sized work
         // shrinks with the rank count, so the sweeps run on the host core (same routine, internal/SmallDense.h,
-        // ~40 us) and only Q (m x m) is uploaded.  MISPEC_RESTART=host|device overrides.
-        static const char* where = getenv("MISPEC_RESTART");
+        // ~40 us) and only Q (m x m) is uploaded.  MISPEC_SMALL=host|device overrides (the same knob as for the Ritz pairs).
+        static const char* where = getenv("MISPEC_SMALL");
         // m > 128: the restart kernels keep the m x m Q in LDS and stop at 128 columns -> host
         const bool on_host = m > kMaxSmallDim || (where ? std::string(where) == "host" : (F.sharded() && F.ctx->world() > 1));
         if (on_host)

@@ -584,8 +584,8 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restri
     __shared__ double sh[kPartialLd];
     const int tid = threadIdx.x, lane = tid & 63;
     const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid < kPartialLd)
-        sh[tid] = 0.0;
+    for (int t = tid; t < kPartialLd; t += 1024)
+        sh[t] = 0.0;
     __syncthreads();
     // column passes of 48 (wave g: c0+g, c0+g+16, c0+g+32); the two scalar slots ride in the last pass when its
     // positions 46/47 are free, otherwise in a pass of their own
@@ -616,8 +616,8 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restri
     if (tid == 0)
         finish_record(sh, ncol, fin);
     __syncthreads();
-    if (tid < kPartialLd)
-        red[tid] = sh[tid];
+    for (int t = tid; t < kPartialLd; t += 1024)
+        red[t] = sh[t];
 }
 
 __global__ void k_finish(double* red, int ncol, FinishArgs fin)
@@ -1022,13 +1022,6 @@ __global__ __launch_bounds__(kThreads) void k_simple_random(double* __restrict__
     }
 }
 
-// Tuning knob read once from the environment (0 = use the built-in default).
-int env_int(const char* name)
-{
-    const char* e = getenv(name);
-    return e ? atoi(e) : 0;
-}
-
 int persistent_grid(const mispec_ctx& ctx, int64_t work_items, int per_cu)
 {
     int64_t g = int64_t(ctx.num_cu) * per_cu;
@@ -1039,16 +1032,13 @@ int persistent_grid(const mispec_ctx& ctx, int64_t work_items, int per_cu)
     return int(g);
 }
 
-int env_int(const char* name);
-
 template <int MODE>
 void launch_orth_mode(const mispec_ctx& ctx, const OrthArgs& a, int grid)
 {
     // One instantiation per slot count (columns per wave, ceil(ncol / 4)): a wave then issues exactly the
     // loads it needs — with a coarser set of sizes the surplus slots re-read column 0 and spend L1/L2 bandwidth.
     const int slots = (a.ncol + 3) / 4;
-    static const int rknob = env_int("MISPEC_ORTH_R");
-    const bool two = (rknob != 1) && slots <= 10;
+    const bool two = slots <= 10;
     const dim3 g(static_cast<unsigned>(grid)), b(kThreads);
     switch (slots)
     {
@@ -1085,8 +1075,7 @@ void launch_orth_mode(const mispec_ctx& ctx, const OrthArgs& a, int grid)
 void launch_orth_lagged(const mispec_ctx& ctx, const OrthArgs& a, int grid)
 {
     const int slots = (a.ncol + 3) / 4;
-    static const int rknob = env_int("MISPEC_ORTH_R");
-    const bool two = (rknob != 1) && slots <= 10;
+    const bool two = slots <= 10;
     const dim3 g(static_cast<unsigned>(grid)), b(kThreads);
     switch (slots)
     {
@@ -1127,8 +1116,7 @@ namespace mispec {
 namespace {
 int orth_tile_rows(int ncol)
 {
-    static const int rknob = env_int("MISPEC_ORTH_R");
-    return kTileRows * ((rknob != 1 && (ncol + 3) / 4 <= 10) ? 2 : 1);
+    return kTileRows * (((ncol + 3) / 4 <= 10) ? 2 : 1);
 }
 
 // one launch over at most kPanelCols columns; grid == 0: choose it from the tile count
@@ -1138,8 +1126,7 @@ int launch_orth_panel(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a, i
     {
         const int rows = orth_tile_rows(a.ncol);
         const int64_t ntiles = (a.n + rows - 1) / rows;
-        static const int knob = env_int("MISPEC_ORTH_BLOCKS_PER_CU");
-        grid = persistent_grid(ctx, ntiles, knob > 0 ? knob : 4);
+        grid = persistent_grid(ctx, ntiles, 4);  // 3 and 6 workgroups per CU measured slower (profiles/r05b_ab_*)
     }
     MISPEC_REQUIRE(a.pstride >= grid, "orth kernel: partial-record stride smaller than the grid");
     switch (mode)
@@ -1174,7 +1161,7 @@ int launch_orth_panel(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a, i
 //                follow on the finished dst.  V is read 1.5 times instead of once — the price of ncv > 64.
 int launch_orth(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a)
 {
-    MISPEC_REQUIRE(a.ncol >= 0 && a.ncol <= kMaxCols, "orth kernel: more than 256 basis columns");
+    MISPEC_REQUIRE(a.ncol >= 0 && a.ncol <= kMaxCols, "orth kernel: more than 1024 basis columns");
     MISPEC_REQUIRE(mode != ORTH_LAGGED || (a.ncol >= 1 && a.ncol < kPanelCols), "one-sweep orth kernel: needs 1 <= columns <= 63");
     if (a.ncol <= kPanelCols)
     {
@@ -1186,8 +1173,7 @@ int launch_orth(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a)
     const int npan = (a.ncol + kPanelCols - 1) / kPanelCols;
     // all panels must leave the same number of records: one grid for all, valid for the coarsest tiling
     const int64_t ntiles = (a.n + 2 * kTileRows - 1) / (2 * kTileRows);
-    static const int knob = env_int("MISPEC_ORTH_BLOCKS_PER_CU");
-    const int grid = persistent_grid(ctx, ntiles, knob > 0 ? knob : 4);
+    const int grid = persistent_grid(ctx, ntiles, 4);
     auto panel = [&](int q) {
         OrthArgs b = a;
         b.col0 = q * kPanelCols;
@@ -1321,8 +1307,7 @@ void launch_vq_panel(const mispec_ctx& ctx, const double* V, int64_t ldv, int m,
     {
         constexpr int NB = 2;
         const int64_t ntiles_m = (n + 4 * 32 * NB - 1) / (4 * 32 * NB);
-        static const int knob_m = env_int("MISPEC_VQ_BLOCKS_PER_CU");
-        const int grid_m = persistent_grid(ctx, ntiles_m, knob_m > 0 ? knob_m : 4);
+        const int grid_m = persistent_grid(ctx, ntiles_m, 4);
         const size_t lds_m = size_t((m + 3) / 4) * size_t((p + 15) / 16) * 64 * sizeof(double);
         const dim3 gm(static_cast<unsigned>(grid_m)), bm(kThreads);
 #define MISPEC_VQM(KB, MB)                                                                                                  \
@@ -1344,8 +1329,7 @@ void launch_vq_panel(const mispec_ctx& ctx, const double* V, int64_t ldv, int m,
     const int slots = (p + 3) / 4;
     const int maxs = slots <= 4 ? 4 : slots <= 8 ? 8 : slots <= 12 ? 12 : 16;
     const size_t lds = (size_t(m) * kTileRows + size_t(m) * 4 * maxs) * sizeof(double);
-    static const int vq_knob = env_int("MISPEC_VQ_BLOCKS_PER_CU");
-    const int grid = persistent_grid(ctx, ntiles, vq_knob > 0 ? vq_knob : 3);
+    const int grid = persistent_grid(ctx, ntiles, 3);
     const dim3 g(static_cast<unsigned>(grid)), b(kThreads);
 #define MISPEC_VQ(S)                                                                                                   \
     do                                                                                                                 \
@@ -1372,7 +1356,7 @@ void launch_vq_panel(const mispec_ctx& ctx, const double* V, int64_t ldv, int m,
 void launch_vq(const mispec_ctx& ctx, const double* V, int64_t ldv, int m, const double* Q, int ldq, int p, double* X,
                int64_t ldx, int64_t n)
 {
-    MISPEC_REQUIRE(m >= 1 && m <= kMaxCols && p >= 1 && p <= kMaxCols, "V*Q kernel: needs 1 <= m, p <= 256");
+    MISPEC_REQUIRE(m >= 1 && m <= kMaxCols && p >= 1 && p <= kMaxCols, "V*Q kernel: needs 1 <= m, p <= 1024");
     if (m <= kPanelCols && p <= kPanelCols)
     {
         launch_vq_panel(ctx, V, ldv, m, Q, ldq, p, X, ldx, n, 0);

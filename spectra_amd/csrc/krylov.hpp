@@ -6,7 +6,7 @@ namespace mispec {
 
 // Per-workgroup partial record (kPartialLd slots) written by the orthogonalisation kernels — stored
 // slot-major so that the summing kernel reads contiguously — and summed by launch_reduce_partials in a fixed order (deterministic: no floating-point atomics anywhere).
-constexpr int kMaxCols = 256;    // basis columns of a factorisation; beyond kMaxSmallDim (128) the m x m restart work runs on the host
+constexpr int kMaxCols = 1024;   // basis columns of a factorisation (ncv); beyond kMaxSmallDim (128) the m x m restart work runs on the host
 constexpr int kPanelCols = 64;   // basis columns handled by ONE orthogonalisation / V*Q launch; wider bases go in panels
 constexpr int kPartialLd = kMaxCols + 8;
 constexpr int kSlotBeta2 = kMaxCols;       // sum f^2

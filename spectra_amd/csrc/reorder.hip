@@ -139,18 +139,26 @@ void bfs(const Graph& g, int32_t start, const std::vector<uint8_t>& done, Bfs& s
 
 double far_fraction(int64_t n, const int32_t* rowptr, const int32_t* colind, const int32_t* inv, int64_t window)
 {
-    int64_t far = 0, total = 0;
-    for (int64_t i = 0; i < n; i++)
-    {
-        const int64_t ri = inv ? inv[i] : i;
-        for (int32_t p = rowptr[i]; p < rowptr[i + 1]; p++)
+    const int nt = int(std::max<int64_t>(1, std::min<int64_t>(ingest_threads(), n / 65536)));
+    std::vector<int64_t> far(static_cast<size_t>(nt), 0);
+    parallel_ranges(n, nt, [&](int t, int64_t b, int64_t e) {
+        int64_t f = 0;
+        for (int64_t i = b; i < e; i++)
         {
-            const int64_t cj = inv ? inv[colind[p]] : colind[p];
-            far += (std::llabs(cj - ri) > window);
-            total++;
+            const int64_t ri = inv ? inv[i] : i;
+            for (int32_t p = rowptr[i]; p < rowptr[i + 1]; p++)
+            {
+                const int64_t cj = inv ? inv[colind[p]] : colind[p];
+                f += (std::llabs(cj - ri) > window);
+            }
         }
-    }
-    return total ? double(far) / double(total) : 0.0;
+        far[size_t(t)] = f;
+    });
+    int64_t total_far = 0;
+    for (int64_t f : far)
+        total_far += f;
+    const int64_t total = n > 0 ? int64_t(rowptr[n]) - int64_t(rowptr[0]) : 0;
+    return total ? double(total_far) / double(total) : 0.0;
 }
 
 bool rcm_order(int64_t n, const int32_t* rowptr, const int32_t* colind, bool symmetric_pattern, double max_level_fraction,
@@ -257,23 +265,27 @@ void permute_csr(int64_t n, const int32_t* rowptr, const int32_t* colind, const 
     }
     ci.resize(size_t(rp[size_t(n)]));
     v.resize(size_t(rp[size_t(n)]));
-    std::vector<std::pair<int32_t, double>> row;
-    for (int64_t i = 0; i < n; i++)
-    {
-        const int32_t o = perm[size_t(i)];
-        row.clear();
-        for (int32_t p = rowptr[o]; p < rowptr[o + 1]; p++)
-            row.emplace_back(inv[size_t(colind[p])], val[p]);
-        // ascending new column; equal columns (duplicates) keep their storage order
-        std::stable_sort(row.begin(), row.end(), [](const std::pair<int32_t, double>& a, const std::pair<int32_t, double>& b) { return a.first < b.first; });
-        int32_t q = rp[size_t(i)];
-        for (const auto& e : row)
+    const int nt = int(std::max<int64_t>(1, std::min<int64_t>(ingest_threads(), n / 16384)));
+    parallel_ranges(n, nt, [&](int, int64_t b, int64_t e) {
+        std::vector<std::pair<int32_t, double>> row;
+        for (int64_t i = b; i < e; i++)
         {
-            ci[size_t(q)] = e.first;
-            v[size_t(q)] = e.second;
-            q++;
+            const int32_t o = perm[size_t(i)];
+            row.clear();
+            for (int32_t p = rowptr[o]; p < rowptr[o + 1]; p++)
+                row.emplace_back(inv[size_t(colind[p])], val[p]);
+            // ascending new column; equal columns (duplicates) keep their storage order
+            std::stable_sort(row.begin(), row.end(),
+                             [](const std::pair<int32_t, double>& a, const std::pair<int32_t, double>& c) { return a.first < c.first; });
+            int32_t q = rp[size_t(i)];
+            for (const auto& en : row)
+            {
+                ci[size_t(q)] = en.first;
+                v[size_t(q)] = en.second;
+                q++;
+            }
         }
-    }
+    });
 }
 
 }  // namespace mispec

@@ -992,10 +992,9 @@ thread_local int g_chunk_bias = 0;
 thread_local bool g_single_chunk = false;
 constexpr int64_t kPivotedLimit = 8192;
 
-// chunk length and chunk count of a level
-// MISPEC_SHIFT_CHUNK="L_big,L_small,N_switch,N_dense": chunk length for levels with more than N_switch rows / for smaller
-// levels, and the size below which a level is inverted densely.  The solve kernels run one lane per chunk, so a level needs
-// many chunks to pull bandwidth: short chunks, paid for with more separator rows (the next level) — measured in profiles/.
+// chunk length and chunk count of a level: 128-row chunks, levels of at most 2048 rows inverted densely.  The solve kernels run
+// one lane per chunk, so a level needs many chunks to pull bandwidth: short chunks, paid for with more separator rows (the next
+// level).  Other lengths measured slower (profiles/r03j_*: 0.137 / 0.182 / 0.205 ms per solve at 160 / 192 / 256 rows, 0.139 at 96).
 struct ChunkPlan
 {
     int64_t big = 128, small = 128, n_switch = 0, n_dense = 2048;
@@ -1004,19 +1003,6 @@ const ChunkPlan& chunk_plan()
 {
     static const ChunkPlan plan = [] {
         ChunkPlan c;
-        if (const char* e = getenv("MISPEC_SHIFT_CHUNK"))
-        {
-            long long a = 0, b2 = 0, c2 = 0, d = 0;
-            const int got = sscanf(e, "%lld,%lld,%lld,%lld", &a, &b2, &c2, &d);
-            if (got >= 1 && a >= 8)
-                c.big = c.small = a;
-            if (got >= 2 && b2 >= 8)
-                c.small = b2;
-            if (got >= 3 && c2 >= 0)
-                c.n_switch = c2;
-            if (got >= 4 && d >= 64 && d <= 8192)
-                c.n_dense = d;
-        }
         return c;
     }();
     return plan;
@@ -1034,10 +1020,38 @@ void plan_level(int64_t N, int b, int64_t& L, int64_t& P)
     }
 }
 
-// whether a level of this shape is factored by k_chunk_factor (MISPEC_SHIFT_FACTOR=host keeps everything on the host)
+// MISPEC_SHIFT="key=value,...": ONE test hook for the kernel variants of the banded solve, so that tests can require that they
+// agree (tests/test_gpu_shift.py): lds=0 (always the general sweep kernel), batch=8|16|32 (rows per batch of the staged sweeps),
+// lanes=8|16|32|64 (chunks per wavefront), block_inverse=<MiB> (size limit of the explicit chunk inverses; 0: sweeps everywhere),
+// factor=host (the top level factored on the host).  Not a tuning interface: the defaults are the measured best.
+long long shift_option(const char* key, long long dflt)
+{
+    static const std::string spec = getenv("MISPEC_SHIFT") ? getenv("MISPEC_SHIFT") : "";
+    const std::string k = std::string(key) + "=";
+    size_t pos = 0;
+    while (pos < spec.size())
+    {
+        size_t end = spec.find(',', pos);
+        if (end == std::string::npos)
+            end = spec.size();
+        if (spec.compare(pos, k.size(), k) == 0)
+        {
+            const std::string v = spec.substr(pos + k.size(), end - pos - k.size());
+            if (v == "host")
+                return 1;
+            if (v == "device")
+                return 0;
+            return atoll(v.c_str());
+        }
+        pos = end + 1;
+    }
+    return dflt;
+}
+
+// whether a level of this shape is factored by k_chunk_factor (MISPEC_SHIFT=factor=host keeps everything on the host)
 bool factored_on_device(int64_t N, int b)
 {
-    static const bool host_only = getenv("MISPEC_SHIFT_FACTOR") && std::string(getenv("MISPEC_SHIFT_FACTOR")) == "host";
+    static const bool host_only = shift_option("factor", 0) != 0;
     int64_t L, P;
     plan_level(N, b, L, P);
     return P > 1 && b <= 8 && !host_only;
@@ -1045,10 +1059,10 @@ bool factored_on_device(int64_t N, int b)
 
 // Whether the chunk interiors of a partitioned level are also inverted explicitly (k_chunk_inverse / k_block_gemv): levels
 // whose chunks would not fill the device with one lane each, as long as the blocks stay small next to the matrix
-// (MISPEC_SHIFT_BLOCK_INVERSE=0 keeps the sweeps; =<MiB> moves the size limit, default 256 MiB per level).
+// (MISPEC_SHIFT=block_inverse=0 keeps the sweeps; =<MiB> moves the size limit, default 256 MiB per level).
 bool wants_block_inverse(int64_t P, int64_t mmax, int b)
 {
-    static const long long limit_mib = getenv("MISPEC_SHIFT_BLOCK_INVERSE") ? atoll(getenv("MISPEC_SHIFT_BLOCK_INVERSE")) : 256;
+    static const long long limit_mib = shift_option("block_inverse", 256);
     if (limit_mib <= 0 || mmax > 256 || b > 16)
         return false;
     const double bytes = double(P) * double(mmax) * double(mmax) * 8.0;
@@ -1421,14 +1435,14 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
     }
 }
 
-// Chunks per wavefront of the solve kernels (MISPEC_SHIFT_LANES = 64 | 32 | 16 | 8).  One lane per chunk makes a level with P
+// Chunks per wavefront of the solve kernels (test hook MISPEC_SHIFT=lanes=64|32|16|8).  One lane per chunk makes a level with P
 // chunks run P / 64 wavefronts — 244 at the top level of C5, 6 at the second; fewer chunks per wavefront (the other lanes idle)
 // means more wavefronts in flight, but measured (profiles/r03a_*) 0.265 / 0.276 / 0.278 / 0.464 ms per solve at 64 / 32 / 16 / 8:
 // the sweeps are bound by their dependency chain, not by the number of wavefronts.  A software-pipelined variant (next batch of
 // rows in flight during the recurrence) measured 0.281 against 0.265 ms (profiles/r03b_*) and was removed again.
 int solve_lanes(int64_t P)
 {
-    static const int knob = getenv("MISPEC_SHIFT_LANES") ? atoi(getenv("MISPEC_SHIFT_LANES")) : 0;
+    static const int knob = int(shift_option("lanes", 0));
     if (knob == 64 || knob == 32 || knob == 16 || knob == 8)
         return knob;
     (void) P;
@@ -1442,9 +1456,9 @@ void launch_chunk_solve(const mispec_ctx& ctx, const BandLevel& lev, dim3 grid_u
     const int lanes = solve_lanes(lev.P);
     const dim3 grid(unsigned((lev.P - 1 + lanes - 1) / lanes) + 1);  // + the last chunk's own workgroup
     const bool chol = mode != 0 || u_out != nullptr;
-    // plain solves of a level whose wavefront segments fit the LDS: the staged kernel (MISPEC_SHIFT_LDS=0: always the general one)
-    static const bool lds_off = getenv("MISPEC_SHIFT_LDS") && atoi(getenv("MISPEC_SHIFT_LDS")) == 0;
-    static const int batch = getenv("MISPEC_SHIFT_BATCH") ? atoi(getenv("MISPEC_SHIFT_BATCH")) : 0;
+    // plain solves of a level whose wavefront segments fit the LDS: the staged kernel (MISPEC_SHIFT=lds=0: always the general one)
+    static const bool lds_off = shift_option("lds", 1) == 0;
+    static const int batch = int(shift_option("batch", 0));
     if (!chol && !lds_off && lev.P > 1 && lev.b >= 1 && lev.b <= 8)
     {
         const int U = (batch == 8 || batch == 16 || batch == 32) ? batch : (lev.b <= 4 ? 32 : 16);

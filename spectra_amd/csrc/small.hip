@@ -399,8 +399,7 @@ void launch_tridiag_eigen(const mispec_ctx& ctx, int n, const double* diag, cons
                           int* info)
 {
     MISPEC_REQUIRE(n >= 1 && n <= kMaxSmallDim, "tridiag_eigen kernel: dimension out of range");
-    static const bool generic = getenv("MISPEC_SMALL_GENERIC") && atoi(getenv("MISPEC_SMALL_GENERIC")) != 0;
-    if (n <= 64 && !generic)
+    if (n <= 64)  // one wavefront, register / LDS resident; larger matrices: the LDS-resident generic kernel
     {
         hipLaunchKernelGGL(k_tridiag_eigen_w64, dim3(1), dim3(64), size_t(n) * n * sizeof(double), ctx.stream, n, diag, subd, evals,
                            evecs, info);
@@ -422,8 +421,7 @@ void launch_restart_sym(const mispec_ctx& ctx, int m, double* diag, double* subd
     ShiftList sl;
     for (int i = 0; i < nshift; i++)
         sl.mu[i] = shifts_host[i];
-    static const bool generic = getenv("MISPEC_SMALL_GENERIC") && atoi(getenv("MISPEC_SMALL_GENERIC")) != 0;
-    if (m <= 64 && !generic)
+    if (m <= 64)
     {
         hipLaunchKernelGGL(k_restart_sym_w64, dim3(1), dim3(64), size_t(m) * m * sizeof(double), ctx.stream, m, diag, subd, sl,
                            nshift, Q);

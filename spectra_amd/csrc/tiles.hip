@@ -32,24 +32,17 @@
 
 namespace mispec {
 
-bool build_tiles(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* colind, const double* val, HostTiles& T)
+namespace {
+// The tiles of segments [s0, s1) appended to `out` (entry offsets of the chunks are relative to their segment's first entry, so
+// pieces built by different threads concatenate without patching).  seg_len / seg_nchunk: entries and chunks of every segment.
+bool build_tiles_range(int64_t s0, int64_t s1, int64_t nrows, int64_t ncb, const int32_t* rowptr, const int32_t* colind, const double* val,
+                       HostTiles& out, std::vector<int64_t>& seg_len, std::vector<int32_t>& seg_nchunk)
 {
-    T = HostTiles{};
-    const int64_t ncb = (ncols + kTileCols - 1) / kTileCols;
-    if (ncb > 65535 || nrows <= 0)
-        return false;
-    const int64_t nseg = (nrows + kTileRows - 1) / kTileRows;
-    T.ncb = ncb;
-    T.seg_entry.assign(size_t(nseg) + 1, 0);
-    T.seg_chunk.assign(size_t(nseg) + 1, 0);
-    const int64_t nnz = rowptr[nrows] - rowptr[0];
-    T.val.reserve(size_t(nnz + nnz / 32));
-    T.idx.reserve(size_t(nnz + nnz / 32));
-    std::vector<int64_t> count(static_cast<size_t>(ncb)), start(size_t(ncb) + 1);
+    std::vector<int64_t> count(static_cast<size_t>(ncb)), start(size_t(ncb) + 1), fill(static_cast<size_t>(ncb));
     std::vector<uint32_t> tidx;  // entries of the segment, bucketed by tile (row-major inside a tile)
     std::vector<double> tval;
     std::vector<std::pair<int64_t, int64_t>> groups;  // (first entry, length) of every row's run inside the current tile
-    for (int64_t s = 0; s < nseg; s++)
+    for (int64_t s = s0; s < s1; s++)
     {
         const int64_t r0 = s * kTileRows, r1 = std::min<int64_t>(r0 + kTileRows, nrows);
         std::fill(count.begin(), count.end(), 0);
@@ -66,7 +59,7 @@ bool build_tiles(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int3
         const int64_t seg_nnz = start[size_t(ncb)];
         tidx.resize(size_t(seg_nnz));
         tval.resize(size_t(seg_nnz));
-        std::vector<int64_t> fill(start.begin(), start.end() - 1);
+        std::copy(start.begin(), start.end() - 1, fill.begin());
         for (int64_t r = r0; r < r1; r++)
         {
             int32_t p = rowptr[r];
@@ -88,9 +81,8 @@ bool build_tiles(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int3
             }
         }
         // emit: chunks of at most kTileChunk entries of one tile; a run never straddles a 64-entry group of its chunk
-        const int64_t seg_first = int64_t(T.val.size());
-        T.seg_entry[size_t(s)] = seg_first;
-        T.seg_chunk[size_t(s)] = int32_t(T.chunks.size());
+        const int64_t seg_first = int64_t(out.val.size());
+        const size_t chunk_first = out.chunks.size();
         for (int64_t c = 0; c < ncb; c++)
         {
             // A row's entries inside the tile are consecutive.  Pass 0 emits the first (up to) 7 of every row, pass 1 the next
@@ -112,7 +104,7 @@ bool build_tiles(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int3
                 while (gi < groups.size())
                 {
                     TileChunk ch;
-                    ch.offset = int32_t(int64_t(T.val.size()) - seg_first);
+                    ch.offset = int32_t(int64_t(out.val.size()) - seg_first);
                     ch.colblock = uint16_t(c);
                     int cnt = 0;
                     while (gi < groups.size())
@@ -131,20 +123,20 @@ bool build_tiles(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int3
                             break;
                         for (int k = 0; k < pad; k++)
                         {
-                            T.val.push_back(0.0);
-                            T.idx.push_back(kTileSkip);
+                            out.val.push_back(0.0);
+                            out.idx.push_back(kTileSkip);
                         }
-                        T.padding += pad;
+                        out.padding += pad;
                         for (int k = 0; k < run; k++)
                         {
-                            T.val.push_back(tval[size_t(e + k)]);
-                            T.idx.push_back(tidx[size_t(e + k)] | uint32_t(k == 0 ? run : 0));
+                            out.val.push_back(tval[size_t(e + k)]);
+                            out.idx.push_back(tidx[size_t(e + k)] | uint32_t(k == 0 ? run : 0));
                         }
                         cnt += pad + run;
                         gi++;
                     }
                     ch.count = uint16_t(cnt);
-                    T.chunks.push_back(ch);
+                    out.chunks.push_back(ch);
                 }
                 // rows with more entries than the passes so far have emitted stay for the next pass
                 size_t keep = 0;
@@ -154,14 +146,72 @@ bool build_tiles(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int3
                 groups.resize(keep);
             }
         }
+        seg_len[size_t(s)] = int64_t(out.val.size()) - seg_first;
+        seg_nchunk[size_t(s)] = int32_t(out.chunks.size() - chunk_first);
     }
-    T.seg_entry[size_t(nseg)] = int64_t(T.val.size());
-    T.seg_chunk[size_t(nseg)] = int32_t(T.chunks.size());
+    return true;
+}
+}  // namespace
+
+// Segments are independent: the host threads (ingest_threads) build contiguous ranges of them into pieces of their own, which are
+// then concatenated in segment order — the image is the one a single thread builds, byte for byte.
+bool build_tiles(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* colind, const double* val, HostTiles& T)
+{
+    T = HostTiles{};
+    const int64_t ncb = (ncols + kTileCols - 1) / kTileCols;
+    if (ncb > 65535 || nrows <= 0)
+        return false;
+    const int64_t nseg = (nrows + kTileRows - 1) / kTileRows;
+    T.ncb = ncb;
+    std::vector<int64_t> seg_len(static_cast<size_t>(nseg), 0);
+    std::vector<int32_t> seg_nchunk(static_cast<size_t>(nseg), 0);
+    const int nt = int(std::max<int64_t>(1, std::min<int64_t>(ingest_threads(), nseg / 4)));
+    std::vector<HostTiles> piece(static_cast<size_t>(nt));
+    std::vector<char> ok(static_cast<size_t>(nt), 1);
+    parallel_ranges(nseg, nt, [&](int t, int64_t s0, int64_t s1) {
+        const int64_t nnz = rowptr[std::min<int64_t>(s1 * kTileRows, nrows)] - rowptr[s0 * kTileRows];
+        piece[size_t(t)].val.reserve(size_t(nnz + nnz / 32 + 64));
+        piece[size_t(t)].idx.reserve(size_t(nnz + nnz / 32 + 64));
+        ok[size_t(t)] = build_tiles_range(s0, s1, nrows, ncb, rowptr, colind, val, piece[size_t(t)], seg_len, seg_nchunk) ? 1 : 0;
+    });
+    for (char o : ok)
+        if (!o)
+        {
+            T = HostTiles{};
+            return false;
+        }
+    T.seg_entry.assign(size_t(nseg) + 1, 0);
+    T.seg_chunk.assign(size_t(nseg) + 1, 0);
+    for (int64_t s = 0; s < nseg; s++)
+    {
+        T.seg_entry[size_t(s) + 1] = T.seg_entry[size_t(s)] + seg_len[size_t(s)];
+        T.seg_chunk[size_t(s) + 1] = T.seg_chunk[size_t(s)] + seg_nchunk[size_t(s)];
+    }
+    const int64_t total = T.seg_entry[size_t(nseg)];
+    T.val.resize(size_t(total) + kTileSlack);
+    T.idx.resize(size_t(total) + kTileSlack);
+    T.chunks.resize(size_t(T.seg_chunk[size_t(nseg)]));
+    std::vector<int64_t> at(static_cast<size_t>(nt) + 1, 0), cat(static_cast<size_t>(nt) + 1, 0);
+    for (int t = 0; t < nt; t++)
+    {
+        at[size_t(t) + 1] = at[size_t(t)] + int64_t(piece[size_t(t)].val.size());
+        cat[size_t(t) + 1] = cat[size_t(t)] + int64_t(piece[size_t(t)].chunks.size());
+        T.padding += piece[size_t(t)].padding;
+    }
+    parallel_ranges(nt, nt, [&](int, int64_t t0, int64_t t1) {
+        for (int64_t t = t0; t < t1; t++)
+        {
+            const HostTiles& P = piece[size_t(t)];
+            std::copy(P.val.begin(), P.val.end(), T.val.begin() + at[size_t(t)]);
+            std::copy(P.idx.begin(), P.idx.end(), T.idx.begin() + at[size_t(t)]);
+            std::copy(P.chunks.begin(), P.chunks.end(), T.chunks.begin() + cat[size_t(t)]);
+        }
+    });
     // slack so that the kernel's unconditional loads (two chunks ahead) never leave the arrays
     for (int k = 0; k < kTileSlack; k++)
     {
-        T.val.push_back(0.0);
-        T.idx.push_back(kTileSkip);
+        T.val[size_t(total + k)] = 0.0;
+        T.idx[size_t(total + k)] = kTileSkip;
     }
     return true;
 }
@@ -216,198 +266,200 @@ __device__ __forceinline__ double rounded_add(double a, double b)
     return s;
 }
 
-// Loose barrier among the workgroups of one group (the ~160 workgroups an XCD holds: blockIdx % 8): keeps the sweeps over
-// the column blocks in step, so that the group's gathers stay inside the 1-3 MiB of x its L2 holds.  Thread 0 arrives on a
-// monotonic counter and polls it; a wait that outlasts `spin_cap` polls gives up for the rest of the launch (a workgroup
-// that is not resident can therefore never hang the others — only the locality is lost).
-struct TileSync
+// ---- one-phase kernel: gathers x per entry --------------------------------------------------------------------------------
+// PROD = false: v = matrix value, product formed here with a gather from x.  PROD = true (phase 2 of the two-phase product): v =
+// the product phase 1 left at the entry's position, `meta` = the 16-bit row/run half of the index, x unused.
+template <bool PROD>
+struct TileMeta
 {
-    unsigned int* counter;  // 8 counters (one per XCD, 128 bytes apart), zero at launch
-    int period;             // barrier every `period` column blocks; 0: no synchronisation (one segment per workgroup)
-    int group_size;         // workgroups per group
-    int sweeps;             // segments per workgroup (idle sweeps only pass the barriers)
-    int ncb;                // column blocks
-    int spin_cap;
-    unsigned int zero;      // 0 (a value the compiler cannot fold)
-    int xload;              // how x is gathered: 0 plain loads, 1 non-temporal, 2 system scope (L2 bypass) — MISPEC_TILES_XLOAD
+    using type = uint32_t;
+};
+template <>
+struct TileMeta<true>
+{
+    using type = uint16_t;
 };
 
-// The counter lives in the L2 of the group's own XCD: read-modify-writes without the agent-scope cache-bypass bits are
-// executed there (atomics never run in the per-CU L1), so arriving and polling cost an L2 round trip instead of a trip to
-// memory; the XCDs' L2s are not coherent with each other, which is why every XCD has its own counter and only its own
-// workgroups (hardware register XCC_ID) touch it.
-__device__ __forceinline__ void tile_group_barrier(const TileSync& ts, int xcd, unsigned int target, bool& give_up)
-{
-    if (threadIdx.x == 0 && !give_up)
-    {
-        unsigned int* c = ts.counter + xcd * 32;  // one 128-byte line per counter
-        __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        int spins = 0;
-        // polled with a read-modify-write of a run-time zero: a plain (even atomic) load could be served by this CU's L1 forever
-        while (__hip_atomic_fetch_add(c, ts.zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target)
-        {
-            __builtin_amdgcn_s_sleep(16);
-            if (++spins > ts.spin_cap)
-            {
-                give_up = true;
-                break;
-            }
-        }
-    }
-}
-
-template <int XL>
-__device__ __forceinline__ double tile_load_x(const double* p)
-{
-    if (XL == 1)
-        return __builtin_nontemporal_load(p);
-    if (XL == 2)
-        return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    return *p;
-}
-
-template <bool EPI, int XL>
+template <bool EPI, bool PROD>
 __global__ __launch_bounds__(kTileThreads) void k_spmv_tiles(const int64_t* __restrict__ seg_entry, const int32_t* __restrict__ seg_chunk,
                                                     const TileChunk* __restrict__ chunks, const double* __restrict__ val,
-                                                    const uint32_t* __restrict__ idx, const double* __restrict__ x, double* __restrict__ y,
-                                                    int64_t nrows, int nblocks256, int nseg, SpmvEpilogue epi, TileSync ts)
+                                                    const typename TileMeta<PROD>::type* __restrict__ idx, const double* __restrict__ x,
+                                                    double* __restrict__ y, int64_t nrows, int nblocks256, int nseg, SpmvEpilogue epi)
 {
+    using meta_t = typename TileMeta<PROD>::type;
     __shared__ double acc[kTileRows];  // 64 KiB with the default geometry: two workgroups per CU
     if (EPI && epi.status && *epi.status != 0)
         return;
     const int tid = threadIdx.x;
     constexpr int kPer = kTileChunk / kTileThreads;  // entries per thread and chunk
-    bool give_up = false;         // thread 0 only
-    unsigned int arrivals = 0;    // barriers passed so far (all sweeps)
-    // XCC_ID: the XCD this workgroup runs on (hwreg 20, bits 3:0); workgroups are dealt round-robin, gridDim.x / 8 per XCD
-    const int xcd = ts.period > 0 ? int(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) : 0;
-    const int nsweep = ts.period > 0 ? ts.sweeps : 1;
-    for (int sweep = 0; sweep < nsweep; sweep++)
+    const int seg = int(blockIdx.x);
+    if (seg >= nseg)
+        return;
+    for (int r = tid; r < kTileRows; r += kTileThreads)
+        acc[r] = 0.0;
+    const int c0 = seg_chunk[seg], c1 = seg_chunk[seg + 1];
+    const int64_t base = seg_entry[seg];
+    double v[kPer], nv[kPer];
+    meta_t id[kPer], nid[kPer];
+    int off = (c0 < c1) ? chunks[c0].offset : 0;
+#pragma unroll
+    for (int k = 0; k < kPer; k++)
     {
-        const int seg = int(blockIdx.x) + sweep * int(gridDim.x);
-        int next_sync = ts.period;  // first column block that lies behind the next barrier
-        if (seg < nseg)
+        v[k] = __builtin_nontemporal_load(val + base + off + k * kTileThreads + tid);  // streamed once: keep x in the L2
+        id[k] = __builtin_nontemporal_load(idx + base + off + k * kTileThreads + tid);
+    }
+    __syncthreads();
+    for (int ci = c0; ci < c1; ci++)
+    {
+        const TileChunk ch = chunks[ci];
+        const int count = ch.count;
+        // the next chunk's entries follow this chunk's: issue their loads now (the arrays end with slack).  Also issuing
+        // the NEXT chunk's x gathers here (three chunks in flight per thread) measured 1.46 against 1.33 ms on M-rand
+        // (profiles/r03t_*): the gathers are bound by the fabric, more of them in flight only evict each other
+        const int noff = off + count;
+#pragma unroll
+        for (int k = 0; k < kPer; k++)
         {
-            for (int r = tid; r < kTileRows; r += kTileThreads)
-                acc[r] = 0.0;
-            const int c0 = seg_chunk[seg], c1 = seg_chunk[seg + 1];
-            const int64_t base = seg_entry[seg];
-            double v[kPer], nv[kPer];
-            uint32_t id[kPer], nid[kPer];
-            int off = (c0 < c1) ? chunks[c0].offset : 0;
-#pragma unroll
-            for (int k = 0; k < kPer; k++)
-            {
-                v[k] = __builtin_nontemporal_load(val + base + off + k * kTileThreads + tid);  // streamed once: keep x in the L2
-                id[k] = __builtin_nontemporal_load(idx + base + off + k * kTileThreads + tid);
-            }
-            __syncthreads();
-            for (int ci = c0; ci < c1; ci++)
-            {
-                const TileChunk ch = chunks[ci];
-                const int count = ch.count;
-                // the next chunk's entries follow this chunk's: issue their loads now (the arrays end with slack).  Also issuing
-                // the NEXT chunk's x gathers here (three chunks in flight per thread) measured 1.46 against 1.33 ms on M-rand
-                // (profiles/r03t_*): the gathers are bound by the fabric, more of them in flight only evict each other
-                const int noff = off + count;
-#pragma unroll
-                for (int k = 0; k < kPer; k++)
-                {
-                    nv[k] = __builtin_nontemporal_load(val + base + noff + k * kTileThreads + tid);
-                    nid[k] = __builtin_nontemporal_load(idx + base + noff + k * kTileThreads + tid);
-                }
-                if (ts.period > 0 && next_sync <= int(ch.colblock))
-                {
-                    while (next_sync <= int(ch.colblock))  // do not run ahead of the group into the next piece of x
-                    {
-                        arrivals++;
-                        tile_group_barrier(ts, xcd, arrivals * unsigned(ts.group_size), give_up);
-                        next_sync += ts.period;
-                    }
-                    __syncthreads();  // the whole workgroup waits for thread 0's wait
-                }
-                const int64_t col0 = int64_t(ch.colblock) << kTileColBits;
-                double p[kPer];
-                int run[kPer];
-#pragma unroll
-                for (int k = 0; k < kPer; k++)
-                {
-                    const bool live = (k * kTileThreads + tid < count) && id[k] != kTileSkip;
-                    run[k] = live ? int(id[k] & uint32_t(kTileMaxRun)) : 0;
-                    const int64_t col = live ? col0 + int64_t((id[k] >> kTileRunBits) & uint32_t(kTileCols - 1)) : col0;
-                    p[k] = live ? rounded_product(v[k], tile_load_x<XL>(x + col)) : 0.0;
-                }
-#pragma unroll
-                for (int k = 0; k < kPer; k++)
-                {
-                    // head lanes add the products of their run in order: own, then the next lanes' (a run never leaves its wavefront)
-                    const int row = int(id[k] >> (kTileColBits + kTileRunBits)) & (kTileRows - 1);
-                    double a = (run[k] > 0) ? acc[row] : 0.0;
-                    a = rounded_add(a, p[k]);
-                    for (int j = 1; j < kTileMaxRun; j++)
-                    {
-                        if (__ballot(run[k] > j) == 0ull)
-                            break;
-                        const double pj = __shfl_down(p[k], j, 64);
-                        if (run[k] > j)
-                            a = rounded_add(a, pj);
-                    }
-                    if (run[k] > 0)
-                        acc[row] = a;
-                }
-                __syncthreads();  // the next chunk may address the same rows from other lanes
-                off = noff;
-#pragma unroll
-                for (int k = 0; k < kPer; k++)
-                {
-                    v[k] = nv[k];
-                    id[k] = nid[k];
-                }
-            }
-            // rows of the segment -> y, in the 256-row blocks of the CSR kernels (identical alpha partial records)
-            const int64_t row0 = int64_t(seg) * kTileRows;
-#pragma unroll 1
-            for (int j = 0; j < kTileRows / 256; j++)
-            {
-                const int64_t row = row0 + j * 256 + tid;
-                const int64_t blk = row0 / 256 + j;
-                if (blk >= nblocks256)
-                    break;
-                double contrib = 0.0;
-                if (tid < 256 && row < nrows)
-                {
-                    double yv = acc[j * 256 + tid];
-                    if (EPI)
-                    {
-                        if (epi.v_prev)
-                            yv -= (epi.h_prev_dev ? *epi.h_prev_dev : epi.h_prev) * epi.v_prev[row];  // Lanczos.h:139
-                        contrib = epi.v_rows[row] * yv;                                                 // Lanczos.h:142
-                    }
-                    y[row] = yv;
-                }
-                if (EPI)
-                {
-                    // cross-wave sum through the accumulator slots of this block, which every thread has read by now
-                    const double t = tile_wave_sum(contrib);
-                    __syncthreads();
-                    double* red = acc + j * 256;
-                    if ((tid & 63) == 0 && tid < 256)
-                        red[tid >> 6] = t;
-                    __syncthreads();
-                    if (tid == 0)
-                        epi.partials[blk] = (red[0] + red[1]) + (red[2] + red[3]);
-                }
-            }
-            __syncthreads();  // acc is reused by the next sweep
+            nv[k] = __builtin_nontemporal_load(val + base + noff + k * kTileThreads + tid);
+            nid[k] = __builtin_nontemporal_load(idx + base + noff + k * kTileThreads + tid);
         }
-        // the barriers of this sweep that the segment's chunks did not reach (empty trailing tiles, idle sweep)
-        if (ts.period > 0)
-            while (next_sync < ts.ncb + ts.period)
+        const int64_t col0 = int64_t(ch.colblock) << kTileColBits;
+        double p[kPer];
+        int run[kPer], rowk[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; k++)
+        {
+            if (PROD)
             {
-                arrivals++;
-                tile_group_barrier(ts, xcd, arrivals * unsigned(ts.group_size), give_up);
-                next_sync += ts.period;
+                const bool live = k * kTileThreads + tid < count;
+                run[k] = live ? int(id[k] & meta_t(kTileMaxRun)) : 0;
+                rowk[k] = int(id[k] >> kTileRunBits) & (kTileRows - 1);
+                p[k] = live ? v[k] : 0.0;
             }
+            else
+            {
+                const bool live = (k * kTileThreads + tid < count) && uint32_t(id[k]) != kTileSkip;
+                run[k] = live ? int(uint32_t(id[k]) & uint32_t(kTileMaxRun)) : 0;
+                rowk[k] = int(uint32_t(id[k]) >> (kTileColBits + kTileRunBits)) & (kTileRows - 1);
+                const int64_t col = live ? col0 + int64_t((uint32_t(id[k]) >> kTileRunBits) & uint32_t(kTileCols - 1)) : col0;
+                p[k] = live ? rounded_product(v[k], x[col]) : 0.0;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kPer; k++)
+        {
+            // head lanes add the products of their run in order: own, then the next lanes' (a run never leaves its wavefront)
+            const int row = rowk[k];
+            double a = (run[k] > 0) ? acc[row] : 0.0;
+            a = rounded_add(a, p[k]);
+            for (int j = 1; j < kTileMaxRun; j++)
+            {
+                if (__ballot(run[k] > j) == 0ull)
+                    break;
+                const double pj = __shfl_down(p[k], j, 64);
+                if (run[k] > j)
+                    a = rounded_add(a, pj);
+            }
+            if (run[k] > 0)
+                acc[row] = a;
+        }
+        __syncthreads();  // the next chunk may address the same rows from other lanes
+        off = noff;
+#pragma unroll
+        for (int k = 0; k < kPer; k++)
+        {
+            v[k] = nv[k];
+            id[k] = nid[k];
+        }
+    }
+    // rows of the segment -> y, in the 256-row blocks of the CSR kernels (identical alpha partial records)
+    const int64_t row0 = int64_t(seg) * kTileRows;
+#pragma unroll 1
+    for (int j = 0; j < kTileRows / 256; j++)
+    {
+        const int64_t row = row0 + j * 256 + tid;
+        const int64_t blk = row0 / 256 + j;
+        if (blk >= nblocks256)
+            break;
+        double contrib = 0.0;
+        if (tid < 256 && row < nrows)
+        {
+            double yv = acc[j * 256 + tid];
+            if (EPI)
+            {
+                if (epi.v_prev)
+                    yv -= (epi.h_prev_dev ? *epi.h_prev_dev : epi.h_prev) * epi.v_prev[row];  // Lanczos.h:139
+                contrib = epi.v_rows[row] * yv;                                                 // Lanczos.h:142
+            }
+            y[row] = yv;
+        }
+        if (EPI)
+        {
+            // cross-wave sum through the accumulator slots of this block, which every thread has read by now
+            const double t = tile_wave_sum(contrib);
+            __syncthreads();
+            double* red = acc + j * 256;
+            if ((tid & 63) == 0 && tid < 256)
+                red[tid >> 6] = t;
+            __syncthreads();
+            if (tid == 0)
+                epi.partials[blk] = (red[0] + red[1]) + (red[2] + red[3]);
+        }
+    }
+}
+
+// ---- two-phase product, phase 1: prod[e] = val[e] * x[column of e], chunks taken in COLUMN-BLOCK order ---------------------------
+// A persistent grid walks the block-sorted chunk list with a grid stride, so the chunks in flight at any moment belong to one or
+// two neighbouring column blocks: every XCD's L2 then holds the 0.5-1 MiB of x all its workgroups are gathering from, and x is
+// read from memory once per XCD instead of once per entry.  A chunk is one contiguous run of <= 1024 entries: values (8 B) and
+// 16-bit columns in, products out, all streamed; the products are rounded on their own, so phase 2 adds exactly what the
+// one-phase kernel adds.
+constexpr int kProdThreads = 512;
+__global__ __launch_bounds__(kProdThreads) void k_tile_products(const int32_t* __restrict__ order, int nchunks, const int64_t* __restrict__ chunk_abs,
+                                                                const TileChunk* __restrict__ chunks, const double* __restrict__ val,
+                                                                const uint16_t* __restrict__ col16, const double* __restrict__ x,
+                                                                double* __restrict__ prod, const int* status)
+{
+    if (status && *status != 0)
+        return;
+    constexpr int kPer = kTileChunk / kProdThreads;
+    const int tid = threadIdx.x;
+    for (int i = int(blockIdx.x); i < nchunks; i += int(gridDim.x))
+    {
+        const int c = order[i];
+        const TileChunk ch = chunks[c];
+        const int64_t base = chunk_abs[c];
+        const int64_t col0 = int64_t(ch.colblock) << kTileColBits;
+        double v[kPer];
+        unsigned cc[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; k++)
+        {
+            const int e = min(k * kProdThreads + tid, int(ch.count) - 1);  // lanes past the end repeat the last entry (result dropped)
+            v[k] = __builtin_nontemporal_load(val + base + e);
+            cc[k] = __builtin_nontemporal_load(col16 + base + e);
+        }
+        double xv[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; k++)
+            xv[k] = x[col0 + cc[k]];
+#pragma unroll
+        for (int k = 0; k < kPer; k++)
+            if (k * kProdThreads + tid < int(ch.count))
+                __builtin_nontemporal_store(rounded_product(v[k], xv[k]), prod + base + k * kProdThreads + tid);
+    }
+}
+
+// idx (32 bit) -> the two 16-bit halves of the two-phase image.  Padding entries become orphan continuations (run 0, product 0)
+__global__ __launch_bounds__(256) void k_tiles_split(const uint32_t* __restrict__ idx, int64_t n, uint16_t* __restrict__ col16,
+                                                     uint16_t* __restrict__ rowrun)
+{
+    for (int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x; e < n; e += int64_t(gridDim.x) * 256)
+    {
+        const uint32_t id = idx[e];
+        const bool skip = id == kTileSkip;
+        col16[e] = skip ? uint16_t(0) : uint16_t((id >> kTileRunBits) & uint32_t(kTileCols - 1));
+        rowrun[e] = skip ? uint16_t(0) : uint16_t(((id >> (kTileColBits + kTileRunBits)) << kTileRunBits) | (id & uint32_t(kTileMaxRun)));
     }
 }
 }  // namespace
@@ -423,129 +475,102 @@ void upload_tiles(const HostTiles& H, hipStream_t stream, DevTiles& D)
     up(D.chunks, H.chunks);
     up(D.val, H.val);
     up(D.idx, H.idx);
-    MISPEC_HIP(hipStreamSynchronize(stream));
     D.nseg = int64_t(H.seg_entry.size()) - 1;
     D.entries = int64_t(H.val.size()) - kTileSlack;
     D.nchunks = int64_t(H.chunks.size());
     D.padding = H.padding;
     D.ncb = H.ncb;
-    D.sync_counters.alloc(8 * 32);
-    MISPEC_HIP(hipMemset(D.sync_counters.p, 0, 8 * 32 * sizeof(unsigned int)));
+    // the two-phase image: chunk table in column-block order (a counting sort of <= a few 100k chunks on the host) and the split
+    // index halves (device).  MISPEC_SPMV_TILES=onephase keeps the one-phase kernel (and skips the 10 extra bytes per entry).
+    const char* mode = getenv("MISPEC_SPMV_TILES");
+    D.two_phase = !(mode && std::strcmp(mode, "onephase") == 0);
+    if (D.two_phase)
+    {
+        std::vector<int64_t> abs(H.chunks.size());
+        std::vector<int32_t> order(H.chunks.size()), start(size_t(H.ncb) + 1, 0);
+        for (int64_t s = 0; s < D.nseg; s++)
+            for (int32_t c = H.seg_chunk[size_t(s)]; c < H.seg_chunk[size_t(s) + 1]; c++)
+            {
+                abs[size_t(c)] = H.seg_entry[size_t(s)] + H.chunks[size_t(c)].offset;
+                start[size_t(H.chunks[size_t(c)].colblock) + 1]++;
+            }
+        for (int64_t b = 0; b < H.ncb; b++)
+            start[size_t(b) + 1] += start[size_t(b)];
+        for (size_t c = 0; c < H.chunks.size(); c++)
+            order[size_t(start[size_t(H.chunks[c].colblock)]++)] = int32_t(c);
+        up(D.chunk_abs, abs);
+        up(D.cb_order, order);
+        MISPEC_HIP(hipStreamSynchronize(stream));  // abs / order go out of scope
+        D.col16.alloc(H.idx.size());
+        D.rowrun.alloc(H.idx.size());
+        D.prod.alloc(H.val.size());
+        MISPEC_HIP(hipMemsetAsync(D.prod.p, 0, D.prod.n * sizeof(double), stream));
+        hipLaunchKernelGGL(k_tiles_split, dim3(4096), dim3(256), 0, stream, D.idx.p, int64_t(H.idx.size()), D.col16.p, D.rowrun.p);
+        MISPEC_HIP(hipGetLastError());
+    }
+    MISPEC_HIP(hipStreamSynchronize(stream));
 }
 
 void launch_spmv_tiles(const DevTiles& T, hipStream_t stream, const double* x, double* y, int64_t nrows, int nblocks256,
                        const SpmvEpilogue* epi, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     const SpmvEpilogue e = epi ? *epi : SpmvEpilogue{};
-    // sync_period = k > 0: persistent workgroups (as many as are resident at once), each sweeping several segments, with a
-    // loose barrier per XCD group every k column blocks so that the sweeps stay in step and the gathers stay in the L2;
-    // 0: one workgroup per segment, free-running.
-    // sync_period: per matrix, chosen by calibrate_tiles() at ingest (or forced by MISPEC_TILES_SYNC=k)
-    const int period = T.sync_period;
-    static const int xload = getenv("MISPEC_TILES_XLOAD") ? atoi(getenv("MISPEC_TILES_XLOAD")) : 0;
-    TileSync ts{nullptr, 0, 0, 1, int(T.ncb), 0, 0u, xload};
-    dim3 grid(static_cast<unsigned>(T.nseg)), block(kTileThreads);
-    if (period > 0 && T.sync_counters.p)
+    const dim3 grid(static_cast<unsigned>(T.nseg)), block(kTileThreads);
+    if (T.two_phase)
     {
-        static int resident = 0;
-        if (!resident)
+        // phase 1 on a persistent grid (four 512-thread workgroups per CU), phase 2 one workgroup per segment; an event pair times
+        // the two launches together (start of the first, end of the second)
+        static int num_cu = 0;
+        if (!num_cu)
         {
-            int per_cu = 0, dev = 0;
+            int dev = 0;
             hipDeviceProp_t prop;
             MISPEC_HIP(hipGetDevice(&dev));
             MISPEC_HIP(hipGetDeviceProperties(&prop, dev));
-            int per_cu2 = 0;
-            MISPEC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_spmv_tiles<true, 0>), kTileThreads, 0));
-            MISPEC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, reinterpret_cast<const void*>(&k_spmv_tiles<false, 0>), kTileThreads, 0));
-            // one below what the occupancy calculator allows (5 x 32 KiB is the whole LDS of a CU: measured, the fifth
-            // workgroup is not resident), overridable for experiments
-            per_cu = std::max(1, std::min(per_cu, per_cu2) - 1);
-            if (getenv("MISPEC_TILES_WG_PER_CU"))
-                per_cu = std::max(1, atoi(getenv("MISPEC_TILES_WG_PER_CU")));
-            resident = std::max(8, per_cu * prop.multiProcessorCount / 8 * 8);
+            num_cu = prop.multiProcessorCount;
         }
-        const int g = int(std::min<int64_t>(resident, (T.nseg + 7) / 8 * 8));
-        grid = dim3(static_cast<unsigned>(g));
-        ts.counter = T.sync_counters.p;
-        ts.period = period;
-        ts.group_size = g / 8;
-        ts.sweeps = int((T.nseg + g - 1) / g);
-        ts.spin_cap = 20000;  // ~ a few ms of polling: far beyond any healthy wait
-        MISPEC_HIP(hipMemsetAsync(T.sync_counters.p, 0, 8 * 32 * sizeof(unsigned int), stream));
+        const dim3 g1(static_cast<unsigned>(std::min<int64_t>(int64_t(num_cu) * 4, T.nchunks))), b1(kProdThreads);
+        const int* status = epi ? e.status : nullptr;
+        if (ev_start && ev_stop)
+            hipExtLaunchKernelGGL(k_tile_products, g1, b1, 0, stream, ev_start, nullptr, 0, T.cb_order.p, int(T.nchunks), T.chunk_abs.p, T.chunks.p,
+                                  T.val.p, T.col16.p, x, T.prod.p, status);
+        else
+            hipLaunchKernelGGL(k_tile_products, g1, b1, 0, stream, T.cb_order.p, int(T.nchunks), T.chunk_abs.p, T.chunks.p, T.val.p, T.col16.p, x,
+                               T.prod.p, status);
+#define MISPEC_TILES2(E)                                                                                                              \
+    do                                                                                                                                \
+    {                                                                                                                                 \
+        if (ev_start && ev_stop)                                                                                                      \
+            hipExtLaunchKernelGGL((k_spmv_tiles<E, true>), grid, block, 0, stream, nullptr, ev_stop, 0, T.seg_entry.p, T.seg_chunk.p, T.chunks.p, \
+                                  T.prod.p, T.rowrun.p, x, y, nrows, nblocks256, int(T.nseg), e);                                     \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((k_spmv_tiles<E, true>), grid, block, 0, stream, T.seg_entry.p, T.seg_chunk.p, T.chunks.p, T.prod.p,   \
+                               T.rowrun.p, x, y, nrows, nblocks256, int(T.nseg), e);                                                  \
+    } while (0)
+        if (epi)
+            MISPEC_TILES2(true);
+        else
+            MISPEC_TILES2(false);
+#undef MISPEC_TILES2
+        MISPEC_HIP(hipGetLastError());
+        return;
     }
-#define MISPEC_TILES(E, X)                                                                                                  \
+#define MISPEC_TILES(E)                                                                                                     \
     do                                                                                                                      \
     {                                                                                                                       \
         if (ev_start && ev_stop)                                                                                            \
-            hipExtLaunchKernelGGL((k_spmv_tiles<E, X>), grid, block, 0, stream, ev_start, ev_stop, 0, T.seg_entry.p, T.seg_chunk.p, \
-                                  T.chunks.p, T.val.p, T.idx.p, x, y, nrows, nblocks256, int(T.nseg), e, ts);              \
+            hipExtLaunchKernelGGL((k_spmv_tiles<E, false>), grid, block, 0, stream, ev_start, ev_stop, 0, T.seg_entry.p, T.seg_chunk.p, \
+                                  T.chunks.p, T.val.p, T.idx.p, x, y, nrows, nblocks256, int(T.nseg), e);                  \
         else                                                                                                                \
-            hipLaunchKernelGGL((k_spmv_tiles<E, X>), grid, block, 0, stream, T.seg_entry.p, T.seg_chunk.p, T.chunks.p, T.val.p, \
-                               T.idx.p, x, y, nrows, nblocks256, int(T.nseg), e, ts);                                      \
-    } while (0)
-#define MISPEC_TILES_X(E)        \
-    do                           \
-    {                            \
-        if (xload == 1)          \
-            MISPEC_TILES(E, 1);  \
-        else if (xload == 2)     \
-            MISPEC_TILES(E, 2);  \
-        else                     \
-            MISPEC_TILES(E, 0);  \
+            hipLaunchKernelGGL((k_spmv_tiles<E, false>), grid, block, 0, stream, T.seg_entry.p, T.seg_chunk.p, T.chunks.p, T.val.p, \
+                               T.idx.p, x, y, nrows, nblocks256, int(T.nseg), e);                                          \
     } while (0)
     if (epi)
-        MISPEC_TILES_X(true);
+        MISPEC_TILES(true);
     else
-        MISPEC_TILES_X(false);
-#undef MISPEC_TILES_X
+        MISPEC_TILES(false);
 #undef MISPEC_TILES
     MISPEC_HIP(hipGetLastError());
-}
-
-// Pick the launch variant of this matrix by measurement: free-running workgroups against persistent ones that meet every
-// quarter of the column sweep (measured at n = 1e7: 1.87 vs 1.73-1.76 ms; frequent barriers lose, profiles/r02_mrand_variants.jsonl).
-// The persistent variant relies on every workgroup of its grid being resident; if that ever fails its barriers time out and
-// the timing here says so — the free-running kernel is then kept.  MISPEC_TILES_SYNC=k forces a period (0: free-running).
-void calibrate_tiles(DevTiles& T, hipStream_t stream, int64_t nrows, int64_t ncols, int nblocks256)
-{
-    T.sync_period = 0;
-    if (const char* e = getenv("MISPEC_TILES_SYNC"))
-    {
-        T.sync_period = std::max(0, atoi(e));
-        return;
-    }
-    if (T.nseg < 2048 || T.ncb < 16)  // fewer segments than two generations of resident workgroups: nothing to keep in step
-        return;
-    DevBuf<double> x, y;
-    x.alloc(size_t(ncols) + 2);
-    y.alloc(size_t(nrows) + 2);
-    MISPEC_HIP(hipMemsetAsync(x.p, 0, x.n * sizeof(double), stream));
-    hipEvent_t e0, e1;
-    MISPEC_HIP(hipEventCreate(&e0));
-    MISPEC_HIP(hipEventCreate(&e1));
-    const int candidate = int(std::max<int64_t>(1, T.ncb / 4));
-    float best_ms = 0.f;
-    int best = 0;
-    for (int variant = 0; variant < 2; variant++)
-    {
-        T.sync_period = variant ? candidate : 0;
-        launch_spmv_tiles(T, stream, x.p, y.p, nrows, nblocks256, nullptr, nullptr, nullptr);  // warm-up
-        MISPEC_HIP(hipEventRecord(e0, stream));
-        for (int r = 0; r < 3; r++)
-            launch_spmv_tiles(T, stream, x.p, y.p, nrows, nblocks256, nullptr, nullptr, nullptr);
-        MISPEC_HIP(hipEventRecord(e1, stream));
-        MISPEC_HIP(hipEventSynchronize(e1));
-        float ms = 0.f;
-        MISPEC_HIP(hipEventElapsedTime(&ms, e0, e1));
-        if (variant == 0 || ms < 0.97f * best_ms)
-        {
-            best_ms = ms;
-            best = T.sync_period;
-        }
-    }
-    T.sync_period = best;
-    (void) hipEventDestroy(e0);
-    (void) hipEventDestroy(e1);
 }
 
 }  // namespace mispec

@@ -28,6 +28,7 @@ constexpr int kTileThreads = MISPEC_TILE_THREADS;   // threads of the workgroup 
 constexpr int kTileCols = 1 << kTileColBits;
 constexpr int kTileRunBits = 32 - MISPEC_TILE_ROW_BITS - MISPEC_TILE_COL_BITS;  // run length of a head entry: the bits that are left
 constexpr int kTileMaxRun = (1 << kTileRunBits) - 1;
+static_assert(kTileRowBits + kTileRunBits <= 16 && kTileColBits <= 16, "the two-phase image keeps row+run and column in 16 bits each");
 #ifndef MISPEC_TILE_CHUNK
 #define MISPEC_TILE_CHUNK 1024
 #endif
@@ -69,9 +70,17 @@ struct DevTiles
     DevBuf<TileChunk> chunks;
     DevBuf<double> val;
     DevBuf<uint32_t> idx;
-    DevBuf<unsigned int> sync_counters;  // the loose per-XCD barrier of the persistent variant (MISPEC_TILES_SYNC)
+    // Two-phase image of the same tiles (round 3, "propagation blocking": Beamer, Asanovic, Patterson 2017), derived on the device
+    // at upload.  Phase 1 walks the CHUNKS IN COLUMN-BLOCK ORDER (cb_order), so that at any moment the whole device gathers from
+    // one or two 512 KiB pieces of x, and writes every product to `prod` at its entry's position; phase 2 is the segment sweep of
+    // the one-phase kernel reading products instead of gathering.  The 32-bit index is split into the half each phase needs.
+    DevBuf<uint16_t> col16;      // column inside the block (phase 1)
+    DevBuf<uint16_t> rowrun;     // row inside the segment << run bits | run length (phase 2); padding entries: 0 (an orphan continuation)
+    DevBuf<double> prod;         // scratch: one product per entry
+    DevBuf<int64_t> chunk_abs;   // absolute first entry of every chunk
+    DevBuf<int32_t> cb_order;    // chunk indices sorted by column block (stable: ascending segment inside a block)
+    bool two_phase = false;
     int64_t nseg = 0, entries = 0, nchunks = 0, padding = 0, ncb = 0;
-    int sync_period = 0;                 // 0: free-running workgroups; k: persistent workgroups meeting every k column blocks
     bool present() const { return nseg > 0; }
     void swap(DevTiles& o)
     {
@@ -80,9 +89,13 @@ struct DevTiles
         chunks.swap(o.chunks);
         val.swap(o.val);
         idx.swap(o.idx);
-        sync_counters.swap(o.sync_counters);
+        col16.swap(o.col16);
+        rowrun.swap(o.rowrun);
+        prod.swap(o.prod);
+        chunk_abs.swap(o.chunk_abs);
+        cb_order.swap(o.cb_order);
+        std::swap(two_phase, o.two_phase);
         std::swap(ncb, o.ncb);
-        std::swap(sync_period, o.sync_period);
         std::swap(nseg, o.nseg);
         std::swap(entries, o.entries);
         std::swap(nchunks, o.nchunks);
@@ -90,7 +103,6 @@ struct DevTiles
     }
 };
 void upload_tiles(const HostTiles& H, hipStream_t stream, DevTiles& D);
-void calibrate_tiles(DevTiles& T, hipStream_t stream, int64_t nrows, int64_t ncols, int nblocks256);
 struct SpmvEpilogue;
 void launch_spmv_tiles(const DevTiles& T, hipStream_t stream, const double* x, double* y, int64_t nrows, int nblocks256,
                        const SpmvEpilogue* epi, hipEvent_t ev_start, hipEvent_t ev_stop);

@@ -188,8 +188,8 @@ def test_wide_basis_restart_and_limits(ctx):
     assert np.abs(resid).max() < 1e-10 and np.abs(V.T @ V - np.eye(k)).max() < 1e-11   # A V = V H + f e_k'
     fac.factorize_from(k, m)
     check_identities(fac, Sd, m, tol=1e-10)
-    with pytest.raises(ValueError, match="256"):
-        sa.Factorization(sa.SparseGenMatProd(S3, ctx=ctx), 257, True)
+    with pytest.raises(ValueError, match="1024"):
+        sa.Factorization(sa.SparseGenMatProd(S3, ctx=ctx), 1025, True)
     # m = 200 > 128: the restart sweeps run on the host (the LDS-resident kernel stops at 128 columns)
     m2, k2 = 200, 90
     fac2 = sa.Factorization(sa.SparseGenMatProd(S3, ctx=ctx), m2, True)

@@ -150,7 +150,7 @@ def test_davidson_and_regular_inverse_use_the_callers_diagonal_on_a_reordered_ma
     # Davidson preconditioner / unit start vectors and the Jacobi preconditioner of the CG solve work in the CALLER's order and
     # must not read that diagonal unpermuted.  A diagonal ramp makes the difference decisive: with the permuted diagonal the
     # Davidson start vectors point at the wrong rows and the iteration counts blow up.
-    B = shuffled_stencil(24, seed=3).tolil()
+    B = (0.02 * shuffled_stencil(24, seed=3)).tolil()    # weak coupling: the diagonal preconditioner is then nearly exact
     n = B.shape[0]
     ramp = np.random.default_rng(9).permutation(n) + 1.0
     B.setdiag(ramp)
@@ -161,15 +161,15 @@ def test_davidson_and_regular_inverse_use_the_callers_diagonal_on_a_reordered_ma
         op = sa.SparseSymMatProd(sp.tril(B).tocsc(), ctx=ctx, reorder=mode)
         assert op.reordering() == mode
         eigs = sa.DavidsonSymEigsSolver(op, k)
-        nconv = eigs.compute(sa.SortRule.LargestAlge, maxit=100, tol=1e-10)
+        nconv = eigs.compute(sa.SortRule.LargestAlge, maxit=100, tol=1e-7)   # |lambda| ~ 1.4e4: 1e-7 is ~1e-11 relative
         assert nconv == k and eigs.info() == sa.CompInfo.Successful
         ev, X = eigs.eigenvalues(), eigs.eigenvectors()
-        assert np.abs(B @ X - X * ev).max() < 1e-8
+        assert np.abs(B @ X - X * ev).max() < 1e-6
         out[mode] = (ev, eigs.num_iterations())
-    assert np.abs(out["none"][0] - out["rcm"][0]).max() < 1e-9
+    assert np.abs(out["none"][0] - out["rcm"][0]).max() < 1e-8
     assert abs(out["none"][1] - out["rcm"][1]) <= 2, out          # same preconditioner => same convergence history
     # regular inverse: B^{-1} x by CG with the Jacobi preconditioner, reordering forced through the environment
-    M = (B + sp.diags(np.full(n, 8.0))).tocsc()                    # diagonally dominant => positive definite
+    M = B.tocsc()                                                  # diagonal >= 1, off-diagonal row sums < 0.1: positive definite
     x = np.random.default_rng(4).uniform(-1, 1, n)
     its = {}
     for mode in ("none", "rcm"):

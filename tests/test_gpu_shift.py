@@ -71,7 +71,7 @@ def test_device_factorisation_reports_vanishing_pivots_and_matches_the_host_one(
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
     res = []
     for mode in ("device", "host"):
-        env = dict(os.environ, MISPEC_SHIFT_FACTOR=mode)
+        env = dict(os.environ, MISPEC_SHIFT="factor=" + mode)
         r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
         res.append(np.frombuffer(bytes.fromhex(r.stdout.strip()), dtype=np.float64))
@@ -258,18 +258,18 @@ def _solve_in_subprocess(env_extra, cases):
 
 def test_solve_kernel_variants_agree():
     # (i) the LDS-staged sweeps (k_chunk_solve_lds: 16-byte loads, whole batches over the zero padding, vector in LDS) against the
-    # general kernel (MISPEC_SHIFT_LDS=0), any batch length and chunks per wavefront: the same operations in the same order, so
+    # general kernel (MISPEC_SHIFT=lds=0), any batch length and chunks per wavefront: the same operations in the same order, so
     # the SAME BITS; (ii) the explicit inverses of the lower levels' chunk interiors (k_chunk_inverse / k_block_gemv) against the
-    # sweeps there (MISPEC_SHIFT_BLOCK_INVERSE=0): a different but equally stable evaluation — residual at the same level.
+    # sweeps there (MISPEC_SHIFT=block_inverse=0): a different but equally stable evaluation — residual at the same level.
     # Sizes: two / three levels, a last chunk longer than the others (n not a multiple of 128), every instantiated bandwidth.
     cases = [(300_001, 1, 0.0, 0), (300_077, 2, -1.0, 0), (1_000_003, 3, 0.0, 0), (200_050, 4, 0.0, 0), (150_001, 5, -0.5, 0),
              (100_003, 7, 0.0, 0), (100_000, 8, 0.0, 0), (400_000, 3, 0.3, 1)]
     base = _solve_in_subprocess({}, cases)
-    for env in ({"MISPEC_SHIFT_LDS": "0"}, {"MISPEC_SHIFT_BATCH": "16"}, {"MISPEC_SHIFT_BATCH": "8"}, {"MISPEC_SHIFT_LANES": "32"},
-                {"MISPEC_SHIFT_LANES": "16", "MISPEC_SHIFT_BATCH": "16"}):
+    for env in ({"MISPEC_SHIFT": "lds=0"}, {"MISPEC_SHIFT": "batch=16"}, {"MISPEC_SHIFT": "batch=8"}, {"MISPEC_SHIFT": "lanes=32"},
+                {"MISPEC_SHIFT": "lanes=16,batch=16"}):
         other = _solve_in_subprocess(env, cases)
         assert [o[0] for o in other] == [o[0] for o in base], (env, other, base)
-    sweeps = _solve_in_subprocess({"MISPEC_SHIFT_BLOCK_INVERSE": "0"}, cases)
+    sweeps = _solve_in_subprocess({"MISPEC_SHIFT": "block_inverse=0"}, cases)
     for (crc_a, res_a, steps_a), (crc_b, res_b, steps_b), case in zip(base, sweeps, cases):
         tol = 1e-10 if case[3] else 1e-12   # interior shift: the matrix is indefinite and worse conditioned
         assert float(res_a) <= tol and float(res_b) <= tol, (case, res_a, res_b)

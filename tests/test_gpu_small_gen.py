@@ -46,7 +46,7 @@ def test_device_sweeps_match_the_oracle(ctx, n):
 
 
 def test_restart_on_the_device_gives_the_host_solve():
-    # MISPEC_SMALL_GEN=device|host A/B: the same arithmetic (one source), so the same eigenvalues and operation counts
+    # MISPEC_SMALL=device|host A/B: the same arithmetic (one source), so the same eigenvalues and operation counts
     code = (
         "import sys, time, numpy as np; sys.path.insert(0, %r); import spectra_amd as sa\n"
         "op = sa.SparseGenMatProd.synth_band(300000)\n"
@@ -57,7 +57,7 @@ def test_restart_on_the_device_gives_the_host_solve():
     ) % ROOT
     outs = []
     for mode in ("host", "device"):
-        env = dict(os.environ, MISPEC_SMALL_GEN=mode)
+        env = dict(os.environ, MISPEC_SMALL=mode)
         r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
         outs.append(r.stdout.split())

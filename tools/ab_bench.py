@@ -1,7 +1,8 @@
 """Same-box A/B of environment switches on the headline workload: runs `bench.py --no-secondary --no-cpu-baseline` once per
 variant (each in its own process: the switches are read at library / matrix construction) and prints one line per variant.
 
-    python tools/ab_bench.py [--steps K] NAME=ENV1=v,ENV2=v ...     e.g.  base= dia_diagonal=MISPEC_DIA_LAYOUT=diagonal
+    python tools/ab_bench.py [--steps K] NAME=ENV1=v,ENV2=v ...     e.g.  base= host_steps=MISPEC_HOST_STEPS=1
+An item that starts with "--" is passed to bench.py instead (e.g. one=--orth=onesweep).
 """
 import json
 import os
@@ -17,10 +18,14 @@ if args and args[0] == "--steps":
 for spec in args:
     name, _, envs = spec.partition("=")
     env = dict(os.environ)
+    extra = []
     for kv in filter(None, envs.split(",")):
+        if kv.startswith("--"):
+            extra.append(kv)
+            continue
         k, _, v = kv.partition("=")
         env[k] = v
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", steps, "--warmup", "1", "--no-secondary", "--no-cpu-baseline"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", steps, "--warmup", "1", "--no-secondary", "--no-cpu-baseline"] + extra,
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     try:
         d = json.loads(r.stdout.strip().splitlines()[-1])
@@ -29,6 +34,8 @@ for spec in args:
                           "spmv_ms_per_launch": round(d["roofline"]["ms_per_launch"], 4), "spmv_frac": round(d["roofline"]["frac"], 4),
                           "spmv_standalone_ms": round(d["roofline"]["standalone_ms_per_launch"], 4),
                           "kernels_ms_per_solve": {a: round(b, 1) for a, b in k.items()}, "max_residual": d["solve"]["max_residual"],
-                          "num_operations": d["solve"]["num_operations"]}), flush=True)
+                          "num_operations": d["solve"]["num_operations"], "orth": d["solve"].get("orth_info", {}).get("mode"),
+                          "other_orth_mode": (d.get("other_orth_mode") or {}).get("value"),
+                          "with_host_eigenvectors": (d.get("value_with_host_eigenvectors") or {}).get("value")}), flush=True)
     except Exception as e:  # noqa: BLE001
         print(json.dumps({"variant": name, "error": repr(e), "stderr": r.stderr[-500:]}), flush=True)
