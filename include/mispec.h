@@ -127,10 +127,8 @@ int mispec_csr_use_offset_codes(mispec_csr* A, int enable);
  * storage (values kept diagonal-major, no index and no gather; chosen when the dictionary has <= 32 diagonals that are
  * at least 3/4 full, rows sorted, no duplicate entries), 3 = column-blocked tiles (built at
  * ingest for unsharded matrices with more than a quarter of their entries further than 131072 columns from the diagonal
- * that reordering did not localise: 8192-row segments x 65536-column blocks; two-phase product — phase 1 forms all products
- * chunk by chunk in column-block order, so that the whole device gathers from the same 0.5-1 MiB of x at any moment, phase 2
- * sums them per segment in LDS; MISPEC_SPMV_TILES=0 turns the format off, =1 builds it for any matrix, =onephase builds it with
- * the older kernel that gathers x during the segment sweep).  All give bit-identical products for finite x
+ * that reordering did not localise: 8192-row segments x 65536-column blocks, the segment's sums in LDS, the gathers of the
+ * workgroups resident on an XCD sharing its L2; MISPEC_SPMV_TILES=0 turns the format off, =1 builds it for any matrix).  All give bit-identical products for finite x
  * (the diagonal format multiplies x by explicit zeros where the matrix has no entry).
  * mispec_csr_set_spmv_format forces a format for this matrix (-1 = automatic; a format that was not built falls back). */
 int mispec_csr_spmv_format(const mispec_csr* A);
@@ -166,9 +164,8 @@ int mispec_csr_reorder(mispec_csr* A, int method, int* applied);
 int mispec_csr_reordering(const mispec_csr* A, double* far_before, double* far_after);
 int mispec_csr_permutation(const mispec_csr* A, int32_t* perm_out);
 /* What the tile format of this matrix looks like (segments = 0: not built): stored entries incl. padding, padding entries,
- * and whether the two-phase product is in use (1: products in column-block order, then segment sums — tiles.hpp; 0: the
- * one-phase kernel that gathers x per entry, MISPEC_SPMV_TILES=onephase). */
-int mispec_csr_tiles_info(const mispec_csr* A, int64_t* segments, int64_t* entries, int64_t* padding, int* two_phase);
+ * chunks (runs of <= 1024 entries of one tile, the unit between two barriers of the kernel). */
+int mispec_csr_tiles_info(const mispec_csr* A, int64_t* segments, int64_t* entries, int64_t* padding, int64_t* chunks);
 /* Wall-clock seconds of the host stages of the last mispec_csr_upload / mispec_csr_from_triangle on the calling thread:
  * [0] the whole call, [1] triangle -> full matrix, [2] validation + local row pointers, [3] index formats (offset codes, diagonal
  * storage) incl. the H2D copies of the CSR arrays, [4] far-gather statistics + reordering, [5] tile image on the host, [6] its

@@ -259,10 +259,10 @@ class _DeviceMatrix:
         return float(lib().mispec_csr_spmv_bytes(self.h, 1))
 
     def tiles_info(self):
-        """{segments, entries, padding, two_phase} of the column-blocked tile format (segments = 0: not built)."""
-        a, b, c, d = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int(0)
+        """{segments, entries, padding, chunks} of the column-blocked tile format (segments = 0: not built)."""
+        a, b, c, d = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
         check(lib().mispec_csr_tiles_info(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
-        return {"segments": a.value, "entries": b.value, "padding": c.value, "two_phase": bool(d.value)}
+        return {"segments": a.value, "entries": b.value, "padding": c.value, "chunks": d.value}
 
     def reorder(self, method="rcm"):
         """Symmetric reordering of the stored matrix (mispec_csr_reorder): "rcm" always, "auto" only when it pays.  Returns

@@ -883,11 +883,10 @@ mispec_csr* upload_rows(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const i
         // MISPEC_REORDER = auto (default) | rcm | none: an unsharded square matrix whose gathers are scattered (more than a
         // quarter of the entries further than kFarWindow from the diagonal, and x larger than an L2 slice) is reordered
         // at ingest when reverse Cuthill-McKee localises them (reorder.hip)
-        // MISPEC_SPMV_TILES = auto (default) | 0 | 1 | onephase: the column-blocked tile format for scattered patterns that stay
-        // scattered (decided below, after the reordering attempt; "onephase" = forced, with the gathering one-phase kernel)
+        // MISPEC_SPMV_TILES = auto (default) | 0 | 1: the column-blocked tile format for scattered patterns that stay
+        // scattered (decided below, after the reordering attempt)
         const char* tmode = getenv("MISPEC_SPMV_TILES");
-        const bool tiles_off = tmode && std::strcmp(tmode, "0") == 0;
-        const bool tiles_force = tmode && (std::strcmp(tmode, "1") == 0 || std::strcmp(tmode, "onephase") == 0);
+        const bool tiles_off = tmode && std::strcmp(tmode, "0") == 0, tiles_force = tmode && std::strcmp(tmode, "1") == 0;
         const char* mode = getenv("MISPEC_REORDER");
         const bool off = mode && std::strcmp(mode, "none") == 0;
         const bool force = mode && std::strcmp(mode, "rcm") == 0;
@@ -1575,7 +1574,7 @@ extern "C" double mispec_csr_spmv_bytes(const mispec_csr* A, int stored)
     return stored ? A->stored_bytes() : A->algorithmic_bytes();
 }
 
-extern "C" int mispec_csr_tiles_info(const mispec_csr* A, int64_t* segments, int64_t* entries, int64_t* padding, int* two_phase)
+extern "C" int mispec_csr_tiles_info(const mispec_csr* A, int64_t* segments, int64_t* entries, int64_t* padding, int64_t* chunks)
 {
     return guarded([&] {
         MISPEC_REQUIRE(A, "mispec_csr_tiles_info: NULL argument");
@@ -1585,8 +1584,8 @@ extern "C" int mispec_csr_tiles_info(const mispec_csr* A, int64_t* segments, int
             *entries = A->tiles.entries;
         if (padding)
             *padding = A->tiles.padding;
-        if (two_phase)
-            *two_phase = A->tiles.two_phase ? 1 : 0;
+        if (chunks)
+            *chunks = A->tiles.nchunks;
     });
 }
 

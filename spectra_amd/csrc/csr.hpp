@@ -73,16 +73,9 @@ struct mispec_csr
     {
         if (format == 2)
             return 8.0 * double(ndia) * double(local_rows()) + 8.0 * double(n_cols) + 8.0 * double(local_rows());
-        if (format == 3)
-        {
-            // one-phase: 12 bytes per stored entry (padding included) + the chunk table; x counted once like everywhere.
-            // two-phase: value 8 + column 2 read and product 8 written by phase 1, product 8 + row/run 2 read by phase 2 = 28 per
-            // entry, the chunk table read by both (+ 12 bytes per chunk for phase 1's order and absolute offsets)
-            const double per_entry = tiles.two_phase ? 28.0 : 12.0;
-            const double per_chunk = tiles.two_phase ? 28.0 : 8.0;
-            return per_entry * double(tiles.entries) + per_chunk * double(tiles.nchunks) + 12.0 * double(tiles.nseg) + 8.0 * double(n_cols) +
+        if (format == 3)  // 12 bytes per stored entry (padding included) + the chunk table; x counted once like everywhere
+            return 12.0 * double(tiles.entries) + 8.0 * double(tiles.nchunks) + 12.0 * double(tiles.nseg) + 8.0 * double(n_cols) +
                    8.0 * double(local_rows());
-        }
         const double per_entry = format == 1 ? 9.0 : 12.0;
         return per_entry * double(nnz) + 4.0 * double(local_rows() + 1) + 8.0 * double(n_cols) + 8.0 * double(local_rows());
     }

@@ -20,7 +20,13 @@
 // added in ascending column order — the CSR storage order — and, rounded individually, the result is BIT-IDENTICAL to the
 // CSR kernels and to the oracle's row-dot.  One barrier per <= 1024 entries; the next chunk's entries are in flight while
 // the current one is gathered and accumulated.
-// Bound: HBM for the 12 nnz bytes of the stream + L2 for the gathers.
+// Bound: the gather rate.  Round 3 measured what a device-wide stream of random 8-byte gathers reaches when EVERY gather hits
+// the L2 (a two-phase "propagation blocking" variant whose first phase did nothing but stream values in column-block-major order,
+// gather x from one or two 512 KiB blocks and stream the products out: 150 M gathers in 1.59 ms, profiles/r05d_*): ~95 G gathers/s,
+// i.e. 2.7 clocks per gather and CU — each one moves a 128-byte line from the L2 to the L1.  This kernel's 1.31-1.36 ms for the
+// same 150 M gathers (~110 G/s) sits on that same limit whatever its L2 hit rate; only x staged in LDS (<= 16 Ki columns per
+// block, hence tiles of ~25-200 entries and a different second phase) would lift it.  The two-phase variants (2.38 / 2.11 ms
+// in total) were removed again.
 #include "tiles.hpp"
 #include "csr.hpp"
 
@@ -266,27 +272,12 @@ __device__ __forceinline__ double rounded_add(double a, double b)
     return s;
 }
 
-// ---- one-phase kernel: gathers x per entry --------------------------------------------------------------------------------
-// PROD = false: v = matrix value, product formed here with a gather from x.  PROD = true (phase 2 of the two-phase product): v =
-// the product phase 1 left at the entry's position, `meta` = the 16-bit row/run half of the index, x unused.
-template <bool PROD>
-struct TileMeta
-{
-    using type = uint32_t;
-};
-template <>
-struct TileMeta<true>
-{
-    using type = uint16_t;
-};
-
-template <bool EPI, bool PROD>
+template <bool EPI>
 __global__ __launch_bounds__(kTileThreads) void k_spmv_tiles(const int64_t* __restrict__ seg_entry, const int32_t* __restrict__ seg_chunk,
                                                     const TileChunk* __restrict__ chunks, const double* __restrict__ val,
-                                                    const typename TileMeta<PROD>::type* __restrict__ idx, const double* __restrict__ x,
+                                                    const uint32_t* __restrict__ idx, const double* __restrict__ x,
                                                     double* __restrict__ y, int64_t nrows, int nblocks256, int nseg, SpmvEpilogue epi)
 {
-    using meta_t = typename TileMeta<PROD>::type;
     __shared__ double acc[kTileRows];  // 64 KiB with the default geometry: two workgroups per CU
     if (EPI && epi.status && *epi.status != 0)
         return;
@@ -300,7 +291,7 @@ __global__ __launch_bounds__(kTileThreads) void k_spmv_tiles(const int64_t* __re
     const int c0 = seg_chunk[seg], c1 = seg_chunk[seg + 1];
     const int64_t base = seg_entry[seg];
     double v[kPer], nv[kPer];
-    meta_t id[kPer], nid[kPer];
+    uint32_t id[kPer], nid[kPer];
     int off = (c0 < c1) ? chunks[c0].offset : 0;
 #pragma unroll
     for (int k = 0; k < kPer; k++)
@@ -329,21 +320,11 @@ __global__ __launch_bounds__(kTileThreads) void k_spmv_tiles(const int64_t* __re
 #pragma unroll
         for (int k = 0; k < kPer; k++)
         {
-            if (PROD)
-            {
-                const bool live = k * kTileThreads + tid < count;
-                run[k] = live ? int(id[k] & meta_t(kTileMaxRun)) : 0;
-                rowk[k] = int(id[k] >> kTileRunBits) & (kTileRows - 1);
-                p[k] = live ? v[k] : 0.0;
-            }
-            else
-            {
-                const bool live = (k * kTileThreads + tid < count) && uint32_t(id[k]) != kTileSkip;
-                run[k] = live ? int(uint32_t(id[k]) & uint32_t(kTileMaxRun)) : 0;
-                rowk[k] = int(uint32_t(id[k]) >> (kTileColBits + kTileRunBits)) & (kTileRows - 1);
-                const int64_t col = live ? col0 + int64_t((uint32_t(id[k]) >> kTileRunBits) & uint32_t(kTileCols - 1)) : col0;
-                p[k] = live ? rounded_product(v[k], x[col]) : 0.0;
-            }
+            const bool live = (k * kTileThreads + tid < count) && id[k] != kTileSkip;
+            run[k] = live ? int(id[k] & uint32_t(kTileMaxRun)) : 0;
+            rowk[k] = int(id[k] >> (kTileColBits + kTileRunBits)) & (kTileRows - 1);
+            const int64_t col = live ? col0 + int64_t((id[k] >> kTileRunBits) & uint32_t(kTileCols - 1)) : col0;
+            p[k] = live ? rounded_product(v[k], x[col]) : 0.0;
         }
 #pragma unroll
         for (int k = 0; k < kPer; k++)
@@ -408,60 +389,6 @@ __global__ __launch_bounds__(kTileThreads) void k_spmv_tiles(const int64_t* __re
     }
 }
 
-// ---- two-phase product, phase 1: prod[e] = val[e] * x[column of e], chunks taken in COLUMN-BLOCK order ---------------------------
-// A persistent grid walks the block-sorted chunk list with a grid stride, so the chunks in flight at any moment belong to one or
-// two neighbouring column blocks: every XCD's L2 then holds the 0.5-1 MiB of x all its workgroups are gathering from, and x is
-// read from memory once per XCD instead of once per entry.  A chunk is one contiguous run of <= 1024 entries: values (8 B) and
-// 16-bit columns in, products out, all streamed; the products are rounded on their own, so phase 2 adds exactly what the
-// one-phase kernel adds.
-constexpr int kProdThreads = 512;
-__global__ __launch_bounds__(kProdThreads) void k_tile_products(const int32_t* __restrict__ order, int nchunks, const int64_t* __restrict__ chunk_abs,
-                                                                const TileChunk* __restrict__ chunks, const double* __restrict__ val,
-                                                                const uint16_t* __restrict__ col16, const double* __restrict__ x,
-                                                                double* __restrict__ prod, const int* status)
-{
-    if (status && *status != 0)
-        return;
-    constexpr int kPer = kTileChunk / kProdThreads;
-    const int tid = threadIdx.x;
-    for (int i = int(blockIdx.x); i < nchunks; i += int(gridDim.x))
-    {
-        const int c = order[i];
-        const TileChunk ch = chunks[c];
-        const int64_t base = chunk_abs[c];
-        const int64_t col0 = int64_t(ch.colblock) << kTileColBits;
-        double v[kPer];
-        unsigned cc[kPer];
-#pragma unroll
-        for (int k = 0; k < kPer; k++)
-        {
-            const int e = min(k * kProdThreads + tid, int(ch.count) - 1);  // lanes past the end repeat the last entry (result dropped)
-            v[k] = __builtin_nontemporal_load(val + base + e);
-            cc[k] = __builtin_nontemporal_load(col16 + base + e);
-        }
-        double xv[kPer];
-#pragma unroll
-        for (int k = 0; k < kPer; k++)
-            xv[k] = x[col0 + cc[k]];
-#pragma unroll
-        for (int k = 0; k < kPer; k++)
-            if (k * kProdThreads + tid < int(ch.count))
-                __builtin_nontemporal_store(rounded_product(v[k], xv[k]), prod + base + k * kProdThreads + tid);
-    }
-}
-
-// idx (32 bit) -> the two 16-bit halves of the two-phase image.  Padding entries become orphan continuations (run 0, product 0)
-__global__ __launch_bounds__(256) void k_tiles_split(const uint32_t* __restrict__ idx, int64_t n, uint16_t* __restrict__ col16,
-                                                     uint16_t* __restrict__ rowrun)
-{
-    for (int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x; e < n; e += int64_t(gridDim.x) * 256)
-    {
-        const uint32_t id = idx[e];
-        const bool skip = id == kTileSkip;
-        col16[e] = skip ? uint16_t(0) : uint16_t((id >> kTileRunBits) & uint32_t(kTileCols - 1));
-        rowrun[e] = skip ? uint16_t(0) : uint16_t(((id >> (kTileColBits + kTileRunBits)) << kTileRunBits) | (id & uint32_t(kTileMaxRun)));
-    }
-}
 }  // namespace
 
 void upload_tiles(const HostTiles& H, hipStream_t stream, DevTiles& D)
@@ -480,34 +407,6 @@ void upload_tiles(const HostTiles& H, hipStream_t stream, DevTiles& D)
     D.nchunks = int64_t(H.chunks.size());
     D.padding = H.padding;
     D.ncb = H.ncb;
-    // the two-phase image: chunk table in column-block order (a counting sort of <= a few 100k chunks on the host) and the split
-    // index halves (device).  MISPEC_SPMV_TILES=onephase keeps the one-phase kernel (and skips the 10 extra bytes per entry).
-    const char* mode = getenv("MISPEC_SPMV_TILES");
-    D.two_phase = !(mode && std::strcmp(mode, "onephase") == 0);
-    if (D.two_phase)
-    {
-        std::vector<int64_t> abs(H.chunks.size());
-        std::vector<int32_t> order(H.chunks.size()), start(size_t(H.ncb) + 1, 0);
-        for (int64_t s = 0; s < D.nseg; s++)
-            for (int32_t c = H.seg_chunk[size_t(s)]; c < H.seg_chunk[size_t(s) + 1]; c++)
-            {
-                abs[size_t(c)] = H.seg_entry[size_t(s)] + H.chunks[size_t(c)].offset;
-                start[size_t(H.chunks[size_t(c)].colblock) + 1]++;
-            }
-        for (int64_t b = 0; b < H.ncb; b++)
-            start[size_t(b) + 1] += start[size_t(b)];
-        for (size_t c = 0; c < H.chunks.size(); c++)
-            order[size_t(start[size_t(H.chunks[c].colblock)]++)] = int32_t(c);
-        up(D.chunk_abs, abs);
-        up(D.cb_order, order);
-        MISPEC_HIP(hipStreamSynchronize(stream));  // abs / order go out of scope
-        D.col16.alloc(H.idx.size());
-        D.rowrun.alloc(H.idx.size());
-        D.prod.alloc(H.val.size());
-        MISPEC_HIP(hipMemsetAsync(D.prod.p, 0, D.prod.n * sizeof(double), stream));
-        hipLaunchKernelGGL(k_tiles_split, dim3(4096), dim3(256), 0, stream, D.idx.p, int64_t(H.idx.size()), D.col16.p, D.rowrun.p);
-        MISPEC_HIP(hipGetLastError());
-    }
     MISPEC_HIP(hipStreamSynchronize(stream));
 }
 
@@ -516,53 +415,14 @@ void launch_spmv_tiles(const DevTiles& T, hipStream_t stream, const double* x, d
 {
     const SpmvEpilogue e = epi ? *epi : SpmvEpilogue{};
     const dim3 grid(static_cast<unsigned>(T.nseg)), block(kTileThreads);
-    if (T.two_phase)
-    {
-        // phase 1 on a persistent grid (four 512-thread workgroups per CU), phase 2 one workgroup per segment; an event pair times
-        // the two launches together (start of the first, end of the second)
-        static int num_cu = 0;
-        if (!num_cu)
-        {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            MISPEC_HIP(hipGetDevice(&dev));
-            MISPEC_HIP(hipGetDeviceProperties(&prop, dev));
-            num_cu = prop.multiProcessorCount;
-        }
-        const dim3 g1(static_cast<unsigned>(std::min<int64_t>(int64_t(num_cu) * 4, T.nchunks))), b1(kProdThreads);
-        const int* status = epi ? e.status : nullptr;
-        if (ev_start && ev_stop)
-            hipExtLaunchKernelGGL(k_tile_products, g1, b1, 0, stream, ev_start, nullptr, 0, T.cb_order.p, int(T.nchunks), T.chunk_abs.p, T.chunks.p,
-                                  T.val.p, T.col16.p, x, T.prod.p, status);
-        else
-            hipLaunchKernelGGL(k_tile_products, g1, b1, 0, stream, T.cb_order.p, int(T.nchunks), T.chunk_abs.p, T.chunks.p, T.val.p, T.col16.p, x,
-                               T.prod.p, status);
-#define MISPEC_TILES2(E)                                                                                                              \
-    do                                                                                                                                \
-    {                                                                                                                                 \
-        if (ev_start && ev_stop)                                                                                                      \
-            hipExtLaunchKernelGGL((k_spmv_tiles<E, true>), grid, block, 0, stream, nullptr, ev_stop, 0, T.seg_entry.p, T.seg_chunk.p, T.chunks.p, \
-                                  T.prod.p, T.rowrun.p, x, y, nrows, nblocks256, int(T.nseg), e);                                     \
-        else                                                                                                                          \
-            hipLaunchKernelGGL((k_spmv_tiles<E, true>), grid, block, 0, stream, T.seg_entry.p, T.seg_chunk.p, T.chunks.p, T.prod.p,   \
-                               T.rowrun.p, x, y, nrows, nblocks256, int(T.nseg), e);                                                  \
-    } while (0)
-        if (epi)
-            MISPEC_TILES2(true);
-        else
-            MISPEC_TILES2(false);
-#undef MISPEC_TILES2
-        MISPEC_HIP(hipGetLastError());
-        return;
-    }
 #define MISPEC_TILES(E)                                                                                                     \
     do                                                                                                                      \
     {                                                                                                                       \
         if (ev_start && ev_stop)                                                                                            \
-            hipExtLaunchKernelGGL((k_spmv_tiles<E, false>), grid, block, 0, stream, ev_start, ev_stop, 0, T.seg_entry.p, T.seg_chunk.p, \
+            hipExtLaunchKernelGGL((k_spmv_tiles<E>), grid, block, 0, stream, ev_start, ev_stop, 0, T.seg_entry.p, T.seg_chunk.p, \
                                   T.chunks.p, T.val.p, T.idx.p, x, y, nrows, nblocks256, int(T.nseg), e);                  \
         else                                                                                                                \
-            hipLaunchKernelGGL((k_spmv_tiles<E, false>), grid, block, 0, stream, T.seg_entry.p, T.seg_chunk.p, T.chunks.p, T.val.p, \
+            hipLaunchKernelGGL((k_spmv_tiles<E>), grid, block, 0, stream, T.seg_entry.p, T.seg_chunk.p, T.chunks.p, T.val.p, \
                                T.idx.p, x, y, nrows, nblocks256, int(T.nseg), e);                                          \
     } while (0)
     if (epi)

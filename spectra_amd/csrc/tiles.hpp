@@ -28,7 +28,6 @@ constexpr int kTileThreads = MISPEC_TILE_THREADS;   // threads of the workgroup 
 constexpr int kTileCols = 1 << kTileColBits;
 constexpr int kTileRunBits = 32 - MISPEC_TILE_ROW_BITS - MISPEC_TILE_COL_BITS;  // run length of a head entry: the bits that are left
 constexpr int kTileMaxRun = (1 << kTileRunBits) - 1;
-static_assert(kTileRowBits + kTileRunBits <= 16 && kTileColBits <= 16, "the two-phase image keeps row+run and column in 16 bits each");
 #ifndef MISPEC_TILE_CHUNK
 #define MISPEC_TILE_CHUNK 1024
 #endif
@@ -70,16 +69,6 @@ struct DevTiles
     DevBuf<TileChunk> chunks;
     DevBuf<double> val;
     DevBuf<uint32_t> idx;
-    // Two-phase image of the same tiles (round 3, "propagation blocking": Beamer, Asanovic, Patterson 2017), derived on the device
-    // at upload.  Phase 1 walks the CHUNKS IN COLUMN-BLOCK ORDER (cb_order), so that at any moment the whole device gathers from
-    // one or two 512 KiB pieces of x, and writes every product to `prod` at its entry's position; phase 2 is the segment sweep of
-    // the one-phase kernel reading products instead of gathering.  The 32-bit index is split into the half each phase needs.
-    DevBuf<uint16_t> col16;      // column inside the block (phase 1)
-    DevBuf<uint16_t> rowrun;     // row inside the segment << run bits | run length (phase 2); padding entries: 0 (an orphan continuation)
-    DevBuf<double> prod;         // scratch: one product per entry
-    DevBuf<int64_t> chunk_abs;   // absolute first entry of every chunk
-    DevBuf<int32_t> cb_order;    // chunk indices sorted by column block (stable: ascending segment inside a block)
-    bool two_phase = false;
     int64_t nseg = 0, entries = 0, nchunks = 0, padding = 0, ncb = 0;
     bool present() const { return nseg > 0; }
     void swap(DevTiles& o)
@@ -89,12 +78,6 @@ struct DevTiles
         chunks.swap(o.chunks);
         val.swap(o.val);
         idx.swap(o.idx);
-        col16.swap(o.col16);
-        rowrun.swap(o.rowrun);
-        prod.swap(o.prod);
-        chunk_abs.swap(o.chunk_abs);
-        cb_order.swap(o.cb_order);
-        std::swap(two_phase, o.two_phase);
         std::swap(ncb, o.ncb);
         std::swap(nseg, o.nseg);
         std::swap(entries, o.entries);

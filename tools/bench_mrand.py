@@ -1,5 +1,5 @@
 """Scattered-pattern SpMV (SURVEY.md 8d M-rand) at n = argv[1] (default 1e7): the tile kernel (format 3) and the int32 CSR kernel
-on the same matrix, stand-alone.  One JSON line.  MISPEC_SPMV_TILES (auto | 1 | onephase) is read from the environment."""
+on the same matrix, stand-alone.  One JSON line.  MISPEC_SPMV_TILES (auto | 1 | 0) is read from the environment."""
 import json
 import os
 import sys
