@@ -332,6 +332,13 @@ public:
         return X;
     }
 
+    // The same product written into caller-provided host memory (local_rows() x Y.cols(), column-major, no intermediate matrix)
+    void ritz_vectors_into(const Matrix& Y, Scalar* X_host) const
+    {
+        if (Y.cols() > 0)
+            internal::check(mispec_fac_ritz_vectors(m_fac.get(), Y.data(), static_cast<int>(Y.cols()), X_host, nullptr));
+    }
+
     // Same product left in HBM only (valid until the next call); returns the device pointer, leading dimension in *ld.
     const Scalar* ritz_vectors_device(const Matrix& Y, Index* ld = nullptr) const
     {

@@ -62,6 +62,14 @@ public:
         return res;
     }
     Matrix eigenvectors() const override { return SymGEigsSolver<OpType, BOpType, GEigsMode::Cholesky>::eigenvectors(this->m_nev); }
+    Index eigenvectors_to(Scalar* out_host, Index nvec) const override  // the back-transformed vectors, copied out
+    {
+        const Matrix res = eigenvectors(nvec);
+        for (Index i = 0; i < res.cols(); i++)
+            for (Index r = 0; r < res.rows(); r++)
+                out_host[static_cast<std::size_t>(i) * static_cast<std::size_t>(res.rows()) + static_cast<std::size_t>(r)] = res(r, i);
+        return res.cols();
+    }
 };
 
 // Partial specialization for mode = GEigsMode::RegularInverse (reference :224-238)

@@ -853,7 +853,7 @@ class SymEigsSolver:
         if not to_host:
             check(lib().mispec_symeigs_eigenvectors(self.h, nvec, None, C.byref(cnt)))
             return cnt.value
-        out = np.zeros((self.local_rows(), max(min(nvec, self.nev), 1)), order="F")
+        out = np.empty((self.local_rows(), max(min(nvec, self.nev), 1)), order="F")  # filled by the library's host threads
         check(lib().mispec_symeigs_eigenvectors(self.h, nvec, _dp(out), C.byref(cnt)))
         return np.asfortranarray(out[:, :cnt.value])
 

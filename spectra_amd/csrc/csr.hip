@@ -394,7 +394,11 @@ __global__ __launch_bounds__(256) void k_spmv_dia(DiaArgs da, const double* __re
 // The same product with the x entries of a row-block staged through LDS: the offsets cluster, so a block of 256 rows reads
 // a few contiguous windows of x (coalesced, once) instead of one 8-byte load per row and diagonal through the L1.
 // NG = groups of eight diagonals whose values a thread keeps in registers.
-template <bool EPI, int NG, int NCW = 8>  // NCW: registers for window entries (>= number of windows)
+// POST (one-sweep Lanczos steps only, fac.hip lanczos_step_lagged): the input is the UN-normalised residual f and the division
+// by beta = |f| (read from the step state) is applied to the row sums and to the epilogue's v instead of to every window entry —
+// w = (A f)/beta - beta v_prev, alpha partial = (f/beta) w — together with the step start that k_scale_step otherwise does
+// (H(i,i-1) = beta, the beta < sqrt(eps) stop): no scaling pass and no scaled copy of f, two divisions per row.
+template <bool EPI, int NG, int NCW = 8, bool POST = false>  // NCW: registers for window entries (>= number of windows)
 __global__ __launch_bounds__(256) void k_spmv_dia_win(DiaArgs da, mispec_dia_windows w, const double* __restrict__ x,
                                                       double* __restrict__ y, int64_t nrows, int nblocks, SpmvEpilogue epi)
 {
@@ -408,6 +412,26 @@ __global__ __launch_bounds__(256) void k_spmv_dia_win(DiaArgs da, mispec_dia_win
     if (EPI && epi.status && *epi.status != 0)
         return;
     const int tid = threadIdx.x;
+    double beta = 1.0;
+    if (POST)
+    {
+        // every block takes the same decision from the same beta; one thread records it (Lanczos.h:99-128 without the restart branch)
+        StepState* st = static_cast<StepState*>(epi.post_scale_state);
+        beta = st->beta;
+        const bool first = (lmap == 0 && tid == 0);
+        if (beta < epi.post_scale_eps_sqrt)
+        {
+            if (first)
+            {
+                st->status = kStepSmallBeta;
+                st->stop_step = epi.post_scale_step;
+                st->stop_count = 0;
+            }
+            return;
+        }
+        if (first)
+            st->subd[epi.post_scale_step - 1] = beta;
+    }
     const int64_t row0 = int64_t(lb) * 256;
     const int nr = int(min(int64_t(256), nrows - row0));
     int64_t vstride;
@@ -426,9 +450,11 @@ __global__ __launch_bounds__(256) void k_spmv_dia_win(DiaArgs da, mispec_dia_win
         if (epi.v_prev)
         {
             vprev_early = epi.v_prev[row0 + tid];
-            hprev_early = epi.h_prev_dev ? *epi.h_prev_dev : epi.h_prev;
+            hprev_early = POST ? beta : (epi.h_prev_dev ? *epi.h_prev_dev : epi.h_prev);
         }
         vrow_early = epi.v_rows[row0 + tid];
+        if (POST)
+            vrow_early = vrow_early / beta;  // Lanczos.h:106
     }
     const int64_t g0 = da.row_begin + row0;
     // x windows -> LDS.  A window is 256 + span entries: two per thread, ALL loaded before the first LDS write.  (Written as
@@ -493,7 +519,7 @@ __global__ __launch_bounds__(256) void k_spmv_dia_win(DiaArgs da, mispec_dia_win
         if (tid < nr)
         {
             const int64_t row = row0 + tid;
-            double yv = acc;
+            double yv = POST ? acc / beta : acc;
             if (epi.v_prev)
                 yv -= (early ? hprev_early : (epi.h_prev_dev ? *epi.h_prev_dev : epi.h_prev)) *
                       (early ? vprev_early : epi.v_prev[row]);  // Lanczos.h:139
@@ -1065,6 +1091,8 @@ void interior_blocks(const mispec_csr& A, int64_t col_lo, int64_t col_hi, int& f
 
 int spmv_rows_per_block() { return 256; }
 
+bool spmv_can_post_scale(const mispec_csr& A) { return A.spmv_format() == 2 && A.dia_win.nc > 0; }
+
 void launch_to_stored_order(const mispec_csr& A, const double* src, double* dst)
 {
     const int64_t n = A.local_rows();
@@ -1124,6 +1152,8 @@ void launch_spmv_raw(const mispec_csr& A, const double* x_dev, double* y_dev, co
         return;
     MISPEC_REQUIRE(block_first >= 0 && block_first + block_count <= all_blocks, "SpMV: row-block range out of bounds");
     const int nblocks = block_count;  // the kernels map blockIdx onto [first_block, first_block + nblocks)
+    MISPEC_REQUIRE(!(epi && epi->post_scale_state) || spmv_can_post_scale(A),
+                   "SpMV: a post-scaled step start was requested for a matrix that cannot take it");
     const int per = (nblocks + 7) >> 3;
     const int threads = spmv_rows_per_block();
     const dim3 grid(unsigned(per * 8)), block(static_cast<unsigned>(threads));
@@ -1177,7 +1207,40 @@ void launch_spmv_raw(const mispec_csr& A, const double* x_dev, double* y_dev, co
         else                         \
             MISPEC_DIA_WIN(E, 4);    \
     } while (0)
-            if (epi)
+            if (epi && e.post_scale_state)
+            {
+#define MISPEC_DIA_WIN_POST_W(G, W)                                                                                                    \
+    do                                                                                                                                 \
+    {                                                                                                                                  \
+        if (ev_start && ev_stop)                                                                                                       \
+            hipExtLaunchKernelGGL((k_spmv_dia_win<true, G, W, true>), grid, block, lds, A.ctx->stream, ev_start, ev_stop, 0, da, A.dia_win, \
+                                  x_dev, y_dev, nloc, nblocks, e);                                                                     \
+        else                                                                                                                           \
+            hipLaunchKernelGGL((k_spmv_dia_win<true, G, W, true>), grid, block, lds, A.ctx->stream, da, A.dia_win, x_dev, y_dev, nloc, \
+                               nblocks, e);                                                                                            \
+    } while (0)
+#define MISPEC_DIA_WIN_POST(G)               \
+    do                                       \
+    {                                        \
+        if (A.dia_win.nc <= 4)               \
+            MISPEC_DIA_WIN_POST_W(G, 4);     \
+        else if (A.dia_win.nc <= 6)          \
+            MISPEC_DIA_WIN_POST_W(G, 6);     \
+        else                                 \
+            MISPEC_DIA_WIN_POST_W(G, 8);     \
+    } while (0)
+                if (ng == 1)
+                    MISPEC_DIA_WIN_POST(1);
+                else if (ng == 2)
+                    MISPEC_DIA_WIN_POST(2);
+                else if (ng == 3)
+                    MISPEC_DIA_WIN_POST(3);
+                else
+                    MISPEC_DIA_WIN_POST(4);
+#undef MISPEC_DIA_WIN_POST
+#undef MISPEC_DIA_WIN_POST_W
+            }
+            else if (epi)
                 MISPEC_DIA_WIN_G(true);
             else
                 MISPEC_DIA_WIN_G(false);

@@ -98,7 +98,15 @@ struct SpmvEpilogue
     const int* status = nullptr;      // if set, the launch is a no-op unless *status == 0
     double* partials = nullptr;       // one double per block, deterministic second stage elsewhere
     int first_block = 0;              // set by the launcher: first 256-row block this launch covers
+    // One-sweep Lanczos steps on diagonal storage (spmv_can_post_scale): x_dev is the un-normalised residual f, v_rows = f; the
+    // kernel divides the row sums and v by beta = StepState::beta, uses beta as H(i,i-1), records it and takes the
+    // beta < sqrt(eps) stop of k_scale_step (csr.hip k_spmv_dia_win<.., POST>).
+    void* post_scale_state = nullptr;  // StepState* (krylov.hpp)
+    int post_scale_step = 0;
+    double post_scale_eps_sqrt = 0.0;
 };
+// true when launch_spmv_raw(A, ...) honours SpmvEpilogue::post_scale_state (else the caller scales with k_scale_step)
+bool spmv_can_post_scale(const ::mispec_csr& A);
 // Rows per SpMV workgroup (one thread per row in the reduction phase)
 int spmv_rows_per_block();
 inline int spmv_num_blocks(int64_t local_rows)

@@ -89,6 +89,8 @@ struct mispec_fac
     PinnedBuf<double> h_H;
     PinnedBuf<StepState> h_state;  // its pinned host mirror
     PinnedBuf<double> h_red, h_small, h_x, h_y;
+    PinnedBuf<double> h_stage[2];  // pinned staging of download_columns (allocated on first use)
+    hipEvent_t ev_stage[2] = {nullptr, nullptr};
     bool device_steps = true;      // MISPEC_HOST_STEPS=1 forces the host-synchronous path
     // Opt-in one-sweep variant of the Lanczos steps (mispec_fac_set_orth_mode / MISPEC_ORTH=onesweep): the
     // correction of a step rides on the next step's pass over V.  Default off = the reference's control flow.
@@ -111,6 +113,7 @@ struct mispec_fac
     // The matrix is stored reordered (P A P', reorder.hip) and this factorisation works in that order: start vectors are
     // permuted on the way in, V / f / Ritz vectors on the way out; plain operators only (product, generalized and
     // Cholesky operators use the order-preserving product instead)
+    int post_scale_step = 0;  // > 0 while apply_op is to let the SpMV take the un-normalised residual of that one-sweep step
     bool perm_mode = false;
     bool x_original = false;  // the columns of X have been put back into the caller's order
     DevBuf<double> pscratch;
@@ -146,6 +149,9 @@ struct mispec_fac
             }
         for (auto e : ev_pool)
             (void) hipEventDestroy(e);
+        for (auto e : ev_stage)
+            if (e)
+                (void) hipEventDestroy(e);
         if (ev_x_ready)
             (void) hipEventDestroy(ev_x_ready);
         if (ev_x_landed)
@@ -514,6 +520,12 @@ void apply_op(mispec_fac& F, const double* x_loc, double* y_loc, bool lanczos_ep
             epi.h_prev_dev = h_prev_dev;
             epi.status = status;
             epi.partials = F.alpha_partials.p;
+            if (F.post_scale_step > 0)
+            {
+                epi.post_scale_state = F.d_state.p;
+                epi.post_scale_step = F.post_scale_step;
+                epi.post_scale_eps_sqrt = std::sqrt(kEps);
+            }
             if (overlap)
                 overlapped_spmv(F, *last, x, y_loc, &epi, e0, e1);
             else
@@ -959,11 +971,24 @@ void lanczos_step_lagged(mispec_fac& F, int i, bool last)
 {
     StepState* st = F.d_state.p;
     double* v = F.col(i);
+    // Column i is written by the pass below (from f, with the pending correction); until then only the product needs f / beta.
+    // On diagonal storage the SpMV takes the un-normalised f and divides its row sums instead (csr.hpp post_scale_state): the
+    // scaling pass and its copy of f disappear.  Other formats: k_scale_step, as in the reference flow.
+    const bool post = F.A && !F.A2 && !F.perm_mode && spmv_can_post_scale(*F.A);
+    if (post)
     {
-        Timed t(F, FAM_SCALE);
-        launch_scale_step(*F.ctx, F.f.p, v, F.ldv, st, i, std::sqrt(kEps));
+        F.post_scale_step = i;
+        apply_op(F, F.f.p, F.w.p, true, F.col(i - 1), 0.0, &st->subd[i - 1], &st->status);
+        F.post_scale_step = 0;
     }
-    apply_op(F, v, F.w.p, true, F.col(i - 1), 0.0, &st->subd[i - 1], &st->status);
+    else
+    {
+        {
+            Timed t(F, FAM_SCALE);
+            launch_scale_step(*F.ctx, F.f.p, v, F.ldv, st, i, std::sqrt(kEps));
+        }
+        apply_op(F, v, F.w.p, true, F.col(i - 1), 0.0, &st->subd[i - 1], &st->status);
+    }
 
     const int cur = i & 1;
     FinishArgs fin;
@@ -1308,6 +1333,55 @@ void update_f_after_compress(mispec_fac& F, double q_last, double h_sub)
     }
     reduce_to_host(F, nrec, 0, 0);
     F.beta = F.h_red.p[kSlotBeta];
+}
+
+// Device columns -> a pageable host matrix (the reference's eigenvectors() / matrix_V() return host matrices).  A direct
+// hipMemcpy into pageable memory runs at a few GB/s (the runtime stages it in small pieces and the first touch of a fresh
+// 1.6 GB allocation faults every page on one thread); here 64 MB pieces go D2H into two pinned buffers at PCIe rate while the host
+// threads copy the piece before into the caller's memory (first touch spread over the threads).
+void download_columns(mispec_fac& F, const double* src, int64_t ld_src, int64_t rows, int ncols, double* dst, int64_t ld_dst)
+{
+    if (rows <= 0 || ncols <= 0)
+        return;
+    constexpr int64_t kPiece = int64_t(8) << 20;  // doubles per piece (64 MB)
+    for (int b = 0; b < 2; b++)
+    {
+        if (F.h_stage[b].n < size_t(kPiece))
+            F.h_stage[b].alloc(size_t(kPiece));
+        if (!F.ev_stage[b])
+            MISPEC_HIP(hipEventCreateWithFlags(&F.ev_stage[b], hipEventDisableTiming));
+    }
+    struct Piece
+    {
+        double* dst;
+        int64_t count;
+    };
+    Piece pending[2] = {{nullptr, 0}, {nullptr, 0}};
+    const int nt = std::min(ingest_threads(), 32);
+    auto drain = [&](int b) {
+        if (!pending[b].dst)
+            return;
+        MISPEC_HIP(hipEventSynchronize(F.ev_stage[b]));
+        const double* from = F.h_stage[b].p;
+        double* to = pending[b].dst;
+        parallel_ranges(pending[b].count, nt, [&](int, int64_t lo, int64_t hi) { std::memcpy(to + lo, from + lo, size_t(hi - lo) * sizeof(double)); });
+        pending[b].dst = nullptr;
+    };
+    int b = 0;
+    for (int j = 0; j < ncols; j++)
+        for (int64_t r0 = 0; r0 < rows; r0 += kPiece)
+        {
+            const int64_t cnt = std::min(kPiece, rows - r0);
+            drain(b);  // this buffer's previous piece must be out before it is overwritten
+            MISPEC_HIP(hipMemcpyAsync(F.h_stage[b].p, src + int64_t(j) * ld_src + r0, size_t(cnt) * sizeof(double), hipMemcpyDeviceToHost, F.stream()));
+            MISPEC_HIP(hipEventRecord(F.ev_stage[b], F.stream()));
+            pending[b] = {dst + int64_t(j) * ld_dst + r0, cnt};
+            b ^= 1;
+            drain(b);  // while the piece just enqueued travels, copy the other buffer's
+        }
+    drain(0);
+    drain(1);
+    F.n_sync++;
 }
 
 }  // namespace
@@ -1952,8 +2026,7 @@ extern "C" int mispec_fac_ritz_vectors(mispec_fac* fac, const double* Y_host, in
             for (int j = 0; j < ncols; j++)
                 from_stored_order(F, F.X.p + int64_t(j) * F.ldv);  // rows back in the caller's order
         if (X_host && F.nloc)
-            MISPEC_HIP(hipMemcpy2DAsync(X_host, size_t(F.nloc) * sizeof(double), F.X.p, size_t(F.ldv) * sizeof(double),
-                                        size_t(F.nloc) * sizeof(double), size_t(ncols), hipMemcpyDeviceToHost, F.stream()));
+            download_columns(F, F.X.p, F.ldv, F.nloc, ncols, X_host, F.nloc);
         sync_stream(F);
         if (X_dev)
             *X_dev = F.X.p;

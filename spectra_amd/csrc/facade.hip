@@ -387,10 +387,7 @@ extern "C" int mispec_symeigs_eigenvectors(mispec_symeigs* s, int64_t nvec, doub
                 *ncols = solver.eigenvectors_on_device(Spectra::Index(nvec));
                 return 0;
             }
-            const auto X = solver.eigenvectors(Spectra::Index(nvec));
-            *ncols = X.cols();
-            if (X.size() > 0)
-                std::memcpy(out_host, X.data(), size_t(X.size()) * sizeof(double));
+            *ncols = solver.eigenvectors_to(out_host, Spectra::Index(nvec));  // straight into the caller's memory
             return 0;
         });
     });

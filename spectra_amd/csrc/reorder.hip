@@ -161,6 +161,81 @@ double far_fraction(int64_t n, const int32_t* rowptr, const int32_t* colind, con
     return total ? double(total_far) / double(total) : 0.0;
 }
 
+namespace {
+// The give-up test of rcm_order evaluated BEFORE anything serial is built, for a structurally symmetric pattern: a level-
+// synchronous breadth-first search from the vertex the ordering would start from (minimum degree, lowest index), the frontier
+// expanded by the host threads straight from the CSR rows.  The set of vertices of a level does not depend on the order in
+// which threads reach them, so the widths are those of the serial search.  Returns true (and the width) as soon as a level is
+// wider than `fraction` of the whole matrix with at least 4096 vertices reached — then no ordering can localise the gathers and
+// the seconds a graph copy, a degree sort and a full serial search of a 10M-row expander would cost are saved.
+bool expander_precheck(int64_t n, const int32_t* rowptr, const int32_t* colind, double fraction, int64_t* widest_out)
+{
+    if (n < 65536 || fraction <= 0.0)
+        return false;
+    const int nt = int(std::max<int64_t>(1, std::min<int64_t>(ingest_threads(), n / 65536)));
+    // start vertex: minimum degree without counting the diagonal, lowest index among equals (rcm_order's first seed)
+    std::vector<std::pair<int32_t, int64_t>> best(static_cast<size_t>(nt), {INT32_MAX, -1});
+    parallel_ranges(n, nt, [&](int t, int64_t b, int64_t e) {
+        std::pair<int32_t, int64_t> m{INT32_MAX, -1};
+        for (int64_t i = b; i < e; i++)
+        {
+            int32_t d = 0;
+            for (int32_t p = rowptr[i]; p < rowptr[i + 1]; p++)
+                d += (colind[p] != i);
+            if (d < m.first)
+                m = {d, i};
+        }
+        best[size_t(t)] = m;
+    });
+    std::pair<int32_t, int64_t> m{INT32_MAX, -1};
+    for (const auto& b : best)
+        if (b.second >= 0 && b.first < m.first)
+            m = b;
+    if (m.second < 0)
+        return false;
+    std::vector<uint8_t> seen(size_t(n), 0);
+    std::vector<int32_t> frontier{int32_t(m.second)}, next;
+    seen[size_t(m.second)] = 1;
+    int64_t reached = 1, widest = 1;
+    std::vector<std::vector<int32_t>> local(static_cast<size_t>(nt));
+    while (!frontier.empty())
+    {
+        const int64_t fsz = int64_t(frontier.size());
+        const int parts = int(std::max<int64_t>(1, std::min<int64_t>(nt, fsz / 256)));
+        for (auto& l : local)
+            l.clear();
+        parallel_ranges(fsz, parts, [&](int t, int64_t b, int64_t e) {
+            std::vector<int32_t>& out = local[size_t(t)];
+            for (int64_t k = b; k < e; k++)
+            {
+                const int32_t v = frontier[size_t(k)];
+                for (int32_t p = rowptr[v]; p < rowptr[v + 1]; p++)
+                {
+                    const int32_t u = colind[p];
+                    if (u != v && !__atomic_load_n(&seen[size_t(u)], __ATOMIC_RELAXED) &&
+                        __atomic_exchange_n(&seen[size_t(u)], uint8_t(1), __ATOMIC_RELAXED) == 0)
+                        out.push_back(u);
+                }
+            }
+        });
+        next.clear();
+        for (int t = 0; t < parts; t++)
+            next.insert(next.end(), local[size_t(t)].begin(), local[size_t(t)].end());
+        frontier.swap(next);
+        const int64_t width = int64_t(frontier.size());
+        reached += width;
+        widest = std::max(widest, width);
+        if (reached >= 4096 && double(widest) > fraction * double(n))
+        {
+            if (widest_out)
+                *widest_out = widest;
+            return true;
+        }
+    }
+    return false;
+}
+}  // namespace
+
 bool rcm_order(int64_t n, const int32_t* rowptr, const int32_t* colind, bool symmetric_pattern, double max_level_fraction,
                std::vector<int32_t>& perm, ReorderStats* stats)
 {
@@ -169,6 +244,17 @@ bool rcm_order(int64_t n, const int32_t* rowptr, const int32_t* colind, bool sym
         *stats = ReorderStats{};
     if (n <= 0)
         return true;
+    int64_t pre_widest = 0;
+    if (symmetric_pattern && expander_precheck(n, rowptr, colind, max_level_fraction, &pre_widest))
+    {
+        if (stats)
+        {
+            stats->gave_up = true;
+            stats->widest_level = pre_widest;
+            stats->first_component = n;
+        }
+        return false;
+    }
     const Graph g = build_graph(n, rowptr, colind, symmetric_pattern);
     std::vector<uint8_t> done(size_t(n), 0);
     Bfs s;

@@ -148,12 +148,11 @@ def test_automatic_reordering_at_ingest(ctx):
 def test_davidson_and_regular_inverse_use_the_callers_diagonal_on_a_reordered_matrix(ctx, monkeypatch):
     # the stored matrix of a reordered operator is P A P', so its i-th diagonal entry is A(perm[i], perm[i]); the
     # Davidson preconditioner / unit start vectors and the Jacobi preconditioner of the CG solve work in the CALLER's order and
-    # must not read that diagonal unpermuted.  A diagonal ramp makes the difference decisive: with the permuted diagonal the
-    # Davidson start vectors point at the wrong rows and the iteration counts blow up.
+    # must not read that diagonal unpermuted.  A diagonal ramp makes the difference decisive: with the permuted diagonal
+    # the preconditioner divides by the wrong entries and the iteration counts blow up.
     B = (0.02 * shuffled_stencil(24, seed=3)).tolil()    # weak coupling: the diagonal preconditioner is then nearly exact
     n = B.shape[0]
-    ramp = np.random.default_rng(9).permutation(n) + 1.0
-    B.setdiag(ramp)
+    B.setdiag(np.arange(1.0, n + 1.0))   # the reference's Davidson fixture: a_ii = i + 1 (test/DavidsonSymEigs.cpp:46-67)
     B = B.tocsr()
     k = 5
     out = {}
@@ -161,10 +160,11 @@ def test_davidson_and_regular_inverse_use_the_callers_diagonal_on_a_reordered_ma
         op = sa.SparseSymMatProd(sp.tril(B).tocsc(), ctx=ctx, reorder=mode)
         assert op.reordering() == mode
         eigs = sa.DavidsonSymEigsSolver(op, k)
-        nconv = eigs.compute(sa.SortRule.LargestAlge, maxit=100, tol=1e-7)   # |lambda| ~ 1.4e4: 1e-7 is ~1e-11 relative
+        # smallest eigenvalues: they live on the rows the solver's initial unit vectors e_0, e_1, ... point at
+        nconv = eigs.compute(sa.SortRule.SmallestAlge, maxit=100, tol=1e-9)
         assert nconv == k and eigs.info() == sa.CompInfo.Successful
         ev, X = eigs.eigenvalues(), eigs.eigenvectors()
-        assert np.abs(B @ X - X * ev).max() < 1e-6
+        assert np.abs(B @ X - X * ev).max() < 1e-8
         out[mode] = (ev, eigs.num_iterations())
     assert np.abs(out["none"][0] - out["rcm"][0]).max() < 1e-8
     assert abs(out["none"][1] - out["rcm"][1]) <= 2, out          # same preconditioner => same convergence history

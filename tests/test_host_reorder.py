@@ -62,3 +62,33 @@ def test_rcm_gives_up_on_an_expander():
     S = (U + U.T).tocsr()
     perm, gave_up, widest = sa.rcm_order(S.indptr, S.indices, True)
     assert gave_up and np.array_equal(perm, np.arange(n)) and widest > n // 8
+
+
+def test_expander_is_recognised_by_the_threaded_pre_check_and_a_large_stencil_is_not():
+    # n >= 65536: rcm_order first runs a level-synchronous search on the host threads (reorder.hip expander_precheck) and gives
+    # up there for an expander — before the graph copy, the degree sort and the serial search; a shuffled stencil of the same size
+    # must pass that test and come back with its band
+    import time
+
+    n = 300_000
+    rng = np.random.default_rng(5)
+    r = np.repeat(np.arange(n), 7)
+    c = rng.integers(0, n, r.size)
+    U = sp.coo_matrix((np.ones(r.size), (r, c)), shape=(n, n)).tocsr()
+    S = (U + U.T).tocsr()
+    t0 = time.perf_counter()
+    perm, gave_up, widest = sa.rcm_order(S.indptr, S.indices, True)
+    t_expander = time.perf_counter() - t0
+    assert gave_up and np.array_equal(perm, np.arange(n)) and widest > n // 8
+    A = stencil7(67)                                   # 300 763 rows
+    m = A.shape[0]
+    p = rng.permutation(m)
+    B = A[p][:, p].tocsr()
+    B.sort_indices()
+    t0 = time.perf_counter()
+    perm, gave_up, widest = sa.rcm_order(B.indptr, B.indices, True)
+    t_stencil = time.perf_counter() - t0
+    assert not gave_up and sorted(perm.tolist()) == list(range(m))
+    Bp = B[perm][:, perm]
+    assert bandwidth(Bp.tocsr()) < m // 10
+    assert t_expander < t_stencil                      # the pre-check is the cheap path
