@@ -116,9 +116,10 @@ KERNEL_OF_FORMAT = {0: "k_spmv_csr_stream<EPI, NT, 256, CODES=false>", 1: "k_spm
                     3: "k_spmv_tiles (column-blocked tiles, segment sums in LDS)"}
 
 
-def pmc_traffic(n, fmt):
+def pmc_traffic(n, fmt, post_scaled=False):
     """HBM bytes per launch of the fused SpMV (the instantiation the solve used: 0 int32 indices, 1 offset codes,
-    2 diagonal storage) as measured by the committed PMC passes (tools/pmc_summarize.py), or None."""
+    2 diagonal storage; post_scaled: the one-sweep steps' instantiation k_spmv_dia_win<true, NG, NCW, true>) as measured by the
+    committed PMC passes (tools/pmc_summarize.py), or None."""
     import glob
 
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
@@ -128,10 +129,13 @@ def pmc_traffic(n, fmt):
             if int(d.get("n", -1)) != int(n):
                 continue
             for name, rec in d["kernels"].items():
-                args_ = name.split("<", 1)[1].rstrip(">").split(",") if "<" in name else []
-                is_coded = len(args_) >= 4 and args_[3].strip() == "true"
-                if fmt == 2 and name.startswith("k_spmv_dia") and "<true" in name:
-                    return float(rec["hbm_bytes"]), os.path.basename(path)
+                args_ = [a.strip() for a in name.split("<", 1)[1].rstrip(">").split(",")] if "<" in name else []
+                if fmt == 2 and name.startswith("k_spmv_dia") and args_ and args_[0] == "true":
+                    # round 3 names: <EPI, NG, NCW, POST>; earlier rounds: <EPI, NG, FUSE, NCW> (no post-scaled variant)
+                    is_post = len(args_) == 4 and args_[3] == "true"
+                    if is_post == bool(post_scaled):
+                        return float(rec["hbm_bytes"]), os.path.basename(path)
+                is_coded = len(args_) >= 4 and args_[3] == "true"
                 if fmt != 2 and name.startswith("k_spmv_csr_stream<true") and is_coded == (fmt == 1):
                     return float(rec["hbm_bytes"]), os.path.basename(path)
         except Exception:  # noqa: BLE001 - a malformed summary just means "no PMC figure"
@@ -492,7 +496,7 @@ def main():
     else:
         exchange_desc = f", {transport_name} all-gather of the Krylov vector per SpMV" + (f" ({exchange_note})" if exchange_note else "")
     if rank == 0:
-        traffic, traffic_file = pmc_traffic(args.n, fmt) if world == 1 else (None, None)
+        traffic, traffic_file = pmc_traffic(args.n, fmt, post_scaled=(args.orth == "onesweep")) if world == 1 else (None, None)
         out = {
             "metric": "eigenpairs_per_sec",
             "value": total_pairs / elapsed,
@@ -524,7 +528,7 @@ def main():
                                  "at ~55 GB/s PCIe and is not part of `value`)"),
             },
             "roofline": {
-                "kernel": head["kernel"] + " (SpMV fused with w -= beta*v_prev and the alpha dot)",
+                "kernel": head["kernel"] + " (SpMV fused with w -= beta*v_prev and the alpha dot" + ("; one-sweep steps: input f, row sums divided by beta" if args.orth == "onesweep" else "") + ")",
                 "bound": "hbm",
                 "achieved": head["achieved"],
                 "peak": HBM_PEAK_GBPS,
@@ -559,6 +563,18 @@ def main():
             },
             "other_orth_mode": other_mode,
             "value_with_host_eigenvectors": with_host,
+            "roofline_orth": ({
+                "kernel": {"onesweep": "k_orth_lagged: correction of step i-1 + projection of step i in one pass over V (the largest share of a solve)",
+                           "reference": "k_orth<RESID_VTF>: f = w - alpha v, |f|, V'f (the first of the two passes over V of a step)"}[args.orth],
+                "bound": "hbm", "bytes_per_launch_mean": split["bytes_vtf"] / max(split["n_vtf"], 1),
+                "ms_per_launch_mean": split["ms_vtf"] / max(split["n_vtf"], 1),
+                "achieved": split["bytes_vtf"] / (split["ms_vtf"] * 1e-3) / 1e9 if split["ms_vtf"] > 0 else None,
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": split["bytes_vtf"] / (split["ms_vtf"] * 1e-3) / 1e9 / HBM_PEAK_GBPS if split["ms_vtf"] > 0 else None,
+                "note": "algorithmic bytes (8 n x vectors read + written, summed over the launches of one solve) over the family's HIP-event "
+                        "time, which also covers the ~10 us record reduction behind every pass; from the instrumented extra solve",
+                "compress": {"kernel": "k_vq (V <- V Q in place, X = V Y)", "achieved": split["bytes_compress"] / (split["ms_compress"] * 1e-3) / 1e9
+                             if split["ms_compress"] > 0 else None}} if split else None),
             "kernels_ms_per_solve": ({k[3:]: split[k] for k in split if k.startswith("ms_")} if split else None),
             "kernels_ms_note": "from one additional solve with every kernel family bracketed by HIP events, outside the timed region",
             "kernels_launches_per_solve": {k[2:]: prof[k] / args.steps for k in prof if k.startswith("n_")},

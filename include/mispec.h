@@ -56,7 +56,11 @@ void* mispec_ctx_stream(mispec_ctx* ctx);
 
 /* Row sharding (the reference has no notion of it).  rank/world and two collectives over
  * the ranks: an all-gather of equal-sized blocks of doubles (the Krylov vector before each SpMV) and an
- * in-place sum all-reduce of a few doubles (alpha, |f|^2, V'f).  Both are enqueued on `hip_stream`. */
+ * in-place sum all-reduce of a few doubles (alpha, |f|^2, V'f).
+ * Contract of the callbacks: (i) the collective must be ORDERED ON `hip_stream` — the solver's stream, or a second stream of the
+ * library while the exchange overlaps the product of the local rows (mispec_fac_overlap_info): a transport that runs on a
+ * stream of its own has to wait for / signal that stream itself; (ii) the all-gather is called IN PLACE: send_dev is
+ * recv_dev + rank * count_per_rank; (iii) return 0 on success, anything else aborts the solve with MISPEC_ERUNTIME. */
 typedef struct mispec_comm
 {
     int rank, world;
@@ -399,6 +403,11 @@ typedef struct mispec_profile
     int64_t n_spmv, n_vtf, n_gemv, n_scale, n_compress, n_small, n_host_sync;
     double ms_spmv, ms_vtf, ms_gemv, ms_scale, ms_compress, ms_small;
     double spmv_bytes; /* algorithmic bytes per SpMV launch of this shard: 12*nnz + 4*(rows+1) + 8*cols + 8*rows */
+    /* algorithmic bytes of the length-n dense kernels, summed over their launches (8 bytes x local rows x vectors read + written):
+     * vtf = the projection passes of the device-driven Lanczos steps (f = w - alpha v + V'f; one-sweep: the lagged pass),
+     * compress = V <- V Q and X = V Y; gemv (the correction passes) is not counted — the device decides whether they run.  bytes / ms of the same family = the rate those kernels ran at (the family's event pair
+     * also covers its record reduction, ~10 us per launch). */
+    double bytes_vtf, bytes_gemv, bytes_compress;
 } mispec_profile;
 int mispec_fac_profile(mispec_fac* fac, int enable);
 int mispec_fac_get_profile(const mispec_fac* fac, mispec_profile* out);

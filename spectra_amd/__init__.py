@@ -1382,6 +1382,10 @@ class Factorization:
         v0 = _f64(v0)
         check(lib().mispec_fac_init(self.h, _dp(v0), C.byref(self.nmatop)))
 
+    def set_orth_mode(self, mode):
+        """'reference' (default) or 'onesweep' (mispec_fac_set_orth_mode); call before factorize_from."""
+        check(lib().mispec_fac_set_orth_mode(self.h, {"reference": 0, "onesweep": 1, 0: 0, 1: 1}[mode]))
+
     def init_random(self, seed=0):
         check(lib().mispec_fac_init_random(self.h, seed, C.byref(self.nmatop)))
 

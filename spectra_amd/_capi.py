@@ -44,7 +44,8 @@ class Comm(C.Structure):
 
 class Profile(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("n_spmv", "n_vtf", "n_gemv", "n_scale", "n_compress", "n_small", "n_host_sync")] + \
-               [(n, C.c_double) for n in ("ms_spmv", "ms_vtf", "ms_gemv", "ms_scale", "ms_compress", "ms_small", "spmv_bytes")]
+               [(n, C.c_double) for n in ("ms_spmv", "ms_vtf", "ms_gemv", "ms_scale", "ms_compress", "ms_small", "spmv_bytes",
+                                             "bytes_vtf", "bytes_gemv", "bytes_compress")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -127,6 +127,8 @@ struct mispec_fac
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[FAM_COUNT];
     std::vector<hipEvent_t> ev_pool;
     double ms_acc[FAM_COUNT] = {0, 0, 0, 0, 0, 0};
+    double bytes_acc[FAM_COUNT] = {0, 0, 0, 0, 0, 0};  // algorithmic bytes of the n-sized dense kernels (mispec_profile)
+    void count_bytes(int fam, int vectors) { bytes_acc[fam] += 8.0 * double(nloc) * double(vectors); }
 
     double& Hat(int i, int j) { return H[size_t(j) * m + i]; }
     double* col(int j) { return V.p + int64_t(j) * ldv; }
@@ -941,6 +943,7 @@ void lanczos_step_device(mispec_fac& F, int i)
         a.alpha_dev = F.alpha_slot();
         a.status = &st->status;
         Timed t(F, FAM_VTF);
+        F.count_bytes(FAM_VTF, i1 + 2);  // i + 1 columns (v_i among them) and w read, f written
         const int nrec = launch_orth(*F.ctx, ORTH_RESID_VTF, a);
         fin.mode = kFinishStepFirst;
         fin.alpha_src = F.alpha_slot();
@@ -1012,6 +1015,7 @@ void lanczos_step_lagged(mispec_fac& F, int i, bool last)
         a.pending = &st->lag_pending;
         a.status = &st->status;
         Timed t(F, FAM_VTF);
+        F.count_bytes(FAM_VTF, i + 4);  // i columns, f and w read; column i and f written
         const int nrec = launch_orth(*F.ctx, ORTH_LAGGED, a);
         fin.mode = kFinishLagged;
         fin.alpha_src = F.alpha_slot();
@@ -1308,6 +1312,7 @@ void compress_basis(mispec_fac& F, int p)
     const int m = F.m;
     if (m <= kPanelCols)
     {
+        F.count_bytes(FAM_COMPRESS, m + p);
         launch_vq(*F.ctx, F.V.p, F.ldv, m, F.Qdev.p, m, p, F.V.p, F.ldv, F.nloc);
         return;
     }
@@ -2018,6 +2023,7 @@ extern "C" int mispec_fac_ritz_vectors(mispec_fac* fac, const double* Y_host, in
         MISPEC_HIP(hipMemcpyAsync(F.d_Y.p, F.h_small.p, size_t(m) * size_t(ncols) * 8, hipMemcpyHostToDevice, F.stream()));
         {
             Timed t(F, FAM_COMPRESS);
+            F.count_bytes(FAM_COMPRESS, m + ncols);
             launch_vq(*F.ctx, F.V.p, F.ldv, m, F.d_Y.p, m, ncols, F.X.p, F.ldv, F.nloc);  // HermEigsBase.h:467
         }
         F.x_cols = ncols;
@@ -2129,5 +2135,8 @@ extern "C" int mispec_fac_get_profile(const mispec_fac* fac_c, mispec_profile* o
         out->ms_small = F.ms_acc[FAM_SMALL];
         out->spmv_bytes = (F.A ? F.A->algorithmic_bytes() : 0.0) + (F.A2 ? F.A2->algorithmic_bytes() : 0.0) +
                           (F.D ? F.D->algorithmic_bytes() : 0.0);
+        out->bytes_vtf = F.bytes_acc[FAM_VTF];
+        out->bytes_gemv = F.bytes_acc[FAM_GEMV];
+        out->bytes_compress = F.bytes_acc[FAM_COMPRESS];
     });
 }

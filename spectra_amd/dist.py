@@ -66,11 +66,20 @@ class TorchComm:
     def allreduce_sum(self, buf):
         self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group)
 
+    def _on(self, stream):
+        """The stream the library passed to the callback (the solver's stream, or its communication stream while the exchange
+        overlaps the local rows): the collective must be ordered on THAT stream — mispec_comm's contract, include/mispec.h."""
+        import torch
+
+        if stream:
+            return torch.cuda.stream(torch.cuda.ExternalStream(int(stream)))
+        return torch.cuda.stream(self.stream)
+
     # raw-pointer forms used as C callbacks (device memory)
     def _allgather_ptr(self, send_ptr, recv_ptr, count, stream):
         import torch
 
-        with torch.cuda.stream(self.stream):
+        with self._on(stream):
             send = torch.as_tensor(_DeviceArray(send_ptr, count), device="cuda")
             recv = torch.as_tensor(_DeviceArray(recv_ptr, count * self.world), device="cuda")
             self.allgather(send, recv)
@@ -79,7 +88,7 @@ class TorchComm:
     def _allreduce_ptr(self, buf_ptr, count, stream):
         import torch
 
-        with torch.cuda.stream(self.stream):
+        with self._on(stream):
             self.allreduce_sum(torch.as_tensor(_DeviceArray(buf_ptr, count), device="cuda"))
         return 0
 

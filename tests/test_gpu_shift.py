@@ -273,4 +273,4 @@ def test_solve_kernel_variants_agree():
     for (crc_a, res_a, steps_a), (crc_b, res_b, steps_b), case in zip(base, sweeps, cases):
         tol = 1e-10 if case[3] else 1e-12   # interior shift: the matrix is indefinite and worse conditioned
         assert float(res_a) <= tol and float(res_b) <= tol, (case, res_a, res_b)
-        assert int(steps_a) <= 2 and int(steps_b) <= 2, (case, steps_a, steps_b)   # calibrated separately: may differ by one
+        assert int(steps_a) <= 3 and int(steps_b) <= 3, (case, steps_a, steps_b)   # calibrated separately (+ one safety step when pivots were boosted)

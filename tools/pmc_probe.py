@@ -6,7 +6,7 @@
 For each storage format of the matrix (diagonal, offset-coded CSR, int32 CSR), in order: k_scale_step launches on an n-vector (calibration: exactly 8n bytes read + 8n written with the same
 16-byte-per-lane access pattern the guide's FETCH_SIZE correction is about), 5 x stand-alone SpMV, then
 init() + one full Lanczos factorisation (39 steps: fused SpMV, RESID_VTF, CORRECT_VTF) and one restart
-(shifted-QR kernel + V*Q).  tools/pmc_summarize.py turns the two CSVs into per-kernel bytes per launch.
+(shifted-QR kernel + V*Q), in the reference flow and again with the one-sweep steps (post-scaled SpMV, k_orth_lagged).  tools/pmc_summarize.py turns the two CSVs into per-kernel bytes per launch.
 """
 import os
 import sys
@@ -30,14 +30,18 @@ for fmt in [int(f) for f in os.environ.get("PROBE_FORMATS", "2,1,0").split(",")]
     for _ in range(5):
         op.spmv_device(x.data_ptr(), y.data_ptr())
     ctx.sync()
-    fac = sa.Factorization(op, 40, True)
-    fac.init_random(0)
-    fac.factorize_from(1, 40)
-    ev, U = fac.tridiag_eigen()
-    order = np.argsort(-np.abs(ev))
-    fac.restart_sym(ev[order][25:])
-    fac.factorize_from(25, 40)
-    ctx.sync()
-    print("probe done: format", op.spmv_format(), "k =", fac.subspace_dim(), "nops =", fac.num_operations())
-    del fac
+    # the reference flow (k_scale_step — the calibration kernel —, fused SpMV, RESID_VTF, CORRECT_VTF), then the one-sweep steps
+    # (post-scaled SpMV on diagonal storage, k_orth_lagged)
+    for mode in ("reference", "onesweep"):
+        fac = sa.Factorization(op, 40, True)
+        fac.set_orth_mode(mode)
+        fac.init_random(0)
+        fac.factorize_from(1, 40)
+        ev, U = fac.tridiag_eigen()
+        order = np.argsort(-np.abs(ev))
+        fac.restart_sym(ev[order][25:])
+        fac.factorize_from(25, 40)
+        ctx.sync()
+        print("probe done: format", op.spmv_format(), mode, "k =", fac.subspace_dim(), "nops =", fac.num_operations())
+        del fac
 op.set_spmv_format(-1)
