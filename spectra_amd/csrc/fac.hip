@@ -1046,7 +1046,7 @@ void factorize_lanczos(mispec_fac& F, int from_k, int to_m, int64_t* nmatop)
 {
     zero_H_outside(F, from_k);
     const bool fast = F.device_steps && F.A != nullptr && !F.bmode() && F.Chol == nullptr;
-    const bool lagged = fast && F.onesweep && F.m <= kPanelCols;
+    const bool lagged = fast && F.onesweep && F.m <= kPanelCols && !F.A2;  // standard problems, one column panel
     int i = from_k;
     while (i <= to_m - 1)
     {
@@ -1721,7 +1721,7 @@ extern "C" int mispec_fac_orth_info(const mispec_fac* fac, int* mode, int64_t* l
 {
     return guarded([&] {
         MISPEC_REQUIRE(fac, "mispec_fac_orth_info: NULL argument");
-        const bool active = fac->onesweep && fac->device_steps && fac->symmetric && fac->A && !fac->bmode() && !fac->Chol &&
+        const bool active = fac->onesweep && fac->device_steps && fac->symmetric && fac->A && !fac->A2 && !fac->bmode() && !fac->Chol &&
                             fac->m <= kPanelCols;
         if (mode)
             *mode = active ? MISPEC_ORTH_ONESWEEP : MISPEC_ORTH_REFERENCE;

@@ -33,12 +33,19 @@ def main():
     rule = sa.SortRule[os.environ.get("MP_RULE", "LargestMagn")]
     op = sa.SparseSymMatProd.synth_band(n, offsets=offsets, ctx=ctx)
     eigs = sa.SymEigsSolver(op, nev, ncv)
+    eigs.set_orth_mode(os.environ.get("MP_ORTH", "reference"))
     eigs.init()
     nconv = eigs.compute(rule, 1000, 1e-11)
+    # MP_SAVE_X=0 (full-size runs): keep the eigenvectors out of the result files, hand back per-column checksums instead
+    save_x = os.environ.get("MP_SAVE_X", "1") != "0"
     X = eigs.eigenvectors()
+    xsum = np.array([float(np.sum(X[:, j] * X[:, j])) for j in range(X.shape[1])])
+    if not save_x:
+        X = np.zeros((0, X.shape[1]))
     out = os.environ["MP_OUT"]
     np.savez(os.path.join(out, f"rank{rank}.npz"), nconv=nconv, info=int(eigs.info()), evals=eigs.eigenvalues(), X=X,
              nops=eigs.num_operations(), niter=eigs.num_iterations(), res=eigs.residuals(), rows=np.array(sa.shard_range(n, world, rank)),
+             xsum=xsum,
              exchange=np.array(eigs.exchange_info(), dtype=np.int64))
     with open(os.path.join(out, f"rank{rank}.json"), "w") as f:
         json.dump({"rank": rank, "world": world, "transport": transport, "device": device, "pid": os.getpid(), "nconv": int(nconv),

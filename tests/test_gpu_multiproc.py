@@ -65,6 +65,35 @@ def test_two_processes_equal_the_loopback_run(ctx, tmp_path, exchange):
     assert np.abs(np.abs(np.sum(X * single.eigenvectors(), axis=0)) - 1.0).max() < 1e-8
 
 
+def test_two_processes_full_size_c3(tmp_path):
+    # BASELINE.json configs[2] at FULL size as two operating-system processes (row blocks of 5M rows each, neighbour exchange of
+    # 100 001 doubles per product staged through gloo): pinned to the oracle's complete C2 solve like the unsharded and the
+    # loopback runs, and bit-identical to the loopback run of the same partition.
+    import json as _json
+
+    from test_gpu_sharded import run_sharded
+
+    with open(os.path.join(ROOT, "tests", "golden", "full_size_c2.json")) as f:
+        g = _json.load(f)
+    n, nev, ncv = g["n"], g["nev"], g["ncv"]
+    procs = run_processes(2, tmp_path, MP_N=n, MP_OFFSETS="1,2,3,1000,1001,100000,100001", MP_NEV=nev, MP_NCV=ncv, MP_SAVE_X=0)
+    assert len({p["meta"]["pid"] for p in procs}) == 2
+    ref = np.array(g["eigenvalues"])
+    for rank, p in enumerate(procs):
+        assert int(p["nconv"]) == g["nconv"] == nev and int(p["info"]) == 0
+        assert bool(p["exchange"][0]) and int(p["exchange"][1]) == 100001
+        assert np.all(np.abs(p["evals"] - ref) <= 1e-9 * np.maximum(1.0, np.abs(ref)))
+        assert abs(int(p["nops"]) - g["num_operations"]) <= ncv - nev and abs(int(p["niter"]) - g["num_iterations"]) <= 1
+        assert p["res"].max() <= 1e-10
+        assert tuple(p["rows"]) == (rank * (n // 2), (rank + 1) * (n // 2))
+    assert np.array_equal(procs[0]["evals"], procs[1]["evals"])
+    assert np.abs(procs[0]["xsum"] + procs[1]["xsum"] - 1.0).max() <= 1e-10      # the two row blocks of every unit eigenvector
+    loop = run_sharded(2, n, None, nev, ncv, sa.SortRule.LargestMagn, 1e-11, keep_vectors=False)
+    for p, l in zip(procs, loop):
+        assert np.array_equal(p["evals"], l["evals"]) and (int(p["nops"]), int(p["niter"])) == (l["nops"], l["niter"])
+        assert np.array_equal(p["res"], l["res"])
+
+
 def test_bench_with_two_ranks_end_to_end(tmp_path):
     # `python bench.py --gpus 2` as the driver starts it (a plain process): it must spawn its two ranks itself, run the
     # self-check of the neighbour exchange, time the steps with both exchange modes and print ONE JSON line.  On this 1-GPU

@@ -39,3 +39,6 @@ def test_pmc_traffic_lookup_finds_every_instantiation():
     for fmt in (0, 1, 2):
         traffic, src = bench.pmc_traffic(10_000_000, fmt)
         assert traffic is not None and 1.0e9 < traffic < 3.0e9, (fmt, traffic, src)
+    # ... and for the post-scaled instantiation the one-sweep steps run on diagonal storage (bench.py's timed mode)
+    traffic, src = bench.pmc_traffic(10_000_000, 2, post_scaled=True)
+    assert traffic is not None and 1.4e9 < traffic < 1.7e9, (traffic, src)

@@ -12,9 +12,10 @@ case $WHAT in
   ab)           # ab <tag> <steps> NAME=ENV=v,... ...      (tools/ab_bench.py)
     STEPS=$1; shift
     timeout 1200 python tools/ab_bench.py --steps $STEPS "$@" > $OUT/ab.jsonl 2> $OUT/ab.err; cut -c1-600 $OUT/ab.jsonl; tail -3 $OUT/ab.err ;;
-  bench)        # bench <tag> [bench.py args]: the driver's command + a rocprofv3 kernel trace of the same command
+  bench)        # bench <tag> [bench.py args]: the driver's command + a rocprofv3 kernel trace of the same command (secondary
+                # configurations included, so that every figure of the line has its kernels in the stats; CPU baseline left out)
     timeout 900 python bench.py "$@" > $OUT/bench.json 2> $OUT/bench.err; tail -c 800 $OUT/bench.json; tail -5 $OUT/bench.err
-    (cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --no-secondary --no-cpu-baseline "$@" > $GRAFT_REPO_ROOT/$OUT/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$OUT/rocprof.err)
+    (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --no-cpu-baseline "$@" > $GRAFT_REPO_ROOT/$OUT/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$OUT/rocprof.err)
     find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/bench_kernel_stats.csv
     rm -rf $OUT/prof; head -12 $OUT/bench_kernel_stats.csv ;;
   trace)        # trace <tag> <script> [args]: rocprofv3 kernel trace + stats of a python script
