@@ -27,6 +27,16 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 constexpr int kThreads = 256;
 constexpr int kTileRows = 128;
 
+// 16-byte load of two rows of a basis column with the non-temporal hint (streamed once per pass)
+__device__ __forceinline__ double2 load_streamed(const double* p)
+{
+    const v2d t = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p));
+    double2 r;
+    r.x = t.x;
+    r.y = t.y;
+    return r;
+}
+
 __device__ __forceinline__ double wave_reduce_sum(double v)
 {
 #pragma unroll
@@ -109,12 +119,16 @@ __global__ __launch_bounds__(kThreads) void k_orth(OrthArgs a)
             rc[q] = valid[q] ? r[q] : 0;
         }
 
+        // The basis is streamed once per pass and is far larger than any cache (3.2 GB at C2); loaded with the non-temporal hint
+        // it does not push the step's vectors (f, w, the newest columns: 80 MB each) out of the 256 MiB Infinity Cache, from which
+        // the next kernels then read them.  Measured on C2 (profiles/r05g_*): lagged pass 667 -> 592 ms per solve, and the SpMV
+        // behind it 301 -> 291 ms.
         double2 vv[MAXS][R];
 #pragma unroll
         for (int jj = 0; jj < MAXS; jj++)
 #pragma unroll
             for (int q = 0; q < R; q++)
-                vv[jj][q] = *reinterpret_cast<const double2*>(colp[jj] + rc[q]);
+                vv[jj][q] = load_streamed(colp[jj] + rc[q]);
 
         double2 fv[R];
 #pragma unroll
@@ -271,7 +285,7 @@ __global__ __launch_bounds__(kThreads) void k_orth_lagged(OrthArgs a)
         for (int jj = 0; jj < MAXS; jj++)
 #pragma unroll
             for (int q = 0; q < R; q++)
-                vv[jj][q] = *reinterpret_cast<const double2*>(colp[jj] + rc[q]);
+                vv[jj][q] = load_streamed(colp[jj] + rc[q]);  // non-temporal: see k_orth
         double2 fv[R], wv[R];
 #pragma unroll
         for (int q = 0; q < R; q++)
@@ -812,7 +826,7 @@ __device__ __forceinline__ void vq_fetch(v2d (&pre)[NJ], const double* __restric
     for (int jj = 0; jj < NJ; jj++)
     {
         const int jc = (jj < nj) ? (w + 4 * jj) : w;
-        pre[jj] = *reinterpret_cast<const v2d*>(V + int64_t(jc) * ldv + rc);
+        pre[jj] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(V + int64_t(jc) * ldv + rc));  // streamed once: see k_orth
     }
 }
 
@@ -882,8 +896,8 @@ __global__ __launch_bounds__(kThreads) void k_vq(const double* __restrict__ V, i
             for (int jj = 0; jj < MAXS; jj++)
             {
                 const int i = w + 4 * jj;
-                if (i < p)
-                    *reinterpret_cast<double2*>(X + int64_t(i) * ldx + r) = acc[jj];
+                if (i < p)  // 2 GB of output per restart: streamed past the caches like the input
+                    __builtin_nontemporal_store(v2d{acc[jj].x, acc[jj].y}, reinterpret_cast<v2d*>(X + int64_t(i) * ldx + r));
             }
         }
     }

@@ -128,6 +128,18 @@ static void run_test_sets(const Csc& A, int k, int m)
                     (int) eigs.num_iterations(), (int) eigs.num_operations(), err);
         REQUIRE(nconv == k);
         REQUIRE(err < 1e-9);  // test/SymEigs.cpp:64
+        // the opt-in one-sweep orthogonalisation through the header API: same eigenvalues, the reference's bar on the residual
+        SymEigsSolver<SparseSymMatProd<double>> one(op, k, m);
+        one.set_onesweep_orthogonalization(true);
+        one.init();
+        const int nconv1 = (int) one.compute(rule);
+        REQUIRE(one.info() == CompInfo::Successful && nconv1 == k);
+        const auto evals1 = one.eigenvalues();
+        double dmax = 0.0;
+        for (int i = 0; i < k; i++)
+            dmax = std::max(dmax, std::fabs(evals1[i] - evals[i]));
+        REQUIRE(dmax < 1e-9);
+        REQUIRE(residual(A, evals1, one.eigenvectors()) < 1e-9);
     }
 }
 
