@@ -139,7 +139,8 @@ __global__ __launch_bounds__(kThreads) void k_spmv_csr_stream(const int32_t* __r
         for (int it = 0; it < kLoadIters; it++)
         {
             const int base = min(a0 + tid * 4 + it * (kThreads * 4), last);
-            // val / col_ind are read exactly once per SpMV: non-temporal, so they do not evict x from L2
+            // (NT instantiations are not launched: non-temporal val / col_ind streams measured slower stand-alone in round 1 and in
+            // the solver loop in round 3 — 0.424 -> 0.459 ms int32, 0.363 -> 0.395 ms coded, profiles/r05k_*)
             if (NT)
             {
                 const v2d a01 = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(val + base));
