@@ -6,6 +6,8 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <new>
 #include <functional>
 #include <utility>
 #include <stdexcept>
@@ -133,6 +135,47 @@ struct PinnedBuf
 };
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// malloc for the gigabyte-sized host arrays of the ingest stages (free with std::free).  Throws std::bad_alloc.
+void* big_host_alloc(size_t bytes);
+
+// Host array whose storage is NOT value-initialised (std::vector<T>::resize zero-fills on one thread and faults every page
+// in there; the ingest stages fill gigabyte-sized arrays from many threads instead).  Trivially copyable T only.
+template <typename T>
+struct RawVec
+{
+    T* p = nullptr;
+    size_t n = 0;
+    RawVec() {}
+    RawVec(const RawVec&) = delete;
+    RawVec& operator=(const RawVec&) = delete;
+    RawVec(RawVec&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    RawVec& operator=(RawVec&& o) noexcept
+    {
+        if (this != &o)
+        {
+            std::free(p);
+            p = o.p;
+            n = o.n;
+            o.p = nullptr;
+            o.n = 0;
+        }
+        return *this;
+    }
+    ~RawVec() { std::free(p); }
+    void resize_uninitialized(size_t count)
+    {
+        std::free(p);
+        p = count ? static_cast<T*>(big_host_alloc(count * sizeof(T))) : nullptr;
+        n = count;
+    }
+    size_t size() const { return n; }
+    T* data() { return p; }
+    const T* data() const { return p; }
+    T* begin() { return p; }
+    T& operator[](size_t i) { return p[i]; }
+    const T& operator[](size_t i) const { return p[i]; }
+};
 
 // Host threads of the ingest stages (format builders, triangle mirroring, validation passes): the machine's hardware threads,
 // at most 64.  Every parallel stage produces the bytes the serial loop would.

@@ -1392,89 +1392,158 @@ namespace {
 struct MirroredCsr
 {
     std::vector<int32_t> rp;
-    std::unique_ptr<int32_t[]> ci;
-    std::unique_ptr<double[]> v;
+    RawVec<int32_t> ci;
+    RawVec<double> v;
     int64_t nnz = 0;
 };
 void mirror_triangle(int64_t n, const int32_t* outer, const int32_t* inner, const double* val, bool lower, bool row_major, MirroredCsr& M)
 {
+    // (r, c) is the matrix position of an entry whatever the storage order; an entry is kept iff it lies in the requested
+    // triangle (selfadjointView<Uplo> ignores the rest).  Row r of the full matrix receives column c, row c column r.
+    //
+    // A bucketed transpose on the host threads.  The rows are cut into buckets of 2^shift rows whose output (12 bytes per
+    // entry) stays cache-resident; pass 1: every thread walks its piece of the INPUT once, sequentially, and appends
+    // (row, column, value) records to staging areas per (bucket, thread) — sized by a counting walk, laid out bucket-major and
+    // thread-minor, so a bucket's records are contiguous and in input order; pass 2: every bucket is turned into its rows by
+    // one thread (count, prefix, place).  Every row is therefore filled in input order — for a sorted triangle that IS
+    // ascending column order — with no atomics, and the bytes do not depend on the number of threads.  All traffic is
+    // sequential except the placement inside a bucket.
     std::vector<int32_t>& rp = M.rp;
-        // (r, c) is the matrix position of an entry whatever the storage order; an entry is kept iff it lies in the requested
-        // triangle (selfadjointView<Uplo> ignores the rest).  Row r of the full matrix receives column c, row c column r.
-        //
-        // Host threads: thread t owns the rows [b, e) of the OUTPUT and walks the whole input in storage order, acting only on
-        // entries that land in its rows — so every row is filled in input order (for a sorted triangle that IS ascending column
-        // order: the columns below the diagonal arrive outer by outer, then the diagonal and the mirrored run), with no atomics and
-        // the same bytes whatever the thread count.  The index array is read once per thread (4 B per entry, streamed), a value
-        // only by the owners of its two rows.
-        const int64_t nnz_in = outer[n] - outer[0];
-        const int nt = int(std::max<int64_t>(1, std::min<int64_t>(std::min(ingest_threads(), 32), nnz_in / 262144)));
-        std::vector<char> bad(static_cast<size_t>(nt), 0);
-        rp.assign(size_t(n) + 1, 0);
-        auto walk = [&](int64_t b, int64_t e, char& flag, auto&& fn) {
-            for (int64_t o = 0; o < n; o++)
-                for (int32_t p = outer[o]; p < outer[o + 1]; p++)
-                {
-                    const int64_t in = inner[p];
-                    if (in < 0 || in >= n)
-                    {
-                        flag = 1;
-                        continue;
-                    }
-                    const int64_t r = row_major ? o : in, c = row_major ? in : o;
-                    if (!(lower ? (r >= c) : (r <= c)))
-                        continue;
-                    if (r >= b && r < e)
-                        fn(r, c, p);
-                    if (r != c && c >= b && c < e)
-                        fn(c, r, p);
-                }
-        };
-        parallel_ranges(n, nt, [&](int t, int64_t b, int64_t e) {
-            walk(b, e, bad[size_t(t)], [&](int64_t row, int64_t, int32_t) { rp[size_t(row) + 1]++; });
-        });
-        for (char f : bad)
-            MISPEC_REQUIRE(!f, "mispec_csr_from_triangle: index out of range");
-        for (int64_t i = 0; i < n; i++)
-        {
-            MISPEC_REQUIRE(int64_t(rp[size_t(i) + 1]) + rp[size_t(i)] <= INT32_MAX, "mispec_csr_from_triangle: more than 2^31 - 1 entries");
-            rp[size_t(i) + 1] += rp[size_t(i)];
-        }
-        const int64_t nnz = rp[size_t(n)];
-        M.nnz = nnz;
-        M.ci.reset(new int32_t[size_t(std::max<int64_t>(nnz, 1))]);
-        M.v.reset(new double[size_t(std::max<int64_t>(nnz, 1))]);
-        int32_t* const ci = M.ci.get();
-        double* const v = M.v.get();
-        parallel_ranges(n, nt, [&](int t, int64_t b, int64_t e) {
-            std::vector<int32_t> fill(rp.begin() + b, rp.begin() + e);
-            walk(b, e, bad[size_t(t)], [&](int64_t row, int64_t col, int32_t p) {
-                const int32_t q = fill[size_t(row - b)]++;
-                ci[size_t(q)] = int32_t(col);
-                v[size_t(q)] = val[p];
-            });
-        });
-        // sort every row by column (the SpMV sums in storage order); rows of a sorted triangle are sorted already
-        parallel_ranges(n, ingest_threads(), [&](int, int64_t b, int64_t e) {
-            std::vector<int32_t> perm, tc;
-            std::vector<double> tv;
-            for (int64_t i = b; i < e; i++)
+    const int64_t nnz_in = n > 0 ? int64_t(outer[n]) - int64_t(outer[0]) : 0;
+    rp.assign(size_t(n) + 1, 0);
+    int shift = 15;  // 32768 rows per bucket: ~6 MB of output at 15 entries per row
+    while ((n >> shift) > 4096)
+        shift++;
+    const int64_t nb = (n >> shift) + 1;
+    const int nt = int(std::max<int64_t>(1, std::min<int64_t>(ingest_threads(), nnz_in / 131072)));
+    struct Rec
+    {
+        int32_t row, col;
+        double val;
+    };
+    // input pieces: contiguous runs of outers with about the same number of entries
+    std::vector<int64_t> piece(static_cast<size_t>(nt) + 1, n);
+    piece[0] = 0;
+    for (int t = 1; t < nt; t++)
+    {
+        const int64_t want = outer[0] + nnz_in * t / nt;
+        piece[size_t(t)] = std::lower_bound(outer, outer + n, want, [](int32_t a, int64_t w) { return int64_t(a) < w; }) - outer;
+    }
+    std::vector<char> bad(static_cast<size_t>(nt), 0);
+    auto walk = [&](int t, auto&& fn) {
+        for (int64_t o = piece[size_t(t)]; o < piece[size_t(t) + 1]; o++)
+            for (int32_t p = outer[o]; p < outer[o + 1]; p++)
             {
-                const int32_t s0 = rp[size_t(i)], e0 = rp[size_t(i) + 1];
-                if (e0 - s0 < 2 || std::is_sorted(ci + s0, ci + e0))
-                    continue;
-                perm.resize(size_t(e0 - s0));
-                std::iota(perm.begin(), perm.end(), 0);
-                std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t c) { return ci[size_t(s0 + a)] < ci[size_t(s0 + c)]; });
-                tc.assign(ci + s0, ci + e0);
-                tv.assign(v + s0, v + e0);
-                for (int32_t k = 0; k < e0 - s0; k++)
+                const int64_t in = inner[p];
+                if (in < 0 || in >= n)
                 {
-                    ci[size_t(s0 + k)] = tc[size_t(perm[size_t(k)])];
-                    v[size_t(s0 + k)] = tv[size_t(perm[size_t(k)])];
+                    bad[size_t(t)] = 1;
+                    continue;
                 }
+                const int64_t r = row_major ? o : in, c = row_major ? in : o;
+                if (!(lower ? (r >= c) : (r <= c)))
+                    continue;
+                fn(r, c, p);
+                if (r != c)
+                    fn(c, r, p);
             }
-        });
+    };
+    // counting walk: records per (thread, bucket)
+    std::vector<int64_t> cnt(size_t(nt) * size_t(nb), 0);
+    parallel_ranges(nt, nt, [&](int, int64_t t0, int64_t t1) {
+        for (int64_t t = t0; t < t1; t++)
+        {
+            int64_t* c = cnt.data() + size_t(t) * size_t(nb);
+            walk(int(t), [&](int64_t row, int64_t, int32_t) { c[row >> shift]++; });
+        }
+    });
+    for (char f : bad)
+        MISPEC_REQUIRE(!f, "mispec_csr_from_triangle: index out of range");
+    // staging offsets, bucket-major / thread-minor
+    std::vector<int64_t> off(size_t(nt) * size_t(nb) + 1, 0), bucket_begin(size_t(nb) + 1, 0);
+    int64_t total = 0;
+    for (int64_t b = 0; b < nb; b++)
+    {
+        bucket_begin[size_t(b)] = total;
+        for (int t = 0; t < nt; t++)
+        {
+            off[size_t(t) * size_t(nb) + size_t(b)] = total;
+            total += cnt[size_t(t) * size_t(nb) + size_t(b)];
+        }
+    }
+    bucket_begin[size_t(nb)] = total;
+    MISPEC_REQUIRE(total <= INT32_MAX, "mispec_csr_from_triangle: more than 2^31 - 1 entries");
+    M.nnz = total;
+    RawVec<Rec> stage;
+    stage.resize_uninitialized(size_t(std::max<int64_t>(total, 1)));
+    M.ci.resize_uninitialized(size_t(std::max<int64_t>(total, 1)));
+    M.v.resize_uninitialized(size_t(std::max<int64_t>(total, 1)));
+    int32_t* const ci = M.ci.data();
+    double* const v = M.v.data();
+    parallel_ranges(nt, nt, [&](int, int64_t t0, int64_t t1) {
+        for (int64_t t = t0; t < t1; t++)
+        {
+            std::vector<int64_t> cur(off.begin() + t * nb, off.begin() + (t + 1) * nb);
+            walk(int(t), [&](int64_t row, int64_t col, int32_t p) {
+                Rec& r = stage[size_t(cur[size_t(row >> shift)]++)];
+                r.row = int32_t(row);
+                r.col = int32_t(col);
+                r.val = val[p];
+            });
+        }
+    });
+    // pass 2: a bucket at a time — row counts, then placement; the row pointers get their global base from the bucket's offset
+    parallel_ranges(nb, std::min<int64_t>(ingest_threads(), nb), [&](int, int64_t b0, int64_t b1) {
+        std::vector<int32_t> cursor;
+        for (int64_t b = b0; b < b1; b++)
+        {
+            const int64_t r0 = b << shift, r1 = std::min<int64_t>(n, (b + 1) << shift);
+            if (r0 >= r1)
+                continue;
+            const Rec* rec = stage.data() + bucket_begin[size_t(b)];
+            const int64_t m = bucket_begin[size_t(b) + 1] - bucket_begin[size_t(b)];
+            cursor.assign(size_t(r1 - r0) + 1, 0);
+            for (int64_t k = 0; k < m; k++)
+                cursor[size_t(rec[k].row - r0) + 1]++;
+            int64_t run = bucket_begin[size_t(b)];
+            for (int64_t r = r0; r < r1; r++)
+            {
+                const int64_t c = cursor[size_t(r - r0) + 1];
+                rp[size_t(r)] = int32_t(run);  // rp[n] is set below
+                cursor[size_t(r - r0)] = int32_t(run - bucket_begin[size_t(b)]);
+                run += c;
+            }
+            for (int64_t k = 0; k < m; k++)
+            {
+                const int64_t q = bucket_begin[size_t(b)] + cursor[size_t(rec[k].row - r0)]++;
+                ci[size_t(q)] = rec[k].col;
+                v[size_t(q)] = rec[k].val;
+            }
+        }
+    });
+    rp[size_t(n)] = int32_t(total);
+    stage.resize_uninitialized(0);
+    // sort every row by column (the SpMV sums in storage order); rows of a sorted triangle are sorted already
+    parallel_ranges(n, ingest_threads(), [&](int, int64_t b, int64_t e) {
+        std::vector<int32_t> perm, tc;
+        std::vector<double> tv;
+        for (int64_t i = b; i < e; i++)
+        {
+            const int32_t s0 = rp[size_t(i)], e0 = rp[size_t(i) + 1];
+            if (e0 - s0 < 2 || std::is_sorted(ci + s0, ci + e0))
+                continue;
+            perm.resize(size_t(e0 - s0));
+            std::iota(perm.begin(), perm.end(), 0);
+            std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t c) { return ci[size_t(s0 + a)] < ci[size_t(s0 + c)]; });
+            tc.assign(ci + s0, ci + e0);
+            tv.assign(v + s0, v + e0);
+            for (int32_t k = 0; k < e0 - s0; k++)
+            {
+                ci[size_t(s0 + k)] = tc[size_t(perm[size_t(k)])];
+                v[size_t(s0 + k)] = tv[size_t(perm[size_t(k)])];
+            }
+        }
+    });
 }
 }  // namespace
 
@@ -1490,8 +1559,8 @@ extern "C" int mispec_mirror_triangle_host(int64_t n, const int32_t* outer, cons
         mirror_triangle(n, outer, inner, val, uplo == 'L' || uplo == 'l', row_major != 0, M);
         MISPEC_REQUIRE(M.nnz <= capacity, "mispec_mirror_triangle_host: output capacity too small");
         std::copy(M.rp.begin(), M.rp.end(), rowptr_out);
-        std::copy(M.ci.get(), M.ci.get() + M.nnz, colind_out);
-        std::copy(M.v.get(), M.v.get() + M.nnz, val_out);
+        std::copy(M.ci.data(), M.ci.data() + M.nnz, colind_out);
+        std::copy(M.v.data(), M.v.data() + M.nnz, val_out);
         *nnz_out = M.nnz;
     });
 }
@@ -1510,7 +1579,7 @@ extern "C" int mispec_csr_from_triangle(mispec_ctx* ctx, int64_t n, const int32_
             IngestTimer timer(1);
             mirror_triangle(n, outer, inner, val, lower, row_major != 0, M);
         }
-        *out = upload_rows(ctx, n, n, M.rp.data(), M.ci.get(), M.v.get(), true, true);
+        *out = upload_rows(ctx, n, n, M.rp.data(), M.ci.data(), M.v.data(), true, true);
     });
 }
 

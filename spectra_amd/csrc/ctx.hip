@@ -23,6 +23,16 @@ namespace mispec {
 static thread_local std::string g_last_error;
 void set_last_error(const std::string& msg) { g_last_error = msg; }
 
+void* big_host_alloc(size_t bytes)
+{
+    // plain malloc: asking for transparent huge pages (madvise) made the first touch SLOWER where it was tried (direct
+    // compaction and 2 MiB zeroing inside the page faults: 0.28 -> 2.8 s for the mirroring of a 2M-row matrix)
+    void* q = std::malloc(bytes ? bytes : 1);
+    if (!q)
+        throw std::bad_alloc();
+    return q;
+}
+
 int ingest_threads()
 {
     static const int n = [] {

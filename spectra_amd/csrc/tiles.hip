@@ -41,8 +41,15 @@ namespace mispec {
 namespace {
 // The tiles of segments [s0, s1) appended to `out` (entry offsets of the chunks are relative to their segment's first entry, so
 // pieces built by different threads concatenate without patching).  seg_len / seg_nchunk: entries and chunks of every segment.
+struct TilePiece  // what one thread builds: growable, concatenated into the HostTiles afterwards
+{
+    std::vector<TileChunk> chunks;
+    std::vector<double> val;
+    std::vector<uint32_t> idx;
+    int64_t padding = 0;
+};
 bool build_tiles_range(int64_t s0, int64_t s1, int64_t nrows, int64_t ncb, const int32_t* rowptr, const int32_t* colind, const double* val,
-                       HostTiles& out, std::vector<int64_t>& seg_len, std::vector<int32_t>& seg_nchunk)
+                       TilePiece& out, std::vector<int64_t>& seg_len, std::vector<int32_t>& seg_nchunk)
 {
     std::vector<int64_t> count(static_cast<size_t>(ncb)), start(size_t(ncb) + 1), fill(static_cast<size_t>(ncb));
     std::vector<uint32_t> tidx;  // entries of the segment, bucketed by tile (row-major inside a tile)
@@ -172,7 +179,7 @@ bool build_tiles(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int3
     std::vector<int64_t> seg_len(static_cast<size_t>(nseg), 0);
     std::vector<int32_t> seg_nchunk(static_cast<size_t>(nseg), 0);
     const int nt = int(std::max<int64_t>(1, std::min<int64_t>(ingest_threads(), nseg / 4)));
-    std::vector<HostTiles> piece(static_cast<size_t>(nt));
+    std::vector<TilePiece> piece(static_cast<size_t>(nt));
     std::vector<char> ok(static_cast<size_t>(nt), 1);
     parallel_ranges(nseg, nt, [&](int t, int64_t s0, int64_t s1) {
         const int64_t nnz = rowptr[std::min<int64_t>(s1 * kTileRows, nrows)] - rowptr[s0 * kTileRows];
@@ -194,9 +201,9 @@ bool build_tiles(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int3
         T.seg_chunk[size_t(s) + 1] = T.seg_chunk[size_t(s)] + seg_nchunk[size_t(s)];
     }
     const int64_t total = T.seg_entry[size_t(nseg)];
-    T.val.resize(size_t(total) + kTileSlack);
-    T.idx.resize(size_t(total) + kTileSlack);
-    T.chunks.resize(size_t(T.seg_chunk[size_t(nseg)]));
+    T.val.resize_uninitialized(size_t(total) + kTileSlack);  // filled by the threads below: no zero-fill pass
+    T.idx.resize_uninitialized(size_t(total) + kTileSlack);
+    T.chunks.resize_uninitialized(size_t(T.seg_chunk[size_t(nseg)]));
     std::vector<int64_t> at(static_cast<size_t>(nt) + 1, 0), cat(static_cast<size_t>(nt) + 1, 0);
     for (int t = 0; t < nt; t++)
     {
@@ -207,7 +214,7 @@ bool build_tiles(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int3
     parallel_ranges(nt, nt, [&](int, int64_t t0, int64_t t1) {
         for (int64_t t = t0; t < t1; t++)
         {
-            const HostTiles& P = piece[size_t(t)];
+            const TilePiece& P = piece[size_t(t)];
             std::copy(P.val.begin(), P.val.end(), T.val.begin() + at[size_t(t)]);
             std::copy(P.idx.begin(), P.idx.end(), T.idx.begin() + at[size_t(t)]);
             std::copy(P.chunks.begin(), P.chunks.end(), T.chunks.begin() + cat[size_t(t)]);
@@ -395,7 +402,8 @@ void upload_tiles(const HostTiles& H, hipStream_t stream, DevTiles& D)
 {
     auto up = [&](auto& dst, const auto& src) {
         dst.alloc(src.size());
-        MISPEC_HIP(hipMemcpyAsync(dst.p, src.data(), src.size() * sizeof(src[0]), hipMemcpyHostToDevice, stream));
+        if (src.size())
+            MISPEC_HIP(hipMemcpyAsync(dst.p, src.data(), src.size() * sizeof(src[0]), hipMemcpyHostToDevice, stream));
     };
     up(D.seg_entry, H.seg_entry);
     up(D.seg_chunk, H.seg_chunk);

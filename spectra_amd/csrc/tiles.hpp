@@ -49,9 +49,9 @@ struct HostTiles
 {
     std::vector<int64_t> seg_entry;   // nseg + 1: first entry of every segment
     std::vector<int32_t> seg_chunk;   // nseg + 1: first chunk of every segment
-    std::vector<TileChunk> chunks;
-    std::vector<double> val;          // padded entries carry 0.0
-    std::vector<uint32_t> idx;
+    RawVec<TileChunk> chunks;
+    RawVec<double> val;               // padded entries carry 0.0
+    RawVec<uint32_t> idx;
     int64_t padding = 0;              // padding entries inserted
     int64_t ncb = 0;                  // column blocks
 };

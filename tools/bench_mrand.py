@@ -16,14 +16,15 @@ import spectra_amd as sa
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
 ctx = sa.default_context()
 A = bench.m_rand_host(n)
+tri = sp.tril(A).tocsc()
 t0 = time.perf_counter()
-op = sa.SparseSymMatProd(sp.tril(A).tocsc(), ctx=ctx)
+op = sa.SparseSymMatProd(tri, ctx=ctx)
 ingest = time.perf_counter() - t0
 x = torch.rand(n, dtype=torch.float64, device="cuda") - 0.5
 y3 = torch.empty(n + 2, dtype=torch.float64, device="cuda")
 y0 = torch.empty(n + 2, dtype=torch.float64, device="cuda")
 torch.cuda.synchronize()
-out = {"n": n, "nnz": op.nnz(), "ingest_s": round(ingest, 2), "MISPEC_SPMV_TILES": os.environ.get("MISPEC_SPMV_TILES", "auto"), "tiles": op.tiles_info()}
+out = {"n": n, "nnz": op.nnz(), "ingest_s": round(ingest, 3), "ingest_stages": {k: round(v, 3) for k, v in sa.last_ingest_info().items()}, "MISPEC_SPMV_TILES": os.environ.get("MISPEC_SPMV_TILES", "auto"), "tiles": op.tiles_info()}
 for fmt, yy in ((3, y3), (0, y0)):
     op.set_spmv_format(fmt)
     op.spmv_time(x.data_ptr(), yy.data_ptr(), 3)
