@@ -1889,13 +1889,13 @@ extern "C" int mispec_fac_restart_sym(mispec_fac* fac, const double* shifts_host
             hs[i] = F.Hat(i, i);
         for (int i = 0; i < m; i++)
             hs[m + i] = (i < m - 1) ? F.Hat(i + 1, i) : 0.0;
-        // Where the (m-k) shifted QR sweeps run.  One GPU: on the device (k_restart_sym*, 0.24 ms, < 1 % of a restart
-        // cycle).  Row-sharded: every rank would repeat the same serial 0.24 ms while its share of the n-sized work
-        // shrinks with the rank count, so the sweeps run on the host core (same routine, internal/SmallDense.h,
-        // ~40 us) and only Q (m x m) is uploaded.  MISPEC_SMALL=host|device overrides (the same knob as for the Ritz pairs).
+        // Where the (m-k) shifted QR sweeps run: on the host core by default (same routine as the kernel, internal/SmallDense.h:
+        // ~40 us + a 12.8 KB upload of Q, against 0.24 ms for the one-wavefront kernel k_restart_sym* — a serial chain the GPU
+        // cannot speed up and that every rank of a sharded run would repeat).  Measured on C2, one GPU, end of round 3: 18.35 ->
+        // 18.72 eigenpairs/s (profiles/r05m_*; -2.3 % already in round 2, when the default was still the device).
+        // MISPEC_SMALL=device keeps the sweeps on the GPU (m <= 128; tested in both settings).
         static const char* where = getenv("MISPEC_SMALL");
-        // m > 128: the restart kernels keep the m x m Q in LDS and stop at 128 columns -> host
-        const bool on_host = m > kMaxSmallDim || (where ? std::string(where) == "host" : (F.sharded() && F.ctx->world() > 1));
+        const bool on_host = m > kMaxSmallDim || !(where && std::string(where) == "device");
         if (on_host)
         {
             F.counts[FAM_SMALL]++;

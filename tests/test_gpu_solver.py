@@ -234,8 +234,7 @@ def test_ritz_pairs_on_device_or_host_give_the_same_solve():
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for mode in ("default", "device", "host"):
-        # default: Ritz pairs on the host, restart sweeps on the device (one GPU); "device" / "host": both there (MISPEC_SMALL;
-        # "host" is what a row-sharded run uses)
+        # default = "host" since round 3 (Ritz pairs and restart sweeps on the host core); "device": both as HIP kernels
         env = dict(os.environ)
         env.pop("MISPEC_SMALL", None)
         if mode != "default":
