@@ -52,7 +52,7 @@ def parse():
                     help="HIP-event instrumentation of the timed solves: 2 = operator applications only (default), 1 = every kernel family")
     p.add_argument("--cpu-steps", type=int, default=20, help="Lanczos steps of the CPU sample (about 10 s of one host core at n = 1e7)")
     p.add_argument("--spmv-reps", type=int, default=50, help="stand-alone SpMV launches timed after the solves")
-    p.add_argument("--orth", default=ORTH_DEFAULT, choices=["reference", "onesweep"],
+    p.add_argument("--orth", default=ORTH_DEFAULT, choices=["reference", "onesweep", "onesweep-eager"],
                    help="orthogonalisation of the Lanczos steps in the timed region (include/mispec.h mispec_fac_set_orth_mode); the other "
                         "mode is timed as well, outside the timed region, and reported as `other_orth_mode`")
     return p.parse_args()
@@ -448,7 +448,7 @@ def main():
     # the other orthogonalisation mode on the same matrix, same number of steps (not part of `value`)
     other_mode = None
     if not args.no_profile:
-        other = "reference" if args.orth == "onesweep" else "onesweep"
+        other = "reference" if args.orth.startswith("onesweep") else "onesweep"
         oe = new_solver(0, other)
         solve(oe)
         o_elapsed, o_pairs, _ = timed_steps(oe, args.steps)
@@ -496,7 +496,7 @@ def main():
     else:
         exchange_desc = f", {transport_name} all-gather of the Krylov vector per SpMV" + (f" ({exchange_note})" if exchange_note else "")
     if rank == 0:
-        traffic, traffic_file = pmc_traffic(args.n, fmt, post_scaled=(args.orth == "onesweep")) if world == 1 else (None, None)
+        traffic, traffic_file = pmc_traffic(args.n, fmt, post_scaled=args.orth.startswith("onesweep")) if world == 1 else (None, None)
         out = {
             "metric": "eigenpairs_per_sec",
             "value": total_pairs / elapsed,
@@ -521,14 +521,15 @@ def main():
                                        "onesweep": "opt-in one-sweep variant (mispec_fac_set_orth_mode, DESIGN.md 3.2.1): the correction of a step "
                                                    "rides on the next step's pass over V; same decisions and fixed points, parity-gated by "
                                                    "tests/test_gpu_onesweep.py and the full-size golden; the reference-flow figure of the same "
-                                                   "run is `other_orth_mode`"}[args.orth]),
+                                                   "run is `other_orth_mode`; the last correction of every sweep rides on the restart's "
+                                                   "V*Q pass (mispec_fac_restart_sym_fused)"}[args.orth.replace("-eager", "")]),
                 "solver_object": "one SymEigsSolver (V, X, work vectors) allocated before the timed region and re-used by every step",
                 "eigenvectors": ("X = V*Y is formed in HBM and left there (the reference's eigenvectors() returns a host matrix: "
                                  f"the D2H copy of {8e-9 * args.n * args.nev:.1f} GB would add ~{8e-9 * args.n * args.nev / 55 * 1e3:.0f} ms per solve "
                                  "at ~55 GB/s PCIe and is not part of `value`)"),
             },
             "roofline": {
-                "kernel": head["kernel"] + " (SpMV fused with w -= beta*v_prev and the alpha dot" + ("; one-sweep steps: input f, row sums divided by beta" if args.orth == "onesweep" else "") + ")",
+                "kernel": head["kernel"] + " (SpMV fused with w -= beta*v_prev and the alpha dot" + ("; one-sweep steps: input f, row sums divided by beta" if args.orth.startswith("onesweep") else "") + ")",
                 "bound": "hbm",
                 "achieved": head["achieved"],
                 "peak": HBM_PEAK_GBPS,
@@ -565,7 +566,7 @@ def main():
             "value_with_host_eigenvectors": with_host,
             "roofline_orth": ({
                 "kernel": {"onesweep": "k_orth_lagged: correction of step i-1 + projection of step i in one pass over V (the largest share of a solve)",
-                           "reference": "k_orth<RESID_VTF>: f = w - alpha v, |f|, V'f (the first of the two passes over V of a step)"}[args.orth],
+                           "reference": "k_orth<RESID_VTF>: f = w - alpha v, |f|, V'f (the first of the two passes over V of a step)"}[args.orth.replace("-eager", "")],
                 "bound": "hbm", "bytes_per_launch_mean": split["bytes_vtf"] / max(split["n_vtf"], 1),
                 "ms_per_launch_mean": split["ms_vtf"] / max(split["n_vtf"], 1),
                 "achieved": split["bytes_vtf"] / (split["ms_vtf"] * 1e-3) / 1e9 if split["ms_vtf"] > 0 else None,
@@ -585,7 +586,7 @@ def main():
                 "exchange": {"count": 1, "kind": "neighbour send/recv" if halo else "all-gather",
                              "megabytes_received_per_rank": recv_doubles * 8 / 1e6 if halo else (world - 1) * block_mb},
                 "all_reduce_sum": [{"what": "alpha = <v, w>", "bytes": 8}] +
-                                  [{"what": "record: V'f (<= ncv slots used), |f|^2", "bytes": 8 * 1025}] * (1 if args.orth == "onesweep" else 2),
+                                  [{"what": "record: V'f (<= ncv slots used), |f|^2", "bytes": 8 * 1025}] * (1 if args.orth.startswith("onesweep") else 2),
                 "note": "per Lanczos step and rank; one-sweep: one record per step (+ one finishing pass per restart cycle), reference flow: "
                         "V'f and the correction's V'f check"}
         if allgather_run:

@@ -25,6 +25,12 @@ BAND_OFFSETS = (1, 2, 3, 1000, 1001, 100000, 100001)  # SURVEY.md §8(d) "M-band
 SYNTH_SEED = 20240607
 
 
+# include/mispec.h MISPEC_ORTH_*: the reference's control flow, or the opt-in one-sweep steps; "onesweep-eager" applies the
+# last correction of every sweep at once instead of letting it ride on the restart's V*Q pass, "onesweep-redo" is the test
+# hook that makes every such fused restart count as failed
+ORTH_MODES = {"reference": 0, "onesweep": 1, "onesweep-eager": 1 | 0x100, "onesweep-redo": 1 | 0x200}
+
+
 class SortRule(enum.IntEnum):
     """Util/SelectionRule.h:33-58 (same order as the C++ enum)."""
     LargestMagn = 0
@@ -875,15 +881,17 @@ class SymEigsSolver:
     def set_orth_mode(self, mode):
         """'reference' (default: Lanczos.h:145-181, two passes over V per step) or 'onesweep' (opt-in: the correction of a
         step rides on the next step's pass, include/mispec.h mispec_fac_set_orth_mode).  Call before init()."""
-        modes = {"reference": 0, "onesweep": 1, 0: 0, 1: 1}
-        check(lib().mispec_symeigs_set_orth_mode(self.h, modes[mode]))
+        check(lib().mispec_symeigs_set_orth_mode(self.h, ORTH_MODES.get(mode, mode)))
 
     def orth_info(self):
         mode, a, b, c = C.c_int(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
         r, k = C.c_double(0.0), C.c_double(0.0)
         check(lib().mispec_symeigs_orth_info(self.h, C.byref(mode), C.byref(a), C.byref(b), C.byref(c), C.byref(r), C.byref(k)))
+        fused, redone = C.c_int64(0), C.c_int64(0)
+        check(lib().mispec_symeigs_restart_info(self.h, C.byref(fused), C.byref(redone)))
         return {"mode": "onesweep" if mode.value else "reference", "lagged_steps": a.value, "check_stops": b.value,
-                "state_stops": c.value, "max_rel_c": r.value, "max_chk": k.value}
+                "state_stops": c.value, "max_rel_c": r.value, "max_chk": k.value, "fused_restarts": fused.value,
+                "fused_redone": redone.value}
 
     def overlap_info(self):
         """(first interior 256-row block, interior blocks, all blocks): what is multiplied while the exchange is in flight."""
@@ -1384,7 +1392,7 @@ class Factorization:
 
     def set_orth_mode(self, mode):
         """'reference' (default) or 'onesweep' (mispec_fac_set_orth_mode); call before factorize_from."""
-        check(lib().mispec_fac_set_orth_mode(self.h, {"reference": 0, "onesweep": 1, 0: 0, 1: 1}[mode]))
+        check(lib().mispec_fac_set_orth_mode(self.h, ORTH_MODES.get(mode, mode)))
 
     def init_random(self, seed=0):
         check(lib().mispec_fac_init_random(self.h, seed, C.byref(self.nmatop)))
@@ -1431,6 +1439,19 @@ class Factorization:
     def restart_sym(self, shifts):
         s = _f64(shifts)
         check(lib().mispec_fac_restart_sym(self.h, _dp(s), len(s)))
+
+    def restart_sym_fused(self, shifts):
+        """mispec_fac_restart_sym_fused: True if restarted; False if the pending correction of the one-sweep steps failed the
+        reference's test — the factorisation is then complete and corrected, recompute the Ritz values and restart again."""
+        s = _f64(shifts)
+        redo = C.c_int(0)
+        check(lib().mispec_fac_restart_sym_fused(self.h, _dp(s), len(s), C.byref(redo)))
+        return redo.value == 0
+
+    def restart_info(self):
+        fused, redone = C.c_int64(0), C.c_int64(0)
+        check(lib().mispec_fac_restart_info(self.h, C.byref(fused), C.byref(redone)))
+        return {"fused_restarts": fused.value, "fused_redone": redone.value}
 
     def compress_V(self, Q, H, new_k):
         Q = np.asfortranarray(Q, dtype=np.float64)

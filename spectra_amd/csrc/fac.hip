@@ -118,6 +118,14 @@ struct mispec_fac
     bool x_original = false;  // the columns of X have been put back into the caller's order
     DevBuf<double> pscratch;
     int red_cur = 0;   // which half of `red` holds the latest reduced record
+    // One-sweep steps: the correction of the LAST step of a full sweep is left pending (c = red_buf(end_rec)[0, m), H and beta
+    // already carry it) so that the restart's V*Q pass can apply it on the way (mispec_fac_restart_sym_fused); everything else
+    // that needs f calls finish_pending first.  V2: the out-of-place target of that pass, swapped with V when it is accepted.
+    bool end_pending = false;
+    bool eager_last = false, test_redo = false;  // MISPEC_ORTH_EAGER_LAST / MISPEC_ORTH_TEST_REDO
+    int end_rec = 0;
+    int64_t fused_restarts = 0, fused_redone = 0;
+    DevBuf<double> V2;
     int x_cols = 0;    // columns currently held in X
 
     // profile
@@ -136,6 +144,8 @@ struct mispec_fac
     // <v, w> of the fused SpMV epilogue: a device scalar of its own behind the two record halves (a reduction rewrites every
     // slot of the half it targets, and the one-sweep steps let records land in either half while alpha is still needed)
     double* alpha_slot() { return red.p + 2 * kPartialLd; }
+    // sharded runs: where the local sums of a record are all-reduced before they become a record half (krylov.hpp launch_finish)
+    double* red_stage() { return red.p + 2 * kPartialLd + 8; }
     hipStream_t stream() const { return ctx->stream; }
     // a communicator is attached (world may be 1: the collectives are then still issued, which is how the
     // RCCL / torch transports are smoke-tested on a single GPU)
@@ -614,9 +624,9 @@ void reduce_record(mispec_fac& F, int nrec, int ncol, int which, const FinishArg
     {
         FinishArgs none;
         none.mode = kFinishNone;
-        launch_reduce_partials(*F.ctx, F.partials.p, F.pstride, nrec, ncol, red, none);
-        allreduce(F, red, kSlotBeta2 + 1);  // slots [0, 64] are sums
-        launch_finish(*F.ctx, red, ncol, fin);
+        launch_reduce_partials(*F.ctx, F.partials.p, F.pstride, nrec, ncol, F.red_stage(), none);
+        allreduce(F, F.red_stage(), kSlotBeta2 + 1);  // slots [0, kSlotBeta2] are sums
+        launch_finish(*F.ctx, F.red_stage(), red, ncol, fin);
     }
     F.red_cur = which;
 }
@@ -762,6 +772,7 @@ void zero_vector(mispec_fac& F, double* v)
 // Common start of Arnoldi::init once the start vector is in F.tmp (Arnoldi.h:145-195).
 void init_from_tmp(mispec_fac& F, int64_t* nmatop)
 {
+    F.end_pending = false;
     std::fill(F.H.begin(), F.H.end(), 0.0);
     MISPEC_HIP(hipMemsetAsync(F.V.p, 0, F.V.n * sizeof(double), F.stream()));
     zero_vector(F, F.f.p);
@@ -846,6 +857,26 @@ void lanczos_corrections_host(mispec_fac& F, int i, int count)
         ortho_err = F.h_red.p[kSlotErr];
         count++;
     }
+}
+
+// MISPEC_SMALL=device keeps the m x m work of a restart on the GPU (tested in both settings); the default is the host core.
+bool small_on_device()
+{
+    static const bool on = getenv("MISPEC_SMALL") && std::string(getenv("MISPEC_SMALL")) == "device";
+    return on;
+}
+
+// One-sweep steps: apply the correction that the last step of the sweep left pending, then continue the reference's loop
+// (Lanczos.h:156-182) from "one correction applied".  H and beta already carry that correction (finish_lagged).
+void finish_pending(mispec_fac& F)
+{
+    if (!F.end_pending)
+        return;
+    F.end_pending = false;
+    F.red_cur = F.end_rec;
+    correct_vtf(F, F.f.p, F.f.p, F.m);  // :171, :177, :179
+    F.beta = F.h_red.p[kSlotBeta];
+    lanczos_corrections_host(F, F.m - 1, 1);
 }
 
 // One whole step of Lanczos.h:88-183 with every decision taken on the host (2-3 stream synchronisations).
@@ -969,8 +1000,9 @@ void lanczos_step_device(mispec_fac& F, int i)
 // applied to the not yet corrected column i; the pass that follows finishes column i with the correction measured in the
 // previous step, forms the next residual and measures its V'f — one sweep over V per step instead of two.  Records
 // alternate between the two halves of `red`: step i writes half (i & 1) and takes its coefficients from the other one.
-// `last`: the sweep ends here, so the residual is finished the reference's way by the CORRECT_VTF launches that follow.
-void lanczos_step_lagged(mispec_fac& F, int i, bool last)
+// `last`: the sweep ends here, so the residual is finished the reference's way by the CORRECT_VTF launches that follow —
+// unless `defer`: then the correction stays pending like that of any other step and the restart applies it (F.end_pending).
+void lanczos_step_lagged(mispec_fac& F, int i, bool last, bool defer)
 {
     StepState* st = F.d_state.p;
     double* v = F.col(i);
@@ -1001,7 +1033,7 @@ void lanczos_step_lagged(mispec_fac& F, int i, bool last)
     fin.beta_thresh = kEps * std::sqrt(double(F.n));
     fin.eps_sqrt = std::sqrt(kEps);
     fin.lag_limit = F.lag_limit;
-    fin.lag_last = last ? 1 : 0;
+    fin.lag_last = (last && !defer) ? 1 : 0;
     fin.max_spec = speculative_corrections(F);
     {
         OrthArgs a = orth_args(F, i);
@@ -1022,7 +1054,7 @@ void lanczos_step_lagged(mispec_fac& F, int i, bool last)
         fin.prev_red = F.red_buf(cur ^ 1);
         reduce_record(F, nrec, 2 * i + 1, cur, fin);
     }
-    if (!last)
+    if (!last || defer)
         return;
     const int i1 = i + 1;
     for (int c = 0; c < fin.max_spec; c++)
@@ -1047,6 +1079,9 @@ void factorize_lanczos(mispec_fac& F, int from_k, int to_m, int64_t* nmatop)
     zero_H_outside(F, from_k);
     const bool fast = F.device_steps && F.A != nullptr && !F.bmode() && F.Chol == nullptr;
     const bool lagged = fast && F.onesweep && F.m <= kPanelCols && !F.A2;  // standard problems, one column panel
+    // a sweep that completes the factorisation is followed by a restart (or by nothing that needs f): its last correction can wait
+    const bool defer = lagged && to_m == F.m && !F.eager_last && !small_on_device();
+    F.end_pending = false;
     int i = from_k;
     while (i <= to_m - 1)
     {
@@ -1070,7 +1105,7 @@ void factorize_lanczos(mispec_fac& F, int from_k, int to_m, int64_t* nmatop)
         for (int s = i; s <= to_m - 1; s++)
         {
             if (lagged)
-                lanczos_step_lagged(F, s, s == to_m - 1);
+                lanczos_step_lagged(F, s, s == to_m - 1, defer);
             else
                 lanczos_step_device(F, s);
         }
@@ -1094,7 +1129,14 @@ void factorize_lanczos(mispec_fac& F, int from_k, int to_m, int64_t* nmatop)
         *nmatop += (last_done - i + 1);
         F.beta = hs.beta;
         if (status == kStepOk)
+        {
+            if (defer && hs.lag_pending)
+            {
+                F.end_pending = true;
+                F.end_rec = (to_m - 1) & 1;
+            }
             break;
+        }
         // ---- the rare branches continue on the host path, then the device path resumes ---------------
         if (status == kStepLagCheck)
         {
@@ -1508,7 +1550,7 @@ int fac_create_impl(mispec_ctx* ctx, const mispec_csr* A, const mispec_symshift*
             F->partials.alloc(size_t(max_rec) * kPartialLd);
             const int64_t nparts = std::max<int64_t>(A ? spmv_num_blocks(F->nloc) : 0, lanczos_epilogue_records(*ctx, F->nloc));
             F->alpha_partials.alloc(size_t(std::max<int64_t>(nparts, 1)));
-            F->red.alloc(2 * kPartialLd + 8);
+            F->red.alloc(3 * kPartialLd + 16);
             MISPEC_HIP(hipMemsetAsync(F->red.p, 0, F->red.n * sizeof(double), ctx->stream));
             F->Qdev.alloc(size_t(ncv) * ncv);
             F->d_diag.alloc(size_t(ncv));
@@ -1680,6 +1722,7 @@ extern "C" int mispec_fac_factorize(mispec_fac* fac, int from_k, int to_m, int64
         F.ctx->make_current();
         if (to_m <= from_k)
             return;
+        finish_pending(F);
         MISPEC_REQUIRE(to_m <= F.m && from_k >= 1, "factorize_from: need 1 <= from_k < to_m <= ncv");
         if (from_k > F.k)  // Lanczos.h:70-75 / Arnoldi.h:206-211
             throw Error(MISPEC_EINVAL, std::string(F.symmetric ? "Lanczos" : "Arnoldi") + ": from_k (= " + std::to_string(from_k) +
@@ -1711,8 +1754,13 @@ extern "C" int mispec_fac_set_orth_mode(mispec_fac* fac, int mode)
 {
     return guarded([&] {
         MISPEC_REQUIRE(fac, "mispec_fac_set_orth_mode: NULL argument");
-        MISPEC_REQUIRE(mode == MISPEC_ORTH_REFERENCE || mode == MISPEC_ORTH_ONESWEEP, "mispec_fac_set_orth_mode: unknown mode");
-        fac->onesweep = (mode == MISPEC_ORTH_ONESWEEP);
+        const int base = mode & 0xff, flags = mode & ~0xff;
+        MISPEC_REQUIRE((base == MISPEC_ORTH_REFERENCE && flags == 0) ||
+                           (base == MISPEC_ORTH_ONESWEEP && (flags & ~(MISPEC_ORTH_EAGER_LAST | MISPEC_ORTH_TEST_REDO)) == 0),
+                       "mispec_fac_set_orth_mode: unknown mode");
+        fac->onesweep = (base == MISPEC_ORTH_ONESWEEP);
+        fac->eager_last = (flags & MISPEC_ORTH_EAGER_LAST) != 0;
+        fac->test_redo = (flags & MISPEC_ORTH_TEST_REDO) != 0;
     });
 }
 
@@ -1738,6 +1786,17 @@ extern "C" int mispec_fac_orth_info(const mispec_fac* fac, int* mode, int64_t* l
     });
 }
 
+extern "C" int mispec_fac_restart_info(const mispec_fac* fac, int64_t* fused, int64_t* redone)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(fac, "mispec_fac_restart_info: NULL argument");
+        if (fused)
+            *fused = fac->fused_restarts;
+        if (redone)
+            *redone = fac->fused_redone;
+    });
+}
+
 extern "C" int mispec_fac_exchange_info(const mispec_fac* fac, int* halo, int64_t* recv_doubles)
 {
     return guarded([&] {
@@ -1759,6 +1818,11 @@ extern "C" int mispec_fac_get_H(const mispec_fac* fac, double* H_host)
 {
     return guarded([&] {
         MISPEC_REQUIRE(fac && H_host, "mispec_fac_get_H: NULL argument");
+        if (fac->end_pending)  // a further correction, should the reference's loop take one, still changes H(m-1, m-2 : m-1)
+        {
+            fac->ctx->make_current();
+            finish_pending(*const_cast<mispec_fac*>(fac));
+        }
         std::memcpy(H_host, fac->H.data(), fac->H.size() * sizeof(double));
     });
 }
@@ -1767,6 +1831,11 @@ extern "C" int mispec_fac_set_H(mispec_fac* fac, const double* H_host, int k)
 {
     return guarded([&] {
         MISPEC_REQUIRE(fac && H_host && k >= 0 && k <= fac->m, "mispec_fac_set_H: bad argument");
+        if (fac->end_pending)
+        {
+            fac->ctx->make_current();
+            finish_pending(*fac);
+        }
         std::memcpy(fac->H.data(), H_host, fac->H.size() * sizeof(double));
         fac->k = k;
     });
@@ -1800,6 +1869,7 @@ extern "C" int mispec_fac_get_f(const mispec_fac* fac, double* f_host)
     return guarded([&] {
         MISPEC_REQUIRE(fac && f_host, "mispec_fac_get_f: NULL argument");
         fac->ctx->make_current();
+        finish_pending(*const_cast<mispec_fac*>(fac));  // one-sweep steps: the last correction may still be owed
         MISPEC_HIP(hipStreamSynchronize(fac->ctx->stream));
         if (fac->perm_mode)
         {
@@ -1873,76 +1943,145 @@ extern "C" int mispec_fac_tridiag_eigen(mispec_fac* fac, double* evals_host, dou
     });
 }
 
-extern "C" int mispec_fac_restart_sym(mispec_fac* fac, const double* shifts_host, int nshift)
+namespace {
+
+// mispec_fac_restart_sym / _fused.  `redo` != nullptr: a pending correction of the one-sweep steps may ride on the V*Q pass.
+void restart_sym_impl(mispec_fac* fac, const double* shifts_host, int nshift, int* redo)
 {
-    return guarded([&] {
-        require_init(fac, "mispec_fac_restart_sym");
-        mispec_fac& F = *fac;
-        MISPEC_REQUIRE(F.symmetric, "mispec_fac_restart_sym: symmetric (Lanczos) factorisations only");
-        MISPEC_REQUIRE(shifts_host && nshift >= 1 && nshift < F.m, "mispec_fac_restart_sym: need 1 <= nshift < ncv");
-        MISPEC_REQUIRE(F.k == F.m, "mispec_fac_restart_sym: the factorisation must be complete (k == ncv)");
-        F.ctx->make_current();
-        const int m = F.m;
-        const int k = m - nshift;  // compress_H decrements k once per shift (Lanczos.h:198-202)
-        double* hs = F.h_small.p;  // [diag m][subd m][Q m*m]
+    require_init(fac, "mispec_fac_restart_sym");
+    mispec_fac& F = *fac;
+    MISPEC_REQUIRE(F.symmetric, "mispec_fac_restart_sym: symmetric (Lanczos) factorisations only");
+    MISPEC_REQUIRE(shifts_host && nshift >= 1 && nshift < F.m, "mispec_fac_restart_sym: need 1 <= nshift < ncv");
+    MISPEC_REQUIRE(F.k == F.m, "mispec_fac_restart_sym: the factorisation must be complete (k == ncv)");
+    F.ctx->make_current();
+    if (redo)
+        *redo = 0;
+    else
+        finish_pending(F);
+    const int m = F.m;
+    const int k = m - nshift;  // compress_H decrements k once per shift (Lanczos.h:198-202)
+    double* hs = F.h_small.p;  // [diag m][subd m][Q m*m]
+    for (int i = 0; i < m; i++)
+        hs[i] = F.Hat(i, i);
+    for (int i = 0; i < m; i++)
+        hs[m + i] = (i < m - 1) ? F.Hat(i + 1, i) : 0.0;
+    // Where the (m-k) shifted QR sweeps run: on the host core by default (same routine as the kernel, internal/SmallDense.h:
+    // ~40 us + a 12.8 KB upload of Q, against 0.24 ms for the one-wavefront kernel k_restart_sym* — a serial chain the GPU
+    // cannot speed up and that every rank of a sharded run would repeat).  Measured on C2, one GPU, end of round 3: 18.35 ->
+    // 18.72 eigenpairs/s (profiles/r05m_*; -2.3 % already in round 2, when the default was still the device).
+    // MISPEC_SMALL=device keeps the sweeps on the GPU (m <= 128; tested in both settings).
+    const bool on_host = m > kMaxSmallDim || !small_on_device();
+    if (on_host)
+    {
+        F.counts[FAM_SMALL]++;
+        double* Q = hs + 2 * m;
+        std::fill(Q, Q + size_t(m) * m, 0.0);
         for (int i = 0; i < m; i++)
-            hs[i] = F.Hat(i, i);
-        for (int i = 0; i < m; i++)
-            hs[m + i] = (i < m - 1) ? F.Hat(i + 1, i) : 0.0;
-        // Where the (m-k) shifted QR sweeps run: on the host core by default (same routine as the kernel, internal/SmallDense.h:
-        // ~40 us + a 12.8 KB upload of Q, against 0.24 ms for the one-wavefront kernel k_restart_sym* — a serial chain the GPU
-        // cannot speed up and that every rank of a sharded run would repeat).  Measured on C2, one GPU, end of round 3: 18.35 ->
-        // 18.72 eigenpairs/s (profiles/r05m_*; -2.3 % already in round 2, when the default was still the device).
-        // MISPEC_SMALL=device keeps the sweeps on the GPU (m <= 128; tested in both settings).
-        static const char* where = getenv("MISPEC_SMALL");
-        const bool on_host = m > kMaxSmallDim || !(where && std::string(where) == "device");
-        if (on_host)
+            Q[size_t(i) * m + i] = 1.0;
+        std::vector<double> work(size_t(4) * m);
+        for (int sft = 0; sft < nshift; sft++)
+            small::tridiag_shifted_qr(m, hs, hs + m, shifts_host[sft], Q, m, m, work.data(), small::Lanes{0, 1});
+        MISPEC_HIP(hipMemcpyAsync(F.Qdev.p, Q, size_t(m) * m * 8, hipMemcpyHostToDevice, F.stream()));
+        const double q_last = Q[size_t(k - 1) * m + (m - 1)], h_sub = hs[m + k - 1];  // Q(m-1, k-1), the new H(k, k-1)
+        const bool fused = F.end_pending;
+        if (fused)
         {
-            F.counts[FAM_SMALL]++;
-            double* Q = hs + 2 * m;
-            std::fill(Q, Q + size_t(m) * m, 0.0);
-            for (int i = 0; i < m; i++)
-                Q[size_t(i) * m + i] = 1.0;
-            std::vector<double> work(size_t(4) * m);
-            for (int sft = 0; sft < nshift; sft++)
-                small::tridiag_shifted_qr(m, hs, hs + m, shifts_host[sft], Q, m, m, work.data(), small::Lanes{0, 1});
-            MISPEC_HIP(hipMemcpyAsync(F.Qdev.p, Q, size_t(m) * m * 8, hipMemcpyHostToDevice, F.stream()));
+            // One-sweep steps: the last step's correction f = ftilde - V c and the reference's test of the result (Lanczos.h:
+            // 156: max |V'f| <= eps |f|) ride on the V*Q pass (k_vq_fused) — one sweep over the basis instead of two.  Out of
+            // place, so that a failed test costs nothing but the pass: the old basis is then finished by the reference's loop
+            // and the caller recomputes its Ritz values (H(m-1, m-2 : m-1) has changed) before restarting again.
+            if (F.V2.n < F.V.n)
+            {
+                F.V2.alloc(F.V.n);
+                MISPEC_HIP(hipMemsetAsync(F.V2.p, 0, F.V2.n * sizeof(double), F.stream()));
+            }
+            VqFusedArgs fa;
+            fa.c = F.red_buf(F.end_rec);
+            fa.ftilde = F.f.p;
+            fa.fnew = F.tmp.p;
+            fa.q_last = q_last;
+            fa.h_sub = h_sub;
+            fa.kcol = k;
+            fa.partials = F.partials.p;
+            fa.pstride = F.pstride;
+            int nrec;
             {
                 Timed t(F, FAM_COMPRESS);
-                compress_basis(F, k + 1);
+                F.count_bytes(FAM_COMPRESS, m + k + 1 + 2);  // m columns and ftilde read, k + 1 columns and the new f written
+                nrec = launch_vq_fused(*F.ctx, F.V.p, F.ldv, m, F.Qdev.p, m, k + 1, F.V2.p, F.ldv, F.nloc, fa);
             }
-            std::fill(F.H.begin(), F.H.end(), 0.0);
-            for (int i = 0; i < m; i++)
-                F.Hat(i, i) = hs[i];
-            for (int i = 0; i < m - 1; i++)
-                F.Hat(i + 1, i) = F.Hat(i, i + 1) = hs[m + i];
-            F.k = k;
-            update_f_after_compress(F, Q[size_t(k - 1) * m + (m - 1)], F.Hat(k, k - 1));  // syncs: Q has been consumed by then
-            return;
+            reduce_to_host(F, nrec, m + 1, F.end_rec ^ 1);  // slots [0, m) V'f, m |f_new|^2, kSlotBeta2 |f|^2
+            double err = 0.0;
+            for (int j = 0; j < m; j++)
+                err = std::max(err, std::fabs(F.h_red.p[j]));
+            const double beta_corr = F.h_red.p[kSlotBeta];
+            F.lag_chk_max = std::max(F.lag_chk_max, beta_corr > 0.0 ? err / beta_corr : 0.0);
+            if (err > kEps * beta_corr || F.test_redo)  // Lanczos.h:156 with count = 1
+            {
+                F.fused_redone++;
+                finish_pending(F);
+                *redo = 1;
+                return;
+            }
+            F.fused_restarts++;
+            F.end_pending = false;
+            F.V.swap(F.V2);
+            F.f.swap(F.tmp);
+            F.beta = std::sqrt(F.h_red.p[m]);  // Arnoldi.h:339
         }
-        MISPEC_HIP(hipMemcpyAsync(F.d_diag.p, hs, size_t(m) * 8, hipMemcpyHostToDevice, F.stream()));
-        MISPEC_HIP(hipMemcpyAsync(F.d_subd.p, hs + m, size_t(m) * 8, hipMemcpyHostToDevice, F.stream()));
-        {
-            Timed t(F, FAM_SMALL);
-            launch_restart_sym(*F.ctx, m, F.d_diag.p, F.d_subd.p, shifts_host, nshift, F.Qdev.p);
-        }
-        // V[:, :k+1] <- V Q  (Arnoldi.h:326-335), in place, straight from the device Q
+        else
         {
             Timed t(F, FAM_COMPRESS);
             compress_basis(F, k + 1);
         }
-        MISPEC_HIP(hipMemcpyAsync(hs, F.d_diag.p, size_t(m) * 8, hipMemcpyDeviceToHost, F.stream()));
-        MISPEC_HIP(hipMemcpyAsync(hs + m, F.d_subd.p, size_t(m) * 8, hipMemcpyDeviceToHost, F.stream()));
-        MISPEC_HIP(hipMemcpyAsync(hs + 2 * m, F.Qdev.p + size_t(k - 1) * m + (m - 1), sizeof(double), hipMemcpyDeviceToHost,
-                                  F.stream()));
-        sync_stream(F);
         std::fill(F.H.begin(), F.H.end(), 0.0);
         for (int i = 0; i < m; i++)
             F.Hat(i, i) = hs[i];
         for (int i = 0; i < m - 1; i++)
             F.Hat(i + 1, i) = F.Hat(i, i + 1) = hs[m + i];
         F.k = k;
-        update_f_after_compress(F, hs[2 * m], F.Hat(k, k - 1));
+        if (!fused)
+            update_f_after_compress(F, q_last, h_sub);  // syncs: Q has been consumed by then
+        return;
+    }
+    finish_pending(F);
+    MISPEC_HIP(hipMemcpyAsync(F.d_diag.p, hs, size_t(m) * 8, hipMemcpyHostToDevice, F.stream()));
+    MISPEC_HIP(hipMemcpyAsync(F.d_subd.p, hs + m, size_t(m) * 8, hipMemcpyHostToDevice, F.stream()));
+    {
+        Timed t(F, FAM_SMALL);
+        launch_restart_sym(*F.ctx, m, F.d_diag.p, F.d_subd.p, shifts_host, nshift, F.Qdev.p);
+    }
+    // V[:, :k+1] <- V Q  (Arnoldi.h:326-335), in place, straight from the device Q
+    {
+        Timed t(F, FAM_COMPRESS);
+        compress_basis(F, k + 1);
+    }
+    MISPEC_HIP(hipMemcpyAsync(hs, F.d_diag.p, size_t(m) * 8, hipMemcpyDeviceToHost, F.stream()));
+    MISPEC_HIP(hipMemcpyAsync(hs + m, F.d_subd.p, size_t(m) * 8, hipMemcpyDeviceToHost, F.stream()));
+    MISPEC_HIP(hipMemcpyAsync(hs + 2 * m, F.Qdev.p + size_t(k - 1) * m + (m - 1), sizeof(double), hipMemcpyDeviceToHost,
+                              F.stream()));
+    sync_stream(F);
+    std::fill(F.H.begin(), F.H.end(), 0.0);
+    for (int i = 0; i < m; i++)
+        F.Hat(i, i) = hs[i];
+    for (int i = 0; i < m - 1; i++)
+        F.Hat(i + 1, i) = F.Hat(i, i + 1) = hs[m + i];
+    F.k = k;
+    update_f_after_compress(F, hs[2 * m], F.Hat(k, k - 1));
+}
+
+}  // namespace
+
+extern "C" int mispec_fac_restart_sym(mispec_fac* fac, const double* shifts_host, int nshift)
+{
+    return guarded([&] { restart_sym_impl(fac, shifts_host, nshift, nullptr); });
+}
+
+extern "C" int mispec_fac_restart_sym_fused(mispec_fac* fac, const double* shifts_host, int nshift, int* redo)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(redo, "mispec_fac_restart_sym_fused: redo is NULL");
+        restart_sym_impl(fac, shifts_host, nshift, redo);
     });
 }
 
@@ -1953,6 +2092,7 @@ extern "C" int mispec_fac_compress_V(mispec_fac* fac, const double* Q_host, cons
         mispec_fac& F = *fac;
         MISPEC_REQUIRE(Q_host && H_host && new_k >= 1 && new_k < F.m, "mispec_fac_compress_V: bad argument");
         F.ctx->make_current();
+        finish_pending(F);
         const int m = F.m;
         std::memcpy(F.h_small.p, Q_host, size_t(m) * m * sizeof(double));
         MISPEC_HIP(hipMemcpyAsync(F.Qdev.p, F.h_small.p, size_t(m) * m * 8, hipMemcpyHostToDevice, F.stream()));

@@ -432,6 +432,10 @@ extern "C" int mispec_symeigs_orth_info(const mispec_symeigs* s, int* mode, int6
 {
     return s ? mispec_fac_orth_info(s->fac(), mode, lagged_steps, check_stops, state_stops, max_rel_c, max_chk) : MISPEC_EINVAL;
 }
+extern "C" int mispec_symeigs_restart_info(const mispec_symeigs* s, int64_t* fused, int64_t* redone)
+{
+    return s ? mispec_fac_restart_info(s->fac(), fused, redone) : MISPEC_EINVAL;
+}
 extern "C" int mispec_symeigs_exchange_info(const mispec_symeigs* s, int* halo, int64_t* recv_doubles)
 {
     return s ? mispec_fac_exchange_info(s->fac(), halo, recv_doubles) : MISPEC_EINVAL;

@@ -598,6 +598,10 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restri
                                                            int ncol, double* __restrict__ red, FinishArgs fin)
 {
     __shared__ double sh[kPartialLd];
+    // A device-driven run that has stopped: the launches still in the queue are no-ops, and so is this one — the two record
+    // halves must stay what the stopping pass and the one before it left there, the host continues from them.
+    if (fin.st != nullptr && fin.st->status != kStepOk)
+        return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int t = tid; t < kPartialLd; t += 1024)
@@ -636,9 +640,15 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restri
         red[t] = sh[t];
 }
 
-__global__ void k_finish(double* red, int ncol, FinishArgs fin)
+// Sharded runs: the all-reduced record sits in a staging area; it becomes the content of a record half only while the run is live.
+__global__ __launch_bounds__(256) void k_finish(const double* __restrict__ stage, double* __restrict__ red, int ncol, FinishArgs fin)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0)
+    if (fin.st != nullptr && fin.st->status != kStepOk)
+        return;
+    for (int t = threadIdx.x; t < kPartialLd; t += 256)
+        red[t] = stage[t];
+    __syncthreads();
+    if (threadIdx.x == 0)
         finish_record(red, ncol, fin);
 }
 
@@ -901,6 +911,138 @@ __global__ __launch_bounds__(kThreads) void k_vq(const double* __restrict__ V, i
                 if (i < p)  // 2 GB of output per restart: streamed past the caches like the input
                     __builtin_nontemporal_store(v2d{acc[jj].x, acc[jj].y}, reinterpret_cast<v2d*>(X + int64_t(i) * ldx + r));
             }
+        }
+    }
+}
+
+// ---- V*Q with the pending correction of the last one-sweep step riding on it (krylov.hpp launch_vq_fused) ----------------------
+// k_vq's tiling (128-row tiles of all m columns staged in LDS, wave w = output columns w, w+4, ...), out of place.  Every wave
+// additionally forms the corrected residual of its rows from the staged tile (p = V c: m LDS reads, the same for all four
+// waves — cheaper than a second barrier), accumulates chk_j = <V_j, f_corr> for the input columns j = w (mod 4), and the wave
+// that holds output column kcol writes fnew.  Rows past the end are staged from row 0 (clamped address) and masked out of every sum.
+template <int MAXS>
+__global__ __launch_bounds__(kThreads) void k_vq_fused(const double* __restrict__ V, int64_t ldv, int m, const double* __restrict__ Q,
+                                                        int ldq, int p, double* __restrict__ X, int64_t ldx, int64_t n, VqFusedArgs fa)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* Vt = smem;                           // [m][128]
+    double* Qs = smem + int64_t(m) * kTileRows;  // [m][4][MAXS]
+    double* cs = Qs + int64_t(m) * 4 * MAXS;     // [m]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int kMaxJ = kPanelCols / 4;
+    const int nj = (m - w + 3) / 4;
+    for (int idx = tid; idx < m * 4 * MAXS; idx += kThreads)
+    {
+        const int jj = idx % MAXS, ww = (idx / MAXS) & 3, j = idx / (4 * MAXS);
+        const int i = ww + 4 * jj;
+        Qs[idx] = (i < p) ? Q[j + int64_t(i) * ldq] : 0.0;
+    }
+    for (int j = tid; j < m; j += kThreads)
+        cs[j] = fa.c[j];
+    double chk[kMaxJ];
+#pragma unroll
+    for (int jj = 0; jj < kMaxJ; jj++)
+        chk[jj] = 0.0;
+    double b2c = 0.0, b2n = 0.0;
+    const int64_t ntiles = (n + kTileRows - 1) / kTileRows;
+    v2d pre[kMaxJ];
+    int64_t t = blockIdx.x;
+    if (t < ntiles)
+        vq_fetch<kMaxJ>(pre, V, ldv, w, nj, t * kTileRows + 2 * lane, n);
+    for (; t < ntiles; t += gridDim.x)
+    {
+        const int64_t r = t * kTileRows + 2 * lane;
+        const bool valid = r < n;
+        __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < kMaxJ; jj++)
+            if (jj < nj)
+                *reinterpret_cast<v2d*>(&Vt[(w + 4 * jj) * kTileRows + 2 * lane]) = pre[jj];
+        double2 ft;
+        ft.x = ft.y = 0.0;
+        if (valid)
+            ft = *reinterpret_cast<const double2*>(fa.ftilde + r);
+        __syncthreads();
+        if (t + gridDim.x < ntiles)
+            vq_fetch<kMaxJ>(pre, V, ldv, w, nj, (t + gridDim.x) * kTileRows + 2 * lane, n);
+
+        double2 acc[MAXS];
+#pragma unroll
+        for (int jj = 0; jj < MAXS; jj++)
+        {
+            acc[jj].x = 0.0;
+            acc[jj].y = 0.0;
+        }
+        double2 pc;  // (V c) of this lane's two rows
+        pc.x = pc.y = 0.0;
+        for (int j = 0; j < m; j++)
+        {
+            const double2 v = *reinterpret_cast<const double2*>(&Vt[j * kTileRows + 2 * lane]);
+            const double* q = &Qs[(j * 4 + w) * MAXS];
+            const double cj = cs[j];
+            pc.x += v.x * cj;  // Lanczos.h:171
+            pc.y += v.y * cj;
+#pragma unroll
+            for (int jj = 0; jj < MAXS; jj++)
+            {
+                acc[jj].x += v.x * q[jj];  // Arnoldi.h:332-334
+                acc[jj].y += v.y * q[jj];
+            }
+        }
+        double2 fc;
+        fc.x = valid ? ft.x - pc.x : 0.0;
+        fc.y = valid ? ft.y - pc.y : 0.0;
+#pragma unroll
+        for (int jj = 0; jj < kMaxJ; jj++)
+            if (jj < nj)
+            {
+                const double2 v = *reinterpret_cast<const double2*>(&Vt[(w + 4 * jj) * kTileRows + 2 * lane]);
+                chk[jj] += v.x * fc.x + v.y * fc.y;  // Lanczos.h:179
+            }
+        if (w == 0)
+            b2c += fc.x * fc.x + fc.y * fc.y;
+        if (valid)
+        {
+#pragma unroll
+            for (int jj = 0; jj < MAXS; jj++)
+            {
+                const int i = w + 4 * jj;
+                if (i < p)
+                    __builtin_nontemporal_store(v2d{acc[jj].x, acc[jj].y}, reinterpret_cast<v2d*>(X + int64_t(i) * ldx + r));
+                if (i == fa.kcol)  // wave-uniform: this wave holds the column that enters the new residual
+                {
+                    double2 fn;
+                    fn.x = fc.x * fa.q_last + acc[jj].x * fa.h_sub;  // Arnoldi.h:337
+                    fn.y = fc.y * fa.q_last + acc[jj].y * fa.h_sub;
+                    *reinterpret_cast<double2*>(fa.fnew + r) = fn;
+                    b2n += fn.x * fn.x + fn.y * fn.y;
+                }
+            }
+        }
+    }
+    double* rec = fa.partials + blockIdx.x;
+#pragma unroll
+    for (int jj = 0; jj < kMaxJ; jj++)
+    {
+        const double sum = wave_reduce_sum(chk[jj]);
+        const int j = w + 4 * jj;
+        if (lane == 0 && j < m)
+            rec[int64_t(j) * fa.pstride] = sum;
+    }
+    if (w == (fa.kcol & 3))
+    {
+        const double sum = wave_reduce_sum(b2n);
+        if (lane == 0)
+            rec[int64_t(m) * fa.pstride] = sum;
+    }
+    if (w == 0)
+    {
+        const double sum = wave_reduce_sum(b2c);
+        if (lane == 0)
+        {
+            rec[kSlotBeta2 * fa.pstride] = sum;
+            rec[kSlotMaxAbs * fa.pstride] = 0.0;
         }
     }
 }
@@ -1250,9 +1392,9 @@ void launch_reduce_partials(const mispec_ctx& ctx, const double* partials, int64
     MISPEC_HIP(hipGetLastError());
 }
 
-void launch_finish(const mispec_ctx& ctx, double* red, int ncol, const FinishArgs& fin)
+void launch_finish(const mispec_ctx& ctx, const double* stage, double* red, int ncol, const FinishArgs& fin)
 {
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, ctx.stream, red, ncol, fin);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, ctx.stream, stage, red, ncol, fin);
     MISPEC_HIP(hipGetLastError());
 }
 
@@ -1383,6 +1525,38 @@ void launch_vq(const mispec_ctx& ctx, const double* V, int64_t ldv, int m, const
         for (int m0 = 0; m0 < m; m0 += kPanelCols)
             launch_vq_panel(ctx, V + int64_t(m0) * ldv, ldv, std::min(kPanelCols, m - m0), Q + m0 + int64_t(p0) * ldq, ldq,
                             std::min(kPanelCols, p - p0), X + int64_t(p0) * ldx, ldx, n, m0 > 0);
+}
+
+int launch_vq_fused(const mispec_ctx& ctx, const double* V, int64_t ldv, int m, const double* Q, int ldq, int p, double* X, int64_t ldx,
+                    int64_t n, const VqFusedArgs& fa)
+{
+    MISPEC_REQUIRE(m >= 1 && m <= kPanelCols && p >= 1 && p <= kPanelCols && X != V && fa.kcol >= 0 && fa.kcol < p && fa.fnew != fa.ftilde,
+                   "fused V*Q kernel: needs 1 <= m, p <= 64, an output buffer of its own and kcol < p");
+    const int64_t ntiles = (n + kTileRows - 1) / kTileRows;
+    const int slots = (p + 3) / 4;
+    const int maxs = slots <= 4 ? 4 : slots <= 8 ? 8 : slots <= 12 ? 12 : 16;
+    const size_t lds = (size_t(m) * kTileRows + size_t(m) * 4 * maxs + size_t(m)) * sizeof(double);
+    const int grid = persistent_grid(ctx, ntiles, 3);
+    MISPEC_REQUIRE(fa.pstride >= grid, "fused V*Q kernel: partial-record stride smaller than the grid");
+    const dim3 g(static_cast<unsigned>(grid)), b(kThreads);
+#define MISPEC_VQF(S)                                                                                                          \
+    do                                                                                                                         \
+    {                                                                                                                          \
+        MISPEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vq_fused<S>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       int(lds)));                                                                             \
+        hipLaunchKernelGGL((k_vq_fused<S>), g, b, lds, ctx.stream, V, ldv, m, Q, ldq, p, X, ldx, n, fa);                       \
+    } while (0)
+    if (maxs == 4)
+        MISPEC_VQF(4);
+    else if (maxs == 8)
+        MISPEC_VQF(8);
+    else if (maxs == 12)
+        MISPEC_VQF(12);
+    else
+        MISPEC_VQF(16);
+#undef MISPEC_VQF
+    MISPEC_HIP(hipGetLastError());
+    return grid;
 }
 
 int lanczos_epilogue_records(const mispec_ctx& ctx, int64_t n)

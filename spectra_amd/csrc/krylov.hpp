@@ -113,7 +113,9 @@ int launch_orth(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a);  // re
 // red[0..kPartialLd): column sums of the records (+ max for kSlotMaxAbs); finish additionally fills kSlotBeta / kSlotErr.
 void launch_reduce_partials(const mispec_ctx& ctx, const double* partials, int64_t pstride, int nrec, int ncol, double* red,
                             const FinishArgs& fin);
-void launch_finish(const mispec_ctx& ctx, double* red, int ncol, const FinishArgs& fin);
+// While the device-driven run `fin.st` is live both kernels write `red`; once it has stopped they leave it alone (the host
+// continues from the records of the stopping pass).  launch_finish: red <- stage (an all-reduced record), then the scalar tail.
+void launch_finish(const mispec_ctx& ctx, const double* stage, double* red, int ncol, const FinishArgs& fin);
 // out[0] = sum of `count` doubles (SpMV alpha partials), fixed order
 void launch_reduce_sum(const mispec_ctx& ctx, const double* in, int64_t count, double* out);
 // dst = src / divisor over npad elements (v = f / beta, Lanczos.h:106)
@@ -128,6 +130,23 @@ int launch_axpby(const mispec_ctx& ctx, double* f, double a, const double* v, do
 // X[:, 0:p] = V[:, 0:m] * Q (Q device, m x p col-major, ldq); X may alias V (in-place compress_V).
 void launch_vq(const mispec_ctx& ctx, const double* V, int64_t ldv, int m, const double* Q, int ldq, int p, double* X,
                int64_t ldx, int64_t n);
+// One-sweep steps, end of a sweep: the restart's V <- V Q with the PENDING correction of the last Lanczos step riding on it
+// (fac.hip restart_sym).  Out of place: X[:, 0:p] = V[:, 0:m] Q (X != V), and from the same tile of V:
+//   f_corr = ftilde - V c ;  chk = V' f_corr  (the reference's test for a second correction, Lanczos.h:156) ;  |f_corr|^2
+//   fnew = f_corr * q_last + X[:, kcol] * h_sub  (Arnoldi.h:337) ;  |fnew|^2
+// Records: slots [0, m) chk, slot m |fnew|^2, kSlotBeta2 |f_corr|^2.  m, p <= kPanelCols.  Returns the number of records.
+struct VqFusedArgs
+{
+    const double* c = nullptr;       // device: the accepted V'f of the last step (m entries)
+    const double* ftilde = nullptr;  // the uncorrected residual
+    double* fnew = nullptr;          // out (must not alias ftilde)
+    double q_last = 0.0, h_sub = 0.0;
+    int kcol = 0;                    // output column that enters fnew (= the new subspace dimension k)
+    double* partials = nullptr;
+    int64_t pstride = 0;
+};
+int launch_vq_fused(const mispec_ctx& ctx, const double* V, int64_t ldv, int m, const double* Q, int ldq, int p, double* X, int64_t ldx,
+                    int64_t n, const VqFusedArgs& fa);
 // res[j] = || A x_j - lambda_j x_j ||^2 partials and ||x_j||^2 partials are produced by the caller with the kernels above.
 // r = y - lambda*x ; records hold |r|^2 in kSlotBeta2 and |x|^2 in slot 0.
 int launch_resid_norms(const mispec_ctx& ctx, const double* y, const double* x, double lambda, int64_t n, double* partials,

@@ -104,3 +104,82 @@ def test_onesweep_is_ignored_where_it_does_not_apply(ctx):
     eigs, nconv = solve(op, 20, 80, sa.SortRule.LargestAlge, "onesweep")
     assert nconv == 20 and eigs.orth_info()["mode"] == "reference" and eigs.orth_info()["lagged_steps"] == 0
     assert np.abs(eigs.eigenvalues() - wanted_by_rule(GOLD["spectrum_1000"], "LargestAlge", 20)[::-1]).max() < 1e-9
+
+
+def lanczos_identities(fac, S, k, tol):
+    V, H, f = fac.matrix_V(k), fac.matrix_H()[:k, :k], fac.vector_f()
+    resid = S @ V - V @ H
+    resid[:, k - 1] -= f
+    assert np.abs(resid).max() < tol and np.abs(V.T @ V - np.eye(k)).max() < tol  # A V = V H + f e_k'
+    assert np.abs(V.T @ f).max() < tol * max(1.0, np.abs(f).max()) and abs(np.linalg.norm(f) - fac.f_norm()) < tol
+
+
+@pytest.mark.parametrize("n,m,k", [(1000, 20, 12), (1000, 64, 30), (40_003, 20, 8), (40_003, 37, 17)])
+def test_fused_restart_equals_the_two_pass_sequence(ctx, n, m, k):
+    # End of a full sweep in one-sweep mode: the last step's correction rides on the restart's V*Q pass (k_vq_fused,
+    # mispec_fac_restart_sym_fused).  Against the same steps with that correction applied at once and the plain restart
+    # ("onesweep-eager"): same H, same basis, same residual up to the order of the sums.
+    if n == 1000:
+        A, S = sparse_fixture(n, 0.01)
+        op = sa.SparseSymMatProd(A, ctx=ctx)
+    else:
+        op = sa.SparseSymMatProd.synth_band(n, offsets=(1, 2, 3, 50, 51, 1500, 1501), ctx=ctx)
+        rp, ci, v = O.synth_band_csr(n, offsets=(1, 2, 3, 50, 51, 1500, 1501))
+        S = sp.csr_matrix((v, ci, rp), shape=(n, n))
+    facs = {}
+    for mode in ("onesweep", "onesweep-eager"):
+        fac = sa.Factorization(op, m, True)
+        fac.set_orth_mode(mode)
+        fac.init_random(0)
+        fac.factorize_from(1, m)
+        ev, _ = fac.tridiag_eigen()
+        shifts = ev[np.argsort(-np.abs(ev))][k:]
+        if mode == "onesweep":
+            beta_pending = fac.f_norm()                 # sqrt(|f~|^2 - |c|^2) while the correction is pending
+            restarted = fac.restart_sym_fused(shifts)
+            if not restarted:                           # the reference's test asked for a further correction (rare)
+                assert fac.restart_info() == {"fused_restarts": 0, "fused_redone": 1}
+                ev, _ = fac.tridiag_eigen()
+                shifts = ev[np.argsort(-np.abs(ev))][k:]
+                assert fac.restart_sym_fused(shifts)
+            else:
+                assert fac.restart_info() == {"fused_restarts": 1, "fused_redone": 0}
+        else:
+            beta_eager = fac.f_norm()
+            fac.restart_sym(shifts)
+            assert fac.restart_info() == {"fused_restarts": 0, "fused_redone": 0}
+        assert fac.subspace_dim() == k
+        facs[mode] = fac
+    assert abs(beta_pending - beta_eager) <= 1e-13 * beta_eager
+    one, eager = facs["onesweep"], facs["onesweep-eager"]
+    scale = np.abs(eager.matrix_H()).max()
+    assert np.abs(one.matrix_H()[:k + 1, :k] - eager.matrix_H()[:k + 1, :k]).max() <= 1e-12 * scale
+    assert np.abs(one.matrix_V(k + 1) - eager.matrix_V(k + 1)).max() <= 1e-12
+    assert np.abs(one.vector_f() - eager.vector_f()).max() <= 1e-12 * scale
+    assert abs(one.f_norm() - eager.f_norm()) <= 1e-12 * scale
+    lanczos_identities(one, S, k, 1e-10)
+    one.factorize_from(k, m)                            # back to an m-step factorisation on the swapped buffers
+    eager.factorize_from(k, m)
+    assert np.abs(one.matrix_H() - eager.matrix_H()).max() <= 1e-10 * scale
+    lanczos_identities(one, S, m, 1e-10)                # get_f applies the pending correction of this second sweep
+
+
+@pytest.mark.parametrize("rule", ["LargestAlge", "SmallestAlge", "BothEnds"])
+def test_fused_restart_redo_path(ctx, rule):
+    # MISPEC_ORTH_TEST_REDO: every fused restart counts as failed -> the old basis is finished by the reference's loop, the
+    # Ritz pairs are retrieved again and the restart repeated: bit for bit the solve with the corrections applied at once
+    A, S = sparse_fixture(1000, 0.01)
+    op = sa.SparseSymMatProd(A, ctx=ctx)
+    eager, nconv_e = solve(op, 10, 30, sa.SortRule[rule], "onesweep-eager")
+    redo, nconv_r = solve(op, 10, 30, sa.SortRule[rule], "onesweep-redo")
+    fused, nconv_f = solve(op, 10, 30, sa.SortRule[rule], "onesweep")
+    assert nconv_e == nconv_r == nconv_f == 10
+    assert np.array_equal(redo.eigenvalues(), eager.eigenvalues()) and np.array_equal(redo.eigenvectors(), eager.eigenvectors())
+    assert (redo.num_operations(), redo.num_iterations()) == (eager.num_operations(), eager.num_iterations())
+    ri, ei, fi = redo.orth_info(), eager.orth_info(), fused.orth_info()
+    assert ri["fused_restarts"] == 0 and ri["fused_redone"] > 0 and ei["fused_restarts"] == ei["fused_redone"] == 0
+    assert fi["fused_restarts"] > 0 and fi["fused_redone"] <= 1
+    assert np.abs(fused.eigenvalues() - eager.eigenvalues()).max() <= 1e-12 * np.abs(eager.eigenvalues()).max()
+    assert abs(fused.num_operations() - eager.num_operations()) <= 20
+    evals, evecs = fused.eigenvalues(), fused.eigenvectors()
+    assert np.abs(S @ evecs - evecs * evals).max() < 1e-9 and np.abs(evecs.T @ evecs - np.eye(10)).max() <= 1e-10
