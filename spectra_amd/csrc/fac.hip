@@ -624,9 +624,12 @@ void reduce_record(mispec_fac& F, int nrec, int ncol, int which, const FinishArg
     {
         FinishArgs none;
         none.mode = kFinishNone;
+        none.packed = 1;
         launch_reduce_partials(*F.ctx, F.partials.p, F.pstride, nrec, ncol, F.red_stage(), none);
-        allreduce(F, F.red_stage(), kSlotBeta2 + 1);  // slots [0, kSlotBeta2] are sums
-        launch_finish(*F.ctx, F.red_stage(), red, ncol, fin);
+        allreduce(F, F.red_stage(), ncol + 1);  // the sums: slots [0, ncol) and, packed behind them, sum f^2
+        FinishArgs tail = fin;
+        tail.packed = 1;
+        launch_finish(*F.ctx, F.red_stage(), red, ncol, tail);
     }
     F.red_cur = which;
 }

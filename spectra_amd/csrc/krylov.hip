@@ -634,7 +634,11 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restri
     }
     __syncthreads();
     if (tid == 0)
+    {
+        if (fin.packed)
+            sh[ncol] = sh[kSlotBeta2];
         finish_record(sh, ncol, fin);
+    }
     __syncthreads();
     for (int t = tid; t < kPartialLd; t += 1024)
         red[t] = sh[t];
@@ -649,7 +653,15 @@ __global__ __launch_bounds__(256) void k_finish(const double* __restrict__ stage
         red[t] = stage[t];
     __syncthreads();
     if (threadIdx.x == 0)
+    {
+        if (fin.packed)
+        {
+            red[kSlotBeta2] = stage[ncol];
+            if (ncol != kSlotBeta2)
+                red[ncol] = 0.0;
+        }
         finish_record(red, ncol, fin);
+    }
 }
 
 __global__ __launch_bounds__(1024) void k_reduce_sum(const double* __restrict__ in, int64_t count, double* __restrict__ out)

@@ -82,6 +82,9 @@ struct FinishArgs
     int lag_last = 0;        // kFinishLagged: last step of the sweep — the following CORRECT_VTF launches finish f the reference's way
     double lag_limit = 1e-6; // kFinishLagged: a correction is lagged only while |c|^2 <= lag_limit |f|^2
     double eps_sqrt = 0.0;   // kFinishLagged: ... and the corrected norm stays >= sqrt(eps) (Lanczos.h:107 needs a finished f)
+    // Sharded runs: the sums travel as ONE contiguous message [0, ncol] — the reduction also stores sum f^2 in slot `ncol` of the
+    // staging record, the finish step takes it from there (a record is (2 ncv) doubles on the wire, not kSlotBeta2 + 1 = 1025)
+    int packed = 0;
 };
 
 struct OrthArgs

@@ -150,3 +150,30 @@ def test_exchange_overlapped_with_the_local_rows_changes_nothing(world, exchange
         assert np.array_equal(a["evals"], b["evals"]) and np.array_equal(a["X"], b["X"])
         assert (a["nops"], a["niter"]) == (b["nops"], b["niter"])
         assert a["res"].max() <= 1e-10
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("orth", ["onesweep", "onesweep-eager", "reference"])
+def test_sharded_device_run_that_stops_mid_sweep(ctx, world, orth):
+    # ncv = 60 on a small band: Ritz pairs converge inside a sweep, the corrections grow beyond what a lagged step may carry
+    # and the device-driven run STOPS in mid-sweep (state_stops); the host continues from the record of the stopping pass while
+    # the launches still in the queue — their reductions and all-reduces included — must leave that record alone.  Sharded,
+    # only ONE correction is enqueued speculatively, so a record overwritten by a later no-op step would not be repaired by
+    # chance.  Every rank identical, equal to the unsharded solve, residuals and orthogonality at rounding level.
+    n, offsets, nev, ncv = 20_001, (1, 2, 3, 50, 51, 1500, 1501), 10, 60
+    single = sa.SymEigsSolver(sa.SparseSymMatProd.synth_band(n, offsets=offsets, ctx=ctx), nev, ncv)
+    single.set_orth_mode(orth)
+    single.init()
+    assert single.compute(sa.SortRule.LargestAlge, 1000, 1e-11) == nev
+    res = run_sharded(world, n, offsets, nev, ncv, sa.SortRule.LargestAlge, 1e-11, orth=orth)
+    X = np.vstack([r["X"] for r in res])
+    for r in res:
+        assert r["nconv"] == nev and r["info"] == sa.CompInfo.Successful
+        assert np.array_equal(r["evals"], res[0]["evals"]) and (r["nops"], r["niter"]) == (res[0]["nops"], res[0]["niter"])
+        assert r["res"].max() <= 1e-10
+        if orth != "reference":
+            assert r["orth"]["mode"] == "onesweep" and r["orth"]["state_stops"] > 0
+            assert (r["orth"]["fused_restarts"] > 0) == (orth == "onesweep")
+    assert np.abs(res[0]["evals"] - single.eigenvalues()).max() < 1e-10
+    assert abs(res[0]["nops"] - single.num_operations()) <= ncv - nev
+    assert np.abs(X.T @ X - np.eye(nev)).max() <= 1e-10
