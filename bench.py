@@ -522,7 +522,7 @@ def main():
                                                    "rides on the next step's pass over V; same decisions and fixed points, parity-gated by "
                                                    "tests/test_gpu_onesweep.py and the full-size golden; the reference-flow figure of the same "
                                                    "run is `other_orth_mode`; the last correction of every sweep rides on the restart's "
-                                                   "V*Q pass (mispec_fac_restart_sym_fused)"}[args.orth.replace("-eager", "")]),
+                                                   "V*Q pass (k_vq_fused)"}[args.orth.replace("-eager", "")]),
                 "solver_object": "one SymEigsSolver (V, X, work vectors) allocated before the timed region and re-used by every step",
                 "eigenvectors": ("X = V*Y is formed in HBM and left there (the reference's eigenvectors() returns a host matrix: "
                                  f"the D2H copy of {8e-9 * args.n * args.nev:.1f} GB would add ~{8e-9 * args.n * args.nev / 55 * 1e3:.0f} ms per solve "

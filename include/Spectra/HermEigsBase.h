@@ -132,18 +132,13 @@ private:
         if (k >= m_ncv)
             return;
         const Index nshift = m_ncv - k;
+        // the unwanted Ritz values are the shifts; large magnitudes first
         std::vector<RealScalar> shifts(static_cast<std::size_t>(nshift));
-        for (int attempt = 0; attempt < 2; attempt++)
-        {
-            // the unwanted Ritz values are the shifts; large magnitudes first
-            for (Index i = 0; i < nshift; i++)
-                shifts[static_cast<std::size_t>(i)] = m_ritz_val[k + i];
-            std::sort(shifts.begin(), shifts.end(), [](const RealScalar& a, const RealScalar& b) { return std::abs(a) > std::abs(b); });
-            // shifted QR sweeps on H, Q accumulation, V <- VQ and the new residual: all on the device
-            if (m_fac.restart_with_shifts(shifts.data(), nshift))
-                break;
-            retrieve_ritzpair(selection);  // one-sweep mode: H changed under a further correction of the last step (Lanczos.h)
-        }
+        for (Index i = 0; i < nshift; i++)
+            shifts[static_cast<std::size_t>(i)] = m_ritz_val[k + i];
+        std::sort(shifts.begin(), shifts.end(), [](const RealScalar& a, const RealScalar& b) { return std::abs(a) > std::abs(b); });
+        // shifted QR sweeps on H, Q accumulation, V <- VQ and the new residual: all on the device
+        m_fac.restart_with_shifts(shifts.data(), nshift);
         // back to an ncv-step factorisation
         m_fac.factorize_from(k, m_ncv, m_nmatop);
         retrieve_ritzpair(selection);

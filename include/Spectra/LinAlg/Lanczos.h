@@ -35,14 +35,9 @@ public:
     // (HermEigsBase.h:118-147): per shift QR of H - mu I by Givens rotations, Q <- Q Qi, H <- Qi' H Qi —
     // one LDS-resident kernel — then V <- V Q and the new residual (Arnoldi.h:320-340).
     // Afterwards subspace_dim() == m - nshift.
-    // Returns false (one-sweep orthogonalisation only, rare) if nothing was restarted: the last step's correction, which
-    // rides on this pass, failed the reference's test (Lanczos.h:156) and the factorisation was finished by the reference's
-    // loop instead; H may have changed in its last two entries — retrieve the Ritz pairs again and call once more.
-    bool restart_with_shifts(const Scalar* shifts, Index nshift)
+    void restart_with_shifts(const Scalar* shifts, Index nshift)
     {
-        int redo = 0;
-        internal::check(mispec_fac_restart_sym_fused(m_fac.get(), shifts, static_cast<int>(nshift), &redo));
-        return redo == 0;
+        internal::check(mispec_fac_restart_sym(m_fac.get(), shifts, static_cast<int>(nshift)));
     }
 };
 

@@ -346,20 +346,19 @@ int mispec_fac_f_norm(const mispec_fac* fac, double* beta);  /* f_norm() */
  * |c|/|f| and the largest |V'v| measured after a lagged correction. */
 enum { MISPEC_ORTH_REFERENCE = 0, MISPEC_ORTH_ONESWEEP = 1,
        /* flags, or-ed to MISPEC_ORTH_ONESWEEP: */
-       MISPEC_ORTH_EAGER_LAST = 0x100, /* apply the last correction of a full sweep at once (no fused restart, see below) */
-       MISPEC_ORTH_TEST_REDO = 0x200   /* test hook: every fused restart counts as failed, so that the redo path runs */ };
+       MISPEC_ORTH_EAGER_LAST = 0x100,    /* apply the last correction of a full sweep at once (no fused restart, see below) */
+       MISPEC_ORTH_TEST_RECORRECT = 0x200 /* test hook: every fused restart is followed by one more correction (see below) */ };
 int mispec_fac_set_orth_mode(mispec_fac* fac, int mode);
 int mispec_fac_orth_info(const mispec_fac* fac, int* mode, int64_t* lagged_steps, int64_t* check_stops, int64_t* state_stops,
                          double* max_rel_c, double* max_chk);
 /* One-sweep mode, end of a full sweep (factorize up to ncv): the correction of the LAST step stays pending as well, and
- * mispec_fac_restart_sym_fused lets it ride on the restart's V*Q pass together with the reference's test of the corrected residual
- * (Lanczos.h:156).  *redo = 0: restarted, as mispec_fac_restart_sym.  *redo = 1 (rare): the test asked for a further correction;
- * nothing was restarted, the factorisation has been finished by the reference's loop instead — H(m-1, m-2 : m-1) may have changed
- * by O(eps |f|), so the caller recomputes its Ritz values and shifts and calls again.  Every other entry point that needs the
- * residual (get_f, get_H, factorize, compress_V, the plain restart_sym) applies a pending correction first; f_norm() reports
- * sqrt(|f~|^2 - |c|^2) until then.  mispec_fac_restart_info counts the restarts that went the fused way and the redone ones. */
-int mispec_fac_restart_sym_fused(mispec_fac* fac, const double* shifts_host, int nshift, int* redo);
-int mispec_fac_restart_info(const mispec_fac* fac, int64_t* fused, int64_t* redone);
+ * mispec_fac_restart_sym lets it ride on the restart's V*Q pass (one sweep over the basis instead of two) together with the
+ * reference's test of the corrected residual (Lanczos.h:156).  If that test asks for a further correction (rare: max |V'f| a few
+ * eps above the bar), the reference's loop continues on the compressed factorisation — V[:, :k]'f is measured again and f, H(k-2 : k-1,
+ * k-1) corrected while the test fails.  Every other entry point that needs the residual (get_f, get_H, factorize, compress_V)
+ * applies a pending correction first; f_norm() reports sqrt(|f~|^2 - |c|^2) until then.  mispec_fac_restart_info counts the
+ * restarts that went the fused way and those that were followed by further corrections. */
+int mispec_fac_restart_info(const mispec_fac* fac, int64_t* fused, int64_t* recorrected);
 /* How a sharded device matrix moves the Krylov vector before each product: *halo = 1 if only the referenced
  * parts of the other ranks' slices are exchanged point-to-point (recv_doubles of them per product), 0 if the
  * full all-gather is used (or the context is not sharded). */
@@ -511,7 +510,7 @@ int mispec_symeigs_profile(mispec_symeigs* s, int enable);
 int mispec_symeigs_set_orth_mode(mispec_symeigs* s, int mode);
 int mispec_symeigs_orth_info(const mispec_symeigs* s, int* mode, int64_t* lagged_steps, int64_t* check_stops,
                              int64_t* state_stops, double* max_rel_c, double* max_chk);
-int mispec_symeigs_restart_info(const mispec_symeigs* s, int64_t* fused, int64_t* redone); /* see mispec_fac_restart_info */
+int mispec_symeigs_restart_info(const mispec_symeigs* s, int64_t* fused, int64_t* recorrected); /* see mispec_fac_restart_info */
 
 /* ---------------------------------------------------------------------------
  * General (non-symmetric) solver: Spectra::GenEigsSolver<Spectra::SparseGenMatProd<double>> behind a handle.

@@ -26,9 +26,9 @@ SYNTH_SEED = 20240607
 
 
 # include/mispec.h MISPEC_ORTH_*: the reference's control flow, or the opt-in one-sweep steps; "onesweep-eager" applies the
-# last correction of every sweep at once instead of letting it ride on the restart's V*Q pass, "onesweep-redo" is the test
-# hook that makes every such fused restart count as failed
-ORTH_MODES = {"reference": 0, "onesweep": 1, "onesweep-eager": 1 | 0x100, "onesweep-redo": 1 | 0x200}
+# last correction of every sweep at once instead of letting it ride on the restart's V*Q pass, "onesweep-recorrect" is the test
+# hook that lets one more correction follow every such fused restart
+ORTH_MODES = {"reference": 0, "onesweep": 1, "onesweep-eager": 1 | 0x100, "onesweep-recorrect": 1 | 0x200}
 
 
 class SortRule(enum.IntEnum):
@@ -891,7 +891,7 @@ class SymEigsSolver:
         check(lib().mispec_symeigs_restart_info(self.h, C.byref(fused), C.byref(redone)))
         return {"mode": "onesweep" if mode.value else "reference", "lagged_steps": a.value, "check_stops": b.value,
                 "state_stops": c.value, "max_rel_c": r.value, "max_chk": k.value, "fused_restarts": fused.value,
-                "fused_redone": redone.value}
+                "fused_recorrected": redone.value}
 
     def overlap_info(self):
         """(first interior 256-row block, interior blocks, all blocks): what is multiplied while the exchange is in flight."""
@@ -1440,18 +1440,10 @@ class Factorization:
         s = _f64(shifts)
         check(lib().mispec_fac_restart_sym(self.h, _dp(s), len(s)))
 
-    def restart_sym_fused(self, shifts):
-        """mispec_fac_restart_sym_fused: True if restarted; False if the pending correction of the one-sweep steps failed the
-        reference's test — the factorisation is then complete and corrected, recompute the Ritz values and restart again."""
-        s = _f64(shifts)
-        redo = C.c_int(0)
-        check(lib().mispec_fac_restart_sym_fused(self.h, _dp(s), len(s), C.byref(redo)))
-        return redo.value == 0
-
     def restart_info(self):
         fused, redone = C.c_int64(0), C.c_int64(0)
         check(lib().mispec_fac_restart_info(self.h, C.byref(fused), C.byref(redone)))
-        return {"fused_restarts": fused.value, "fused_redone": redone.value}
+        return {"fused_restarts": fused.value, "fused_recorrected": redone.value}
 
     def compress_V(self, Q, H, new_k):
         Q = np.asfortranarray(Q, dtype=np.float64)

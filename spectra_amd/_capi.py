@@ -202,7 +202,6 @@ SIGNATURES = {
     "mispec_symeigs_orth_info": (C.c_int, [_vp, C.POINTER(C.c_int), _lp, _lp, _lp, _dp, _dp]),
     "mispec_fac_set_orth_mode": (C.c_int, [_vp, C.c_int]),
     "mispec_fac_orth_info": (C.c_int, [_vp, C.POINTER(C.c_int), _lp, _lp, _lp, _dp, _dp]),
-    "mispec_fac_restart_sym_fused": (C.c_int, [_vp, _dp, C.c_int, C.POINTER(C.c_int)]),
     "mispec_fac_restart_info": (C.c_int, [_vp, _lp, _lp]),
     "mispec_symeigs_restart_info": (C.c_int, [_vp, _lp, _lp]),
     "mispec_geneigs_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vpp]),

@@ -119,13 +119,12 @@ struct mispec_fac
     DevBuf<double> pscratch;
     int red_cur = 0;   // which half of `red` holds the latest reduced record
     // One-sweep steps: the correction of the LAST step of a full sweep is left pending (c = red_buf(end_rec)[0, m), H and beta
-    // already carry it) so that the restart's V*Q pass can apply it on the way (mispec_fac_restart_sym_fused); everything else
-    // that needs f calls finish_pending first.  V2: the out-of-place target of that pass, swapped with V when it is accepted.
+    // already carry it) so that the restart's V*Q pass can apply it on the way (mispec_fac_restart_sym); everything else that
+    // needs f calls finish_pending first.
     bool end_pending = false;
-    bool eager_last = false, test_redo = false;  // MISPEC_ORTH_EAGER_LAST / MISPEC_ORTH_TEST_REDO
+    bool eager_last = false, test_redo = false;  // MISPEC_ORTH_EAGER_LAST / MISPEC_ORTH_TEST_RECORRECT
     int end_rec = 0;
-    int64_t fused_restarts = 0, fused_redone = 0;
-    DevBuf<double> V2;
+    int64_t fused_restarts = 0, fused_recorrected = 0;
     int x_cols = 0;    // columns currently held in X
 
     // profile
@@ -1759,11 +1758,11 @@ extern "C" int mispec_fac_set_orth_mode(mispec_fac* fac, int mode)
         MISPEC_REQUIRE(fac, "mispec_fac_set_orth_mode: NULL argument");
         const int base = mode & 0xff, flags = mode & ~0xff;
         MISPEC_REQUIRE((base == MISPEC_ORTH_REFERENCE && flags == 0) ||
-                           (base == MISPEC_ORTH_ONESWEEP && (flags & ~(MISPEC_ORTH_EAGER_LAST | MISPEC_ORTH_TEST_REDO)) == 0),
+                           (base == MISPEC_ORTH_ONESWEEP && (flags & ~(MISPEC_ORTH_EAGER_LAST | MISPEC_ORTH_TEST_RECORRECT)) == 0),
                        "mispec_fac_set_orth_mode: unknown mode");
         fac->onesweep = (base == MISPEC_ORTH_ONESWEEP);
         fac->eager_last = (flags & MISPEC_ORTH_EAGER_LAST) != 0;
-        fac->test_redo = (flags & MISPEC_ORTH_TEST_REDO) != 0;
+        fac->test_redo = (flags & MISPEC_ORTH_TEST_RECORRECT) != 0;
     });
 }
 
@@ -1789,14 +1788,14 @@ extern "C" int mispec_fac_orth_info(const mispec_fac* fac, int* mode, int64_t* l
     });
 }
 
-extern "C" int mispec_fac_restart_info(const mispec_fac* fac, int64_t* fused, int64_t* redone)
+extern "C" int mispec_fac_restart_info(const mispec_fac* fac, int64_t* fused, int64_t* recorrected)
 {
     return guarded([&] {
         MISPEC_REQUIRE(fac, "mispec_fac_restart_info: NULL argument");
         if (fused)
             *fused = fac->fused_restarts;
-        if (redone)
-            *redone = fac->fused_redone;
+        if (recorrected)
+            *recorrected = fac->fused_recorrected;
     });
 }
 
@@ -1948,143 +1947,154 @@ extern "C" int mispec_fac_tridiag_eigen(mispec_fac* fac, double* evals_host, dou
 
 namespace {
 
-// mispec_fac_restart_sym / _fused.  `redo` != nullptr: a pending correction of the one-sweep steps may ride on the V*Q pass.
-void restart_sym_impl(mispec_fac* fac, const double* shifts_host, int nshift, int* redo)
+// One-sweep steps: the restart went ahead on a residual whose single correction left max |V'f| above eps |f| (Lanczos.h:156, the
+// case in which the reference's loop corrects once more).  The loop continues on the COMPRESSED factorisation: V[:, :k]'f is
+// measured again and, while the test still fails, f -= V c with c[k-2], c[k-1] absorbed by H(k-2 : k-1, k-1) (Lanczos.h:171-180
+// for the residual of a k-step factorisation; count continues at 1).  `force`: apply one correction in any case (test hook).
+void corrections_after_fused_restart(mispec_fac& F, bool force)
 {
-    require_init(fac, "mispec_fac_restart_sym");
-    mispec_fac& F = *fac;
-    MISPEC_REQUIRE(F.symmetric, "mispec_fac_restart_sym: symmetric (Lanczos) factorisations only");
-    MISPEC_REQUIRE(shifts_host && nshift >= 1 && nshift < F.m, "mispec_fac_restart_sym: need 1 <= nshift < ncv");
-    MISPEC_REQUIRE(F.k == F.m, "mispec_fac_restart_sym: the factorisation must be complete (k == ncv)");
-    F.ctx->make_current();
-    if (redo)
-        *redo = 0;
-    else
-        finish_pending(F);
-    const int m = F.m;
-    const int k = m - nshift;  // compress_H decrements k once per shift (Lanczos.h:198-202)
-    double* hs = F.h_small.p;  // [diag m][subd m][Q m*m]
-    for (int i = 0; i < m; i++)
-        hs[i] = F.Hat(i, i);
-    for (int i = 0; i < m; i++)
-        hs[m + i] = (i < m - 1) ? F.Hat(i + 1, i) : 0.0;
-    // Where the (m-k) shifted QR sweeps run: on the host core by default (same routine as the kernel, internal/SmallDense.h:
-    // ~40 us + a 12.8 KB upload of Q, against 0.24 ms for the one-wavefront kernel k_restart_sym* — a serial chain the GPU
-    // cannot speed up and that every rank of a sharded run would repeat).  Measured on C2, one GPU, end of round 3: 18.35 ->
-    // 18.72 eigenpairs/s (profiles/r05m_*; -2.3 % already in round 2, when the default was still the device).
-    // MISPEC_SMALL=device keeps the sweeps on the GPU (m <= 128; tested in both settings).
-    const bool on_host = m > kMaxSmallDim || !small_on_device();
-    if (on_host)
+    const int k = F.k;
+    const double beta_thresh = kEps * std::sqrt(double(F.n));
+    vtf(F, F.f.p, k, 0);
+    F.beta = F.h_red.p[kSlotBeta];
+    double ortho_err = F.h_red.p[kSlotErr];
+    int count = 1;
+    while (count < 5 && (ortho_err > kEps * F.beta || force))
     {
-        F.counts[FAM_SMALL]++;
-        double* Q = hs + 2 * m;
-        std::fill(Q, Q + size_t(m) * m, 0.0);
-        for (int i = 0; i < m; i++)
-            Q[size_t(i) * m + i] = 1.0;
-        std::vector<double> work(size_t(4) * m);
-        for (int sft = 0; sft < nshift; sft++)
-            small::tridiag_shifted_qr(m, hs, hs + m, shifts_host[sft], Q, m, m, work.data(), small::Lanes{0, 1});
-        MISPEC_HIP(hipMemcpyAsync(F.Qdev.p, Q, size_t(m) * m * 8, hipMemcpyHostToDevice, F.stream()));
-        const double q_last = Q[size_t(k - 1) * m + (m - 1)], h_sub = hs[m + k - 1];  // Q(m-1, k-1), the new H(k, k-1)
-        const bool fused = F.end_pending;
-        if (fused)
+        force = false;
+        if (F.beta < beta_thresh)
         {
-            // One-sweep steps: the last step's correction f = ftilde - V c and the reference's test of the result (Lanczos.h:
-            // 156: max |V'f| <= eps |f|) ride on the V*Q pass (k_vq_fused) — one sweep over the basis instead of two.  Out of
-            // place, so that a failed test costs nothing but the pass: the old basis is then finished by the reference's loop
-            // and the caller recomputes its Ritz values (H(m-1, m-2 : m-1) has changed) before restarting again.
-            if (F.V2.n < F.V.n)
-            {
-                F.V2.alloc(F.V.n);
-                MISPEC_HIP(hipMemsetAsync(F.V2.p, 0, F.V2.n * sizeof(double), F.stream()));
-            }
-            VqFusedArgs fa;
-            fa.c = F.red_buf(F.end_rec);
-            fa.ftilde = F.f.p;
-            fa.fnew = F.tmp.p;
-            fa.q_last = q_last;
-            fa.h_sub = h_sub;
-            fa.kcol = k;
-            fa.partials = F.partials.p;
-            fa.pstride = F.pstride;
-            int nrec;
-            {
-                Timed t(F, FAM_COMPRESS);
-                F.count_bytes(FAM_COMPRESS, m + k + 1 + 2);  // m columns and ftilde read, k + 1 columns and the new f written
-                nrec = launch_vq_fused(*F.ctx, F.V.p, F.ldv, m, F.Qdev.p, m, k + 1, F.V2.p, F.ldv, F.nloc, fa);
-            }
-            reduce_to_host(F, nrec, m + 1, F.end_rec ^ 1);  // slots [0, m) V'f, m |f_new|^2, kSlotBeta2 |f|^2
-            double err = 0.0;
-            for (int j = 0; j < m; j++)
-                err = std::max(err, std::fabs(F.h_red.p[j]));
-            const double beta_corr = F.h_red.p[kSlotBeta];
-            F.lag_chk_max = std::max(F.lag_chk_max, beta_corr > 0.0 ? err / beta_corr : 0.0);
-            if (err > kEps * beta_corr || F.test_redo)  // Lanczos.h:156 with count = 1
-            {
-                F.fused_redone++;
-                finish_pending(F);
-                *redo = 1;
-                return;
-            }
-            F.fused_restarts++;
-            F.end_pending = false;
-            F.V.swap(F.V2);
-            F.f.swap(F.tmp);
-            F.beta = std::sqrt(F.h_red.p[m]);  // Arnoldi.h:339
+            zero_vector(F, F.f.p);
+            F.beta = 0.0;
+            break;
         }
-        else
+        const double c_km2 = k >= 2 ? F.h_red.p[k - 2] : 0.0, c_km1 = F.h_red.p[k - 1];
+        correct_vtf(F, F.f.p, F.f.p, k);
+        if (k >= 2)
         {
-            Timed t(F, FAM_COMPRESS);
-            compress_basis(F, k + 1);
+            F.Hat(k - 2, k - 1) += c_km2;
+            F.Hat(k - 1, k - 2) = F.Hat(k - 2, k - 1);
         }
-        std::fill(F.H.begin(), F.H.end(), 0.0);
-        for (int i = 0; i < m; i++)
-            F.Hat(i, i) = hs[i];
-        for (int i = 0; i < m - 1; i++)
-            F.Hat(i + 1, i) = F.Hat(i, i + 1) = hs[m + i];
-        F.k = k;
-        if (!fused)
-            update_f_after_compress(F, q_last, h_sub);  // syncs: Q has been consumed by then
-        return;
+        F.Hat(k - 1, k - 1) += c_km1;
+        F.beta = F.h_red.p[kSlotBeta];
+        ortho_err = F.h_red.p[kSlotErr];
+        count++;
     }
-    finish_pending(F);
-    MISPEC_HIP(hipMemcpyAsync(F.d_diag.p, hs, size_t(m) * 8, hipMemcpyHostToDevice, F.stream()));
-    MISPEC_HIP(hipMemcpyAsync(F.d_subd.p, hs + m, size_t(m) * 8, hipMemcpyHostToDevice, F.stream()));
-    {
-        Timed t(F, FAM_SMALL);
-        launch_restart_sym(*F.ctx, m, F.d_diag.p, F.d_subd.p, shifts_host, nshift, F.Qdev.p);
-    }
-    // V[:, :k+1] <- V Q  (Arnoldi.h:326-335), in place, straight from the device Q
-    {
-        Timed t(F, FAM_COMPRESS);
-        compress_basis(F, k + 1);
-    }
-    MISPEC_HIP(hipMemcpyAsync(hs, F.d_diag.p, size_t(m) * 8, hipMemcpyDeviceToHost, F.stream()));
-    MISPEC_HIP(hipMemcpyAsync(hs + m, F.d_subd.p, size_t(m) * 8, hipMemcpyDeviceToHost, F.stream()));
-    MISPEC_HIP(hipMemcpyAsync(hs + 2 * m, F.Qdev.p + size_t(k - 1) * m + (m - 1), sizeof(double), hipMemcpyDeviceToHost,
-                              F.stream()));
-    sync_stream(F);
-    std::fill(F.H.begin(), F.H.end(), 0.0);
-    for (int i = 0; i < m; i++)
-        F.Hat(i, i) = hs[i];
-    for (int i = 0; i < m - 1; i++)
-        F.Hat(i + 1, i) = F.Hat(i, i + 1) = hs[m + i];
-    F.k = k;
-    update_f_after_compress(F, hs[2 * m], F.Hat(k, k - 1));
 }
 
 }  // namespace
 
 extern "C" int mispec_fac_restart_sym(mispec_fac* fac, const double* shifts_host, int nshift)
 {
-    return guarded([&] { restart_sym_impl(fac, shifts_host, nshift, nullptr); });
-}
-
-extern "C" int mispec_fac_restart_sym_fused(mispec_fac* fac, const double* shifts_host, int nshift, int* redo)
-{
     return guarded([&] {
-        MISPEC_REQUIRE(redo, "mispec_fac_restart_sym_fused: redo is NULL");
-        restart_sym_impl(fac, shifts_host, nshift, redo);
+        require_init(fac, "mispec_fac_restart_sym");
+        mispec_fac& F = *fac;
+        MISPEC_REQUIRE(F.symmetric, "mispec_fac_restart_sym: symmetric (Lanczos) factorisations only");
+        MISPEC_REQUIRE(shifts_host && nshift >= 1 && nshift < F.m, "mispec_fac_restart_sym: need 1 <= nshift < ncv");
+        MISPEC_REQUIRE(F.k == F.m, "mispec_fac_restart_sym: the factorisation must be complete (k == ncv)");
+        F.ctx->make_current();
+        const int m = F.m;
+        const int k = m - nshift;  // compress_H decrements k once per shift (Lanczos.h:198-202)
+        double* hs = F.h_small.p;  // [diag m][subd m][Q m*m]
+        for (int i = 0; i < m; i++)
+            hs[i] = F.Hat(i, i);
+        for (int i = 0; i < m; i++)
+            hs[m + i] = (i < m - 1) ? F.Hat(i + 1, i) : 0.0;
+        // Where the (m-k) shifted QR sweeps run: on the host core by default (same routine as the kernel, internal/SmallDense.h:
+        // ~40 us + a 12.8 KB upload of Q, against 0.24 ms for the one-wavefront kernel k_restart_sym* — a serial chain the GPU
+        // cannot speed up and that every rank of a sharded run would repeat).  Measured on C2, one GPU, end of round 3: 18.35 ->
+        // 18.72 eigenpairs/s (profiles/r05m_*; -2.3 % already in round 2, when the default was still the device).
+        // MISPEC_SMALL=device keeps the sweeps on the GPU (m <= 128; tested in both settings).
+        const bool on_host = m > kMaxSmallDim || !small_on_device();
+        if (on_host)
+        {
+            F.counts[FAM_SMALL]++;
+            double* Q = hs + 2 * m;
+            std::fill(Q, Q + size_t(m) * m, 0.0);
+            for (int i = 0; i < m; i++)
+                Q[size_t(i) * m + i] = 1.0;
+            std::vector<double> work(size_t(4) * m);
+            for (int sft = 0; sft < nshift; sft++)
+                small::tridiag_shifted_qr(m, hs, hs + m, shifts_host[sft], Q, m, m, work.data(), small::Lanes{0, 1});
+            MISPEC_HIP(hipMemcpyAsync(F.Qdev.p, Q, size_t(m) * m * 8, hipMemcpyHostToDevice, F.stream()));
+            const double q_last = Q[size_t(k - 1) * m + (m - 1)], h_sub = hs[m + k - 1];  // Q(m-1, k-1), the new H(k, k-1)
+            const bool fused = F.end_pending;
+            bool test_failed = false;
+            if (fused)
+            {
+                // One-sweep steps: the last step's correction f = ftilde - V c and the reference's test of the result (Lanczos.h:
+                // 156: max |V'f| <= eps |f|) ride on the V*Q pass (k_vq_fused) — one sweep over the basis instead of two.
+                F.end_pending = false;
+                VqFusedArgs fa;
+                fa.c = F.red_buf(F.end_rec);
+                fa.ftilde = F.f.p;
+                fa.fnew = F.tmp.p;
+                fa.q_last = q_last;
+                fa.h_sub = h_sub;
+                fa.kcol = k;
+                fa.partials = F.partials.p;
+                fa.pstride = F.pstride;
+                int nrec;
+                {
+                    Timed t(F, FAM_COMPRESS);
+                    F.count_bytes(FAM_COMPRESS, m + k + 1 + 2);  // m columns and ftilde read, k + 1 columns and the new f written
+                    nrec = launch_vq_fused(*F.ctx, F.V.p, F.ldv, m, F.Qdev.p, m, k + 1, F.V.p, F.ldv, F.nloc, fa);
+                }
+                reduce_to_host(F, nrec, m + 1, F.end_rec ^ 1);  // slots [0, m) V'f, m |f_new|^2, kSlotBeta2 |f|^2
+                double err = 0.0;
+                for (int j = 0; j < m; j++)
+                    err = std::max(err, std::fabs(F.h_red.p[j]));
+                const double beta_corr = F.h_red.p[kSlotBeta];
+                F.lag_chk_max = std::max(F.lag_chk_max, beta_corr > 0.0 ? err / beta_corr : 0.0);
+                test_failed = err > kEps * beta_corr;  // Lanczos.h:156 with count = 1
+                F.fused_restarts++;
+                F.f.swap(F.tmp);
+                F.beta = std::sqrt(F.h_red.p[m]);  // Arnoldi.h:339
+            }
+            else
+            {
+                Timed t(F, FAM_COMPRESS);
+                compress_basis(F, k + 1);
+            }
+            std::fill(F.H.begin(), F.H.end(), 0.0);
+            for (int i = 0; i < m; i++)
+                F.Hat(i, i) = hs[i];
+            for (int i = 0; i < m - 1; i++)
+                F.Hat(i + 1, i) = F.Hat(i, i + 1) = hs[m + i];
+            F.k = k;
+            if (!fused)
+                update_f_after_compress(F, q_last, h_sub);  // syncs: Q has been consumed by then
+            else if (test_failed || F.test_redo)
+            {
+                F.fused_recorrected++;
+                corrections_after_fused_restart(F, F.test_redo);
+            }
+            return;
+        }
+        finish_pending(F);
+        MISPEC_HIP(hipMemcpyAsync(F.d_diag.p, hs, size_t(m) * 8, hipMemcpyHostToDevice, F.stream()));
+        MISPEC_HIP(hipMemcpyAsync(F.d_subd.p, hs + m, size_t(m) * 8, hipMemcpyHostToDevice, F.stream()));
+        {
+            Timed t(F, FAM_SMALL);
+            launch_restart_sym(*F.ctx, m, F.d_diag.p, F.d_subd.p, shifts_host, nshift, F.Qdev.p);
+        }
+        // V[:, :k+1] <- V Q  (Arnoldi.h:326-335), in place, straight from the device Q
+        {
+            Timed t(F, FAM_COMPRESS);
+            compress_basis(F, k + 1);
+        }
+        MISPEC_HIP(hipMemcpyAsync(hs, F.d_diag.p, size_t(m) * 8, hipMemcpyDeviceToHost, F.stream()));
+        MISPEC_HIP(hipMemcpyAsync(hs + m, F.d_subd.p, size_t(m) * 8, hipMemcpyDeviceToHost, F.stream()));
+        MISPEC_HIP(hipMemcpyAsync(hs + 2 * m, F.Qdev.p + size_t(k - 1) * m + (m - 1), sizeof(double), hipMemcpyDeviceToHost,
+                                  F.stream()));
+        sync_stream(F);
+        std::fill(F.H.begin(), F.H.end(), 0.0);
+        for (int i = 0; i < m; i++)
+            F.Hat(i, i) = hs[i];
+        for (int i = 0; i < m - 1; i++)
+            F.Hat(i + 1, i) = F.Hat(i, i + 1) = hs[m + i];
+        F.k = k;
+        update_f_after_compress(F, hs[2 * m], F.Hat(k, k - 1));
     });
 }
 

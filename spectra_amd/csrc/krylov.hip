@@ -928,13 +928,14 @@ __global__ __launch_bounds__(kThreads) void k_vq(const double* __restrict__ V, i
 }
 
 // ---- V*Q with the pending correction of the last one-sweep step riding on it (krylov.hpp launch_vq_fused) ----------------------
-// k_vq's tiling (128-row tiles of all m columns staged in LDS, wave w = output columns w, w+4, ...), out of place.  Every wave
+// k_vq's tiling (128-row tiles of all m columns staged in LDS, wave w = output columns w, w+4, ...), in place like k_vq (a tile is
+// read completely before its rows are written; writing the lines just read measured faster than a second buffer).  Every wave
 // additionally forms the corrected residual of its rows from the staged tile (p = V c: m LDS reads, the same for all four
 // waves — cheaper than a second barrier), accumulates chk_j = <V_j, f_corr> for the input columns j = w (mod 4), and the wave
 // that holds output column kcol writes fnew.  Rows past the end are staged from row 0 (clamped address) and masked out of every sum.
 template <int MAXS>
-__global__ __launch_bounds__(kThreads) void k_vq_fused(const double* __restrict__ V, int64_t ldv, int m, const double* __restrict__ Q,
-                                                        int ldq, int p, double* __restrict__ X, int64_t ldx, int64_t n, VqFusedArgs fa)
+__global__ __launch_bounds__(kThreads) void k_vq_fused(const double* V, int64_t ldv, int m, const double* __restrict__ Q, int ldq, int p,
+                                                        double* X, int64_t ldx, int64_t n, VqFusedArgs fa)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Vt = smem;                           // [m][128]
@@ -1542,8 +1543,8 @@ void launch_vq(const mispec_ctx& ctx, const double* V, int64_t ldv, int m, const
 int launch_vq_fused(const mispec_ctx& ctx, const double* V, int64_t ldv, int m, const double* Q, int ldq, int p, double* X, int64_t ldx,
                     int64_t n, const VqFusedArgs& fa)
 {
-    MISPEC_REQUIRE(m >= 1 && m <= kPanelCols && p >= 1 && p <= kPanelCols && X != V && fa.kcol >= 0 && fa.kcol < p && fa.fnew != fa.ftilde,
-                   "fused V*Q kernel: needs 1 <= m, p <= 64, an output buffer of its own and kcol < p");
+    MISPEC_REQUIRE(m >= 1 && m <= kPanelCols && p >= 1 && p <= kPanelCols && fa.kcol >= 0 && fa.kcol < p && fa.fnew != fa.ftilde,
+                   "fused V*Q kernel: needs 1 <= m, p <= 64, kcol < p and a residual buffer of its own");
     const int64_t ntiles = (n + kTileRows - 1) / kTileRows;
     const int slots = (p + 3) / 4;
     const int maxs = slots <= 4 ? 4 : slots <= 8 ? 8 : slots <= 12 ? 12 : 16;

@@ -134,7 +134,7 @@ int launch_axpby(const mispec_ctx& ctx, double* f, double a, const double* v, do
 void launch_vq(const mispec_ctx& ctx, const double* V, int64_t ldv, int m, const double* Q, int ldq, int p, double* X,
                int64_t ldx, int64_t n);
 // One-sweep steps, end of a sweep: the restart's V <- V Q with the PENDING correction of the last Lanczos step riding on it
-// (fac.hip restart_sym).  Out of place: X[:, 0:p] = V[:, 0:m] Q (X != V), and from the same tile of V:
+// (fac.hip restart_sym).  X[:, 0:p] = V[:, 0:m] Q (X == V allowed: in place), and from the same tile of V:
 //   f_corr = ftilde - V c ;  chk = V' f_corr  (the reference's test for a second correction, Lanczos.h:156) ;  |f_corr|^2
 //   fnew = f_corr * q_last + X[:, kcol] * h_sub  (Arnoldi.h:337) ;  |fnew|^2
 // Records: slots [0, m) chk, slot m |fnew|^2, kSlotBeta2 |f_corr|^2.  m, p <= kPanelCols.  Returns the number of records.

@@ -153,7 +153,7 @@ def test_exchange_overlapped_with_the_local_rows_changes_nothing(world, exchange
 
 
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("orth", ["onesweep", "onesweep-eager", "reference"])
+@pytest.mark.parametrize("orth", ["onesweep", "onesweep-eager", "onesweep-recorrect", "reference"])
 def test_sharded_device_run_that_stops_mid_sweep(ctx, world, orth):
     # ncv = 60 on a small band: Ritz pairs converge inside a sweep, the corrections grow beyond what a lagged step may carry
     # and the device-driven run STOPS in mid-sweep (state_stops); the host continues from the record of the stopping pass while
@@ -173,7 +173,8 @@ def test_sharded_device_run_that_stops_mid_sweep(ctx, world, orth):
         assert r["res"].max() <= 1e-10
         if orth != "reference":
             assert r["orth"]["mode"] == "onesweep" and r["orth"]["state_stops"] > 0
-            assert (r["orth"]["fused_restarts"] > 0) == (orth == "onesweep")
+            assert (r["orth"]["fused_restarts"] > 0) == (orth != "onesweep-eager")
+            assert (r["orth"]["fused_recorrected"] > 0) == (orth == "onesweep-recorrect")
     assert np.abs(res[0]["evals"] - single.eigenvalues()).max() < 1e-10
     assert abs(res[0]["nops"] - single.num_operations()) <= ncv - nev
     assert np.abs(X.T @ X - np.eye(nev)).max() <= 1e-10
