@@ -35,6 +35,14 @@ struct OneSweepStats
     long lagged_steps = 0, faithful_steps = 0, fallbacks_check = 0, fallbacks_state = 0, final_passes = 0;
     double max_rel_c = 0.0;  // max |c| / |f~| over the accepted lagged corrections
     double max_chk = 0.0;    // max |V' v_i| after a lagged correction
+    // The fused restart (fac.hip mispec_fac_restart_sym, krylov.hip k_vq_fused): with defer_last the correction of the LAST step
+    // of a full sweep stays pending too (end_pending, end_c) and is applied by compress_onesweep on the way into V <- V Q,
+    // together with the reference's test of the corrected residual; a failed test lets the reference's loop continue on the
+    // compressed factorisation.  force_recorrect: test hook, one such correction after every fused restart.
+    bool defer_last = false, force_recorrect = false;
+    bool end_pending = false;
+    std::vector<double> end_c;
+    long fused_restarts = 0, fused_recorrected = 0;
 };
 
 namespace onesweep_detail {
@@ -158,6 +166,15 @@ inline void factorize_from_lanczos_onesweep(Factorization& F, Index from_k, Inde
     OneSweepStats local;
     OneSweepStats& S = stats ? *stats : local;
     std::vector<double> Vf(to_m + 1), c(to_m + 1, 0.0), chk(to_m + 1), w(n), vi(n);
+    if (S.end_pending)  // a factorisation continued without a restart in between: finish the last step the reference's way
+    {
+        S.end_pending = false;
+        F.axpy_V(F.m, S.end_c.data());
+        F.beta = F.nrm(F.f.data());
+        std::vector<double> Vm(F.m + 1);
+        F.adj(F.m, F.f.data(), Vm.data());
+        corrections(F, F.m - 1, 1, Vm);
+    }
     F.zero_outside_leading(from_k);
 
     // pending == true: F.f is the UNCORRECTED residual f~ of step i-1, c = V[:, :i]' f~ (accepted), F.beta the norm the
@@ -245,7 +262,7 @@ inline void factorize_from_lanczos_onesweep(Factorization& F, Index from_k, Inde
                 c2 += Vf[j] * Vf[j];
             const double b2 = gamma2 - c2;
             const bool can_lag = (gamma >= beta_thresh) && (c2 <= 1e-6 * gamma2) && (b2 > 0.0) && (std::sqrt(b2) >= eps_sqrt) &&
-                                 (i < to_m - 1);
+                                 (i < to_m - 1 || (S.defer_last && to_m == F.m));
             if (can_lag)
             {
                 F.H(i - 1, i) += Vf[i - 1];  // Lanczos.h:173-175
@@ -269,7 +286,67 @@ inline void factorize_from_lanczos_onesweep(Factorization& F, Index from_k, Inde
         }
         i++;
     }
+    if (pending)  // only with defer_last: the correction of step to_m - 1 waits for the restart (compress_onesweep)
+    {
+        S.end_pending = true;
+        S.end_c.assign(c.begin(), c.begin() + to_m);
+    }
     F.k = to_m;
+}
+
+// Drop-in for Factorization::compress_V in the variant: a pending last correction is applied first, f = f~ - V c with ALL m
+// columns of the old basis (the device does it on the tiles of the V*Q pass), then Arnoldi.h:320-340 as in the reference.
+// The reference's test of the corrected residual (Lanczos.h:156, count = 1) is evaluated on the old basis; if it fails the
+// loop continues on the compressed factorisation: V[:, :k]'f is measured again, f and H(k-2 : k-1, k-1) are corrected.
+inline void compress_onesweep(Factorization& F, const Mat& Q, OneSweepStats* stats)
+{
+    using namespace onesweep_detail;
+    if (!stats || !stats->end_pending)
+    {
+        F.compress_V_reference(Q);
+        return;
+    }
+    OneSweepStats& S = *stats;
+    const Index n = F.n, m = F.m, k = F.k;
+    S.end_pending = false;
+    S.fused_restarts++;
+    F.axpy_V(m, S.end_c.data());  // Lanczos.h:171
+    std::vector<double> chk(m + 1);
+    adjoint_tree(F.V, n, m, F.f.data(), chk.data());
+    const double beta_corr = std::sqrt(dot_tree(F.f.data(), F.f.data(), n));
+    const bool failed = max_abs(chk.data(), m) > kEps * beta_corr;
+    S.max_chk = std::max(S.max_chk, beta_corr > 0.0 ? max_abs(chk.data(), m) / beta_corr : 0.0);
+    F.compress_V_reference(Q);
+    if (!failed && !S.force_recorrect)
+        return;
+    S.fused_recorrected++;
+    const double beta_thresh = kEps * std::sqrt(double(n));
+    std::vector<double> Vf(k + 1);
+    adjoint_tree(F.V, n, k, F.f.data(), Vf.data());
+    double ortho_err = max_abs(Vf.data(), k);
+    bool force = S.force_recorrect;
+    int count = 1;
+    while (count < 5 && (ortho_err > kEps * F.beta || force))
+    {
+        force = false;
+        if (F.beta < beta_thresh)
+        {
+            std::fill(F.f.begin(), F.f.end(), 0.0);
+            F.beta = 0.0;
+            break;
+        }
+        F.axpy_V(k, Vf.data());
+        if (k >= 2)
+        {
+            F.H(k - 2, k - 1) += Vf[k - 2];
+            F.H(k - 1, k - 2) = F.H(k - 2, k - 1);
+        }
+        F.H(k - 1, k - 1) += Vf[k - 1];
+        F.beta = F.nrm(F.f.data());
+        adjoint_tree(F.V, n, k, F.f.data(), Vf.data());
+        ortho_err = max_abs(Vf.data(), k);
+        count++;
+    }
 }
 
 }  // namespace oracle

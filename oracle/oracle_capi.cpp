@@ -396,26 +396,34 @@ long oracle_geigs_cg_solve(void* h, const double* rhs, double* x)
 void oracle_geigs_bprod(void* h, const double* x, double* y) { static_cast<GEigsHolder*>(h)->B.perform_op(x, y); }
 // NON-reference variant (oracle/onesweep_variant.hpp): the repository's opt-in one-sweep Lanczos factorisation under the
 // reference's driver.  on == 0 restores the reference's algorithm.
+// on: bit 0 the variant, bit 1 the last correction of a sweep rides on the restart (fused restart), bit 2 test hook: one more
+// correction after every fused restart
 void oracle_symeigs_set_onesweep(void* s, int on)
 {
     auto* S = static_cast<SymEigs*>(s);
-    if (!on)
+    if (!(on & 1))
     {
         S->fac.lanczos_variant = nullptr;
+        S->fac.compress_variant = nullptr;
         S->fac.variant_user.reset();
         return;
     }
-    S->fac.variant_user = std::make_shared<OneSweepStats>();
+    auto st = std::make_shared<OneSweepStats>();
+    st->defer_last = (on & 2) != 0;
+    st->force_recorrect = (on & 4) != 0;
+    S->fac.variant_user = st;
     S->fac.lanczos_variant = [](Factorization& F, Index from_k, Index to_m, Index& ops, void* user) {
         factorize_from_lanczos_onesweep(F, from_k, to_m, ops, static_cast<OneSweepStats*>(user));
     };
+    S->fac.compress_variant = [](Factorization& F, const Mat& Q, void* user) { compress_onesweep(F, Q, static_cast<OneSweepStats*>(user)); };
 }
-// out[0..7): lagged steps, faithful steps, check fallbacks, state fallbacks, final passes, max |c|/|f~|, max |V'v| after a lagged correction
+// out[0..9): lagged steps, faithful steps, check fallbacks, state fallbacks, final passes, max |c|/|f~|, max |V'v| after a lagged
+// correction, fused restarts, fused restarts followed by further corrections
 void oracle_symeigs_onesweep_stats(void* s, double* out)
 {
     auto* S = static_cast<SymEigs*>(s);
     const auto* st = static_cast<const OneSweepStats*>(S->fac.variant_user.get());
-    for (int i = 0; i < 7; i++)
+    for (int i = 0; i < 9; i++)
         out[i] = 0.0;
     if (!st)
         return;
@@ -426,6 +434,8 @@ void oracle_symeigs_onesweep_stats(void* s, double* out)
     out[4] = double(st->final_passes);
     out[5] = st->max_rel_c;
     out[6] = st->max_chk;
+    out[7] = double(st->fused_restarts);
+    out[8] = double(st->fused_recorrected);
 }
 void oracle_symeigs_set_shift_invert(void* s, double sigma)
 {

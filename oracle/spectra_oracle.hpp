@@ -862,6 +862,9 @@ public:
     // (oracle/onesweep_variant.hpp restates this repository's opt-in one-sweep variant so that it can be compared with the
     // reference-faithful code below under the same driver).  nullptr = the reference's algorithm.
     void (*lanczos_variant)(Factorization&, Index, Index, Index&, void*) = nullptr;
+    // ... and, for the same variant, a hook around compress_V (the variant may leave the last correction of a sweep pending and
+    // let it ride on the restart).  nullptr = the reference's compress_V.
+    void (*compress_variant)(Factorization&, const Mat&, void*) = nullptr;
     std::shared_ptr<void> variant_user;
 
     Factorization(const Op& op_, Index m_, const Op* bop_ = nullptr) : op(op_), n(op_.rows()), m(m_), bop(bop_) {}
@@ -1139,8 +1142,16 @@ public:
         k--;
     }
 
-    // Arnoldi.h:320-340.  Column i of Q has its first (m - k + i + 1) entries non-zero.
     void compress_V(const Mat& Q)
+    {
+        if (compress_variant)  // test hook (see the member): not the reference's algorithm
+            compress_variant(*this, Q, variant_user.get());
+        else
+            compress_V_reference(Q);
+    }
+
+    // Arnoldi.h:320-340.  Column i of Q has its first (m - k + i + 1) entries non-zero.
+    void compress_V_reference(const Mat& Q)
     {
         Mat Vs(n, k + 1);
         for (Index i = 0; i < k; i++)

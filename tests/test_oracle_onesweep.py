@@ -15,10 +15,15 @@ RULE = {"LargestMagn": O.LargestMagn, "LargestAlge": O.LargestAlge, "SmallestMag
         "SmallestAlge": O.SmallestAlge, "BothEnds": O.BothEnds}
 
 
+# flavours of the variant: "eager" applies the last correction of a sweep at once; "fused" lets it ride on the restart (what the
+# device does by default in one-sweep mode: k_vq_fused); "recorrect" additionally forces the loop that follows a failed test
+FLAVOURS = {"eager": {}, "fused": {"fused": True}, "recorrect": {"fused": True, "recorrect": True}}
+
+
 def solve(op, k, m, rule, onesweep, tol=1e-10, maxit=1000, sorting=O.LargestAlge, v0=None):
     s = O.SymEigsSolver(op, k, m)
     if onesweep:
-        s.set_onesweep(True)
+        s.set_onesweep(True, **FLAVOURS[onesweep if isinstance(onesweep, str) else "eager"])
     s.init(v0)
     nconv = s.compute(rule, maxit, tol, sorting)
     return dict(nconv=nconv, info=s.info(), niter=s.num_iterations(), nops=s.num_operations(), evals=s.eigenvalues(),
@@ -27,14 +32,15 @@ def solve(op, k, m, rule, onesweep, tol=1e-10, maxit=1000, sorting=O.LargestAlge
 
 @pytest.mark.parametrize("n,prob,k,m", SPARSE_CASES + [(1000, 0.01, 20, 30)])
 @pytest.mark.parametrize("rule", RULES_SYM)
-def test_variant_equals_reference_on_the_reference_fixtures(n, prob, k, m, rule):
+@pytest.mark.parametrize("flavour", list(FLAVOURS))
+def test_variant_equals_reference_on_the_reference_fixtures(n, prob, k, m, rule, flavour):
     # test/SymEigs.cpp:133-167 x :78-97
     if (n, m, rule) == (1000, 30, "SmallestMagn"):
         pytest.skip("does not converge within maxit for either algorithm")
     A, S = sparse_fixture(n, prob)
     op = O.Op.csc_sym(n, A.indptr, A.indices, A.data, True)
     ref = solve(op, k, m, RULE[rule], False)
-    one = solve(op, k, m, RULE[rule], True)
+    one = solve(op, k, m, RULE[rule], flavour)
     assert (one["nconv"], one["info"]) == (ref["nconv"], ref["info"]) and one["nconv"] == k
     assert np.abs(one["evals"] - ref["evals"]).max() <= 1e-9
     slack = max(m - k, (0.15 if rule == "SmallestMagn" else 0.0) * ref["nops"])
@@ -44,49 +50,59 @@ def test_variant_equals_reference_on_the_reference_fixtures(n, prob, k, m, rule)
     assert np.abs(U.T @ U - np.eye(k)).max() <= 1e-10
     st = one["stats"]
     assert st["lagged_steps"] > 0 and st["max_chk"] <= 4 * np.finfo(float).eps
+    if flavour == "eager":
+        assert st["fused_restarts"] == 0
+    else:   # most sweeps end with a correction that can wait for the restart; the forced loop runs after each of them
+        assert st["fused_restarts"] > 0 and st["fused_restarts"] >= 0.5 * (one["niter"] - 1)
+        assert st["fused_recorrected"] == (st["fused_restarts"] if flavour == "recorrect" else st["fused_recorrected"])
+        assert st["fused_recorrected"] <= (st["fused_restarts"] if flavour == "recorrect" else max(2, 0.2 * st["fused_restarts"]))
 
 
+@pytest.mark.parametrize("flavour", list(FLAVOURS))
 @pytest.mark.parametrize("k,m", [(3, 6), (5, 12), (6, 12)])
-def test_variant_on_example1_degenerate_spectrum(k, m):
+def test_variant_on_example1_degenerate_spectrum(k, m, flavour):
     # test/Example1.cpp:34-68 incl. the (20, 5, 12) case whose Krylov space is exhausted after 10 steps: the breakdown clamp
     # (Lanczos.h:163-168) and the new random direction must be reached through the variant's fall-backs
     M = cycle_laplacian(20)
     true = np.sort(1.0 - np.cos(2 * np.pi * np.arange(20) / 20))
     Mc = sp.csc_matrix(M)
     op = O.Op.csc_sym(20, Mc.indptr, Mc.indices, Mc.data, True)
-    one = solve(op, k, m, O.LargestMagn, True, tol=1e-15, sorting=O.SmallestAlge)
+    one = solve(op, k, m, O.LargestMagn, flavour, tol=1e-15, sorting=O.SmallestAlge)
     assert one["info"] == 0 and one["nconv"] == k
     assert np.abs(true[-k:] - one["evals"]).max() < 1e-9
     assert np.abs(M @ one["evecs"] - one["evecs"] * one["evals"]).max() < 1e-9
 
 
+@pytest.mark.parametrize("flavour", list(FLAVOURS))
 @pytest.mark.parametrize("case", range(3))
-def test_variant_on_example2(case):
+def test_variant_on_example2(case, flavour):
     M = EXAMPLE2[case]
-    one = solve(O.Op.dense_sym(M), 1, 3, O.LargestAlge, True)
+    one = solve(O.Op.dense_sym(M), 1, 3, O.LargestAlge, flavour)
     assert abs(one["evals"][0] - np.linalg.eigvalsh(M)[-1]) < 1e-8
 
 
-def test_variant_doc_example_and_zero_matrix():
+@pytest.mark.parametrize("flavour", list(FLAVOURS))
+def test_variant_doc_example_and_zero_matrix(flavour):
     # SymEigsSolver.h:99-126 and test/Example4.cpp:59-72
     ref = solve(O.Op.diag(np.arange(1.0, 11.0)), 3, 6, O.LargestAlge, False)
-    one = solve(O.Op.diag(np.arange(1.0, 11.0)), 3, 6, O.LargestAlge, True)
+    one = solve(O.Op.diag(np.arange(1.0, 11.0)), 3, 6, O.LargestAlge, flavour)
     assert np.allclose(one["evals"], [10.0, 9.0, 8.0], atol=1e-10) and (one["nops"], one["niter"]) == (ref["nops"], ref["niter"])
     n = 100
     Z = sp.csr_matrix((n, n))
     v0 = np.random.default_rng(123).uniform(-1, 1, n)
-    one = solve(O.Op.csr(n, n, Z.indptr.astype(np.int32), Z.indices.astype(np.int32), Z.data), 3, 6, O.LargestAlge, True, v0=v0)
+    one = solve(O.Op.csr(n, n, Z.indptr.astype(np.int32), Z.indices.astype(np.int32), Z.data), 3, 6, O.LargestAlge, flavour, v0=v0)
     assert one["info"] == 0 and np.abs(one["evals"]).max() < 1e-8
 
 
-def test_variant_on_the_benchmark_matrix_family():
+@pytest.mark.parametrize("flavour", list(FLAVOURS))
+def test_variant_on_the_benchmark_matrix_family(flavour):
     # M-band of SURVEY.md 8d at a size the oracle solves in seconds; k = 20, ncv = 40, tol 1e-11 as in bench.py
     n, k, m = 20000, 20, 40
     rp, ci, va = O.synth_band_csr(n)
     S = sp.csr_matrix((va, ci, rp), shape=(n, n))
     op = O.Op.csr(n, n, rp, ci, va)
     ref = solve(op, k, m, O.LargestMagn, False, tol=1e-11)
-    one = solve(op, k, m, O.LargestMagn, True, tol=1e-11)
+    one = solve(op, k, m, O.LargestMagn, flavour, tol=1e-11)
     assert one["nconv"] == ref["nconv"] == k
     assert np.abs(one["evals"] - ref["evals"]).max() <= 1e-9
     assert abs(one["nops"] - ref["nops"]) <= m - k and abs(one["niter"] - ref["niter"]) <= 1
@@ -95,5 +111,7 @@ def test_variant_on_the_benchmark_matrix_family():
     assert res.max() <= 1e-10
     assert np.abs(U.T @ U - np.eye(k)).max() <= 1e-10
     st = one["stats"]
-    # practically every step is lagged: one sweep of V per step plus one finishing pass per restart cycle
+    # practically every step is lagged: one sweep of V per step plus one finishing pass per restart cycle ("eager") or none
     assert st["lagged_steps"] >= 0.95 * one["nops"] and st["fallbacks_check"] + st["fallbacks_state"] <= 0.05 * one["nops"]
+    if flavour != "eager":
+        assert st["fused_restarts"] >= 0.9 * (one["niter"] - 1) and st["final_passes"] <= 0.1 * one["niter"]
