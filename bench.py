@@ -574,7 +574,9 @@ def main():
                 "frac": split["bytes_vtf"] / (split["ms_vtf"] * 1e-3) / 1e9 / HBM_PEAK_GBPS if split["ms_vtf"] > 0 else None,
                 "note": "algorithmic bytes (8 n x vectors read + written, summed over the launches of one solve) over the family's HIP-event "
                         "time, which also covers the ~10 us record reduction behind every pass; from the instrumented extra solve",
-                "compress": {"kernel": "k_vq (V <- V Q in place, X = V Y)", "achieved": split["bytes_compress"] / (split["ms_compress"] * 1e-3) / 1e9
+                "compress": {"kernel": ("k_vq_fused (V <- V Q in place with the pending correction of the sweep's last step, its V'f test and the "
+                                        "restarted residual on the same tiles), k_vq (X = V Y)" if args.orth == "onesweep"
+                                        else "k_vq (V <- V Q in place, X = V Y)"), "achieved": split["bytes_compress"] / (split["ms_compress"] * 1e-3) / 1e9
                              if split["ms_compress"] > 0 else None}} if split else None),
             "kernels_ms_per_solve": ({k[3:]: split[k] for k in split if k.startswith("ms_")} if split else None),
             "kernels_ms_note": "from one additional solve with every kernel family bracketed by HIP events, outside the timed region",
