@@ -469,7 +469,17 @@ def main():
             Xh = eigs.eigenvectors()
         barrier()
         with_host = {"value": hp / (time.perf_counter() - t0), "note": f"eigenvectors() returned as a {Xh.shape[0]} x {Xh.shape[1]} host matrix "
-                     "(pageable numpy array, D2H inside the timed loop) as the reference's API does"}
+                     "(a FRESH pageable numpy array per solve, D2H inside the timed loop) as the reference's API does"}
+        # ... and into the SAME host matrix every time (eigenvectors(out=...), C++: eigenvectors_to): without the first-touch page faults
+        barrier()
+        t0 = time.perf_counter()
+        hp = 0
+        for _ in range(args.steps):
+            eigs.init()
+            hp += eigs.compute(rule, 1000, args.tol)
+            eigs.eigenvectors(out=Xh)
+        barrier()
+        with_host["value_into_a_reused_host_matrix"] = hp / (time.perf_counter() - t0)
         del Xh
     # per-family kernel split: one more solve with every family instrumented, not part of `value`
     split = None

@@ -852,16 +852,24 @@ class SymEigsSolver:
         return self.op.local_rows() if isinstance(self.op, (_DeviceMatrix, SVDMatOp, _GEigsRegInvOp, _GEigsShiftOp, _GEigsCholeskyOp,
                                                             _DenseMatrix, DeviceOp)) else self.op.rows()
 
-    def eigenvectors(self, nvec=None, to_host=True):
-        """n x nconv (this shard's rows).  to_host=False leaves the result in HBM and returns the column count."""
+    def eigenvectors(self, nvec=None, to_host=True, out=None):
+        """n x nconv (this shard's rows).  to_host=False leaves the result in HBM and returns the column count.  out: a
+        column-major float64 array of at least local_rows x min(nvec, nev) to be filled instead of a fresh one (the reference's
+        eigenvectors() returns a new matrix every time; a caller that solves repeatedly saves the first-touch page faults of
+        1.6 GB at n = 1e7 by handing the previous result back — SymEigsSolver::eigenvectors_to in the C++ headers)."""
         nvec = self.nev if nvec is None else int(nvec)
         cnt = C.c_int64()
         if not to_host:
             check(lib().mispec_symeigs_eigenvectors(self.h, nvec, None, C.byref(cnt)))
             return cnt.value
-        out = np.empty((self.local_rows(), max(min(nvec, self.nev), 1)), order="F")  # filled by the library's host threads
+        ncol = max(min(nvec, self.nev), 1)
+        if out is None:
+            out = np.empty((self.local_rows(), ncol), order="F")  # filled by the library's host threads
+        elif not (isinstance(out, np.ndarray) and out.dtype == np.float64 and out.flags.f_contiguous and out.ndim == 2 and
+                  out.shape[0] == self.local_rows() and out.shape[1] >= ncol):
+            raise ValueError("eigenvectors(out=...): need a column-major float64 array of local_rows x >= min(nvec, nev)")
         check(lib().mispec_symeigs_eigenvectors(self.h, nvec, _dp(out), C.byref(cnt)))
-        return np.asfortranarray(out[:, :cnt.value])
+        return out[:, :cnt.value] if out.shape[1] != cnt.value else out
 
     def residuals(self):
         """||A x - lambda x|| / ||x|| of the converged pairs, evaluated on the device."""

@@ -56,20 +56,26 @@ def test_reordered_spmv_is_bit_exact_on_the_permuted_csr_and_keeps_the_callers_o
     assert np.allclose(op @ X, B @ X, rtol=0, atol=1e-13)
 
 
+@pytest.mark.parametrize("orth", ["reference", "onesweep"])
 @pytest.mark.parametrize("rule", ["LargestMagn", "SmallestAlge", "BothEnds"])
-def test_reordered_solve_equals_the_unreordered_one(ctx, rule):
+def test_reordered_solve_equals_the_unreordered_one(ctx, rule, orth):
+    # orth = "onesweep": the one-sweep steps and the fused restart on a factorisation that works in the stored (permuted) order
     B = shuffled_stencil(24, seed=3)
     n = B.shape[0]
     out = []
     for mode in ("none", "rcm"):
         op = sa.SparseSymMatProd(sp.tril(B).tocsc(), ctx=ctx, reorder=mode)
         eigs = sa.SymEigsSolver(op, 8, 24)
+        eigs.set_orth_mode(orth)
         eigs.init()
         assert eigs.compute(sa.SortRule[rule], 1000, 1e-12) == 8
         ev, X = eigs.eigenvalues(), eigs.eigenvectors()
         assert np.abs(B @ X - X * ev).max() <= 1e-9             # eigenvectors are in the CALLER's order
         assert eigs.residuals().max() <= 1e-10
         assert eigs.eigenvectors(to_host=False) == 8
+        if orth == "onesweep":
+            info = eigs.orth_info()
+            assert info["mode"] == "onesweep" and info["lagged_steps"] > 0 and info["fused_restarts"] > 0
         out.append((ev, X, eigs.num_operations()))
     assert np.abs(out[0][0] - out[1][0]).max() <= 1e-12
     assert np.abs(np.abs(np.sum(out[0][1] * out[1][1], axis=0)) - 1.0).max() <= 1e-8

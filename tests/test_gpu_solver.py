@@ -41,6 +41,13 @@ def run_test(mat, eigs, selection, **kw):
     assert eigs.info() == sa.CompInfo.Successful, (nconv, eigs.num_iterations(), eigs.num_operations())
     evals, evecs = eigs.eigenvalues(), eigs.eigenvectors()
     err = np.abs(mat @ evecs - evecs * evals).max()
+    # the same result written into a caller-provided host matrix (eigenvectors(out=...): no fresh allocation per solve)
+    buf = np.full((evecs.shape[0], eigs.nev), np.nan, order="F")
+    again = eigs.eigenvectors(out=buf)
+    assert np.array_equal(again, evecs) and np.shares_memory(again, buf)
+    if eigs.nev > 1 and evecs.shape[0] > 1:
+        with pytest.raises(ValueError):
+            eigs.eigenvectors(out=np.zeros((evecs.shape[0], eigs.nev)))  # row-major
     return nconv, evals, evecs, err
 
 
