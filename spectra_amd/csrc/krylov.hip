@@ -933,7 +933,7 @@ __global__ __launch_bounds__(kThreads) void k_vq(const double* __restrict__ V, i
 // additionally forms the corrected residual of its rows from the staged tile (p = V c: m LDS reads, the same for all four
 // waves — cheaper than a second barrier), accumulates chk_j = <V_j, f_corr> for the input columns j = w (mod 4), and the wave
 // that holds output column kcol writes fnew.  Rows past the end are staged from row 0 (clamped address) and masked out of every sum.
-template <int MAXS>
+template <int MAXS, int NJ>
 __global__ __launch_bounds__(kThreads) void k_vq_fused(const double* V, int64_t ldv, int m, const double* __restrict__ Q, int ldq, int p,
                                                         double* X, int64_t ldx, int64_t n, VqFusedArgs fa)
 {
@@ -943,7 +943,7 @@ __global__ __launch_bounds__(kThreads) void k_vq_fused(const double* V, int64_t 
     double* cs = Qs + int64_t(m) * 4 * MAXS;     // [m]
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int kMaxJ = kPanelCols / 4;
+    constexpr int kMaxJ = NJ;  // input columns per wave: ceil(m / 4) <= NJ
     const int nj = (m - w + 3) / 4;
     for (int idx = tid; idx < m * 4 * MAXS; idx += kThreads)
     {
@@ -1552,21 +1552,25 @@ int launch_vq_fused(const mispec_ctx& ctx, const double* V, int64_t ldv, int m, 
     const int grid = persistent_grid(ctx, ntiles, 3);
     MISPEC_REQUIRE(fa.pstride >= grid, "fused V*Q kernel: partial-record stride smaller than the grid");
     const dim3 g(static_cast<unsigned>(grid)), b(kThreads);
-#define MISPEC_VQF(S)                                                                                                          \
+#define MISPEC_VQF(S, J)                                                                                                       \
     do                                                                                                                         \
     {                                                                                                                          \
-        MISPEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vq_fused<S>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+        MISPEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vq_fused<S, J>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                        int(lds)));                                                                             \
-        hipLaunchKernelGGL((k_vq_fused<S>), g, b, lds, ctx.stream, V, ldv, m, Q, ldq, p, X, ldx, n, fa);                       \
+        hipLaunchKernelGGL((k_vq_fused<S, J>), g, b, lds, ctx.stream, V, ldv, m, Q, ldq, p, X, ldx, n, fa);                    \
     } while (0)
-    if (maxs == 4)
-        MISPEC_VQF(4);
+    // the benchmark's shape (ncv = 40: ten input columns per wavefront, <= 32 output columns) has an instantiation of its own:
+    // 16 column slots cost 238 registers = 2 workgroups per CU, ten fit 3
+    if (maxs == 8 && m <= 40)
+        MISPEC_VQF(8, 10);
+    else if (maxs == 4)
+        MISPEC_VQF(4, 16);
     else if (maxs == 8)
-        MISPEC_VQF(8);
+        MISPEC_VQF(8, 16);
     else if (maxs == 12)
-        MISPEC_VQF(12);
+        MISPEC_VQF(12, 16);
     else
-        MISPEC_VQF(16);
+        MISPEC_VQF(16, 16);
 #undef MISPEC_VQF
     MISPEC_HIP(hipGetLastError());
     return grid;
