@@ -895,11 +895,11 @@ class SymEigsSolver:
         mode, a, b, c = C.c_int(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
         r, k = C.c_double(0.0), C.c_double(0.0)
         check(lib().mispec_symeigs_orth_info(self.h, C.byref(mode), C.byref(a), C.byref(b), C.byref(c), C.byref(r), C.byref(k)))
-        fused, redone = C.c_int64(0), C.c_int64(0)
-        check(lib().mispec_symeigs_restart_info(self.h, C.byref(fused), C.byref(redone)))
+        fused, again = C.c_int64(0), C.c_int64(0)
+        check(lib().mispec_symeigs_restart_info(self.h, C.byref(fused), C.byref(again)))
         return {"mode": "onesweep" if mode.value else "reference", "lagged_steps": a.value, "check_stops": b.value,
                 "state_stops": c.value, "max_rel_c": r.value, "max_chk": k.value, "fused_restarts": fused.value,
-                "fused_recorrected": redone.value}
+                "fused_recorrected": again.value}
 
     def overlap_info(self):
         """(first interior 256-row block, interior blocks, all blocks): what is multiplied while the exchange is in flight."""
@@ -1449,9 +1449,9 @@ class Factorization:
         check(lib().mispec_fac_restart_sym(self.h, _dp(s), len(s)))
 
     def restart_info(self):
-        fused, redone = C.c_int64(0), C.c_int64(0)
-        check(lib().mispec_fac_restart_info(self.h, C.byref(fused), C.byref(redone)))
-        return {"fused_restarts": fused.value, "fused_recorrected": redone.value}
+        fused, again = C.c_int64(0), C.c_int64(0)
+        check(lib().mispec_fac_restart_info(self.h, C.byref(fused), C.byref(again)))
+        return {"fused_restarts": fused.value, "fused_recorrected": again.value}
 
     def compress_V(self, Q, H, new_k):
         Q = np.asfortranarray(Q, dtype=np.float64)

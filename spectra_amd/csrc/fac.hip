@@ -122,7 +122,7 @@ struct mispec_fac
     // already carry it) so that the restart's V*Q pass can apply it on the way (mispec_fac_restart_sym); everything else that
     // needs f calls finish_pending first.
     bool end_pending = false;
-    bool eager_last = false, test_redo = false;  // MISPEC_ORTH_EAGER_LAST / MISPEC_ORTH_TEST_RECORRECT
+    bool eager_last = false, test_recorrect = false;  // MISPEC_ORTH_EAGER_LAST / MISPEC_ORTH_TEST_RECORRECT
     int end_rec = 0;
     int64_t fused_restarts = 0, fused_recorrected = 0;
     int x_cols = 0;    // columns currently held in X
@@ -1762,7 +1762,7 @@ extern "C" int mispec_fac_set_orth_mode(mispec_fac* fac, int mode)
                        "mispec_fac_set_orth_mode: unknown mode");
         fac->onesweep = (base == MISPEC_ORTH_ONESWEEP);
         fac->eager_last = (flags & MISPEC_ORTH_EAGER_LAST) != 0;
-        fac->test_redo = (flags & MISPEC_ORTH_TEST_RECORRECT) != 0;
+        fac->test_recorrect = (flags & MISPEC_ORTH_TEST_RECORRECT) != 0;
     });
 }
 
@@ -2064,10 +2064,10 @@ extern "C" int mispec_fac_restart_sym(mispec_fac* fac, const double* shifts_host
             F.k = k;
             if (!fused)
                 update_f_after_compress(F, q_last, h_sub);  // syncs: Q has been consumed by then
-            else if (test_failed || F.test_redo)
+            else if (test_failed || F.test_recorrect)
             {
                 F.fused_recorrected++;
-                corrections_after_fused_restart(F, F.test_redo);
+                corrections_after_fused_restart(F, F.test_recorrect);
             }
             return;
         }
