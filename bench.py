@@ -598,9 +598,11 @@ def main():
                 "exchange": {"count": 1, "kind": "neighbour send/recv" if halo else "all-gather",
                              "megabytes_received_per_rank": recv_doubles * 8 / 1e6 if halo else (world - 1) * block_mb},
                 "all_reduce_sum": [{"what": "alpha = <v, w>", "bytes": 8}] +
-                                  [{"what": "record: V'f (<= ncv slots used), |f|^2", "bytes": 8 * 1025}] * (1 if args.orth.startswith("onesweep") else 2),
-                "note": "per Lanczos step and rank; one-sweep: one record per step (+ one finishing pass per restart cycle), reference flow: "
-                        "V'f and the correction's V'f check"}
+                                  ([{"what": "record of the one-sweep pass of step i: c' = [V, v_i]'f (i + 1 sums), chk = V'v_i (i), |f|^2 — one "
+                                             "contiguous message", "bytes_max": 8 * 2 * args.ncv}] if args.orth.startswith("onesweep") else
+                                   [{"what": "record: V'f (i + 1 sums), |f|^2 — one contiguous message", "bytes_max": 8 * (args.ncv + 1)}] * 2),
+                "note": "per Lanczos step and rank; one-sweep: one record per step (the last correction of a sweep and its test ride on the "
+                        "restart's V*Q pass: one more record of ncv + 2 sums per restart), reference flow: V'f and the correction's V'f check"}
         if allgather_run:
             out["allgather_variant"] = allgather_run
         if world == 1 and not args.no_secondary and not args.no_profile:
