@@ -840,7 +840,8 @@ __global__ __launch_bounds__(kThreads) void k_resid_norms_complex(const double* 
 // may overwrite V in place (compress_V): a tile's rows are private to its workgroup and fully read
 // before the first write.  Wave w produces output columns i = w (mod 4).  Q is re-laid out in LDS
 // so that a wave's coefficients for one j are contiguous (broadcast ds_read_b128).
-// this wave's columns (w, w+4, ...) of one 128-row tile -> registers; surplus slots re-read column w
+// this wave's columns (w, w+4, ...) of one 128-row tile -> registers; surplus slots re-read column w (column 0 for a wave that
+// has no column at all: m < 4 — column w would lie behind the basis)
 template <int NJ>
 __device__ __forceinline__ void vq_fetch(v2d (&pre)[NJ], const double* __restrict__ V, int64_t ldv, int w, int nj,
                                          int64_t r, int64_t n)
@@ -849,7 +850,7 @@ __device__ __forceinline__ void vq_fetch(v2d (&pre)[NJ], const double* __restric
 #pragma unroll
     for (int jj = 0; jj < NJ; jj++)
     {
-        const int jc = (jj < nj) ? (w + 4 * jj) : w;
+        const int jc = (jj < nj) ? (w + 4 * jj) : (nj > 0 ? w : 0);
         pre[jj] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(V + int64_t(jc) * ldv + rc));  // streamed once: see k_orth
     }
 }

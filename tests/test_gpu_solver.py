@@ -328,3 +328,21 @@ def test_wide_basis_at_scale(ctx):
     assert eigs.residuals().max() <= 1e-10
     ev = eigs.eigenvalues()
     assert np.all(np.diff(ev) <= 0)
+
+
+@pytest.mark.parametrize("orth", ["reference", "onesweep"])
+def test_narrowest_basis_on_a_large_matrix(ctx, orth):
+    # nev = 1, ncv = 3 (the smallest the reference accepts besides ncv = 2) at a size where a column behind the basis would lie
+    # outside its allocation: the V*Q kernels' wavefronts without a column of their own must not touch memory behind V
+    n = 1_000_003
+    op = sa.SparseSymMatProd.synth_band(n, offsets=(1, 2, 3), ctx=ctx)
+    eigs = sa.SymEigsSolver(op, 1, 3)
+    eigs.set_orth_mode(orth)
+    eigs.init()
+    nconv = eigs.compute(sa.SortRule.LargestAlge, 3000, 1e-8)
+    assert nconv == 1 and eigs.info() == sa.CompInfo.Successful
+    assert eigs.residuals().max() <= 1e-6
+    again = sa.SymEigsSolver(op, 1, 3)
+    again.init()
+    assert again.compute(sa.SortRule.LargestAlge, 3000, 1e-8) == 1
+    assert abs(again.eigenvalues()[0] - eigs.eigenvalues()[0]) <= 1e-9
