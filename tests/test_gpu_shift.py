@@ -222,6 +222,17 @@ def test_interior_eigenvalues_of_a_large_banded_matrix(ctx, n, sigma):
     assert o.compute(O.LargestMagn, 1000, 1e-11) == 6
     assert np.abs(np.sort(o.eigenvalues()) - np.sort(ev)).max() <= 1e-9
     assert np.abs(ev - sigma).max() < 1e-3  # they are the ones next to sigma
+    # right-hand sides ALIGNED with the eigenvectors nearest sigma — the directions a boosted factor is least
+    # accurate in, and what the Lanczos vectors turn into: the calibrated number of refinement steps (set on one random probe,
+    # + one safety step when pivots were boosted) must leave these solves backward stable too
+    M = (A - sigma * sp.identity(n)).tocsr()
+    norm_M = abs(M).sum(axis=1).max()
+    for j in range(X.shape[1]):
+        x = X[:, j]
+        y = op.perform_op(x)
+        bwd = np.abs(M @ y - x).max() / (norm_M * np.abs(y).max() + np.abs(x).max())
+        assert bwd <= 1e-13, (j, bwd, op.refinement_info())
+        assert np.abs(y * (ev[j] - sigma) - x).max() <= 1e-6 * np.abs(x).max()     # y = x / (lambda - sigma) up to cond * eps
 
 
 def test_definite_matrices_need_no_refinement(ctx):
