@@ -115,3 +115,50 @@ def test_variant_on_the_benchmark_matrix_family(flavour):
     assert st["lagged_steps"] >= 0.95 * one["nops"] and st["fallbacks_check"] + st["fallbacks_state"] <= 0.05 * one["nops"]
     if flavour != "eager":
         assert st["fused_restarts"] >= 0.9 * (one["niter"] - 1) and st["final_passes"] <= 0.1 * one["niter"]
+
+
+@pytest.mark.parametrize("flavour", list(FLAVOURS))
+@pytest.mark.parametrize("scale", [1e-8, 1.0, 1e8])
+def test_variant_is_scale_free_where_the_reference_is(flavour, scale):
+    # every threshold of the variant is relative (|c| vs |f|, |V'v| vs eps) except the ones the reference itself takes as
+    # absolute (beta < sqrt(eps), near_0): scaling the matrix by 1e+-8 must scale the eigenvalues and change nothing else
+    n, k, m = 1000, 10, 30
+    A, S = sparse_fixture(n, 0.01)
+    op1 = O.Op.csc_sym(n, A.indptr, A.indices, A.data, True)
+    As = (A * scale).tocsc()
+    ops = O.Op.csc_sym(n, As.indptr, As.indices, As.data, True)
+    ref = solve(ops, k, m, O.LargestAlge, False)
+    one = solve(ops, k, m, O.LargestAlge, flavour)
+    base = solve(op1, k, m, O.LargestAlge, flavour)
+    assert one["nconv"] == ref["nconv"] == k
+    assert np.abs(one["evals"] - ref["evals"]).max() <= 1e-9 * scale
+    assert abs(one["nops"] - ref["nops"]) <= m - k
+    if scale >= 1.0:  # above the reference's absolute sqrt(eps) threshold the runs are images of each other
+        assert one["nops"] == base["nops"] and np.abs(one["evals"] / scale - base["evals"]).max() <= 1e-12
+    U, D = one["evecs"], one["evals"]
+    assert np.abs((S * scale) @ U - U * D).max() < 1e-9 * scale and np.abs(U.T @ U - np.eye(k)).max() <= 1e-10
+
+
+@pytest.mark.parametrize("flavour", list(FLAVOURS))
+def test_variant_on_a_2d_laplacian_with_multiple_eigenvalues(flavour):
+    # 5-point Laplacian on a 40 x 40 grid: the spectrum is full of exactly double eigenvalues (lambda_ij = lambda_ji), the case
+    # in which Lanczos vectors lose orthogonality fastest and the corrections are largest
+    g = 40
+    T = sp.diags([np.full(g, 2.0), np.full(g - 1, -1.0), np.full(g - 1, -1.0)], [0, 1, -1])
+    L = (sp.kron(sp.identity(g), T) + sp.kron(T, sp.identity(g))).tocsc()
+    n, k, m = g * g, 8, 24
+    op = O.Op.csc_sym(n, L.indptr, L.indices, L.data, True)
+    ref = solve(op, k, m, O.LargestAlge, False, tol=1e-10)
+    one = solve(op, k, m, O.LargestAlge, flavour, tol=1e-10)
+    assert one["nconv"] == ref["nconv"] == k and one["info"] == ref["info"] == 0
+    lam = 2.0 - 2.0 * np.cos(np.pi * np.arange(1, g + 1) / (g + 1))
+    true = np.sort((lam[:, None] + lam[None, :]).ravel())[::-1][:k]
+    assert np.abs(one["evals"] - ref["evals"]).max() <= 1e-9
+    # a Krylov space started from one vector sees each multiple eigenvalue once until rounding brings the second copy in: both
+    # algorithms return the same set, which need not be the true top-k WITH multiplicity
+    spectrum = np.sort((lam[:, None] + lam[None, :]).ravel())
+    assert np.abs(spectrum[:, None] - one["evals"][None, :]).min(axis=0).max() <= 1e-9
+    assert abs(one["nops"] - ref["nops"]) <= 2 * (m - k)
+    U, D = one["evecs"], one["evals"]
+    assert np.abs(L @ U - U * D).max() < 1e-9 and np.abs(U.T @ U - np.eye(k)).max() <= 1e-10
+    assert true[0] - one["evals"].max() <= 1e-9
