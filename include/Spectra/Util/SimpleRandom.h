@@ -22,7 +22,8 @@ public:
     // one draw in [-0.5, 0.5)
     Scalar random()
     {
-        m_state = (16807ULL * m_state) % kMod;
+        if (m_state != kMod)  // 2^31 - 1 (seed & m_max) is a fixed point of the reference's folded product (Util/SimpleRandom.h:30-52)
+            m_state = (16807ULL * m_state) % kMod;
         return Scalar(static_cast<long>(m_state)) / Scalar(2147483647L) - Scalar(0.5);
     }
     void random_vec(Scalar* out, std::ptrdiff_t len)

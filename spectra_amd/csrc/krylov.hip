@@ -1187,6 +1187,12 @@ __global__ __launch_bounds__(kThreads) void k_simple_random(double* __restrict__
     }
     uint64_t s = mod_m31(s0 * pw);
     const int64_t last = (first + kRun < nloc) ? first + kRun : nloc;
+    if (s0 == 2147483647ULL)  // a fixed point of the reference's folded product (the stream is the constant 0.5)
+    {
+        for (int64_t i = first; i < last; i++)
+            v[i] = double(int64_t(s0)) / double(2147483647L) - 0.5;
+        return;
+    }
     for (int64_t i = first; i < last; i++)
     {
         s = mod_m31(s * 16807ULL);
