@@ -21,5 +21,5 @@ if [ "${1:-}" != "--force" ] && [ -f "$LIB" ] &&
     echo "up to date $LIB"
     exit 0
 fi
-${CXX:-g++} -std=c++17 -O2 -fPIC -ffp-contract=off -Wall -I"$HERE/eigen_shim" -I"$REF/include" -shared "$HERE/ref_driver.cpp" -o "$LIB" || exit 1
+${CXX:-g++} -std=c++17 -O2 -fPIC -ffp-contract=off -fvisibility=hidden -fvisibility-inlines-hidden -Wall -I"$HERE/eigen_shim" -I"$REF/include" -shared -Wl,-Bsymbolic "$HERE/ref_driver.cpp" -o "$LIB" || exit 1
 echo "built $LIB"

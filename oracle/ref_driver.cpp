@@ -176,6 +176,10 @@ static int run_fac(const OpT& mop, long n, long m, int symmetric, const double* 
     scal[2] = double(nops);
     return 0;
 }
+// Only the ref_* entry points are exported (build_ref.sh compiles with -fvisibility=hidden): the reference's classes live in
+// namespace Spectra, and so do the classes of this repository's include/Spectra inside libmispec.so — left visible, the dynamic
+// linker would merge same-named template instantiations of the two libraries when both are loaded into one process.
+#pragma GCC visibility push(default)
 extern "C" {
 
 const char* ref_last_error() { return g_err.c_str(); }
@@ -482,3 +486,4 @@ double ref_symeigs_time(const RefOp* op, long nev, long ncv, long maxit, double 
 }
 
 }  // extern "C"
+#pragma GCC visibility pop
