@@ -50,7 +50,8 @@ def parse():
     p.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     p.add_argument("--profile-level", type=int, default=2, choices=[1, 2],
                     help="HIP-event instrumentation of the timed solves: 2 = operator applications only (default), 1 = every kernel family")
-    p.add_argument("--cpu-steps", type=int, default=20, help="Lanczos steps of the CPU sample (about 10 s of one host core at n = 1e7)")
+    p.add_argument("--cpu-steps", type=int, default=0, help="> 0: quick CPU sample of that many Lanczos steps instead of the default (first sweep + restart cycles)")
+    p.add_argument("--cpu-cycles", type=int, default=1, help="restart cycles of the CPU sample after the first sweep (SURVEY.md 8d; about 25 s each at n = 1e7)")
     p.add_argument("--spmv-reps", type=int, default=50, help="stand-alone SpMV launches timed after the solves")
     p.add_argument("--orth", default=ORTH_DEFAULT, choices=["reference", "onesweep", "onesweep-eager"],
                    help="orthogonalisation of the Lanczos steps in the timed region (include/mispec.h mispec_fac_set_orth_mode); the other "
@@ -73,29 +74,47 @@ def respawn_as_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
-def cpu_baseline(args, gpu_nops, gpu_nconv):
-    """The oracle (a 'port': Eigen is absent, see oracle/spectra_oracle.hpp) on the host, 1 thread."""
+def cpu_baseline(args, gpu_nops, gpu_nconv, gpu_niter):
+    """The oracle (a 'port': Eigen is absent, see oracle/spectra_oracle.hpp — pinned bit for bit to the reference's own headers by
+    tests/test_ref_pin.py) on the host, 1 thread.  SURVEY.md 8(d)'s sample: init() + factorize_from(1, ncv) (the first sweep),
+    then --cpu-cycles measured restart cycles of the IRLM driver (shifts, compress_V, factorize_from(k, ncv)); a complete solve
+    is the first sweep plus as many cycles as the solve makes, so the estimate is
+        first sweep + (operations of the GPU run - operations of the first sweep) x seconds per operation of the measured cycles."""
     import oracle as O
 
     t0 = time.time()
     rp, ci, v = O.synth_band_csr(args.n)
     op = O.Op.csr(args.n, args.n, rp, ci, v)
     t_gen = time.time() - t0
-    secs, nops = O.time_lanczos_steps(op, args.ncv, args.cpu_steps)
+    if args.cpu_steps > 0:  # quick variant for tests and hand runs: the first few steps only (cheap steps: few basis columns)
+        secs, nops = O.time_lanczos_steps(op, args.ncv, args.cpu_steps)
+        t_first, ops_first, t_cyc, ops_cyc, ncyc = secs, nops, 0.0, 0, 0
+        per_op = secs / nops
+        est_total = per_op * gpu_nops
+        sample = (f"QUICK SAMPLE (--cpu-steps): oracle init() + {args.cpu_steps} Lanczos steps at n={args.n} ({nops} perform_op, "
+                  f"{secs:.1f} s); early steps orthogonalise against few columns, so this flatters the CPU")
+    else:
+        t_first, ops_first, t_cyc, ops_cyc, ncyc = O.time_restart_cycles(op, args.nev, args.ncv, getattr(O, args.selection), args.tol, args.cpu_cycles)
+        per_op = t_cyc / ops_cyc if ops_cyc else t_first / ops_first
+        est_total = t_first + max(0, gpu_nops - ops_first) * per_op
+        sample = (f"oracle init() + factorize_from(1, {args.ncv}) ({ops_first} perform_op, {t_first:.1f} s) + {ncyc} restart cycle(s) "
+                  f"(shifted QR, compress_V, factorize_from(k, {args.ncv}): {ops_cyc} perform_op, {t_cyc:.1f} s = {per_op:.3f} s/op in "
+                  f"steady state) at n={args.n}; complete solve estimated as first sweep + ({gpu_nops} - {ops_first}) x {per_op:.3f} s "
+                  f"= {est_total:.0f} s; matrix generation {t_gen:.1f} s not timed")
     x = O.simple_random(args.n, 0)
     t_spmv = op.time_op(x, 3)
-    per_op = secs / nops
-    est_total = per_op * gpu_nops
     out = {
         "value": gpu_nconv / est_total,
         "unit": "eigenpairs/s",
         "cores": 1,
         "kind": "port",
-        "sample": (f"oracle init() + {args.cpu_steps} Lanczos steps at n={args.n} ({nops} perform_op, {secs:.1f} s, "
-                   f"{per_op:.3f} s/op incl. re-orthogonalisation; matrix generation {t_gen:.1f} s not timed), "
-                   f"extrapolated to the GPU run's {gpu_nops} operations — early steps orthogonalise against few "
-                   f"columns, so this favours the CPU"),
-        "seconds_per_op": per_op,
+        "sample": sample,
+        "seconds_first_sweep": t_first,
+        "operations_first_sweep": ops_first,
+        "seconds_restart_cycles": t_cyc,
+        "operations_restart_cycles": ops_cyc,
+        "seconds_per_op_steady_state": per_op,
+        "estimated_seconds_per_solve": est_total,
         "spmv_seconds": t_spmv,
         "spmv_gbps": (12.0 * len(v) + 20.0 * args.n + 4) / t_spmv / 1e9,
     }
@@ -104,9 +123,15 @@ def cpu_baseline(args, gpu_nops, gpu_nconv):
         with open(os.path.join(ROOT, "tests", "golden", "full_size_c2.json")) as f:
             g = json.load(f)
         if g["n"] == args.n and g["nev"] == args.nev and g["ncv"] == args.ncv:
-            out["complete_solve_on_build_host"] = {"seconds": g["oracle_seconds_one_thread"], "num_operations": g["num_operations"],
-                                                   "eigenpairs_per_s": g["nconv"] / g["oracle_seconds_one_thread"],
-                                                   "note": "not this box: recorded when the golden file was generated"}
+            ratio = g["oracle_seconds_one_thread"] / est_total
+            out["complete_solve_on_build_host"] = {
+                "seconds": g["oracle_seconds_one_thread"], "num_operations": g["num_operations"],
+                "eigenpairs_per_s": g["nconv"] / g["oracle_seconds_one_thread"],
+                "ratio_to_this_estimate": ratio,
+                "note": ("not this box: recorded when the golden file was generated, on the build container's host (a shared "
+                         "machine whose one core sustains a fraction of this box's memory bandwidth); the same code, the same "
+                         f"{g['num_operations']} operations — the ratio is the two hosts' per-core streaming rate, compare "
+                         "spmv_gbps here with the build host's figure in tests/golden/full_size_c2.json if recorded")}
     except Exception:  # noqa: BLE001 - informational only
         pass
     return out
@@ -611,7 +636,7 @@ def main():
             except Exception as e:  # noqa: BLE001 - the headline line must still be printed
                 out["secondary"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, int(eigs.num_operations()), int(total_pairs // args.steps))
+            out["cpu_baseline"] = cpu_baseline(args, int(eigs.num_operations()), int(total_pairs // args.steps), int(eigs.num_iterations()))
         print(json.dumps(out), flush=True)
     if using_dist:
         dist.barrier()

@@ -100,6 +100,7 @@ def lib():
             "oracle_symeigs_eigenvalues": (C.c_long, [vp, dp]),
             "oracle_symeigs_eigenvectors": (C.c_long, [vp, C.c_long, dp]),
             "oracle_symeigs_time_steps": (C.c_double, [vp, C.c_long, C.c_long, lp]),
+            "oracle_symeigs_time_cycles": (C.c_int, [vp, C.c_long, C.c_long, C.c_int, C.c_double, C.c_long, dp]),
             "oracle_hess_qr": (C.c_int, [C.c_long, dp, C.c_double, dp, dp]),
             "oracle_double_shift_qr": (C.c_int, [C.c_long, dp, C.c_double, C.c_double, dp, dp]),
             "oracle_hess_schur": (C.c_int, [C.c_long, dp, dp, dp]),
@@ -632,6 +633,14 @@ class GenEigsSolver:
             lib().oracle_geneigs_free(self.h)
         except Exception:
             pass
+
+
+def time_restart_cycles(op, nev, ncv, selection=LargestMagn, tol=1e-10, cycles=1):
+    """cpu_baseline helper: init() + factorize_from(1, ncv), then `cycles` restart cycles of the IRLM driver.
+    Returns (seconds of the first sweep, its perform_op count, seconds of the cycles, their perform_op count, cycles run)."""
+    out = np.zeros(5)
+    _check(lib().oracle_symeigs_time_cycles(op.h, nev, ncv, selection, tol, cycles, _dp(out)))
+    return float(out[0]), int(out[1]), float(out[2]), int(out[3]), int(out[4])
 
 
 def time_lanczos_steps(op, ncv, nsteps):

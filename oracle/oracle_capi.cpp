@@ -496,6 +496,38 @@ double oracle_symeigs_time_steps(void* op, long ncv, long nsteps, long* nops_out
 }
 
 
+// The sample SURVEY.md 8(d) prescribes for the CPU baseline: init() + factorize_from(1, ncv) [the first sweep], then `cycles`
+// restart cycles of the IRLM driver (HermEigsBase.h:366-390: num_converged, nev_adjusted, restart = shifts + compress_V +
+// factorize_from(k, ncv)).  out = {seconds of the first sweep, its perform_op count, seconds of the restart cycles,
+// their perform_op count, number of cycles run (fewer if the solve converged first)}.
+int oracle_symeigs_time_cycles(void* op, long nev, long ncv, int selection, double tol, long cycles, double* out)
+{
+    return guarded([&] {
+        Op& O = *static_cast<Op*>(op);
+        SymEigs s(O, nev, ncv);
+        const auto t0 = std::chrono::steady_clock::now();
+        s.init();
+        s.fac.factorize_from_lanczos(1, ncv, s.nmatop);
+        s.retrieve_ritzpair(static_cast<SortRule>(selection));
+        const auto t1 = std::chrono::steady_clock::now();
+        const Index ops_first = s.nmatop;
+        long done = 0;
+        for (; done < cycles; done++)
+        {
+            const Index nconv = s.num_converged(tol);
+            if (nconv >= nev)
+                break;
+            s.restart(s.nev_adjusted(nconv), static_cast<SortRule>(selection));
+        }
+        const auto t2 = std::chrono::steady_clock::now();
+        out[0] = std::chrono::duration<double>(t1 - t0).count();
+        out[1] = double(ops_first);
+        out[2] = std::chrono::duration<double>(t2 - t1).count();
+        out[3] = double(s.nmatop - ops_first);
+        out[4] = double(done);
+    });
+}
+
 // ---- general (non-symmetric) path: LinAlg/UpperHessenbergQR.h, DoubleShiftQR.h, UpperHessenbergSchur.h,
 // ---- UpperHessenbergEigen.h, GenEigsBase.h ------------------------------------------------------------
 int oracle_hess_qr(long n, const double* Hm, double shift, double* Q, double* QtHQ)

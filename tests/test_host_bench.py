@@ -42,3 +42,26 @@ def test_pmc_traffic_lookup_finds_every_instantiation():
     # ... and for the post-scaled instantiation the one-sweep steps run on diagonal storage (bench.py's timed mode)
     traffic, src = bench.pmc_traffic(10_000_000, 2, post_scaled=True)
     assert traffic is not None and 1.4e9 < traffic < 1.7e9, (traffic, src)
+
+
+def test_cpu_baseline_is_the_first_sweep_plus_measured_restart_cycles():
+    # init + factorize_from(1, ncv) + restart cycles, extrapolated by the steady-state cycle — checked at a size
+    # where the oracle's complete solve takes a second: the estimate must be within 2x of the solve it stands for
+    import time
+
+    import bench
+    import oracle as O
+
+    class A:
+        n, nev, ncv, tol, selection, cpu_steps, cpu_cycles = 40_000, 20, 40, 1e-11, "LargestMagn", 0, 2
+
+    rp, ci, v = O.synth_band_csr(A.n)
+    s = O.SymEigsSolver(O.Op.csr(A.n, A.n, rp, ci, v), A.nev, A.ncv)
+    t0 = time.perf_counter()
+    s.init()
+    nconv = s.compute(O.LargestMagn, 1000, A.tol)
+    full = time.perf_counter() - t0
+    out = bench.cpu_baseline(A(), s.num_operations(), nconv, s.num_iterations())
+    assert out["kind"] == "port" and out["cores"] == 1 and out["operations_first_sweep"] == A.ncv + 1
+    assert out["operations_restart_cycles"] > 0 and "restart cycle" in out["sample"]
+    assert 0.5 < out["estimated_seconds_per_solve"] / full < 2.0, (out["estimated_seconds_per_solve"], full)
