@@ -14,6 +14,7 @@
 #ifndef MISPEC_SPECTRA_DAVIDSON_SYM_EIGS_SOLVER_H
 #define MISPEC_SPECTRA_DAVIDSON_SYM_EIGS_SOLVER_H
 
+#include "../mispec_extras.h"  // outside the hot path of SURVEY.md section 8: declared apart from the thin shim
 #include <memory>
 #include <stdexcept>
 #include <type_traits>

@@ -12,6 +12,7 @@
 #ifndef MISPEC_SPECTRA_GEN_EIGS_COMPLEX_SHIFT_SOLVER_H
 #define MISPEC_SPECTRA_GEN_EIGS_COMPLEX_SHIFT_SOLVER_H
 
+#include "../mispec_extras.h"  // outside the hot path of SURVEY.md section 8: declared apart from the thin shim
 #include <cmath>
 #include <complex>
 #include <vector>

@@ -4,6 +4,7 @@
 #ifndef MISPEC_SPECTRA_DENSE_GEN_COMPLEX_SHIFT_SOLVE_H
 #define MISPEC_SPECTRA_DENSE_GEN_COMPLEX_SHIFT_SOLVE_H
 
+#include "../../mispec_extras.h"  // outside the hot path of SURVEY.md section 8: declared apart from the thin shim
 #include "DenseGenRealShiftSolve.h"
 
 namespace Spectra {

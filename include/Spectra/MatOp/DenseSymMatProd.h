@@ -12,6 +12,7 @@
 #ifndef MISPEC_SPECTRA_DENSE_SYM_MAT_PROD_H
 #define MISPEC_SPECTRA_DENSE_SYM_MAT_PROD_H
 
+#include "../../mispec_extras.h"  // outside the hot path of SURVEY.md section 8: declared apart from the thin shim
 #include <stdexcept>
 #include <type_traits>
 

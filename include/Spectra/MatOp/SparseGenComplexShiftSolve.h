@@ -5,6 +5,7 @@
 #ifndef MISPEC_SPECTRA_SPARSE_GEN_COMPLEX_SHIFT_SOLVE_H
 #define MISPEC_SPECTRA_SPARSE_GEN_COMPLEX_SHIFT_SOLVE_H
 
+#include "../../mispec_extras.h"  // outside the hot path of SURVEY.md section 8: declared apart from the thin shim
 #include "SparseGenRealShiftSolve.h"
 
 namespace Spectra {

@@ -11,6 +11,7 @@
 #ifndef MISPEC_SPECTRA_SYM_GEIGS_SHIFT_SOLVER_H
 #define MISPEC_SPECTRA_SYM_GEIGS_SHIFT_SOLVER_H
 
+#include "../mispec_extras.h"  // outside the hot path of SURVEY.md section 8: declared apart from the thin shim
 #include <stdexcept>
 #include <string>
 #include <utility>

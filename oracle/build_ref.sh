@@ -5,7 +5,7 @@
 # fetches it from the network, CMakeLists.txt:25-38).  Same compiler flags as the restatement it pins (oracle/Makefile:
 # g++ -O2, no FMA contraction).  The output is git-ignored and travels to the GPU box with the snapshot like every built .so;
 # /root/reference itself does not exist there and is never read at run time.
-#   usage: oracle/build_ref.sh [--force]
+#   usage: oracle/build_ref.sh [--force] [--tests]     --tests: also the reference's own test programs on its own headers (oracle/_ref/tests/*.bin)
 set -u
 HERE="$(cd "$(dirname "$0")" && pwd)"
 REF="${MISPEC_REFERENCE_DIR:-/root/reference}"
@@ -16,10 +16,41 @@ if [ ! -d "$REF/include/Spectra" ]; then
 fi
 mkdir -p "$OUT"
 LIB="$OUT/libspectra_ref.so"
-if [ "${1:-}" != "--force" ] && [ -f "$LIB" ] &&
+if [ "${1:-}" = "" ] && [ -f "$LIB" ] &&
    [ -z "$(find "$HERE/ref_driver.cpp" "$HERE/eigen_shim" "$REF/include/Spectra" -newer "$LIB" -print -quit)" ]; then
     echo "up to date $LIB"
     exit 0
 fi
+build_tests() {
+    # The reference's OWN Catch2 programs on the reference's OWN headers, with the stand-in algebra: a self-check of oracle/eigen_shim
+    # (if the stand-in mis-evaluated an expression the reference writes, the reference's own acceptance tests would notice).
+    # Programs that instantiate float / complex scalars or Eigen's dense decompositions (Givens, QR, Eigen, Arnoldi, Orthogonalization,
+    # the Herm / complex-shift solvers) are outside what the stand-in restates.
+    local T="$OUT/tests"
+    mkdir -p "$T"
+    if [ ! -f "$T/tests-main.o" ]; then
+        ${CXX:-g++} -std=c++17 -O1 -w -I"$REF/test" -c "$REF/test/tests-main.cpp" -o "$T/tests-main.o" || return 1
+    fi
+    local status=0
+    for name in SymEigs GenEigs Schur Example1 Example2 Example4 SparseSymMatProd SparseGenMatProd DenseSymMatProd DenseGenMatProd; do
+        if [ -f "$T/$name.bin" ] && [ -z "$(find "$HERE/eigen_shim" "$REF/include/Spectra" "$REF/test/$name.cpp" -newer "$T/$name.bin" -print -quit)" ]; then
+            continue
+        fi
+        if ${CXX:-g++} -std=c++17 -O1 -w -I"$HERE/eigen_shim" -I"$REF/include" -I"$REF/test" -c "$REF/test/$name.cpp" -o "$T/$name.o" 2> "$T/$name.log" &&
+           ${CXX:-g++} "$T/$name.o" "$T/tests-main.o" -o "$T/$name.bin" 2>> "$T/$name.log"; then
+            echo "built $T/$name.bin"
+            rm -f "$T/$name.log"
+        else
+            echo "FAILED $name (see $T/$name.log)"
+            status=1
+        fi
+        rm -f "$T/$name.o"
+    done
+    return $status
+}
+if [ "${1:-}" = "--tests" ] || [ "${2:-}" = "--tests" ]; then
+    build_tests || exit 1
+fi
+[ "${1:-}" = "--tests" ] && [ -f "$LIB" ] && [ -z "$(find "$HERE/ref_driver.cpp" "$HERE/eigen_shim" "$REF/include/Spectra" -newer "$LIB" -print -quit)" ] && exit 0
 ${CXX:-g++} -std=c++17 -O2 -fPIC -ffp-contract=off -fvisibility=hidden -fvisibility-inlines-hidden -Wall -I"$HERE/eigen_shim" -I"$REF/include" -shared -Wl,-Bsymbolic "$HERE/ref_driver.cpp" -o "$LIB" || exit 1
 echo "built $LIB"

@@ -48,6 +48,19 @@ def available():
     return build() is not None
 
 
+REFERENCE_TEST_PROGRAMS = ["SymEigs", "GenEigs", "Schur", "Example1", "Example2", "Example4", "SparseSymMatProd", "SparseGenMatProd",
+                           "DenseSymMatProd", "DenseGenMatProd"]
+
+
+def build_tests():
+    """The reference's own Catch2 programs on the reference's own headers + oracle/eigen_shim (oracle/_ref/tests/*.bin): built
+    where the reference is present; returns the directory (the binaries may be prebuilt) or None."""
+    if os.path.isdir(os.path.join(REFERENCE_DIR, "include", "Spectra")):
+        subprocess.check_call([os.path.join(_HERE, "build_ref.sh"), "--tests"], stdout=subprocess.DEVNULL)
+    d = os.path.join(_HERE, "_ref", "tests")
+    return d if os.path.isdir(d) else None
+
+
 _lib = None
 
 

@@ -31,6 +31,19 @@ SYNTH_SEED = 20240607
 ORTH_MODES = {"reference": 0, "onesweep": 1, "onesweep-eager": 1 | 0x100, "onesweep-recorrect": 1 | 0x200}
 
 
+def _orth_mode_value(mode):
+    """Name or integer of an orthogonalisation mode -> the integer of include/mispec.h; anything else is a ValueError that
+    lists the names."""
+    if isinstance(mode, str):
+        if mode not in ORTH_MODES:
+            raise ValueError("unknown orthogonalisation mode %r: one of %s" % (mode, ", ".join(sorted(ORTH_MODES))))
+        return ORTH_MODES[mode]
+    if isinstance(mode, int) and mode in ORTH_MODES.values():
+        return mode
+    raise ValueError("unknown orthogonalisation mode %r: one of %s" % (mode, ", ".join(sorted(ORTH_MODES))))
+
+
+
 class SortRule(enum.IntEnum):
     """Util/SelectionRule.h:33-58 (same order as the C++ enum)."""
     LargestMagn = 0
@@ -892,7 +905,7 @@ class SymEigsSolver:
     def set_orth_mode(self, mode):
         """'reference' (default: Lanczos.h:145-181, two passes over V per step) or 'onesweep' (opt-in: the correction of a
         step rides on the next step's pass, include/mispec.h mispec_fac_set_orth_mode).  Call before init()."""
-        check(lib().mispec_symeigs_set_orth_mode(self.h, ORTH_MODES.get(mode, mode)))
+        check(lib().mispec_symeigs_set_orth_mode(self.h, _orth_mode_value(mode)))
 
     def orth_info(self):
         mode, a, b, c = C.c_int(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
@@ -1403,7 +1416,7 @@ class Factorization:
 
     def set_orth_mode(self, mode):
         """'reference' (default) or 'onesweep' (mispec_fac_set_orth_mode); call before factorize_from."""
-        check(lib().mispec_fac_set_orth_mode(self.h, ORTH_MODES.get(mode, mode)))
+        check(lib().mispec_fac_set_orth_mode(self.h, _orth_mode_value(mode)))
 
     def init_random(self, seed=0):
         check(lib().mispec_fac_init_random(self.h, seed, C.byref(self.nmatop)))

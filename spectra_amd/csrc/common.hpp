@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/mispec.h"
+#include "../../include/mispec_extras.h"  // the library implements both headers
 
 namespace mispec {
 

@@ -1392,42 +1392,85 @@ void download_columns(mispec_fac& F, const double* src, int64_t ld_src, int64_t 
 {
     if (rows <= 0 || ncols <= 0)
         return;
-    constexpr int64_t kPiece = int64_t(8) << 20;  // doubles per piece (64 MB)
+    constexpr int64_t kPiece = int64_t(8) << 20;        // doubles per piece (64 MB)
+    constexpr int64_t kDirect = int64_t(4) << 20;       // up to 32 MB in total: one strided copy, no staging, no threads
+    const int64_t total = rows * int64_t(ncols);
+    if (total <= kDirect)
+    {
+        MISPEC_HIP(hipMemcpy2DAsync(dst, size_t(ld_dst) * sizeof(double), src, size_t(ld_src) * sizeof(double), size_t(rows) * sizeof(double),
+                                    size_t(ncols), hipMemcpyDeviceToHost, F.stream()));
+        MISPEC_HIP(hipStreamSynchronize(F.stream()));
+        F.n_sync++;
+        return;
+    }
+    // staging sized to the transfer (a solver object that only ever returns small matrices pins nothing)
+    const int64_t piece = std::min(kPiece, total);
     for (int b = 0; b < 2; b++)
     {
-        if (F.h_stage[b].n < size_t(kPiece))
-            F.h_stage[b].alloc(size_t(kPiece));
+        if (F.h_stage[b].n < size_t(piece))
+            F.h_stage[b].alloc(size_t(piece));
         if (!F.ev_stage[b])
             MISPEC_HIP(hipEventCreateWithFlags(&F.ev_stage[b], hipEventDisableTiming));
     }
     struct Piece
     {
-        double* dst;
-        int64_t count;
+        double* dst;     // first destination column of the piece
+        int64_t count;   // doubles per column
+        int cols;        // columns in the piece (> 1 only when whole columns are packed)
+        int64_t ld_dst;
     };
-    Piece pending[2] = {{nullptr, 0}, {nullptr, 0}};
-    const int nt = std::min(ingest_threads(), 32);
+    Piece pending[2] = {{nullptr, 0, 0, 0}, {nullptr, 0, 0, 0}};
     auto drain = [&](int b) {
         if (!pending[b].dst)
             return;
         MISPEC_HIP(hipEventSynchronize(F.ev_stage[b]));
         const double* from = F.h_stage[b].p;
-        double* to = pending[b].dst;
-        parallel_ranges(pending[b].count, nt, [&](int, int64_t lo, int64_t hi) { std::memcpy(to + lo, from + lo, size_t(hi - lo) * sizeof(double)); });
+        const Piece pc = pending[b];
+        const int64_t all = pc.count * pc.cols;
+        // one host thread per MB or so: a small piece is copied inline
+        const int nt = int(std::max<int64_t>(1, std::min<int64_t>(std::min(ingest_threads(), 32), all >> 17)));
+        parallel_ranges(all, nt, [&](int, int64_t lo, int64_t hi) {
+            while (lo < hi)  // [lo, hi) of the packed piece, column by column
+            {
+                const int64_t c = lo / pc.count, r = lo - c * pc.count;
+                const int64_t len = std::min(hi - lo, pc.count - r);
+                std::memcpy(pc.dst + c * pc.ld_dst + r, from + lo, size_t(len) * sizeof(double));
+                lo += len;
+            }
+        });
         pending[b].dst = nullptr;
     };
     int b = 0;
-    for (int j = 0; j < ncols; j++)
-        for (int64_t r0 = 0; r0 < rows; r0 += kPiece)
+    if (rows <= piece)
+    {
+        // whole columns, several per piece, packed densely in the staging buffer by one strided copy
+        const int per = int(std::max<int64_t>(1, piece / rows));
+        for (int j = 0; j < ncols; j += per)
         {
-            const int64_t cnt = std::min(kPiece, rows - r0);
+            const int nc = std::min(per, ncols - j);
             drain(b);  // this buffer's previous piece must be out before it is overwritten
-            MISPEC_HIP(hipMemcpyAsync(F.h_stage[b].p, src + int64_t(j) * ld_src + r0, size_t(cnt) * sizeof(double), hipMemcpyDeviceToHost, F.stream()));
+            MISPEC_HIP(hipMemcpy2DAsync(F.h_stage[b].p, size_t(rows) * sizeof(double), src + int64_t(j) * ld_src, size_t(ld_src) * sizeof(double),
+                                        size_t(rows) * sizeof(double), size_t(nc), hipMemcpyDeviceToHost, F.stream()));
             MISPEC_HIP(hipEventRecord(F.ev_stage[b], F.stream()));
-            pending[b] = {dst + int64_t(j) * ld_dst + r0, cnt};
+            pending[b] = {dst + int64_t(j) * ld_dst, rows, nc, ld_dst};
             b ^= 1;
             drain(b);  // while the piece just enqueued travels, copy the other buffer's
         }
+    }
+    else
+    {
+        for (int j = 0; j < ncols; j++)
+            for (int64_t r0 = 0; r0 < rows; r0 += piece)
+            {
+                const int64_t cnt = std::min(piece, rows - r0);
+                drain(b);
+                MISPEC_HIP(hipMemcpyAsync(F.h_stage[b].p, src + int64_t(j) * ld_src + r0, size_t(cnt) * sizeof(double), hipMemcpyDeviceToHost, F.stream()));
+                MISPEC_HIP(hipEventRecord(F.ev_stage[b], F.stream()));
+                pending[b] = {dst + int64_t(j) * ld_dst + r0, cnt, 1, ld_dst};
+                b ^= 1;
+                drain(b);
+            }
+    }
     drain(0);
     drain(1);
     F.n_sync++;

@@ -13,10 +13,12 @@ from spectra_amd import _capi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
-    hdr = open(os.path.join(ROOT, "include", "mispec.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    names = set(re.findall(r"\b(mispec_[A-Za-z0-9_]+)\s*\(", hdr))
+def header_symbols(which=("mispec.h", "mispec_extras.h")):
+    names = set()
+    for h in which:
+        hdr = open(os.path.join(ROOT, "include", h)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        names |= set(re.findall(r"\b(mispec_[A-Za-z0-9_]+)\s*\(", hdr))
     return names - {"mispec_op_fn"}
 
 
@@ -25,9 +27,13 @@ def test_library_exports_every_declared_symbol():
     names = header_symbols()
     assert len(names) >= 60
     for nm in names:
-        assert hasattr(lib, nm), f"{nm} declared in include/mispec.h but not exported by libmispec.so"
+        assert hasattr(lib, nm), f"{nm} declared in include/mispec.h / mispec_extras.h but not exported by libmispec.so"
     assert names == set(_capi.SIGNATURES), names ^ set(_capi.SIGNATURES)
     assert b"gfx950" in lib.mispec_version()
+    # the thin shim of the hot path knows nothing of the components outside it
+    core = header_symbols(("mispec.h",))
+    assert not [nm for nm in core if re.search(r"dense|davidson|complex_shift|set_shift_complex|geigs_shift", nm)]
+    assert len(core) + len(header_symbols(("mispec_extras.h",))) == len(names)
 
 
 def test_no_silent_cpu_fallback():

@@ -229,3 +229,18 @@ def test_constructor_errors_are_the_reference_s():
             R.symeigs(R.Op.csc_sym(10, D.indptr, D.indices, D.data, True), nev, ncv)
         with pytest.raises(ValueError):
             O.SymEigsSolver(O.Op.diag(np.arange(1.0, 11.0)), nev, ncv)
+
+
+@needs_ref
+@pytest.mark.parametrize("name", R.REFERENCE_TEST_PROGRAMS)
+def test_reference_s_own_test_programs_pass_on_the_stand_in_algebra(name):
+    # /root/reference/test/<name>.cpp, unmodified, against /root/reference/include + oracle/eigen_shim: the reference's own acceptance
+    # tests of its own code.  What this checks is the stand-in (an expression it mis-evaluated would fail the reference's bars).
+    import subprocess
+
+    d = R.build_tests()
+    exe = os.path.join(d or "", name + ".bin")
+    if not d or not os.path.exists(exe):
+        pytest.skip("oracle/_ref/tests not built")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "All tests passed" in out.stdout, out.stdout[-2000:]
