@@ -286,8 +286,9 @@ public:
     // mispec_fac_residuals() / profiling through the C ABI.
     const LanczosFac& factorization() const { return m_fac; }
 
-    // Device-side extra (no counterpart in the reference): opt in to the one-sweep orthogonalisation of the Lanczos steps
-    // (include/mispec.h mispec_fac_set_orth_mode).  Off by default = the reference's control flow.  Call before init().
+    // Device-side extra (no counterpart in the reference): the one-sweep orthogonalisation of the Lanczos steps
+    // (include/mispec.h mispec_fac_set_orth_mode) is the default; false selects the reference's two-pass control flow
+    // (also: MISPEC_ORTH=reference in the environment).  Call before init().
     void set_onesweep_orthogonalization(bool on)
     {
         internal::check(mispec_fac_set_orth_mode(m_fac.handle(), on ? MISPEC_ORTH_ONESWEEP : MISPEC_ORTH_REFERENCE));

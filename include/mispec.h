@@ -302,9 +302,10 @@ int mispec_fac_factorize(mispec_fac* fac, int from_k, int to_m, int64_t* nmatop)
 int mispec_fac_subspace_dim(const mispec_fac* fac);          /* subspace_dim() */
 int mispec_fac_f_norm(const mispec_fac* fac, double* beta);  /* f_norm() */
 /* Orthogonalisation scheme of the symmetric (Lanczos) steps of a device-matrix factorisation.
- *   MISPEC_ORTH_REFERENCE (default): the reference's control flow, Lanczos.h:145-181 — V'f, then f -= V c with |f| and the
- *     V'f check: two passes over V per step.
- *   MISPEC_ORTH_ONESWEEP (opt-in; also MISPEC_ORTH=onesweep in the environment): the operator is applied to the not yet
+ *   MISPEC_ORTH_REFERENCE (also MISPEC_ORTH=reference in the environment, which sets the default of every factorisation
+ *     created afterwards): the reference's control flow, Lanczos.h:145-181 — V'f, then f -= V c with |f| and the V'f check:
+ *     two passes over V per step.
+ *   MISPEC_ORTH_ONESWEEP (the default since round 4: every parity gate holds in both modes): the operator is applied to the not yet
  *     corrected vector and the correction rides on the next step's pass — ONE pass over V per step.  Same decisions and the
  *     same fixed points (H follows from the Lanczos relation of the previous step), different rounding;
  *     every case the reference treats specially (second correction, breakdown clamp, tiny beta, restart heuristics) leaves
@@ -438,8 +439,8 @@ int mispec_symeigs_get_profile(const mispec_symeigs* s, mispec_profile* out);
 int mispec_symeigs_exchange_info(const mispec_symeigs* s, int* halo, int64_t* recv_doubles); /* see mispec_fac_exchange_info */
 int mispec_symeigs_overlap_info(const mispec_symeigs* s, int* first_block, int* block_count, int* total_blocks);
 int mispec_symeigs_profile(mispec_symeigs* s, int enable);
-/* Orthogonalisation scheme of the Lanczos steps (see mispec_fac_set_orth_mode): MISPEC_ORTH_REFERENCE (default) or the
- * opt-in MISPEC_ORTH_ONESWEEP.  Call before init() / compute(). */
+/* Orthogonalisation scheme of the Lanczos steps (see mispec_fac_set_orth_mode): MISPEC_ORTH_ONESWEEP (default) or
+ * MISPEC_ORTH_REFERENCE, the reference's two-pass control flow.  Call before init() / compute(). */
 int mispec_symeigs_set_orth_mode(mispec_symeigs* s, int mode);
 int mispec_symeigs_orth_info(const mispec_symeigs* s, int* mode, int64_t* lagged_steps, int64_t* check_stops,
                              int64_t* state_stops, double* max_rel_c, double* max_chk);

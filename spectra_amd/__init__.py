@@ -903,8 +903,10 @@ class SymEigsSolver:
         return p.as_dict()
 
     def set_orth_mode(self, mode):
-        """'reference' (default: Lanczos.h:145-181, two passes over V per step) or 'onesweep' (opt-in: the correction of a
-        step rides on the next step's pass, include/mispec.h mispec_fac_set_orth_mode).  Call before init()."""
+        """'onesweep' (default: the correction of a step rides on the next step's pass over V, include/mispec.h
+        mispec_fac_set_orth_mode) or 'reference' (Lanczos.h:145-181, two passes over V per step; also MISPEC_ORTH=reference in
+        the environment).  Call before init().  Where the one-sweep steps do not apply (ncv > 64, generalized problems, user
+        operators) the reference flow runs whatever is set: orth_info()['mode'] says which one is in effect."""
         check(lib().mispec_symeigs_set_orth_mode(self.h, _orth_mode_value(mode)))
 
     def orth_info(self):
@@ -913,7 +915,8 @@ class SymEigsSolver:
         check(lib().mispec_symeigs_orth_info(self.h, C.byref(mode), C.byref(a), C.byref(b), C.byref(c), C.byref(r), C.byref(k)))
         fused, again = C.c_int64(0), C.c_int64(0)
         check(lib().mispec_symeigs_restart_info(self.h, C.byref(fused), C.byref(again)))
-        return {"mode": "onesweep" if mode.value else "reference", "lagged_steps": a.value, "check_stops": b.value,
+        return {"mode": "onesweep" if (mode.value & 0xFF) else "reference", "eager_last": bool(mode.value & 0x100),
+                "recorrect_hook": bool(mode.value & 0x200), "lagged_steps": a.value, "check_stops": b.value,
                 "state_stops": c.value, "max_rel_c": r.value, "max_chk": k.value, "fused_restarts": fused.value,
                 "fused_recorrected": again.value}
 
@@ -1415,7 +1418,7 @@ class Factorization:
         check(lib().mispec_fac_init(self.h, _dp(v0), C.byref(self.nmatop)))
 
     def set_orth_mode(self, mode):
-        """'reference' (default) or 'onesweep' (mispec_fac_set_orth_mode); call before factorize_from."""
+        """'onesweep' (default) or 'reference' (mispec_fac_set_orth_mode); call before factorize_from."""
         check(lib().mispec_fac_set_orth_mode(self.h, _orth_mode_value(mode)))
 
     def init_random(self, seed=0):

@@ -92,9 +92,10 @@ struct mispec_fac
     PinnedBuf<double> h_stage[2];  // pinned staging of download_columns (allocated on first use)
     hipEvent_t ev_stage[2] = {nullptr, nullptr};
     bool device_steps = true;      // MISPEC_HOST_STEPS=1 forces the host-synchronous path
-    // Opt-in one-sweep variant of the Lanczos steps (mispec_fac_set_orth_mode / MISPEC_ORTH=onesweep): the
-    // correction of a step rides on the next step's pass over V.  Default off = the reference's control flow.
-    bool onesweep = false;
+    // One-sweep variant of the Lanczos steps: the correction of a step rides on the next step's pass over V.
+    // On by default since round 4 (set at creation from MISPEC_ORTH, default "onesweep"); mispec_fac_set_orth_mode /
+    // MISPEC_ORTH=reference select the reference's two-pass control flow.
+    bool onesweep = true;
     double lag_limit = 1e-6;
     int64_t lag_steps = 0, lag_check_stops = 0, lag_state_stops = 0;
     double lag_rel_c_max = 0.0, lag_chk_max = 0.0;
@@ -123,6 +124,9 @@ struct mispec_fac
     // needs f calls finish_pending first.
     bool end_pending = false;
     bool eager_last = false, test_recorrect = false;  // MISPEC_ORTH_EAGER_LAST / MISPEC_ORTH_TEST_RECORRECT
+    // set when a fused restart's test (Lanczos.h:156 on the corrected residual) failed or came within a factor of two of its bar:
+    // the remaining sweeps of this solve apply their last correction before the restart, the reference's order (cleared by init)
+    bool eager_sticky = false;
     int end_rec = 0;
     int64_t fused_restarts = 0, fused_recorrected = 0;
     int x_cols = 0;    // columns currently held in X
@@ -775,6 +779,7 @@ void zero_vector(mispec_fac& F, double* v)
 void init_from_tmp(mispec_fac& F, int64_t* nmatop)
 {
     F.end_pending = false;
+    F.eager_sticky = false;
     std::fill(F.H.begin(), F.H.end(), 0.0);
     MISPEC_HIP(hipMemsetAsync(F.V.p, 0, F.V.n * sizeof(double), F.stream()));
     zero_vector(F, F.f.p);
@@ -1082,7 +1087,7 @@ void factorize_lanczos(mispec_fac& F, int from_k, int to_m, int64_t* nmatop)
     const bool fast = F.device_steps && F.A != nullptr && !F.bmode() && F.Chol == nullptr;
     const bool lagged = fast && F.onesweep && F.m <= kPanelCols && !F.A2;  // standard problems, one column panel
     // a sweep that completes the factorisation is followed by a restart (or by nothing that needs f): its last correction can wait
-    const bool defer = lagged && to_m == F.m && !F.eager_last && !small_on_device();
+    const bool defer = lagged && to_m == F.m && !F.eager_last && !F.eager_sticky && !small_on_device();
     F.end_pending = false;
     int i = from_k;
     while (i <= to_m - 1)
@@ -1612,7 +1617,16 @@ int fac_create_impl(mispec_ctx* ctx, const mispec_csr* A, const mispec_symshift*
             }
             F->h_state.alloc(1);
             F->device_steps = !(getenv("MISPEC_HOST_STEPS") && atoi(getenv("MISPEC_HOST_STEPS")) != 0);
-            F->onesweep = getenv("MISPEC_ORTH") && std::string(getenv("MISPEC_ORTH")) == "onesweep";
+            {
+                // default since round 4: the one-sweep steps (every gate of tests/test_gpu_onesweep.py and the reference's own test
+                // programs hold in both modes); MISPEC_ORTH=reference restores the reference's two-pass control flow everywhere
+                const char* o = getenv("MISPEC_ORTH");
+                const std::string mode = o ? o : "onesweep";
+                MISPEC_REQUIRE(mode == "onesweep" || mode == "reference" || mode == "onesweep-eager",
+                               "MISPEC_ORTH: expected reference, onesweep or onesweep-eager");
+                F->onesweep = mode != "reference";
+                F->eager_last = mode == "onesweep-eager";
+            }
             F->h_red.alloc(kPartialLd + 8);
             F->h_small.alloc(size_t(ncv) * ncv + 4 * size_t(ncv) + 8);
             if (op)
@@ -1817,7 +1831,9 @@ extern "C" int mispec_fac_orth_info(const mispec_fac* fac, int* mode, int64_t* l
         const bool active = fac->onesweep && fac->device_steps && fac->symmetric && fac->A && !fac->A2 && !fac->bmode() && !fac->Chol &&
                             fac->m <= kPanelCols;
         if (mode)
-            *mode = active ? MISPEC_ORTH_ONESWEEP : MISPEC_ORTH_REFERENCE;
+            *mode = active ? (MISPEC_ORTH_ONESWEEP | ((fac->eager_last || fac->eager_sticky) ? MISPEC_ORTH_EAGER_LAST : 0) |
+                              (fac->test_recorrect ? MISPEC_ORTH_TEST_RECORRECT : 0))
+                           : MISPEC_ORTH_REFERENCE;
         if (lagged_steps)
             *lagged_steps = fac->lag_steps;
         if (check_stops)
@@ -2090,6 +2106,8 @@ extern "C" int mispec_fac_restart_sym(mispec_fac* fac, const double* shifts_host
                 const double beta_corr = F.h_red.p[kSlotBeta];
                 F.lag_chk_max = std::max(F.lag_chk_max, beta_corr > 0.0 ? err / beta_corr : 0.0);
                 test_failed = err > kEps * beta_corr;  // Lanczos.h:156 with count = 1
+                if (!F.test_recorrect && err > 0.5 * kEps * beta_corr)
+                    F.eager_sticky = true;  // the Ritz values of this restart were computed before the correction: do not repeat that
                 F.fused_restarts++;
                 F.f.swap(F.tmp);
                 F.beta = std::sqrt(F.h_red.p[m]);  // Arnoldi.h:339

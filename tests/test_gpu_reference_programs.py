@@ -15,6 +15,17 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(params=["onesweep", "reference"], autouse=True)
+def orth_env(request, monkeypatch):
+    """Every test of this module runs under both defaults of the orthogonalisation scheme (MISPEC_ORTH: the library default
+    `onesweep` and the reference's two-pass control flow); solvers that set a mode themselves are run once."""
+    params = getattr(getattr(request.node, "callspec", None), "params", {})
+    if "orth" in params and request.param == "reference":
+        pytest.skip("this test selects its modes itself")
+    monkeypatch.setenv("MISPEC_ORTH", request.param)
+    return request.param
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "tests", "cpp", "_ref")
 PROGRAMS = ["SymEigs", "SymEigsShift", "GenEigs", "GenEigsRealShift", "GenEigsComplexShift", "SymGEigsCholesky", "SymGEigsRegInv",

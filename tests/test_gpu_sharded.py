@@ -15,7 +15,18 @@ from spectra_amd import _capi
 pytestmark = pytest.mark.gpu
 
 
-def run_sharded(world, n, offsets, nev, ncv, rule, tol, exchange=None, orth="reference", keep_vectors=True, profile=False):
+@pytest.fixture(params=["onesweep", "reference"], autouse=True)
+def orth_env(request, monkeypatch):
+    """Every test of this module runs under both defaults of the orthogonalisation scheme (MISPEC_ORTH: the library default
+    `onesweep` and the reference's two-pass control flow); solvers that set a mode themselves are run once."""
+    params = getattr(getattr(request.node, "callspec", None), "params", {})
+    if "orth" in params and request.param == "reference":
+        pytest.skip("this test selects its modes itself")
+    monkeypatch.setenv("MISPEC_ORTH", request.param)
+    return request.param
+
+
+def run_sharded(world, n, offsets, nev, ncv, rule, tol, exchange=None, orth=None, keep_vectors=True, profile=False):
     import os
 
     lib = sa.lib()
@@ -34,7 +45,8 @@ def run_sharded(world, n, offsets, nev, ncv, rule, tol, exchange=None, orth="ref
             op = sa.SparseSymMatProd.synth_band(n, offsets=offsets, ctx=ctx) if offsets is not None else \
                 sa.SparseSymMatProd.synth_band(n, ctx=ctx)
             eigs = sa.SymEigsSolver(op, nev, ncv)
-            eigs.set_orth_mode(orth)
+            if orth is not None:  # None: the library default / MISPEC_ORTH
+                eigs.set_orth_mode(orth)
             if profile:
                 eigs.profile(1)
             eigs.init()

@@ -11,6 +11,17 @@ from helpers import RULES_SYM, cycle_laplacian, sparse_fixture
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(params=["onesweep", "reference"], autouse=True)
+def orth_env(request, monkeypatch):
+    """Every test of this module runs under both defaults of the orthogonalisation scheme (MISPEC_ORTH: the library default
+    `onesweep` and the reference's two-pass control flow); solvers that set a mode themselves are run once."""
+    params = getattr(getattr(request.node, "callspec", None), "params", {})
+    if "orth" in params and request.param == "reference":
+        pytest.skip("this test selects its modes itself")
+    monkeypatch.setenv("MISPEC_ORTH", request.param)
+    return request.param
+
 SHIFT_CASES = [(10, 0.5, 3, 6, 1.0), (100, 0.1, 10, 20, 10.0), (1000, 0.01, 20, 50, 100.0)]  # test/SymEigsShift.cpp:148-185
 
 

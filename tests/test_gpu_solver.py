@@ -218,7 +218,8 @@ def test_device_driven_steps_equal_host_driven_steps():
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for host in ("0", "1"):
-        env = dict(os.environ, MISPEC_HOST_STEPS=host)
+        # the host-synchronous path IS the reference's control flow: compare it with the device-driven reference flow
+        env = dict(os.environ, MISPEC_HOST_STEPS=host, MISPEC_ORTH="reference")
         r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
         outs.append(r.stdout.split())
