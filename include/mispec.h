@@ -170,10 +170,15 @@ int mispec_csr_permutation(const mispec_csr* A, int32_t* perm_out);
 /* What the tile format of this matrix looks like (segments = 0: not built): stored entries incl. padding, padding entries,
  * chunks (runs of <= 1024 entries of one tile, the unit between two barriers of the kernel). */
 int mispec_csr_tiles_info(const mispec_csr* A, int64_t* segments, int64_t* entries, int64_t* padding, int64_t* chunks);
+/* What the staged format of this matrix looks like (format 4: the product in two streaming kernels with x and y in LDS, built
+ * for the same patterns as the tiles): row bins of 8192 rows (0: not built), phase-1 slots (stored entries + the padding of the
+ * 8192-column blocks to even counts), batches (<= 1024 entries of one bin, the unit of phase 2) and the chunks they are made of
+ * (runs that are contiguous in phase-1 order). */
+int mispec_csr_staged_info(const mispec_csr* A, int64_t* bins, int64_t* slots, int64_t* batches, int64_t* chunks);
 /* Wall-clock seconds of the host stages of the last mispec_csr_upload / mispec_csr_from_triangle on the calling thread:
  * [0] the whole call, [1] triangle -> full matrix, [2] validation + local row pointers, [3] index formats (offset codes, diagonal
  * storage) incl. the H2D copies of the CSR arrays, [4] far-gather statistics + reordering, [5] tile image on the host, [6] its
- * upload and split.  count <= 8 values are written. */
+ * upload and split, [8] staged image on the host, [9] its upload.  count <= 10 values are written. */
 int mispec_last_ingest_info(double* seconds_out, int count);
 int mispec_ingest_threads(void); /* host threads the ingest stages use: the machine's hardware threads, at most 64 */
 /* Host-only test hook (no device needed): the full symmetric CSR matrix (rows sorted by column) that mispec_csr_from_triangle

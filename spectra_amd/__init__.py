@@ -95,10 +95,13 @@ def tiles_spmv_host(mat, x):
 
 def last_ingest_info():
     """Seconds the host stages of the last matrix ingest on this thread took (mispec_last_ingest_info)."""
-    out = np.zeros(8)
-    check(lib().mispec_last_ingest_info(_dp(out), 7))
-    keys = ("total", "mirror_triangle", "validate", "index_formats_and_h2d", "far_statistics_and_reordering", "tiles_build", "tiles_upload")
-    return dict(zip(keys, out[:7].tolist()))
+    out = np.zeros(10)
+    check(lib().mispec_last_ingest_info(_dp(out), 10))
+    keys = ("total", "mirror_triangle", "validate", "index_formats_and_h2d", "far_statistics_and_reordering", "tiles_build", "tiles_upload",
+            "unused", "staged_build", "staged_upload")
+    d = dict(zip(keys, out.tolist()))
+    d.pop("unused")
+    return d
 
 
 def mirror_triangle_host(mat, uplo="L"):
@@ -276,6 +279,12 @@ class _DeviceMatrix:
     def stored_bytes(self):
         """Compulsory SpMV traffic with the index format in use (9 instead of 12 bytes per entry with offset codes)."""
         return float(lib().mispec_csr_spmv_bytes(self.h, 1))
+
+    def staged_info(self):
+        """{bins, slots, batches, chunks} of the staged format (two streaming phases with x and y in LDS; bins = 0: not built)."""
+        a, b, c, d = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(lib().mispec_csr_staged_info(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return {"bins": a.value, "slots": b.value, "batches": c.value, "chunks": d.value}
 
     def tiles_info(self):
         """{segments, entries, padding, chunks} of the column-blocked tile format (segments = 0: not built)."""

@@ -97,6 +97,7 @@ SIGNATURES = {
     "mispec_symshift_destroy": (C.c_int, [_vp]),
     "mispec_symshift_rows": (C.c_int64, [_vp]),
     "mispec_csr_tiles_info": (C.c_int, [_vp, _lp, _lp, _lp, _lp]),
+    "mispec_csr_staged_info": (C.c_int, [_vp, _lp, _lp, _lp, _lp]),
     "mispec_csr_reorder": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     "mispec_csr_reordering": (C.c_int, [_vp, _dp, _dp]),
     "mispec_csr_permutation": (C.c_int, [_vp, _ip]),

@@ -825,7 +825,7 @@ bool build_offset_codes(int64_t b, int64_t e, const int32_t* rowptr, const int32
 // Wall-clock seconds of the host stages of the last ingest on this thread (mispec_last_ingest_info): [0] the whole library call,
 // [1] triangle -> full matrix, [2] validation + local row pointers, [3] index formats (offset codes, diagonal storage) incl. the
 // H2D copies of the CSR arrays, [4] far-gather statistics + reordering, [5] tile image on the host, [6] its upload and split.
-thread_local double g_ingest[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+thread_local double g_ingest[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 struct IngestTimer
 {
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
@@ -942,6 +942,23 @@ mispec_csr* upload_rows(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const i
                     upload_tiles(H, ctx->stream, A->tiles);
                 }
             }
+            // MISPEC_SPMV_STAGED = 0 | 1 | auto: the two-phase format with x and y in LDS (staged.hip), for the same patterns
+            const char* smode = getenv("MISPEC_SPMV_STAGED");
+            const bool st_off = smode && std::strcmp(smode, "0") == 0, st_force = smode && std::strcmp(smode, "1") == 0;
+            if (!st_off && (st_force || (n_cols >= 2 * kFarWindow && far > 0.25)))
+            {
+                HostStaged H;
+                bool built;
+                {
+                    IngestTimer timer(8);
+                    built = build_staged(n_rows, n_cols, rowptr, colind, val, H);
+                }
+                if (built)
+                {
+                    IngestTimer timer(9);
+                    upload_staged(H, ctx->stream, A->staged);
+                }
+            }
         }
     }
     catch (...)
@@ -987,6 +1004,7 @@ bool reorder_matrix(mispec_csr& A, const int32_t* rowptr, const int32_t* colind,
     std::swap(A.ndia, B->ndia);
     std::swap(A.dia_win, B->dia_win);
     A.tiles.swap(B->tiles);
+    A.staged.swap(B->staged);
     A.nnz = B->nnz;
     A.perm.alloc(size_t(n));
     MISPEC_HIP(hipMemcpy(A.perm.p, perm.data(), size_t(n) * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -1163,6 +1181,12 @@ void launch_spmv_raw(const mispec_csr& A, const double* x_dev, double* y_dev, co
     const int format = A.spmv_format();
     const bool coded = format == 1;
     const SpmvCodes cd{A.codes.p, A.dict.p, A.ndict, int(A.n_cols - 1), A.row_begin};
+    if (format == 4)
+    {
+        MISPEC_REQUIRE(block_count == all_blocks, "SpMV: the staged format does not take row-block sub-ranges");
+        launch_spmv_staged(A.staged, A.ctx->stream, x_dev, y_dev, nloc, A.n_cols, all_blocks, epi, ev_start, ev_stop);
+        return;
+    }
     if (format == 3)
     {
         MISPEC_REQUIRE(block_count == all_blocks, "SpMV: the tile format does not take row-block sub-ranges");
@@ -1343,7 +1367,7 @@ extern "C" int mispec_csr_upload(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols
     return guarded([&] {
         MISPEC_REQUIRE(ctx && out && rowptr_host, "mispec_csr_upload: NULL argument");
         MISPEC_REQUIRE((colind_host && val_host) || rowptr_host[n_rows] == 0, "mispec_csr_upload: NULL arrays");
-        std::fill(g_ingest, g_ingest + 8, 0.0);
+        std::fill(g_ingest, g_ingest + 10, 0.0);
         IngestTimer total(0);
         *out = upload_rows(ctx, n_rows, n_cols, rowptr_host, colind_host, val_host);
     });
@@ -1354,7 +1378,7 @@ extern "C" int mispec_ingest_threads(void) { return mispec::ingest_threads(); }
 extern "C" int mispec_last_ingest_info(double* seconds_out, int count)
 {
     return guarded([&] {
-        MISPEC_REQUIRE(seconds_out && count >= 1 && count <= 8, "mispec_last_ingest_info: bad argument");
+        MISPEC_REQUIRE(seconds_out && count >= 1 && count <= 10, "mispec_last_ingest_info: bad argument");
         for (int i = 0; i < count; i++)
             seconds_out[i] = g_ingest[i];
     });
@@ -1574,7 +1598,7 @@ extern "C" int mispec_csr_from_triangle(mispec_ctx* ctx, int64_t n, const int32_
         MISPEC_REQUIRE(ctx && out && outer, "mispec_csr_from_triangle: NULL argument");
         MISPEC_REQUIRE(uplo == 'L' || uplo == 'U' || uplo == 'l' || uplo == 'u', "mispec_csr_from_triangle: uplo must be 'L' or 'U'");
         const bool lower = (uplo == 'L' || uplo == 'l');
-        std::fill(g_ingest, g_ingest + 8, 0.0);
+        std::fill(g_ingest, g_ingest + 10, 0.0);
         IngestTimer total(0);
         MirroredCsr M;
         {
@@ -1668,12 +1692,17 @@ int mispec_csr::spmv_format() const
     const bool can_codes = ndict > 0 && blocks256;
     const bool can_dia = ndia > 0 && blocks256;
     const bool can_tiles = tiles.present() && blocks256;
+    const bool can_staged = staged.present() && blocks256;
+    if (forced_format == 4)
+        return can_staged ? 4 : (can_tiles ? 3 : 0);
     if (forced_format == 3)
         return can_tiles ? 3 : 0;
     if (forced_format == 0)
         return 0;
+    if (forced_format == -1 && can_staged)
+        return 4;  // built only when the pattern asked for it; measured faster than the tiles
     if (forced_format == -1 && can_tiles)
-        return 3;  // built only when the pattern asked for it
+        return 3;
     if (!use_codes)
         return 0;
     if (forced_format == 1)
@@ -1691,7 +1720,7 @@ extern "C" int mispec_csr_spmv_format(const mispec_csr* A) { return A ? A->spmv_
 extern "C" int mispec_csr_set_spmv_format(mispec_csr* A, int format)
 {
     return guarded([&] {
-        MISPEC_REQUIRE(A && format >= -1 && format <= 3, "mispec_csr_set_spmv_format: format must be -1 (automatic), 0, 1, 2 or 3");
+        MISPEC_REQUIRE(A && format >= -1 && format <= 4, "mispec_csr_set_spmv_format: format must be -1 (automatic), 0, 1, 2, 3 or 4");
         A->forced_format = format;
     });
 }
@@ -1707,6 +1736,21 @@ extern "C" double mispec_csr_spmv_bytes(const mispec_csr* A, int stored)
     if (!A)
         return 0.0;
     return stored ? A->stored_bytes() : A->algorithmic_bytes();
+}
+
+extern "C" int mispec_csr_staged_info(const mispec_csr* A, int64_t* bins, int64_t* slots, int64_t* batches, int64_t* chunks)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(A, "mispec_csr_staged_info: NULL argument");
+        if (bins)
+            *bins = A->staged.nbins;
+        if (slots)
+            *slots = A->staged.slots;
+        if (batches)
+            *batches = A->staged.nbatches;
+        if (chunks)
+            *chunks = A->staged.nchunks;
+    });
 }
 
 extern "C" int mispec_csr_tiles_info(const mispec_csr* A, int64_t* segments, int64_t* entries, int64_t* padding, int64_t* chunks)

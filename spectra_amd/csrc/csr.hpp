@@ -4,6 +4,7 @@
 
 #include "common.hpp"
 #include "tiles.hpp"
+#include "staged.hpp"
 
 // x windows of the diagonal format: the offsets of a matrix cluster (here: ±1..3, ±1000/1001, ±100000/100001), and a
 // 256-row block needs, per cluster, one contiguous piece of x of 256 + span entries.  Staged through LDS once per block.
@@ -43,10 +44,13 @@ struct mispec_csr
     int64_t dia_ld = 0;
     int ndia = 0;
     mispec_dia_windows dia_win;
-    int forced_format = -1;          // mispec_csr_set_spmv_format: -1 automatic, 0 int32 indices, 1 offset codes, 2 diagonals, 3 tiles
+    int forced_format = -1;          // mispec_csr_set_spmv_format: -1 automatic, 0 int32 indices, 1 offset codes, 2 diagonals, 3 tiles, 4 staged
     // Column-blocked tiles (fourth format, tiles.hip): built at ingest for matrices whose gathers are scattered over the
     // whole of x and that reordering does not localise; bit-identical products again.
     mispec::DevTiles tiles;
+    // Staged format (fifth, staged.hip): the product in two streaming phases with x and y in LDS; built at ingest next to (and
+    // preferred over) the tiles when MISPEC_SPMV_STAGED allows; bit-identical products again.
+    mispec::DevStaged staged;
     // Symmetric reordering (reorder.hip): when perm is set, the arrays above hold B = P A P', B(i, j) = A(perm[i], perm[j]).
     // The public products (mispec_spmv*, operator(), downloads) keep the ORIGINAL index order (gather x, product, scatter
     // y); the eigensolvers work in the permuted order and un-permute what they return.  Unsharded square matrices only.
@@ -73,6 +77,8 @@ struct mispec_csr
     {
         if (format == 2)
             return 8.0 * double(ndia) * double(local_rows()) + 8.0 * double(n_cols) + 8.0 * double(local_rows());
+        if (format == 4)  // both phases: values, indices, the product array's round trip, tables; x counted once like everywhere
+            return staged.stored_bytes(local_rows(), n_cols);
         if (format == 3)  // 12 bytes per stored entry (padding included) + the chunk table; x counted once like everywhere
             return 12.0 * double(tiles.entries) + 8.0 * double(tiles.nchunks) + 12.0 * double(tiles.nseg) + 8.0 * double(n_cols) +
                    8.0 * double(local_rows());

@@ -1,0 +1,504 @@
+// The "staged" SpMV format for scattered patterns (staged.hpp): y = A x in two streaming kernels with x and y in LDS.
+// Replaces, for such matrices, the product of SparseSymMatProd / SparseGenMatProd::perform_op (MatOp/SparseSymMatProd.h:83-88,
+// SparseGenMatProd.h:82-87); same results as every other format of this library and as the oracle's CSR row sum, bit for bit.
+//
+// Why two phases.  A one-phase kernel has to gather x (or scatter into y) through the memory hierarchy once per entry, and for
+// uniformly scattered columns that costs an L1 miss each: the device sustains about 110 G such gathers per second, 1.3-1.4 ms for
+// 1.5e8 entries, whatever the rest of the kernel does.  LDS serves random 8-byte reads an order of magnitude
+// faster, but only from 64 KiB windows: so phase 1 walks the entries column block by column block (x window in LDS, products
+// written back as a stream) and phase 2 walks them row bin by row bin (y window in LDS, products read as short contiguous runs).
+// The price is the product array's round trip: 28 bytes per entry instead of 12.
+#include "staged.hpp"
+
+#include "csr.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace mispec {
+
+namespace {
+
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double st_wave_sum(double v)  // the reduction tree of the CSR kernels' records
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// ---- phase 1: products, column block by column block ------------------------------------------------------------------------------
+__global__ __launch_bounds__(kStThreads) void k_staged_products(const StPiece* __restrict__ pieces, const double* __restrict__ val,
+                                                                 const uint16_t* __restrict__ lcol, const double* __restrict__ x,
+                                                                 double* __restrict__ prod, int64_t ncols, const int* status)
+{
+    __shared__ double xs[kStCols];  // 64 KiB: two workgroups per CU
+    if (status && *status != 0)
+        return;
+    const StPiece pc = pieces[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int64_t c0 = int64_t(pc.colblock) << kStColBits;
+#pragma unroll
+    for (int k = 0; k < kStCols / kStThreads; k++)
+    {
+        const int64_t col = c0 + k * kStThreads + tid;
+        xs[k * kStThreads + tid] = (col < ncols) ? x[col] : 0.0;
+    }
+    __syncthreads();
+    // two entries per thread and step (16-byte value loads, 4-byte index loads, 16-byte product stores), four steps in flight
+    constexpr int64_t kStep = 2 * kStThreads;
+    int64_t i = pc.begin + 2 * tid;
+    for (; i + 3 * kStep < pc.end; i += 4 * kStep)
+    {
+        v2d a[4];
+        uint32_t c[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        {
+            a[u] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(val + i + u * kStep));
+            c[u] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(lcol + i + u * kStep));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        {
+            v2d p;
+            p.x = a[u].x * xs[c[u] & 0xFFFFu];
+            p.y = a[u].y * xs[c[u] >> 16];
+            __builtin_nontemporal_store(p, reinterpret_cast<v2d*>(prod + i + u * kStep));
+        }
+    }
+    for (; i < pc.end; i += kStep)
+    {
+        const v2d a = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(val + i));
+        const uint32_t c = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(lcol + i));
+        v2d p;
+        p.x = a.x * xs[c & 0xFFFFu];
+        p.y = a.y * xs[c >> 16];
+        __builtin_nontemporal_store(p, reinterpret_cast<v2d*>(prod + i));
+    }
+}
+
+// ---- phase 2: row sums, bin by bin ------------------------------------------------------------------------------------------------
+struct StLoad  // what a thread holds of one batch
+{
+    double p;
+    uint32_t rr;  // row | rank << kStRowBits, or 0xFFFFFFFF: no entry
+};
+
+template <bool EPI>
+__global__ __launch_bounds__(kStThreads) void k_staged_rows(const int32_t* __restrict__ bin_batch, const StBatch* __restrict__ batches,
+                                                             const uint32_t* __restrict__ chunk_pos, const uint16_t* __restrict__ chunk_off,
+                                                             const uint16_t* __restrict__ rowrank, const double* __restrict__ prod,
+                                                             double* __restrict__ y, int64_t nrows, int nblocks256, SpmvEpilogue epi)
+{
+    __shared__ double acc[kStRows];                // 64 KiB: two workgroups per CU
+    __shared__ uint32_t cpos[3][kStMaxChunks];     // chunk tables of three consecutive batches
+    __shared__ uint16_t coff[3][kStMaxChunks + 1];
+    if (EPI && epi.status && *epi.status != 0)
+        return;
+    const int tid = threadIdx.x;
+    const int bin = int(blockIdx.x);
+#pragma unroll
+    for (int k = 0; k < kStRows / kStThreads; k++)
+        acc[k * kStThreads + tid] = 0.0;
+    const int b0 = bin_batch[bin], b1 = bin_batch[bin + 1];
+
+    // chunk table of batch b -> buffer b % 3 (the first nchunks threads); visible after the next barrier
+    auto stage_table = [&](int b) {
+        if (b < b1)
+        {
+            const StBatch bb = batches[b];
+            if (tid < int(bb.nchunks))
+            {
+                cpos[b % 3][tid] = chunk_pos[bb.chunk0 + tid];
+                coff[b % 3][tid] = chunk_off[bb.chunk0 + tid];
+            }
+            if (tid == int(bb.nchunks))
+                coff[b % 3][tid] = bb.count;
+        }
+    };
+    // this thread's entry of batch b, from the table in buffer b % 3
+    auto fetch = [&](int b) {
+        StLoad L;
+        L.p = 0.0;
+        L.rr = 0xFFFFFFFFu;
+        if (b < b1)
+        {
+            const StBatch bb = batches[b];
+            if (tid < int(bb.count))
+            {
+                const uint16_t* off = coff[b % 3];
+                int lo = 0, hi = int(bb.nchunks) - 1;  // the chunk g with off[g] <= tid < off[g + 1]
+                while (lo < hi)
+                {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (int(off[mid]) <= tid)
+                        lo = mid;
+                    else
+                        hi = mid - 1;
+                }
+                L.p = __builtin_nontemporal_load(prod + (int64_t(cpos[b % 3][lo]) + (tid - int(off[lo]))));
+                L.rr = uint32_t(__builtin_nontemporal_load(rowrank + bb.first + tid));
+            }
+        }
+        return L;
+    };
+
+    stage_table(b0);
+    stage_table(b0 + 1);
+    __syncthreads();  // accumulators zeroed, first two tables staged
+    StLoad cur = fetch(b0);
+    for (int b = b0; b < b1; b++)
+    {
+        stage_table(b + 2);               // buffer (b + 2) % 3 was last read by fetch(b - 1), a barrier ago
+        const StLoad nxt = fetch(b + 1);  // its table became visible with the last barrier of the previous iteration
+        const int rounds = int(batches[b].maxrank) + 1;
+        const int row = int(cur.rr & uint32_t(kStRows - 1));
+        const int rank = int(cur.rr >> kStRowBits);  // >= 8 for "no entry"
+        for (int r = 0; r < rounds; r++)
+        {
+            if (rank == r)
+            {
+#pragma clang fp contract(off)
+                acc[row] = acc[row] + cur.p;  // entries of one rank address distinct rows
+            }
+            __syncthreads();
+        }
+        cur = nxt;
+    }
+    if (b0 == b1)
+        __syncthreads();
+
+    // rows of the bin -> y, in the 256-row records of the CSR kernels (identical alpha partials)
+    const int64_t row0 = int64_t(bin) << kStRowBits;
+#pragma unroll 1
+    for (int j = 0; j < kStRows / kStThreads; j++)
+    {
+        const int64_t row = row0 + j * kStThreads + tid;
+        const int64_t blk = (row0 >> 8) + j * (kStThreads / 256) + (tid >> 8);
+        double contrib = 0.0;
+        if (row < nrows)
+        {
+            double yv = acc[j * kStThreads + tid];
+            if (EPI)
+            {
+                if (epi.v_prev)
+                    yv -= (epi.h_prev_dev ? *epi.h_prev_dev : epi.h_prev) * epi.v_prev[row];  // Lanczos.h:139
+                contrib = epi.v_rows[row] * yv;                                                 // Lanczos.h:142
+            }
+            y[row] = yv;
+        }
+        if (EPI)
+        {
+            const double t = st_wave_sum(contrib);
+            __syncthreads();  // every thread has read its accumulator of this round
+            double* red = acc + j * kStThreads;
+            if ((tid & 63) == 0)
+                red[tid >> 6] = t;
+            __syncthreads();
+            if ((tid & 255) == 0 && blk < nblocks256)
+            {
+                const double* q = red + (tid >> 6);
+                epi.partials[blk] = (q[0] + q[1]) + (q[2] + q[3]);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// ---- host image ---------------------------------------------------------------------------------------------------------------------
+bool build_staged(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* colind, const double* val, HostStaged& out)
+{
+    const int64_t nnz = int64_t(rowptr[nrows]) - rowptr[0];
+    const int64_t ncb = (ncols + kStCols - 1) >> kStColBits, nbins = (nrows + kStRows - 1) >> kStRowBits;
+    if (nnz <= 0 || nnz + ncb >= (int64_t(1) << 32) - 2)
+        return false;
+    const int64_t p00 = rowptr[0];
+    const int nt = int(std::max<int64_t>(1, std::min<int64_t>(ingest_threads(), nnz / (1 << 20))));
+    // rows per thread: contiguous ranges; per-thread histograms over the column blocks; rows must be sorted by column
+    std::vector<std::vector<int64_t>> hist(static_cast<size_t>(nt), std::vector<int64_t>(static_cast<size_t>(ncb), 0));
+    std::vector<char> unsorted(static_cast<size_t>(nt), 0);
+    std::vector<int64_t> rb(static_cast<size_t>(nt) + 1);
+    for (int t = 0; t <= nt; t++)
+        rb[size_t(t)] = nrows * t / nt;
+    parallel_ranges(nt, nt, [&](int, int64_t tb, int64_t te) {
+        for (int64_t t = tb; t < te; t++)
+        {
+            std::vector<int64_t>& h = hist[size_t(t)];
+            char bad = 0;
+            for (int64_t i = rb[size_t(t)]; i < rb[size_t(t) + 1]; i++)
+                for (int64_t p = rowptr[i]; p < rowptr[i + 1]; p++)
+                {
+                    h[size_t(colind[p] >> kStColBits)]++;
+                    bad |= char(p > rowptr[i] && colind[p] <= colind[p - 1]);
+                }
+            unsorted[size_t(t)] = bad;
+        }
+    });
+    for (int t = 0; t < nt; t++)
+        if (unsorted[size_t(t)])
+            return false;  // the row sums would not follow the storage order
+    // column-block segments (padded to an even number of slots) and each thread's first slot inside every segment
+    std::vector<int64_t> cb_ptr(static_cast<size_t>(ncb) + 1, 0);
+    for (int64_t c = 0; c < ncb; c++)
+    {
+        int64_t tot = 0;
+        for (int t = 0; t < nt; t++)
+        {
+            const int64_t h = hist[size_t(t)][size_t(c)];
+            hist[size_t(t)][size_t(c)] = cb_ptr[size_t(c)] + tot;  // becomes the thread's write cursor
+            tot += h;
+        }
+        cb_ptr[size_t(c) + 1] = cb_ptr[size_t(c)] + ((tot + 1) & ~int64_t(1));
+    }
+    const int64_t slots = cb_ptr[size_t(ncb)];
+    out.nrows = nrows;
+    out.ncols = ncols;
+    out.nnz = nnz;
+    out.slots = slots;
+    out.nbins = nbins;
+    out.ncb = ncb;
+    out.val.resize_uninitialized(size_t(slots));
+    out.lcol.resize_uninitialized(size_t(slots));
+    RawVec<int32_t> grow;  // row of every slot (-1: padding); temporary
+    grow.resize_uninitialized(size_t(slots));
+    // padding slots (at most one per segment, the last one) first, the scatter overwrites nothing else
+    for (int64_t c = 0; c < ncb; c++)
+        if (cb_ptr[size_t(c) + 1] > cb_ptr[size_t(c)])
+        {
+            const int64_t last = cb_ptr[size_t(c) + 1] - 1;
+            out.val[size_t(last)] = 0.0;
+            out.lcol[size_t(last)] = 0;
+            grow[size_t(last)] = -1;
+        }
+    parallel_ranges(nt, nt, [&](int, int64_t tb, int64_t te) {
+        for (int64_t t = tb; t < te; t++)
+        {
+            std::vector<int64_t>& cur = hist[size_t(t)];
+            for (int64_t i = rb[size_t(t)]; i < rb[size_t(t) + 1]; i++)
+                for (int64_t p = rowptr[i]; p < rowptr[i + 1]; p++)
+                {
+                    const int32_t col = colind[p];
+                    const int64_t s = cur[size_t(col >> kStColBits)]++;
+                    out.val[size_t(s)] = val[p];
+                    out.lcol[size_t(s)] = uint16_t(col & (kStCols - 1));
+                    grow[size_t(s)] = int32_t(i);
+                }
+        }
+    });
+    // phase-1 work list
+    out.pieces.clear();
+    for (int64_t c = 0; c < ncb; c++)
+        for (int64_t b = cb_ptr[size_t(c)]; b < cb_ptr[size_t(c) + 1]; b += kStPiece)
+            out.pieces.push_back(StPiece{b, std::min(b + kStPiece, cb_ptr[size_t(c) + 1]), int32_t(c), 0});
+    // first slot of every (column block, bin) tile: rows ascend inside a segment
+    std::vector<uint32_t> tile(static_cast<size_t>(ncb) * size_t(nbins + 1));
+    parallel_ranges(ncb, nt, [&](int, int64_t cb0, int64_t cb1) {
+        for (int64_t c = cb0; c < cb1; c++)
+        {
+            uint32_t* T = tile.data() + size_t(c) * size_t(nbins + 1);
+            int64_t s = cb_ptr[size_t(c)];
+            const int64_t e = cb_ptr[size_t(c) + 1];
+            for (int64_t bin = 0; bin <= nbins; bin++)
+            {
+                const int64_t first_row = bin << kStRowBits;
+                while (s < e && grow[size_t(s)] >= 0 && grow[size_t(s)] < first_row)
+                    s++;
+                T[bin] = uint32_t(s);  // (a padding slot, row -1, ends the segment: s stops there for every later bin)
+            }
+        }
+    });
+    // phase 2, bin by bin: batches of <= kStBatch entries from consecutive column blocks, ranks inside the batch
+    out.rowrank.resize_uninitialized(size_t(nnz));
+    struct BinOut
+    {
+        std::vector<StBatch> batches;
+        std::vector<uint32_t> cpos;
+        std::vector<uint16_t> coff;
+    };
+    std::vector<BinOut> bins(static_cast<size_t>(nbins));
+    parallel_ranges(nbins, nt, [&](int, int64_t bin0, int64_t bin1) {
+        std::vector<uint16_t> seen(static_cast<size_t>(kStRows), 0);   // rank counter per row of the bin ...
+        std::vector<uint32_t> stamp(static_cast<size_t>(kStRows), 0);  // ... valid for the batch with this number
+        uint32_t batch_no = 0;
+        for (int64_t bin = bin0; bin < bin1; bin++)
+        {
+            BinOut& B = bins[size_t(bin)];
+            const int64_t first_row = bin << kStRowBits, last_row = std::min(nrows, first_row + kStRows);
+            int64_t w = int64_t(rowptr[first_row]) - p00;  // phase-2 order: the bin's entries start where its first row starts
+            const int64_t wend = int64_t(rowptr[last_row]) - p00;
+            StBatch cur{w, 0, 0, 0, 0, 0};
+            int64_t last_slot = -2;
+            auto close = [&]() {
+                if (cur.count)
+                    B.batches.push_back(cur);
+                cur = StBatch{w, int32_t(B.cpos.size()), 0, 0, 0, 0};
+                last_slot = -2;
+                batch_no++;
+            };
+            batch_no++;
+            for (int64_t c = 0; c < ncb; c++)
+            {
+                const uint32_t* T = tile.data() + size_t(c) * size_t(nbins + 1);
+                for (int64_t s = T[bin]; s < int64_t(T[bin + 1]); s++)
+                {
+                    const int r = int(grow[size_t(s)] - first_row);
+                    int rank = (stamp[size_t(r)] == batch_no) ? int(seen[size_t(r)]) : 0;
+                    const bool new_chunk = (s != last_slot + 1);
+                    if (cur.count == kStBatch || rank > kStMaxRank || (new_chunk && cur.nchunks == kStMaxChunks))
+                    {
+                        close();
+                        rank = 0;
+                    }
+                    if (s != last_slot + 1)
+                    {
+                        B.cpos.push_back(uint32_t(s));
+                        B.coff.push_back(cur.count);
+                        cur.nchunks++;
+                    }
+                    out.rowrank[size_t(w++)] = uint16_t(r | (rank << kStRowBits));
+                    stamp[size_t(r)] = batch_no;
+                    seen[size_t(r)] = uint16_t(rank + 1);
+                    cur.maxrank = std::max<uint16_t>(cur.maxrank, uint16_t(rank));
+                    cur.count++;
+                    last_slot = s;
+                }
+            }
+            close();
+            if (w != wend)
+                throw Error(MISPEC_ERUNTIME, "staged format: a bin's entries do not add up");
+        }
+    });
+    // concatenate
+    out.bin_batch.assign(static_cast<size_t>(nbins) + 1, 0);
+    out.batches.clear();
+    out.chunk_pos.clear();
+    out.chunk_cnt.clear();
+    for (int64_t bin = 0; bin < nbins; bin++)
+    {
+        BinOut& B = bins[size_t(bin)];
+        const int32_t chunk_base = int32_t(out.chunk_pos.size());
+        for (StBatch bb : B.batches)
+        {
+            bb.chunk0 += chunk_base;
+            out.batches.push_back(bb);
+        }
+        out.chunk_pos.insert(out.chunk_pos.end(), B.cpos.begin(), B.cpos.end());
+        out.chunk_cnt.insert(out.chunk_cnt.end(), B.coff.begin(), B.coff.end());
+        out.bin_batch[size_t(bin) + 1] = int32_t(out.batches.size());
+        BinOut().batches.swap(B.batches);
+    }
+    return true;
+}
+
+void staged_spmv_host(const HostStaged& S, const double* x, double* y)
+{
+    // phase 1
+    std::vector<double> prod(static_cast<size_t>(S.slots));
+    for (const StPiece& pc : S.pieces)
+    {
+        const int64_t c0 = int64_t(pc.colblock) << kStColBits;
+        for (int64_t s = pc.begin; s < pc.end; s++)
+        {
+            const int64_t col = c0 + S.lcol[size_t(s)];
+            prod[size_t(s)] = S.val[size_t(s)] * (col < S.ncols ? x[col] : 0.0);
+        }
+    }
+    // phase 2: batch after batch, rank after rank
+    std::vector<double> acc(static_cast<size_t>(kStRows));
+    for (int64_t bin = 0; bin < S.nbins; bin++)
+    {
+        std::fill(acc.begin(), acc.end(), 0.0);
+        for (int32_t b = S.bin_batch[size_t(bin)]; b < S.bin_batch[size_t(bin) + 1]; b++)
+        {
+            const StBatch& bb = S.batches[size_t(b)];
+            for (int r = 0; r <= int(bb.maxrank); r++)
+                for (int g = 0; g < int(bb.nchunks); g++)
+                {
+                    const int o0 = S.chunk_cnt[size_t(bb.chunk0 + g)];
+                    const int o1 = (g + 1 < int(bb.nchunks)) ? int(S.chunk_cnt[size_t(bb.chunk0 + g + 1)]) : int(bb.count);
+                    for (int t = o0; t < o1; t++)
+                    {
+                        const uint16_t rr = S.rowrank[size_t(bb.first + t)];
+                        if ((rr >> kStRowBits) == r)
+                            acc[size_t(rr & (kStRows - 1))] += prod[size_t(S.chunk_pos[size_t(bb.chunk0 + g)]) + size_t(t - o0)];
+                    }
+                }
+        }
+        const int64_t row0 = bin << kStRowBits;
+        for (int64_t r = 0; r < kStRows && row0 + r < S.nrows; r++)
+            y[row0 + r] = acc[size_t(r)];
+    }
+}
+
+// ---- device image ---------------------------------------------------------------------------------------------------------------------
+void DevStaged::swap(DevStaged& o)
+{
+    val.swap(o.val);
+    prod.swap(o.prod);
+    lcol.swap(o.lcol);
+    rowrank.swap(o.rowrank);
+    pieces.swap(o.pieces);
+    bin_batch.swap(o.bin_batch);
+    batches.swap(o.batches);
+    chunk_pos.swap(o.chunk_pos);
+    chunk_cnt.swap(o.chunk_cnt);
+    std::swap(nnz, o.nnz);
+    std::swap(slots, o.slots);
+    std::swap(nbins, o.nbins);
+    std::swap(ncb, o.ncb);
+    std::swap(npieces, o.npieces);
+    std::swap(nbatches, o.nbatches);
+    std::swap(nchunks, o.nchunks);
+}
+
+void upload_staged(const HostStaged& H, hipStream_t stream, DevStaged& D)
+{
+    auto up = [&](auto& dst, const auto* src, size_t count) {
+        dst.alloc(count);
+        if (count)
+            MISPEC_HIP(hipMemcpyAsync(dst.p, src, count * sizeof(*src), hipMemcpyHostToDevice, stream));
+    };
+    up(D.val, H.val.data(), H.val.size());
+    up(D.lcol, H.lcol.data(), H.lcol.size());
+    up(D.rowrank, H.rowrank.data(), H.rowrank.size());
+    up(D.pieces, H.pieces.data(), H.pieces.size());
+    up(D.bin_batch, H.bin_batch.data(), H.bin_batch.size());
+    up(D.batches, H.batches.data(), H.batches.size());
+    up(D.chunk_pos, H.chunk_pos.data(), H.chunk_pos.size());
+    up(D.chunk_cnt, H.chunk_cnt.data(), H.chunk_cnt.size());
+    D.prod.alloc(size_t(H.slots));
+    D.nnz = H.nnz;
+    D.slots = H.slots;
+    D.nbins = H.nbins;
+    D.ncb = H.ncb;
+    D.npieces = int64_t(H.pieces.size());
+    D.nbatches = int64_t(H.batches.size());
+    D.nchunks = int64_t(H.chunk_pos.size());
+    MISPEC_HIP(hipStreamSynchronize(stream));
+}
+
+void launch_spmv_staged(const DevStaged& S, hipStream_t stream, const double* x, double* y, int64_t nrows, int64_t ncols, int nblocks256,
+                        const SpmvEpilogue* epi, hipEvent_t ev_start, hipEvent_t ev_stop)
+{
+    const SpmvEpilogue e = epi ? *epi : SpmvEpilogue();
+    const int* status = epi ? epi->status : nullptr;
+    if (ev_start)
+        MISPEC_HIP(hipEventRecord(ev_start, stream));
+    hipLaunchKernelGGL(k_staged_products, dim3(unsigned(S.npieces)), dim3(kStThreads), 0, stream, S.pieces.p, S.val.p, S.lcol.p, x, S.prod.p,
+                       ncols, status);
+    if (epi)
+        hipLaunchKernelGGL((k_staged_rows<true>), dim3(unsigned(S.nbins)), dim3(kStThreads), 0, stream, S.bin_batch.p, S.batches.p, S.chunk_pos.p,
+                           S.chunk_cnt.p, S.rowrank.p, S.prod.p, y, nrows, nblocks256, e);
+    else
+        hipLaunchKernelGGL((k_staged_rows<false>), dim3(unsigned(S.nbins)), dim3(kStThreads), 0, stream, S.bin_batch.p, S.batches.p, S.chunk_pos.p,
+                           S.chunk_cnt.p, S.rowrank.p, S.prod.p, y, nrows, nblocks256, e);
+    if (ev_stop)
+        MISPEC_HIP(hipEventRecord(ev_stop, stream));
+    MISPEC_HIP(hipGetLastError());
+}
+
+}  // namespace mispec
