@@ -191,6 +191,11 @@ int mispec_mirror_triangle_host(int64_t n, const int32_t* outer, const int32_t* 
  * column blocks; a row with more than 7 entries inside one column block is emitted in several passes).  stats (optional): entries incl. padding, padding entries, chunks. */
 int mispec_tiles_spmv_host(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* colind, const double* val,
                            const double* x, double* y, int* built, int64_t* stats);
+/* The same for the staged format (format 4): y = A x through its host image in the order of the two kernels; *built = 0 when the
+ * format does not apply (unsorted rows, 2^32 stored entries or more).  stats (optional, 5 values): row bins, phase-1 slots,
+ * batches, chunks, the largest number of rank rounds a batch needs. */
+int mispec_staged_spmv_host(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* colind, const double* val,
+                            const double* x, double* y, int* built, int64_t* stats);
 /* The ordering alone, on host arrays (no device needed): perm_out[new] = old for the pattern of an n x n CSR matrix;
  * *gave_up = 1 (identity returned) when the first breadth-first level structure is too wide for any ordering to help. */
 int mispec_rcm_order(int64_t n, const int32_t* rowptr, const int32_t* colind, int symmetric_pattern, int32_t* perm_out,

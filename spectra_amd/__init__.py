@@ -93,6 +93,18 @@ def tiles_spmv_host(mat, x):
     return (y if built.value else None), {"entries": st[0], "padding": st[1], "chunks": st[2]}
 
 
+def staged_spmv_host(mat, x):
+    """y = A x through the HOST image of the staged format, in the order of its two kernels (mispec_staged_spmv_host; no device
+    needed).  mat: scipy CSR with sorted rows.  Returns (y or None when the format does not apply, stats dict)."""
+    rp, ci, v = _i32(mat.indptr), _i32(mat.indices), _f64(mat.data)
+    x = _f64(x)
+    y = np.zeros(mat.shape[0])
+    built = C.c_int(0)
+    st = (C.c_int64 * 5)()
+    check(lib().mispec_staged_spmv_host(mat.shape[0], mat.shape[1], _ip(rp), _ip(ci), _dp(v), _dp(x), _dp(y), C.byref(built), st))
+    return (y if built.value else None), {"bins": st[0], "slots": st[1], "batches": st[2], "chunks": st[3], "max_rounds": st[4]}
+
+
 def last_ingest_info():
     """Seconds the host stages of the last matrix ingest on this thread took (mispec_last_ingest_info)."""
     out = np.zeros(10)

@@ -101,6 +101,7 @@ SIGNATURES = {
     "mispec_csr_reorder": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     "mispec_csr_reordering": (C.c_int, [_vp, _dp, _dp]),
     "mispec_csr_permutation": (C.c_int, [_vp, _ip]),
+    "mispec_staged_spmv_host": (C.c_int, [C.c_int64, C.c_int64, _ip, _ip, _dp, _dp, _dp, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "mispec_tiles_spmv_host": (C.c_int, [C.c_int64, C.c_int64, _ip, _ip, _dp, _dp, _dp, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "mispec_rcm_order": (C.c_int, [C.c_int64, _ip, _ip, C.c_int, _ip, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "mispec_symshift_set_shift": (C.c_int, [_vp, C.c_double]),

@@ -944,8 +944,10 @@ mispec_csr* upload_rows(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const i
             }
             // MISPEC_SPMV_STAGED = 0 | 1 | auto: the two-phase format with x and y in LDS (staged.hip), for the same patterns
             const char* smode = getenv("MISPEC_SPMV_STAGED");
-            const bool st_off = smode && std::strcmp(smode, "0") == 0, st_force = smode && std::strcmp(smode, "1") == 0;
-            if (!st_off && (st_force || (n_cols >= 2 * kFarWindow && far > 0.25)))
+            // (round 4: built on request only — "1" for any matrix, "auto" for the patterns that get tiles — until its place in the
+            // automatic choice is settled by measurement)
+            const bool st_force = smode && std::strcmp(smode, "1") == 0, st_auto = smode && std::strcmp(smode, "auto") == 0;
+            if (st_force || (st_auto && n_cols >= 2 * kFarWindow && far > 0.25))
             {
                 HostStaged H;
                 bool built;

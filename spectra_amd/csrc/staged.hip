@@ -502,3 +502,29 @@ void launch_spmv_staged(const DevStaged& S, hipStream_t stream, const double* x,
 }
 
 }  // namespace mispec
+
+// Host-only test hook (no device): builds the staged image of a CSR matrix and multiplies with it on the host in the two kernels'
+// order.  *built = 0 when the format does not apply.  stats: [bins, phase-1 slots, batches, chunks, largest rank + 1 of a batch]
+extern "C" int mispec_staged_spmv_host(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* colind, const double* val,
+                                       const double* x, double* y, int* built, int64_t* stats)
+{
+    return mispec::guarded([&] {
+        MISPEC_REQUIRE(rowptr && x && y && built, "mispec_staged_spmv_host: NULL argument");
+        mispec::HostStaged S;
+        *built = mispec::build_staged(nrows, ncols, rowptr, colind, val, S) ? 1 : 0;
+        if (!*built)
+            return;
+        mispec::staged_spmv_host(S, x, y);
+        if (stats)
+        {
+            stats[0] = S.nbins;
+            stats[1] = S.slots;
+            stats[2] = int64_t(S.batches.size());
+            stats[3] = int64_t(S.chunk_pos.size());
+            int64_t rounds = 0;
+            for (const mispec::StBatch& b : S.batches)
+                rounds = std::max<int64_t>(rounds, int64_t(b.maxrank) + 1);
+            stats[4] = rounds;
+        }
+    });
+}
