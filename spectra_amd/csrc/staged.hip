@@ -87,86 +87,77 @@ struct StLoad  // what a thread holds of one batch
     uint32_t rr;  // row | rank << kStRowBits, or 0xFFFFFFFF: no entry
 };
 
+constexpr int kStAhead = 4;      // batches whose entries are in flight while one is being added
+constexpr int kStDescAhead = 8;  // ... and whose chunk descriptors are (the entry loads depend on them)
+
+// A batch = one chunk per wavefront (<= 64 entries that are contiguous in phase-1 order, i.e. a piece of one bin's share of one
+// column block); desc = phase-1 position | entries << 32 | rounds of the batch << 40.  Nothing of a batch passes through LDS
+// tables and no load sits between two barriers: per batch the workgroup only meets for the rank rounds.
 template <bool EPI>
-__global__ __launch_bounds__(kStThreads) void k_staged_rows(const int32_t* __restrict__ bin_batch, const StBatch* __restrict__ batches,
-                                                             const uint32_t* __restrict__ chunk_pos, const uint16_t* __restrict__ chunk_off,
+__global__ __launch_bounds__(kStThreads) void k_staged_rows(const int32_t* __restrict__ bin_batch, const uint64_t* __restrict__ desc,
                                                              const uint16_t* __restrict__ rowrank, const double* __restrict__ prod,
                                                              double* __restrict__ y, int64_t nrows, int nblocks256, SpmvEpilogue epi)
 {
-    __shared__ double acc[kStRows];                // 64 KiB: two workgroups per CU
-    __shared__ uint32_t cpos[3][kStMaxChunks];     // chunk tables of three consecutive batches
-    __shared__ uint16_t coff[3][kStMaxChunks + 1];
+    __shared__ double acc[kStRows];  // 64 KiB: two workgroups per CU
     if (EPI && epi.status && *epi.status != 0)
         return;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bin = int(blockIdx.x);
 #pragma unroll
     for (int k = 0; k < kStRows / kStThreads; k++)
         acc[k * kStThreads + tid] = 0.0;
     const int b0 = bin_batch[bin], b1 = bin_batch[bin + 1];
+    constexpr int kWaves = kStThreads / 64;
 
-    // chunk table of batch b -> buffer b % 3 (the first nchunks threads); visible after the next barrier
-    auto stage_table = [&](int b) {
-        if (b < b1)
-        {
-            const StBatch bb = batches[b];
-            if (tid < int(bb.nchunks))
-            {
-                cpos[b % 3][tid] = chunk_pos[bb.chunk0 + tid];
-                coff[b % 3][tid] = chunk_off[bb.chunk0 + tid];
-            }
-            if (tid == int(bb.nchunks))
-                coff[b % 3][tid] = bb.count;
-        }
-    };
-    // this thread's entry of batch b, from the table in buffer b % 3
-    auto fetch = [&](int b) {
+    auto load_desc = [&](int b) -> uint64_t { return (b < b1) ? desc[int64_t(b) * kWaves + w] : 0ull; };
+    auto fetch = [&](int b, uint64_t d) {
         StLoad L;
         L.p = 0.0;
-        L.rr = 0xFFFFFFFFu;
-        if (b < b1)
+        const int cnt = int((d >> 32) & 0xFFu);
+        uint32_t rr = 0x1FFFFu;  // no entry: a rank no round reaches (bit 16)
+        if (lane < cnt)
         {
-            const StBatch bb = batches[b];
-            if (tid < int(bb.count))
-            {
-                const uint16_t* off = coff[b % 3];
-                int lo = 0, hi = int(bb.nchunks) - 1;  // the chunk g with off[g] <= tid < off[g + 1]
-                while (lo < hi)
-                {
-                    const int mid = (lo + hi + 1) >> 1;
-                    if (int(off[mid]) <= tid)
-                        lo = mid;
-                    else
-                        hi = mid - 1;
-                }
-                L.p = __builtin_nontemporal_load(prod + (int64_t(cpos[b % 3][lo]) + (tid - int(off[lo]))));
-                L.rr = uint32_t(__builtin_nontemporal_load(rowrank + bb.first + tid));
-            }
+            L.p = __builtin_nontemporal_load(prod + (int64_t(uint32_t(d)) + lane));
+            rr = uint32_t(__builtin_nontemporal_load(rowrank + ((int64_t(b) * kWaves + w) << 6) + lane));
         }
+        L.rr = rr | (uint32_t((d >> 40) & 0xFFu) << 20);
         return L;
     };
 
-    stage_table(b0);
-    stage_table(b0 + 1);
-    __syncthreads();  // accumulators zeroed, first two tables staged
-    StLoad cur = fetch(b0);
-    for (int b = b0; b < b1; b++)
+    uint64_t dq[kStDescAhead];
+    StLoad ring[kStAhead];
+#pragma unroll
+    for (int d = 0; d < kStDescAhead; d++)
+        dq[d] = load_desc(b0 + d);
+#pragma unroll
+    for (int d = 0; d < kStAhead; d++)
+        ring[d] = fetch(b0 + d, dq[d]);
+    __syncthreads();  // accumulators zeroed
+    for (int b = b0; b < b1; b += kStDescAhead)
     {
-        stage_table(b + 2);               // buffer (b + 2) % 3 was last read by fetch(b - 1), a barrier ago
-        const StLoad nxt = fetch(b + 1);  // its table became visible with the last barrier of the previous iteration
-        const int rounds = int(batches[b].maxrank) + 1;
-        const int row = int(cur.rr & uint32_t(kStRows - 1));
-        const int rank = int(cur.rr >> kStRowBits);  // >= 8 for "no entry"
-        for (int r = 0; r < rounds; r++)
+#pragma unroll
+        for (int u = 0; u < kStDescAhead; u++)
         {
-            if (rank == r)
+            const int bb = b + u;
+            if (bb >= b1)
+                break;
+            const StLoad cur = ring[u % kStAhead];
+            ring[u % kStAhead] = fetch(bb + kStAhead, dq[(u + kStAhead) % kStDescAhead]);
+            dq[u] = load_desc(bb + kStDescAhead);
+            const int rounds = __builtin_amdgcn_readfirstlane(int(cur.rr >> 20));  // the same for every thread of the batch
+            const int row = int(cur.rr & uint32_t(kStRows - 1));
+            const int rank = int((cur.rr >> kStRowBits) & 0xFu);  // 8..15: no entry
+            for (int r = 0; r < rounds; r++)
             {
+                if (rank == r)
+                {
 #pragma clang fp contract(off)
-                acc[row] = acc[row] + cur.p;  // entries of one rank address distinct rows
+                    acc[row] = acc[row] + cur.p;  // entries of one rank address distinct rows
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
-        cur = nxt;
     }
     if (b0 == b1)
         __syncthreads();
@@ -216,7 +207,6 @@ bool build_staged(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int
     const int64_t ncb = (ncols + kStCols - 1) >> kStColBits, nbins = (nrows + kStRows - 1) >> kStRowBits;
     if (nnz <= 0 || nnz + ncb >= (int64_t(1) << 32) - 2)
         return false;
-    const int64_t p00 = rowptr[0];
     const int nt = int(std::max<int64_t>(1, std::min<int64_t>(ingest_threads(), nnz / (1 << 20))));
     // rows per thread: contiguous ranges; per-thread histograms over the column blocks; rows must be sorted by column
     std::vector<std::vector<int64_t>> hist(static_cast<size_t>(nt), std::vector<int64_t>(static_cast<size_t>(ncb), 0));
@@ -311,13 +301,13 @@ bool build_staged(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int
             }
         }
     });
-    // phase 2, bin by bin: batches of <= kStBatch entries from consecutive column blocks, ranks inside the batch
-    out.rowrank.resize_uninitialized(size_t(nnz));
+    out.nnz = nnz;
+    // phase 2, bin by bin: chunks of <= 64 phase-1-contiguous entries, kStWaves chunks per batch, ranks inside the batch
     struct BinOut
     {
-        std::vector<StBatch> batches;
-        std::vector<uint32_t> cpos;
-        std::vector<uint16_t> coff;
+        std::vector<uint64_t> desc;     // kStWaves per batch
+        std::vector<uint16_t> rowrank;  // kStThreads per batch
+        int64_t chunks = 0;
     };
     std::vector<BinOut> bins(static_cast<size_t>(nbins));
     parallel_ranges(nbins, nt, [&](int, int64_t bin0, int64_t bin1) {
@@ -327,70 +317,90 @@ bool build_staged(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int
         for (int64_t bin = bin0; bin < bin1; bin++)
         {
             BinOut& B = bins[size_t(bin)];
-            const int64_t first_row = bin << kStRowBits, last_row = std::min(nrows, first_row + kStRows);
-            int64_t w = int64_t(rowptr[first_row]) - p00;  // phase-2 order: the bin's entries start where its first row starts
-            const int64_t wend = int64_t(rowptr[last_row]) - p00;
-            StBatch cur{w, 0, 0, 0, 0, 0};
+            const int64_t first_row = bin << kStRowBits;
+            int nch = 0, cnt = 0, maxrank = 0;  // of the open batch: chunks started, entries in the open chunk, largest rank
             int64_t last_slot = -2;
-            auto close = [&]() {
-                if (cur.count)
-                    B.batches.push_back(cur);
-                cur = StBatch{w, int32_t(B.cpos.size()), 0, 0, 0, 0};
+            size_t base = 0;  // the open batch's first descriptor
+            auto open = [&]() {
+                base = B.desc.size();
+                B.desc.resize(base + kStWaves, 0ull);
+                B.rowrank.resize(B.rowrank.size() + kStThreads, uint16_t(0));
+                nch = 0;
+                cnt = 0;
+                maxrank = 0;
                 last_slot = -2;
                 batch_no++;
             };
-            batch_no++;
+            auto close = [&]() {  // the rounds of the batch into every descriptor
+                for (int g = 0; g < kStWaves; g++)
+                    B.desc[base + size_t(g)] |= uint64_t(maxrank + 1) << 40;
+            };
+            bool is_open = false;
             for (int64_t c = 0; c < ncb; c++)
             {
                 const uint32_t* T = tile.data() + size_t(c) * size_t(nbins + 1);
                 for (int64_t s = T[bin]; s < int64_t(T[bin + 1]); s++)
                 {
                     const int r = int(grow[size_t(s)] - first_row);
+                    if (!is_open)
+                    {
+                        open();
+                        is_open = true;
+                    }
                     int rank = (stamp[size_t(r)] == batch_no) ? int(seen[size_t(r)]) : 0;
-                    const bool new_chunk = (s != last_slot + 1);
-                    if (cur.count == kStBatch || rank > kStMaxRank || (new_chunk && cur.nchunks == kStMaxChunks))
+                    bool new_chunk = (s != last_slot + 1) || cnt == kStChunk;
+                    if (rank > kStMaxRank || (new_chunk && nch == kStWaves))
                     {
                         close();
+                        open();
                         rank = 0;
+                        new_chunk = true;
                     }
-                    if (s != last_slot + 1)
+                    if (new_chunk)
                     {
-                        B.cpos.push_back(uint32_t(s));
-                        B.coff.push_back(cur.count);
-                        cur.nchunks++;
+                        B.desc[base + size_t(nch)] = uint64_t(uint32_t(s));
+                        nch++;
+                        cnt = 0;
+                        B.chunks++;
                     }
-                    out.rowrank[size_t(w++)] = uint16_t(r | (rank << kStRowBits));
+                    B.rowrank[(base + size_t(nch - 1)) * kStChunk + size_t(cnt)] = uint16_t(r | (rank << kStRowBits));
+                    cnt++;
+                    B.desc[base + size_t(nch - 1)] = (B.desc[base + size_t(nch - 1)] & 0xFFFFFFFFull) | (uint64_t(cnt) << 32);
                     stamp[size_t(r)] = batch_no;
                     seen[size_t(r)] = uint16_t(rank + 1);
-                    cur.maxrank = std::max<uint16_t>(cur.maxrank, uint16_t(rank));
-                    cur.count++;
+                    maxrank = std::max(maxrank, rank);
                     last_slot = s;
                 }
             }
-            close();
-            if (w != wend)
-                throw Error(MISPEC_ERUNTIME, "staged format: a bin's entries do not add up");
+            if (is_open)
+                close();
         }
     });
     // concatenate
     out.bin_batch.assign(static_cast<size_t>(nbins) + 1, 0);
-    out.batches.clear();
-    out.chunk_pos.clear();
-    out.chunk_cnt.clear();
+    int64_t nb = 0;
+    out.nchunks = 0;
     for (int64_t bin = 0; bin < nbins; bin++)
     {
-        BinOut& B = bins[size_t(bin)];
-        const int32_t chunk_base = int32_t(out.chunk_pos.size());
-        for (StBatch bb : B.batches)
-        {
-            bb.chunk0 += chunk_base;
-            out.batches.push_back(bb);
-        }
-        out.chunk_pos.insert(out.chunk_pos.end(), B.cpos.begin(), B.cpos.end());
-        out.chunk_cnt.insert(out.chunk_cnt.end(), B.coff.begin(), B.coff.end());
-        out.bin_batch[size_t(bin) + 1] = int32_t(out.batches.size());
-        BinOut().batches.swap(B.batches);
+        nb += int64_t(bins[size_t(bin)].desc.size()) / kStWaves;
+        out.bin_batch[size_t(bin) + 1] = int32_t(nb);
+        out.nchunks += bins[size_t(bin)].chunks;
     }
+    out.nbatches = nb;
+    out.desc.resize_uninitialized(size_t(nb) * kStWaves);
+    out.rowrank.resize_uninitialized(size_t(nb) * kStThreads);
+    parallel_ranges(nbins, nt, [&](int, int64_t bin0, int64_t bin1) {
+        for (int64_t bin = bin0; bin < bin1; bin++)
+        {
+            const BinOut& B = bins[size_t(bin)];
+            const size_t at = size_t(out.bin_batch[size_t(bin)]);
+            if (!B.desc.empty())
+            {
+                std::memcpy(out.desc.data() + at * kStWaves, B.desc.data(), B.desc.size() * sizeof(uint64_t));
+                std::memcpy(out.rowrank.data() + at * kStThreads, B.rowrank.data(), B.rowrank.size() * sizeof(uint16_t));
+            }
+        }
+    });
     return true;
 }
 
@@ -412,19 +422,19 @@ void staged_spmv_host(const HostStaged& S, const double* x, double* y)
     for (int64_t bin = 0; bin < S.nbins; bin++)
     {
         std::fill(acc.begin(), acc.end(), 0.0);
-        for (int32_t b = S.bin_batch[size_t(bin)]; b < S.bin_batch[size_t(bin) + 1]; b++)
+        for (int64_t b = S.bin_batch[size_t(bin)]; b < S.bin_batch[size_t(bin) + 1]; b++)
         {
-            const StBatch& bb = S.batches[size_t(b)];
-            for (int r = 0; r <= int(bb.maxrank); r++)
-                for (int g = 0; g < int(bb.nchunks); g++)
+            const int rounds = int((S.desc[size_t(b) * kStWaves] >> 40) & 0xFFu);
+            for (int r = 0; r < rounds; r++)
+                for (int g = 0; g < kStWaves; g++)
                 {
-                    const int o0 = S.chunk_cnt[size_t(bb.chunk0 + g)];
-                    const int o1 = (g + 1 < int(bb.nchunks)) ? int(S.chunk_cnt[size_t(bb.chunk0 + g + 1)]) : int(bb.count);
-                    for (int t = o0; t < o1; t++)
+                    const uint64_t d = S.desc[size_t(b) * kStWaves + size_t(g)];
+                    const int cnt = int((d >> 32) & 0xFFu);
+                    for (int t = 0; t < cnt; t++)
                     {
-                        const uint16_t rr = S.rowrank[size_t(bb.first + t)];
+                        const uint16_t rr = S.rowrank[(size_t(b) * kStWaves + size_t(g)) * kStChunk + size_t(t)];
                         if ((rr >> kStRowBits) == r)
-                            acc[size_t(rr & (kStRows - 1))] += prod[size_t(S.chunk_pos[size_t(bb.chunk0 + g)]) + size_t(t - o0)];
+                            acc[size_t(rr & (kStRows - 1))] += prod[size_t(uint32_t(d)) + size_t(t)];
                     }
                 }
         }
@@ -443,9 +453,7 @@ void DevStaged::swap(DevStaged& o)
     rowrank.swap(o.rowrank);
     pieces.swap(o.pieces);
     bin_batch.swap(o.bin_batch);
-    batches.swap(o.batches);
-    chunk_pos.swap(o.chunk_pos);
-    chunk_cnt.swap(o.chunk_cnt);
+    desc.swap(o.desc);
     std::swap(nnz, o.nnz);
     std::swap(slots, o.slots);
     std::swap(nbins, o.nbins);
@@ -467,17 +475,15 @@ void upload_staged(const HostStaged& H, hipStream_t stream, DevStaged& D)
     up(D.rowrank, H.rowrank.data(), H.rowrank.size());
     up(D.pieces, H.pieces.data(), H.pieces.size());
     up(D.bin_batch, H.bin_batch.data(), H.bin_batch.size());
-    up(D.batches, H.batches.data(), H.batches.size());
-    up(D.chunk_pos, H.chunk_pos.data(), H.chunk_pos.size());
-    up(D.chunk_cnt, H.chunk_cnt.data(), H.chunk_cnt.size());
+    up(D.desc, H.desc.data(), H.desc.size());
     D.prod.alloc(size_t(H.slots));
     D.nnz = H.nnz;
     D.slots = H.slots;
     D.nbins = H.nbins;
     D.ncb = H.ncb;
     D.npieces = int64_t(H.pieces.size());
-    D.nbatches = int64_t(H.batches.size());
-    D.nchunks = int64_t(H.chunk_pos.size());
+    D.nbatches = H.nbatches;
+    D.nchunks = H.nchunks;
     MISPEC_HIP(hipStreamSynchronize(stream));
 }
 
@@ -491,11 +497,11 @@ void launch_spmv_staged(const DevStaged& S, hipStream_t stream, const double* x,
     hipLaunchKernelGGL(k_staged_products, dim3(unsigned(S.npieces)), dim3(kStThreads), 0, stream, S.pieces.p, S.val.p, S.lcol.p, x, S.prod.p,
                        ncols, status);
     if (epi)
-        hipLaunchKernelGGL((k_staged_rows<true>), dim3(unsigned(S.nbins)), dim3(kStThreads), 0, stream, S.bin_batch.p, S.batches.p, S.chunk_pos.p,
-                           S.chunk_cnt.p, S.rowrank.p, S.prod.p, y, nrows, nblocks256, e);
+        hipLaunchKernelGGL((k_staged_rows<true>), dim3(unsigned(S.nbins)), dim3(kStThreads), 0, stream, S.bin_batch.p, S.desc.p, S.rowrank.p, S.prod.p, y, nrows,
+                           nblocks256, e);
     else
-        hipLaunchKernelGGL((k_staged_rows<false>), dim3(unsigned(S.nbins)), dim3(kStThreads), 0, stream, S.bin_batch.p, S.batches.p, S.chunk_pos.p,
-                           S.chunk_cnt.p, S.rowrank.p, S.prod.p, y, nrows, nblocks256, e);
+        hipLaunchKernelGGL((k_staged_rows<false>), dim3(unsigned(S.nbins)), dim3(kStThreads), 0, stream, S.bin_batch.p, S.desc.p, S.rowrank.p, S.prod.p, y, nrows,
+                           nblocks256, e);
     if (ev_stop)
         MISPEC_HIP(hipEventRecord(ev_stop, stream));
     MISPEC_HIP(hipGetLastError());
@@ -519,11 +525,11 @@ extern "C" int mispec_staged_spmv_host(int64_t nrows, int64_t ncols, const int32
         {
             stats[0] = S.nbins;
             stats[1] = S.slots;
-            stats[2] = int64_t(S.batches.size());
-            stats[3] = int64_t(S.chunk_pos.size());
+            stats[2] = S.nbatches;
+            stats[3] = S.nchunks;
             int64_t rounds = 0;
-            for (const mispec::StBatch& b : S.batches)
-                rounds = std::max<int64_t>(rounds, int64_t(b.maxrank) + 1);
+            for (int64_t b = 0; b < S.nbatches; b++)
+                rounds = std::max<int64_t>(rounds, int64_t((S.desc[size_t(b) * mispec::kStWaves] >> 40) & 0xFFu));
             stats[4] = rounds;
         }
     });

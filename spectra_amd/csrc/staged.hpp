@@ -4,12 +4,13 @@
 //
 //   phase 1  entries in COLUMN-BLOCK-major order (blocks of 8192 columns): a workgroup stages its block of x in LDS (64 KiB),
 //            streams value + 16-bit local column of its entries and writes the products, in the same order — a pure stream.
-//   phase 2  a workgroup owns a BIN of 8192 rows (64 KiB of accumulators in LDS) and adds the bin's products in batches of
-//            <= 1024 (one per thread).  A batch is made of the bin's pieces of consecutive column blocks; inside a batch the
-//            entries of one row are ranked in column order and applied rank by rank with a barrier in between, batches follow
-//            each other in column-block order: every row is summed in ascending column order, one accumulator, i.e. exactly the
-//            CSR row sum of the other kernels and of the oracle (bit-identical results).
-// Bytes per entry: phase 1 reads 10 and writes 8, phase 2 reads 10 (product + 16-bit row/rank) = 28, against 12 + a gather.
+//   phase 2  a workgroup owns a BIN of 8192 rows (64 KiB of accumulators in LDS) and adds the bin's products in batches: one
+//            CHUNK per wavefront, a chunk being <= 64 entries that are contiguous in phase-1 order (a piece of the bin's share of
+//            one column block), chunks and batches following the column blocks.  Inside a batch the entries of one row are
+//            ranked in column order and applied rank by rank with a barrier in between: every row is summed in ascending column
+//            order, one accumulator, i.e. exactly the CSR row sum of the other kernels and of the oracle (bit-identical results).
+// Bytes per entry: phase 1 reads 10 and writes 8, phase 2 reads 8 + 2 / (fill of the chunks) + the descriptors, about 29 in
+// all, against 12 + a gather.
 #pragma once
 #include <vector>
 
@@ -22,21 +23,12 @@ constexpr int kStRows = 1 << kStRowBits;
 constexpr int kStColBits = 13;                  // columns per block: 8192 (64 KiB of x)
 constexpr int kStCols = 1 << kStColBits;
 constexpr int kStThreads = 1024;                // both kernels: two workgroups per CU
-constexpr int kStBatch = kStThreads;            // entries per batch: one per thread
+constexpr int kStWaves = kStThreads / 64;       // chunks per batch: one per wavefront
+constexpr int kStChunk = 64;                    // entries per chunk: one per lane
 constexpr int kStRankBits = 16 - kStRowBits;    // 3: an entry's rank among the entries of its row inside its batch
 constexpr int kStMaxRank = (1 << kStRankBits) - 1;
-constexpr int kStMaxChunks = 64;                // pieces (runs that are contiguous in phase-1 order) per batch
 constexpr int64_t kStPiece = 1 << 16;           // phase 1: entries per workgroup and staging of an x block
 
-struct StBatch
-{
-    int64_t first;      // first entry of the batch in phase-2 order (index into rowrank)
-    int32_t chunk0;     // first chunk
-    uint16_t nchunks;   // <= kStMaxChunks
-    uint16_t count;     // <= kStBatch
-    uint16_t maxrank;   // rounds - 1
-    uint16_t pad;
-};
 struct StPiece
 {
     int64_t begin, end;  // phase-1 positions (multiples of 2)
@@ -51,11 +43,11 @@ struct HostStaged
     RawVec<double> val;            // [slots] phase-1 order; padding slots carry 0.0
     RawVec<uint16_t> lcol;         // [slots] column inside the block
     std::vector<StPiece> pieces;   // phase-1 work list
-    RawVec<uint16_t> rowrank;      // [nnz] phase-2 order: row inside the bin | rank << kStRowBits
+    // phase 2: batch b of a bin = chunks [b * kStWaves, (b + 1) * kStWaves)
     std::vector<int32_t> bin_batch;    // nbins + 1
-    std::vector<StBatch> batches;
-    std::vector<uint32_t> chunk_pos;   // phase-1 position of the chunk's first entry
-    std::vector<uint16_t> chunk_cnt;
+    RawVec<uint64_t> desc;         // [batches * kStWaves] phase-1 position of the chunk | entries << 32 | rounds of its batch << 40
+    RawVec<uint16_t> rowrank;      // [batches * kStThreads] per chunk 64 slots: row inside the bin | rank << kStRowBits
+    int64_t nbatches = 0, nchunks = 0;  // nchunks: chunks that hold entries
 };
 
 // Build the image of rows [0, nrows) of a CSR matrix (any pattern; rows need not be sorted: the row sums follow the storage
@@ -68,16 +60,14 @@ struct DevStaged
     DevBuf<uint16_t> lcol, rowrank;
     DevBuf<StPiece> pieces;
     DevBuf<int32_t> bin_batch;
-    DevBuf<StBatch> batches;
-    DevBuf<uint32_t> chunk_pos;
-    DevBuf<uint16_t> chunk_cnt;
+    DevBuf<uint64_t> desc;
     int64_t nnz = 0, slots = 0, nbins = 0, ncb = 0, npieces = 0, nbatches = 0, nchunks = 0;
     bool present() const { return nbins > 0; }
     void swap(DevStaged& o);
     // bytes one product has to move (both phases, incl. the product array's round trip and the tables)
     double stored_bytes(int64_t n_rows, int64_t n_cols) const
     {
-        return 18.0 * double(slots) + 10.0 * double(nnz) + 16.0 * double(npieces) + 24.0 * double(nbatches) + 6.0 * double(nchunks) +
+        return 18.0 * double(slots) + 8.0 * double(nnz) + (2.0 * kStChunk + 8.0) * double(nchunks) + 16.0 * double(npieces) +
                8.0 * double(n_cols) + 8.0 * double(n_rows);
     }
 };

@@ -25,7 +25,7 @@ t_ingest = time.time() - t0
 print(json.dumps({"n": n, "nnz": int(A.nnz), "host_generation_s": t_gen, "ingest_s": t_ingest, "ingest_stages": sa.last_ingest_info(),
                   "staged": op.staged_info(), "tiles": op.tiles_info()}), flush=True)
 csr_bytes = 12.0 * A.nnz + 20.0 * n + 4
-for fmt in (4, 3, 0):
+for fmt in [int(a) for a in os.environ.get("BENCH_FORMATS", "4,3,0").split(",")]:
     op.set_spmv_format(fmt)
     if op.spmv_format() != fmt:
         continue
