@@ -953,7 +953,7 @@ mispec_csr* upload_rows(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const i
                 bool built;
                 {
                     IngestTimer timer(8);
-                    built = build_staged(n_rows, n_cols, rowptr, colind, val, H);
+                    built = build_staged(n_rows, n_cols, rowptr, colind, val, H, 2 * ctx->num_cu);
                 }
                 if (built)
                 {

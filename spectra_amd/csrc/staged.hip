@@ -96,9 +96,10 @@ constexpr int kStDescAhead = 8;  // ... and whose chunk descriptors are (the ent
 template <bool EPI>
 __global__ __launch_bounds__(kStThreads) void k_staged_rows(const int32_t* __restrict__ bin_batch, const uint64_t* __restrict__ desc,
                                                              const uint16_t* __restrict__ rowrank, const double* __restrict__ prod,
-                                                             double* __restrict__ y, int64_t nrows, int nblocks256, SpmvEpilogue epi)
+                                                             double* __restrict__ y, int64_t nrows, int nblocks256, int bin_rows, SpmvEpilogue epi)
 {
     __shared__ double acc[kStRows];  // 64 KiB: two workgroups per CU
+    __shared__ double red[(kStRows / kStThreads) * (kStThreads / 64)];  // wave sums of the epilogue
     if (EPI && epi.status && *epi.status != 0)
         return;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -162,17 +163,19 @@ __global__ __launch_bounds__(kStThreads) void k_staged_rows(const int32_t* __res
     if (b0 == b1)
         __syncthreads();
 
-    // rows of the bin -> y, in the 256-row records of the CSR kernels (identical alpha partials)
-    const int64_t row0 = int64_t(bin) << kStRowBits;
-#pragma unroll 1
+    // rows of the bin -> y, in the 256-row records of the CSR kernels (identical alpha partials: wave sums by the same shuffle
+    // tree, then (w0 + w1) + (w2 + w3) per record)
+    const int64_t row0 = int64_t(bin) * bin_rows;
+    constexpr int kWavesPer = kStThreads / 64;
+#pragma unroll
     for (int j = 0; j < kStRows / kStThreads; j++)
     {
-        const int64_t row = row0 + j * kStThreads + tid;
-        const int64_t blk = (row0 >> 8) + j * (kStThreads / 256) + (tid >> 8);
+        const int lr = j * kStThreads + tid;
+        const int64_t row = row0 + lr;
         double contrib = 0.0;
-        if (row < nrows)
+        if (lr < bin_rows && row < nrows)
         {
-            double yv = acc[j * kStThreads + tid];
+            double yv = acc[lr];
             if (EPI)
             {
                 if (epi.v_prev)
@@ -184,14 +187,20 @@ __global__ __launch_bounds__(kStThreads) void k_staged_rows(const int32_t* __res
         if (EPI)
         {
             const double t = st_wave_sum(contrib);
-            __syncthreads();  // every thread has read its accumulator of this round
-            double* red = acc + j * kStThreads;
-            if ((tid & 63) == 0)
-                red[tid >> 6] = t;
-            __syncthreads();
-            if ((tid & 255) == 0 && blk < nblocks256)
+            if (lane == 0)
+                red[j * kWavesPer + w] = t;
+        }
+    }
+    if (EPI)
+    {
+        __syncthreads();
+        if (tid < (kStRows / 256))
+        {
+            const int lr0 = tid * 256;  // first row of the record inside the bin
+            const int64_t blk = (row0 >> 8) + tid;
+            if (lr0 < bin_rows && blk < nblocks256)
             {
-                const double* q = red + (tid >> 6);
+                const double* q = red + tid * 4;  // record tid = waves 4 tid .. 4 tid + 3 of the (j, wave) grid
                 epi.partials[blk] = (q[0] + q[1]) + (q[2] + q[3]);
             }
         }
@@ -201,10 +210,17 @@ __global__ __launch_bounds__(kStThreads) void k_staged_rows(const int32_t* __res
 }  // namespace
 
 // ---- host image ---------------------------------------------------------------------------------------------------------------------
-bool build_staged(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* colind, const double* val, HostStaged& out)
+bool build_staged(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* colind, const double* val, HostStaged& out,
+                  int resident)
 {
     const int64_t nnz = int64_t(rowptr[nrows]) - rowptr[0];
-    const int64_t ncb = (ncols + kStCols - 1) >> kStColBits, nbins = (nrows + kStRows - 1) >> kStRowBits;
+    // bin height: the smallest number of whole rounds of `resident` workgroups that 8192-row bins would need, then the rows spread
+    // evenly over that many bins (multiple of 256: the alpha records of the fused epilogue are per 256 rows)
+    const int64_t min_bins = (nrows + kStRows - 1) >> kStRowBits;
+    const int64_t rounds = std::max<int64_t>(1, (min_bins + std::max(resident, 1) - 1) / std::max(resident, 1));
+    int64_t R = (nrows + rounds * resident - 1) / (rounds * std::max(resident, 1));
+    R = std::min<int64_t>(kStRows, std::max<int64_t>(256, (R + 255) / 256 * 256));
+    const int64_t ncb = (ncols + kStCols - 1) >> kStColBits, nbins = (nrows + R - 1) / R;
     if (nnz <= 0 || nnz + ncb >= (int64_t(1) << 32) - 2)
         return false;
     const int nt = int(std::max<int64_t>(1, std::min<int64_t>(ingest_threads(), nnz / (1 << 20))));
@@ -251,6 +267,7 @@ bool build_staged(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int
     out.slots = slots;
     out.nbins = nbins;
     out.ncb = ncb;
+    out.bin_rows = int(R);
     out.val.resize_uninitialized(size_t(slots));
     out.lcol.resize_uninitialized(size_t(slots));
     RawVec<int32_t> grow;  // row of every slot (-1: padding); temporary
@@ -294,7 +311,7 @@ bool build_staged(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int
             const int64_t e = cb_ptr[size_t(c) + 1];
             for (int64_t bin = 0; bin <= nbins; bin++)
             {
-                const int64_t first_row = bin << kStRowBits;
+                const int64_t first_row = bin * R;
                 while (s < e && grow[size_t(s)] >= 0 && grow[size_t(s)] < first_row)
                     s++;
                 T[bin] = uint32_t(s);  // (a padding slot, row -1, ends the segment: s stops there for every later bin)
@@ -317,7 +334,7 @@ bool build_staged(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int
         for (int64_t bin = bin0; bin < bin1; bin++)
         {
             BinOut& B = bins[size_t(bin)];
-            const int64_t first_row = bin << kStRowBits;
+            const int64_t first_row = bin * R;
             int nch = 0, cnt = 0, maxrank = 0;  // of the open batch: chunks started, entries in the open chunk, largest rank
             int64_t last_slot = -2;
             size_t base = 0;  // the open batch's first descriptor
@@ -438,8 +455,8 @@ void staged_spmv_host(const HostStaged& S, const double* x, double* y)
                     }
                 }
         }
-        const int64_t row0 = bin << kStRowBits;
-        for (int64_t r = 0; r < kStRows && row0 + r < S.nrows; r++)
+        const int64_t row0 = bin * S.bin_rows;
+        for (int64_t r = 0; r < S.bin_rows && row0 + r < S.nrows; r++)
             y[row0 + r] = acc[size_t(r)];
     }
 }
@@ -461,6 +478,7 @@ void DevStaged::swap(DevStaged& o)
     std::swap(npieces, o.npieces);
     std::swap(nbatches, o.nbatches);
     std::swap(nchunks, o.nchunks);
+    std::swap(bin_rows, o.bin_rows);
 }
 
 void upload_staged(const HostStaged& H, hipStream_t stream, DevStaged& D)
@@ -483,6 +501,7 @@ void upload_staged(const HostStaged& H, hipStream_t stream, DevStaged& D)
     D.ncb = H.ncb;
     D.npieces = int64_t(H.pieces.size());
     D.nbatches = H.nbatches;
+    D.bin_rows = H.bin_rows;
     D.nchunks = H.nchunks;
     MISPEC_HIP(hipStreamSynchronize(stream));
 }
@@ -498,10 +517,10 @@ void launch_spmv_staged(const DevStaged& S, hipStream_t stream, const double* x,
                        ncols, status);
     if (epi)
         hipLaunchKernelGGL((k_staged_rows<true>), dim3(unsigned(S.nbins)), dim3(kStThreads), 0, stream, S.bin_batch.p, S.desc.p, S.rowrank.p, S.prod.p, y, nrows,
-                           nblocks256, e);
+                           nblocks256, S.bin_rows, e);
     else
         hipLaunchKernelGGL((k_staged_rows<false>), dim3(unsigned(S.nbins)), dim3(kStThreads), 0, stream, S.bin_batch.p, S.desc.p, S.rowrank.p, S.prod.p, y, nrows,
-                           nblocks256, e);
+                           nblocks256, S.bin_rows, e);
     if (ev_stop)
         MISPEC_HIP(hipEventRecord(ev_stop, stream));
     MISPEC_HIP(hipGetLastError());

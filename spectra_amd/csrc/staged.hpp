@@ -18,8 +18,8 @@
 
 namespace mispec {
 
-constexpr int kStRowBits = 13;                  // rows per bin: 8192 (64 KiB of fp64 accumulators)
-constexpr int kStRows = 1 << kStRowBits;
+constexpr int kStRowBits = 13;                  // rows per bin: at most 8192 (64 KiB of fp64 accumulators); a multiple of 256 chosen
+constexpr int kStRows = 1 << kStRowBits;        // per matrix so that the bins fill whole rounds of resident workgroups
 constexpr int kStColBits = 13;                  // columns per block: 8192 (64 KiB of x)
 constexpr int kStCols = 1 << kStColBits;
 constexpr int kStThreads = 1024;                // both kernels: two workgroups per CU
@@ -40,6 +40,7 @@ struct HostStaged
 {
     int64_t nrows = 0, ncols = 0, nnz = 0, slots = 0;  // slots: phase-1 positions (nnz + padding of the column blocks to even counts)
     int64_t nbins = 0, ncb = 0;
+    int bin_rows = kStRows;        // rows per bin (multiple of 256, <= kStRows)
     RawVec<double> val;            // [slots] phase-1 order; padding slots carry 0.0
     RawVec<uint16_t> lcol;         // [slots] column inside the block
     std::vector<StPiece> pieces;   // phase-1 work list
@@ -52,7 +53,10 @@ struct HostStaged
 
 // Build the image of rows [0, nrows) of a CSR matrix (any pattern; rows need not be sorted: the row sums follow the storage
 // order either way).  Returns false (nothing built) when the format does not apply: more than 2^32 - 2 stored entries.
-bool build_staged(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* colind, const double* val, HostStaged& out);
+// resident: workgroups of phase 2 the device holds at a time (2 per CU): the bin height is chosen so that the bins come in whole
+// rounds of that many (with 8192-row bins a 1e7-row matrix would run 2.4 rounds, i.e. three with the last one mostly idle).
+bool build_staged(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* colind, const double* val, HostStaged& out,
+                  int resident = 512);
 
 struct DevStaged
 {
@@ -62,6 +66,7 @@ struct DevStaged
     DevBuf<int32_t> bin_batch;
     DevBuf<uint64_t> desc;
     int64_t nnz = 0, slots = 0, nbins = 0, ncb = 0, npieces = 0, nbatches = 0, nchunks = 0;
+    int bin_rows = kStRows;
     bool present() const { return nbins > 0; }
     void swap(DevStaged& o);
     // bytes one product has to move (both phases, incl. the product array's round trip and the tables)
