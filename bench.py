@@ -296,8 +296,20 @@ def secondary_configs(args, ctx, op, sa):
     rop.set_spmv_format(0)
     csr_alone = spmv_block(rop, standalone_ms(rop, args.n, 10), 10, False)
     rop.set_spmv_format(-1)
+    # M-rand's figures are quoted on the ALGORITHMIC bytes of SURVEY.md 8d (CSR with int32 indices, x counted once, + the fused
+    # epilogue's two vector reads in the loop) whatever format ran, so that they stay comparable across rounds and formats: the
+    # staged format (4) moves about 2.2 x those bytes by design — its rate on its own traffic is reported next to it.
+    standalone = spmv_block(rop, alone, 20, False)
+    for blk, extra in ((inloop, 16.0 * rop.local_rows()), (standalone, 0.0)):
+        alg = rop.algorithmic_bytes() + extra
+        ms = blk["ms_per_launch"]
+        blk.update({"moved_bytes_per_launch": blk["bytes_per_launch"], "achieved_on_moved_bytes": blk["achieved"], "frac_on_moved_bytes": blk["frac"],
+                    "bytes_per_launch": alg, "achieved": alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0})
+        blk["frac"] = blk["achieved"] / HBM_PEAK_GBPS
+        blk["bytes_note"] = "algorithmic: 12 nnz + 4 (rows + 1) + 8 cols + 8 rows" + (" + 16 rows (fused epilogue)" if extra else "")
     out["m_rand"] = {"n": args.n, "nnz": rop.nnz(), "spmv_format": rop.spmv_format(), "reordering": rop.reordering(), "tiles": rop.tiles_info(),
-                     "standalone": spmv_block(rop, alone, 20, False), "in_loop": inloop, "standalone_csr_int32_kernel": csr_alone,
+                     "staged": rop.staged_info(),
+                     "standalone": standalone, "in_loop": inloop, "standalone_csr_int32_kernel": csr_alone,
                      "ingest_seconds": t_ingest, "ingest_stages": ingest_stages, "ingest_host_threads": int(sa.lib().mispec_ingest_threads()),
                      "solve_12_restarts": {"seconds": dt, "nconv": int(nconv), "num_operations": int(e.num_operations())},
                      "host_generation_seconds": t_gen}

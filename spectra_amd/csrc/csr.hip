@@ -924,11 +924,31 @@ mispec_csr* upload_rows(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const i
             if (force || (n_rows >= 2 * kFarWindow && A->far_before > 0.25))
                 reorder_matrix(*A, rowptr, colind, val, force);
         }
-        if (!A->reordered() && !tiles_off && ctx->world() == 1 && ctx->comm.allgather == nullptr && p1 > p0 && spmv_rows_per_block() == 256)
+        if (!A->reordered() && ctx->world() == 1 && ctx->comm.allgather == nullptr && p1 > p0 && spmv_rows_per_block() == 256)
         {
             const double far = (allow_reorder && !off && n_rows == n_cols) ? A->far_before : far_fraction(n_rows, rowptr, colind, nullptr, kFarWindow);
             A->far_before = far;
-            if (tiles_force || (n_cols >= 2 * kFarWindow && far > 0.25))
+            // MISPEC_SPMV_STAGED = auto (default) | 0 | 1: the two-phase format with x and y in LDS (staged.hip).  Since round 4 it is
+            // what scattered patterns get (M-rand n = 1e7 in the solver loop: 1.02 ms against 1.45 ms from the tiles); the tiles
+            // are then built only on request (MISPEC_SPMV_TILES=1) or when the staged format declines the matrix.
+            const char* smode = getenv("MISPEC_SPMV_STAGED");
+            const bool st_off = smode && std::strcmp(smode, "0") == 0, st_force = smode && std::strcmp(smode, "1") == 0;
+            const bool scattered = n_cols >= 2 * kFarWindow && far > 0.25;
+            bool staged_built = false;
+            if (!st_off && (st_force || scattered))
+            {
+                HostStaged H;
+                {
+                    IngestTimer timer(8);
+                    staged_built = build_staged(n_rows, n_cols, rowptr, colind, val, H, 2 * ctx->num_cu);
+                }
+                if (staged_built)
+                {
+                    IngestTimer timer(9);
+                    upload_staged(H, ctx->stream, A->staged);
+                }
+            }
+            if (!tiles_off && (tiles_force || (scattered && !staged_built)))
             {
                 HostTiles H;
                 bool built;
@@ -940,25 +960,6 @@ mispec_csr* upload_rows(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const i
                 {
                     IngestTimer timer(6);
                     upload_tiles(H, ctx->stream, A->tiles);
-                }
-            }
-            // MISPEC_SPMV_STAGED = 0 | 1 | auto: the two-phase format with x and y in LDS (staged.hip), for the same patterns
-            const char* smode = getenv("MISPEC_SPMV_STAGED");
-            // (round 4: built on request only — "1" for any matrix, "auto" for the patterns that get tiles — until its place in the
-            // automatic choice is settled by measurement)
-            const bool st_force = smode && std::strcmp(smode, "1") == 0, st_auto = smode && std::strcmp(smode, "auto") == 0;
-            if (st_force || (st_auto && n_cols >= 2 * kFarWindow && far > 0.25))
-            {
-                HostStaged H;
-                bool built;
-                {
-                    IngestTimer timer(8);
-                    built = build_staged(n_rows, n_cols, rowptr, colind, val, H, 2 * ctx->num_cu);
-                }
-                if (built)
-                {
-                    IngestTimer timer(9);
-                    upload_staged(H, ctx->stream, A->staged);
                 }
             }
         }

@@ -29,6 +29,15 @@ __device__ __forceinline__ double st_wave_sum(double v)  // the reduction tree o
     return v;
 }
 
+__device__ __forceinline__ void st_store(v2d p, double* at)
+{
+#if MISPEC_ST_NT_STORE
+    __builtin_nontemporal_store(p, reinterpret_cast<v2d*>(at));
+#else
+    *reinterpret_cast<v2d*>(at) = p;
+#endif
+}
+
 // ---- phase 1: products, column block by column block ------------------------------------------------------------------------------
 __global__ __launch_bounds__(kStThreads) void k_staged_products(const StPiece* __restrict__ pieces, const double* __restrict__ val,
                                                                  const uint16_t* __restrict__ lcol, const double* __restrict__ x,
@@ -66,7 +75,7 @@ __global__ __launch_bounds__(kStThreads) void k_staged_products(const StPiece* _
             v2d p;
             p.x = a[u].x * xs[c[u] & 0xFFFFu];
             p.y = a[u].y * xs[c[u] >> 16];
-            __builtin_nontemporal_store(p, reinterpret_cast<v2d*>(prod + i + u * kStep));
+            st_store(p, prod + i + u * kStep);
         }
     }
     for (; i < pc.end; i += kStep)
@@ -76,7 +85,7 @@ __global__ __launch_bounds__(kStThreads) void k_staged_products(const StPiece* _
         v2d p;
         p.x = a.x * xs[c & 0xFFFFu];
         p.y = a.y * xs[c >> 16];
-        __builtin_nontemporal_store(p, reinterpret_cast<v2d*>(prod + i));
+        st_store(p, prod + i);
     }
 }
 
@@ -87,8 +96,14 @@ struct StLoad  // what a thread holds of one batch
     uint32_t rr;  // row | rank << kStRowBits, or 0xFFFFFFFF: no entry
 };
 
-constexpr int kStAhead = 4;      // batches whose entries are in flight while one is being added
-constexpr int kStDescAhead = 8;  // ... and whose chunk descriptors are (the entry loads depend on them)
+#ifndef MISPEC_ST_AHEAD
+#define MISPEC_ST_AHEAD 4
+#endif
+#ifndef MISPEC_ST_NT_STORE
+#define MISPEC_ST_NT_STORE 1
+#endif
+constexpr int kStAhead = MISPEC_ST_AHEAD;          // batches whose entries are in flight while one is being added
+constexpr int kStDescAhead = 2 * MISPEC_ST_AHEAD;  // ... and whose chunk descriptors are (the entry loads depend on them)
 
 // A batch = one chunk per wavefront (<= 64 entries that are contiguous in phase-1 order, i.e. a piece of one bin's share of one
 // column block); desc = phase-1 position | entries << 32 | rounds of the batch << 40.  Nothing of a batch passes through LDS
@@ -214,12 +229,17 @@ bool build_staged(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int
                   int resident)
 {
     const int64_t nnz = int64_t(rowptr[nrows]) - rowptr[0];
-    // bin height: the smallest number of whole rounds of `resident` workgroups that 8192-row bins would need, then the rows spread
-    // evenly over that many bins (multiple of 256: the alpha records of the fused epilogue are per 256 rows)
+    // bin height: 8192 rows — except for matrices with fewer such bins than the device holds workgroups (`resident`): their rows
+    // are spread over `resident` bins (a multiple of 256 rows each: the alpha records of the fused epilogue are per 256 rows), so
+    // that every CU has work.  (Spreading larger matrices over whole rounds of resident workgroups was measured too, r07f/r07g:
+    // the smaller tiles fill the 64-entry chunks worse and the gain of the evened-out last round is lost again.)
     const int64_t min_bins = (nrows + kStRows - 1) >> kStRowBits;
-    const int64_t rounds = std::max<int64_t>(1, (min_bins + std::max(resident, 1) - 1) / std::max(resident, 1));
-    int64_t R = (nrows + rounds * resident - 1) / (rounds * std::max(resident, 1));
-    R = std::min<int64_t>(kStRows, std::max<int64_t>(256, (R + 255) / 256 * 256));
+    int64_t R = kStRows;
+    if (min_bins < resident)
+    {
+        R = (nrows + resident - 1) / std::max(resident, 1);
+        R = std::min<int64_t>(kStRows, std::max<int64_t>(256, (R + 255) / 256 * 256));
+    }
     const int64_t ncb = (ncols + kStCols - 1) >> kStColBits, nbins = (nrows + R - 1) / R;
     if (nnz <= 0 || nnz + ncb >= (int64_t(1) << 32) - 2)
         return false;

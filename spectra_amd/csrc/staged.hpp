@@ -27,7 +27,10 @@ constexpr int kStWaves = kStThreads / 64;       // chunks per batch: one per wav
 constexpr int kStChunk = 64;                    // entries per chunk: one per lane
 constexpr int kStRankBits = 16 - kStRowBits;    // 3: an entry's rank among the entries of its row inside its batch
 constexpr int kStMaxRank = (1 << kStRankBits) - 1;
-constexpr int64_t kStPiece = 1 << 16;           // phase 1: entries per workgroup and staging of an x block
+#ifndef MISPEC_ST_PIECE_LOG2
+#define MISPEC_ST_PIECE_LOG2 16
+#endif
+constexpr int64_t kStPiece = int64_t(1) << MISPEC_ST_PIECE_LOG2;  // phase 1: entries per workgroup and staging of an x block
 
 struct StPiece
 {
@@ -53,8 +56,8 @@ struct HostStaged
 
 // Build the image of rows [0, nrows) of a CSR matrix (any pattern; rows need not be sorted: the row sums follow the storage
 // order either way).  Returns false (nothing built) when the format does not apply: more than 2^32 - 2 stored entries.
-// resident: workgroups of phase 2 the device holds at a time (2 per CU): the bin height is chosen so that the bins come in whole
-// rounds of that many (with 8192-row bins a 1e7-row matrix would run 2.4 rounds, i.e. three with the last one mostly idle).
+// resident: workgroups of phase 2 the device holds at a time (2 per CU): a matrix with fewer 8192-row bins than that gets lower
+// bins, so that every CU has one.
 bool build_staged(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* colind, const double* val, HostStaged& out,
                   int resident = 512);
 

@@ -15,8 +15,21 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True)
-def staged_on(monkeypatch):
+def every_format(monkeypatch):
+    """Staged format forced for every matrix of this module (the automatic choice takes it for scattered patterns only), tiles
+    built next to it so that the formats can be compared on one operator."""
     monkeypatch.setenv("MISPEC_SPMV_STAGED", "1")
+    monkeypatch.setenv("MISPEC_SPMV_TILES", "1")
+
+
+def test_scattered_patterns_get_the_staged_format_by_default(ctx, monkeypatch):
+    monkeypatch.delenv("MISPEC_SPMV_STAGED")
+    monkeypatch.delenv("MISPEC_SPMV_TILES")
+    A = m_rand(300_001)
+    op = sa.SparseSymMatProd(sp.tril(A).tocsc(), ctx=ctx)
+    assert op.reordering() == "none" and op.spmv_format() == 4 and op.staged_info()["bins"] > 0 and op.tiles_info()["segments"] == 0
+    x = np.random.default_rng(2).standard_normal(300_001)
+    assert np.array_equal(device_spmv(op, x), O.Op.csr(300_001, 300_001, A.indptr, A.indices, A.data).perform_op(x))
 
 
 @pytest.mark.parametrize("n", [300_001, 1_000_000])

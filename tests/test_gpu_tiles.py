@@ -13,6 +13,12 @@ import spectra_amd as sa
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def tiles_are_the_scattered_format(monkeypatch):
+    """Since round 4 scattered patterns get the staged format (tests/test_gpu_staged.py); this module tests the tiles."""
+    monkeypatch.setenv("MISPEC_SPMV_STAGED", "0")
+
+
 def m_rand(n, seed=1):
     rng = np.random.default_rng(seed)
     r = np.repeat(np.arange(n), 7)

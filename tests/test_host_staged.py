@@ -19,9 +19,8 @@ def check(A, seed=0):
     y, st = sa.staged_spmv_host(A, x)
     assert y is not None
     assert np.array_equal(y, O.Op.csr(n, ncols, A.indptr, A.indices, A.data).perform_op(x))
-    # bins: whole rounds of 512 resident workgroups, bin height a multiple of 256 and at most 8192 rows
-    rounds = max(1, -(-((n + 8191) // 8192) // 512))
-    height = min(8192, max(256, -(-(-(-n // (rounds * 512))) // 256) * 256))
+    # bins of 8192 rows, lower ones (a multiple of 256 rows) when there would be fewer than 512 of them
+    height = 8192 if (n + 8191) // 8192 >= 512 else min(8192, max(256, -(-(-(-n // 512)) // 256) * 256))
     assert st["bins"] == -(-n // height) and A.nnz <= st["slots"] <= A.nnz + (ncols + 8191) // 8192
     return st
 
