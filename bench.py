@@ -128,10 +128,11 @@ def cpu_baseline(args, gpu_nops, gpu_nconv, gpu_niter):
                 "seconds": g["oracle_seconds_one_thread"], "num_operations": g["num_operations"],
                 "eigenpairs_per_s": g["nconv"] / g["oracle_seconds_one_thread"],
                 "ratio_to_this_estimate": ratio,
-                "note": ("not this box: recorded when the golden file was generated, on the build container's host (a shared "
-                         "machine whose one core sustains a fraction of this box's memory bandwidth); the same code, the same "
-                         f"{g['num_operations']} operations — the ratio is the two hosts' per-core streaming rate, compare "
-                         "spmv_gbps here with the build host's figure in tests/golden/full_size_c2.json if recorded")}
+                "build_host_oracle_spmv_gbps": g.get("build_host_oracle_spmv_gbps"),
+                "note": ("not this box: the oracle's complete solve as recorded on the build container's host, whose one core runs the "
+                         f"oracle's SpMV at {g.get('build_host_oracle_spmv_gbps')} GB/s against {out['spmv_gbps']:.1f} GB/s here — the same code and "
+                         f"the same {g['num_operations']} operations; the ratio of the two solve times ({ratio:.1f}) is the ratio of the two hosts' "
+                         "memory systems (every kernel of the solve is a stream), not of the sample's extrapolation")}
     except Exception:  # noqa: BLE001 - informational only
         pass
     return out

@@ -346,7 +346,12 @@ int mispec_fac_exchange_info(const mispec_fac* fac, int* halo, int64_t* recv_dou
  * only the rank's own slice of the vector and are multiplied while the exchange is in flight on a second stream; the
  * others follow when it has landed.  block_count = 0: no overlap (unsharded, MISPEC_OVERLAP=0, or too few such blocks). */
 int mispec_fac_overlap_info(const mispec_fac* fac, int* first_block, int* block_count, int* total_blocks);
-int mispec_fac_get_H(const mispec_fac* fac, double* H_host); /* matrix_H(), ncv x ncv col-major */
+/* matrix_H(), ncv x ncv col-major.  NOTE (one-sweep steps): when the last correction of a full sweep is still pending (it
+ * would ride on the restart's V*Q pass), this getter, mispec_fac_get_f and mispec_fac_get_V MATERIALISE it first (kernel
+ * launches, a stream synchronisation, f / H / beta updated) although the handle is const: the values returned are the finished
+ * ones, and the restart that follows then takes the plain (two-pass) way instead of the fused one — same results to rounding,
+ * not to the bit.  Not safe to call from two threads at once. */
+int mispec_fac_get_H(const mispec_fac* fac, double* H_host);
 int mispec_fac_set_H(mispec_fac* fac, const double* H_host, int k); /* after a host-side compress_H */
 /* matrix_V().leftCols(ncols) / vector_f() of this shard to host (ld = local_rows). */
 int mispec_fac_get_V(const mispec_fac* fac, int ncols, double* V_host);
