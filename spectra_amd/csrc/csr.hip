@@ -1306,9 +1306,8 @@ void launch_spmv_raw(const mispec_csr& A, const double* x_dev, double* y_dev, co
     } while (0)
     // up to 16 entries per row on average: the 16 KiB-chunk instantiation.  Measured in the solver loop: 7 per row (reordered
     // stencil) 0.258 -> 0.215 ms, 15 per row (M-band) 0.413 -> 0.394 ms, stand-alone equal
-    // (experiment knob of round 4, read once: MISPEC_CSR_CHUNK=2 / 4 forces the 16 KiB / 32 KiB chunk instantiation)
-    static const int chunk_knob = getenv("MISPEC_CSR_CHUNK") ? atoi(getenv("MISPEC_CSR_CHUNK")) : 0;
-    const bool small_chunk = !coded && (chunk_knob == 2 || (chunk_knob != 4 && double(A.nnz) <= 16.0 * double(nloc)));
+    // (round 4, profiles/r07a: on M-band the two chunk sizes measure alike in the loop, 0.417-0.422 ms, in both step flows)
+    const bool small_chunk = !coded && double(A.nnz) <= 16.0 * double(nloc);
 #define MISPEC_SPMV(E)                                                    \
     do                                                                    \
     {                                                                     \

@@ -30,11 +30,7 @@ constexpr int kTileRows = 128;
 // 16-byte load of two rows of a basis column with the non-temporal hint (streamed once per pass)
 __device__ __forceinline__ double2 load_streamed(const double* p)
 {
-#ifdef MISPEC_NO_NT_BASIS  // experiment build (tools/r07b.sh): plain loads
-    const v2d t = *reinterpret_cast<const v2d*>(p);
-#else
-    const v2d t = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p));
-#endif
+    const v2d t = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p));  // (plain loads: round 4, profiles/r07b — the solve 1.7 % slower)
     double2 r;
     r.x = t.x;
     r.y = t.y;
@@ -855,11 +851,7 @@ __device__ __forceinline__ void vq_fetch(v2d (&pre)[NJ], const double* __restric
     for (int jj = 0; jj < NJ; jj++)
     {
         const int jc = (jj < nj) ? (w + 4 * jj) : (nj > 0 ? w : 0);
-#ifdef MISPEC_NO_NT_BASIS
-        pre[jj] = *reinterpret_cast<const v2d*>(V + int64_t(jc) * ldv + rc);
-#else
         pre[jj] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(V + int64_t(jc) * ldv + rc));  // streamed once: see k_orth
-#endif
     }
 }
 

@@ -29,13 +29,9 @@ __device__ __forceinline__ double st_wave_sum(double v)  // the reduction tree o
     return v;
 }
 
-__device__ __forceinline__ void st_store(v2d p, double* at)
-{
-#if MISPEC_ST_NT_STORE
+__device__ __forceinline__ void st_store(v2d p, double* at)  // streamed: read back by phase 2 only after 1.2 GB more (plain stores
+{                                                             // measured the same, profiles/r07g)
     __builtin_nontemporal_store(p, reinterpret_cast<v2d*>(at));
-#else
-    *reinterpret_cast<v2d*>(at) = p;
-#endif
 }
 
 // ---- phase 1: products, column block by column block ------------------------------------------------------------------------------
@@ -96,14 +92,9 @@ struct StLoad  // what a thread holds of one batch
     uint32_t rr;  // row | rank << kStRowBits, or 0xFFFFFFFF: no entry
 };
 
-#ifndef MISPEC_ST_AHEAD
-#define MISPEC_ST_AHEAD 4
-#endif
-#ifndef MISPEC_ST_NT_STORE
-#define MISPEC_ST_NT_STORE 1
-#endif
-constexpr int kStAhead = MISPEC_ST_AHEAD;          // batches whose entries are in flight while one is being added
-constexpr int kStDescAhead = 2 * MISPEC_ST_AHEAD;  // ... and whose chunk descriptors are (the entry loads depend on them)
+// (measured, profiles/r07g: eight batches ahead cost the epilogue instantiation its registers — 0.69-0.77 ms against 0.46)
+constexpr int kStAhead = 4;                 // batches whose entries are in flight while one is being added
+constexpr int kStDescAhead = 2 * kStAhead;  // ... and whose chunk descriptors are (the entry loads depend on them)
 
 // A batch = one chunk per wavefront (<= 64 entries that are contiguous in phase-1 order, i.e. a piece of one bin's share of one
 // column block); desc = phase-1 position | entries << 32 | rounds of the batch << 40.  Nothing of a batch passes through LDS

@@ -18,8 +18,8 @@
 
 namespace mispec {
 
-constexpr int kStRowBits = 13;                  // rows per bin: at most 8192 (64 KiB of fp64 accumulators); a multiple of 256 chosen
-constexpr int kStRows = 1 << kStRowBits;        // per matrix so that the bins fill whole rounds of resident workgroups
+constexpr int kStRowBits = 13;                  // rows per bin: 8192 (64 KiB of fp64 accumulators); fewer (a multiple of 256) for
+constexpr int kStRows = 1 << kStRowBits;        // matrices that would otherwise have fewer bins than the device holds workgroups
 constexpr int kStColBits = 13;                  // columns per block: 8192 (64 KiB of x)
 constexpr int kStCols = 1 << kStColBits;
 constexpr int kStThreads = 1024;                // both kernels: two workgroups per CU
@@ -27,10 +27,7 @@ constexpr int kStWaves = kStThreads / 64;       // chunks per batch: one per wav
 constexpr int kStChunk = 64;                    // entries per chunk: one per lane
 constexpr int kStRankBits = 16 - kStRowBits;    // 3: an entry's rank among the entries of its row inside its batch
 constexpr int kStMaxRank = (1 << kStRankBits) - 1;
-#ifndef MISPEC_ST_PIECE_LOG2
-#define MISPEC_ST_PIECE_LOG2 16
-#endif
-constexpr int64_t kStPiece = int64_t(1) << MISPEC_ST_PIECE_LOG2;  // phase 1: entries per workgroup and staging of an x block
+constexpr int64_t kStPiece = int64_t(1) << 16;  // phase 1: entries per workgroup and staging of an x block (2^18: 5 % slower, r07g)
 
 struct StPiece
 {
