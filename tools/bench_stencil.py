@@ -73,7 +73,7 @@ Bl = sp.tril(B).tocsc()
 del A
 for name, kw, env in (("random order, reordered at ingest (RCM)", {}, {}),
                       ("random order, as it comes: tiles", {"reorder": "none"}, {}),
-                      ("random order, as it comes: int32 CSR kernel", {"reorder": "none"}, {"MISPEC_SPMV_TILES": "0"})):
+                      ("random order, as it comes: int32 CSR kernel", {"reorder": "none"}, {"MISPEC_SPMV_TILES": "0", "MISPEC_SPMV_STAGED": "0"})):
     key = name.split(",")[1].split(":")[-1].strip().split(" ")[0]
     if only and not any(k in name for k in only):
         continue
