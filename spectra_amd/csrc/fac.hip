@@ -1085,7 +1085,7 @@ void factorize_lanczos(mispec_fac& F, int from_k, int to_m, int64_t* nmatop)
 {
     zero_H_outside(F, from_k);
     const bool fast = F.device_steps && F.A != nullptr && !F.bmode() && F.Chol == nullptr;
-    const bool lagged = fast && F.onesweep && F.m <= kPanelCols && !F.A2;  // standard problems, one column panel
+    const bool lagged = fast && F.onesweep && F.m <= kPanelCols;  // standard problems (incl. the product operator of the SVD solver), one column panel
     // a sweep that completes the factorisation is followed by a restart (or by nothing that needs f): its last correction can wait
     const bool defer = lagged && to_m == F.m && !F.eager_last && !F.eager_sticky && !small_on_device();
     F.end_pending = false;
@@ -1828,7 +1828,7 @@ extern "C" int mispec_fac_orth_info(const mispec_fac* fac, int* mode, int64_t* l
 {
     return guarded([&] {
         MISPEC_REQUIRE(fac, "mispec_fac_orth_info: NULL argument");
-        const bool active = fac->onesweep && fac->device_steps && fac->symmetric && fac->A && !fac->A2 && !fac->bmode() && !fac->Chol &&
+        const bool active = fac->onesweep && fac->device_steps && fac->symmetric && fac->A && !fac->bmode() && !fac->Chol &&
                             fac->m <= kPanelCols;
         if (mode)
             *mode = active ? (MISPEC_ORTH_ONESWEEP | ((fac->eager_last || fac->eager_sticky) ? MISPEC_ORTH_EAGER_LAST : 0) |

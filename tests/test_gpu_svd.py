@@ -66,7 +66,7 @@ def test_product_operator_host_contract(ctx):
         assert np.abs(op.perform_op(x) - ref).max() <= 1e-12 * np.abs(ref).max()
 
 
-def test_partial_svd_large_sparse(ctx):
+def test_partial_svd_large_sparse(ctx, orth_env):
     # 200k x 50k, ~8 nnz/row: triplet residuals ||A v - s u|| and ||A' u - s v|| relative to s
     m, n, k, ncv = 200_000, 50_000, 6, 24
     rng = np.random.default_rng(11)
@@ -82,3 +82,6 @@ def test_partial_svd_large_sparse(ctx):
     assert np.abs(np.linalg.norm(A @ V - U * sv, axis=0) / sv).max() <= 1e-9
     assert np.abs(np.linalg.norm(A.T @ U - V * sv, axis=0) / sv).max() <= 1e-9
     assert np.abs(V.T @ V - np.eye(k)).max() <= 1e-10
+    # round 4: the product operator A'A takes the one-sweep steps too (the epilogue rides on the second product)
+    info = svds.eigs.orth_info()
+    assert info["mode"] == orth_env and (info["lagged_steps"] > 0) == (orth_env == "onesweep")
