@@ -575,14 +575,14 @@ void apply_op(mispec_fac& F, const double* x_loc, double* y_loc, bool lanczos_ep
         Timed t(F, FAM_SPMV);
         launch_shiftsolve(*F.S, x_loc, y_loc);
         if (lanczos_epi)
-            launch_lanczos_epilogue(*F.ctx, y_loc, x_loc, v_prev, h_prev, F.nloc, F.alpha_partials.p);
+            launch_lanczos_epilogue(*F.ctx, y_loc, x_loc, v_prev, h_prev, F.nloc, F.alpha_partials.p, h_prev_dev, status);
     }
     else if (F.D)
     {
         Timed t(F, FAM_SPMV);
         launch_row_gemv(*F.ctx, F.D->a.p, F.D->ld, F.D->rows, F.D->cols, x_loc, y_loc, true);
         if (lanczos_epi)
-            launch_lanczos_epilogue(*F.ctx, y_loc, x_loc, v_prev, h_prev, F.nloc, F.alpha_partials.p);
+            launch_lanczos_epilogue(*F.ctx, y_loc, x_loc, v_prev, h_prev, F.nloc, F.alpha_partials.p, h_prev_dev, status);
     }
     else if (F.dop)
     {
@@ -593,7 +593,7 @@ void apply_op(mispec_fac& F, const double* x_loc, double* y_loc, bool lanczos_ep
                 throw Error(MISPEC_ERUNTIME, "user device operator callback reported failure");
         }
         if (lanczos_epi)
-            launch_lanczos_epilogue(*F.ctx, y_loc, x_loc, v_prev, h_prev, F.nloc, F.alpha_partials.p);
+            launch_lanczos_epilogue(*F.ctx, y_loc, x_loc, v_prev, h_prev, F.nloc, F.alpha_partials.p, h_prev_dev, status);
     }
     else
     {
@@ -1080,11 +1080,17 @@ void lanczos_step_lagged(mispec_fac& F, int i, bool last, bool defer)
     }
 }
 
+// operators applied entirely by enqueued device work (apply_op never waits for the host)
+bool device_operator(const mispec_fac& F) { return F.A != nullptr || (F.S != nullptr && F.Bcsr == nullptr) || F.D != nullptr || F.dop != nullptr; }
+
 // Lanczos.h:62-187
 void factorize_lanczos(mispec_fac& F, int from_k, int to_m, int64_t* nmatop)
 {
     zero_H_outside(F, from_k);
-    const bool fast = F.device_steps && F.A != nullptr && !F.bmode() && F.Chol == nullptr;
+    // device-driven steps: every operator that works on device pointers without a host turn — device matrices (incl. the SVD
+    // solver's product), and since round 4 the banded / dense shift-solve, dense matrices and user operators on device pointers
+    // (their Lanczos epilogue is a kernel of its own that reads H(i,i-1) and the stop flag from device memory)
+    const bool fast = F.device_steps && device_operator(F) && !F.bmode() && F.Chol == nullptr;
     const bool lagged = fast && F.onesweep && F.m <= kPanelCols;  // standard problems (incl. the product operator of the SVD solver), one column panel
     // a sweep that completes the factorisation is followed by a restart (or by nothing that needs f): its last correction can wait
     const bool defer = lagged && to_m == F.m && !F.eager_last && !F.eager_sticky && !small_on_device();
@@ -1296,7 +1302,7 @@ void arnoldi_step_device(mispec_fac& F, int i)
 void factorize_arnoldi(mispec_fac& F, int from_k, int to_m, int64_t* nmatop)
 {
     zero_H_outside(F, from_k);
-    const bool fast = F.device_steps && F.A != nullptr;
+    const bool fast = F.device_steps && device_operator(F);
     int i = from_k;
     while (i <= to_m - 1)
     {
@@ -1828,7 +1834,7 @@ extern "C" int mispec_fac_orth_info(const mispec_fac* fac, int* mode, int64_t* l
 {
     return guarded([&] {
         MISPEC_REQUIRE(fac, "mispec_fac_orth_info: NULL argument");
-        const bool active = fac->onesweep && fac->device_steps && fac->symmetric && fac->A && !fac->bmode() && !fac->Chol &&
+        const bool active = fac->onesweep && fac->device_steps && fac->symmetric && device_operator(*fac) && !fac->bmode() && !fac->Chol &&
                             fac->m <= kPanelCols;
         if (mode)
             *mode = active ? (MISPEC_ORTH_ONESWEEP | ((fac->eager_last || fac->eager_sticky) ? MISPEC_ORTH_EAGER_LAST : 0) |

@@ -760,9 +760,14 @@ __global__ __launch_bounds__(kThreads) void k_axpby(double* __restrict__ f, doub
 
 __global__ __launch_bounds__(kThreads) void k_lanczos_epilogue(double* __restrict__ w, const double* __restrict__ v,
                                                                 const double* __restrict__ v_prev, double h_prev,
-                                                                int64_t npairs, double* __restrict__ partials)
+                                                                int64_t npairs, double* __restrict__ partials,
+                                                                const double* __restrict__ h_prev_dev, const int* __restrict__ status)
 {
     __shared__ double red[4];
+    if (status && *status != 0)
+        return;
+    if (h_prev_dev)
+        h_prev = *h_prev_dev;
     double acc = 0.0;
     for (int64_t i = int64_t(blockIdx.x) * kThreads + threadIdx.x; i < npairs; i += int64_t(gridDim.x) * kThreads)
     {
@@ -1590,12 +1595,12 @@ int lanczos_epilogue_records(const mispec_ctx& ctx, int64_t n)
 }
 
 void launch_lanczos_epilogue(const mispec_ctx& ctx, double* w, const double* v, const double* v_prev, double h_prev, int64_t n,
-                             double* partials)
+                             double* partials, const double* h_prev_dev, const int* status)
 {
     const int64_t npairs = (n + 1) / 2;
     const int grid = lanczos_epilogue_records(ctx, n);
     hipLaunchKernelGGL(k_lanczos_epilogue, dim3(unsigned(grid)), dim3(kThreads), 0, ctx.stream, w, v, v_prev, h_prev, npairs,
-                       partials);
+                       partials, h_prev_dev, status);
     MISPEC_HIP(hipGetLastError());
 }
 

@@ -161,8 +161,9 @@ int launch_resid_norms_complex(const mispec_ctx& ctx, const double* yr, const do
 // Un-fused Lanczos epilogue for user operators (Lanczos.h:139-142): w -= h_prev*v_prev (if v_prev), one partial
 // of <v, w> per workgroup in partials[0 .. lanczos_epilogue_records).
 int lanczos_epilogue_records(const mispec_ctx& ctx, int64_t n);
+// h_prev_dev (device-driven steps): H(i,i-1) is read from device memory instead; status: the launch is a no-op unless *status == 0
 void launch_lanczos_epilogue(const mispec_ctx& ctx, double* w, const double* v, const double* v_prev, double h_prev, int64_t n,
-                             double* partials);
+                             double* partials, const double* h_prev_dev = nullptr, const int* status = nullptr);
 // fill v[i] = SimpleRandom(seed) stream element (row_begin + i), i < nloc, by LCG jump-ahead (Util/SimpleRandom.h:30-123)
 void launch_simple_random(const mispec_ctx& ctx, double* v, int64_t row_begin, int64_t nloc, uint64_t seed);
 

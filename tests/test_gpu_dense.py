@@ -129,7 +129,9 @@ def test_factorisation_on_a_dense_operator_equals_the_sparse_one(ctx):
     assert fd.num_operations() == fs.num_operations() == 21  # init: 2 (v = A v0, w = A v), then 19 steps
 
 
-def test_user_operator_on_device_pointers(ctx):
+@pytest.mark.parametrize("orth", ["onesweep", "reference"])
+def test_user_operator_on_device_pointers(ctx, orth, monkeypatch):
+    monkeypatch.setenv("MISPEC_ORTH", orth)
     # y = A x through the library's own SpMV called from the callback with DEVICE pointers: the factorisation never
     # leaves HBM, and the solve must agree with the bound device matrix (same kernels apart from the fused epilogue)
     n, k, m = 1000, 20, 50
@@ -148,6 +150,9 @@ def test_user_operator_on_device_pointers(ctx):
     evals, evecs = eigs.eigenvalues(), eigs.eigenvectors()
     assert np.abs(S @ evecs - evecs * evals).max() < 1e-9
     assert len(calls) == eigs.num_operations()
+    # device-pointer operators take the device-driven steps, in the default mode the one-sweep ones
+    info = eigs.orth_info()
+    assert info["mode"] == orth and (info["lagged_steps"] > 0) == (orth == "onesweep")
     ref = sa.SymEigsSolver(mat, k, m)
     ref.init()
     ref.compute(sa.SortRule.LargestAlge)

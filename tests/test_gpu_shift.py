@@ -127,7 +127,7 @@ def test_example1_smallest_by_shift_invert(ctx, k, m):
 
 
 @pytest.mark.parametrize("n", [100_000, 2_000_000])
-def test_config5_banded(ctx, n):
+def test_config5_banded(ctx, n, orth_env):
     # BASELINE.json configs[4]: SymEigsShiftSolver, 2M x 2M banded (half-bandwidth 3, definite), sigma = 0, k = 6, ncv = 20:
     # the 6 eigenvalues closest to 0 (= the smallest ones of a positive definite matrix)
     if n == 2_000_000:  # full size: against the oracle's complete solve (tests/golden/full_size_c5.json)
@@ -143,6 +143,8 @@ def test_config5_banded(ctx, n):
     evals, X = eigs.eigenvalues(), eigs.eigenvectors()
     res = np.linalg.norm(A @ X - X * evals, axis=0) / np.linalg.norm(X, axis=0)
     assert res.max() <= 1e-10, res
+    info = eigs.orth_info()  # the shift solve is enqueued device work: device-driven steps, one sweep of V each by default
+    assert info["mode"] == orth_env and (info["lagged_steps"] > 0) == (orth_env == "onesweep")
     if n <= 100_000:
         ref = np.sort(spla.eigsh(A, k=6, sigma=0.0, which="LM", tol=1e-13)[0])[::-1]
         assert np.abs(evals - ref).max() < 1e-9
