@@ -924,9 +924,13 @@ mispec_csr* upload_rows(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const i
             if (force || (n_rows >= 2 * kFarWindow && A->far_before > 0.25))
                 reorder_matrix(*A, rowptr, colind, val, force);
         }
-        if (!A->reordered() && ctx->world() == 1 && ctx->comm.allgather == nullptr && p1 > p0 && spmv_rows_per_block() == 256)
+        // the two formats for scattered patterns are built from the rows this rank keeps (a row shard: all columns, x is the
+        // gathered vector), so they serve sharded runs too; only the reordering above needs the whole matrix on one rank
+        const bool whole = ctx->world() == 1 && ctx->comm.allgather == nullptr;
+        if (!A->reordered() && p1 > p0 && spmv_rows_per_block() == 256)
         {
-            const double far = (allow_reorder && !off && n_rows == n_cols) ? A->far_before : far_fraction(n_rows, rowptr, colind, nullptr, kFarWindow);
+            const double far = (whole && allow_reorder && !off && n_rows == n_cols) ? A->far_before
+                                                                                     : far_fraction(nloc, rowptr, colind, nullptr, kFarWindow, b);
             A->far_before = far;
             // MISPEC_SPMV_STAGED = auto (default) | 0 | 1: the two-phase format with x and y in LDS (staged.hip).  Since round 4 it is
             // what scattered patterns get (M-rand n = 1e7 in the solver loop: 1.02 ms against 1.45 ms from the tiles); the tiles
@@ -940,7 +944,7 @@ mispec_csr* upload_rows(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const i
                 HostStaged H;
                 {
                     IngestTimer timer(8);
-                    staged_built = build_staged(n_rows, n_cols, rowptr, colind, val, H, 2 * ctx->num_cu);
+                    staged_built = build_staged(nloc, n_cols, rp.data(), colind + p0, val + p0, H, 2 * ctx->num_cu);
                 }
                 if (staged_built)
                 {
@@ -954,7 +958,7 @@ mispec_csr* upload_rows(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const i
                 bool built;
                 {
                     IngestTimer timer(5);
-                    built = build_tiles(n_rows, n_cols, rowptr, colind, val, H);
+                    built = build_tiles(nloc, n_cols, rp.data(), colind + p0, val + p0, H);
                 }
                 if (built)
                 {

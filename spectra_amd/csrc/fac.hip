@@ -300,7 +300,7 @@ void allreduce_max_scalar(mispec_fac& F, double* dev_scalar)
 void plan_overlap(mispec_fac& F)
 {
     F.interior_first = F.interior_count = 0;
-    if (!F.A || !F.sharded() || F.ctx->world() < 2 || F.A2 || F.Bop || F.Chol || F.A->spmv_format() == 3)
+    if (!F.A || !F.sharded() || F.ctx->world() < 2 || F.A2 || F.Bop || F.Chol || F.A->spmv_format() >= 3)  // tiles, staged: no row sub-ranges
         return;
     const char* e = getenv("MISPEC_OVERLAP");
     if (e && atoi(e) == 0)

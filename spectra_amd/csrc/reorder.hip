@@ -137,15 +137,16 @@ void bfs(const Graph& g, int32_t start, const std::vector<uint8_t>& done, Bfs& s
 
 }  // namespace
 
-double far_fraction(int64_t n, const int32_t* rowptr, const int32_t* colind, const int32_t* inv, int64_t window)
+double far_fraction(int64_t n, const int32_t* rowptr, const int32_t* colind, const int32_t* inv, int64_t window, int64_t row0)
 {
+    rowptr += row0;
     const int nt = int(std::max<int64_t>(1, std::min<int64_t>(ingest_threads(), n / 65536)));
     std::vector<int64_t> far(static_cast<size_t>(nt), 0);
     parallel_ranges(n, nt, [&](int t, int64_t b, int64_t e) {
         int64_t f = 0;
         for (int64_t i = b; i < e; i++)
         {
-            const int64_t ri = inv ? inv[i] : i;
+            const int64_t ri = inv ? inv[i] : row0 + i;
             for (int32_t p = rowptr[i]; p < rowptr[i + 1]; p++)
             {
                 const int64_t cj = inv ? inv[colind[p]] : colind[p];

@@ -16,7 +16,8 @@ struct ReorderStats
 
 // Fraction of the stored entries whose column is more than `window` positions away from their row; with inv != nullptr
 // rows and columns are first mapped through inv (old -> new), i.e. the measure of the reordered matrix.
-double far_fraction(int64_t n, const int32_t* rowptr, const int32_t* colind, const int32_t* inv, int64_t window);
+// rows [row0, row0 + n) of the matrix the arrays describe (a row shard: inv must then be nullptr)
+double far_fraction(int64_t n, const int32_t* rowptr, const int32_t* colind, const int32_t* inv, int64_t window, int64_t row0 = 0);
 
 // perm[new] = old.  symmetric_pattern: the pattern is known to be structurally symmetric (else A + A' is used).
 // max_level_fraction > 0: give up (return false, perm empty) when the widest level of the first BFS exceeds that

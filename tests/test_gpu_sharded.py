@@ -26,7 +26,8 @@ def orth_env(request, monkeypatch):
     return request.param
 
 
-def run_sharded(world, n, offsets, nev, ncv, rule, tol, exchange=None, orth=None, keep_vectors=True, profile=False):
+def run_sharded(world, n, offsets, nev, ncv, rule, tol, exchange=None, orth=None, keep_vectors=True, profile=False, make_op=None,
+                spmv_format=None):
     import os
 
     lib = sa.lib()
@@ -42,8 +43,14 @@ def run_sharded(world, n, offsets, nev, ncv, rule, tol, exchange=None, orth=None
             ctx = sa.Context(0)
             _capi.check(lib.mispec_loopback_attach(grp, ctx.h, rank))
             ctx.rank, ctx.world = rank, world
-            op = sa.SparseSymMatProd.synth_band(n, offsets=offsets, ctx=ctx) if offsets is not None else \
-                sa.SparseSymMatProd.synth_band(n, ctx=ctx)
+            if make_op is not None:  # a matrix from host arrays: every rank is handed the whole matrix and keeps its rows
+                op = make_op(ctx)
+            else:
+                op = sa.SparseSymMatProd.synth_band(n, offsets=offsets, ctx=ctx) if offsets is not None else \
+                    sa.SparseSymMatProd.synth_band(n, ctx=ctx)
+            chosen = op.spmv_format()
+            if spmv_format is not None:
+                op.set_spmv_format(spmv_format)
             eigs = sa.SymEigsSolver(op, nev, ncv)
             if orth is not None:  # None: the library default / MISPEC_ORTH
                 eigs.set_orth_mode(orth)
@@ -55,7 +62,8 @@ def run_sharded(world, n, offsets, nev, ncv, rule, tol, exchange=None, orth=None
                                  X=eigs.eigenvectors() if keep_vectors else None,
                                  nops=eigs.num_operations(), niter=eigs.num_iterations(), res=eigs.residuals(),
                                  rows=sa.shard_range(n, world, rank), local=op.local_rows(), exchange=eigs.exchange_info(),
-                                 overlap=eigs.overlap_info(), orth=eigs.orth_info(),
+                                 overlap=eigs.overlap_info(), orth=eigs.orth_info(), chosen_format=chosen,
+                                 format=op.spmv_format(),
                                  profile=eigs.get_profile() if profile else None)
         except Exception as e:  # noqa: BLE001
             errors.append((rank, repr(e)))
@@ -190,3 +198,39 @@ def test_sharded_device_run_that_stops_mid_sweep(ctx, world, orth):
     assert np.abs(res[0]["evals"] - single.eigenvalues()).max() < 1e-10
     assert abs(res[0]["nops"] - single.num_operations()) <= ncv - nev
     assert np.abs(X.T @ X - np.eye(nev)).max() <= 1e-10
+
+
+@pytest.mark.parametrize("world,which", [(2, "staged"), (3, "staged"), (2, "tiles")])
+def test_scattered_pattern_sharded_uses_the_staged_format(ctx, world, which, monkeypatch):
+    # a pattern with uniformly scattered columns, row-sharded: every shard builds the staged (or tile) image of ITS rows — all
+    # columns, x = the gathered vector — and the run equals the one from plain CSR on the same shards bit for bit, and the
+    # unsharded solve to rounding
+    import scipy.sparse as sp
+
+    monkeypatch.setenv("MISPEC_SPMV_STAGED", "auto" if which == "staged" else "0")
+    n, nev, ncv = 600_000, 6, 20
+    rng = np.random.default_rng(11)
+    rows = np.repeat(np.arange(n), 3)
+    cols = rng.integers(0, n, rows.size)
+    T = sp.coo_matrix((rng.uniform(-1.0, 1.0, rows.size), (rows, cols)), shape=(n, n)).tocsr()
+    d = rng.uniform(1.0, 2.0, n)
+    d[rng.choice(n, 8, replace=False)] = 50.0 + 5.0 * np.arange(8)  # separated outliers: a short solve
+    A = (T + T.T + sp.diags(d)).tocsr()
+    A.sum_duplicates()
+    A.sort_indices()
+    L = sp.tril(A).tocsc()
+    make = lambda c: sa.SparseSymMatProd(L, ctx=c)
+    fmt = 4 if which == "staged" else 3
+    res = run_sharded(world, n, None, nev, ncv, sa.SortRule.LargestAlge, 1e-10, make_op=make)
+    csr = run_sharded(world, n, None, nev, ncv, sa.SortRule.LargestAlge, 1e-10, make_op=make, spmv_format=0)
+    for r, c in zip(res, csr):
+        assert r["chosen_format"] == r["format"] == fmt and c["format"] == 0
+        assert r["overlap"][1] == 0  # these formats take no row-block sub-ranges: nothing is multiplied ahead of the exchange
+        assert r["nconv"] == nev and np.array_equal(r["evals"], c["evals"]) and np.array_equal(r["X"], c["X"])
+        assert (r["nops"], r["niter"]) == (c["nops"], c["niter"])
+    single = sa.SymEigsSolver(sa.SparseSymMatProd(L, ctx=ctx), nev, ncv)
+    single.init()
+    assert single.compute(sa.SortRule.LargestAlge, 1000, 1e-10) == nev
+    assert np.abs(single.eigenvalues() - res[0]["evals"]).max() < 1e-9
+    X = np.vstack([r["X"] for r in res])
+    assert (np.linalg.norm(A @ X - X * res[0]["evals"], axis=0) / np.linalg.norm(X, axis=0)).max() <= 1e-8
