@@ -47,6 +47,8 @@ def parse():
     p.add_argument("--selection", default="LargestMagn")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations (M-rand, C4, C5, CSR kernels)")
+    p.add_argument("--no-live-pmc", action="store_true", help="do not run the two rocprofv3 --pmc passes that measure `roofline.traffic` in this run "
+                   "(about a minute; the committed profiles/*pmc_traffic*.json figure is reported instead)")
     p.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     p.add_argument("--profile-level", type=int, default=2, choices=[1, 2],
                     help="HIP-event instrumentation of the timed solves: 2 = operator applications only (default), 1 = every kernel family")
@@ -143,10 +145,24 @@ KERNEL_OF_FORMAT = {0: "k_spmv_csr_stream<EPI, NT, 256, CODES=false>", 1: "k_spm
                     4: "k_staged_products + k_staged_rows (two streaming phases, x and y in LDS)"}
 
 
+def fused_spmv_bytes(kernels, fmt, post_scaled):
+    """The fused SpMV instantiation of a PMC summary's kernel table (tools/pmc_summarize.py): 0 int32 indices, 1 offset codes,
+    2 diagonal storage; post_scaled: the one-sweep steps' instantiation k_spmv_dia_win<true, NG, NCW, true>."""
+    for name, rec in kernels.items():
+        args_ = [a.strip() for a in name.split("<", 1)[1].rstrip(">").split(",")] if "<" in name else []
+        if fmt == 2 and name.startswith("k_spmv_dia") and args_ and args_[0] == "true":
+            # round 3 names: <EPI, NG, NCW, POST>; earlier rounds: <EPI, NG, FUSE, NCW> (no post-scaled variant)
+            is_post = len(args_) == 4 and args_[3] == "true"
+            if is_post == bool(post_scaled):
+                return float(rec["hbm_bytes"])
+        is_coded = len(args_) >= 4 and args_[3] == "true"
+        if fmt != 2 and name.startswith("k_spmv_csr_stream<true") and is_coded == (fmt == 1):
+            return float(rec["hbm_bytes"])
+    return None
+
+
 def pmc_traffic(n, fmt, post_scaled=False):
-    """HBM bytes per launch of the fused SpMV (the instantiation the solve used: 0 int32 indices, 1 offset codes,
-    2 diagonal storage; post_scaled: the one-sweep steps' instantiation k_spmv_dia_win<true, NG, NCW, true>) as measured by the
-    committed PMC passes (tools/pmc_summarize.py), or None."""
+    """HBM bytes per launch of the fused SpMV as measured by the COMMITTED PMC passes (profiles/*pmc_traffic*.json), or None."""
     import glob
 
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
@@ -155,19 +171,65 @@ def pmc_traffic(n, fmt, post_scaled=False):
                 d = json.load(f)
             if int(d.get("n", -1)) != int(n):
                 continue
-            for name, rec in d["kernels"].items():
-                args_ = [a.strip() for a in name.split("<", 1)[1].rstrip(">").split(",")] if "<" in name else []
-                if fmt == 2 and name.startswith("k_spmv_dia") and args_ and args_[0] == "true":
-                    # round 3 names: <EPI, NG, NCW, POST>; earlier rounds: <EPI, NG, FUSE, NCW> (no post-scaled variant)
-                    is_post = len(args_) == 4 and args_[3] == "true"
-                    if is_post == bool(post_scaled):
-                        return float(rec["hbm_bytes"]), os.path.basename(path)
-                is_coded = len(args_) >= 4 and args_[3] == "true"
-                if fmt != 2 and name.startswith("k_spmv_csr_stream<true") and is_coded == (fmt == 1):
-                    return float(rec["hbm_bytes"]), os.path.basename(path)
+            b = fused_spmv_bytes(d["kernels"], fmt, post_scaled)
+            if b is not None:
+                return b, os.path.basename(path)
         except Exception:  # noqa: BLE001 - a malformed summary just means "no PMC figure"
             continue
     return None, None
+
+
+def live_pmc_traffic(n, fmt, post_scaled, timeout=240):
+    """HBM bytes per launch of the fused SpMV measured IN THIS RUN: two rocprofv3 passes (FETCH_SIZE, then WRITE_SIZE — separate
+    runs with --kernel-trace only, as MI355X_MICROARCH.md prescribes) of tools/pmc_probe.py (the same matrix, the same
+    instantiations, one factorisation sweep + restart per flow) in child processes, FETCH_SIZE calibrated on the probe's k_scale
+    launches (8n bytes each way).  Returns (bytes or None, note).  Any failure — no rocprofv3, a pass that does not finish in
+    `timeout` seconds (its process group is killed), no calibration kernel — leaves the committed figure in place."""
+    import glob
+    import importlib.util
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="mispec_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", PROBE_N=str(n), PROBE_FORMATS=str(fmt), PROBE_SPMV_REPS="0")
+    files = {}
+    t0 = time.time()
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, counter), "-o", "p", "--",
+                   sys.executable, os.path.join(ROOT, "tools", "pmc_probe.py")]
+            child = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                child.wait(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                os.killpg(child.pid, signal.SIGKILL)  # the session this call started, nothing else
+                child.wait()
+                return None, f"the {counter} pass did not finish in {timeout} s"
+            found = glob.glob(os.path.join(tmp, counter, "**", "*counter_collection.csv"), recursive=True)
+            if child.returncode != 0 or not found:
+                return None, f"the {counter} pass failed (exit code {child.returncode})"
+            files[counter] = found[0]
+        spec = importlib.util.spec_from_file_location("pmc_summarize", os.path.join(ROOT, "tools", "pmc_summarize.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        d = mod.summarize(files["FETCH_SIZE"], files["WRITE_SIZE"], n)
+        if not d["calibration"]["found"]:
+            return None, "no k_scale launch in the probe to calibrate FETCH_SIZE on"
+        b = fused_spmv_bytes(d["kernels"], fmt, post_scaled)
+        if b is None:
+            return None, "the probe did not launch the instantiation the solve used"
+        return b, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes, --kernel-trace only) of "
+                   f"tools/pmc_probe.py, {time.time() - t0:.0f} s; FETCH_SIZE x {d['calibration']['read']:.3f} (calibrated on k_scale: 8n bytes "
+                   f"each way), WRITE_SIZE x {d['calibration']['write']:.3f}")
+    except Exception as e:  # noqa: BLE001 - informational: the committed figure stays
+        return None, f"live PMC passes failed: {e!r}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def spmv_block(op, ms, launches, fused):
@@ -546,6 +608,11 @@ def main():
         exchange_desc = f", {transport_name} all-gather of the Krylov vector per SpMV" + (f" ({exchange_note})" if exchange_note else "")
     if rank == 0:
         traffic, traffic_file = pmc_traffic(args.n, fmt, post_scaled=args.orth.startswith("onesweep")) if world == 1 else (None, None)
+        traffic_committed, live_note = traffic, "not attempted (--no-live-pmc or more than one rank)"
+        if world == 1 and not args.no_live_pmc:
+            live, live_note = live_pmc_traffic(args.n, fmt, args.orth.startswith("onesweep"))
+            if live is not None:
+                traffic, traffic_file = live, None
         out = {
             "metric": "eigenpairs_per_sec",
             "value": total_pairs / elapsed,
@@ -586,9 +653,10 @@ def main():
                 "unit": "GB/s",
                 "frac": head["frac"],
                 "traffic": traffic,
-                "traffic_source": (f"profiles/{traffic_file}: " if traffic_file else "") +
-                                  "HBM bytes per launch of the in-loop SpMV instantiation from rocprofv3 PMC passes (FETCH_SIZE x calibration + "
-                                  "WRITE_SIZE, separate runs; see profiles/README.md)",
+                "traffic_source": ((f"profiles/{traffic_file}: HBM bytes per launch of the in-loop SpMV instantiation from the committed rocprofv3 PMC "
+                                    f"passes (FETCH_SIZE x calibration + WRITE_SIZE, separate runs; see profiles/README.md); live passes: {live_note}")
+                                   if traffic_file or traffic is None else live_note),
+                "traffic_committed": traffic_committed,
                 "bytes_per_launch": head["bytes_per_launch"],
                 "bytes_note": {0: "CSR int32: 12 nnz + 4 (rows+1) + 8 cols + 8 rows (SURVEY.md 8d) + 16 rows for the fused epilogue's v_prev / v reads",
                                1: "offset-coded CSR: 9 nnz + 4 (rows+1) + 8 cols + 8 rows + 16 rows for the fused epilogue's v_prev / v reads",

@@ -27,7 +27,7 @@ torch.cuda.synchronize()
 # (PROBE_FORMATS=2,1,0: diagonal storage, offset-coded CSR, int32 CSR)
 for fmt in [int(f) for f in os.environ.get("PROBE_FORMATS", "2,1,0").split(",")]:
     op.set_spmv_format(fmt)
-    for _ in range(5):
+    for _ in range(int(os.environ.get("PROBE_SPMV_REPS", 5))):
         op.spmv_device(x.data_ptr(), y.data_ptr())
     ctx.sync()
     # the reference flow (k_scale_step — the calibration kernel —, fused SpMV, RESID_VTF, CORRECT_VTF), then the one-sweep steps

@@ -31,31 +31,40 @@ def short(name):
     return name.split("(")[0][:60]
 
 
-def main():
-    fetch = load(sys.argv[1], "FETCH_SIZE")
-    write = load(sys.argv[2], "WRITE_SIZE")
-    n = int(sys.argv[3]) if len(sys.argv) > 3 else 10_000_000
+def summarize(fetch_csv, write_csv, n, verbose=False):
+    """{"n", "calibration", "source", "kernels": {name: {"launches", "hbm_bytes"}}} from the two counter-collection CSVs."""
+    fetch = load(fetch_csv, "FETCH_SIZE")
+    write = load(write_csv, "WRITE_SIZE")
     known = 8.0 * n
     cal_r = cal_w = 1.0
+    calibrated = False
     for k in fetch:
         if "k_scale" in k:
             cal_r = known / (1024.0 * sum(fetch[k]) / len(fetch[k]))
+            calibrated = True
     for k in write:
         if "k_scale" in k:
             cal_w = known / (1024.0 * sum(write[k]) / len(write[k]))
-    print(f"calibration on k_scale (8n = {known:.3e} B each way): read x{cal_r:.3f}, write x{cal_w:.3f}")
-    print(f"{'kernel':62s} {'launches':>8s} {'fetch_raw_MB':>13s} {'write_raw_MB':>13s} {'hbm_corrected_MB':>17s}")
+    if verbose:
+        print(f"calibration on k_scale (8n = {known:.3e} B each way): read x{cal_r:.3f}, write x{cal_w:.3f}")
+        print(f"{'kernel':62s} {'launches':>8s} {'fetch_raw_MB':>13s} {'write_raw_MB':>13s} {'hbm_corrected_MB':>17s}")
     kernels = {}
     for k in sorted(fetch, key=lambda k: -sum(fetch[k])):
         fr = 1024.0 * sum(fetch[k]) / len(fetch[k])
         wr = 1024.0 * sum(write.get(k, [0.0])) / max(len(write.get(k, [0.0])), 1)
-        print(f"{short(k):62s} {len(fetch[k]):8d} {fr / 1e6:13.2f} {wr / 1e6:13.2f} {(fr * cal_r + wr * cal_w) / 1e6:17.2f}")
+        if verbose:
+            print(f"{short(k):62s} {len(fetch[k]):8d} {fr / 1e6:13.2f} {wr / 1e6:13.2f} {(fr * cal_r + wr * cal_w) / 1e6:17.2f}")
         kernels[short(k)] = {"launches": len(fetch[k]), "hbm_bytes": fr * cal_r + wr * cal_w}
+    return {"n": n, "calibration": {"read": cal_r, "write": cal_w, "on": "k_scale (8n bytes each way)", "found": calibrated},
+            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/pmc_probe.py", "kernels": kernels}
+
+
+def main():
+    n = int(sys.argv[3]) if len(sys.argv) > 3 else 10_000_000
+    d = summarize(sys.argv[1], sys.argv[2], n, verbose=True)
     if len(sys.argv) > 4:
         with open(sys.argv[4], "w") as f:
-            json.dump({"n": n, "calibration": {"read": cal_r, "write": cal_w, "on": "k_scale (8n bytes each way)"},
-                       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/pmc_probe.py",
-                       "kernels": kernels}, f, indent=1)
+            json.dump(d, f, indent=1)
 
 
 if __name__ == "__main__":
