@@ -92,41 +92,44 @@ struct StLoad  // what a thread holds of one batch
     uint32_t rr;  // row | rank << kStRowBits, or 0xFFFFFFFF: no entry
 };
 
-// (measured, profiles/r07g: eight batches ahead cost the epilogue instantiation its registers — 0.69-0.77 ms against 0.46)
-constexpr int kStAhead = 4;                 // batches whose entries are in flight while one is being added
-constexpr int kStDescAhead = 2 * kStAhead;  // ... and whose chunk descriptors are (the entry loads depend on them)
+// (profiles/r07r: 8 chunk loads = 4 batches in flight; with one chunk per wavefront and batch, r07g, eight were too many)
+constexpr int kStAhead = 8;                 // chunk loads of a wavefront in flight while a batch is being added
+constexpr int kStDescAhead = 2 * kStAhead;  // ... and chunk descriptors (the entry loads depend on them)
+static_assert(kStAhead % kStPerWave == 0, "staged format: the ring holds whole batches");
 
 // A batch = one chunk per wavefront (<= 64 entries that are contiguous in phase-1 order, i.e. a piece of one bin's share of one
 // column block); desc = phase-1 position | entries << 32 | rounds of the batch << 40.  Nothing of a batch passes through LDS
 // tables and no load sits between two barriers: per batch the workgroup only meets for the rank rounds.
 template <bool EPI>
-__global__ __launch_bounds__(kStThreads) void k_staged_rows(const int32_t* __restrict__ bin_batch, const uint64_t* __restrict__ desc,
+__global__ __launch_bounds__(kStRowThreads) void k_staged_rows(const int32_t* __restrict__ bin_batch, const uint64_t* __restrict__ desc,
                                                              const uint16_t* __restrict__ rowrank, const double* __restrict__ prod,
                                                              double* __restrict__ y, int64_t nrows, int nblocks256, int bin_rows, SpmvEpilogue epi)
 {
     __shared__ double acc[kStRows];  // 64 KiB: two workgroups per CU
-    __shared__ double red[(kStRows / kStThreads) * (kStThreads / 64)];  // wave sums of the epilogue
+    __shared__ double red[(kStRows / kStRowThreads) * (kStRowThreads / 64)];  // wave sums of the epilogue
     if (EPI && epi.status && *epi.status != 0)
         return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bin = int(blockIdx.x);
 #pragma unroll
-    for (int k = 0; k < kStRows / kStThreads; k++)
-        acc[k * kStThreads + tid] = 0.0;
-    const int b0 = bin_batch[bin], b1 = bin_batch[bin + 1];
-    constexpr int kWaves = kStThreads / 64;
+    for (int k = 0; k < kStRows / kStRowThreads; k++)
+        acc[k * kStRowThreads + tid] = 0.0;
+    // chunk slots of this wavefront: kStPerWave per batch
+    const int q0 = bin_batch[bin] * kStPerWave, q1 = bin_batch[bin + 1] * kStPerWave;
+    constexpr int kWaves = kStRowThreads / 64;
 
-    auto load_desc = [&](int b) -> uint64_t { return (b < b1) ? desc[int64_t(b) * kWaves + w] : 0ull; };
-    auto fetch = [&](int b, uint64_t d) {
+    auto load_desc = [&](int q) -> uint64_t { return (q < q1) ? desc[int64_t(q) * kWaves + w] : 0ull; };
+    auto fetch = [&](uint64_t d) {
         StLoad L;
         L.p = 0.0;
         const int cnt = int((d >> 32) & 0xFFu);
         uint32_t rr = 0x1FFFFu;  // no entry: a rank no round reaches (bit 16)
+        static_assert(kStRowBits + kStRankBits == 16 && kStRows % kStRowThreads == 0 && kStRowThreads % 256 == 0, "staged format: field layout");
         if (lane < cnt)
         {
             L.p = __builtin_nontemporal_load(prod + (int64_t(uint32_t(d)) + lane));
-            rr = uint32_t(__builtin_nontemporal_load(rowrank + ((int64_t(b) * kWaves + w) << 6) + lane));
+            rr = uint32_t(__builtin_nontemporal_load(rowrank + (int64_t(uint32_t(d)) + lane)));  // stored at the entry's phase-1 position
         }
         L.rr = rr | (uint32_t((d >> 40) & 0xFFu) << 20);
         return L;
@@ -136,47 +139,57 @@ __global__ __launch_bounds__(kStThreads) void k_staged_rows(const int32_t* __res
     StLoad ring[kStAhead];
 #pragma unroll
     for (int d = 0; d < kStDescAhead; d++)
-        dq[d] = load_desc(b0 + d);
+        dq[d] = load_desc(q0 + d);
 #pragma unroll
     for (int d = 0; d < kStAhead; d++)
-        ring[d] = fetch(b0 + d, dq[d]);
+        ring[d] = fetch(dq[d]);
     __syncthreads();  // accumulators zeroed
-    for (int b = b0; b < b1; b += kStDescAhead)
+    for (int q = q0; q < q1; q += kStDescAhead)
     {
 #pragma unroll
-        for (int u = 0; u < kStDescAhead; u++)
+        for (int ub = 0; ub < kStDescAhead / kStPerWave; ub++)
         {
-            const int bb = b + u;
-            if (bb >= b1)
+            const int qq = q + ub * kStPerWave;
+            if (qq >= q1)
                 break;
-            const StLoad cur = ring[u % kStAhead];
-            ring[u % kStAhead] = fetch(bb + kStAhead, dq[(u + kStAhead) % kStDescAhead]);
-            dq[u] = load_desc(bb + kStDescAhead);
-            const int rounds = __builtin_amdgcn_readfirstlane(int(cur.rr >> 20));  // the same for every thread of the batch
-            const int row = int(cur.rr & uint32_t(kStRows - 1));
-            const int rank = int((cur.rr >> kStRowBits) & 0xFu);  // 8..15: no entry
+            StLoad cur[kStPerWave];
+#pragma unroll
+            for (int c = 0; c < kStPerWave; c++)
+            {
+                const int u = ub * kStPerWave + c;
+                cur[c] = ring[u % kStAhead];
+                ring[u % kStAhead] = fetch(dq[(u + kStAhead) % kStDescAhead]);
+                dq[u] = load_desc(qq + c + kStDescAhead);
+            }
+            const int rounds = __builtin_amdgcn_readfirstlane(int(cur[0].rr >> 20));  // the same in every descriptor of the batch
             for (int r = 0; r < rounds; r++)
             {
-                if (rank == r)
+#pragma unroll
+                for (int c = 0; c < kStPerWave; c++)
                 {
+                    const int row = int(cur[c].rr & uint32_t(kStRows - 1));
+                    const int rank = int((cur[c].rr >> kStRowBits) & uint32_t((2 << kStRankBits) - 1));  // > kStMaxRank: no entry
+                    if (rank == r)
+                    {
 #pragma clang fp contract(off)
-                    acc[row] = acc[row] + cur.p;  // entries of one rank address distinct rows
+                        acc[row] = acc[row] + cur[c].p;  // entries of one rank address distinct rows
+                    }
                 }
                 __syncthreads();
             }
         }
     }
-    if (b0 == b1)
+    if (q0 == q1)
         __syncthreads();
 
     // rows of the bin -> y, in the 256-row records of the CSR kernels (identical alpha partials: wave sums by the same shuffle
     // tree, then (w0 + w1) + (w2 + w3) per record)
     const int64_t row0 = int64_t(bin) * bin_rows;
-    constexpr int kWavesPer = kStThreads / 64;
+    constexpr int kWavesPer = kStRowThreads / 64;
 #pragma unroll
-    for (int j = 0; j < kStRows / kStThreads; j++)
+    for (int j = 0; j < kStRows / kStRowThreads; j++)
     {
-        const int lr = j * kStThreads + tid;
+        const int lr = j * kStRowThreads + tid;
         const int64_t row = row0 + lr;
         double contrib = 0.0;
         if (lr < bin_rows && row < nrows)
@@ -331,10 +344,13 @@ bool build_staged(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int
     });
     out.nnz = nnz;
     // phase 2, bin by bin: chunks of <= 64 phase-1-contiguous entries, kStWaves chunks per batch, ranks inside the batch
+    out.rowrank.resize_uninitialized(size_t(slots));  // row inside the bin | rank, at the entry's phase-1 position (padding: never read)
+    for (int64_t c = 0; c < ncb; c++)
+        if (cb_ptr[size_t(c) + 1] > cb_ptr[size_t(c)])
+            out.rowrank[size_t(cb_ptr[size_t(c) + 1] - 1)] = 0;
     struct BinOut
     {
-        std::vector<uint64_t> desc;     // kStWaves per batch
-        std::vector<uint16_t> rowrank;  // kStThreads per batch
+        std::vector<uint64_t> desc;     // kStBatchChunks per batch
         int64_t chunks = 0;
     };
     std::vector<BinOut> bins(static_cast<size_t>(nbins));
@@ -351,8 +367,7 @@ bool build_staged(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int
             size_t base = 0;  // the open batch's first descriptor
             auto open = [&]() {
                 base = B.desc.size();
-                B.desc.resize(base + kStWaves, 0ull);
-                B.rowrank.resize(B.rowrank.size() + kStThreads, uint16_t(0));
+                B.desc.resize(base + kStBatchChunks, 0ull);
                 nch = 0;
                 cnt = 0;
                 maxrank = 0;
@@ -360,7 +375,7 @@ bool build_staged(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int
                 batch_no++;
             };
             auto close = [&]() {  // the rounds of the batch into every descriptor
-                for (int g = 0; g < kStWaves; g++)
+                for (int g = 0; g < kStBatchChunks; g++)
                     B.desc[base + size_t(g)] |= uint64_t(maxrank + 1) << 40;
             };
             bool is_open = false;
@@ -377,7 +392,7 @@ bool build_staged(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int
                     }
                     int rank = (stamp[size_t(r)] == batch_no) ? int(seen[size_t(r)]) : 0;
                     bool new_chunk = (s != last_slot + 1) || cnt == kStChunk;
-                    if (rank > kStMaxRank || (new_chunk && nch == kStWaves))
+                    if (rank > kStMaxRank || (new_chunk && nch == kStBatchChunks))
                     {
                         close();
                         open();
@@ -391,7 +406,7 @@ bool build_staged(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int
                         cnt = 0;
                         B.chunks++;
                     }
-                    B.rowrank[(base + size_t(nch - 1)) * kStChunk + size_t(cnt)] = uint16_t(r | (rank << kStRowBits));
+                    out.rowrank[size_t(s)] = uint16_t(r | (rank << kStRowBits));  // a slot belongs to one bin: no two threads meet
                     cnt++;
                     B.desc[base + size_t(nch - 1)] = (B.desc[base + size_t(nch - 1)] & 0xFFFFFFFFull) | (uint64_t(cnt) << 32);
                     stamp[size_t(r)] = batch_no;
@@ -410,13 +425,12 @@ bool build_staged(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int
     out.nchunks = 0;
     for (int64_t bin = 0; bin < nbins; bin++)
     {
-        nb += int64_t(bins[size_t(bin)].desc.size()) / kStWaves;
+        nb += int64_t(bins[size_t(bin)].desc.size()) / kStBatchChunks;
         out.bin_batch[size_t(bin) + 1] = int32_t(nb);
         out.nchunks += bins[size_t(bin)].chunks;
     }
     out.nbatches = nb;
-    out.desc.resize_uninitialized(size_t(nb) * kStWaves);
-    out.rowrank.resize_uninitialized(size_t(nb) * kStThreads);
+    out.desc.resize_uninitialized(size_t(nb) * kStBatchChunks);
     parallel_ranges(nbins, nt, [&](int, int64_t bin0, int64_t bin1) {
         for (int64_t bin = bin0; bin < bin1; bin++)
         {
@@ -424,8 +438,7 @@ bool build_staged(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int
             const size_t at = size_t(out.bin_batch[size_t(bin)]);
             if (!B.desc.empty())
             {
-                std::memcpy(out.desc.data() + at * kStWaves, B.desc.data(), B.desc.size() * sizeof(uint64_t));
-                std::memcpy(out.rowrank.data() + at * kStThreads, B.rowrank.data(), B.rowrank.size() * sizeof(uint16_t));
+                std::memcpy(out.desc.data() + at * kStBatchChunks, B.desc.data(), B.desc.size() * sizeof(uint64_t));
             }
         }
     });
@@ -452,15 +465,15 @@ void staged_spmv_host(const HostStaged& S, const double* x, double* y)
         std::fill(acc.begin(), acc.end(), 0.0);
         for (int64_t b = S.bin_batch[size_t(bin)]; b < S.bin_batch[size_t(bin) + 1]; b++)
         {
-            const int rounds = int((S.desc[size_t(b) * kStWaves] >> 40) & 0xFFu);
+            const int rounds = int((S.desc[size_t(b) * kStBatchChunks] >> 40) & 0xFFu);
             for (int r = 0; r < rounds; r++)
-                for (int g = 0; g < kStWaves; g++)
+                for (int g = 0; g < kStBatchChunks; g++)
                 {
-                    const uint64_t d = S.desc[size_t(b) * kStWaves + size_t(g)];
+                    const uint64_t d = S.desc[size_t(b) * kStBatchChunks + size_t(g)];
                     const int cnt = int((d >> 32) & 0xFFu);
                     for (int t = 0; t < cnt; t++)
                     {
-                        const uint16_t rr = S.rowrank[(size_t(b) * kStWaves + size_t(g)) * kStChunk + size_t(t)];
+                        const uint16_t rr = S.rowrank[size_t(uint32_t(d)) + size_t(t)];
                         if ((rr >> kStRowBits) == r)
                             acc[size_t(rr & (kStRows - 1))] += prod[size_t(uint32_t(d)) + size_t(t)];
                     }
@@ -527,10 +540,10 @@ void launch_spmv_staged(const DevStaged& S, hipStream_t stream, const double* x,
     hipLaunchKernelGGL(k_staged_products, dim3(unsigned(S.npieces)), dim3(kStThreads), 0, stream, S.pieces.p, S.val.p, S.lcol.p, x, S.prod.p,
                        ncols, status);
     if (epi)
-        hipLaunchKernelGGL((k_staged_rows<true>), dim3(unsigned(S.nbins)), dim3(kStThreads), 0, stream, S.bin_batch.p, S.desc.p, S.rowrank.p, S.prod.p, y, nrows,
+        hipLaunchKernelGGL((k_staged_rows<true>), dim3(unsigned(S.nbins)), dim3(kStRowThreads), 0, stream, S.bin_batch.p, S.desc.p, S.rowrank.p, S.prod.p, y, nrows,
                            nblocks256, S.bin_rows, e);
     else
-        hipLaunchKernelGGL((k_staged_rows<false>), dim3(unsigned(S.nbins)), dim3(kStThreads), 0, stream, S.bin_batch.p, S.desc.p, S.rowrank.p, S.prod.p, y, nrows,
+        hipLaunchKernelGGL((k_staged_rows<false>), dim3(unsigned(S.nbins)), dim3(kStRowThreads), 0, stream, S.bin_batch.p, S.desc.p, S.rowrank.p, S.prod.p, y, nrows,
                            nblocks256, S.bin_rows, e);
     if (ev_stop)
         MISPEC_HIP(hipEventRecord(ev_stop, stream));
@@ -559,7 +572,7 @@ extern "C" int mispec_staged_spmv_host(int64_t nrows, int64_t ncols, const int32
             stats[3] = S.nchunks;
             int64_t rounds = 0;
             for (int64_t b = 0; b < S.nbatches; b++)
-                rounds = std::max<int64_t>(rounds, int64_t((S.desc[size_t(b) * mispec::kStWaves] >> 40) & 0xFFu));
+                rounds = std::max<int64_t>(rounds, int64_t((S.desc[size_t(b) * mispec::kStBatchChunks] >> 40) & 0xFFu));
             stats[4] = rounds;
         }
     });

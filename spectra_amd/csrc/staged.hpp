@@ -4,13 +4,13 @@
 //
 //   phase 1  entries in COLUMN-BLOCK-major order (blocks of 8192 columns): a workgroup stages its block of x in LDS (64 KiB),
 //            streams value + 16-bit local column of its entries and writes the products, in the same order — a pure stream.
-//   phase 2  a workgroup owns a BIN of 8192 rows (64 KiB of accumulators in LDS) and adds the bin's products in batches: one
-//            CHUNK per wavefront, a chunk being <= 64 entries that are contiguous in phase-1 order (a piece of the bin's share of
-//            one column block), chunks and batches following the column blocks.  Inside a batch the entries of one row are
+//   phase 2  a workgroup owns a BIN of 8192 rows (64 KiB of accumulators in LDS) and adds the bin's products in batches: two
+//            CHUNKS per wavefront, a chunk being <= 64 entries that are contiguous in phase-1 order (a piece of the bin's share
+//            of one column block), chunks and batches following the column blocks.  Inside a batch the entries of one row are
 //            ranked in column order and applied rank by rank with a barrier in between: every row is summed in ascending column
 //            order, one accumulator, i.e. exactly the CSR row sum of the other kernels and of the oracle (bit-identical results).
-// Bytes per entry: phase 1 reads 10 and writes 8, phase 2 reads 8 + 2 / (fill of the chunks) + the descriptors, about 29 in
-// all, against 12 + a gather.
+// Bytes per entry: phase 1 reads 10 and writes 8, phase 2 reads 8 + 2 (row | rank, stored at the entry's phase-1 position like
+// the product) + the descriptors (8 per chunk), about 28.2 in all, against 12 + a gather.
 #pragma once
 #include <vector>
 
@@ -22,8 +22,14 @@ constexpr int kStRowBits = 13;                  // rows per bin: 8192 (64 KiB of
 constexpr int kStRows = 1 << kStRowBits;        // matrices that would otherwise have fewer bins than the device holds workgroups
 constexpr int kStColBits = 13;                  // columns per block: 8192 (64 KiB of x)
 constexpr int kStCols = 1 << kStColBits;
-constexpr int kStThreads = 1024;                // both kernels: two workgroups per CU
-constexpr int kStWaves = kStThreads / 64;       // chunks per batch: one per wavefront
+constexpr int kStThreads = 1024;                // phase 1: two workgroups per CU
+constexpr int kStRowThreads = 1024;             // phase 2 (4096-row bins with 512 threads: the same time, profiles/r07q)
+constexpr int kStWaves = kStRowThreads / 64;
+// chunks a wavefront adds per batch.  Phase 2 is bound by its chain of rank rounds (one LDS read-add-write and a barrier each,
+// about 3 per batch whatever its size up to here): two chunks per wavefront halve the rounds per entry — 0.468 -> 0.402 ms on
+// M-rand; four gain nothing more (profiles/r07r)
+constexpr int kStPerWave = 2;
+constexpr int kStBatchChunks = kStWaves * kStPerWave;  // chunks per batch: chunk j of a batch goes to wavefront j % kStWaves
 constexpr int kStChunk = 64;                    // entries per chunk: one per lane
 constexpr int kStRankBits = 16 - kStRowBits;    // 3: an entry's rank among the entries of its row inside its batch
 constexpr int kStMaxRank = (1 << kStRankBits) - 1;
@@ -44,10 +50,10 @@ struct HostStaged
     RawVec<double> val;            // [slots] phase-1 order; padding slots carry 0.0
     RawVec<uint16_t> lcol;         // [slots] column inside the block
     std::vector<StPiece> pieces;   // phase-1 work list
-    // phase 2: batch b of a bin = chunks [b * kStWaves, (b + 1) * kStWaves)
+    // phase 2: batch b of a bin = chunks [b * kStBatchChunks, (b + 1) * kStBatchChunks)
     std::vector<int32_t> bin_batch;    // nbins + 1
-    RawVec<uint64_t> desc;         // [batches * kStWaves] phase-1 position of the chunk | entries << 32 | rounds of its batch << 40
-    RawVec<uint16_t> rowrank;      // [batches * kStThreads] per chunk 64 slots: row inside the bin | rank << kStRowBits
+    RawVec<uint64_t> desc;         // [batches * kStBatchChunks] phase-1 position of the chunk | entries << 32 | rounds of its batch << 40
+    RawVec<uint16_t> rowrank;      // [slots] phase-1 order like val: row inside the bin | rank << kStRowBits
     int64_t nbatches = 0, nchunks = 0;  // nchunks: chunks that hold entries
 };
 
@@ -72,7 +78,7 @@ struct DevStaged
     // bytes one product has to move (both phases, incl. the product array's round trip and the tables)
     double stored_bytes(int64_t n_rows, int64_t n_cols) const
     {
-        return 18.0 * double(slots) + 8.0 * double(nnz) + (2.0 * kStChunk + 8.0) * double(nchunks) + 16.0 * double(npieces) +
+        return 18.0 * double(slots) + 10.0 * double(nnz) + 8.0 * double(kStBatchChunks) * double(nbatches) + 16.0 * double(npieces) +
                8.0 * double(n_cols) + 8.0 * double(n_rows);
     }
 };
