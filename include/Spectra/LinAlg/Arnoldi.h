@@ -80,6 +80,8 @@ struct has_device_dense<T, void_t<decltype(std::declval<const T&>().mispec_dense
 {};
 // user operator that works on device pointers:
 //   void perform_op_device(const Scalar* x_dev, Scalar* y_dev, void* hip_stream) const
+// It ENQUEUES y = Op(x) on hip_stream (a hipStream_t) and returns; the steps of a sweep are enqueued ahead of their execution,
+// so x_dev is valid in stream order only (mispec.h, mispec_device_op_fn).
 template <typename T, typename = void>
 struct has_device_perform_op : std::false_type
 {};

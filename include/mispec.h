@@ -253,7 +253,12 @@ int mispec_fac_create(mispec_ctx* ctx, const mispec_csr* A, mispec_op_fn op, voi
 /* User operator on DEVICE pointers: y_dev = Op(x_dev) for n doubles each, enqueued on hip_stream (a hipStream_t; the
  * factorisation's own stream — do not synchronise it).  No staging: the Krylov vectors never leave HBM.  This is the
  * perform_op contract of the reference (SymEigsSolver.h:43-51) with the two pointers in device memory; x_dev may be a
- * column of V and must not be written.  Must return 0 on success. */
+ * column of V and must not be written.  Must return 0 on success.
+ * The steps of a sweep are enqueued ahead of their execution (device-driven steps, since round 4 for these operators too):
+ * the callback runs while earlier steps are still queued, so x_dev holds its data only in stream order — work issued on
+ * another stream, or host code that reads x_dev, would see stale values.  A sweep that the device-side control flow stops
+ * (a rare branch of Lanczos.h:99-181 / Arnoldi.h:228-291) has its remaining steps enqueued already; they turn into no-ops on
+ * the library's side and the host path repeats them, so the callback can be invoked more often than num_operations() counts. */
 typedef int (*mispec_device_op_fn)(void* user, const double* x_dev, double* y_dev, void* hip_stream);
 int mispec_fac_create_device_op(mispec_ctx* ctx, mispec_device_op_fn op, void* op_user, int64_t n, int ncv, int symmetric,
                                 mispec_fac** out);
