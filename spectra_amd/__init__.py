@@ -926,7 +926,7 @@ class SymEigsSolver:
     def set_orth_mode(self, mode):
         """'onesweep' (default: the correction of a step rides on the next step's pass over V, include/mispec.h
         mispec_fac_set_orth_mode) or 'reference' (Lanczos.h:145-181, two passes over V per step; also MISPEC_ORTH=reference in
-        the environment).  Call before init().  Where the one-sweep steps do not apply (ncv > 64, generalized problems, user
+        the environment).  Call before init().  Where the one-sweep steps do not apply (ncv > 128, generalized problems, host-pointer user
         operators) the reference flow runs whatever is set: orth_info()['mode'] says which one is in effect."""
         check(lib().mispec_symeigs_set_orth_mode(self.h, _orth_mode_value(mode)))
 

@@ -1092,9 +1092,11 @@ void factorize_lanczos(mispec_fac& F, int from_k, int to_m, int64_t* nmatop)
     // solver's product), and since round 4 the banded / dense shift-solve, dense matrices and user operators on device pointers
     // (their Lanczos epilogue is a kernel of its own that reads H(i,i-1) and the stop flag from device memory)
     const bool fast = F.device_steps && device_operator(F) && !F.bmode() && F.Chol == nullptr;
-    const bool lagged = fast && F.onesweep && F.m <= kPanelCols;  // standard problems (incl. the product operator of the SVD solver), one column panel
+    // standard problems (incl. the product operator of the SVD solver); bases of up to 128 columns (k_orth_lagged with 4 or 8 wavefronts)
+    const bool lagged = fast && F.onesweep && F.m <= 2 * kPanelCols;
     // a sweep that completes the factorisation is followed by a restart (or by nothing that needs f): its last correction can wait
-    const bool defer = lagged && to_m == F.m && !F.eager_last && !F.eager_sticky && !small_on_device();
+    // — for the fused restart (k_vq_fused: one column panel); wider bases finish every sweep the reference's way
+    const bool defer = lagged && F.m <= kPanelCols && to_m == F.m && !F.eager_last && !F.eager_sticky && !small_on_device();
     F.end_pending = false;
     int i = from_k;
     while (i <= to_m - 1)
@@ -1846,7 +1848,7 @@ extern "C" int mispec_fac_orth_info(const mispec_fac* fac, int* mode, int64_t* l
     return guarded([&] {
         MISPEC_REQUIRE(fac, "mispec_fac_orth_info: NULL argument");
         const bool active = fac->onesweep && fac->device_steps && fac->symmetric && device_operator(*fac) && !fac->bmode() && !fac->Chol &&
-                            fac->m <= kPanelCols;
+                            fac->m <= 2 * kPanelCols;
         if (mode)
             *mode = active ? (MISPEC_ORTH_ONESWEEP | ((fac->eager_last || fac->eager_sticky) ? MISPEC_ORTH_EAGER_LAST : 0) |
                               (fac->test_recorrect ? MISPEC_ORTH_TEST_RECORRECT : 0))

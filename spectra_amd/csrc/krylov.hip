@@ -235,12 +235,15 @@ __global__ __launch_bounds__(kThreads) void k_orth(OrthArgs a)
 //   chk_j = <V_j, v_i> ;  dst = w - alpha v_i -> f ;  c_j = <V_j, dst>, c_i = <v_i, dst>, |dst|^2
 // Same tiling, load pattern and record layout as k_orth; with c_in = 0 (no pending correction) column i is rewritten
 // with the bits k_scale_step gave it.
-template <int MAXS, int R>
-__global__ __launch_bounds__(kThreads) void k_orth_lagged(OrthArgs a)
+// NW wavefronts per workgroup: 4 (up to 63 finished columns) or 8 (64..127: bases of up to 128 columns, round 4 — the same
+// 16 columns per wavefront, twice the row sums through LDS).
+template <int MAXS, int R, int NW>
+__global__ __launch_bounds__(64 * NW) void k_orth_lagged(OrthArgs a)
 {
     constexpr int kRows = kTileRows * R;
-    __shared__ double cs[kPanelCols];
-    __shared__ __attribute__((aligned(16))) double psum[2][4][kRows];
+    constexpr int kCols = 16 * NW;
+    __shared__ double cs[kCols];
+    __shared__ __attribute__((aligned(16))) double psum[2][NW][kRows];
 
     if (a.status && *a.status != kStepOk)
         return;
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(kThreads) void k_orth_lagged(OrthArgs a)
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool pending = *a.pending != 0;
-    if (tid < kPanelCols)
+    if (tid < kCols)
         cs[tid] = (pending && tid < a.ncol) ? a.c_in[tid] : 0.0;
     __syncthreads();
     const double alpha = *a.alpha_dev;
@@ -259,9 +262,9 @@ __global__ __launch_bounds__(kThreads) void k_orth_lagged(OrthArgs a)
 #pragma unroll
     for (int jj = 0; jj < MAXS; jj++)
     {
-        const int j = w + 4 * jj;
+        const int j = w + NW * jj;
         colp[jj] = a.V + int64_t(j < a.ncol ? j : 0) * a.ldv;
-        cw[jj] = (j < kPanelCols) ? cs[j] : 0.0;
+        cw[jj] = (j < kCols) ? cs[j] : 0.0;
         acc[jj] = 0.0;
         chk[jj] = 0.0;
     }
@@ -322,8 +325,18 @@ __global__ __launch_bounds__(kThreads) void k_orth_lagged(OrthArgs a)
             const double2 p1 = *reinterpret_cast<const double2*>(&psum[buf][1][o]);
             const double2 p2 = *reinterpret_cast<const double2*>(&psum[buf][2][o]);
             const double2 p3 = *reinterpret_cast<const double2*>(&psum[buf][3][o]);
-            vi[q].x = (fv[q].x - ((p0.x + p1.x) + (p2.x + p3.x))) / beta;  // Lanczos.h:171 then :106 (true division)
-            vi[q].y = (fv[q].y - ((p0.y + p1.y) + (p2.y + p3.y))) / beta;
+            double px = (p0.x + p1.x) + (p2.x + p3.x), py = (p0.y + p1.y) + (p2.y + p3.y);
+            if (NW == 8)
+            {
+                const double2 p4 = *reinterpret_cast<const double2*>(&psum[buf][NW - 4][o]);
+                const double2 p5 = *reinterpret_cast<const double2*>(&psum[buf][NW - 3][o]);
+                const double2 p6 = *reinterpret_cast<const double2*>(&psum[buf][NW - 2][o]);
+                const double2 p7 = *reinterpret_cast<const double2*>(&psum[buf][NW - 1][o]);
+                px += (p4.x + p5.x) + (p6.x + p7.x);
+                py += (p4.y + p5.y) + (p6.y + p7.y);
+            }
+            vi[q].x = (fv[q].x - px) / beta;  // Lanczos.h:171 then :106 (true division)
+            vi[q].y = (fv[q].y - py) / beta;
             if (!valid[q])  // rows past the end were loaded from row 0 (clamped address): they must not reach the sums
             {
                 vi[q].x = 0.0;
@@ -366,7 +379,7 @@ __global__ __launch_bounds__(kThreads) void k_orth_lagged(OrthArgs a)
     {
         const double s = wave_reduce_sum(acc[jj]);
         const double c = wave_reduce_sum(chk[jj]);
-        const int j = w + 4 * jj;
+        const int j = w + NW * jj;
         if (lane == 0 && j < a.ncol)
         {
             rec[int64_t(j) * a.pstride] = s;
@@ -1257,17 +1270,42 @@ void launch_orth_mode(const mispec_ctx& ctx, const OrthArgs& a, int grid)
 
 void launch_orth_lagged(const mispec_ctx& ctx, const OrthArgs& a, int grid)
 {
+    const dim3 g(static_cast<unsigned>(grid));
+    if (a.ncol >= kPanelCols)  // 64..127 finished columns: eight wavefronts of 16 columns
+    {
+        const dim3 b8(512);
+        switch ((a.ncol + 7) / 8)
+        {
+#define MISPEC_LAG_CASE8(S)                                                     \
+    case S:                                                                     \
+        hipLaunchKernelGGL((k_orth_lagged<S, 1, 8>), g, b8, 0, ctx.stream, a); \
+        break;
+            MISPEC_LAG_CASE8(8)
+            MISPEC_LAG_CASE8(9)
+            MISPEC_LAG_CASE8(10)
+            MISPEC_LAG_CASE8(11)
+            MISPEC_LAG_CASE8(12)
+            MISPEC_LAG_CASE8(13)
+            MISPEC_LAG_CASE8(14)
+            MISPEC_LAG_CASE8(15)
+            default:
+                hipLaunchKernelGGL((k_orth_lagged<16, 1, 8>), g, b8, 0, ctx.stream, a);
+                break;
+#undef MISPEC_LAG_CASE8
+        }
+        return;
+    }
     const int slots = (a.ncol + 3) / 4;
     const bool two = slots <= 10;
-    const dim3 g(static_cast<unsigned>(grid)), b(kThreads);
+    const dim3 b(kThreads);
     switch (slots)
     {
 #define MISPEC_LAG_CASE(S)                                                  \
     case S:                                                                 \
         if (two)                                                            \
-            hipLaunchKernelGGL((k_orth_lagged<S, 2>), g, b, 0, ctx.stream, a); \
+            hipLaunchKernelGGL((k_orth_lagged<S, 2, 4>), g, b, 0, ctx.stream, a); \
         else                                                                \
-            hipLaunchKernelGGL((k_orth_lagged<S, 1>), g, b, 0, ctx.stream, a); \
+            hipLaunchKernelGGL((k_orth_lagged<S, 1, 4>), g, b, 0, ctx.stream, a); \
         break;
         case 0:
             MISPEC_LAG_CASE(1)
@@ -1286,7 +1324,7 @@ void launch_orth_lagged(const mispec_ctx& ctx, const OrthArgs& a, int grid)
             MISPEC_LAG_CASE(14)
             MISPEC_LAG_CASE(15)
         default:
-            hipLaunchKernelGGL((k_orth_lagged<16, 1>), g, b, 0, ctx.stream, a);
+            hipLaunchKernelGGL((k_orth_lagged<16, 1, 4>), g, b, 0, ctx.stream, a);
             break;
 #undef MISPEC_LAG_CASE
     }
@@ -1309,7 +1347,8 @@ int launch_orth_panel(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a, i
     {
         const int rows = orth_tile_rows(a.ncol);
         const int64_t ntiles = (a.n + rows - 1) / rows;
-        grid = persistent_grid(ctx, ntiles, 4);  // 3 and 6 workgroups per CU measured slower (profiles/r05b_ab_*)
+        // 3 and 6 workgroups per CU measured slower (profiles/r05b_ab_*); the 512-thread one-sweep kernel of wide bases: 2
+        grid = persistent_grid(ctx, ntiles, (mode == ORTH_LAGGED && a.ncol >= kPanelCols) ? 2 : 4);
     }
     MISPEC_REQUIRE(a.pstride >= grid, "orth kernel: partial-record stride smaller than the grid");
     switch (mode)
@@ -1345,8 +1384,8 @@ int launch_orth_panel(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a, i
 int launch_orth(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a)
 {
     MISPEC_REQUIRE(a.ncol >= 0 && a.ncol <= kMaxCols, "orth kernel: more than 1024 basis columns");
-    MISPEC_REQUIRE(mode != ORTH_LAGGED || (a.ncol >= 1 && a.ncol < kPanelCols), "one-sweep orth kernel: needs 1 <= columns <= 63");
-    if (a.ncol <= kPanelCols)
+    MISPEC_REQUIRE(mode != ORTH_LAGGED || (a.ncol >= 1 && a.ncol < 2 * kPanelCols), "one-sweep orth kernel: needs 1 <= columns <= 127");
+    if (a.ncol <= kPanelCols || mode == ORTH_LAGGED)
     {
         OrthArgs one = a;
         one.col0 = 0;

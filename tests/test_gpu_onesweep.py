@@ -98,10 +98,10 @@ def test_onesweep_on_the_benchmark_matrix(ctx, n):
 
 
 def test_onesweep_is_ignored_where_it_does_not_apply(ctx):
-    # ncv > 64 (column panels) keeps the reference's flow
+    # ncv > 128 (column panels) keeps the reference's flow
     A, S = sparse_fixture(1000, 0.01)
     op = sa.SparseSymMatProd(A, ctx=ctx)
-    eigs, nconv = solve(op, 20, 80, sa.SortRule.LargestAlge, "onesweep")
+    eigs, nconv = solve(op, 20, 130, sa.SortRule.LargestAlge, "onesweep")
     assert nconv == 20 and eigs.orth_info()["mode"] == "reference" and eigs.orth_info()["lagged_steps"] == 0
     assert np.abs(eigs.eigenvalues() - wanted_by_rule(GOLD["spectrum_1000"], "LargestAlge", 20)[::-1]).max() < 1e-9
 
@@ -257,3 +257,39 @@ def test_adversarial_cases_leave_the_lagged_path(ctx):
             check += info["check_stops"]
             state += info["state_stops"]
     assert state > 0 and check >= 0, (check, state)
+
+
+@pytest.mark.parametrize("n,k,m", [(1000, 30, 65), (1000, 40, 100), (30_001, 34, 80), (30_001, 50, 128), (200_000, 60, 127)])
+@pytest.mark.parametrize("rule", ["LargestAlge", "BothEnds"])
+def test_onesweep_on_wide_bases(ctx, n, k, m, rule):
+    # 64 < ncv <= 128: the one-sweep pass runs with eight wavefronts of 16 columns (k_orth_lagged<S, 1, 8>); the sweeps end the
+    # reference's way (the fused restart is a one-panel kernel).  Gate: the reference flow (column panels) and the oracle.
+    if n == 1000:
+        A, S = sparse_fixture(n, 0.01)
+        op = sa.SparseSymMatProd(A, ctx=ctx)
+        Sc = sp.csr_matrix(S)
+        Sc.sort_indices()
+        oop = O.Op.csr(n, n, Sc.indptr.astype(np.int32), Sc.indices.astype(np.int32), Sc.data)
+    else:
+        offsets = (1, 2, 3, 100, 101, 2000, 2001)
+        op = sa.SparseSymMatProd.synth_band(n, offsets=offsets, ctx=ctx)
+        rp, ci, v = O.synth_band_csr(n, offsets=offsets)
+        S = sp.csr_matrix((v, ci, rp), shape=(n, n))
+        oop = O.Op.csr(n, n, rp, ci, v)
+    ref, nconv_ref = solve(op, k, m, sa.SortRule[rule], "reference", maxit=1000, tol=1e-11)
+    one, nconv = solve(op, k, m, sa.SortRule[rule], "onesweep", maxit=1000, tol=1e-11)
+    assert one.info() == sa.CompInfo.Successful and nconv == nconv_ref == k
+    evals, evecs = one.eigenvalues(), one.eigenvectors()
+    assert (np.linalg.norm(S @ evecs - evecs * evals, axis=0) / np.linalg.norm(evecs, axis=0)).max() <= 1e-10
+    assert np.abs(evals - ref.eigenvalues()).max() < 1e-9
+    assert np.abs(evecs.T @ evecs - np.eye(k)).max() <= 1e-10
+    assert abs(one.num_operations() - ref.num_operations()) <= (m - k)
+    info = one.orth_info()
+    assert info["mode"] == "onesweep" and info["lagged_steps"] >= 0.8 * one.num_operations() and ref.orth_info()["lagged_steps"] == 0
+    assert info["fused_restarts"] == 0 and info["max_chk"] <= 64 * np.finfo(float).eps
+    if n <= 30_001:
+        o = O.SymEigsSolver(oop, k, m)
+        o.init()
+        assert o.compute(getattr(O, rule), 1000, 1e-11) == k
+        assert np.abs(np.sort(o.eigenvalues()) - np.sort(evals)).max() < 1e-9
+        assert abs(o.num_operations() - one.num_operations()) <= (m - k)
