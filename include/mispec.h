@@ -326,8 +326,8 @@ int mispec_fac_f_norm(const mispec_fac* fac, double* beta);  /* f_norm() */
  *     every case the reference treats specially (second correction, breakdown clamp, tiny beta, restart heuristics) leaves
  *     the lagged path and continues with the reference's loop.  Effective for ncv <= 128 on standard problems over every operator that
  *     works on device pointers (device matrices incl. the product operator A'A / AA' of the SVD solver, the shift solve of
- *     SymEigsShiftSolver, dense matrices, user operators on device pointers); ignored otherwise (generalized problems, user
- *     operators with host pointers, wider bases).  For 64 < ncv <= 128 every sweep ends the reference's way (no fused restart).
+ *     SymEigsShiftSolver, dense matrices, user operators on device pointers, the Cholesky mode of the generalized problem);
+ *     ignored otherwise (B-inner-product modes of the generalized problem, user operators with host pointers, wider bases).  For 64 < ncv <= 128 every sweep ends the reference's way (no fused restart).
  * mispec_fac_orth_info reports the mode in effect, the lagged steps executed, how often the lagged path was left because a
  * column needed a second correction (check_stops) or a correction could not be carried (state_stops), the largest accepted
  * |c|/|f| and the largest |V'v| measured after a lagged correction. */

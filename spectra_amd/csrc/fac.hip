@@ -498,7 +498,7 @@ void apply_op(mispec_fac& F, const double* x_loc, double* y_loc, bool lanczos_ep
             }
             if (lanczos_epi)
             {
-                launch_lanczos_epilogue(*F.ctx, y_loc, x_loc, v_prev, h_prev, F.nloc, F.alpha_partials.p);
+                launch_lanczos_epilogue(*F.ctx, y_loc, x_loc, v_prev, h_prev, F.nloc, F.alpha_partials.p, h_prev_dev, status);
                 launch_reduce_sum(*F.ctx, F.alpha_partials.p, lanczos_epilogue_records(*F.ctx, F.nloc), alpha_dev);
             }
             return;
@@ -1017,7 +1017,7 @@ void lanczos_step_lagged(mispec_fac& F, int i, bool last, bool defer)
     // Column i is written by the pass below (from f, with the pending correction); until then only the product needs f / beta.
     // On diagonal storage the SpMV takes the un-normalised f and divides its row sums instead (csr.hpp post_scale_state): the
     // scaling pass and its copy of f disappear.  Other formats: k_scale_step, as in the reference flow.
-    const bool post = F.A && !F.A2 && !F.perm_mode && spmv_can_post_scale(*F.A);
+    const bool post = F.A && !F.A2 && !F.Chol && !F.perm_mode && spmv_can_post_scale(*F.A);  // the plain product operator only
     if (post)
     {
         F.post_scale_step = i;
@@ -1090,8 +1090,9 @@ void factorize_lanczos(mispec_fac& F, int from_k, int to_m, int64_t* nmatop)
     zero_H_outside(F, from_k);
     // device-driven steps: every operator that works on device pointers without a host turn — device matrices (incl. the SVD
     // solver's product), and since round 4 the banded / dense shift-solve, dense matrices and user operators on device pointers
-    // (their Lanczos epilogue is a kernel of its own that reads H(i,i-1) and the stop flag from device memory)
-    const bool fast = F.device_steps && device_operator(F) && !F.bmode() && F.Chol == nullptr;
+    // (their Lanczos epilogue is a kernel of its own that reads H(i,i-1) and the stop flag from device memory), and the Cholesky
+    // mode of the generalized problem: L^{-1} A L^{-T} is a standard symmetric operator made of three enqueued products
+    const bool fast = F.device_steps && device_operator(F) && !F.bmode();
     // standard problems (incl. the product operator of the SVD solver); bases of up to 128 columns (k_orth_lagged with 4 or 8 wavefronts)
     const bool lagged = fast && F.onesweep && F.m <= 2 * kPanelCols;
     // a sweep that completes the factorisation is followed by a restart (or by nothing that needs f): its last correction can wait
@@ -1847,8 +1848,7 @@ extern "C" int mispec_fac_orth_info(const mispec_fac* fac, int* mode, int64_t* l
 {
     return guarded([&] {
         MISPEC_REQUIRE(fac, "mispec_fac_orth_info: NULL argument");
-        const bool active = fac->onesweep && fac->device_steps && fac->symmetric && device_operator(*fac) && !fac->bmode() && !fac->Chol &&
-                            fac->m <= 2 * kPanelCols;
+        const bool active = fac->onesweep && fac->device_steps && fac->symmetric && device_operator(*fac) && !fac->bmode() && fac->m <= 2 * kPanelCols;
         if (mode)
             *mode = active ? (MISPEC_ORTH_ONESWEEP | ((fac->eager_last || fac->eager_sticky) ? MISPEC_ORTH_EAGER_LAST : 0) |
                               (fac->test_recorrect ? MISPEC_ORTH_TEST_RECORRECT : 0))

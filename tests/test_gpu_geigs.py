@@ -204,9 +204,12 @@ def test_cholesky_mode_on_a_large_banded_pencil(ctx):
 
 @pytest.mark.parametrize("n,prob,k,m", GEIGS_CASES)
 @pytest.mark.parametrize("rule", RULES)
-def test_cholesky_fixtures(ctx, n, prob, k, m, rule):
+@pytest.mark.parametrize("orth", ["onesweep", "reference"])
+def test_cholesky_fixtures(ctx, n, prob, k, m, rule, orth):
+    # the Cholesky mode is a STANDARD symmetric problem for L^{-1} A L^{-T}: device-driven steps, one-sweep by default
     A, B, As = geigs_fixture(n, prob)
     eigs = sa.SymGEigsSolver(sa.SparseSymMatProd(A, ctx=ctx), sa.SparseCholesky(B, ctx=ctx), k, m, "Cholesky")
+    eigs.set_orth_mode(orth)
     eigs.init()
     nconv = eigs.compute(sa.SortRule[rule], 100)
     assert eigs.info() == sa.CompInfo.Successful and nconv == k
@@ -218,6 +221,8 @@ def test_cholesky_fixtures(ctx, n, prob, k, m, rule):
     assert oe.compute(getattr(O, rule), 100) == k
     assert np.abs(ev - oe.eigenvalues()).max() <= 1e-9 * max(1.0, np.abs(ev).max())
     assert eigs.num_operations() == pytest.approx(oe.num_operations(), rel=0.2)
+    info = eigs.orth_info()
+    assert info["mode"] == orth and (info["lagged_steps"] > 0) == (orth == "onesweep")
 
 
 def test_example3_issue115(ctx):
