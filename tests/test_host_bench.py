@@ -65,3 +65,54 @@ def test_cpu_baseline_is_the_first_sweep_plus_measured_restart_cycles():
     assert out["kind"] == "port" and out["cores"] == 1 and out["operations_first_sweep"] == A.ncv + 1
     assert out["operations_restart_cycles"] > 0 and "restart cycle" in out["sample"]
     assert 0.5 < out["estimated_seconds_per_solve"] / full < 2.0, (out["estimated_seconds_per_solve"], full)
+
+
+def test_pmc_summary_of_committed_counter_files():
+    # what bench.py's live PMC passes do with the two rocprofv3 CSVs, on the committed passes of round 3: FETCH_SIZE calibrated
+    # on the probe's k_scale launches (x 2 on gfx950), the fused SpMV instantiations found by name
+    import importlib.util
+
+    import bench
+
+    spec = importlib.util.spec_from_file_location("pmc_summarize", os.path.join(ROOT, "tools", "pmc_summarize.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    d = mod.summarize(os.path.join(ROOT, "profiles", "r06j_pmc_fetch_counter_collection.csv"),
+                      os.path.join(ROOT, "profiles", "r06j_pmc_write_counter_collection.csv"), 10_000_000)
+    assert d["calibration"]["found"] and abs(d["calibration"]["read"] - 2.0) < 0.01 and abs(d["calibration"]["write"] - 1.0) < 0.01
+    post = bench.fused_spmv_bytes(d["kernels"], 2, True)
+    plain = bench.fused_spmv_bytes(d["kernels"], 2, False)
+    assert abs(post / 1.52e9 - 1.0) < 0.02 and abs(plain / 1.52e9 - 1.0) < 0.02  # the bytes the kernel has to move, to 2 %
+    assert bench.fused_spmv_bytes(d["kernels"], 0, False) is None             # that probe ran the diagonal storage only
+
+
+def test_live_pmc_falls_back_without_a_profiler(monkeypatch):
+    # no rocprofv3 / a failing pass must leave the committed figure in place, never raise
+    import shutil
+
+    import bench
+
+    monkeypatch.setattr(shutil, "which", lambda name: None)
+    monkeypatch.setattr(os.path, "exists", lambda p: False if str(p).endswith("rocprofv3") else True)
+    value, note = bench.live_pmc_traffic(10_000_000, 2, True, timeout=5)
+    assert value is None and "rocprofv3" in note
+
+
+def test_live_pmc_reports_a_failed_pass():
+    # in this container rocprofv3 exists but there is no GPU: the probe exits non-zero, the function says which pass failed
+    import shutil
+
+    import bench
+
+    if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
+        import pytest
+
+        pytest.skip("no rocprofv3 here")
+    import torch
+
+    if torch.cuda.is_available():
+        import pytest
+
+        pytest.skip("a GPU is present: the passes would succeed")
+    value, note = bench.live_pmc_traffic(1_000_000, 2, True, timeout=120)
+    assert value is None and "pass" in note
