@@ -88,6 +88,8 @@ def lib():
             "ref_op_apply": (C.c_int, [op, dp, dp]),
             "ref_symeigs": (C.c_long, [op, C.c_long, C.c_long, dp, C.c_int, C.c_long, C.c_double, C.c_int, lp, dp, dp]),
             "ref_geneigs": (C.c_long, [op, C.c_long, C.c_long, dp, C.c_int, C.c_long, C.c_double, C.c_int, lp, dp, dp]),
+            "ref_symeigs_shift": (C.c_long, [op, C.c_long, C.c_long, C.c_double, dp, C.c_int, C.c_long, C.c_double, C.c_int, lp, dp, dp]),
+            "ref_geneigs_real_shift": (C.c_long, [op, C.c_long, C.c_long, C.c_double, dp, C.c_int, C.c_long, C.c_double, C.c_int, lp, dp, dp]),
             "ref_factorize": (C.c_int, [op, C.c_long, C.c_int, dp, dp, dp, dp, dp]),
             "ref_symeigs_time": (C.c_double, [op, C.c_long, C.c_long, C.c_long, C.c_double, lp]),
         }
@@ -272,6 +274,40 @@ def geneigs(op, nev, ncv, selection=LargestMagn, maxit=1000, tol=1e-10, sorting=
     v0a = None if v0 is None else np.ascontiguousarray(v0, dtype=np.float64)
     k = _check(lib().ref_geneigs(C.byref(op.c), nev, ncv, None if v0a is None else _dp(v0a), selection, maxit, tol, sorting,
                                  counters.ctypes.data_as(C.POINTER(C.c_long)), _dp(evals), None if evecs is None else _dp(evecs)))
+    r = Result()
+    r.nconv, r.num_iterations, r.num_operations, r.info = (int(c) for c in counters)
+    r.eigenvalues = evals.view(np.complex128)[:k].copy()
+    r.eigenvectors = None if evecs is None else evecs.view(np.complex128).reshape((n, nev), order="F")[:, :k].copy()
+    return r
+
+
+def symeigs_shift(op, nev, ncv, sigma, selection=LargestMagn, maxit=1000, tol=1e-10, sorting=LargestAlge, v0=None, vectors=True):
+    """SymEigsShiftSolver<Op>(op, nev, ncv, sigma) of the reference; `op` is a callback operator that applies
+    (A - sigma I)^{-1} (the reference's SparseSymShiftSolve delegates to Eigen::SparseLU, which the stand-in does not have)."""
+    n = op.n
+    counters = np.zeros(4, dtype=np.int64)
+    evals = np.empty(nev)
+    evecs = np.empty((n, nev), order="F") if vectors else None
+    v0a = None if v0 is None else np.ascontiguousarray(v0, dtype=np.float64)
+    k = _check(lib().ref_symeigs_shift(C.byref(op.c), nev, ncv, float(sigma), None if v0a is None else _dp(v0a), selection, maxit, tol, sorting,
+                                       counters.ctypes.data_as(C.POINTER(C.c_long)), _dp(evals), None if evecs is None else _dp(evecs)))
+    r = Result()
+    r.nconv, r.num_iterations, r.num_operations, r.info = (int(c) for c in counters)
+    r.eigenvalues = evals[:k].copy()
+    r.eigenvectors = None if evecs is None else evecs[:, :k].copy()
+    return r
+
+
+def geneigs_real_shift(op, nev, ncv, sigma, selection=LargestMagn, maxit=1000, tol=1e-10, sorting=LargestMagn, v0=None, vectors=True):
+    """GenEigsRealShiftSolver<Op>(op, nev, ncv, sigma) of the reference; `op` applies (A - sigma I)^{-1}."""
+    n = op.n
+    counters = np.zeros(4, dtype=np.int64)
+    evals = np.empty(2 * nev)
+    evecs = np.empty(2 * n * nev) if vectors else None
+    v0a = None if v0 is None else np.ascontiguousarray(v0, dtype=np.float64)
+    k = _check(lib().ref_geneigs_real_shift(C.byref(op.c), nev, ncv, float(sigma), None if v0a is None else _dp(v0a), selection, maxit, tol,
+                                            sorting, counters.ctypes.data_as(C.POINTER(C.c_long)), _dp(evals),
+                                            None if evecs is None else _dp(evecs)))
     r = Result()
     r.nconv, r.num_iterations, r.num_operations, r.info = (int(c) for c in counters)
     r.eigenvalues = evals.view(np.complex128)[:k].copy()

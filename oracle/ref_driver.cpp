@@ -32,6 +32,8 @@
 #include <Spectra/MatOp/SparseSymMatProd.h>
 #include <Spectra/MatOp/internal/ArnoldiOp.h>
 #include <Spectra/SymEigsSolver.h>
+#include <Spectra/SymEigsShiftSolver.h>
+#include <Spectra/GenEigsRealShiftSolver.h>
 #include <Spectra/Util/SelectionRule.h>
 #include <Spectra/Util/SimpleRandom.h>
 
@@ -84,6 +86,24 @@ public:
     Eigen::Index rows() const { return m_n; }
     Eigen::Index cols() const { return m_n; }
     void perform_op(const double* x, double* y) const { m_cb(x, y); }
+};
+
+// the same with the shift-solve concept (SymEigsShiftSolver.h:25-32): the callback IS y = (A - sigma I)^{-1} x for the sigma the
+// solver is created with (the caller factors A - sigma I); set_shift records what the solver asked for
+class CallbackShiftOp
+{
+    long m_n;
+    void (*m_cb)(const double*, double*);
+    mutable double m_sigma = 0.0;
+
+public:
+    using Scalar = double;
+    CallbackShiftOp(long n, void (*cb)(const double*, double*)) : m_n(n), m_cb(cb) {}
+    Eigen::Index rows() const { return m_n; }
+    Eigen::Index cols() const { return m_n; }
+    void set_shift(const double& sigma) { m_sigma = sigma; }
+    void perform_op(const double* x, double* y) const { m_cb(x, y); }
+    double shift() const { return m_sigma; }
 };
 
 template <typename Solver>
@@ -390,6 +410,44 @@ long ref_symeigs(const RefOp* op, long nev, long ncv, const double* v0, int sele
             g_err = "ref_symeigs: operator kind not symmetric";
             return -1;
     }
+    REF_CATCH
+}
+
+// SymEigsShiftSolver<CallbackShiftOp>(op, nev, ncv, sigma): the eigenvalues come back transformed (1 / nu + sigma) and sorted
+// by the reference's own code (SymEigsShiftSolver.h:190-215)
+long ref_symeigs_shift(const RefOp* op, long nev, long ncv, double sigma, const double* v0, int selection, long maxit, double tol, int sorting,
+                       long* counters, double* evals, double* evecs)
+{
+    REF_TRY
+    if (op->kind != 5)
+    {
+        g_err = "ref_symeigs_shift: needs a callback operator (the shift solve)";
+        return -1;
+    }
+    CallbackShiftOp mop(op->n, op->cb);
+    SymEigsShiftSolver<CallbackShiftOp> eigs(mop, nev, ncv, sigma);
+    if (mop.shift() != sigma)
+    {
+        g_err = "ref_symeigs_shift: the solver did not set the shift";
+        return -1;
+    }
+    return run_sym(eigs, v0, selection, maxit, tol, sorting, counters, evals, evecs, op->n);
+    REF_CATCH
+}
+
+// GenEigsRealShiftSolver<CallbackShiftOp>(op, nev, ncv, sigma) (GenEigsRealShiftSolver.h:52-58)
+long ref_geneigs_real_shift(const RefOp* op, long nev, long ncv, double sigma, const double* v0, int selection, long maxit, double tol, int sorting,
+                            long* counters, double* evals, double* evecs)
+{
+    REF_TRY
+    if (op->kind != 5)
+    {
+        g_err = "ref_geneigs_real_shift: needs a callback operator (the shift solve)";
+        return -1;
+    }
+    CallbackShiftOp mop(op->n, op->cb);
+    GenEigsRealShiftSolver<CallbackShiftOp> eigs(mop, nev, ncv, sigma);
+    return run_gen(eigs, v0, selection, maxit, tol, sorting, counters, evals, evecs, op->n);
     REF_CATCH
 }
 

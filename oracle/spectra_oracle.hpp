@@ -23,7 +23,9 @@
 //  (V, H, f), and whole SymEigsSolver / GenEigsSolver solves (nconv, info,
 //  num_iterations, num_operations, eigenvalues, eigenvectors) on the
 //  reference's fixtures x all selection rules, Example1/2/4 and graded /
-//  clustered spectra.  The vectors the library returned are committed
+//  clustered spectra; SymEigsShiftSolver / GenEigsRealShiftSolver (the back-
+//  transformation and sorting of the Ritz values) on the reference's shift
+//  fixtures with the shift solve handed to both sides as the same callback.  The vectors the library returned are committed
 //  (tests/golden/ref_pin_golden.npz, generator alongside) and checked on every
 //  run, with or without the library.  What stays outside the pin is real
 //  Eigen's vectorised reduction order and its third-party kernels (SparseLU,

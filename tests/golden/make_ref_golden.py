@@ -51,6 +51,20 @@ for i, M2 in enumerate(EXAMPLE2):
     rec(f"example2_{i}", R.symeigs(R.Op.dense_sym(M2), 1, 3, selection=R.LargestAlge))
 D = sp.diags(np.arange(1.0, 11.0)).tocsc()
 rec("doc_diag", R.symeigs(R.Op.csc_sym(10, D.indptr, D.indices, D.data, True), 3, 6, selection=R.LargestAlge))
+# shift-and-invert drivers (SymEigsShiftSolver.h, GenEigsRealShiftSolver.h) on the reference's shift fixtures
+# (test/SymEigsShift.cpp:148-185, test/GenEigsRealShift.cpp:146-180); the shift solve is scipy's sparse LU behind a callback
+import scipy.sparse.linalg as spla  # noqa: E402
+
+for n, prob, k, m, sigma in [(10, 0.5, 3, 6, 1.0), (100, 0.1, 10, 20, 10.0), (1000, 0.01, 20, 50, 100.0)]:
+    A, S = sparse_fixture(n, prob)
+    lu = spla.splu((S - sigma * sp.identity(n)).tocsc())
+    for rule in RULES_SYM:
+        rec(f"symshift_{n}_{rule}", R.symeigs_shift(R.Op.callback(n, lu.solve), k, m, sigma, selection=getattr(R, rule)))
+for n, prob, k, m, sigma in [(10, 0.5, 3, 6, 1.0), (100, 0.1, 10, 30, 10.0), (1000, 0.01, 20, 50, 100.0)]:
+    A, S = sparse_fixture(n, prob)
+    lu = spla.splu((A - sigma * sp.identity(n)).tocsc())
+    for rule in ["LargestMagn", "LargestReal", "LargestImag", "SmallestReal"]:
+        rec(f"genshift_{n}_{rule}", R.geneigs_real_shift(R.Op.callback(n, lu.solve), k, m, sigma, selection=getattr(R, rule)))
 np.savez_compressed(os.path.join(HERE, "ref_pin_golden.npz"), **out)
 print("wrote ref_pin_golden.npz with", len(out), "arrays")
 
