@@ -49,7 +49,8 @@ def available():
 
 
 REFERENCE_TEST_PROGRAMS = ["SymEigs", "GenEigs", "Schur", "Example1", "Example2", "Example4", "SparseSymMatProd", "SparseGenMatProd",
-                           "DenseSymMatProd", "DenseGenMatProd"]
+                           "DenseSymMatProd", "DenseGenMatProd", "SymEigsShift", "GenEigsRealShift", "SymGEigsRegInv", "SymGEigsCholesky",
+                           "Example3"]
 
 
 def build_tests():
@@ -90,6 +91,8 @@ def lib():
             "ref_geneigs": (C.c_long, [op, C.c_long, C.c_long, dp, C.c_int, C.c_long, C.c_double, C.c_int, lp, dp, dp]),
             "ref_symeigs_shift": (C.c_long, [op, C.c_long, C.c_long, C.c_double, dp, C.c_int, C.c_long, C.c_double, C.c_int, lp, dp, dp]),
             "ref_geneigs_real_shift": (C.c_long, [op, C.c_long, C.c_long, C.c_double, dp, C.c_int, C.c_long, C.c_double, C.c_int, lp, dp, dp]),
+            "ref_symgeigs_reginv": (C.c_long, [op, op, _CB, C.c_long, C.c_long, C.c_int, C.c_long, C.c_double, C.c_int, lp, dp, dp]),
+            "ref_symgeigs_shift": (C.c_long, [op, op, C.c_int, C.c_long, C.c_long, C.c_double, C.c_int, C.c_long, C.c_double, C.c_int, lp, dp, dp]),
             "ref_factorize": (C.c_int, [op, C.c_long, C.c_int, dp, dp, dp, dp, dp]),
             "ref_symeigs_time": (C.c_double, [op, C.c_long, C.c_long, C.c_long, C.c_double, lp]),
         }
@@ -313,6 +316,45 @@ def geneigs_real_shift(op, nev, ncv, sigma, selection=LargestMagn, maxit=1000, t
     r.eigenvalues = evals.view(np.complex128)[:k].copy()
     r.eigenvectors = None if evecs is None else evecs.view(np.complex128).reshape((n, nev), order="F")[:, :k].copy()
     return r
+
+
+def _sym_result(k, counters, evals, evecs):
+    r = Result()
+    r.nconv, r.num_iterations, r.num_operations, r.info = (int(c) for c in counters)
+    r.eigenvalues = evals[:k].copy()
+    r.eigenvectors = None if evecs is None else evecs[:, :k].copy()
+    return r
+
+
+def symgeigs_reginv(a, b, bsolve, nev, ncv, selection=LargestMagn, maxit=1000, tol=1e-10, sorting=LargestAlge):
+    """SymGEigsSolver<SparseSymMatProd, BOp, GEigsMode::RegularInverse>(A, B, nev, ncv) of the reference; a, b: Op.csc_sym
+    (lower triangles); bsolve(x) = B^{-1} x (the reference's SparseRegularInverse delegates that to Eigen::ConjugateGradient)."""
+    n = a.n
+
+    def tramp(xp, yp):
+        x = np.ctypeslib.as_array(xp, shape=(n,))
+        y = np.ctypeslib.as_array(yp, shape=(n,))
+        y[:] = bsolve(x)
+
+    cb = _CB(tramp)
+    counters = np.zeros(4, dtype=np.int64)
+    evals, evecs = np.empty(nev), np.empty((n, nev), order="F")
+    k = _check(lib().ref_symgeigs_reginv(C.byref(a.c), C.byref(b.c), cb, nev, ncv, selection, maxit, tol, sorting,
+                                         counters.ctypes.data_as(C.POINTER(C.c_long)), _dp(evals), _dp(evecs)))
+    return _sym_result(k, counters, evals, evecs)
+
+
+def symgeigs_shift(inv, b, mode, nev, ncv, sigma, selection=LargestMagn, maxit=1000, tol=1e-10, sorting=LargestAlge):
+    """SymGEigsShiftSolver<Op, SparseSymMatProd, mode>(op, Bop, nev, ncv, sigma) of the reference; mode "ShiftInvert" /
+    "Buckling" / "Cayley"; inv: Op.callback applying (A - sigma B)^{-1} (buckling: (K - sigma KG)^{-1}); b: Op.csc_sym of the
+    matrix of the inner product (B; K for buckling)."""
+    n = b.n
+    counters = np.zeros(4, dtype=np.int64)
+    evals, evecs = np.empty(nev), np.empty((n, nev), order="F")
+    k = _check(lib().ref_symgeigs_shift(C.byref(inv.c), C.byref(b.c), {"ShiftInvert": 1, "Buckling": 2, "Cayley": 3}[mode], nev, ncv,
+                                        float(sigma), selection, maxit, tol, sorting, counters.ctypes.data_as(C.POINTER(C.c_long)),
+                                        _dp(evals), _dp(evecs)))
+    return _sym_result(k, counters, evals, evecs)
 
 
 def symeigs_time(op, nev, ncv, maxit, tol=1e-10):

@@ -34,6 +34,8 @@
 #include <Spectra/SymEigsSolver.h>
 #include <Spectra/SymEigsShiftSolver.h>
 #include <Spectra/GenEigsRealShiftSolver.h>
+#include <Spectra/SymGEigsSolver.h>
+#include <Spectra/SymGEigsShiftSolver.h>
 #include <Spectra/Util/SelectionRule.h>
 #include <Spectra/Util/SimpleRandom.h>
 
@@ -104,6 +106,22 @@ public:
     void set_shift(const double& sigma) { m_sigma = sigma; }
     void perform_op(const double* x, double* y) const { m_cb(x, y); }
     double shift() const { return m_sigma; }
+};
+
+// B operator of the generalized drivers: y = B x by the reference's own SparseSymMatProd (lower triangle of a CSC matrix),
+// B^{-1} x by a callback (the reference's SparseRegularInverse delegates it to Eigen::ConjugateGradient, third party)
+class PencilBOp
+{
+    SparseSymMatProd<double, Eigen::Lower> m_prod;
+    void (*m_solve)(const double*, double*);
+
+public:
+    using Scalar = double;
+    PencilBOp(const MapCsc& B, void (*solve)(const double*, double*)) : m_prod(B), m_solve(solve) {}
+    Eigen::Index rows() const { return m_prod.rows(); }
+    Eigen::Index cols() const { return m_prod.cols(); }
+    void perform_op(const double* x, double* y) const { m_prod.perform_op(x, y); }
+    void solve(const double* x, double* y) const { m_solve(x, y); }
 };
 
 template <typename Solver>
@@ -432,6 +450,59 @@ long ref_symeigs_shift(const RefOp* op, long nev, long ncv, double sigma, const 
         return -1;
     }
     return run_sym(eigs, v0, selection, maxit, tol, sorting, counters, evals, evecs, op->n);
+    REF_CATCH
+}
+
+// SymGEigsSolver<SparseSymMatProd, PencilBOp, GEigsMode::RegularInverse>(A, B, nev, ncv) (SymGEigsSolver.h:224-238): the Krylov
+// operator B^{-1} A and the B-inner products of ArnoldiOp<Op, BOp> are the reference's; a / b: lower triangles as CSC;
+// bsolve: y = B^{-1} x
+long ref_symgeigs_reginv(const RefOp* a, const RefOp* b, void (*bsolve)(const double*, double*), long nev, long ncv, int selection, long maxit,
+                         double tol, int sorting, long* counters, double* evals, double* evecs)
+{
+    REF_TRY
+    const long n = a->n;
+    MapCsc A(n, n, a->ptr[n], a->ptr, a->ind, a->val), B(n, n, b->ptr[n], b->ptr, b->ind, b->val);
+    SparseSymMatProd<double, Eigen::Lower> aop(A);
+    PencilBOp bop(B, bsolve);
+    SymGEigsSolver<SparseSymMatProd<double, Eigen::Lower>, PencilBOp, GEigsMode::RegularInverse> eigs(aop, bop, nev, ncv);
+    return run_sym(eigs, nullptr, selection, maxit, tol, sorting, counters, evals, evecs, n);
+    REF_CATCH
+}
+
+// SymGEigsShiftSolver<CallbackShiftOp, SparseSymMatProd, mode>(op, Bop, nev, ncv, sigma) (SymGEigsShiftSolver.h:36-207):
+// mode 1 shift-invert, 2 buckling, 3 Cayley; inv: y = (A - sigma B)^{-1} x (buckling: (K - sigma KG)^{-1}); b: the matrix
+// of the inner product (B; K for buckling), lower triangle as CSC
+long ref_symgeigs_shift(const RefOp* inv, const RefOp* b, int mode, long nev, long ncv, double sigma, int selection, long maxit, double tol,
+                        int sorting, long* counters, double* evals, double* evecs)
+{
+    REF_TRY
+    const long n = b->n;
+    if (inv->kind != 5)
+    {
+        g_err = "ref_symgeigs_shift: needs a callback operator (the shift solve)";
+        return -1;
+    }
+    MapCsc B(n, n, b->ptr[n], b->ptr, b->ind, b->val);
+    using BOp = SparseSymMatProd<double, Eigen::Lower>;
+    BOp bop(B);
+    CallbackShiftOp op(n, inv->cb);
+    if (mode == 1)
+    {
+        SymGEigsShiftSolver<CallbackShiftOp, BOp, GEigsMode::ShiftInvert> eigs(op, bop, nev, ncv, sigma);
+        return run_sym(eigs, nullptr, selection, maxit, tol, sorting, counters, evals, evecs, n);
+    }
+    if (mode == 2)
+    {
+        SymGEigsShiftSolver<CallbackShiftOp, BOp, GEigsMode::Buckling> eigs(op, bop, nev, ncv, sigma);
+        return run_sym(eigs, nullptr, selection, maxit, tol, sorting, counters, evals, evecs, n);
+    }
+    if (mode == 3)
+    {
+        SymGEigsShiftSolver<CallbackShiftOp, BOp, GEigsMode::Cayley> eigs(op, bop, nev, ncv, sigma);
+        return run_sym(eigs, nullptr, selection, maxit, tol, sorting, counters, evals, evecs, n);
+    }
+    g_err = "ref_symgeigs_shift: mode must be 1, 2 or 3";
+    return -1;
     REF_CATCH
 }
 

@@ -25,7 +25,10 @@
 //  reference's fixtures x all selection rules, Example1/2/4 and graded /
 //  clustered spectra; SymEigsShiftSolver / GenEigsRealShiftSolver (the back-
 //  transformation and sorting of the Ritz values) on the reference's shift
-//  fixtures with the shift solve handed to both sides as the same callback.  The vectors the library returned are committed
+//  fixtures with the shift solve handed to both sides as the same callback;
+//  the generalized drivers with B-inner products (SymGEigsSolver regular
+//  inverse, SymGEigsShiftSolver shift-invert / buckling / Cayley) with the
+//  inverses as callbacks and B x from the reference's own SparseSymMatProd.  The vectors the library returned are committed
 //  (tests/golden/ref_pin_golden.npz, generator alongside) and checked on every
 //  run, with or without the library.  What stays outside the pin is real
 //  Eigen's vectorised reduction order and its third-party kernels (SparseLU,

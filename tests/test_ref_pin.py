@@ -303,3 +303,79 @@ def test_general_real_shift_solves_equal_the_reference(n, prob, k, m, sigma, rul
         # test/GenEigsRealShift.cpp:58-70 asks 1e-9 with Eigen::SparseLU behind the operator; with scipy's LU behind the SAME
         # reference code the 1000 x 1000 fixture lands at 1.08e-9 — the claim here is the bit-equality above, not the solver's bar
         assert np.abs(A @ r.eigenvectors - r.eigenvectors * r.eigenvalues).max() < 1e-8
+
+
+# ---- generalized drivers with B-inner products (SymGEigsSolver.h:224-238 regular inverse; SymGEigsShiftSolver.h:36-207 shift-invert /
+# ---- buckling / Cayley; ArnoldiOp<Op, BOp>): the reference's code with B x from its own SparseSymMatProd and the inverses handed in
+# ---- as callbacks; the oracle's Krylov callback is composed of the same pieces (its B product is bit-identical, tested above)
+def oracle_b_solver(krylov, bop, n, k, m, transform, sigma):
+    s = O.SymEigsSolver.__new__(O.SymEigsSolver)
+    s._op, s._bop = O.Op.callback(n, krylov), bop
+    s.h = O.lib().oracle_symeigs_create_b(s._op.h, s._bop.h, k, m, transform, float(sigma))
+    assert s.h
+    s.op, s.nev, s.ncv, s.n = s._op, k, min(m, n), n
+    return s
+
+
+def pencil_fixture(n, prob):
+    """gen_sparse_data(n, A, B, prob) of test/SymGEigsRegInv.cpp:35-44: A = sprand (lower triangle used), B = A'A + 0.1 I."""
+    r, c, v = O.gen_sparse_data(n, prob)
+    A = sp.coo_matrix((v, (r, c)), shape=(n, n)).tocsc()
+    A.sort_indices()
+    B = (A.T @ A + 0.1 * sp.identity(n)).tocsc()
+    B.sort_indices()
+    low = lambda M: sp.tril(M).tocsc()
+    return low(A), low(B)
+
+
+@needs_ref
+@pytest.mark.parametrize("n,prob,k,m", [(10, 0.5, 3, 6), (100, 0.1, 10, 20), (1000, 0.01, 20, 50)])  # test/SymGEigsRegInv.cpp:109-145
+@pytest.mark.parametrize("rule", ["LargestMagn", "LargestAlge", "SmallestAlge", "BothEnds"])
+def test_regular_inverse_driver_equals_the_reference(n, prob, k, m, rule):
+    import scipy.sparse.linalg as spla
+
+    Al, Bl = pencil_fixture(n, prob)
+    sym = lambda L: (L + sp.tril(L, -1).T).tocsc()
+    lu = spla.splu(sym(Bl))
+    oa = O.Op.csc_sym(n, Al.indptr, Al.indices, Al.data, True)
+    ob = O.Op.csc_sym(n, Bl.indptr, Bl.indices, Bl.data, True)
+    o = oracle_b_solver(lambda x: lu.solve(oa.perform_op(x)), ob, n, k, m, 0, 0.0)
+    o.init()
+    nconv = o.compute(getattr(O, rule), 100)
+    r = R.symgeigs_reginv(R.Op.csc_sym(n, Al.indptr, Al.indices, Al.data, True), R.Op.csc_sym(n, Bl.indptr, Bl.indices, Bl.data, True),
+                          lu.solve, k, m, selection=getattr(R, rule), maxit=100)
+    assert [nconv, o.info(), o.num_iterations(), o.num_operations()] == counters(r)
+    assert np.array_equal(o.eigenvalues(), r.eigenvalues) and np.array_equal(o.eigenvectors(), r.eigenvectors)
+    if r.info == 0:
+        A, B = sym(Al), sym(Bl)
+        assert np.abs(A @ r.eigenvectors - (B @ r.eigenvectors) * r.eigenvalues).max() < 1e-8
+
+
+@needs_ref
+@pytest.mark.parametrize("mode,transform", [("ShiftInvert", 1), ("Buckling", 2), ("Cayley", 3)])
+@pytest.mark.parametrize("rule", ["LargestMagn", "LargestAlge", "SmallestAlge", "BothEnds"])
+def test_generalized_shift_drivers_equal_the_reference(mode, transform, rule):
+    import scipy.sparse.linalg as spla
+
+    n, k, m, sigma = 100, 10, 20, 1.2345  # test/SymGEigsShift.cpp:121-141, :214-234, :307-327
+    Al, Bl = pencil_fixture(n, 0.1)
+    if mode == "Buckling":  # K = KG'KG + 0.1 I is the first operand, KG the second
+        Al, Bl = Bl, Al
+    sym = lambda L: (L + sp.tril(L, -1).T).tocsc()
+    lu = spla.splu((sym(Al) - sigma * sym(Bl)).tocsc())
+    Pl = Al if mode == "Buckling" else Bl  # the matrix of the inner product and of the product inside the operator
+    op_p = O.Op.csc_sym(n, Pl.indptr, Pl.indices, Pl.data, True)
+    if mode == "Cayley":
+        krylov = lambda x: x + (2.0 * sigma) * lu.solve(op_p.perform_op(x))  # SymGEigsCayleyOp.h:91-100
+    else:
+        krylov = lambda x: lu.solve(op_p.perform_op(x))                      # SymGEigsShiftInvertOp.h / SymGEigsBucklingOp.h
+    o = oracle_b_solver(krylov, O.Op.csc_sym(n, Pl.indptr, Pl.indices, Pl.data, True), n, k, m, transform, sigma)
+    o.init()
+    nconv = o.compute(getattr(O, rule), 100)
+    r = R.symgeigs_shift(R.Op.callback(n, lu.solve), R.Op.csc_sym(n, Pl.indptr, Pl.indices, Pl.data, True), mode, k, m, sigma,
+                         selection=getattr(R, rule), maxit=100)
+    assert [nconv, o.info(), o.num_iterations(), o.num_operations()] == counters(r)
+    assert np.array_equal(o.eigenvalues(), r.eigenvalues) and np.array_equal(o.eigenvectors(), r.eigenvectors)
+    if r.info == 0:
+        A, B = sym(Al), sym(Bl)
+        assert np.abs(A @ r.eigenvectors - (B @ r.eigenvectors) * r.eigenvalues).max() < 1e-8
