@@ -164,6 +164,46 @@ public:
         return m;
     }
     PlainObject eval() const { return PlainObject(derived()); }
+    // rowwise() / colwise() broadcasting of a vector over the rows / columns (eager): a.rowwise() / r divides row i by r entrywise
+    template <bool ByRow>
+    class Broadcast
+    {
+        const Derived& m_a;
+
+    public:
+        explicit Broadcast(const Derived& a) : m_a(a) {}
+        template <typename F, typename O>
+        Array<Scalar, Dynamic, Dynamic> apply(const ArrayBase<O>& v, F f) const
+        {
+            Array<Scalar, Dynamic, Dynamic> r(m_a.rows(), m_a.cols());
+            for (Index j = 0; j < m_a.cols(); j++)
+                for (Index i = 0; i < m_a.rows(); i++)
+                    r.coeffRef(i, j) = f(m_a.coeff(i, j), v.coeff(ByRow ? j : i));
+            return r;
+        }
+        template <typename O>
+        Array<Scalar, Dynamic, Dynamic> operator/(const ArrayBase<O>& v) const
+        {
+            return apply(v, [](const Scalar& a, const Scalar& b) { return a / b; });
+        }
+        template <typename O>
+        Array<Scalar, Dynamic, Dynamic> operator*(const ArrayBase<O>& v) const
+        {
+            return apply(v, [](const Scalar& a, const Scalar& b) { return a * b; });
+        }
+        template <typename O>
+        Array<Scalar, Dynamic, Dynamic> operator+(const ArrayBase<O>& v) const
+        {
+            return apply(v, [](const Scalar& a, const Scalar& b) { return a + b; });
+        }
+        template <typename O>
+        Array<Scalar, Dynamic, Dynamic> operator-(const ArrayBase<O>& v) const
+        {
+            return apply(v, [](const Scalar& a, const Scalar& b) { return a - b; });
+        }
+    };
+    Broadcast<true> rowwise() const { return Broadcast<true>(derived()); }
+    Broadcast<false> colwise() const { return Broadcast<false>(derived()); }
     PlainObject segment(Index start, Index k) const
     {
         PlainObject r(rows() == 1 && Traits::Cols != 1 ? 1 : k, rows() == 1 && Traits::Cols != 1 ? k : 1);

@@ -93,6 +93,8 @@ def lib():
             "ref_geneigs_real_shift": (C.c_long, [op, C.c_long, C.c_long, C.c_double, dp, C.c_int, C.c_long, C.c_double, C.c_int, lp, dp, dp]),
             "ref_symgeigs_reginv": (C.c_long, [op, op, _CB, C.c_long, C.c_long, C.c_int, C.c_long, C.c_double, C.c_int, lp, dp, dp]),
             "ref_symgeigs_shift": (C.c_long, [op, op, C.c_int, C.c_long, C.c_long, C.c_double, C.c_int, C.c_long, C.c_double, C.c_int, lp, dp, dp]),
+            "ref_partial_svd": (C.c_long, [C.c_long, C.c_long, C.POINTER(C.c_int), C.POINTER(C.c_int), dp, C.c_long, C.c_long, C.c_long, C.c_double,
+                                           lp, dp, dp]),
             "ref_factorize": (C.c_int, [op, C.c_long, C.c_int, dp, dp, dp, dp, dp]),
             "ref_symeigs_time": (C.c_double, [op, C.c_long, C.c_long, C.c_long, C.c_double, lp]),
         }
@@ -355,6 +357,24 @@ def symgeigs_shift(inv, b, mode, nev, ncv, sigma, selection=LargestMagn, maxit=1
                                         float(sigma), selection, maxit, tol, sorting, counters.ctypes.data_as(C.POINTER(C.c_long)),
                                         _dp(evals), _dp(evecs)))
     return _sym_result(k, counters, evals, evecs)
+
+
+def partial_svd(A, ncomp, ncv, maxit=1000, tol=1e-10):
+    """contrib/PartialSVDSolver.h of the reference on a scipy sparse matrix (CSC): (nconv, singular values, X) with X the
+    eigenvectors of the product operator — V for a tall matrix (rows > cols), U otherwise."""
+    import scipy.sparse as sp
+
+    A = sp.csc_matrix(A)
+    A.sort_indices()
+    m, n = A.shape
+    cp, ri, v = np.ascontiguousarray(A.indptr, dtype=np.int32), np.ascontiguousarray(A.indices, dtype=np.int32), np.ascontiguousarray(A.data, dtype=np.float64)
+    counters = np.zeros(4, dtype=np.int64)
+    sv = np.empty(ncomp)
+    dim = min(m, n)
+    X = np.empty((dim, ncomp), order="F")
+    k = _check(lib().ref_partial_svd(m, n, _ip(cp), _ip(ri), _dp(v), ncomp, ncv, maxit, tol, counters.ctypes.data_as(C.POINTER(C.c_long)),
+                                     _dp(sv), _dp(X)))
+    return int(counters[0]), sv[:k].copy(), X[:, :k].copy()
 
 
 def symeigs_time(op, nev, ncv, maxit, tol=1e-10):

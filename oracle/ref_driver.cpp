@@ -36,6 +36,7 @@
 #include <Spectra/GenEigsRealShiftSolver.h>
 #include <Spectra/SymGEigsSolver.h>
 #include <Spectra/SymGEigsShiftSolver.h>
+#include <Spectra/contrib/PartialSVDSolver.h>
 #include <Spectra/Util/SelectionRule.h>
 #include <Spectra/Util/SimpleRandom.h>
 
@@ -503,6 +504,33 @@ long ref_symgeigs_shift(const RefOp* inv, const RefOp* b, int mode, long nev, lo
     }
     g_err = "ref_symgeigs_shift: mode must be 1, 2 or 3";
     return -1;
+    REF_CATCH
+}
+
+// contrib/PartialSVDSolver.h:112-209 on a sparse m x n matrix (CSC): compute(), singular_values(), and the singular vectors that
+// ARE the eigenvectors of the product operator (V for a tall matrix, U otherwise: n_small x ncomp); counters as in run_sym
+long ref_partial_svd(long m, long n, const int* colptr, const int* rowind, const double* val, long ncomp, long ncv, long maxit, double tol,
+                     long* counters, double* svals, double* vecs)
+{
+    REF_TRY
+    MapCsc A(m, n, colptr[n], colptr, rowind, val);
+    const SpCsc Acopy = A;  // PartialSVDSolver takes a Ref<const SparseMatrix>
+    PartialSVDSolver<SpCsc> svds(Acopy, ncomp, ncv);
+    const long nconv = long(svds.compute(maxit, tol));
+    counters[0] = nconv;
+    counters[1] = counters[2] = counters[3] = -1;  // the inner solver is private
+    const Eigen::VectorXd sv = svds.singular_values();
+    for (long i = 0; i < long(sv.size()); i++)
+        svals[i] = sv[i];
+    if (vecs)
+    {
+        const long dim = m > n ? n : m;
+        const Eigen::MatrixXd X = m > n ? svds.matrix_V(ncomp) : svds.matrix_U(ncomp);
+        for (long j = 0; j < long(X.cols()); j++)
+            for (long i = 0; i < dim; i++)
+                vecs[j * dim + i] = X(i, j);
+    }
+    return long(sv.size());
     REF_CATCH
 }
 

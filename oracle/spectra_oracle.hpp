@@ -28,7 +28,8 @@
 //  fixtures with the shift solve handed to both sides as the same callback;
 //  the generalized drivers with B-inner products (SymGEigsSolver regular
 //  inverse, SymGEigsShiftSolver shift-invert / buckling / Cayley) with the
-//  inverses as callbacks and B x from the reference's own SparseSymMatProd.  The vectors the library returned are committed
+//  inverses as callbacks and B x from the reference's own SparseSymMatProd;
+//  contrib/PartialSVDSolver (product operators and driver).  The vectors the library returned are committed
 //  (tests/golden/ref_pin_golden.npz, generator alongside) and checked on every
 //  run, with or without the library.  What stays outside the pin is real
 //  Eigen's vectorised reduction order and its third-party kernels (SparseLU,

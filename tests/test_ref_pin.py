@@ -379,3 +379,29 @@ def test_generalized_shift_drivers_equal_the_reference(mode, transform, rule):
     if r.info == 0:
         A, B = sym(Al), sym(Bl)
         assert np.abs(A @ r.eigenvectors - (B @ r.eigenvectors) * r.eigenvalues).max() < 1e-8
+
+
+# ---- contrib/PartialSVDSolver.h:112-209: the reference's product operators (A'A for a tall matrix, AA' for a wide one) and its
+# ---- driver on its own code; the oracle's restatement (oracle.partial_svd) with the two products taken from the oracle's operators
+@needs_ref
+@pytest.mark.parametrize("m,n,prob,ncomp,ncv", [(100, 20, 0.1, 5, 10), (20, 100, 0.1, 5, 10), (1000, 100, 0.01, 10, 30), (100, 1000, 0.01, 10, 30)])
+def test_partial_svd_equals_the_reference(m, n, prob, ncomp, ncv):
+    # test/SVD.cpp:17-33, :100-137 (sparse cases; the shapes of its tall and wide fixtures)
+    r, c, v = O.gen_sparse_data_rect(m, n, prob)
+    A = sp.coo_matrix((v, (r, c)), shape=(m, n)).tocsc()
+    A.sort_indices()
+    a_op = O.Op.csc(m, n, A.indptr, A.indices, A.data)                 # y = A x   (SparseGenMatProd's loop)
+    at_op = O.Op.csr(n, m, A.indptr, A.indices, A.data)                # y = A' x: the same arrays read as the CSR rows of A'
+    tall = m > n
+    krylov = (lambda x: at_op.perform_op(a_op.perform_op(x))) if tall else (lambda x: a_op.perform_op(at_op.perform_op(x)))
+    o = O.SymEigsSolver(O.Op.callback(min(m, n), krylov), ncomp, ncv)
+    o.init()
+    nconv = o.compute(O.LargestAlge, 1000, 1e-10)
+    rn, sv, X = R.partial_svd(A, ncomp, ncv)
+    assert nconv == rn == ncomp
+    assert np.array_equal(np.sqrt(o.eigenvalues()), sv) and np.array_equal(o.eigenvectors(), X)
+    dense = np.linalg.svd(A.toarray(), compute_uv=False)[:ncomp]
+    assert np.abs(sv - dense).max() < 1e-9                               # test/SVD.cpp:53-60
+    # and the restatement the GPU tests use (scipy products inside: another summation order) agrees to rounding
+    n2, sv2, U2, V2 = O.partial_svd(A, ncomp, ncv)
+    assert n2 == ncomp and np.abs(sv2 - sv).max() < 1e-12
