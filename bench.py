@@ -195,6 +195,10 @@ def live_pmc_traffic(n, fmt, post_scaled, timeout=240):
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(prof):
         return None, "rocprofv3 not found"
+    # this process may itself run under a profiler (rocprofv3 -- python bench.py): no profiler inside a profiler
+    under = [k for k in os.environ if k in ("ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_FORCE_LOAD") or k.startswith("ROCPROF_")]
+    if under or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is itself profiled (" + ", ".join(under or ["LD_PRELOAD"]) + "): the live passes are skipped"
     tmp = tempfile.mkdtemp(prefix="mispec_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp", PROBE_N=str(n), PROBE_FORMATS=str(fmt), PROBE_SPMV_REPS="0")
     files = {}
