@@ -94,6 +94,7 @@ public:
     PlainObject inverse() const { return unary([](const Scalar& a) { return Scalar(Scalar(1) / a); }); }
     PlainObject exp() const { return unary([](const Scalar& a) { return Scalar(std::exp(a)); }); }
     PlainObject log() const { return unary([](const Scalar& a) { return Scalar(std::log(a)); }); }
+    PlainObject log10() const { return unary([](const Scalar& a) { return Scalar(std::log10(a)); }); }
     PlainObject pow(const RealScalar& p) const { return unary([p](const Scalar& a) { return Scalar(std::pow(a, p)); }); }
     RealPlain real() const { return unary([](const Scalar& a) { return numext::real(a); }); }
     RealPlain imag() const { return unary([](const Scalar& a) { return numext::imag(a); }); }
