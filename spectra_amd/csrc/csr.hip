@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void k_spmv_dia_win(DiaArgs da, mispec_dia_win
         v[k] = __builtin_nontemporal_load(vrow + int64_t(min(k, da.nd - 1)) * vstride);
     // The epilogue's operands travel with the matrix values: issued here, they are in flight during the window staging and
     // the barrier instead of costing the block a second round trip to HBM after its row sums (the kernel is bound by the
-    // number of resident blocks, i.e. by latency per block: profiles/r02r_*, r03q_*).
+    // number of resident blocks, i.e. by latency per block: profiles/rounds_1_2/r02r_*, r03q_*).
     double vprev_early = 0.0, vrow_early = 0.0, hprev_early = 0.0;
     const bool early = EPI && tid < nr;
     if (early)
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void k_spmv_dia_win(DiaArgs da, mispec_dia_win
     const int64_t g0 = da.row_begin + row0;
     // x windows -> LDS.  A window is 256 + span entries: two per thread, ALL loaded before the first LDS write.  (Written as
     // a loop over windows and pieces, each piece was a load, a wait and a write: ten dependent round trips per block on the
-    // five clusters of M-band, the latency the occupancy experiments of profiles/r02r_* were measuring.)
+    // five clusters of M-band, the latency the occupancy experiments of profiles/rounds_1_2/r02r_* were measuring.)
     const auto xat = [&](int64_t col) { return x[min(max(col, int64_t(0)), int64_t(da.col_max))]; };
     // entry tid of every window in a register of its own; the entries past 256 (the spans: 10 in all for M-band) one per
     // thread, thread t taking the t-th of them — 64 VGPRs in total, i.e. eight workgroups per CU as before

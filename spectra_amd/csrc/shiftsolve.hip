@@ -122,7 +122,7 @@ inline ChunkStore make_chunk_store(int64_t N, int b, int64_t L, int64_t P)
 // Every wavefront runs chunks of ONE interior length: the last chunk has a workgroup of its own.  Row counters and trip counts
 // are therefore wave-uniform, and the factor addresses are `per-lane base + compile-time stride` (ChunkStore).
 //
-// What bounds these kernels (measured, profiles/r03e-r03g): with one wavefront per SIMD nothing overlaps the instruction
+// What bounds these kernels (measured, profiles/rounds_1_2/r03e-r03g): with one wavefront per SIMD nothing overlaps the instruction
 // stream, so the time is the NUMBER OF INSTRUCTIONS per row.  The first version (per-lane interior length in the loop bounds,
 // factor index (k*b + d)*P + p) needed five 64-bit vector integer instructions and a branch per load — 540 cycles per row,
 // unchanged by deeper batches, more wavefronts, or staging the vector in LDS.
@@ -994,7 +994,7 @@ constexpr int64_t kPivotedLimit = 8192;
 
 // chunk length and chunk count of a level: 128-row chunks, levels of at most 2048 rows inverted densely.  The solve kernels run
 // one lane per chunk, so a level needs many chunks to pull bandwidth: short chunks, paid for with more separator rows (the next
-// level).  Other lengths measured slower (profiles/r03j_*: 0.137 / 0.182 / 0.205 ms per solve at 160 / 192 / 256 rows, 0.139 at 96).
+// level).  Other lengths measured slower (profiles/rounds_1_2/r03j_*: 0.137 / 0.182 / 0.205 ms per solve at 160 / 192 / 256 rows, 0.139 at 96).
 struct ChunkPlan
 {
     int64_t big = 128, small = 128, n_switch = 0, n_dense = 2048;
@@ -1437,9 +1437,9 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
 
 // Chunks per wavefront of the solve kernels (test hook MISPEC_SHIFT=lanes=64|32|16|8).  One lane per chunk makes a level with P
 // chunks run P / 64 wavefronts — 244 at the top level of C5, 6 at the second; fewer chunks per wavefront (the other lanes idle)
-// means more wavefronts in flight, but measured (profiles/r03a_*) 0.265 / 0.276 / 0.278 / 0.464 ms per solve at 64 / 32 / 16 / 8:
+// means more wavefronts in flight, but measured (profiles/rounds_1_2/r03a_*) 0.265 / 0.276 / 0.278 / 0.464 ms per solve at 64 / 32 / 16 / 8:
 // the sweeps are bound by their dependency chain, not by the number of wavefronts.  A software-pipelined variant (next batch of
-// rows in flight during the recurrence) measured 0.281 against 0.265 ms (profiles/r03b_*) and was removed again.
+// rows in flight during the recurrence) measured 0.281 against 0.265 ms (profiles/rounds_1_2/r03b_*) and was removed again.
 int solve_lanes(int64_t P)
 {
     static const int knob = int(shift_option("lanes", 0));

@@ -3,7 +3,7 @@
 //
 // Why.  A CSR row sweep over a matrix with uniformly scattered columns issues one 8-byte gather per entry into an 80 MB
 // vector; every gather misses the 4 MiB per-XCD L2 and drags a 128-byte line through the fabric: 16x read amplification,
-// 0.10 of the HBM roofline (profiles/r01g_spmv_patterns.jsonl).  No symmetric reordering helps an expander.
+// 0.10 of the HBM roofline (profiles/rounds_1_2/r01g_spmv_patterns.jsonl).  No symmetric reordering helps an expander.
 //
 // Layout.  The rows are cut into SEGMENTS of 8192 rows, the columns into BLOCKS of 65536 columns (512 KiB of x).  A TILE is
 // the part of a segment inside one column block; a segment stores its tiles one after the other (ascending block), every
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kTileThreads) void k_spmv_tiles(const int64_t* __re
         const int count = ch.count;
         // the next chunk's entries follow this chunk's: issue their loads now (the arrays end with slack).  Also issuing
         // the NEXT chunk's x gathers here (three chunks in flight per thread) measured 1.46 against 1.33 ms on M-rand
-        // (profiles/r03t_*): the gathers are bound by the fabric, more of them in flight only evict each other
+        // (profiles/rounds_1_2/r03t_*): the gathers are bound by the fabric, more of them in flight only evict each other
         const int noff = off + count;
 #pragma unroll
         for (int k = 0; k < kPer; k++)

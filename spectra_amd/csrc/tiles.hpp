@@ -7,7 +7,7 @@
 
 namespace mispec {
 
-// Geometry (compile-time; the defaults are the measured best of profiles/r02_mrand_tile_geometry_sweep.jsonl, M-rand n = 1e7):
+// Geometry (compile-time; the defaults are the measured best of profiles/rounds_1_2/r02_mrand_tile_geometry_sweep.jsonl, M-rand n = 1e7):
 //   segments of 8192 rows (64 KiB of accumulators: two workgroups per CU), column blocks of 65536 columns (512 KiB of x),
 //   512 threads per workgroup, chunks of 1024 entries.  4096 x 131072 x 256 threads: 1.87 ms; 8192 x 65536 x 256: 1.50;
 //   8192 x 65536 x 512: 1.29-1.32; 8192 x 65536 x 1024: 1.40; 8192 x 131072 (2-bit runs): 1.65-1.70; 16384 x 32768: 1.60-1.99;
