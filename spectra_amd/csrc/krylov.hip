@@ -1347,7 +1347,8 @@ int launch_orth_panel(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a, i
     {
         const int rows = orth_tile_rows(a.ncol);
         const int64_t ntiles = (a.n + rows - 1) / rows;
-        // 3 and 6 workgroups per CU measured slower (profiles/r05b_ab_*); the 512-thread one-sweep kernel of wide bases: 2
+        // 3 and 6 workgroups per CU measured slower (profiles/r05b_ab_*); the 512-thread one-sweep kernel of wide bases: 2 (1 the
+        // same, 3 slower: profiles/r07aa)
         grid = persistent_grid(ctx, ntiles, (mode == ORTH_LAGGED && a.ncol >= kPanelCols) ? 2 : 4);
     }
     MISPEC_REQUIRE(a.pstride >= grid, "orth kernel: partial-record stride smaller than the grid");
