@@ -50,7 +50,7 @@ def available():
 
 REFERENCE_TEST_PROGRAMS = ["SymEigs", "GenEigs", "Schur", "Example1", "Example2", "Example4", "SparseSymMatProd", "SparseGenMatProd",
                            "DenseSymMatProd", "DenseGenMatProd", "SymEigsShift", "GenEigsRealShift", "SymGEigsRegInv", "SymGEigsCholesky",
-                           "Example3", "SVD", "Givens"]
+                           "Example3", "SVD", "Givens", "QR", "Eigen", "Arnoldi"]
 
 
 def build_tests():

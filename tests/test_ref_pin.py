@@ -263,6 +263,19 @@ def test_reference_s_own_test_programs_pass_on_the_stand_in_algebra(name):
     assert out.returncode == 0 and "All tests passed" in out.stdout, out.stdout[-2000:]
 
 
+def test_stand_in_decompositions_self_check(tmp_path):
+    # oracle/eigen_shim's HouseholderQR / EigenSolver / ComplexEigenSolver (used, but only timed or compared in modulus, by the
+    # reference's test/QR.cpp and test/Eigen.cpp): residuals of the stand-ins themselves.  Needs no reference.
+    import subprocess
+
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "shim_selfcheck")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-w", "-I" + os.path.join(here, "oracle", "eigen_shim"),
+                           os.path.join(here, "oracle", "eigen_shim_selfcheck.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout
+
+
 # ---- shift-and-invert drivers (SymEigsShiftSolver.h:190-215, GenEigsRealShiftSolver.h:52-58): the reference's back-transformation
 # ---- and sorting of the Ritz values on its own code, the shift solve handed to both sides as the same callback
 
