@@ -4,7 +4,9 @@
 #ifndef MISPEC_SPECTRA_GIVENS_H
 #define MISPEC_SPECTRA_GIVENS_H
 
-#include "../internal/SmallDense.h"
+#include <complex>
+
+#include "../internal/SmallDenseComplex.h"
 
 namespace Spectra {
 
@@ -18,6 +20,24 @@ public:
         mispec::small::givens_rotation(double(x), double(y), rr, cc, ss);
         r = Scalar(rr);
         c = Scalar(cc);
+        s = Scalar(ss);
+    }
+};
+
+// Complex operands: G = [c s; -conj(s) c] with real c, G^H [x; y] = [r; 0]  (reference: LinAlg/Givens.h:236-339)
+template <typename RealScalar>
+class Givens<std::complex<RealScalar>>
+{
+    using Scalar = std::complex<RealScalar>;
+
+public:
+    static void compute_rotation(const Scalar& x, const Scalar& y, Scalar& r, RealScalar& c, Scalar& s)
+    {
+        std::complex<double> rr, ss;
+        double cc;
+        mispec::small::givens_rotation_complex(std::complex<double>(x), std::complex<double>(y), rr, cc, ss);
+        r = Scalar(rr);
+        c = RealScalar(cc);
         s = Scalar(ss);
     }
 };

@@ -9,11 +9,13 @@
 #ifndef MISPEC_SPECTRA_UPPER_HESSENBERG_QR_H
 #define MISPEC_SPECTRA_UPPER_HESSENBERG_QR_H
 
+#include <complex>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
 #include "../internal/Dense.h"
+#include "../internal/SmallDenseComplex.h"
 #include "../internal/SmallDenseGen.h"
 
 namespace Spectra {
@@ -159,6 +161,143 @@ public:
                 b[j] = s * t + c * b[j];
             }
         }
+    }
+};
+
+// Complex upper Hessenberg matrices (reference: the same class template instantiated with std::complex, :45-460):
+// G_i = [c s; -conj(s) c] with real c, Q = G_0 G_1 ... G_{n-2}, Q^H in place of Q'.  Host arithmetic only
+// (internal/SmallDenseComplex.h) — the device solvers are real.
+template <typename RealScalar>
+class UpperHessenbergQR<std::complex<RealScalar>>
+{
+public:
+    using Scalar = std::complex<RealScalar>;
+
+protected:
+    using Matrix = DenseMatrix<Scalar>;
+    using Vector = DenseVector<Scalar>;
+    using cd = std::complex<double>;
+    Index m_n = 0;
+    Scalar m_shift = Scalar(0);
+    std::vector<double> m_cos;
+    std::vector<cd> m_sin;
+    std::vector<cd> m_R;  // n x n column-major
+    bool m_computed = false;
+
+    void require_computed() const
+    {
+        if (!m_computed)
+            throw std::logic_error("UpperHessenbergQR: need to call compute() first");
+    }
+    // rows i, i+1 of an (. x ncol) block with leading dimension ldy:  Y <- G_i Y  or  Y <- G_i^H Y
+    void rotate_rows(Scalar* Y, Index ldy, Index ncol, Index i, bool adjoint) const
+    {
+        const double c = m_cos[std::size_t(i)];
+        const cd s = adjoint ? -m_sin[std::size_t(i)] : m_sin[std::size_t(i)];
+        for (Index j = 0; j < ncol; j++)
+        {
+            Scalar* col = Y + j * ldy;
+            const cd a = col[i], b = col[i + 1];
+            col[i] = Scalar(c * a + s * b);
+            col[i + 1] = Scalar(-std::conj(s) * a + c * b);
+        }
+    }
+    // columns i, i+1 of an (nrow x .) block:  Y <- Y G_i  or  Y <- Y G_i^H
+    void rotate_cols(Scalar* Y, Index nrow, Index i, bool adjoint) const
+    {
+        const double c = m_cos[std::size_t(i)];
+        const cd s = adjoint ? -m_sin[std::size_t(i)] : m_sin[std::size_t(i)];
+        Scalar* a = Y + i * nrow;
+        Scalar* b = a + nrow;
+        for (Index j = 0; j < nrow; j++)
+        {
+            const cd t = a[j], u = b[j];
+            a[j] = Scalar(c * t - std::conj(s) * u);
+            b[j] = Scalar(s * t + c * u);
+        }
+    }
+
+public:
+    explicit UpperHessenbergQR(Index size = 0) : m_n(size) {}
+    UpperHessenbergQR(const Matrix& mat, const Scalar& shift = Scalar(0)) { compute(mat, shift); }
+    virtual ~UpperHessenbergQR() {}
+
+    virtual void compute(const Matrix& mat, const Scalar& shift = Scalar(0))
+    {
+        m_n = mat.rows();
+        if (m_n != mat.cols())
+            throw std::invalid_argument("UpperHessenbergQR: matrix must be square");
+        m_shift = shift;
+        const int n = static_cast<int>(m_n);
+        std::vector<cd> H(std::size_t(n) * n);
+        for (int j = 0; j < n; j++)
+            for (int i = 0; i < n; i++)
+                H[std::size_t(j) * n + i] = cd(mat(i, j));
+        m_cos.assign(std::size_t(n > 0 ? n : 1), 0.0);
+        m_sin.assign(std::size_t(n > 0 ? n : 1), cd(0.0));
+        m_R.assign(std::size_t(n) * n, cd(0.0));
+        mispec::small::hess_shifted_qr_complex(n, H.data(), n, cd(shift), m_R.data(), m_cos.data(), m_sin.data());
+        m_computed = true;
+    }
+
+    virtual Matrix matrix_R() const
+    {
+        require_computed();
+        Matrix R(m_n, m_n);
+        for (Index j = 0; j < m_n; j++)
+            for (Index i = 0; i < m_n; i++)
+                R(i, j) = Scalar(m_R[std::size_t(j) * m_n + i]);
+        return R;
+    }
+
+    // dest <- Q^H H Q = RQ + sI
+    virtual void matrix_QtHQ(Matrix& dest) const
+    {
+        require_computed();
+        const int n = static_cast<int>(m_n);
+        std::vector<cd> out(std::size_t(n) * n);
+        mispec::small::hess_rq_complex(n, m_R.data(), cd(m_shift), m_cos.data(), m_sin.data(), out.data());
+        dest.resize(m_n, m_n);
+        for (Index j = 0; j < m_n; j++)
+            for (Index i = 0; i < m_n; i++)
+                dest(i, j) = Scalar(out[std::size_t(j) * m_n + i]);
+    }
+
+    void apply_QY(Vector& Y) const
+    {
+        require_computed();
+        for (Index i = m_n - 2; i >= 0; i--)
+            rotate_rows(Y.data(), m_n, 1, i, false);
+    }
+    void apply_QY(Matrix& Y) const
+    {
+        require_computed();
+        for (Index i = m_n - 2; i >= 0; i--)
+            rotate_rows(Y.data(), Y.rows(), Y.cols(), i, false);
+    }
+    void apply_QtY(Vector& Y) const
+    {
+        require_computed();
+        for (Index i = 0; i < m_n - 1; i++)
+            rotate_rows(Y.data(), m_n, 1, i, true);
+    }
+    void apply_QtY(Matrix& Y) const
+    {
+        require_computed();
+        for (Index i = 0; i < m_n - 1; i++)
+            rotate_rows(Y.data(), Y.rows(), Y.cols(), i, true);
+    }
+    void apply_YQ(Matrix& Y) const
+    {
+        require_computed();
+        for (Index i = 0; i < m_n - 1; i++)
+            rotate_cols(Y.data(), Y.rows(), i, false);
+    }
+    void apply_YQt(Matrix& Y) const
+    {
+        require_computed();
+        for (Index i = m_n - 2; i >= 0; i--)
+            rotate_cols(Y.data(), Y.rows(), i, true);
     }
 };
 

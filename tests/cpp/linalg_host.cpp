@@ -4,6 +4,7 @@
 // Plain C++11, no GPU, no library: g++ -std=c++11 -I include tests/cpp/linalg_host.cpp
 #include <Spectra/LinAlg/BKLDLT.h>
 #include <Spectra/LinAlg/DoubleShiftQR.h>
+#include <Spectra/LinAlg/Givens.h>
 #include <Spectra/LinAlg/Orthogonalization.h>
 #include <Spectra/LinAlg/TridiagEigen.h>
 #include <Spectra/LinAlg/UpperHessenbergEigen.h>
@@ -132,6 +133,157 @@ static void run_qr(const Matrix& H, double shift)
         e2 = std::fmax(e2, std::fabs(qty[i] - b));
     }
     REQUIRE(e1 <= tol && e2 <= tol);
+}
+
+// ---- complex scalars (test/Givens.cpp:103-152, test/QR.cpp:176-189, test/Eigen.cpp:112-152) --------------------------------
+using cd = std::complex<double>;
+using CMatrix = DenseMatrix<cd>;
+using CVector = DenseVector<cd>;
+
+// op: 0 = as is, 1 = adjoint
+static CMatrix cmul(const CMatrix& A, const CMatrix& B, int opa = 0, int opb = 0)
+{
+    const Index m = opa ? A.cols() : A.rows(), k = opa ? A.rows() : A.cols(), n = opb ? B.rows() : B.cols();
+    CMatrix C(m, n);
+    for (Index j = 0; j < n; j++)
+        for (Index i = 0; i < m; i++)
+        {
+            cd acc(0.0);
+            for (Index l = 0; l < k; l++)
+                acc += (opa ? std::conj(A(l, i)) : A(i, l)) * (opb ? std::conj(B(j, l)) : B(l, j));
+            C(i, j) = acc;
+        }
+    return C;
+}
+static double cmax_diff(const CMatrix& A, const CMatrix& B)
+{
+    double e = 0.0;
+    for (Index j = 0; j < A.cols(); j++)
+        for (Index i = 0; i < A.rows(); i++)
+            e = std::fmax(e, std::abs(A(i, j) - B(i, j)));
+    return e;
+}
+static CMatrix cidentity(Index n)
+{
+    CMatrix I(n, n);
+    for (Index j = 0; j < n; j++)
+        for (Index i = 0; i < n; i++)
+            I(i, j) = (i == j) ? cd(1.0) : cd(0.0);
+    return I;
+}
+static CMatrix crandom(Index r, Index c)
+{
+    CMatrix M(r, c);
+    for (Index j = 0; j < c; j++)
+        for (Index i = 0; i < r; i++)
+            M(i, j) = cd(rnd(), rnd());
+    return M;
+}
+
+static void run_complex_givens()
+{
+    // G = [c s; -conj(s) c]:  c x - s y = r,  conj(s) x + c y = 0, c real; zero and tiny-ratio operands included
+    double r_err = 0.0, z_err = 0.0, u_err = 0.0;
+    for (int it = 0; it < 20000; it++)
+    {
+        cd x(100.0 * rnd(), 100.0 * rnd()), y(100.0 * rnd(), 100.0 * rnd());
+        if (it % 10 == 1) x = cd(0.0);
+        if (it % 10 == 2) y = cd(0.0);
+        if (it % 10 == 3) x = cd(x.real(), 0.0);
+        if (it % 10 == 4) y = cd(0.0, y.imag());
+        if (it % 10 == 5) y *= 1e-9;   // Taylor branch of the scaling
+        if (it % 10 == 6) x *= 1e-9;
+        if (it == 7) x = y = cd(0.0);
+        cd r, s;
+        double c;
+        Givens<cd>::compute_rotation(x, y, r, c, s);
+        const double scale = std::fmax(1.0, std::abs(x) + std::abs(y));
+        r_err = std::fmax(r_err, std::abs(c * x - s * y - r) / scale);
+        z_err = std::fmax(z_err, std::abs(std::conj(s) * x + c * y) / scale);
+        u_err = std::fmax(u_err, std::fabs(c * c + std::norm(s) - 1.0));
+    }
+    REQUIRE(r_err <= 1e-14 && z_err <= 1e-14 && u_err <= 1e-14);
+}
+
+static void run_complex_qr(const CMatrix& H, cd shift)
+{
+    const Index n = H.rows();
+    const double tol = 1e-12;
+    UpperHessenbergQR<cd> decomp(H, shift);
+    CMatrix Hs = H;
+    for (Index i = 0; i < n; i++)
+        Hs(i, i) -= shift;
+    const CMatrix I = cidentity(n);
+    CMatrix Q = I;
+    decomp.apply_QY(Q);
+    REQUIRE(cmax_diff(cmul(Q, Q, 1, 0), I) <= tol);
+    REQUIRE(cmax_diff(cmul(Q, Q, 0, 1), I) <= tol);
+    const CMatrix R = decomp.matrix_R();
+    double low = 0.0;
+    for (Index j = 0; j < n; j++)
+        for (Index i = j + 1; i < n; i++)
+            low = std::fmax(low, std::abs(R(i, j)));
+    REQUIRE(low <= tol);
+    REQUIRE(cmax_diff(Hs, cmul(Q, R)) <= tol);
+    CMatrix QtHQ;
+    decomp.matrix_QtHQ(QtHQ);
+    REQUIRE(cmax_diff(QtHQ, cmul(cmul(Q, H, 1, 0), Q)) <= tol);
+    const CMatrix Y = crandom(n, n);
+    CMatrix W = Y;
+    decomp.apply_QY(W);
+    REQUIRE(cmax_diff(W, cmul(Q, Y)) <= tol);
+    W = Y;
+    decomp.apply_YQ(W);
+    REQUIRE(cmax_diff(W, cmul(Y, Q)) <= tol);
+    W = Y;
+    decomp.apply_QtY(W);
+    REQUIRE(cmax_diff(W, cmul(Q, Y, 1, 0)) <= tol);
+    W = Y;
+    decomp.apply_YQt(W);
+    REQUIRE(cmax_diff(W, cmul(Y, Q, 0, 1)) <= tol);
+    CVector y(n), qy(n), qty(n);
+    for (Index i = 0; i < n; i++)
+        qy[i] = qty[i] = y[i] = cd(rnd(), rnd());
+    decomp.apply_QY(qy);
+    decomp.apply_QtY(qty);
+    double e1 = 0.0, e2 = 0.0;
+    for (Index i = 0; i < n; i++)
+    {
+        cd a(0.0), b(0.0);
+        for (Index l = 0; l < n; l++)
+        {
+            a += Q(i, l) * y[l];
+            b += std::conj(Q(l, i)) * y[l];
+        }
+        e1 = std::fmax(e1, std::abs(qy[i] - a));
+        e2 = std::fmax(e2, std::abs(qty[i] - b));
+    }
+    REQUIRE(e1 <= tol && e2 <= tol);
+}
+
+static void run_complex_eigen(const CMatrix& H)
+{
+    const Index n = H.rows();
+    UpperHessenbergEigen<cd> eig(H);
+    const CVector& ev = eig.eigenvalues();
+    const CMatrix& X = eig.eigenvectors();
+    double err = 0.0, unit = 0.0;
+    for (Index j = 0; j < n; j++)
+    {
+        double nrm2 = 0.0;
+        for (Index i = 0; i < n; i++)
+        {
+            cd acc(0.0);
+            for (Index l = 0; l < n; l++)
+                acc += H(i, l) * X(l, j);
+            err = std::fmax(err, std::abs(acc - ev[j] * X(i, j)));
+            nrm2 += std::norm(X(i, j));
+        }
+        unit = std::fmax(unit, std::fabs(nrm2 - 1.0));
+        if (j > 0)
+            REQUIRE(std::abs(ev[j - 1]) <= std::abs(ev[j]));  // increasing modulus (UpperHessenbergEigen.h:384-399)
+    }
+    REQUIRE(err <= 1e-12 && unit <= 1e-13);
 }
 
 int main()
@@ -385,6 +537,27 @@ int main()
         REQUIRE(be[0] == 4 && be[1] == 1 && be[2] == 2 && be[3] == 3 && be[4] == 5 && be[5] == 0);
         std::vector<double> vec(v, v + 6);
         REQUIRE(argsort(SortRule::SmallestAlge, vec) == (SortEigenvalue<double, SortRule::SmallestAlge>(v, 6).index()));
+    }
+    {
+        // the complex instantiations of the host-side classes
+        run_complex_givens();
+        CMatrix Hc = crandom(n, n);
+        for (Index j = 0; j < n; j++)
+            for (Index i = j + 2; i < n; i++)
+                Hc(i, j) = cd(0.0);
+        run_complex_qr(Hc, cd(1.2345, -5.4321));
+        run_complex_qr(Hc, cd(0.0));
+        run_complex_eigen(Hc);
+        CMatrix Hz = Hc;  // a zero sub-diagonal entry and a repeated diagonal pair
+        Hz(40, 39) = cd(0.0);
+        Hz(11, 11) = Hz(10, 10);
+        Hz(11, 10) = cd(0.0);
+        run_complex_qr(Hz, cd(-0.5, 0.25));
+        run_complex_eigen(Hz);
+        CMatrix one(1, 1);
+        one(0, 0) = cd(2.0, -1.0);
+        run_complex_qr(one, cd(0.5));
+        run_complex_eigen(one);
     }
     std::printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);
     return failures ? 1 : 0;
