@@ -26,9 +26,8 @@
 
 namespace Spectra {
 
-// Placeholder for B = I in A x = lambda B x (reference: MatOp/internal/ArnoldiOp.h:105-106).
-class IdentityBOp
-{};
+// IdentityBOp, the placeholder for B = I in A x = lambda B x, comes from MatOp/internal/ArnoldiOp.h (through LinAlg/Arnoldi.h), where
+// the reference declares it (MatOp/internal/ArnoldiOp.h:105-106).
 
 template <typename OpType, typename BOpType = IdentityBOp>
 class HermEigsBase

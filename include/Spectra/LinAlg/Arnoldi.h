@@ -14,12 +14,16 @@
 #ifndef MISPEC_SPECTRA_ARNOLDI_H
 #define MISPEC_SPECTRA_ARNOLDI_H
 
+#include <complex>
 #include <cstdint>
 #include <memory>
+#include <stdexcept>
 #include <type_traits>
 #include <utility>
 #include <vector>
 
+#include "../MatOp/internal/ArnoldiOp.h"
+#include "../internal/ComplexDense.h"
 #include "../internal/Dense.h"
 #include "../internal/Device.h"
 
@@ -358,6 +362,150 @@ public:
 
     mispec_fac* handle() const { return m_fac.get(); }
     mispec_ctx* context() const { return m_ctx.get(); }
+};
+
+// ---- complex scalars (outside the hot path of SURVEY.md section 8) ---------------------------------------------------------
+namespace internal {
+template <typename T, typename = void>
+struct has_device_zdense : std::false_type
+{};
+template <typename T>
+struct has_device_zdense<T, void_t<decltype(std::declval<const T&>().mispec_zdense_matrix())>> : std::true_type
+{};
+
+// The factorisation for Scalar = std::complex<double>: basis, residual and (for the dense operators) the matrix in HBM behind a
+// mispec_zfac handle (include/mispec_extras.h, csrc/zfac.hip); host-driven steps in the reference's order (Arnoldi.h:136-295,
+// Lanczos.h:62-187).  Any other operator is used through perform_op on host pointers.
+template <typename OpType>
+class ComplexArnoldi
+{
+public:
+    using Scalar = typename OpType::Scalar;
+
+protected:
+    static_assert(std::is_same<Scalar, std::complex<double>>::value, "complex factorisation: Scalar must be std::complex<double>");
+    using Matrix = DenseMatrix<Scalar>;
+    using Vector = DenseVector<Scalar>;
+
+    const OpType& m_op;
+    const Index m_n;
+    const Index m_m;
+    CtxPtr m_ctx;
+    std::shared_ptr<mispec_zfac> m_zfac;
+
+    static int call_user_op(void* user, const double* x_in, double* y_out)
+    {
+        try
+        {
+            static_cast<const OpType*>(user)->perform_op(reinterpret_cast<const Scalar*>(x_in), reinterpret_cast<Scalar*>(y_out));
+            return 0;
+        }
+        catch (...)
+        {
+            return 1;
+        }
+    }
+    template <typename T = OpType>
+    typename std::enable_if<has_device_zdense<T>::value>::type bind(bool hermitian)
+    {
+        m_ctx = borrow_context(m_op.mispec_context());
+        mispec_zfac* raw = nullptr;
+        check(mispec_zfac_create_dense(m_ctx.get(), m_op.mispec_zdense_matrix(), static_cast<int>(m_m), hermitian ? 1 : 0, &raw));
+        m_zfac = std::shared_ptr<mispec_zfac>(raw, [](mispec_zfac* p) { (void) mispec_zfac_destroy(p); });
+    }
+    template <typename T = OpType>
+    typename std::enable_if<!has_device_zdense<T>::value>::type bind(bool hermitian)
+    {
+        m_ctx = context_of(m_op);
+        mispec_zfac* raw = nullptr;
+        check(mispec_zfac_create_op(m_ctx.get(), &ComplexArnoldi::call_user_op, const_cast<OpType*>(&m_op), m_n, static_cast<int>(m_m),
+                                    hermitian ? 1 : 0, &raw));
+        m_zfac = std::shared_ptr<mispec_zfac>(raw, [](mispec_zfac* p) { (void) mispec_zfac_destroy(p); });
+    }
+
+    ComplexArnoldi(const OpType& op, Index m, bool hermitian) : m_op(op), m_n(op.rows()), m_m(m) { bind(hermitian); }
+
+public:
+    ComplexArnoldi(const OpType& op, Index m) : ComplexArnoldi(op, m, false) {}
+    virtual ~ComplexArnoldi() {}
+
+    void init(const Scalar* v0, Index& op_counter)
+    {
+        std::int64_t cnt = op_counter;
+        check(mispec_zfac_init(m_zfac.get(), reinterpret_cast<const double*>(v0), &cnt));
+        op_counter = static_cast<Index>(cnt);
+    }
+    virtual void factorize_from(Index from_k, Index to_m, Index& op_counter)
+    {
+        std::int64_t cnt = op_counter;
+        check(mispec_zfac_factorize(m_zfac.get(), static_cast<int>(from_k), static_cast<int>(to_m), &cnt));
+        op_counter = static_cast<Index>(cnt);
+    }
+    Index subspace_dim() const { return mispec_zfac_subspace_dim(m_zfac.get()); }
+    double f_norm() const
+    {
+        double b = 0;
+        check(mispec_zfac_f_norm(m_zfac.get(), &b));
+        return b;
+    }
+    Matrix matrix_H() const
+    {
+        Matrix H(m_m, m_m);
+        check(mispec_zfac_get_H(m_zfac.get(), reinterpret_cast<double*>(H.data())));
+        return H;
+    }
+    Matrix matrix_V() const
+    {
+        Matrix V(m_n, m_m);
+        check(mispec_zfac_get_V(m_zfac.get(), static_cast<int>(m_m), reinterpret_cast<double*>(V.data())));
+        return V;
+    }
+    Vector vector_f() const
+    {
+        Vector f(m_n);
+        check(mispec_zfac_get_f(m_zfac.get(), reinterpret_cast<double*>(f.data())));
+        return f;
+    }
+    mispec_zfac* handle() const { return m_zfac.get(); }
+    mispec_ctx* context() const { return m_ctx.get(); }
+};
+
+// double -> the device factorisation above, std::complex<double> -> ComplexArnoldi
+template <typename OpType, typename Scalar = typename OpType::Scalar>
+struct factorisation_of
+{
+    using type = Arnoldi<OpType>;
+};
+template <typename OpType>
+struct factorisation_of<OpType, std::complex<double>>
+{
+    using type = ComplexArnoldi<OpType>;
+};
+}  // namespace internal
+
+// The reference's spelling, Arnoldi<ArnoldiOp<OpType, IdentityBOp>> (Arnoldi.h:32-343 takes the wrapper, test/Arnoldi.cpp:94-138):
+// the factorisation of the wrapped operator; init() also takes the start vector as a vector object (Arnoldi.h:136).
+template <typename OpType>
+class Arnoldi<ArnoldiOp<OpType, IdentityBOp>> : public internal::factorisation_of<OpType>::type
+{
+    using Base = typename internal::factorisation_of<OpType>::type;
+
+protected:
+    Arnoldi(const ArnoldiOp<OpType, IdentityBOp>& op, Index m, bool symmetric) : Base(op.op(), m, symmetric) {}
+
+public:
+    using Scalar = typename OpType::Scalar;
+
+    Arnoldi(const ArnoldiOp<OpType, IdentityBOp>& op, Index m) : Base(op.op(), m, false) {}
+
+    using Base::init;
+    template <typename VectorType>
+    auto init(const VectorType& v0, Index& op_counter) -> decltype(v0.data(), void())
+    {
+        if (static_cast<Index>(v0.size()) != this->m_n)
+            throw std::invalid_argument("Arnoldi: the initial vector must have as many entries as the operator has rows");
+        Base::init(v0.data(), op_counter);
+    }
 };
 
 }  // namespace Spectra

@@ -41,6 +41,19 @@ public:
     }
 };
 
+// The reference's spelling, Lanczos<ArnoldiOp<OpType, IdentityBOp>> (Lanczos.h:28-217, test/Arnoldi.cpp:108-158): the symmetric /
+// Hermitian factorisation of the wrapped operator.
+template <typename OpType>
+class Lanczos<ArnoldiOp<OpType, IdentityBOp>> : public Arnoldi<ArnoldiOp<OpType, IdentityBOp>>
+{
+    using Base = Arnoldi<ArnoldiOp<OpType, IdentityBOp>>;
+
+public:
+    using Scalar = typename OpType::Scalar;
+
+    Lanczos(const ArnoldiOp<OpType, IdentityBOp>& op, Index m) : Base(op, m, true) {}
+};
+
 }  // namespace Spectra
 
 #endif

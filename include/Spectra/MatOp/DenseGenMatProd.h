@@ -9,6 +9,7 @@
 #include <stdexcept>
 #include <type_traits>
 
+#include "../internal/ComplexDense.h"
 #include "../internal/Dense.h"
 #include "../internal/Device.h"
 
@@ -82,6 +83,32 @@ public:
 
     mispec_ctx* mispec_context() const { return m_ctx.get(); }
     const mispec_dense* mispec_dense_matrix() const { return m_mat.get(); }
+};
+
+// Complex general dense A (the reference instantiates the same template with std::complex, test/Arnoldi.cpp:122-138): the
+// matrix in HBM as interleaved (re, im) pairs; outside the hot path of SURVEY.md section 8.
+template <int Flags>
+class DenseGenMatProd<std::complex<double>, Flags> : public internal::ComplexDenseOp
+{
+public:
+    using Scalar = std::complex<double>;
+
+    explicit DenseGenMatProd(const DenseView<Scalar>& mat, internal::CtxPtr ctx = internal::CtxPtr()) : internal::ComplexDenseOp(ctx)
+    {
+        ingest(mat, Flags == RowMajor, 0, "DenseGenMatProd");
+    }
+#ifdef MISPEC_HAVE_EIGEN
+    template <typename Derived>
+    DenseGenMatProd(const Eigen::MatrixBase<Derived>& mat) : internal::ComplexDenseOp(internal::CtxPtr())
+    {
+        using Plain = Eigen::Matrix<Scalar, Eigen::Dynamic, Eigen::Dynamic, Flags>;
+        static_assert(static_cast<int>(Derived::PlainObject::IsRowMajor) == static_cast<int>(Plain::IsRowMajor),
+                      "DenseGenMatProd: the \"Flags\" template parameter does not match the input matrix");
+        const Plain tmp(mat);
+        ingest(DenseView<Scalar>(tmp.rows(), tmp.cols(), tmp.data(), tmp.outerStride(), Plain::IsRowMajor), Flags == RowMajor, 0,
+               "DenseGenMatProd");
+    }
+#endif
 };
 
 }  // namespace Spectra

@@ -93,6 +93,36 @@ int mispec_geneigs_create_complex_shift(mispec_ctx* ctx, mispec_symshift* S, int
 
 int mispec_geneigs_create_dense(mispec_ctx* ctx, const mispec_dense* D, int64_t nev, int64_t ncv, mispec_geneigs** out);
 
+/* ---------------------------------------------------------------------------
+ * Complex scalars — the reference's factorisation templates instantiated with std::complex<double>
+ * (LinAlg/Arnoldi.h:136-295, LinAlg/Lanczos.h:62-187 over MatOp/DenseGenMatProd.h / DenseHermMatProd.h; test/Arnoldi.cpp:122-158).
+ * Complex numbers cross the boundary interleaved: a `double*` of 2 * count entries (re, im), the layout of std::complex<double>.
+ * The basis, the residual and a dense operator live in HBM; steps are host-driven in the reference's order.
+ * uplo = 'L' / 'U': Hermitian, only that triangle of the input is read (mirrored conjugated, diagonal taken real); 0: general.
+ * ------------------------------------------------------------------------- */
+typedef struct mispec_zdense mispec_zdense;
+int mispec_zdense_upload(mispec_ctx* ctx, int64_t rows, int64_t cols, const double* data_host, int64_t ld_host, int row_major,
+                         char uplo, mispec_zdense** out);
+int mispec_zdense_destroy(mispec_zdense* D);
+int64_t mispec_zdense_rows(const mispec_zdense* D);
+int64_t mispec_zdense_cols(const mispec_zdense* D);
+int mispec_zdense_gemv_host(const mispec_zdense* D, const double* x_host, double* y_host); /* literal perform_op */
+int mispec_zdense_coeff(const mispec_zdense* D, int64_t i, int64_t j, double* out_re_im);
+/* user operator on host pointers: y = Op(x), n complex entries each; non-zero return = error */
+typedef int (*mispec_zop_fn)(void* user, const double* x_host, double* y_host);
+typedef struct mispec_zfac mispec_zfac;
+/* hermitian != 0: the three-term flow of Lanczos.h; 0: the full projection of Arnoldi.h */
+int mispec_zfac_create_dense(mispec_ctx* ctx, const mispec_zdense* D, int ncv, int hermitian, mispec_zfac** out);
+int mispec_zfac_create_op(mispec_ctx* ctx, mispec_zop_fn op, void* op_user, int64_t n, int ncv, int hermitian, mispec_zfac** out);
+int mispec_zfac_destroy(mispec_zfac* F);
+int mispec_zfac_init(mispec_zfac* F, const double* v0_host, int64_t* op_counter);
+int mispec_zfac_factorize(mispec_zfac* F, int from_k, int to_m, int64_t* op_counter);
+int mispec_zfac_subspace_dim(const mispec_zfac* F);
+int mispec_zfac_f_norm(const mispec_zfac* F, double* out);
+int mispec_zfac_get_H(const mispec_zfac* F, double* H_host);            /* ncv x ncv, column-major */
+int mispec_zfac_get_V(const mispec_zfac* F, int ncols, double* V_host); /* n x ncols, column-major */
+int mispec_zfac_get_f(const mispec_zfac* F, double* f_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -113,6 +113,23 @@ SIGNATURES = {
     "mispec_fac_create_device_op": (C.c_int, [_vp, device_op_fn, _vp, C.c_int64, C.c_int, C.c_int, _vpp]),
     "mispec_fac_create_dense": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vpp]),
     "mispec_dense_upload": (C.c_int, [_vp, C.c_int64, C.c_int64, _dp, C.c_int64, C.c_int, C.c_char, _vpp]),
+    # complex scalars (mispec_extras.h): interleaved (re, im) doubles
+    "mispec_zdense_upload": (C.c_int, [_vp, C.c_int64, C.c_int64, _dp, C.c_int64, C.c_int, C.c_char, _vpp]),
+    "mispec_zdense_destroy": (C.c_int, [_vp]),
+    "mispec_zdense_rows": (C.c_int64, [_vp]),
+    "mispec_zdense_cols": (C.c_int64, [_vp]),
+    "mispec_zdense_gemv_host": (C.c_int, [_vp, _dp, _dp]),
+    "mispec_zdense_coeff": (C.c_int, [_vp, C.c_int64, C.c_int64, _dp]),
+    "mispec_zfac_create_dense": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vpp]),
+    "mispec_zfac_create_op": (C.c_int, [_vp, op_fn, _vp, C.c_int64, C.c_int, C.c_int, _vpp]),
+    "mispec_zfac_destroy": (C.c_int, [_vp]),
+    "mispec_zfac_init": (C.c_int, [_vp, _dp, _lp]),
+    "mispec_zfac_factorize": (C.c_int, [_vp, C.c_int, C.c_int, _lp]),
+    "mispec_zfac_subspace_dim": (C.c_int, [_vp]),
+    "mispec_zfac_f_norm": (C.c_int, [_vp, _dp]),
+    "mispec_zfac_get_H": (C.c_int, [_vp, _dp]),
+    "mispec_zfac_get_V": (C.c_int, [_vp, C.c_int, _dp]),
+    "mispec_zfac_get_f": (C.c_int, [_vp, _dp]),
     "mispec_dense_destroy": (C.c_int, [_vp]),
     "mispec_dense_rows": (C.c_int64, [_vp]),
     "mispec_dense_cols": (C.c_int64, [_vp]),

@@ -16,14 +16,15 @@ fi
 mkdir -p "$OUT"
 CXX="${CXX:-g++}"
 FLAGS="-std=c++11 -O1 -w -I$ROOT/tests/cpp/eigen_lite -I$ROOT/include -I$REF/test"
-# Programs that instantiate complex scalars and Eigen's dense decompositions next to the double cases (Givens, QR, Eigen): the
-# fuller stand-in oracle/eigen_shim (C++17) takes Eigen's place for these — test infrastructure on both sides of the comparison;
-# what is under test is include/Spectra/LinAlg.  They test host-side classes only and run without a GPU.
-SHIM_PROGRAMS=" Givens QR Eigen "
+# Programs that instantiate complex scalars and Eigen's dense decompositions next to the double cases (Givens, QR, Eigen, Arnoldi):
+# the fuller stand-in oracle/eigen_shim (C++17) takes Eigen's place for these — test infrastructure on both sides of the
+# comparison; what is under test is include/Spectra/LinAlg.  Givens, QR and Eigen test host-side classes only and run without a
+# GPU; Arnoldi runs the device factorisations (real and complex, dense operators).
+SHIM_PROGRAMS=" Givens QR Eigen Arnoldi "
 SHIM_FLAGS="-std=c++17 -O2 -w -I$ROOT/oracle/eigen_shim -I$ROOT/include -I$REF/test"
 LINK="-L$ROOT/spectra_amd -lmispec -Wl,-rpath,\$ORIGIN/../../../spectra_amd"
-# the last five test host-side classes only and run without a GPU
-LIST="${*:-SymEigs SymEigsShift GenEigs GenEigsRealShift GenEigsComplexShift SymGEigsCholesky SymGEigsRegInv SVD DavidsonSymEigs Example1 Example2 Example3 Example4 Schur Orthogonalization Givens QR Eigen}"
+# Schur, Orthogonalization, Givens, QR and Eigen test host-side classes only and run without a GPU
+LIST="${*:-SymEigs SymEigsShift GenEigs GenEigsRealShift GenEigsComplexShift SymGEigsCholesky SymGEigsRegInv SVD DavidsonSymEigs Example1 Example2 Example3 Example4 Schur Orthogonalization Givens QR Eigen Arnoldi}"
 # Catch2's main(): compiled once
 if [ ! -f "$OUT/tests-main.o" ] || [ "$REF/test/tests-main.cpp" -nt "$OUT/tests-main.o" ]; then
     $CXX $FLAGS -c "$REF/test/tests-main.cpp" -o "$OUT/tests-main.o" || exit 1

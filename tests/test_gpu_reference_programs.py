@@ -3,11 +3,12 @@ UNMODIFIED against include/Spectra — tests/cpp/eigen_lite stands in for Eigen,
 libmispec.so (tests/cpp/build_reference_tests.sh, run by __graft_entry__.build() where the reference is present).  The binaries
 are built in the container that holds /root/reference and travel to the GPU box; nothing here reads the reference at run time.
 
-Programs that cannot be built against this repository and why: {Dense,Sparse}{Sym,Gen}MatProd.cpp, HermEigs.cpp, ComplexEigs.cpp,
-Arnoldi.cpp, BKLDLT.cpp instantiate float / complex scalars (the device path is fp64 real), SymGEigsShift.cpp passes a dense B
-to SymShiftInvert (sparse only here), Givens / QR / Eigen / Schur / Orthogonalization.cpp need decompositions of Eigen that
-eigen_lite does not restate (their checks are restated in tests/cpp/linalg_host.cpp), JDSym*.cpp / RitzPairs / SearchSpace test
-internals of the Davidson solver that live in libmispec.so here."""
+Elsewhere: Givens / QR / Eigen / Schur / Orthogonalization.cpp test host-side classes and run without a GPU
+(tests/test_cpp_reference_programs_host.py); Arnoldi.cpp (real and complex factorisations over the dense operators) runs in
+tests/test_gpu_zfac.py.  Programs that cannot be built against this repository and why: {Dense,Sparse}{Sym,Gen}MatProd.cpp,
+HermEigs.cpp, ComplexEigs.cpp, BKLDLT.cpp instantiate float scalars or the complex SOLVERS (the device solvers are fp64 real),
+SymGEigsShift.cpp passes a dense B to SymShiftInvert (sparse only here), JDSym*.cpp / RitzPairs / SearchSpace test internals of
+the Davidson solver that live in libmispec.so here."""
 import os
 import subprocess
 
