@@ -2,6 +2,7 @@
 // (MatOp/DenseGenMatProd.h:27-102): Scalar, rows(), cols(), perform_op(), operator*, operator().
 // The matrix is copied to HBM once (row-major there, whatever the input order); the solvers bind the device
 // matrix and never call perform_op, which keeps the reference's host-pointer contract for other callers.
+// Scalar = float is accepted at this boundary (test/DenseGenMatProd.cpp:12): widened to the device's fp64, rounded once on the way out.
 #ifndef MISPEC_SPECTRA_DENSE_GEN_MAT_PROD_H
 #define MISPEC_SPECTRA_DENSE_GEN_MAT_PROD_H
 
@@ -22,7 +23,7 @@ public:
     using Scalar = Scalar_;
 
 private:
-    static_assert(std::is_same<Scalar_, double>::value, "the MI355X path computes in fp64: Scalar must be double");
+    static_assert(internal::is_device_scalar<Scalar_>::value, "Scalar must be double (or float, widened: the MI355X path computes in fp64)");
     using Matrix = DenseMatrix<Scalar>;
 
     internal::CtxPtr m_ctx;
@@ -34,7 +35,9 @@ private:
             throw std::invalid_argument(
                 "DenseGenMatProd: the \"Flags\" template parameter does not match the input matrix (ColMajor/RowMajor)");
         mispec_dense* raw = nullptr;
-        internal::check(mispec_dense_upload(m_ctx.get(), A.rows, A.cols, A.data, A.ld, A.row_major ? 1 : 0, 0, &raw));
+        const Index outer = A.row_major ? A.rows : A.cols, inner = A.row_major ? A.cols : A.rows;
+        const internal::WidenedIn<Scalar> values(A.data, static_cast<std::size_t>(outer > 0 ? (outer - 1) * A.ld + inner : 0));
+        internal::check(mispec_dense_upload(m_ctx.get(), A.rows, A.cols, values.data(), A.ld, A.row_major ? 1 : 0, 0, &raw));
         m_mat = std::shared_ptr<mispec_dense>(raw, [](mispec_dense* p) { (void) mispec_dense_destroy(p); });
     }
 
@@ -62,23 +65,31 @@ public:
     Index cols() const { return static_cast<Index>(mispec_dense_cols(m_mat.get())); }
 
     // y_out = A * x_in, host pointers (DenseGenMatProd.h:78-83)
-    void perform_op(const Scalar* x_in, Scalar* y_out) const { internal::check(mispec_dense_gemv_host(m_mat.get(), x_in, y_out)); }
+    void perform_op(const Scalar* x_in, Scalar* y_out) const
+    {
+        const internal::WidenedIn<Scalar> x(x_in, static_cast<std::size_t>(cols()));
+        internal::NarrowedOut<Scalar> y(y_out, static_cast<std::size_t>(rows()));
+        internal::check(mispec_dense_gemv_host(m_mat.get(), x.data(), y.data()));
+        y.store();
+    }
 
     // Y = A * X (DenseGenMatProd.h:88-91)
     Matrix operator*(const Matrix& mat_in) const
     {
         Matrix res(rows(), mat_in.cols());
-        internal::check(mispec_dense_gemm_host(m_mat.get(), mat_in.data(), mat_in.rows(), static_cast<int>(mat_in.cols()), res.data(),
-                                               res.rows()));
+        const internal::WidenedIn<Scalar> in(mat_in.data(), static_cast<std::size_t>(mat_in.rows() * mat_in.cols()));
+        internal::NarrowedOut<Scalar> out(res.data(), static_cast<std::size_t>(res.rows() * res.cols()));
+        internal::check(mispec_dense_gemm_host(m_mat.get(), in.data(), mat_in.rows(), static_cast<int>(mat_in.cols()), out.data(), res.rows()));
+        out.store();
         return res;
     }
 
     // A(i, j) (DenseGenMatProd.h:96-99)
     Scalar operator()(Index i, Index j) const
     {
-        Scalar v = 0;
+        double v = 0;
         internal::check(mispec_dense_coeff(m_mat.get(), i, j, &v));
-        return v;
+        return static_cast<Scalar>(v);
     }
 
     mispec_ctx* mispec_context() const { return m_ctx.get(); }

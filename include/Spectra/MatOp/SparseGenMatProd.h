@@ -2,6 +2,8 @@
 // signature and members as the reference class (MatOp/SparseGenMatProd.h:28-105).  As for
 // SparseSymMatProd the matrix is copied to HBM at construction (CSC input is transposed to CSR once)
 // and the solvers bind the device matrix directly instead of calling perform_op().
+// Scalar = float is accepted at this boundary like the reference's class (test/SparseGenMatProd.cpp:36): widened to the device's
+// fp64 on the way in, rounded once on the way out; the solvers themselves require double.
 #ifndef MISPEC_SPECTRA_SPARSE_GEN_MAT_PROD_H
 #define MISPEC_SPECTRA_SPARSE_GEN_MAT_PROD_H
 
@@ -19,7 +21,7 @@ public:
     using Scalar = Scalar_;
 
 private:
-    static_assert(std::is_same<Scalar_, double>::value, "the MI355X path computes in fp64: Scalar must be double");
+    static_assert(internal::is_device_scalar<Scalar_>::value, "Scalar must be double (or float, widened: the MI355X path computes in fp64)");
     static_assert(std::is_same<StorageIndex, int>::value, "sparse indices are int32 on the device");
     using Matrix = DenseMatrix<Scalar>;
 
@@ -32,10 +34,11 @@ private:
             throw std::invalid_argument(
                 "SparseGenMatProd: the \"Flags\" template parameter does not match the input matrix (ColMajor/RowMajor)");
         mispec_csr* raw = nullptr;
+        const internal::WidenedIn<Scalar> values(A.values, static_cast<std::size_t>(A.outer[A.row_major ? A.rows : A.cols]));
         if (A.row_major)
-            internal::check(mispec_csr_upload(m_ctx.get(), A.rows, A.cols, A.outer, A.inner, A.values, &raw));
+            internal::check(mispec_csr_upload(m_ctx.get(), A.rows, A.cols, A.outer, A.inner, values.data(), &raw));
         else
-            internal::check(mispec_csr_from_csc(m_ctx.get(), A.rows, A.cols, A.outer, A.inner, A.values, &raw));
+            internal::check(mispec_csr_from_csc(m_ctx.get(), A.rows, A.cols, A.outer, A.inner, values.data(), &raw));
         m_mat = std::shared_ptr<mispec_csr>(raw, [](mispec_csr* p) { (void) mispec_csr_destroy(p); });
     }
 
@@ -76,21 +79,29 @@ public:
     Index rows() const { return static_cast<Index>(mispec_csr_rows(m_mat.get())); }
     Index cols() const { return static_cast<Index>(mispec_csr_cols(m_mat.get())); }
 
-    void perform_op(const Scalar* x_in, Scalar* y_out) const { internal::check(mispec_spmv_host(m_mat.get(), x_in, y_out)); }
+    void perform_op(const Scalar* x_in, Scalar* y_out) const
+    {
+        const internal::WidenedIn<Scalar> x(x_in, static_cast<std::size_t>(cols()));
+        internal::NarrowedOut<Scalar> y(y_out, static_cast<std::size_t>(rows()));
+        internal::check(mispec_spmv_host(m_mat.get(), x.data(), y.data()));
+        y.store();
+    }
 
     Matrix operator*(const Matrix& mat_in) const
     {
         Matrix res(rows(), mat_in.cols());
-        internal::check(mispec_spmm_host(m_mat.get(), mat_in.data(), mat_in.rows(), static_cast<int>(mat_in.cols()), res.data(),
-                                         res.rows()));
+        const internal::WidenedIn<Scalar> in(mat_in.data(), static_cast<std::size_t>(mat_in.rows() * mat_in.cols()));
+        internal::NarrowedOut<Scalar> out(res.data(), static_cast<std::size_t>(res.rows() * res.cols()));
+        internal::check(mispec_spmm_host(m_mat.get(), in.data(), mat_in.rows(), static_cast<int>(mat_in.cols()), out.data(), res.rows()));
+        out.store();
         return res;
     }
 
     Scalar operator()(Index i, Index j) const
     {
-        Scalar v = 0;
+        double v = 0;
         internal::check(mispec_csr_coeff(m_mat.get(), i, j, &v));
-        return v;
+        return static_cast<Scalar>(v);
     }
 
     mispec_ctx* mispec_context() const { return m_ctx.get(); }

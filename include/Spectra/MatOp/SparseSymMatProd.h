@@ -9,6 +9,8 @@
 //   * perform_op(x_in, y_out) still takes HOST pointers and is then a staged H2D / kernel / D2H
 //     round trip; the solvers do not go through it for this class — they bind the device matrix
 //     directly (see HermEigsBase.h) and keep the whole Krylov basis in HBM.
+// Scalar = float is accepted at this boundary like the reference's class (test/SparseSymMatProd.cpp:37): values are widened to the
+// device's fp64 on the way in and results rounded once on the way out; the solvers themselves require double.
 #ifndef MISPEC_SPECTRA_SPARSE_SYM_MAT_PROD_H
 #define MISPEC_SPECTRA_SPARSE_SYM_MAT_PROD_H
 
@@ -27,7 +29,7 @@ public:
     using Scalar = Scalar_;
 
 private:
-    static_assert(std::is_same<Scalar_, double>::value, "the MI355X path computes in fp64: Scalar must be double");
+    static_assert(internal::is_device_scalar<Scalar_>::value, "Scalar must be double (or float, widened: the MI355X path computes in fp64)");
     static_assert(std::is_same<StorageIndex, int>::value, "sparse indices are int32 on the device");
     static_assert(Uplo == Lower || Uplo == Upper, "Uplo must be Lower or Upper");
     using Matrix = DenseMatrix<Scalar>;
@@ -43,7 +45,8 @@ private:
             throw std::invalid_argument(
                 "SparseSymMatProd: the \"Flags\" template parameter does not match the input matrix (ColMajor/RowMajor)");
         mispec_csr* raw = nullptr;
-        internal::check(mispec_csr_from_triangle(m_ctx.get(), A.rows, A.outer, A.inner, A.values, Uplo == Lower ? 'L' : 'U',
+        const internal::WidenedIn<Scalar> values(A.values, static_cast<std::size_t>(A.outer[A.rows]));
+        internal::check(mispec_csr_from_triangle(m_ctx.get(), A.rows, A.outer, A.inner, values.data(), Uplo == Lower ? 'L' : 'U',
                                                  A.row_major ? 1 : 0, &raw));
         m_mat = std::shared_ptr<mispec_csr>(raw, [](mispec_csr* p) { (void) mispec_csr_destroy(p); });
     }
@@ -90,14 +93,22 @@ public:
     Index cols() const { return static_cast<Index>(mispec_csr_cols(m_mat.get())); }
 
     // y_out = A * x_in, host pointers (the reference's contract, SparseSymMatProd.h:83-88)
-    void perform_op(const Scalar* x_in, Scalar* y_out) const { internal::check(mispec_spmv_host(m_mat.get(), x_in, y_out)); }
+    void perform_op(const Scalar* x_in, Scalar* y_out) const
+    {
+        const internal::WidenedIn<Scalar> x(x_in, static_cast<std::size_t>(cols()));
+        internal::NarrowedOut<Scalar> y(y_out, static_cast<std::size_t>(rows()));
+        internal::check(mispec_spmv_host(m_mat.get(), x.data(), y.data()));
+        y.store();
+    }
 
     // Y = A * X for a dense block (SparseSymMatProd.h:93-96)
     Matrix operator*(const Matrix& mat_in) const
     {
         Matrix res(rows(), mat_in.cols());
-        internal::check(mispec_spmm_host(m_mat.get(), mat_in.data(), mat_in.rows(), static_cast<int>(mat_in.cols()), res.data(),
-                                         res.rows()));
+        const internal::WidenedIn<Scalar> in(mat_in.data(), static_cast<std::size_t>(mat_in.rows() * mat_in.cols()));
+        internal::NarrowedOut<Scalar> out(res.data(), static_cast<std::size_t>(res.rows() * res.cols()));
+        internal::check(mispec_spmm_host(m_mat.get(), in.data(), mat_in.rows(), static_cast<int>(mat_in.cols()), out.data(), res.rows()));
+        out.store();
         return res;
     }
 
@@ -105,9 +116,9 @@ public:
     // input; here both triangles answer because the mirror is what is stored).
     Scalar operator()(Index i, Index j) const
     {
-        Scalar v = 0;
+        double v = 0;
         internal::check(mispec_csr_coeff(m_mat.get(), i, j, &v));
-        return v;
+        return static_cast<Scalar>(v);
     }
 
     // Device binding used by the solvers' fast path.

@@ -82,6 +82,76 @@ public:
 
 }  // namespace internal
 
+// fp32 at the operator boundary.  The device computes in fp64 only; the matrix operators also accept Scalar = float, as the
+// reference's do (test/SparseSymMatProd.cpp:37, TEMPLATE_TEST_CASE over float and double): the values are widened on the way in
+// (exact) and the result is rounded once on the way out.  For Scalar = double these are the caller's own pointers, no copy.
+namespace internal {
+template <typename T>
+struct is_device_scalar
+{
+    static constexpr bool value = false;
+};
+template <>
+struct is_device_scalar<double>
+{
+    static constexpr bool value = true;
+};
+template <>
+struct is_device_scalar<float>
+{
+    static constexpr bool value = true;
+};
+
+template <typename T>
+class WidenedIn;  // const T[count] seen as const double*
+template <>
+class WidenedIn<double>
+{
+    const double* m_p;
+
+public:
+    WidenedIn(const double* p, std::size_t) : m_p(p) {}
+    const double* data() const { return m_p; }
+};
+template <>
+class WidenedIn<float>
+{
+    std::vector<double> m_buf;
+
+public:
+    WidenedIn(const float* p, std::size_t count) : m_buf(p, p + (p ? count : 0)) {}
+    const double* data() const { return m_buf.data(); }
+};
+
+template <typename T>
+class NarrowedOut;  // T[count] written through a double*; store() rounds into the destination
+template <>
+class NarrowedOut<double>
+{
+    double* m_p;
+
+public:
+    NarrowedOut(double* p, std::size_t) : m_p(p) {}
+    double* data() { return m_p; }
+    void store() {}
+};
+template <>
+class NarrowedOut<float>
+{
+    float* m_dst;
+    std::vector<double> m_buf;
+
+public:
+    NarrowedOut(float* p, std::size_t count) : m_dst(p), m_buf(count) {}
+    double* data() { return m_buf.data(); }
+    void store()
+    {
+        for (std::size_t i = 0; i < m_buf.size(); i++)
+            m_dst[i] = static_cast<float>(m_buf[i]);
+    }
+};
+}  // namespace internal
+
 #ifdef MISPEC_HAVE_EIGEN
 template <typename T>
 using DenseVector = Eigen::Matrix<T, Eigen::Dynamic, 1>;

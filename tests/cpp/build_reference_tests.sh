@@ -19,12 +19,13 @@ FLAGS="-std=c++11 -O1 -w -I$ROOT/tests/cpp/eigen_lite -I$ROOT/include -I$REF/tes
 # Programs that instantiate complex scalars and Eigen's dense decompositions next to the double cases (Givens, QR, Eigen, Arnoldi):
 # the fuller stand-in oracle/eigen_shim (C++17) takes Eigen's place for these — test infrastructure on both sides of the
 # comparison; what is under test is include/Spectra/LinAlg.  Givens, QR and Eigen test host-side classes only and run without a
-# GPU; Arnoldi runs the device factorisations (real and complex, dense operators).
-SHIM_PROGRAMS=" Givens QR Eigen Arnoldi "
+# GPU; Arnoldi runs the device factorisations (real and complex, dense operators); the four *MatProd programs are
+# TEMPLATE_TEST_CASEs over float and double (their Random / isApprox / sparse expressions are the stand-in's).
+SHIM_PROGRAMS=" Givens QR Eigen Arnoldi SparseSymMatProd SparseGenMatProd DenseSymMatProd DenseGenMatProd "
 SHIM_FLAGS="-std=c++17 -O2 -w -I$ROOT/oracle/eigen_shim -I$ROOT/include -I$REF/test"
 LINK="-L$ROOT/spectra_amd -lmispec -Wl,-rpath,\$ORIGIN/../../../spectra_amd"
 # Schur, Orthogonalization, Givens, QR and Eigen test host-side classes only and run without a GPU
-LIST="${*:-SymEigs SymEigsShift GenEigs GenEigsRealShift GenEigsComplexShift SymGEigsCholesky SymGEigsRegInv SVD DavidsonSymEigs Example1 Example2 Example3 Example4 Schur Orthogonalization Givens QR Eigen Arnoldi}"
+LIST="${*:-SymEigs SymEigsShift GenEigs GenEigsRealShift GenEigsComplexShift SymGEigsCholesky SymGEigsRegInv SVD DavidsonSymEigs Example1 Example2 Example3 Example4 Schur Orthogonalization Givens QR Eigen Arnoldi SparseSymMatProd SparseGenMatProd DenseSymMatProd DenseGenMatProd}"
 # Catch2's main(): compiled once
 if [ ! -f "$OUT/tests-main.o" ] || [ "$REF/test/tests-main.cpp" -nt "$OUT/tests-main.o" ]; then
     $CXX $FLAGS -c "$REF/test/tests-main.cpp" -o "$OUT/tests-main.o" || exit 1

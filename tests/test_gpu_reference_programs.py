@@ -4,9 +4,8 @@ libmispec.so (tests/cpp/build_reference_tests.sh, run by __graft_entry__.build()
 are built in the container that holds /root/reference and travel to the GPU box; nothing here reads the reference at run time.
 
 Elsewhere: Givens / QR / Eigen / Schur / Orthogonalization.cpp test host-side classes and run without a GPU
-(tests/test_cpp_reference_programs_host.py); Arnoldi.cpp (real and complex factorisations over the dense operators) runs in
-tests/test_gpu_zfac.py.  Programs that cannot be built against this repository and why: {Dense,Sparse}{Sym,Gen}MatProd.cpp,
-HermEigs.cpp, ComplexEigs.cpp, BKLDLT.cpp instantiate float scalars or the complex SOLVERS (the device solvers are fp64 real),
+(tests/test_cpp_reference_programs_host.py).  Programs that cannot be built against this repository and why:
+HermEigs.cpp, ComplexEigs.cpp, BKLDLT.cpp instantiate the complex SOLVERS / a complex LDL' (the device solvers are fp64 real),
 SymGEigsShift.cpp passes a dense B to SymShiftInvert (sparse only here), JDSym*.cpp / RitzPairs / SearchSpace test internals of
 the Davidson solver that live in libmispec.so here."""
 import os
@@ -30,7 +29,9 @@ def orth_env(request, monkeypatch):
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "tests", "cpp", "_ref")
 PROGRAMS = ["SymEigs", "SymEigsShift", "GenEigs", "GenEigsRealShift", "GenEigsComplexShift", "SymGEigsCholesky", "SymGEigsRegInv",
-            "SVD", "DavidsonSymEigs", "Example1", "Example2", "Example3", "Example4"]
+            "SVD", "DavidsonSymEigs", "Example1", "Example2", "Example3", "Example4",
+            # built with oracle/eigen_shim in Eigen's place (complex and float instantiations, tests/cpp/build_reference_tests.sh)
+            "Arnoldi", "SparseSymMatProd", "SparseGenMatProd", "DenseSymMatProd", "DenseGenMatProd"]
 
 
 @pytest.mark.parametrize("name", PROGRAMS)
