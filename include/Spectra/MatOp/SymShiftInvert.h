@@ -2,7 +2,7 @@
 // solver are built on (reference: MatOp/SymShiftInvert.h:120-208, which factors A - sigma B with Eigen::SparseLU or
 // a dense Bunch-Kaufman LDLT depending on the storage of A and B).  Here both matrices are sparse and the
 // factorisation is the device one of SparseSymShiftSolve (spectra_amd/csrc/shiftsolve.hip): banded A - sigma B with
-// half-bandwidth <= 8, or any pattern with n <= 4096.
+// half-bandwidth <= 8 (<= 64 beyond n = 4096), or any pattern with n <= 4096.
 #ifndef MISPEC_SPECTRA_SYM_SHIFT_INVERT_H
 #define MISPEC_SPECTRA_SYM_SHIFT_INVERT_H
 

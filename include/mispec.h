@@ -207,7 +207,8 @@ int mispec_spmv_time(const mispec_csr* A, const double* x_dev, double* y_dev, in
  * Shift-and-invert operator  y = (A - sigma I)^{-1} x  for symmetric A — replaces SparseSymShiftSolve
  * (MatOp/SparseSymShiftSolve.h:36-111, which delegates to Eigen::SparseLU).  The factorisation is redone
  * by set_shift (once per shift); every solve runs on the device: a recursive partitioned banded LDL' when the
- * half-bandwidth is <= 8 (any n; sigma may lie inside the spectrum: tiny pivots are boosted and set_shift
+ * half-bandwidth is <= 8 (any n; top level factored on the device) or <= 64 with n > 4096 (longer chunks, levels
+ * factored on the host; sigma may lie inside the spectrum: tiny pivots are boosted and set_shift
  * calibrates the iterative-refinement steps each solve then performs, mispec_symshift_refinement_info), a dense
  * LU inverse + GEMV when n <= 4096 (the reference's own test fixtures); other sparsity patterns are rejected
  * by set_shift (MISPEC_EINVAL).  Input: one triangle of a compressed matrix, as for mispec_csr_from_triangle.
@@ -217,7 +218,7 @@ int mispec_symshift_create(mispec_ctx* ctx, int64_t n, const int32_t* outer_host
                            const double* val_host, char uplo, int row_major, mispec_symshift** out);
 /* Pencil form — SymShiftInvert<double, Eigen::Sparse, Eigen::Sparse> (MatOp/SymShiftInvert.h:140-208): the operator
  * (A - sigma B)^{-1} for two sparse symmetric matrices given by one triangle each; same restrictions as above on
- * the pattern of A - sigma B (banded with half-bandwidth <= 8, or n <= 4096). */
+ * the pattern of A - sigma B (banded with half-bandwidth <= 64, or n <= 4096). */
 int mispec_symshift_create_pencil(mispec_ctx* ctx, int64_t n, const int32_t* a_outer, const int32_t* a_inner,
                                   const double* a_val, char a_uplo, int a_row_major, const int32_t* b_outer,
                                   const int32_t* b_inner, const double* b_val, char b_uplo, int b_row_major,
@@ -228,6 +229,11 @@ int mispec_symshift_create_general(mispec_ctx* ctx, int64_t n, const int32_t* ou
                                    const double* val_host, int row_major, mispec_symshift** out);
 int mispec_symshift_destroy(mispec_symshift* S);
 int64_t mispec_symshift_rows(const mispec_symshift* S);
+/* The levels the banded path plans for an n x n matrix of this half-bandwidth (host arithmetic only): per level rows, half-bandwidth
+ * (2b - 1 of the level above), chunk length, chunk count; the last level (one chunk) is the dense one.  Returns the number of
+ * levels (arrays hold up to max_levels entries, may be NULL), 0 when the dense path is taken, MISPEC_EINVAL when unsupported. */
+int mispec_symshift_level_plan(int64_t n, int64_t half_bandwidth, int max_levels, int64_t* rows, int64_t* bandwidth,
+                               int64_t* chunk_rows, int64_t* chunks);
 /* set_shift(sigma) (SparseSymShiftSolve.h:85-95): MISPEC_EINVAL "factorization failed with the given shift" on breakdown */
 int mispec_symshift_set_shift(mispec_symshift* S, double sigma);
 int mispec_symshift_solve(const mispec_symshift* S, const double* x_dev, double* y_dev);        /* device pointers */

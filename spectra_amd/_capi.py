@@ -93,6 +93,7 @@ SIGNATURES = {
     "mispec_spmv_host": (C.c_int, [_vp, _dp, _dp]),
     "mispec_spmm_host": (C.c_int, [_vp, _dp, C.c_int64, C.c_int, _dp, C.c_int64]),
     "mispec_spmv_time": (C.c_int, [_vp, _vp, _vp, C.c_int, C.POINTER(C.c_float)]),
+    "mispec_symshift_level_plan": (C.c_int, [C.c_int64, C.c_int64, C.c_int, _lp, _lp, _lp, _lp]),
     "mispec_symshift_create": (C.c_int, [_vp, C.c_int64, _ip, _ip, _dp, C.c_char, C.c_int, _vpp]),
     "mispec_symshift_destroy": (C.c_int, [_vp]),
     "mispec_symshift_rows": (C.c_int64, [_vp]),

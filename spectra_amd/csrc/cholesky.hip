@@ -48,7 +48,7 @@ extern "C" int mispec_cholesky_create(mispec_ctx* ctx, int64_t n, const int32_t*
                 throw Error(MISPEC_EINVAL, mispec_last_error());
             C->band = S;
             MISPEC_REQUIRE(S->half_bandwidth <= kMaxBandwidth,
-                           "SparseCholesky: for n > 4096 the matrix must be banded (half-bandwidth <= 8); use the regular-inverse mode "
+                           "SparseCholesky: for n > 4096 the matrix must be banded (half-bandwidth <= 64); use the regular-inverse mode "
                            "for other large B");
             S->want_cholesky = true;
             const int rc = mispec_symshift_set_shift(S, 0.0);

@@ -1008,11 +1008,34 @@ const ChunkPlan& chunk_plan()
     return plan;
 }
 
+// A top level wider than kNarrowBandwidth (round 4: half-bandwidths of up to 64 beyond the dense limit) plans longer chunks at
+// every level — 32 b rows instead of 128 — so that a level keeps 1/32 of its rows as separators whatever b is and the chain
+// n -> n/32 -> n/1024 ... reaches the dense last level before the band (2b - 1 per level) outgrows the chunk kernels.
+thread_local bool g_wide_top = false;
+
 void plan_level(int64_t N, int b, int64_t& L, int64_t& P)
 {
     const ChunkPlan& cp = chunk_plan();
     L = std::max<int64_t>((N > cp.n_switch ? cp.big : cp.small) + g_chunk_bias, 4 * int64_t(b));
-    P = (N <= std::max<int64_t>(cp.n_dense, 8 * int64_t(b)) || (g_single_chunk && N <= kPivotedLimit)) ? 1 : N / L;
+    const bool last = N <= std::max<int64_t>(cp.n_dense, 8 * int64_t(b)) || (g_single_chunk && N <= kPivotedLimit);
+    if (g_wide_top)
+    {
+        L = std::max<int64_t>(L, 32 * int64_t(b) + g_chunk_bias);
+        if (!last && N / L < 2)
+            L = N / 2;  // too large for the dense level, too small for two long chunks: two chunks of half the rows
+    }
+    P = last ? 1 : N / L;
+    // The Schur complement of a level of half-bandwidth b has half-bandwidth 2b - 1.  Where that is more than the chunk kernels
+    // take, the next level has to be the last (dense) one: at most n_dense separator rows, i.e. fewer and longer chunks.
+    if (P > 1 && 2 * int64_t(b) - 1 > kMaxBandwidth)
+    {
+        const int64_t pmax = cp.n_dense / std::max(b, 1) + 1;
+        if (P > pmax)
+        {
+            P = pmax;
+            L = (N + P - 1) / P;
+        }
+    }
     if (P < 2)
     {
         P = 1;
@@ -1092,11 +1115,12 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
 {
     const int64_t N = M.n;
     const int b = M.b;
-    MISPEC_REQUIRE(b <= 64, "internal: band wider than the chunk kernel supports");
     lev.N = N;
     lev.b = b;
     int64_t L, P;
     plan_level(N, b, L, P);
+    // the last level (P == 1) is a band LU with an explicit inverse: any width
+    MISPEC_REQUIRE(P == 1 || b <= kMaxBandwidth, "internal: band wider than the chunk kernel supports");
     lev.L = L;
     lev.P = P;
     const int64_t mmax = (P == 1) ? N : std::max<int64_t>(L - b, N - (P - 1) * L);  // longest interior
@@ -1863,7 +1887,7 @@ int symshift_create_impl(mispec_ctx* ctx, int64_t n, const TriangleInput& A, con
                 S->half_bandwidth = std::max<int64_t>(S->half_bandwidth, r - c);
                 countB++;
             });
-        if (S->half_bandwidth <= kMaxBandwidth)
+        if (band_path(n, S->half_bandwidth))
         {
             // ... then, for a band, the band itself (assembled once; every set_shift() starts from it)
             S->band_b = int(std::max<int64_t>(1, std::min<int64_t>(S->half_bandwidth, n - 1)));  // a diagonal matrix: width 1, zeros
@@ -1985,6 +2009,55 @@ extern "C" int mispec_symshift_destroy(mispec_symshift* S)
 
 extern "C" int64_t mispec_symshift_rows(const mispec_symshift* S) { return S ? S->n : 0; }
 
+// The levels the banded path plans for an n x n matrix of the given half-bandwidth (no device needed): rows, half-bandwidth,
+// chunk length and chunk count per level, the last level (one chunk) being the dense one.  Returns the number of levels, 0 when
+// the matrix takes the dense path instead (n <= 4096, band wider than 8), MISPEC_EINVAL when it is unsupported.
+extern "C" int mispec_symshift_level_plan(int64_t n, int64_t half_bandwidth, int max_levels, int64_t* rows, int64_t* bandwidth,
+                                          int64_t* chunk_rows, int64_t* chunks)
+{
+    int levels = 0;
+    const int rc = guarded([&] {
+        MISPEC_REQUIRE(n >= 1 && half_bandwidth >= 0 && max_levels >= 0, "mispec_symshift_level_plan: bad argument");
+        if (!band_path(n, half_bandwidth))
+        {
+            MISPEC_REQUIRE(n <= kMaxDense, "SparseSymShiftSolve: only banded matrices (half-bandwidth <= 64) or n <= 4096 are supported on the GPU");
+            return;
+        }
+        int64_t N = n;
+        int b = int(std::max<int64_t>(1, std::min<int64_t>(half_bandwidth, n - 1)));
+        struct WideTop
+        {
+            explicit WideTop(bool on) { g_wide_top = on; }
+            ~WideTop() { g_wide_top = false; }
+        } wide_top(b > kNarrowBandwidth);
+        for (;;)
+        {
+            int64_t L, P;
+            plan_level(N, b, L, P);
+            MISPEC_REQUIRE(P == 1 || b <= kMaxBandwidth, "internal: band wider than the chunk kernel supports");
+            if (levels < max_levels)
+            {
+                if (rows)
+                    rows[levels] = N;
+                if (bandwidth)
+                    bandwidth[levels] = b;
+                if (chunk_rows)
+                    chunk_rows[levels] = L;
+                if (chunks)
+                    chunks[levels] = P;
+            }
+            levels++;
+            if (P == 1)
+                break;
+            const int64_t nsep = (P - 1) * b;
+            b = int(std::min<int64_t>(2 * int64_t(b) - 1, std::max<int64_t>(nsep - 1, 0)));
+            N = nsep;
+            MISPEC_REQUIRE(levels < 64, "internal: the level chain does not terminate");
+        }
+    });
+    return rc == MISPEC_OK ? levels : rc;
+}
+
 extern "C" int mispec_symshift_set_shift(mispec_symshift* S, double sigma)
 {
     return guarded([&] {
@@ -1993,8 +2066,13 @@ extern "C" int mispec_symshift_set_shift(mispec_symshift* S, double sigma)
         S->factored = false;
         S->sigma = sigma;
         const int64_t n = S->n, b = S->half_bandwidth;
-        if (!S->general && b <= kMaxBandwidth)
+        if (!S->general && band_path(n, b))
         {
+            struct WideTop  // the planning mode of this factorisation, whichever way the scope is left
+            {
+                explicit WideTop(bool on) { g_wide_top = on; }
+                ~WideTop() { g_wide_top = false; }
+            } wide_top(S->band_b > kNarrowBandwidth);
             HostBand M;
             M.n = n;
             M.b = S->band_b;
@@ -2056,7 +2134,9 @@ extern "C" int mispec_symshift_set_shift(mispec_symshift* S, double sigma)
                     g_chunk_bias = 0;
                     g_single_chunk = false;
                     if (attempt == 4 || (attempt == 3 && n > kPivotedLimit))
+                    {
                         throw Error(e.code, std::string(e.what()) + " [n = " + std::to_string(n) + ", " + std::to_string(attempt + 1) + " attempts]");
+                    }
                 }
             }
         }
@@ -2085,7 +2165,7 @@ extern "C" int mispec_symshift_set_shift(mispec_symshift* S, double sigma)
         }
         else
             throw Error(MISPEC_EINVAL,
-                        "SparseSymShiftSolve: only banded matrices (half-bandwidth <= 8) or n <= 4096 are supported on the GPU "
+                        "SparseSymShiftSolve: only banded matrices (half-bandwidth <= 64) or n <= 4096 are supported on the GPU "
                         "(the reference uses a general sparse LU)");
         S->factored = true;
     });

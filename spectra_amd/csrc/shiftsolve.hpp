@@ -6,8 +6,12 @@
 
 namespace mispec {
 struct BandLevel;
-constexpr int64_t kMaxBandwidth = 8;   // banded path: half-bandwidth of A - sigma I (the Schur levels widen it to 2b-1 each)
-constexpr int64_t kMaxDense = 4096;    // dense path: matrix dimension
+constexpr int64_t kNarrowBandwidth = 8;  // up to here the top level is factored on the device and runs the LDS-staged sweeps
+constexpr int64_t kMaxBandwidth = 64;    // banded path: half-bandwidth of A - sigma I the chunk kernels take at any level
+constexpr int64_t kMaxDense = 4096;      // dense path: matrix dimension
+// Which path a symmetric operator of dimension n and half-bandwidth b takes: the partitioned band factorisation for narrow bands
+// (any n) and for bands of up to 64 beyond the dense limit; the dense inverse otherwise (n <= kMaxDense), else unsupported.
+inline bool band_path(int64_t n, int64_t b) { return b <= kNarrowBandwidth || (b <= kMaxBandwidth && n > kMaxDense); }
 }  // namespace mispec
 
 struct mispec_symshift

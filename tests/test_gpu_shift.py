@@ -33,7 +33,10 @@ def banded_spd(n, b, seed=0):
     return A
 
 
-@pytest.mark.parametrize("n,b", [(50, 1), (1000, 3), (5000, 2), (100_000, 3), (300_001, 5), (200_000, 8), (3000, 16)])
+# half-bandwidths above 8 take the banded path beyond the dense limit (n > 4096) since the end of round 4: longer chunks (32 b rows),
+# every level factored on the host, the general sweep kernels (csrc/shiftsolve.hip plan_level; tests/test_host_shift_plan.py)
+@pytest.mark.parametrize("n,b", [(50, 1), (1000, 3), (5000, 2), (100_000, 3), (300_001, 5), (200_000, 8), (3000, 16),
+                                 (6000, 16), (150_000, 16), (8000, 32), (100_000, 32), (40_000, 40), (5000, 64), (70_000, 64)])
 def test_banded_solve_matches_sparse_lu(ctx, n, b):
     A = banded_spd(n, b, seed=n)
     op = sa.SparseSymShiftSolve(sp.tril(A).tocsc(), ctx=ctx)
@@ -45,6 +48,32 @@ def test_banded_solve_matches_sparse_lu(ctx, n, b):
         ref = lu.solve(x)
         assert np.abs(y - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
         assert np.linalg.norm((A - sigma * sp.identity(n)) @ y - x) <= 1e-12 * np.linalg.norm(x)   # SURVEY §8f bar
+
+
+def test_deep_level_chain_of_a_large_narrow_band(ctx):
+    # n = 1.5e6 with half-bandwidth 8: five levels, the fourth (band 57) ends the recursion with a capped chunk count because its
+    # Schur complement (band 113) is wider than the chunk kernels take — that level used to be rejected (round 4 fix)
+    n, b = 1_500_000, 8
+    A = banded_spd(n, b, seed=3)
+    op = sa.SparseSymShiftSolve(sp.tril(A).tocsc(), ctx=ctx)
+    op.set_shift(-0.5)
+    x = np.random.default_rng(2).uniform(-1, 1, n)
+    y = op.perform_op(x)
+    assert np.linalg.norm((A + 0.5 * sp.identity(n)) @ y - x) <= 1e-12 * np.linalg.norm(x)
+
+
+def test_wide_band_with_an_interior_shift(ctx):
+    # indefinite A - sigma I at half-bandwidth 16: pivot boosting + calibrated refinement on the host-factored levels
+    n, b, sigma = 30_000, 16, 0.3
+    A = banded_indefinite(n, b, seed=5)
+    op = sa.SparseSymShiftSolve(sp.tril(A).tocsc(), ctx=ctx)
+    op.set_shift(sigma)
+    M = (A - sigma * sp.identity(n)).tocsc()
+    x = np.random.default_rng(4).uniform(-1, 1, n)
+    y = op.perform_op(x)
+    assert np.linalg.norm(M @ y - x) <= 1e-10 * np.linalg.norm(x)
+    ref = spla.splu(M).solve(x)
+    assert np.abs(y - ref).max() <= 1e-8 * max(1.0, np.abs(ref).max())
 
 
 def test_dense_path_and_failures(ctx):
