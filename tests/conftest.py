@@ -20,6 +20,8 @@ def pytest_sessionstart(session):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "operator_only: a GPU test of an operator without a solver (modules that run every test in both "
+                            "orthogonalisation modes run these once)")
 
 
 @pytest.fixture(scope="session")

@@ -19,6 +19,8 @@ def orth_env(request, monkeypatch):
     params = getattr(getattr(request.node, "callspec", None), "params", {})
     if "orth" in params and request.param == "reference":
         pytest.skip("this test selects its modes itself")
+    if request.node.get_closest_marker("operator_only") and request.param == "reference":
+        pytest.skip("the operator alone, no solver: one run")
     monkeypatch.setenv("MISPEC_ORTH", request.param)
     return request.param
 
@@ -37,6 +39,7 @@ def banded_spd(n, b, seed=0):
 # every level factored on the host, the general sweep kernels (csrc/shiftsolve.hip plan_level; tests/test_host_shift_plan.py)
 @pytest.mark.parametrize("n,b", [(50, 1), (1000, 3), (5000, 2), (100_000, 3), (300_001, 5), (200_000, 8), (3000, 16),
                                  (6000, 16), (150_000, 16), (8000, 32), (100_000, 32), (40_000, 40), (5000, 64), (70_000, 64)])
+@pytest.mark.operator_only
 def test_banded_solve_matches_sparse_lu(ctx, n, b):
     A = banded_spd(n, b, seed=n)
     op = sa.SparseSymShiftSolve(sp.tril(A).tocsc(), ctx=ctx)
@@ -50,6 +53,7 @@ def test_banded_solve_matches_sparse_lu(ctx, n, b):
         assert np.linalg.norm((A - sigma * sp.identity(n)) @ y - x) <= 1e-12 * np.linalg.norm(x)   # SURVEY §8f bar
 
 
+@pytest.mark.operator_only
 def test_deep_level_chain_of_a_large_narrow_band(ctx):
     # n = 1.5e6 with half-bandwidth 8: five levels, the fourth (band 57) ends the recursion with a capped chunk count because its
     # Schur complement (band 113) is wider than the chunk kernels take — that level used to be rejected (round 4 fix)
@@ -62,6 +66,7 @@ def test_deep_level_chain_of_a_large_narrow_band(ctx):
     assert np.linalg.norm((A + 0.5 * sp.identity(n)) @ y - x) <= 1e-12 * np.linalg.norm(x)
 
 
+@pytest.mark.operator_only
 def test_wide_band_with_an_interior_shift(ctx):
     # indefinite A - sigma I at half-bandwidth 16: pivot boosting + calibrated refinement on the host-factored levels
     n, b, sigma = 30_000, 16, 0.3
@@ -196,6 +201,7 @@ def banded_indefinite(n, b, seed=0):
 
 @pytest.mark.parametrize("n,b,sigma", [(3000, 2, 0.3), (5000, 3, 1.0), (100_000, 3, 0.1234), (300_000, 5, -0.5), (1_000_000, 3, 1.0),
                                        (2_000_000, 3, 0.25)])
+@pytest.mark.operator_only
 def test_banded_solve_with_interior_shift_matches_sparse_lu(ctx, n, b, sigma):
     A = banded_indefinite(n, b, seed=n + b)
     M = (A - sigma * sp.identity(n)).tocsc()
