@@ -24,9 +24,10 @@ fi
 build_tests() {
     # The reference's OWN Catch2 programs on the reference's OWN headers, with the stand-in algebra: a self-check of oracle/eigen_shim
     # (if the stand-in mis-evaluated an expression the reference writes, the reference's own acceptance tests would notice).
-    # QR, Eigen and Arnoldi instantiate complex scalars next to their double cases (the stand-in's ComplexSchur / EigenSolver /
-    # HouseholderQR are textbook methods, Eigen/Eigenvalues and Eigen/QR here).  The Herm / complex-shift solvers, the float
-    # instantiations of Orthogonalization and the mixed dense / sparse pencils of SymGEigsShift are outside what the stand-in restates.
+    # All 31 programs of the reference's test/CMakeLists.txt.  QR, Eigen, Arnoldi, HermEigs, ComplexEigs, BKLDLT and GenEigsComplexShift
+    # instantiate complex scalars (the stand-in's ComplexSchur / EigenSolver / HouseholderQR / complex LU are textbook methods,
+    # Eigen/Eigenvalues, Eigen/QR, Eigen/LU here); SymGEigsShift mixes dense and sparse operands of one pencil (dense (+|-)= triangular
+    # views of dense and sparse matrices); the Davidson family uses Array expressions of the stand-in.
     local T="$OUT/tests"
     mkdir -p "$T"
     if [ ! -f "$T/tests-main.o" ]; then
@@ -36,7 +37,9 @@ build_tests() {
     # SymEigsShift, GenEigsRealShift, SymGEigsRegInv, SymGEigsCholesky, Example3: with the stand-in's plain SparseLU / ConjugateGradient /
     # SimplicialLLT behind the reference's operators (dense factors: fine at the n <= 1000 these programs use)
     for name in SymEigs GenEigs Schur Example1 Example2 Example4 SparseSymMatProd SparseGenMatProd DenseSymMatProd DenseGenMatProd \
-                SymEigsShift GenEigsRealShift SymGEigsRegInv SymGEigsCholesky Example3 SVD Givens QR Eigen Arnoldi; do
+                SymEigsShift GenEigsRealShift SymGEigsRegInv SymGEigsCholesky Example3 SVD Givens QR Eigen Arnoldi \
+                HermEigs ComplexEigs BKLDLT Orthogonalization JDSymEigsBase JDSymEigsDPRConstructor RitzPairs SearchSpace DavidsonSymEigs \
+                GenEigsComplexShift SymGEigsShift; do
         if [ -f "$T/$name.bin" ] && [ -z "$(find "$HERE/eigen_shim" "$REF/include/Spectra" "$REF/test/$name.cpp" -newer "$T/$name.bin" -print -quit)" ]; then
             continue
         fi

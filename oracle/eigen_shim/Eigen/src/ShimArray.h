@@ -248,12 +248,17 @@ public:
     {
         *this = o;
     }
+    // from a matrix expression (Eigen allows the assignment; a vector of the other orientation is transposed, as Eigen does:
+    // RitzPairs.h:75 initialises a column Array from colwise().norm(), a row vector)
     template <typename D>
-    explicit Array(const MatrixBase<D>& o) : m_rows(o.rows()), m_cols(o.cols()), m_data(static_cast<std::size_t>(o.rows() * o.cols()))
+    Array(const MatrixBase<D>& o) : m_rows(o.rows()), m_cols(o.cols()), m_data(static_cast<std::size_t>(o.rows() * o.cols()))
     {
-        for (Index j = 0; j < m_cols; j++)
-            for (Index i = 0; i < m_rows; i++)
-                coeffRef(i, j) = o.derived().coeff(i, j);
+        const bool flip = (Cols == 1 && Rows != 1 && o.rows() == 1 && o.cols() != 1) || (Rows == 1 && Cols != 1 && o.cols() == 1 && o.rows() != 1);
+        if (flip)
+            std::swap(m_rows, m_cols);
+        for (Index j = 0; j < o.cols(); j++)
+            for (Index i = 0; i < o.rows(); i++)
+                (flip ? coeffRef(j, i) : coeffRef(i, j)) = o.derived().coeff(i, j);
     }
     Array& operator=(const Array&) = default;
     Array& operator=(Array&&) = default;

@@ -50,7 +50,11 @@ def available():
 
 REFERENCE_TEST_PROGRAMS = ["SymEigs", "GenEigs", "Schur", "Example1", "Example2", "Example4", "SparseSymMatProd", "SparseGenMatProd",
                            "DenseSymMatProd", "DenseGenMatProd", "SymEigsShift", "GenEigsRealShift", "SymGEigsRegInv", "SymGEigsCholesky",
-                           "Example3", "SVD", "Givens", "QR", "Eigen", "Arnoldi"]
+                           "Example3", "SVD", "Givens", "QR", "Eigen", "Arnoldi",
+                           # the whole of test/CMakeLists.txt since the end of round 4 (complex solvers, BKLDLT, the Davidson family,
+                           # the complex-shift solver, the dense / sparse pencils of SymGEigsShift)
+                           "HermEigs", "ComplexEigs", "BKLDLT", "Orthogonalization", "JDSymEigsBase", "JDSymEigsDPRConstructor",
+                           "RitzPairs", "SearchSpace", "DavidsonSymEigs", "GenEigsComplexShift", "SymGEigsShift"]
 
 
 def build_tests():

@@ -259,8 +259,9 @@ def test_reference_s_own_test_programs_pass_on_the_stand_in_algebra(name):
     exe = os.path.join(d or "", name + ".bin")
     if not d or not os.path.exists(exe):
         pytest.skip("oracle/_ref/tests not built")
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "All tests passed" in out.stdout, out.stdout[-2000:]
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=1200)
+    # (test/RitzPairs.cpp has two test cases without assertions: Catch2 then reports "test cases: 2 | 2 passed")
+    assert out.returncode == 0 and ("All tests passed" in out.stdout or " passed" in out.stdout) and "failed" not in out.stdout, out.stdout[-2000:]
 
 
 def test_stand_in_decompositions_self_check(tmp_path):
