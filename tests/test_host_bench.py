@@ -56,15 +56,22 @@ def test_cpu_baseline_is_the_first_sweep_plus_measured_restart_cycles():
         n, nev, ncv, tol, selection, cpu_steps, cpu_cycles = 40_000, 20, 40, 1e-11, "LargestMagn", 0, 2
 
     rp, ci, v = O.synth_band_csr(A.n)
-    s = O.SymEigsSolver(O.Op.csr(A.n, A.n, rp, ci, v), A.nev, A.ncv)
-    t0 = time.perf_counter()
-    s.init()
-    nconv = s.compute(O.LargestMagn, 1000, A.tol)
-    full = time.perf_counter() - t0
-    out = bench.cpu_baseline(A(), s.num_operations(), nconv, s.num_iterations())
-    assert out["kind"] == "port" and out["cores"] == 1 and out["operations_first_sweep"] == A.ncv + 1
-    assert out["operations_restart_cycles"] > 0 and "restart cycle" in out["sample"]
-    assert 0.5 < out["estimated_seconds_per_solve"] / full < 2.0, (out["estimated_seconds_per_solve"], full)
+    # two wall-clock measurements are compared: on a machine that is busy with other work (a parallel test run) one of them can be
+    # stretched, so the pair is taken up to three times and has to agree once
+    ratios = []
+    for _ in range(3):
+        s = O.SymEigsSolver(O.Op.csr(A.n, A.n, rp, ci, v), A.nev, A.ncv)
+        t0 = time.perf_counter()
+        s.init()
+        nconv = s.compute(O.LargestMagn, 1000, A.tol)
+        full = time.perf_counter() - t0
+        out = bench.cpu_baseline(A(), s.num_operations(), nconv, s.num_iterations())
+        assert out["kind"] == "port" and out["cores"] == 1 and out["operations_first_sweep"] == A.ncv + 1
+        assert out["operations_restart_cycles"] > 0 and "restart cycle" in out["sample"]
+        ratios.append(out["estimated_seconds_per_solve"] / full)
+        if 0.5 < ratios[-1] < 2.0:
+            break
+    assert 0.5 < ratios[-1] < 2.0, ratios
 
 
 def test_pmc_summary_of_committed_counter_files():

@@ -76,9 +76,11 @@ def test_expander_is_recognised_by_the_threaded_pre_check_and_a_large_stencil_is
     c = rng.integers(0, n, r.size)
     U = sp.coo_matrix((np.ones(r.size), (r, c)), shape=(n, n)).tocsr()
     S = (U + U.T).tocsr()
-    t0 = time.perf_counter()
-    perm, gave_up, widest = sa.rcm_order(S.indptr, S.indices, True)
-    t_expander = time.perf_counter() - t0
+    t_expander = float("inf")  # best of three: a busy machine can stretch a 20 ms measurement
+    for _ in range(3):
+        t0 = time.perf_counter()
+        perm, gave_up, widest = sa.rcm_order(S.indptr, S.indices, True)
+        t_expander = min(t_expander, time.perf_counter() - t0)
     assert gave_up and np.array_equal(perm, np.arange(n)) and widest > n // 8
     A = stencil7(67)                                   # 300 763 rows
     m = A.shape[0]
