@@ -403,18 +403,19 @@ class SymEigsSolver:
         if sigma is not None:  # SymEigsShiftSolver.h:190-195 (the op must already be shift-inverted)
             lib().oracle_symeigs_set_shift_invert(self.h, sigma)
 
-    def set_onesweep(self, on=True, fused=False, recorrect=False):
+    def set_onesweep(self, on=True, fused=False, recorrect=False, one_reduction=False):
         """NOT the reference: switch the factorisation to the CPU restatement of this repository's opt-in one-sweep
         variant (oracle/onesweep_variant.hpp), for variant-vs-reference comparisons under the same driver.  fused: the last
         correction of every sweep rides on the restart (the device's default in that mode); recorrect: test hook, one more
-        correction after every such restart."""
-        lib().oracle_symeigs_set_onesweep(self.h, int(bool(on)) | (2 if fused else 0) | (4 if recorrect else 0))
+        correction after every such restart; one_reduction: the product is applied to the un-normalised residual so that a step needs
+        ONE reduction (its <f, Af> joins the previous pass's record; DESIGN.md 8 — CPU restatement only so far)."""
+        lib().oracle_symeigs_set_onesweep(self.h, int(bool(on)) | (2 if fused else 0) | (4 if recorrect else 0) | (8 if one_reduction else 0))
 
     def onesweep_stats(self):
-        out = np.zeros(9)
+        out = np.zeros(10)
         lib().oracle_symeigs_onesweep_stats(self.h, _dp(out))
         keys = ("lagged_steps", "faithful_steps", "fallbacks_check", "fallbacks_state", "final_passes", "max_rel_c", "max_chk",
-                "fused_restarts", "fused_recorrected")
+                "fused_restarts", "fused_recorrected", "one_reduction_steps")
         return dict(zip(keys, out.tolist()))
 
     def init(self, v0=None):

@@ -40,6 +40,13 @@ struct OneSweepStats
     // together with the reference's test of the corrected residual; a failed test lets the reference's loop continue on the
     // compressed factorisation.  force_recorrect: test hook, one such correction after every fused restart.
     bool defer_last = false, force_recorrect = false;
+    // ONE reduction per step (the form VERDICT r03 item 6 asks about; CPU restatement only so far): the operator is
+    // applied to the UN-normalised residual, u = A f~, and its epilogue sum <f~, u> travels with the record of the previous pass
+    // ([V, v_{i-1}]' f~, |f~|^2) in one reduction; beta, alpha~ = <f~, u> / beta^2 - <f~, v_{i-1}> and w = u / beta - beta v_{i-1}
+    // are formed from it afterwards.  A step whose predecessor did not leave that record (the first step of a sweep, a step
+    // after the reference's own loop) runs the two-reduction form.
+    bool one_reduction = false;
+    long one_reduction_steps = 0;
     bool end_pending = false;
     std::vector<double> end_c;
     long fused_restarts = 0, fused_recorrected = 0;
@@ -180,6 +187,10 @@ inline void factorize_from_lanczos_onesweep(Factorization& F, Index from_k, Inde
     // pending == true: F.f is the UNCORRECTED residual f~ of step i-1, c = V[:, :i]' f~ (accepted), F.beta the norm the
     // corrected residual will have; pending == false: F.f / F.beta are final (the reference's state between steps)
     bool pending = false;
+    // one_reduction: whether the previous pass left its record ([V, v_{i-1}]' f~ measured, f~ = F.f untouched since), and its
+    // last entry <f~, v_{i-1}>
+    bool have_prev = false;
+    double prev_last = 0.0;
     Index i = from_k;
     while (i <= to_m - 1)
     {
@@ -190,21 +201,40 @@ inline void factorize_from_lanczos_onesweep(Factorization& F, Index from_k, Inde
             faithful_step(F, i, op_counter, w, Vf);
             S.faithful_steps++;
             // the reference's step leaves a finished f: pending stays false
+            have_prev = false;
             i++;
             continue;
         }
         // ---- lagged step i ---------------------------------------------------------------------------------------
         const double beta = F.beta;
         double* v = F.V.col(i);
-        for (Index r = 0; r < n; r++)
-            v[r] = F.f[r] / beta;  // what the operator is applied to
-        F.op.perform_op(v, w.data());
+        double alpha_t;
+        if (S.one_reduction && have_prev)
         {
+            // the product does not wait for beta: u = A f~ and <f~, u> (the record of the previous pass is reduced with it)
+            F.op.perform_op(F.f.data(), w.data());
+            const double s1 = dot_tree(F.f.data(), w.data(), n);
             const double* vp = F.V.col(i - 1);
             for (Index r = 0; r < n; r++)
-                w[r] -= beta * vp[r];
+            {
+                v[r] = F.f[r] / beta;
+                w[r] = w[r] / beta - beta * vp[r];
+            }
+            alpha_t = s1 / (beta * beta) - prev_last;  // <v, w> = <f~, A f~> / beta^2 - <f~, v_{i-1}>
+            S.one_reduction_steps++;
         }
-        const double alpha_t = dot_tree(v, w.data(), n);
+        else
+        {
+            for (Index r = 0; r < n; r++)
+                v[r] = F.f[r] / beta;  // what the operator is applied to
+            F.op.perform_op(v, w.data());
+            {
+                const double* vp = F.V.col(i - 1);
+                for (Index r = 0; r < n; r++)
+                    w[r] -= beta * vp[r];
+            }
+            alpha_t = dot_tree(v, w.data(), n);
+        }
         // the sweep: finish column i, check it, form the next uncorrected residual and measure it
         if (pending)
         {
@@ -232,6 +262,7 @@ inline void factorize_from_lanczos_onesweep(Factorization& F, Index from_k, Inde
                     Vf[j] = chk[j] * beta;
                 corrections(F, i - 1, 1, Vf);
                 pending = false;
+                have_prev = false;
                 continue;  // step i again from the finished state (the speculative product is not counted)
             }
         }
@@ -255,6 +286,8 @@ inline void factorize_from_lanczos_onesweep(Factorization& F, Index from_k, Inde
         const double err = max_abs(Vf.data(), i1);
         F.beta = gamma;
         pending = false;
+        have_prev = true;       // this pass measured [V, v_i]' f~' on the residual it leaves in F.f
+        prev_last = Vf[i];
         if (err > kEps * gamma)  // Lanczos.h:156: a correction is needed
         {
             double c2 = 0.0;
@@ -282,6 +315,7 @@ inline void factorize_from_lanczos_onesweep(Factorization& F, Index from_k, Inde
                 else
                     S.fallbacks_state++;
                 corrections(F, i, 0, Vf);
+                have_prev = false;  // f was rewritten by the reference's loop
             }
         }
         i++;

@@ -397,7 +397,7 @@ void oracle_geigs_bprod(void* h, const double* x, double* y) { static_cast<GEigs
 // NON-reference variant (oracle/onesweep_variant.hpp): the repository's opt-in one-sweep Lanczos factorisation under the
 // reference's driver.  on == 0 restores the reference's algorithm.
 // on: bit 0 the variant, bit 1 the last correction of a sweep rides on the restart (fused restart), bit 2 test hook: one more
-// correction after every fused restart
+// correction after every fused restart, bit 3 one reduction per step (product on the un-normalised residual)
 void oracle_symeigs_set_onesweep(void* s, int on)
 {
     auto* S = static_cast<SymEigs*>(s);
@@ -411,19 +411,20 @@ void oracle_symeigs_set_onesweep(void* s, int on)
     auto st = std::make_shared<OneSweepStats>();
     st->defer_last = (on & 2) != 0;
     st->force_recorrect = (on & 4) != 0;
+    st->one_reduction = (on & 8) != 0;
     S->fac.variant_user = st;
     S->fac.lanczos_variant = [](Factorization& F, Index from_k, Index to_m, Index& ops, void* user) {
         factorize_from_lanczos_onesweep(F, from_k, to_m, ops, static_cast<OneSweepStats*>(user));
     };
     S->fac.compress_variant = [](Factorization& F, const Mat& Q, void* user) { compress_onesweep(F, Q, static_cast<OneSweepStats*>(user)); };
 }
-// out[0..9): lagged steps, faithful steps, check fallbacks, state fallbacks, final passes, max |c|/|f~|, max |V'v| after a lagged
-// correction, fused restarts, fused restarts followed by further corrections
+// out[0..10): lagged steps, faithful steps, check fallbacks, state fallbacks, final passes, max |c|/|f~|, max |V'v| after a lagged
+// correction, fused restarts, fused restarts followed by further corrections, steps taken with one reduction
 void oracle_symeigs_onesweep_stats(void* s, double* out)
 {
     auto* S = static_cast<SymEigs*>(s);
     const auto* st = static_cast<const OneSweepStats*>(S->fac.variant_user.get());
-    for (int i = 0; i < 9; i++)
+    for (int i = 0; i < 10; i++)
         out[i] = 0.0;
     if (!st)
         return;
@@ -436,6 +437,7 @@ void oracle_symeigs_onesweep_stats(void* s, double* out)
     out[6] = st->max_chk;
     out[7] = double(st->fused_restarts);
     out[8] = double(st->fused_recorrected);
+    out[9] = double(st->one_reduction_steps);
 }
 void oracle_symeigs_set_shift_invert(void* s, double sigma)
 {

@@ -17,7 +17,10 @@ RULE = {"LargestMagn": O.LargestMagn, "LargestAlge": O.LargestAlge, "SmallestMag
 
 # flavours of the variant: "eager" applies the last correction of a sweep at once; "fused" lets it ride on the restart (what the
 # device does by default in one-sweep mode: k_vq_fused); "recorrect" additionally forces the loop that follows a failed test
-FLAVOURS = {"eager": {}, "fused": {"fused": True}, "recorrect": {"fused": True, "recorrect": True}}
+# "one-reduction": the form DESIGN.md 8 proposes for sharded runs — the product on the un-normalised residual, its <f, Af> reduced
+# together with the previous pass's record (one all-reduce per step instead of two); restated on the CPU only so far
+FLAVOURS = {"eager": {}, "fused": {"fused": True}, "recorrect": {"fused": True, "recorrect": True},
+            "one-reduction": {"fused": True, "one_reduction": True}}
 
 
 def solve(op, k, m, rule, onesweep, tol=1e-10, maxit=1000, sorting=O.LargestAlge, v0=None):
@@ -50,6 +53,8 @@ def test_variant_equals_reference_on_the_reference_fixtures(n, prob, k, m, rule,
     assert np.abs(U.T @ U - np.eye(k)).max() <= 1e-10
     st = one["stats"]
     assert st["lagged_steps"] > 0 and st["max_chk"] <= 4 * np.finfo(float).eps
+    # every lagged step but the first of a sweep (and those after the reference's own loop) needs ONE reduction in that flavour
+    assert (st["one_reduction_steps"] >= st["lagged_steps"] - 2 * one["niter"] - 4) if flavour == "one-reduction" else st["one_reduction_steps"] == 0
     if flavour == "eager":
         assert st["fused_restarts"] == 0
     else:   # most sweeps end with a correction that can wait for the restart; the forced loop runs after each of them
