@@ -248,20 +248,47 @@ def test_constructor_errors_are_the_reference_s():
             O.SymEigsSolver(O.Op.diag(np.arange(1.0, 11.0)), nev, ncv)
 
 
+_PROGRAM_RUNS = {}  # name -> future of (returncode, stdout): see _program_result
+
+
+def _run_program(exe):
+    import subprocess
+
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=1800)
+    return out.returncode, out.stdout
+
+
+def _program_result(name, directory):
+    """Returncode and output of oracle/_ref/tests/<name>.bin.  In a serial pytest run the first call starts ALL the programs, one
+    per core, and every test then collects its own — the eight slow ones (dense stand-in LU / complex algebra at n = 1000: 25-75 s
+    each) would otherwise add seven minutes to the suite; under pytest-xdist every worker runs just the program it was asked for."""
+    import concurrent.futures
+
+    exe = os.path.join(directory, name + ".bin")
+    if os.environ.get("PYTEST_XDIST_WORKER"):
+        return _run_program(exe)
+    if not _PROGRAM_RUNS:
+        pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, os.cpu_count() or 1))
+        for nm in R.REFERENCE_TEST_PROGRAMS:
+            e = os.path.join(directory, nm + ".bin")
+            if os.path.exists(e):
+                _PROGRAM_RUNS[nm] = pool.submit(_run_program, e)
+        pool.shutdown(wait=False)
+    return _PROGRAM_RUNS[name].result()
+
+
 @needs_ref
 @pytest.mark.parametrize("name", R.REFERENCE_TEST_PROGRAMS)
 def test_reference_s_own_test_programs_pass_on_the_stand_in_algebra(name):
     # /root/reference/test/<name>.cpp, unmodified, against /root/reference/include + oracle/eigen_shim: the reference's own acceptance
     # tests of its own code.  What this checks is the stand-in (an expression it mis-evaluated would fail the reference's bars).
-    import subprocess
-
     d = R.build_tests()
     exe = os.path.join(d or "", name + ".bin")
     if not d or not os.path.exists(exe):
         pytest.skip("oracle/_ref/tests not built")
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=1200)
+    returncode, stdout = _program_result(name, d)
     # (test/RitzPairs.cpp has two test cases without assertions: Catch2 then reports "test cases: 2 | 2 passed")
-    assert out.returncode == 0 and ("All tests passed" in out.stdout or " passed" in out.stdout) and "failed" not in out.stdout, out.stdout[-2000:]
+    assert returncode == 0 and ("All tests passed" in stdout or " passed" in stdout) and "failed" not in stdout, stdout[-2000:]
 
 
 def test_stand_in_decompositions_self_check(tmp_path):
