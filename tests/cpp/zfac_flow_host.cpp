@@ -2,78 +2,11 @@
 // infrastructure: the library instantiates the same template with the HIP backend of zfac.hip, this program checks the flow where
 // there is no GPU.  Checks of the reference's test/Arnoldi.cpp:20-85 (A V - V H = f e', V^H V = I to 1e-12) for general and
 // Hermitian complex matrices, plus the breakdown paths (invariant subspace -> expand_basis, Arnoldi.h:66-115).
-//   g++ -std=c++17 -O2 -I spectra_amd/csrc tests/cpp/zfac_flow_host.cpp
-#include <zfac_flow.hpp>
+//   g++ -std=c++17 -O2 -I spectra_amd/csrc tests/cpp/zfac_flow_host.cpp   (shares tests/cpp/zfac_host_backend.hpp with zfac_host_capi.cpp)
+#include "zfac_host_backend.hpp"
 
 #include <cstdio>
 #include <random>
-
-using cd = std::complex<double>;
-
-struct HostBackend
-{
-    int64_t n = 0;
-    std::vector<cd> A;  // n x n column-major
-    cd* alloc(size_t count) { return new cd[count](); }
-    void release(cd* p) { delete[] p; }
-    void upload(cd* dev, const cd* host, int64_t count) { std::copy(host, host + count, dev); }
-    void download(cd* host, const cd* dev, int64_t count) { std::copy(dev, dev + count, host); }
-    void apply(const cd* x, cd* y)
-    {
-        for (int64_t i = 0; i < n; i++)
-        {
-            cd acc(0.0);
-            for (int64_t j = 0; j < n; j++)
-                acc += A[size_t(j * n + i)] * x[j];
-            y[i] = acc;
-        }
-    }
-    void dotc(const cd* X, int64_t ldx, int ncols, const cd* y, cd* out)
-    {
-        for (int j = 0; j < ncols; j++)
-        {
-            cd acc(0.0);
-            for (int64_t i = 0; i < n; i++)
-                acc += std::conj(X[j * ldx + i]) * y[i];
-            out[j] = acc;
-        }
-    }
-    void update(cd* f, const cd* w, const cd* V, int64_t ldv, int ncols, const cd* h)
-    {
-        for (int64_t i = 0; i < n; i++)
-        {
-            cd acc = w[i];
-            for (int j = 0; j < ncols; j++)
-                acc -= V[j * ldv + i] * h[j];
-            f[i] = acc;
-        }
-    }
-    void scale_copy(cd* dst, const cd* src, double alpha)
-    {
-        for (int64_t i = 0; i < n; i++)
-            dst[i] = alpha * src[i];
-    }
-    void axpy(cd* y, cd a, const cd* x)
-    {
-        for (int64_t i = 0; i < n; i++)
-            y[i] += a * x[i];
-    }
-    double norm(const cd* x)
-    {
-        double s = 0.0;
-        for (int64_t i = 0; i < n; i++)
-            s += std::norm(x[i]);
-        return std::sqrt(s);
-    }
-    double absmax(const cd* x)
-    {
-        double m = 0.0;
-        for (int64_t i = 0; i < n; i++)
-            m = std::max(m, std::abs(x[i]));
-        return m;
-    }
-    void zero(cd* x) { std::fill(x, x + n, cd(0.0)); }
-};
 
 static int failures = 0;
 #define REQUIRE(cond)                                                        \
@@ -131,28 +64,32 @@ static void check(HostBackend& be, mispec::ZFacFlow<HostBackend>& fac, int k, do
 
 static void run(int64_t n, int m, bool hermitian, int kind)
 {
+    zdense D;  // the operator: a dense column-major matrix
+    D.rows = D.cols = n;
+    std::vector<cd>& A = D.a;
     HostBackend be;
     be.n = n;
-    be.A.assign(size_t(n) * n, cd(0.0));
+    be.dense = &D;
+    A.assign(size_t(n) * n, cd(0.0));
     if (kind == 0)  // dense random
-        for (auto& a : be.A)
+        for (auto& a : A)
             a = cd(rnd(), rnd());
     else if (kind == 1)  // block diagonal: the start vector lives in a 3-dimensional invariant subspace -> breakdown at step 3
         for (int64_t j = 0; j < n; j++)
             for (int64_t i = 0; i < n; i++)
                 if ((i < 3) == (j < 3))
-                    be.A[size_t(j * n + i)] = cd(rnd(), rnd());
+                    A[size_t(j * n + i)] = cd(rnd(), rnd());
     // kind == 2: the zero matrix (every step restarts; test/Example4.cpp's situation)
     if (hermitian)
         for (int64_t j = 0; j < n; j++)
         {
             for (int64_t i = 0; i < j; i++)
             {
-                const cd s = be.A[size_t(j * n + i)] + std::conj(be.A[size_t(i * n + j)]);
-                be.A[size_t(j * n + i)] = s;
-                be.A[size_t(i * n + j)] = std::conj(s);
+                const cd s = A[size_t(j * n + i)] + std::conj(A[size_t(i * n + j)]);
+                A[size_t(j * n + i)] = s;
+                A[size_t(i * n + j)] = std::conj(s);
             }
-            be.A[size_t(j * n + j)] = cd(2.0 * be.A[size_t(j * n + j)].real(), 0.0);
+            A[size_t(j * n + j)] = cd(2.0 * A[size_t(j * n + j)].real(), 0.0);
         }
     std::vector<cd> v0(static_cast<size_t>(n), cd(0.0));
     for (int64_t i = 0; i < (kind == 1 ? 3 : n); i++)
@@ -207,9 +144,12 @@ int main()
         run(12, 6, herm != 0, 2);
     }
     {
+        zdense D;
+        D.rows = D.cols = 5;
+        D.a.assign(25, cd(1.0));
         HostBackend be;
         be.n = 5;
-        be.A.assign(25, cd(1.0));
+        be.dense = &D;
         mispec::ZFacFlow<HostBackend> fac(be, 5, 3, false);
         std::vector<cd> z(5, cd(0.0));
         int64_t ops = 0;
