@@ -140,7 +140,7 @@ def cpu_baseline(args, gpu_nops, gpu_nconv, gpu_niter):
     return out
 
 
-KERNEL_OF_FORMAT = {0: "k_spmv_csr_stream<EPI, NT, 256, CODES=false>", 1: "k_spmv_csr_stream<EPI, NT, 256, CODES=true>", 2: "k_spmv_dia_win / k_spmv_dia",
+KERNEL_OF_FORMAT = {0: "k_spmv_csr_win (int32 CSR, x windows in LDS) / k_spmv_csr_stream<EPI, NT, 256, CODES=false> (gathers)", 1: "k_spmv_csr_stream<EPI, NT, 256, CODES=true>", 2: "k_spmv_dia_win / k_spmv_dia",
                     3: "k_spmv_tiles (column-blocked tiles, segment sums in LDS)",
                     4: "k_staged_products + k_staged_rows (two streaming phases, x and y in LDS)"}
 
@@ -258,18 +258,37 @@ def standalone_ms(op, ncols, reps):
 
 def m_rand_host(n, seed=20240607):
     """M-rand of SURVEY.md 8d: every row has 7 partners at uniformly random columns, symmetrised (degrees vary around 15)."""
-    import numpy as np
-    import scipy.sparse as sp
+    from spectra_amd import workloads
 
-    rng = np.random.default_rng(seed)
-    rows = np.repeat(np.arange(n, dtype=np.int64), 7)
-    cols = rng.integers(0, n, size=rows.size, dtype=np.int64)
-    vals = rng.uniform(-0.5, 0.5, size=rows.size)
-    U = sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()
-    U.sum_duplicates()
-    A = (U + U.T + sp.diags(rng.uniform(-0.5, 0.5, n))).tocsr()
-    A.sort_indices()
-    return A
+    return workloads.m_rand(n, seed)
+
+
+def in_loop_block(sa, ctx, rop, nev, ncv, rule, tol, restarts=12):
+    """The SpMV of `rop` inside a solver loop (a bounded number of restarts: the in-loop time needs no convergence): figures on
+    SURVEY.md 8d's bytes (12 nnz + 4 (rows + 1) + 8 cols + 8 rows — `frac`) and with the fused epilogue's two vector reads."""
+    e = sa.SymEigsSolver(rop, nev, ncv)
+    e.profile(2)
+    e.init()
+    e.compute(rule, 2, tol)  # warm-up: buffers, code paths
+    p0 = e.get_profile()
+    ctx.sync()
+    t0 = time.perf_counter()
+    e.init()
+    nconv = e.compute(rule, restarts, tol)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    p1 = e.get_profile()
+    n_spmv = p1["n_spmv"] - p0["n_spmv"]
+    ms = (p1["ms_spmv"] - p0["ms_spmv"]) / max(n_spmv, 1)
+    alg = rop.algorithmic_bytes()
+    blk = {"kernel": KERNEL_OF_FORMAT[rop.spmv_format()], "spmv_format": rop.spmv_format(), "ms_per_launch": ms, "launches": int(n_spmv),
+           "bytes_per_launch": alg, "achieved": alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+           "bytes_note": "algorithmic: 12 nnz + 4 (rows + 1) + 8 cols + 8 rows (SURVEY.md 8d)",
+           "frac_with_epilogue_operands": (alg + 16.0 * rop.local_rows()) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if ms > 0 else 0.0,
+           "solve": {"seconds": dt, "restarts": restarts, "nconv": int(nconv), "num_operations": int(e.num_operations())}}
+    blk["frac"] = blk["achieved"] / HBM_PEAK_GBPS
+    del e
+    return blk
 
 
 def secondary_configs(args, ctx, op, sa):
@@ -306,6 +325,9 @@ def secondary_configs(args, ctx, op, sa):
             blk["traffic"], blk["traffic_source"] = pmc_traffic(args.n, fmt)
             blk.update({"nconv": int(nconv), "num_operations": int(e.num_operations()), "seconds": secs,
                         "eigenpairs_per_s": nconv / secs, "orth": args.orth})
+            blk["frac_8d"] = blk["csr_equivalent_gbps"] / HBM_PEAK_GBPS  # on SURVEY.md 8d's bytes (no epilogue operands)
+            if fmt == 0:
+                blk["windows"] = op.windows_info()
             csr[name] = blk
             del e
     finally:
@@ -381,6 +403,40 @@ def secondary_configs(args, ctx, op, sa):
                      "solve_12_restarts": {"seconds": dt, "nconv": int(nconv), "num_operations": int(e.num_operations())},
                      "host_generation_seconds": t_gen}
     del e, rop, A
+
+    # (2b) irregular-but-local patterns at the headline size: neither M-band's fixed diagonals nor M-rand's far
+    # gathers.  jitter band: M-band's off-diagonals moved by a per-entry jitter of <= 64 columns (variable row lengths, ~1800
+    # distinct diagonals: no offset codes, no diagonal storage — int32 CSR is the automatic choice); 7-point stencil on a 215^3 grid
+    # handed over in random order and reordered at ingest (reverse Cuthill-McKee).  Both run the int32 CSR kernel with x windows.
+    from spectra_amd import workloads
+    for key, make in (("jitter_band", lambda: workloads.jitter_band(args.n)), ("stencil_rcm", None)):
+        try:
+            t0 = time.perf_counter()
+            if make is not None:
+                A = make()
+            else:
+                B = workloads.stencil7(max(8, int(round(args.n ** (1.0 / 3.0)))))
+                perm = np.random.default_rng(1).permutation(B.shape[0])
+                A = B[perm][:, perm].tocsr()
+                A.sort_indices()
+                del B, perm
+            t_gen = time.perf_counter() - t0
+            tri = sp.tril(A).tocsc()
+            nloc = A.shape[0]
+            del A
+            t0 = time.perf_counter()
+            rop = sa.SparseSymMatProd(tri, ctx=ctx)
+            t_ingest = time.perf_counter() - t0
+            del tri
+            blk = in_loop_block(sa, ctx, rop, args.nev, args.ncv, rule, args.tol)
+            blk.update({"n": nloc, "nnz": rop.nnz(), "reordering": rop.reordering(), "windows": rop.windows_info(),
+                        "standalone_ms_per_launch": standalone_ms(rop, nloc, 20), "host_generation_seconds": t_gen, "ingest_seconds": t_ingest})
+            rop.use_windows(False)
+            blk["gather_kernel_in_loop_ms"] = in_loop_block(sa, ctx, rop, args.nev, args.ncv, rule, args.tol, 6)["ms_per_launch"]
+            out[key] = blk
+            del rop
+        except Exception as e:  # noqa: BLE001
+            out[key] = {"error": repr(e)}
 
     # (3) C4: GenEigsSolver on the 5M non-symmetric band matrix, k = 10, ncv = 30
     gop = sa.SparseGenMatProd.synth_band(5_000_000, ctx=ctx)
@@ -725,13 +781,36 @@ def main():
             # north_star names a CSR SpMV: the int32 CSR kernel's in-loop figure on the SAME matrix sits next to the headline
             # kernel's, so that a regression of either is visible in the top-level block
             c32 = out["secondary"].get("csr_kernels_same_matrix", {}).get("csr_int32") if isinstance(out["secondary"], dict) else None
+            sec = out["secondary"] if isinstance(out["secondary"], dict) else {}
+            flat = out["roofline"]
+            if c32:  # flat scalars: the driver's record keeps the scalars of this block
+                flat["csr_kernel_ms"] = c32.get("ms_per_launch")
+                flat["csr_kernel_frac"] = c32.get("frac_8d")  # 12 nnz + 20 n + 4 bytes (1.995 GB at C2) / time / 8 TB/s
+                flat["csr_kernel_frac_with_epilogue_operands"] = c32.get("frac")
+                flat["csr_kernel_eigenpairs_per_s"] = c32.get("eigenpairs_per_s")
+            for key in ("m_rand", "jitter_band", "stencil_rcm"):
+                blk = sec.get(key, {})
+                blk = blk.get("in_loop", blk) if isinstance(blk, dict) else {}
+                if isinstance(blk, dict) and "frac" in blk:
+                    flat[f"secondary_{key}_frac"] = blk["frac"]
+                    flat[f"secondary_{key}_ms"] = blk["ms_per_launch"]
+                    flat[f"secondary_{key}_format"] = sec[key].get("spmv_format")
+            if isinstance(sec.get("c4"), dict) and "seconds" in sec["c4"]:
+                flat["secondary_c4_seconds"] = sec["c4"]["seconds"]
+            if isinstance(sec.get("c5"), dict) and "seconds" in sec["c5"]:
+                flat["secondary_c5_seconds"] = sec["c5"]["seconds"]
+                flat["secondary_c5_solve_ms"] = sec["c5"].get("solve_ms")
+            if out.get("roofline_orth"):
+                flat["orth_frac"] = out["roofline_orth"].get("frac")
+            flat["host_syncs_per_solve"] = out["solve"]["host_syncs_per_solve"]
             if c32:
                 out["roofline"]["csr_kernel"] = {
                     "kernel": c32.get("kernel"), "ms_per_launch": c32.get("ms_per_launch"), "bytes_per_launch": c32.get("bytes_per_launch"),
                     "achieved": c32.get("achieved"), "frac": c32.get("frac"), "csr_equivalent_gbps": c32.get("csr_equivalent_gbps"),
                     "traffic": c32.get("traffic"), "eigenpairs_per_s": c32.get("eigenpairs_per_s"),
-                    "note": "k_spmv_csr_stream with int32 column indices forced on the headline matrix (mispec_csr_set_spmv_format 0), "
-                            "HIP events inside a complete solve; bytes = 12 nnz + 4 (rows+1) + 8 cols + 8 rows + 16 rows (fused epilogue)"}
+                    "note": "the int32 CSR kernel (x windows in LDS) forced on the headline matrix (mispec_csr_set_spmv_format 0), "
+                            "HIP events inside a complete solve; bytes = 12 nnz + 4 (rows+1) + 8 cols + 8 rows + 16 rows (fused epilogue); "
+                            "csr_kernel_frac above is on SURVEY.md 8d's bytes alone"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, int(eigs.num_operations()), int(total_pairs // args.steps), int(eigs.num_iterations()))
         print(json.dumps(out), flush=True)

@@ -127,6 +127,14 @@ int mispec_csr_offset_codes(const mispec_csr* A);
 /* Per-matrix switch between the two index formats (both give bit-identical products); no effect when the matrix
  * has no dictionary. */
 int mispec_csr_use_offset_codes(mispec_csr* A, int enable);
+/* x windows of the int32 CSR kernel (format 0): at ingest every 256-row block gets the (at most 8) contiguous ranges of x that
+ * hold its columns; when at least 75 % of the entries are covered the kernel stages those ranges through LDS with coalesced
+ * loads instead of gathering x entry by entry (entries outside the windows keep the gather).  The matrix arrays stay the plain
+ * int32 CSR; products and summation order are unchanged (bit-identical).  mispec_csr_use_windows switches the kernel per
+ * matrix; mispec_csr_windows_info reports blocks with windows, entries served from LDS and the LDS doubles reserved (0: not
+ * adopted).  Replaces the x access of MatOp/SparseSymMatProd.h:83-88 / SparseGenMatProd.h:72-77. */
+int mispec_csr_use_windows(mispec_csr* A, int enable);
+int mispec_csr_windows_info(const mispec_csr* A, int64_t* blocks, int64_t* covered_entries, int64_t* lds_doubles);
 /* Storage format the SpMV uses for this shard: 0 = CSR with int32 column indices, 1 = CSR with offset codes, 2 = diagonal
  * storage (values kept diagonal-major, no index and no gather; chosen when the dictionary has <= 32 diagonals that are
  * at least 3/4 full, rows sorted, no duplicate entries), 3 = column-blocked tiles (built at

@@ -280,6 +280,16 @@ class _DeviceMatrix:
     def use_offset_codes(self, enable=True):
         check(lib().mispec_csr_use_offset_codes(self.h, 1 if enable else 0))
 
+    def use_windows(self, enable=True):
+        """Per-matrix switch of the int32 CSR kernel: x staged through LDS windows (True) or gathered entry by entry (False)."""
+        check(lib().mispec_csr_use_windows(self.h, 1 if enable else 0))
+
+    def windows_info(self):
+        """{blocks, covered_entries, lds_doubles} of the x windows of the int32 CSR kernel (lds_doubles = 0: not adopted)."""
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(lib().mispec_csr_windows_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"blocks": a.value, "covered_entries": b.value, "lds_doubles": c.value}
+
     def spmv_format(self):
         """0: CSR with int32 column indices, 1: CSR with offset codes, 2: diagonal storage — what the SpMV uses."""
         return int(lib().mispec_csr_spmv_format(self.h))

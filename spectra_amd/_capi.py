@@ -84,6 +84,8 @@ SIGNATURES = {
     "mispec_csr_local_nnz": (C.c_int64, [_vp]),
     "mispec_csr_offset_codes": (C.c_int, [_vp]),
     "mispec_csr_use_offset_codes": (C.c_int, [_vp, C.c_int]),
+    "mispec_csr_use_windows": (C.c_int, [_vp, C.c_int]),
+    "mispec_csr_windows_info": (C.c_int, [_vp, _lp, _lp, _lp]),
     "mispec_csr_spmv_format": (C.c_int, [_vp]),
     "mispec_csr_set_spmv_format": (C.c_int, [_vp, C.c_int]),
     "mispec_csr_spmv_bytes": (C.c_double, [_vp, C.c_int]),

@@ -44,6 +44,14 @@ struct mispec_csr
     int64_t dia_ld = 0;
     int ndia = 0;
     mispec_dia_windows dia_win;
+    // x windows of the int32 CSR kernel (csr.hip k_spmv_csr_win): per 256-row block a 32-int record naming at most 8 contiguous
+    // ranges of x that hold the block's columns; built on the device at ingest, used by format 0 when most entries are covered.
+    mispec::DevBuf<int32_t> wtab;
+    int win_lds_doubles = 0;         // largest window total over the blocks (doubles of LDS the launch reserves)
+    int64_t win_covered = 0;         // entries whose x comes from a window
+    int64_t win_blocks = 0;          // blocks that have windows
+    bool use_windows = true;         // mispec_csr_use_windows: per-matrix switch (tests compare the two kernels)
+    bool windows_active() const { return use_windows && wtab.p != nullptr && win_lds_doubles > 0; }
     int forced_format = -1;          // mispec_csr_set_spmv_format: -1 automatic, 0 int32 indices, 1 offset codes, 2 diagonals, 3 tiles, 4 staged
     // Column-blocked tiles (fourth format, tiles.hip): built at ingest for matrices whose gathers are scattered over the
     // whole of x and that reordering does not localise; bit-identical products again.
