@@ -135,6 +135,10 @@ int mispec_csr_use_offset_codes(mispec_csr* A, int enable);
  * adopted).  Replaces the x access of MatOp/SparseSymMatProd.h:83-88 / SparseGenMatProd.h:72-77. */
 int mispec_csr_use_windows(mispec_csr* A, int enable);
 int mispec_csr_windows_info(const mispec_csr* A, int64_t* blocks, int64_t* covered_entries, int64_t* lds_doubles);
+/* The table itself, for tests: 32 ints per 256-row block of this shard — [0] windows | far flag << 8, [1] doubles of LDS, [2] entries
+ * served from LDS, [4..11] first column of each window (0x3fffffff: unused), [12..19] LDS position minus first column, [20..27] one
+ * past the last column. */
+int mispec_csr_windows_table(const mispec_csr* A, int32_t* records_out, int64_t capacity);
 /* Storage format the SpMV uses for this shard: 0 = CSR with int32 column indices, 1 = CSR with offset codes, 2 = diagonal
  * storage (values kept diagonal-major, no index and no gather; chosen when the dictionary has <= 32 diagonals that are
  * at least 3/4 full, rows sorted, no duplicate entries), 3 = column-blocked tiles (built at

@@ -290,6 +290,13 @@ class _DeviceMatrix:
         check(lib().mispec_csr_windows_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return {"blocks": a.value, "covered_entries": b.value, "lds_doubles": c.value}
 
+    def windows_table(self):
+        """The per-block window records (blocks x 32 int32; include/mispec.h mispec_csr_windows_table)."""
+        nb = (self.local_rows() + 255) // 256
+        out = np.empty((nb, 32), dtype=np.int32)
+        check(lib().mispec_csr_windows_table(self.h, _ip(out), out.size))
+        return out
+
     def spmv_format(self):
         """0: CSR with int32 column indices, 1: CSR with offset codes, 2: diagonal storage — what the SpMV uses."""
         return int(lib().mispec_csr_spmv_format(self.h))

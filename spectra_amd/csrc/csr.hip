@@ -290,7 +290,7 @@ constexpr int kWinPad = 0x3fffffff;   // start of an unused window (no column re
 constexpr int kWinCapMax = 6144;      // doubles of LDS a block's windows may take (48 KiB); the launch reserves the matrix's maximum
 constexpr int kWinLines = int((2 * kFarWindow + 512) / 16);  // 128-byte lines of x a block's bitmap covers (row0 - 131072 ... row0 + 256 + 131072)
 constexpr int kWinWords = (kWinLines + 31) / 32;
-constexpr int kWinRuns = 64;
+constexpr int kWinRuns = 256;          // raw runs of touched lines a block may have before neighbours further apart are joined
 
 __global__ __launch_bounds__(256) void k_build_windows(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind, int64_t nrows,
                                                        int64_t row_begin, int64_t n_cols, int cap_doubles, int32_t* __restrict__ wtab)
@@ -2330,6 +2330,16 @@ extern "C" int mispec_csr_windows_info(const mispec_csr* A, int64_t* blocks, int
             *covered_entries = A->wtab.p ? A->win_covered : 0;
         if (lds_doubles)
             *lds_doubles = A->wtab.p ? A->win_lds_doubles : 0;
+    });
+}
+extern "C" int mispec_csr_windows_table(const mispec_csr* A, int32_t* records_out, int64_t capacity)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(A && records_out, "mispec_csr_windows_table: NULL argument");
+        MISPEC_REQUIRE(A->wtab.p && int64_t(A->wtab.n) <= capacity, "mispec_csr_windows_table: no table, or capacity below 32 ints per 256-row block");
+        A->ctx->make_current();
+        MISPEC_HIP(hipStreamSynchronize(A->ctx->stream));
+        MISPEC_HIP(hipMemcpy(records_out, A->wtab.p, A->wtab.n * sizeof(int32_t), hipMemcpyDeviceToHost));
     });
 }
 extern "C" int mispec_csr_use_offset_codes(mispec_csr* A, int enable)

@@ -34,6 +34,8 @@ def device_product(op, x):
 def both_kernels(op, A, seeds=(0, 1), expect_windows=True):
     info = op.windows_info()
     assert (info["lds_doubles"] > 0) == expect_windows, info
+    if expect_windows and A.shape[0] <= 700000 and op.reordering() == "none":
+        check_table(op, A)
     op.set_spmv_format(0)
     try:
         for seed in seeds:
@@ -48,6 +50,32 @@ def both_kernels(op, A, seeds=(0, 1), expect_windows=True):
         op.use_windows(True)
         op.set_spmv_format(-1)
     return info
+
+
+def check_table(op, S):
+    """Invariants of the window records (include/mispec.h mispec_csr_windows_table) against the stored matrix S: windows sorted,
+    disjoint, 128-byte aligned, LDS positions consecutive; every entry of a block without the far flag inside a window; the
+    covered count exact."""
+    T = op.windows_table()
+    S = S.tocsr()
+    S.sort_indices()
+    n = S.shape[0]
+    covered = 0
+    for b in range(T.shape[0]):
+        rec = T[b]
+        nw, far, total = int(rec[0] & 255), int(rec[0] >> 8), int(rec[1])
+        st, ad, en = rec[4:12].astype(np.int64), rec[12:20].astype(np.int64), rec[20:28].astype(np.int64)
+        cols = S.indices[S.indptr[b * 256]: S.indptr[min(n, (b + 1) * 256)]].astype(np.int64)
+        inside = np.zeros(cols.size, bool)
+        base = 0
+        for w in range(nw):
+            assert st[w] % 16 == 0 and st[w] + ad[w] == base and en[w] > st[w] and (w == 0 or st[w] >= en[w - 1]), (b, rec)
+            base += en[w] - st[w]
+            inside |= (cols >= st[w]) & (cols < en[w])
+        assert base == total and total % 2 == 0 and np.all(st[nw:] == 0x3FFFFFFF), (b, rec)
+        assert int(inside.sum()) == rec[2] and (far or inside.all()), (b, rec)
+        covered += int(inside.sum())
+    assert covered == op.windows_info()["covered_entries"]
 
 
 def local_random(n, per_row, spread, seed, far=0):
@@ -180,7 +208,17 @@ def test_full_size_irregular_local_matrices_bit_exact(ctx, which):
     assert info["covered_entries"] >= 0.999 * op.nnz() and info["lds_doubles"] > 0  # (thin level sets at the ends of the RCM order are gathered)
     n = A.shape[0]
     x = O.simple_random(n, 0)
-    ref = oracle_product(A, x)
+    if which == "stencil_rcm":
+        # the stored matrix is P A P' with its rows sorted by the NEW column index: that is the summation order the library
+        # guarantees for a reordered matrix (tests/test_gpu_reorder.py), so the oracle runs on the stored matrix
+        p = op.permutation()
+        S = A[p][:, p].tocsr()
+        ref = np.empty(n)
+        ref[p] = oracle_product(S, x[p])
+        check_table(op, S)
+    else:
+        ref = oracle_product(A, x)
+        check_table(op, A)
     for windows in (True, False):
         op.use_windows(windows)
         assert np.array_equal(op.perform_op(x), ref), windows
