@@ -204,8 +204,10 @@ int mispec_mirror_triangle_host(int64_t n, const int32_t* outer, const int32_t* 
 int mispec_tiles_spmv_host(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* colind, const double* val,
                            const double* x, double* y, int* built, int64_t* stats);
 /* The same for the staged format (format 4): y = A x through its host image in the order of the two kernels; *built = 0 when the
- * format does not apply (unsorted rows, 2^32 stored entries or more).  stats (optional, 5 values): row bins, phase-1 slots,
- * batches, chunks, the largest number of rank rounds a batch needs. */
+ * format does not apply (unsorted rows, 2^32 stored entries or more, a (column block, row bin) table beyond 2^26 entries), 2 when
+ * the image is correct but heavy rows leave its batches nearly empty — the automatic format choice at ingest then keeps the
+ * tiles / CSR kernels.  stats (optional, 5 values): row bins, phase-1 slots, batches, chunks, the largest number of rank rounds
+ * a batch needs. */
 int mispec_staged_spmv_host(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* colind, const double* val,
                             const double* x, double* y, int* built, int64_t* stats);
 /* The ordering alone, on host arrays (no device needed): perm_out[new] = old for the pattern of an n x n CSR matrix;

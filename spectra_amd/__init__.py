@@ -102,7 +102,8 @@ def staged_spmv_host(mat, x):
     built = C.c_int(0)
     st = (C.c_int64 * 5)()
     check(lib().mispec_staged_spmv_host(mat.shape[0], mat.shape[1], _ip(rp), _ip(ci), _dp(v), _dp(x), _dp(y), C.byref(built), st))
-    return (y if built.value else None), {"bins": st[0], "slots": st[1], "batches": st[2], "chunks": st[3], "max_rounds": st[4]}
+    return (y if built.value else None), {"bins": st[0], "slots": st[1], "batches": st[2], "chunks": st[3], "max_rounds": st[4],
+                                          "well_filled": built.value == 1}
 
 
 def last_ingest_info():

@@ -1447,6 +1447,10 @@ mispec_csr* upload_rows(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const i
                 {
                     IngestTimer timer(8);
                     staged_built = build_staged(nloc, n_cols, rp.data(), colind + p0, val + p0, H, 2 * ctx->num_cu);
+                    // a few heavy rows among scattered ones: the image is correct but its batches are nearly empty (serial barrier
+                    // rounds); only MISPEC_SPMV_STAGED=1 keeps it, the automatic choice falls back to the tiles / CSR kernels
+                    if (staged_built && !H.well_filled && !st_force)
+                        staged_built = false;
                 }
                 if (staged_built)
                 {

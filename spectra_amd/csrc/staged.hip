@@ -325,7 +325,10 @@ bool build_staged(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int
     for (int64_t c = 0; c < ncb; c++)
         for (int64_t b = cb_ptr[size_t(c)]; b < cb_ptr[size_t(c) + 1]; b += kStPiece)
             out.pieces.push_back(StPiece{b, std::min(b + kStPiece, cb_ptr[size_t(c) + 1]), int32_t(c), 0});
-    // first slot of every (column block, bin) tile: rows ascend inside a segment
+    // first slot of every (column block, bin) tile: rows ascend inside a segment.  The table is ncb x (nbins + 1) — quadratic in
+    // n: 6 MB at n = 1e7, 600 MB at 1e8 — so the format declines matrices beyond a fixed budget (they keep the tiles / CSR kernels)
+    if (double(ncb) * double(nbins + 1) > 64.0 * 1024.0 * 1024.0)
+        return false;
     std::vector<uint32_t> tile(static_cast<size_t>(ncb) * size_t(nbins + 1));
     parallel_ranges(ncb, nt, [&](int, int64_t cb0, int64_t cb1) {
         for (int64_t c = cb0; c < cb1; c++)
@@ -430,6 +433,11 @@ bool build_staged(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int
         out.nchunks += bins[size_t(bin)].chunks;
     }
     out.nbatches = nb;
+    // A row with more than 8 entries inside one batch closes the batch (3-bit ranks): a few dense or heavy rows among scattered
+    // ones produce one nearly empty batch per 8 of their entries, all of them serial barrier rounds of one workgroup — the product
+    // stays correct but takes orders of magnitude longer.  `well_filled` is false when fewer than a quarter of the
+    // chunk slots of the batches are in use: the automatic format choice (csr.hip upload_rows) then declines the image.
+    out.well_filled = !(double(nb) * double(kStBatchChunks) > 4.0 * double(out.nchunks) + 4.0 * double(kStBatchChunks) * double(nbins));
     out.desc.resize_uninitialized(size_t(nb) * kStBatchChunks);
     parallel_ranges(nbins, nt, [&](int, int64_t bin0, int64_t bin1) {
         for (int64_t bin = bin0; bin < bin1; bin++)
@@ -563,6 +571,8 @@ extern "C" int mispec_staged_spmv_host(int64_t nrows, int64_t ncols, const int32
         *built = mispec::build_staged(nrows, ncols, rowptr, colind, val, S) ? 1 : 0;
         if (!*built)
             return;
+        if (!S.well_filled)
+            *built = 2;  // the image is correct, but the automatic format choice declines it (nearly empty batches)
         mispec::staged_spmv_host(S, x, y);
         if (stats)
         {

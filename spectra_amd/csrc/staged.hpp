@@ -55,6 +55,7 @@ struct HostStaged
     RawVec<uint64_t> desc;         // [batches * kStBatchChunks] phase-1 position of the chunk | entries << 32 | rounds of its batch << 40
     RawVec<uint16_t> rowrank;      // [slots] phase-1 order like val: row inside the bin | rank << kStRowBits
     int64_t nbatches = 0, nchunks = 0;  // nchunks: chunks that hold entries
+    bool well_filled = true;            // false: heavy rows split the batches into nearly empty ones (the automatic choice declines)
 };
 
 // Build the image of rows [0, nrows) of a CSR matrix (any pattern; rows need not be sorted: the row sums follow the storage

@@ -32,6 +32,24 @@ def test_scattered_patterns_get_the_staged_format_by_default(ctx, monkeypatch):
     assert np.array_equal(device_spmv(op, x), O.Op.csr(300_001, 300_001, A.indptr, A.indices, A.data).perform_op(x))
 
 
+def test_heavy_rows_make_the_automatic_choice_decline_the_staged_format(ctx, monkeypatch):
+    # three dense rows among scattered ones would give one nearly empty batch per 8 of their entries (serial barrier
+    # rounds of one workgroup).  The automatic choice keeps another kernel; the product stays the CSR row-dot bit for bit.
+    monkeypatch.delenv("MISPEC_SPMV_STAGED")
+    monkeypatch.delenv("MISPEC_SPMV_TILES")
+    n = 300_001
+    A = m_rand(n).tolil()
+    rng = np.random.default_rng(4)
+    for r in (11, 150_000, n - 2):
+        A[r, :] = rng.uniform(-1, 1, n)
+    A = A.tocsr()
+    A.sort_indices()
+    op = sa.SparseGenMatProd(A, ctx=ctx)
+    assert op.spmv_format() != 4 and op.staged_info()["bins"] == 0
+    x = np.random.default_rng(2).standard_normal(n)
+    assert np.array_equal(device_spmv(op, x), O.Op.csr(n, n, A.indptr, A.indices, A.data).perform_op(x))
+
+
 @pytest.mark.parametrize("n", [300_001, 1_000_000])
 def test_staged_product_is_bit_exact(ctx, n):
     A = m_rand(n)

@@ -78,3 +78,22 @@ def test_staged_veto_on_unsorted_rows():
     A.has_sorted_indices = False
     y, _ = sa.staged_spmv_host(A, np.ones(100_000))
     assert y is None  # the row sums would not follow the storage order: the format declines, the CSR kernels take the matrix
+
+
+def test_heavy_rows_among_scattered_ones_are_flagged_for_the_automatic_choice():
+    # a row with more than 8 entries inside one batch closes the batch; a few dense rows among scattered ones give one
+    # nearly empty batch per 8 of their entries.  The image stays correct (and is checked), but is reported as poorly filled, and
+    # the automatic format choice at ingest (csr.hip upload_rows) declines it.
+    n = 200_000
+    S = scattered(n, 8, 4, n)
+    base = sa.staged_spmv_host(S, np.ones(n))[1]
+    assert base["well_filled"]
+    rng = np.random.default_rng(1)
+    dense_rows = np.array([5, 70_000, 130_001, n - 1])
+    D = sp.coo_matrix((rng.uniform(-1, 1, 4 * n), (np.repeat(dense_rows, n), np.tile(np.arange(n), 4))), shape=(n, n)).tocsr()
+    keep = np.ones(n, bool)
+    keep[dense_rows] = False
+    A = (sp.diags(keep.astype(float)) @ S + D).tocsr()
+    A.sort_indices()
+    st = check(A, 3)
+    assert not st["well_filled"] and st["batches"] > 20 * base["batches"]
