@@ -43,7 +43,7 @@ build_tests() {
         if [ -f "$T/$name.bin" ] && [ -z "$(find "$HERE/eigen_shim" "$REF/include/Spectra" "$REF/test/$name.cpp" -newer "$T/$name.bin" -print -quit)" ]; then
             continue
         fi
-        if ${CXX:-g++} -std=c++17 -O2 -w -I"$HERE/eigen_shim" -I"$REF/include" -I"$REF/test" -c "$REF/test/$name.cpp" -o "$T/$name.o" 2> "$T/$name.log" &&
+        if ${CXX:-g++} -std=c++17 -O2 -ffp-contract=off -w -I"$HERE/eigen_shim" -I"$REF/include" -I"$REF/test" -c "$REF/test/$name.cpp" -o "$T/$name.o" 2> "$T/$name.log" &&
            ${CXX:-g++} "$T/$name.o" "$T/tests-main.o" -o "$T/$name.bin" 2>> "$T/$name.log"; then
             echo "built $T/$name.bin"
             rm -f "$T/$name.log"
