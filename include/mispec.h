@@ -354,7 +354,10 @@ int mispec_fac_f_norm(const mispec_fac* fac, double* beta);  /* f_norm() */
 enum { MISPEC_ORTH_REFERENCE = 0, MISPEC_ORTH_ONESWEEP = 1,
        /* flags, or-ed to MISPEC_ORTH_ONESWEEP: */
        MISPEC_ORTH_EAGER_LAST = 0x100,    /* apply the last correction of a full sweep at once (no fused restart, see below) */
-       MISPEC_ORTH_TEST_RECORRECT = 0x200 /* test hook: every fused restart is followed by one more correction (see below) */ };
+       MISPEC_ORTH_TEST_RECORRECT = 0x200, /* test hook: every fused restart is followed by one more correction (see below) */
+       MISPEC_ORTH_TEST_RESTART_CHECK = 0x400 /* test hook: the device-side test of every fused restart reports "one correction was not
+                                                enough", so none of the steps enqueued behind the restart runs and the host continues
+                                                with the reference's loop before the sweep is enqueued again (see below) */ };
 int mispec_fac_set_orth_mode(mispec_fac* fac, int mode);
 int mispec_fac_orth_info(const mispec_fac* fac, int* mode, int64_t* lagged_steps, int64_t* check_stops, int64_t* state_stops,
                          double* max_rel_c, double* max_chk);

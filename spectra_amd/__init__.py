@@ -28,7 +28,8 @@ SYNTH_SEED = 20240607
 # include/mispec.h MISPEC_ORTH_*: the reference's control flow, or the opt-in one-sweep steps; "onesweep-eager" applies the
 # last correction of every sweep at once instead of letting it ride on the restart's V*Q pass, "onesweep-recorrect" is the test
 # hook that lets one more correction follow every such fused restart
-ORTH_MODES = {"reference": 0, "onesweep": 1, "onesweep-eager": 1 | 0x100, "onesweep-recorrect": 1 | 0x200}
+# "onesweep-restart-check" is the test hook of the restart without a host turn: its device-side test always reports a failure
+ORTH_MODES = {"reference": 0, "onesweep": 1, "onesweep-eager": 1 | 0x100, "onesweep-recorrect": 1 | 0x200, "onesweep-restart-check": 1 | 0x400}
 
 
 def _orth_mode_value(mode):

@@ -27,6 +27,7 @@
 #include <memory>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 
 using namespace mispec;
 
@@ -125,10 +126,15 @@ struct mispec_fac
     // needs f calls finish_pending first.
     bool end_pending = false;
     bool eager_last = false, test_recorrect = false;  // MISPEC_ORTH_EAGER_LAST / MISPEC_ORTH_TEST_RECORRECT
+    bool test_restart_check = false;                   // MISPEC_ORTH_TEST_RESTART_CHECK
     // set when a fused restart's test (Lanczos.h:156 on the corrected residual) failed or came within a factor of two of its bar:
     // the remaining sweeps of this solve apply their last correction before the restart, the reference's order (cleared by init)
     bool eager_sticky = false;
     int end_rec = 0;
+    // Fused restart without a host turn: the restart left the start state of the next sweep (beta = |f_new|, the reference's test
+    // of the corrected residual) in d_state and enqueued nothing that needs the host; F.beta is stale until resolve_restart /
+    // the end of the next device-driven sweep.  MISPEC_RESTART_SYNC=1 restores the synchronising restart.
+    bool restart_unresolved = false;
     int64_t fused_restarts = 0, fused_recorrected = 0;
     int x_cols = 0;    // columns currently held in X
 
@@ -780,6 +786,7 @@ void zero_vector(mispec_fac& F, double* v)
 void init_from_tmp(mispec_fac& F, int64_t* nmatop)
 {
     F.end_pending = false;
+    F.restart_unresolved = false;
     F.eager_sticky = false;
     std::fill(F.H.begin(), F.H.end(), 0.0);
     MISPEC_HIP(hipMemsetAsync(F.V.p, 0, F.V.n * sizeof(double), F.stream()));
@@ -876,8 +883,35 @@ bool small_on_device()
 
 // One-sweep steps: apply the correction that the last step of the sweep left pending, then continue the reference's loop
 // (Lanczos.h:156-182) from "one correction applied".  H and beta already carry that correction (finish_lagged).
+void corrections_after_fused_restart(mispec_fac& F, bool force);
+// what the host learns about a sync-free fused restart once the state has come back (diagnostics and the sticky eager mode)
+void absorb_restart_state(mispec_fac& F, const StepState& hs)
+{
+    F.beta = hs.beta;
+    F.lag_chk_max = std::max(F.lag_chk_max, hs.rst_beta_corr > 0.0 ? hs.rst_err / hs.rst_beta_corr : 0.0);
+    if (hs.rst_err > 0.5 * kEps * hs.rst_beta_corr)
+        F.eager_sticky = true;  // the Ritz values of this restart were computed before the correction: do not repeat that
+}
+// A sync-free fused restart whose outcome some host code needs now (f, beta, H, a host-driven step): one synchronisation.
+void resolve_restart(mispec_fac& F)
+{
+    if (!F.restart_unresolved)
+        return;
+    F.restart_unresolved = false;
+    StepState& hs = *F.h_state.p;
+    MISPEC_HIP(hipMemcpyAsync(&hs, F.d_state.p, sizeof(StepState), hipMemcpyDeviceToHost, F.stream()));
+    sync_stream(F);
+    absorb_restart_state(F, hs);
+    if (hs.status == kStepRestartCheck)
+    {
+        F.fused_recorrected++;
+        corrections_after_fused_restart(F, false);
+    }
+}
+
 void finish_pending(mispec_fac& F)
 {
+    resolve_restart(F);
     if (!F.end_pending)
         return;
     F.end_pending = false;
@@ -1099,6 +1133,8 @@ void factorize_lanczos(mispec_fac& F, int from_k, int to_m, int64_t* nmatop)
     // — for the fused restart (k_vq_fused: one column panel); wider bases finish every sweep the reference's way
     const bool defer = lagged && F.m <= kPanelCols && to_m == F.m && !F.eager_last && !F.eager_sticky && !small_on_device();
     F.end_pending = false;
+    if (F.restart_unresolved && !(lagged && from_k == F.k))
+        resolve_restart(F);  // (mispec_fac_factorize resolves through finish_pending unless this sweep can start from the device state)
     int i = from_k;
     while (i <= to_m - 1)
     {
@@ -1110,15 +1146,20 @@ void factorize_lanczos(mispec_fac& F, int from_k, int to_m, int64_t* nmatop)
         }
         // ---- device-driven run of steps i .. to_m-1 -------------------------------------------------
         StepState& hs = *F.h_state.p;
-        std::memset(&hs, 0, sizeof(StepState));
-        hs.beta = F.beta;
-        hs.status = kStepOk;
-        for (int j = 0; j < F.m; j++)
+        const bool from_restart = F.restart_unresolved;  // the start state is already in d_state (mispec_fac_restart_sym)
+        F.restart_unresolved = false;
+        if (!from_restart)
         {
-            hs.diag[j] = F.Hat(j, j);
-            hs.subd[j] = (j + 1 < F.m) ? F.Hat(j + 1, j) : 0.0;
+            std::memset(&hs, 0, sizeof(StepState));
+            hs.beta = F.beta;
+            hs.status = kStepOk;
+            for (int j = 0; j < F.m; j++)
+            {
+                hs.diag[j] = F.Hat(j, j);
+                hs.subd[j] = (j + 1 < F.m) ? F.Hat(j + 1, j) : 0.0;
+            }
+            MISPEC_HIP(hipMemcpyAsync(F.d_state.p, &hs, sizeof(StepState), hipMemcpyHostToDevice, F.stream()));
         }
-        MISPEC_HIP(hipMemcpyAsync(F.d_state.p, &hs, sizeof(StepState), hipMemcpyHostToDevice, F.stream()));
         for (int s = i; s <= to_m - 1; s++)
         {
             if (lagged)
@@ -1130,6 +1171,16 @@ void factorize_lanczos(mispec_fac& F, int from_k, int to_m, int64_t* nmatop)
         sync_stream(F);
 
         const int status = hs.status;
+        if (from_restart)
+        {
+            absorb_restart_state(F, hs);
+            if (status == kStepRestartCheck)  // no step ran: the reference's loop on the compressed factorisation, then the sweep again
+            {
+                F.fused_recorrected++;
+                corrections_after_fused_restart(F, false);
+                continue;
+            }
+        }
         const int stop = (status == kStepOk) ? to_m : hs.stop_step;
         const int last_done = (status == kStepOk) ? to_m - 1 : ((status == kStepSmallBeta || status == kStepLagCheck) ? stop - 1 : stop);
         if (lagged)
@@ -1801,7 +1852,8 @@ extern "C" int mispec_fac_factorize(mispec_fac* fac, int from_k, int to_m, int64
         F.ctx->make_current();
         if (to_m <= from_k)
             return;
-        finish_pending(F);
+        if (!(F.restart_unresolved && F.symmetric))  // (a sync-free restart is picked up by factorize_lanczos itself)
+            finish_pending(F);
         MISPEC_REQUIRE(to_m <= F.m && from_k >= 1, "factorize_from: need 1 <= from_k < to_m <= ncv");
         if (from_k > F.k)  // Lanczos.h:70-75 / Arnoldi.h:206-211
             throw Error(MISPEC_EINVAL, std::string(F.symmetric ? "Lanczos" : "Arnoldi") + ": from_k (= " + std::to_string(from_k) +
@@ -1835,11 +1887,13 @@ extern "C" int mispec_fac_set_orth_mode(mispec_fac* fac, int mode)
         MISPEC_REQUIRE(fac, "mispec_fac_set_orth_mode: NULL argument");
         const int base = mode & 0xff, flags = mode & ~0xff;
         MISPEC_REQUIRE((base == MISPEC_ORTH_REFERENCE && flags == 0) ||
-                           (base == MISPEC_ORTH_ONESWEEP && (flags & ~(MISPEC_ORTH_EAGER_LAST | MISPEC_ORTH_TEST_RECORRECT)) == 0),
+                           (base == MISPEC_ORTH_ONESWEEP &&
+                            (flags & ~(MISPEC_ORTH_EAGER_LAST | MISPEC_ORTH_TEST_RECORRECT | MISPEC_ORTH_TEST_RESTART_CHECK)) == 0),
                        "mispec_fac_set_orth_mode: unknown mode");
         fac->onesweep = (base == MISPEC_ORTH_ONESWEEP);
         fac->eager_last = (flags & MISPEC_ORTH_EAGER_LAST) != 0;
         fac->test_recorrect = (flags & MISPEC_ORTH_TEST_RECORRECT) != 0;
+        fac->test_restart_check = (flags & MISPEC_ORTH_TEST_RESTART_CHECK) != 0;
     });
 }
 
@@ -1851,7 +1905,8 @@ extern "C" int mispec_fac_orth_info(const mispec_fac* fac, int* mode, int64_t* l
         const bool active = fac->onesweep && fac->device_steps && fac->symmetric && device_operator(*fac) && !fac->bmode() && fac->m <= 2 * kPanelCols;
         if (mode)
             *mode = active ? (MISPEC_ORTH_ONESWEEP | ((fac->eager_last || fac->eager_sticky) ? MISPEC_ORTH_EAGER_LAST : 0) |
-                              (fac->test_recorrect ? MISPEC_ORTH_TEST_RECORRECT : 0))
+                              (fac->test_recorrect ? MISPEC_ORTH_TEST_RECORRECT : 0) |
+                              (fac->test_restart_check ? MISPEC_ORTH_TEST_RESTART_CHECK : 0))
                            : MISPEC_ORTH_REFERENCE;
         if (lagged_steps)
             *lagged_steps = fac->lag_steps;
@@ -1890,6 +1945,11 @@ extern "C" int mispec_fac_f_norm(const mispec_fac* fac, double* beta)
 {
     return guarded([&] {
         MISPEC_REQUIRE(fac && beta, "mispec_fac_f_norm: NULL argument");
+        if (fac->restart_unresolved)
+        {
+            fac->ctx->make_current();
+            resolve_restart(*const_cast<mispec_fac*>(fac));
+        }
         *beta = fac->beta;
     });
 }
@@ -1898,7 +1958,7 @@ extern "C" int mispec_fac_get_H(const mispec_fac* fac, double* H_host)
 {
     return guarded([&] {
         MISPEC_REQUIRE(fac && H_host, "mispec_fac_get_H: NULL argument");
-        if (fac->end_pending)  // a further correction, should the reference's loop take one, still changes H(m-1, m-2 : m-1)
+        if (fac->end_pending || fac->restart_unresolved)  // a further correction, should the reference's loop take one, still changes H(m-1, m-2 : m-1)
         {
             fac->ctx->make_current();
             finish_pending(*const_cast<mispec_fac*>(fac));
@@ -1911,7 +1971,7 @@ extern "C" int mispec_fac_set_H(mispec_fac* fac, const double* H_host, int k)
 {
     return guarded([&] {
         MISPEC_REQUIRE(fac && H_host && k >= 0 && k <= fac->m, "mispec_fac_set_H: bad argument");
-        if (fac->end_pending)
+        if (fac->end_pending || fac->restart_unresolved)
         {
             fac->ctx->make_current();
             finish_pending(*fac);
@@ -2112,11 +2172,49 @@ extern "C" int mispec_fac_restart_sym(mispec_fac* fac, const double* shifts_host
                 fa.kcol = k;
                 fa.partials = F.partials.p;
                 fa.pstride = F.pstride;
+                // Without a host turn (the default): the record's scalar tail runs on the device (kFinishFusedRestart) and leaves the
+                // start state of the next sweep in d_state — H after compress_H is known here, beta = |f_new| follows from the
+                // record —, so factorize_lanczos enqueues that sweep at once; should the corrected residual fail the reference's
+                // test (Lanczos.h:156), none of its steps runs and the host continues the reference's loop at the sweep's end.
+                static const bool sync_env = getenv("MISPEC_RESTART_SYNC") && std::string(getenv("MISPEC_RESTART_SYNC")) == "1";
+                const bool no_sync = !sync_env && !F.test_recorrect && F.device_steps && device_operator(F) && !F.bmode();
+                if (no_sync)
+                {
+                    StepState& st0 = *F.h_state.p;
+                    std::memset(&st0, 0, sizeof(StepState));
+                    st0.status = kStepOk;
+                    for (int j = 0; j < m; j++)
+                    {
+                        st0.diag[j] = hs[j];
+                        st0.subd[j] = (j + 1 < m) ? hs[m + j] : 0.0;
+                    }
+                    MISPEC_HIP(hipMemcpyAsync(F.d_state.p, &st0, sizeof(StepState), hipMemcpyHostToDevice, F.stream()));
+                }
                 int nrec;
                 {
                     Timed t(F, FAM_COMPRESS);
                     F.count_bytes(FAM_COMPRESS, m + k + 1 + 2);  // m columns and ftilde read, k + 1 columns and the new f written
                     nrec = launch_vq_fused(*F.ctx, F.V.p, F.ldv, m, F.Qdev.p, m, k + 1, F.V.p, F.ldv, F.nloc, fa);
+                }
+                if (no_sync)
+                {
+                    FinishArgs fin;
+                    fin.mode = kFinishFusedRestart;
+                    fin.st = F.d_state.p;
+                    fin.step = k;
+                    fin.eps = F.test_restart_check ? -1.0 : kEps;  // (the hook: max |V'f| > -|f| always holds)
+                    reduce_record(F, nrec, m + 1, F.end_rec ^ 1, fin);
+                    F.fused_restarts++;
+                    F.f.swap(F.tmp);
+                    F.beta = std::numeric_limits<double>::quiet_NaN();  // unknown on the host until the state comes back
+                    std::fill(F.H.begin(), F.H.end(), 0.0);
+                    for (int i = 0; i < m; i++)
+                        F.Hat(i, i) = hs[i];
+                    for (int i = 0; i < m - 1; i++)
+                        F.Hat(i + 1, i) = F.Hat(i, i + 1) = hs[m + i];
+                    F.k = k;
+                    F.restart_unresolved = true;
+                    return;
                 }
                 reduce_to_host(F, nrec, m + 1, F.end_rec ^ 1);  // slots [0, m) V'f, m |f_new|^2, kSlotBeta2 |f|^2
                 double err = 0.0;

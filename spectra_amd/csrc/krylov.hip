@@ -485,11 +485,42 @@ __device__ void finish_lagged(double* red, const FinishArgs& fa)
     }
 }
 
+// Executed by ONE thread after the reduction of a k_vq_fused record (krylov.hpp VqFusedArgs): what mispec_fac_restart_sym used to
+// do on the host after a stream synchronisation — now the sweep that follows the restart is enqueued at once and starts from
+// this state.
+__device__ void finish_fused_restart(double* red, int ncol, const FinishArgs& fa)
+{
+    const int m = ncol - 1;
+    double err = 0.0;
+    for (int j = 0; j < m; j++)
+        err = fmax(err, fabs(red[j]));
+    const double beta_corr = sqrt(red[kSlotBeta2]);
+    red[kSlotBeta] = beta_corr;
+    red[kSlotErr] = err;
+    StepState* st = fa.st;
+    if (st->status != kStepOk)
+        return;
+    st->beta = sqrt(red[m]);  // Arnoldi.h:339
+    st->rst_err = err;
+    st->rst_beta_corr = beta_corr;
+    if (err > fa.eps * beta_corr)  // Lanczos.h:156 with count = 1
+    {
+        st->status = kStepRestartCheck;
+        st->stop_step = fa.step;
+        st->stop_count = 1;
+    }
+}
+
 // Executed by ONE thread after a reduction: the scalar tail of a Lanczos step.
 __device__ void finish_record(double* red, int ncol, const FinishArgs& fa)
 {
     if (fa.mode == kFinishNone)
         return;
+    if (fa.mode == kFinishFusedRestart)
+    {
+        finish_fused_restart(red, ncol, fa);
+        return;
+    }
     if (fa.mode == kFinishLagged)
     {
         finish_lagged(red, fa);

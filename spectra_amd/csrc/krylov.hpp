@@ -48,6 +48,10 @@ struct StepState
     double lag_rel_c_max;
     double lag_chk_max;
     int64_t lag_steps;
+    // fused restart without a host turn (kFinishFusedRestart): max |V'f| and |f| of the corrected residual the restart's V*Q pass
+    // measured (Lanczos.h:156), read by the host at the end of the sweep that follows
+    double rst_err;
+    double rst_beta_corr;
 };
 enum
 {
@@ -55,8 +59,10 @@ enum
     kStepSmallBeta = 1,  // beta < sqrt(eps) at the start of a step: the reference's restart heuristics run on the host path
     kStepMoreCorr = 2,   // a third correction is needed: continue the loop on the host path
     kStepTinyF = 3,      // beta < eps*sqrt(n) inside the loop (Lanczos.h:163-168): host zeroes f
-    kStepLagCheck = 4    // one-sweep variant: column stop_step needs a second correction (Lanczos.h:156 after the first one);
+    kStepLagCheck = 4,   // one-sweep variant: column stop_step needs a second correction (Lanczos.h:156 after the first one);
                          // the host finishes step stop_step-1 with the reference's loop and repeats step stop_step
+    kStepRestartCheck = 5  // fused restart: the corrected residual fails the reference's test (Lanczos.h:156): no step of the sweep
+                           // that was enqueued behind the restart runs, the host continues the reference's loop and repeats it
 };
 enum
 {
@@ -66,7 +72,9 @@ enum
     kFinishStepCorr = 3,   // + bookkeeping after one correction (Lanczos.h:171-180)
     kFinishArnoldiH = 4,   // Arnoldi: red[0..ncol) is h = V'w -> H(:, step), |h| (Arnoldi.h:251)
     kFinishArnoldiF = 5,   // Arnoldi: after f = w - Vh: beta, the 0.717 test and the need for corrections (Arnoldi.h:255-266)
-    kFinishLagged = 6      // one-sweep variant: bookkeeping after an ORTH_LAGGED pass
+    kFinishLagged = 6,     // one-sweep variant: bookkeeping after an ORTH_LAGGED pass
+    kFinishFusedRestart = 7  // record of k_vq_fused (slots [0, m) V'f_corr, m |f_new|^2, kSlotBeta2 |f_corr|^2; ncol = m + 1): the start
+                             // state of the next sweep — beta = |f_new| — and the reference's test of the corrected residual
 };
 struct FinishArgs
 {

@@ -159,6 +159,58 @@ def test_fused_restart_equals_the_two_pass_sequence(ctx, n, m, k):
         lanczos_identities(facs[mode], S, m, 1e-10)     # get_f applies the pending correction of this second sweep
 
 
+@pytest.mark.parametrize("rule", ["LargestAlge", "BothEnds"])
+def test_restart_without_a_host_turn_and_its_fallback(ctx, rule):
+    # Since round 5 the fused restart leaves the start state of the next sweep on the device (kFinishFusedRestart) and the sweep
+    # is enqueued behind it at once: about one stream synchronisation per restart instead of two.  MISPEC_ORTH_TEST_RESTART_CHECK
+    # makes the device-side test of the corrected residual (Lanczos.h:156) fail every time: none of the enqueued steps runs, the
+    # host continues with the reference's loop on the compressed factorisation (which finds nothing to correct) and enqueues the
+    # sweep again — same solve up to the rounding of one norm.
+    A, S = sparse_fixture(1000, 0.01)
+    op = sa.SparseSymMatProd(A, ctx=ctx)
+    plain, nconv_p = solve(op, 10, 30, sa.SortRule[rule], "onesweep")
+    hooked, nconv_h = solve(op, 10, 30, sa.SortRule[rule], "onesweep-restart-check")
+    assert nconv_p == nconv_h == 10
+    pi, hi = plain.orth_info(), hooked.orth_info()
+    assert pi["fused_restarts"] > 0 and pi["fused_recorrected"] == 0
+    assert hi["fused_restarts"] == hi["fused_recorrected"] > 0
+    assert np.abs(hooked.eigenvalues() - plain.eigenvalues()).max() <= 1e-12 * np.abs(plain.eigenvalues()).max()
+    assert abs(hooked.num_operations() - plain.num_operations()) <= 20
+    evals, evecs = hooked.eigenvalues(), hooked.eigenvectors()
+    assert np.abs(S @ evecs - evecs * evals).max() < 1e-9 and np.abs(evecs.T @ evecs - np.eye(10)).max() <= 1e-10
+    # synchronisations: a sweep's end (H and the step state come home) + the Ritz test; the restart itself needs none
+    e = sa.SymEigsSolver(op, 10, 30)
+    e.set_orth_mode("onesweep")
+    e.profile(2)
+    e.init()
+    assert e.compute(sa.SortRule[rule], 1000, 1e-10) == 10
+    p = e.get_profile()
+    assert p["n_host_sync"] <= e.num_iterations() + 6, (p["n_host_sync"], e.num_iterations())
+
+
+def test_a_host_query_between_restart_and_sweep_resolves_the_device_state(ctx):
+    # f_norm / vector_f / matrix_H right after a restart without a host turn: the state comes home on demand and the
+    # factorisation continues from the host copy; same H as the un-queried run to rounding
+    n, m, k = 20000, 24, 10
+    op = sa.SparseSymMatProd.synth_band(n, offsets=(1, 2, 3, 50, 51, 1500, 1501), ctx=ctx)
+    out = []
+    for query in (False, True):
+        fac = sa.Factorization(op, m, True)
+        fac.set_orth_mode("onesweep")
+        fac.init_random(0)
+        fac.factorize_from(1, m)
+        ev, _ = fac.tridiag_eigen()
+        fac.restart_sym(ev[np.argsort(-np.abs(ev))][k:])
+        if query:
+            beta = fac.f_norm()
+            f = fac.vector_f()
+            assert np.isfinite(beta) and abs(np.linalg.norm(f) - beta) <= 1e-12 * beta
+        fac.factorize_from(k, m)
+        out.append(fac.matrix_H())
+        assert np.isfinite(fac.f_norm())
+    assert np.abs(out[0] - out[1]).max() <= 1e-12 * np.abs(out[0]).max()
+
+
 @pytest.mark.parametrize("rule", ["LargestAlge", "SmallestAlge", "BothEnds"])
 def test_fused_restart_followed_by_further_corrections(ctx, rule):
     # MISPEC_ORTH_TEST_RECORRECT: every fused restart is followed by the loop the reference runs when one correction was not
