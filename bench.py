@@ -699,7 +699,9 @@ def main():
                                                    "tests/test_gpu_onesweep.py, the reference's own test programs in both modes and the full-size "
                                                    "golden; the reference-flow (MISPEC_ORTH=reference) figure of the same "
                                                    "run is `other_orth_mode`; the last correction of every sweep rides on the restart's "
-                                                   "V*Q pass (k_vq_fused)"}[args.orth.replace("-eager", "")]),
+                                                   "V*Q pass (k_vq_fused); since round 5 with ONE reduction per lagged step (the product runs on the "
+                                                   "un-normalised residual, its <f~, A f~> is reduced with the record of the previous pass; "
+                                                   "MISPEC_ONE_REDUCTION=0 restores two) and a restart that needs no host turn"}[args.orth.replace("-eager", "")]),
                 "solver_object": "one SymEigsSolver (V, X, work vectors) allocated before the timed region and re-used by every step",
                 "eigenvectors": ("X = V*Y is formed in HBM and left there (the reference's eigenvectors() returns a host matrix: "
                                  f"the D2H copy of {8e-9 * args.n * args.nev:.1f} GB would add ~{8e-9 * args.n * args.nev / 55 * 1e3:.0f} ms per solve "
@@ -765,12 +767,17 @@ def main():
             out["collectives_per_step"] = {
                 "exchange": {"count": 1, "kind": "neighbour send/recv" if halo else "all-gather",
                              "megabytes_received_per_rank": recv_doubles * 8 / 1e6 if halo else (world - 1) * block_mb},
-                "all_reduce_sum": [{"what": "alpha = <v, w>", "bytes": 8}] +
-                                  ([{"what": "record of the one-sweep pass of step i: c' = [V, v_i]'f (i + 1 sums), chk = V'v_i (i), |f|^2 — one "
-                                             "contiguous message", "bytes_max": 8 * 2 * args.ncv}] if args.orth.startswith("onesweep") else
-                                   [{"what": "record: V'f (i + 1 sums), |f|^2 — one contiguous message", "bytes_max": 8 * (args.ncv + 1)}] * 2),
-                "note": "per Lanczos step and rank; one-sweep: one record per step (the last correction of a sweep and its test ride on the "
-                        "restart's V*Q pass: one more record of ncv + 2 sums per restart), reference flow: V'f and the correction's V'f check"}
+                "all_reduce_sum": ([{"what": "ONE message per lagged step (include/mispec.h MISPEC_ORTH_ONE_REDUCTION): the record of the pass of step i "
+                                             "— c' = [V, v_i]'f~ (i + 1 sums), chk = V'v_i (i), |f~|^2 — and, behind it, <f~, A f~> of the product of "
+                                             "step i + 1, which ran on the un-normalised residual", "bytes_max": 8 * (2 * args.ncv + 1)}]
+                                   if args.orth.startswith("onesweep") and eigs.orth_info().get("one_reduction") else
+                                   [{"what": "alpha = <v, w>", "bytes": 8}] +
+                                   ([{"what": "record of the one-sweep pass of step i: c' = [V, v_i]'f (i + 1 sums), chk = V'v_i (i), |f|^2 — one "
+                                              "contiguous message", "bytes_max": 8 * 2 * args.ncv}] if args.orth.startswith("onesweep") else
+                                    [{"what": "record: V'f (i + 1 sums), |f|^2 — one contiguous message", "bytes_max": 8 * (args.ncv + 1)}] * 2)),
+                "note": "per Lanczos step and rank; one-sweep: one record per step (the first step of a sweep takes the two-reduction form; the "
+                        "last correction of a sweep and its test ride on the restart's V*Q pass: one more record of ncv + 2 sums per restart), "
+                        "reference flow: alpha, V'f and the correction's V'f check"}
         if allgather_run:
             out["allgather_variant"] = allgather_run
         if world == 1 and not args.no_secondary and not args.no_profile:

@@ -355,10 +355,23 @@ enum { MISPEC_ORTH_REFERENCE = 0, MISPEC_ORTH_ONESWEEP = 1,
        /* flags, or-ed to MISPEC_ORTH_ONESWEEP: */
        MISPEC_ORTH_EAGER_LAST = 0x100,    /* apply the last correction of a full sweep at once (no fused restart, see below) */
        MISPEC_ORTH_TEST_RECORRECT = 0x200, /* test hook: every fused restart is followed by one more correction (see below) */
+       MISPEC_ORTH_ONE_REDUCTION = 0x800,  /* one reduction per lagged step (below); MISPEC_ORTH_TWO_REDUCTIONS: alpha = <v, w> reduced on
+                                              its own before the pass.  Neither flag: the library default — one reduction, MISPEC_ONE_REDUCTION=0 in the environment
+                                              restores two */
+       MISPEC_ORTH_TWO_REDUCTIONS = 0x1000,
        MISPEC_ORTH_TEST_RESTART_CHECK = 0x400 /* test hook: the device-side test of every fused restart reports "one correction was not
                                                 enough", so none of the steps enqueued behind the restart runs and the host continues
                                                 with the reference's loop before the sweep is enqueued again (see below) */ };
 int mispec_fac_set_orth_mode(mispec_fac* fac, int mode);
+/* One reduction per one-sweep step (MISPEC_ORTH_ONE_REDUCTION; plain matrix operators, ncv <= 64; CPU restatement: oracle/
+ * onesweep_variant.hpp, flavour one-reduction).  The reference's step needs alpha = <v, w> before f = w - alpha v (Lanczos.h:142-145)
+ * and beta = |f| before the next product (Lanczos.h:106): two global sums on the critical path, two all-reduces on a sharded run.
+ * Here the product of step i + 1 runs on the UN-normalised residual f~ of step i, u = A f~, and its epilogue's partial sums of
+ * <f~, u> are reduced by the kernel that reduces the record of step i's pass ([V, v_i]'f~, |f~|^2) — sharded: one all-reduce of
+ * 2 i + 3 doubles; beta, alpha~ = <f~, u> / beta^2 - <f~, v_i> and w = u / beta - beta v_i follow from it (nothing cancels: both
+ * norms are still measured).  The first step of a sweep and every step after the reference's own loop take the two-reduction
+ * form.  mispec_fac_onered_steps counts the steps that took the one-reduction form. */
+int mispec_fac_onered_steps(const mispec_fac* fac, int64_t* steps);
 int mispec_fac_orth_info(const mispec_fac* fac, int* mode, int64_t* lagged_steps, int64_t* check_stops, int64_t* state_stops,
                          double* max_rel_c, double* max_chk);
 /* One-sweep mode, end of a full sweep (factorize up to ncv): the correction of the LAST step stays pending as well, and
@@ -491,6 +504,7 @@ int mispec_symeigs_set_orth_mode(mispec_symeigs* s, int mode);
 int mispec_symeigs_orth_info(const mispec_symeigs* s, int* mode, int64_t* lagged_steps, int64_t* check_stops,
                              int64_t* state_stops, double* max_rel_c, double* max_chk);
 int mispec_symeigs_restart_info(const mispec_symeigs* s, int64_t* fused, int64_t* recorrected); /* see mispec_fac_restart_info */
+int mispec_symeigs_onered_steps(const mispec_symeigs* s, int64_t* steps);                        /* see mispec_fac_onered_steps */
 
 /* ---------------------------------------------------------------------------
  * General (non-symmetric) solver: Spectra::GenEigsSolver<Spectra::SparseGenMatProd<double>> behind a handle.

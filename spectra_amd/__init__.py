@@ -29,7 +29,10 @@ SYNTH_SEED = 20240607
 # last correction of every sweep at once instead of letting it ride on the restart's V*Q pass, "onesweep-recorrect" is the test
 # hook that lets one more correction follow every such fused restart
 # "onesweep-restart-check" is the test hook of the restart without a host turn: its device-side test always reports a failure
-ORTH_MODES = {"reference": 0, "onesweep": 1, "onesweep-eager": 1 | 0x100, "onesweep-recorrect": 1 | 0x200, "onesweep-restart-check": 1 | 0x400}
+# "onesweep-onered" / "onesweep-twored": one reduction per lagged step (include/mispec.h MISPEC_ORTH_ONE_REDUCTION) or the separate
+# alpha reduction, whatever the library default is
+ORTH_MODES = {"reference": 0, "onesweep": 1, "onesweep-eager": 1 | 0x100, "onesweep-recorrect": 1 | 0x200, "onesweep-restart-check": 1 | 0x400,
+              "onesweep-onered": 1 | 0x800, "onesweep-twored": 1 | 0x1000, "onesweep-onered-eager": 1 | 0x800 | 0x100}
 
 
 def _orth_mode_value(mode):
@@ -955,10 +958,12 @@ class SymEigsSolver:
         check(lib().mispec_symeigs_orth_info(self.h, C.byref(mode), C.byref(a), C.byref(b), C.byref(c), C.byref(r), C.byref(k)))
         fused, again = C.c_int64(0), C.c_int64(0)
         check(lib().mispec_symeigs_restart_info(self.h, C.byref(fused), C.byref(again)))
+        ored = C.c_int64(0)
+        check(lib().mispec_symeigs_onered_steps(self.h, C.byref(ored)))
         return {"mode": "onesweep" if (mode.value & 0xFF) else "reference", "eager_last": bool(mode.value & 0x100),
-                "recorrect_hook": bool(mode.value & 0x200), "lagged_steps": a.value, "check_stops": b.value,
+                "recorrect_hook": bool(mode.value & 0x200), "one_reduction": bool(mode.value & 0x800), "lagged_steps": a.value, "check_stops": b.value,
                 "state_stops": c.value, "max_rel_c": r.value, "max_chk": k.value, "fused_restarts": fused.value,
-                "fused_recorrected": again.value}
+                "fused_recorrected": again.value, "one_reduction_steps": ored.value}
 
     def overlap_info(self):
         """(first interior 256-row block, interior blocks, all blocks): what is multiplied while the exchange is in flight."""

@@ -226,6 +226,8 @@ SIGNATURES = {
     "mispec_fac_set_orth_mode": (C.c_int, [_vp, C.c_int]),
     "mispec_fac_orth_info": (C.c_int, [_vp, C.POINTER(C.c_int), _lp, _lp, _lp, _dp, _dp]),
     "mispec_fac_restart_info": (C.c_int, [_vp, _lp, _lp]),
+    "mispec_fac_onered_steps": (C.c_int, [_vp, _lp]),
+    "mispec_symeigs_onered_steps": (C.c_int, [_vp, _lp]),
     "mispec_symeigs_restart_info": (C.c_int, [_vp, _lp, _lp]),
     "mispec_geneigs_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vpp]),
     "mispec_geneigs_create_op": (C.c_int, [_vp, op_fn, _vp, C.c_int64, C.c_int64, C.c_int64, _vpp]),

@@ -127,6 +127,17 @@ struct mispec_fac
     bool end_pending = false;
     bool eager_last = false, test_recorrect = false;  // MISPEC_ORTH_EAGER_LAST / MISPEC_ORTH_TEST_RECORRECT
     bool test_restart_check = false;                   // MISPEC_ORTH_TEST_RESTART_CHECK
+    // One reduction per lagged step (MISPEC_ORTH_ONE_REDUCTION): the record of a lagged pass is not reduced at
+    // once — the next step's product runs on the un-normalised residual and ONE kernel (sharded: one all-reduce) reduces that
+    // record together with the product's <f~, A f~>.  `lag_def` is the record waiting for that.
+    bool onered = false, skip_alpha_reduce = false;
+    int64_t onered_steps = 0;
+    struct DeferredRecord
+    {
+        bool have = false;
+        int nrec = 0, ncol = 0, half = 0;
+        FinishArgs fin;
+    } lag_def;
     // set when a fused restart's test (Lanczos.h:156 on the corrected residual) failed or came within a factor of two of its bar:
     // the remaining sweeps of this solve apply their last correction before the restart, the reference's order (cleared by init)
     bool eager_sticky = false;
@@ -615,7 +626,7 @@ void apply_op(mispec_fac& F, const double* x_loc, double* y_loc, bool lanczos_ep
         if (lanczos_epi)
             launch_lanczos_epilogue(*F.ctx, y_loc, x_loc, v_prev, h_prev, F.nloc, F.alpha_partials.p);
     }
-    if (lanczos_epi)
+    if (lanczos_epi && !F.skip_alpha_reduce)  // (one-reduction steps: the partial sums travel with the record of the previous pass)
     {
         const int64_t nparts = F.A ? spmv_num_blocks(F.nloc) : lanczos_epilogue_records(*F.ctx, F.nloc);
         launch_reduce_sum(*F.ctx, F.alpha_partials.p, nparts, alpha_dev);
@@ -635,8 +646,10 @@ void reduce_record(mispec_fac& F, int nrec, int ncol, int which, const FinishArg
         FinishArgs none;
         none.mode = kFinishNone;
         none.packed = 1;
+        none.alpha_parts = fin.alpha_parts;  // one-reduction steps: this rank's <f~, A f~> is packed behind sum f^2
+        none.alpha_count = fin.alpha_count;
         launch_reduce_partials(*F.ctx, F.partials.p, F.pstride, nrec, ncol, F.red_stage(), none);
-        allreduce(F, F.red_stage(), ncol + 1);  // the sums: slots [0, ncol) and, packed behind them, sum f^2
+        allreduce(F, F.red_stage(), ncol + 1 + (fin.alpha_parts ? 1 : 0));  // the sums: slots [0, ncol) and, packed behind them, sum f^2
         FinishArgs tail = fin;
         tail.packed = 1;
         launch_finish(*F.ctx, F.red_stage(), red, ncol, tail);
@@ -1052,7 +1065,26 @@ void lanczos_step_lagged(mispec_fac& F, int i, bool last, bool defer)
     // On diagonal storage the SpMV takes the un-normalised f and divides its row sums instead (csr.hpp post_scale_state): the
     // scaling pass and its copy of f disappear.  Other formats: k_scale_step, as in the reference flow.
     const bool post = F.A && !F.A2 && !F.Chol && !F.perm_mode && spmv_can_post_scale(*F.A);  // the plain product operator only
-    if (post)
+    // One reduction per step: the previous step of this run left its record unreduced (F.lag_def).  The product does not wait for
+    // beta: u = A f~ with the partial sums of <f~, u>; then ONE reduction — that record and the sums — whose tail finishes step
+    // i - 1, takes this step's small-beta stop and forms alpha~; the pass below turns u into w = u / beta - beta v_{i-1} itself.
+    const bool onered = F.lag_def.have;
+    if (onered)
+    {
+        F.skip_alpha_reduce = true;
+        apply_op(F, F.f.p, F.w.p, true, nullptr, 0.0, nullptr, &st->status);
+        F.skip_alpha_reduce = false;
+        FinishArgs fin = F.lag_def.fin;
+        fin.alpha_parts = F.alpha_partials.p;
+        fin.alpha_count = spmv_num_blocks(F.nloc);
+        fin.alpha_out = F.alpha_slot();
+        {
+            Timed t(F, FAM_VTF);
+            reduce_record(F, F.lag_def.nrec, F.lag_def.ncol, F.lag_def.half, fin);
+        }
+        F.lag_def.have = false;
+    }
+    else if (post)
     {
         F.post_scale_step = i;
         apply_op(F, F.f.p, F.w.p, true, F.col(i - 1), 0.0, &st->subd[i - 1], &st->status);
@@ -1088,13 +1120,27 @@ void lanczos_step_lagged(mispec_fac& F, int i, bool last, bool defer)
         a.beta_dev = &st->beta;
         a.pending = &st->lag_pending;
         a.status = &st->status;
+        a.onered = onered ? 1 : 0;
         Timed t(F, FAM_VTF);
         F.count_bytes(FAM_VTF, i + 4);  // i columns, f and w read; column i and f written
         const int nrec = launch_orth(*F.ctx, ORTH_LAGGED, a);
         fin.mode = kFinishLagged;
         fin.alpha_src = F.alpha_slot();
         fin.prev_red = F.red_buf(cur ^ 1);
-        reduce_record(F, nrec, 2 * i + 1, cur, fin);
+        // the plain matrix product on bases of one column panel; the last step of a sweep is reduced at once (what follows — the
+        // reference's corrections or the restart — needs its record)
+        const bool defer_record = F.onered && !last && F.A && !F.A2 && !F.Chol && F.m <= kPanelCols;
+        if (defer_record)
+        {
+            F.lag_def.have = true;
+            F.lag_def.nrec = nrec;
+            F.lag_def.ncol = 2 * i + 1;
+            F.lag_def.half = cur;
+            F.lag_def.fin = fin;
+            F.red_cur = cur;
+        }
+        else
+            reduce_record(F, nrec, 2 * i + 1, cur, fin);
     }
     if (!last || defer)
         return;
@@ -1116,6 +1162,14 @@ void lanczos_step_lagged(mispec_fac& F, int i, bool last, bool defer)
 }
 
 // operators applied entirely by enqueued device work (apply_op never waits for the host)
+// MISPEC_ONE_REDUCTION = 1 | 0: the default of the one-reduction form of the lagged steps (mispec_fac_set_orth_mode's
+// MISPEC_ORTH_ONE_REDUCTION / MISPEC_ORTH_TWO_REDUCTIONS select it per factorisation)
+bool default_one_reduction()
+{
+    const char* e = getenv("MISPEC_ONE_REDUCTION");
+    return e ? atoi(e) != 0 : true;  // the default since round 5 (C2: 0.986 -> 0.939 s per solve, same counters; profiles/r09l)
+}
+
 bool device_operator(const mispec_fac& F) { return F.A != nullptr || (F.S != nullptr && F.Bcsr == nullptr) || F.D != nullptr || F.dop != nullptr; }
 
 // Lanczos.h:62-187
@@ -1160,6 +1214,7 @@ void factorize_lanczos(mispec_fac& F, int from_k, int to_m, int64_t* nmatop)
             }
             MISPEC_HIP(hipMemcpyAsync(F.d_state.p, &hs, sizeof(StepState), hipMemcpyHostToDevice, F.stream()));
         }
+        F.lag_def.have = false;
         for (int s = i; s <= to_m - 1; s++)
         {
             if (lagged)
@@ -1186,6 +1241,7 @@ void factorize_lanczos(mispec_fac& F, int from_k, int to_m, int64_t* nmatop)
         if (lagged)
         {
             F.lag_steps += hs.lag_steps;
+            F.onered_steps += hs.onered_steps;
             F.lag_rel_c_max = std::max(F.lag_rel_c_max, hs.lag_rel_c_max);
             F.lag_chk_max = std::max(F.lag_chk_max, hs.lag_chk_max);
         }
@@ -1697,6 +1753,7 @@ int fac_create_impl(mispec_ctx* ctx, const mispec_csr* A, const mispec_symshift*
                                "MISPEC_ORTH: expected reference, onesweep or onesweep-eager");
                 F->onesweep = mode != "reference";
                 F->eager_last = mode == "onesweep-eager";
+                F->onered = F->onesweep && default_one_reduction();
             }
             F->h_red.alloc(kPartialLd + 8);
             F->h_small.alloc(size_t(ncv) * ncv + 4 * size_t(ncv) + 8);
@@ -1888,12 +1945,19 @@ extern "C" int mispec_fac_set_orth_mode(mispec_fac* fac, int mode)
         const int base = mode & 0xff, flags = mode & ~0xff;
         MISPEC_REQUIRE((base == MISPEC_ORTH_REFERENCE && flags == 0) ||
                            (base == MISPEC_ORTH_ONESWEEP &&
-                            (flags & ~(MISPEC_ORTH_EAGER_LAST | MISPEC_ORTH_TEST_RECORRECT | MISPEC_ORTH_TEST_RESTART_CHECK)) == 0),
+                            (flags & ~(MISPEC_ORTH_EAGER_LAST | MISPEC_ORTH_TEST_RECORRECT | MISPEC_ORTH_TEST_RESTART_CHECK |
+                                       MISPEC_ORTH_ONE_REDUCTION | MISPEC_ORTH_TWO_REDUCTIONS)) == 0),
                        "mispec_fac_set_orth_mode: unknown mode");
         fac->onesweep = (base == MISPEC_ORTH_ONESWEEP);
         fac->eager_last = (flags & MISPEC_ORTH_EAGER_LAST) != 0;
         fac->test_recorrect = (flags & MISPEC_ORTH_TEST_RECORRECT) != 0;
         fac->test_restart_check = (flags & MISPEC_ORTH_TEST_RESTART_CHECK) != 0;
+        if (flags & MISPEC_ORTH_ONE_REDUCTION)
+            fac->onered = true;
+        else if (flags & MISPEC_ORTH_TWO_REDUCTIONS)
+            fac->onered = false;
+        else if (base == MISPEC_ORTH_ONESWEEP)
+            fac->onered = default_one_reduction();
     });
 }
 
@@ -1906,7 +1970,8 @@ extern "C" int mispec_fac_orth_info(const mispec_fac* fac, int* mode, int64_t* l
         if (mode)
             *mode = active ? (MISPEC_ORTH_ONESWEEP | ((fac->eager_last || fac->eager_sticky) ? MISPEC_ORTH_EAGER_LAST : 0) |
                               (fac->test_recorrect ? MISPEC_ORTH_TEST_RECORRECT : 0) |
-                              (fac->test_restart_check ? MISPEC_ORTH_TEST_RESTART_CHECK : 0))
+                              (fac->test_restart_check ? MISPEC_ORTH_TEST_RESTART_CHECK : 0) |
+                              (fac->onered ? MISPEC_ORTH_ONE_REDUCTION : 0))
                            : MISPEC_ORTH_REFERENCE;
         if (lagged_steps)
             *lagged_steps = fac->lag_steps;
@@ -1918,6 +1983,14 @@ extern "C" int mispec_fac_orth_info(const mispec_fac* fac, int* mode, int64_t* l
             *max_rel_c = fac->lag_rel_c_max;
         if (max_chk)
             *max_chk = fac->lag_chk_max;
+    });
+}
+
+extern "C" int mispec_fac_onered_steps(const mispec_fac* fac, int64_t* steps)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(fac && steps, "mispec_fac_onered_steps: NULL argument");
+        *steps = fac->onered_steps;
     });
 }
 

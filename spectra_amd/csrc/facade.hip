@@ -432,6 +432,10 @@ extern "C" int mispec_symeigs_orth_info(const mispec_symeigs* s, int* mode, int6
 {
     return s ? mispec_fac_orth_info(s->fac(), mode, lagged_steps, check_stops, state_stops, max_rel_c, max_chk) : MISPEC_EINVAL;
 }
+extern "C" int mispec_symeigs_onered_steps(const mispec_symeigs* s, int64_t* steps)
+{
+    return s ? mispec_fac_onered_steps(s->fac(), steps) : MISPEC_EINVAL;
+}
 extern "C" int mispec_symeigs_restart_info(const mispec_symeigs* s, int64_t* fused, int64_t* recorrected)
 {
     return s ? mispec_fac_restart_info(s->fac(), fused, recorrected) : MISPEC_EINVAL;

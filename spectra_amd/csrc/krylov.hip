@@ -237,13 +237,17 @@ __global__ __launch_bounds__(kThreads) void k_orth(OrthArgs a)
 // with the bits k_scale_step gave it.
 // NW wavefronts per workgroup: 4 (up to 63 finished columns) or 8 (64..127: bases of up to 128 columns, round 4 — the same
 // 16 columns per wavefront, twice the row sums through LDS).
-template <int MAXS, int R, int NW>
+// ONERED (one reduction per step, krylov.hpp FinishArgs::alpha_parts): src is u = A f~ on the UN-normalised residual; the pass
+// forms w = u / beta - beta v_{i-1} itself (Lanczos.h:106 and :139 applied after the product; column i-1 is among the columns the
+// pass reads: its owner wavefront hands the tile's entries to the others through LDS, next to the row sums).
+template <int MAXS, int R, int NW, bool ONERED = false>
 __global__ __launch_bounds__(64 * NW) void k_orth_lagged(OrthArgs a)
 {
     constexpr int kRows = kTileRows * R;
     constexpr int kCols = 16 * NW;
     __shared__ double cs[kCols];
     __shared__ __attribute__((aligned(16))) double psum[2][NW][kRows];
+    __shared__ __attribute__((aligned(16))) double vprev_s[ONERED ? 2 : 1][ONERED ? kRows : 2];
 
     if (a.status && *a.status != kStepOk)
         return;
@@ -315,7 +319,38 @@ __global__ __launch_bounds__(64 * NW) void k_orth_lagged(OrthArgs a)
             }
             *reinterpret_cast<double2*>(&psum[buf][w][q * kTileRows + 2 * lane]) = p;
         }
+        if (ONERED)
+        {
+            // column i-1 = slot (i-1) / NW of wavefront (i-1) % NW (a.ncol = i >= 1)
+            const int jp = a.ncol - 1;
+            if (w == jp % NW)
+            {
+#pragma unroll
+                for (int jj = 0; jj < MAXS; jj++)
+                    if (jj == jp / NW)
+                    {
+#pragma unroll
+                        for (int q = 0; q < R; q++)
+                            *reinterpret_cast<double2*>(&vprev_s[buf][q * kTileRows + 2 * lane]) = vv[jj][q];
+                    }
+            }
+        }
         __syncthreads();
+        if (ONERED)
+        {
+#pragma unroll
+            for (int q = 0; q < R; q++)
+            {
+                const double2 vp = *reinterpret_cast<const double2*>(&vprev_s[buf][q * kTileRows + 2 * lane]);
+                wv[q].x = wv[q].x / beta - beta * vp.x;
+                wv[q].y = wv[q].y / beta - beta * vp.y;
+                if (!valid[q])
+                {
+                    wv[q].x = 0.0;
+                    wv[q].y = 0.0;
+                }
+            }
+        }
         double2 vi[R], fn[R];
 #pragma unroll
         for (int q = 0; q < R; q++)
@@ -483,6 +518,26 @@ __device__ void finish_lagged(double* red, const FinishArgs& fa)
         st->stop_step = i;
         st->stop_count = 0;
     }
+}
+
+// One reduction per step: after the bookkeeping of step i the same thread starts step i + 1 — its beta < sqrt(eps) stop
+// (Lanczos.h:107; the restart heuristics need a finished f: host) and alpha~ = <f~, A f~> / beta^2 - <f~, v_i> from the sum s1 that
+// travelled with the record (oracle/onesweep_variant.hpp, one_reduction).
+__device__ void start_next_onered(const double* red, const FinishArgs& fa, double s1)
+{
+    StepState* st = fa.st;
+    if (st->status != kStepOk)
+        return;
+    const double beta = st->beta;
+    if (beta < fa.eps_sqrt)
+    {
+        st->status = kStepSmallBeta;
+        st->stop_step = fa.step + 1;
+        st->stop_count = 0;
+        return;
+    }
+    *fa.alpha_out = s1 / (beta * beta) - red[fa.step];
+    st->onered_steps++;
 }
 
 // Executed by ONE thread after the reduction of a k_vq_fused record (krylov.hpp VqFusedArgs): what mispec_fac_restart_sym used to
@@ -676,12 +731,45 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restri
         slot[0] = (g == 0) ? kSlotBeta2 : (g == 1 ? kSlotMaxAbs : -1);
         reduce_slots<1>(partials, pstride, nrec, slot, lane, sh);
     }
+    __shared__ double sh_a[16];
+    if (fin.alpha_parts)
+    {
+        // k_reduce_sum's order: thread t adds in[t], in[t + 1024], ... ; wave sums; the 16 wave sums one after the other
+        constexpr int kBatch = 40;
+        double v = 0.0;
+        for (int64_t base = tid; base < fin.alpha_count; base += int64_t(kBatch) * 1024)
+        {
+            double x[kBatch];
+#pragma unroll
+            for (int k = 0; k < kBatch; k++)
+            {
+                const int64_t i = base + int64_t(k) * 1024;
+                x[k] = (i < fin.alpha_count) ? fin.alpha_parts[i] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < kBatch; k++)
+                v += x[k];
+        }
+        v = wave_reduce_sum(v);
+        if (lane == 0)
+            sh_a[g] = v;
+    }
     __syncthreads();
     if (tid == 0)
     {
+        double s1 = 0.0;
+        if (fin.alpha_parts)
+            for (int k = 0; k < 16; k++)
+                s1 += sh_a[k];
         if (fin.packed)
+        {
             sh[ncol] = sh[kSlotBeta2];
+            if (fin.alpha_parts)
+                sh[ncol + 1] = s1;  // sharded: the local sum travels behind sum f^2
+        }
         finish_record(sh, ncol, fin);
+        if (fin.alpha_parts && !fin.packed && fin.mode == kFinishLagged)
+            start_next_onered(sh, fin, s1);
     }
     __syncthreads();
     for (int t = tid; t < kPartialLd; t += 1024)
@@ -698,13 +786,21 @@ __global__ __launch_bounds__(256) void k_finish(const double* __restrict__ stage
     __syncthreads();
     if (threadIdx.x == 0)
     {
+        double s1 = 0.0;
         if (fin.packed)
         {
             red[kSlotBeta2] = stage[ncol];
             if (ncol != kSlotBeta2)
                 red[ncol] = 0.0;
+            if (fin.alpha_parts)
+            {
+                s1 = stage[ncol + 1];
+                red[ncol + 1] = 0.0;
+            }
         }
         finish_record(red, ncol, fin);
+        if (fin.alpha_parts && fin.mode == kFinishLagged)
+            start_next_onered(red, fin, s1);
     }
 }
 
@@ -1304,6 +1400,7 @@ void launch_orth_lagged(const mispec_ctx& ctx, const OrthArgs& a, int grid)
     const dim3 g(static_cast<unsigned>(grid));
     if (a.ncol >= kPanelCols)  // 64..127 finished columns: eight wavefronts of 16 columns
     {
+        MISPEC_REQUIRE(!a.onered, "one-reduction steps: bases of up to 64 columns");
         const dim3 b8(512);
         switch ((a.ncol + 7) / 8)
         {
@@ -1333,7 +1430,11 @@ void launch_orth_lagged(const mispec_ctx& ctx, const OrthArgs& a, int grid)
     {
 #define MISPEC_LAG_CASE(S)                                                  \
     case S:                                                                 \
-        if (two)                                                            \
+        if (a.onered && two)                                                \
+            hipLaunchKernelGGL((k_orth_lagged<S, 2, 4, true>), g, b, 0, ctx.stream, a); \
+        else if (a.onered)                                                  \
+            hipLaunchKernelGGL((k_orth_lagged<S, 1, 4, true>), g, b, 0, ctx.stream, a); \
+        else if (two)                                                       \
             hipLaunchKernelGGL((k_orth_lagged<S, 2, 4>), g, b, 0, ctx.stream, a); \
         else                                                                \
             hipLaunchKernelGGL((k_orth_lagged<S, 1, 4>), g, b, 0, ctx.stream, a); \
@@ -1355,7 +1456,10 @@ void launch_orth_lagged(const mispec_ctx& ctx, const OrthArgs& a, int grid)
             MISPEC_LAG_CASE(14)
             MISPEC_LAG_CASE(15)
         default:
-            hipLaunchKernelGGL((k_orth_lagged<16, 1, 4>), g, b, 0, ctx.stream, a);
+            if (a.onered)
+                hipLaunchKernelGGL((k_orth_lagged<16, 1, 4, true>), g, b, 0, ctx.stream, a);
+            else
+                hipLaunchKernelGGL((k_orth_lagged<16, 1, 4>), g, b, 0, ctx.stream, a);
             break;
 #undef MISPEC_LAG_CASE
     }

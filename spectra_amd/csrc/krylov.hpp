@@ -52,6 +52,7 @@ struct StepState
     // measured (Lanczos.h:156), read by the host at the end of the sweep that follows
     double rst_err;
     double rst_beta_corr;
+    int64_t onered_steps;  // lagged steps that took the one-reduction form
 };
 enum
 {
@@ -93,6 +94,14 @@ struct FinishArgs
     // Sharded runs: the sums travel as ONE contiguous message [0, ncol] — the reduction also stores sum f^2 in slot `ncol` of the
     // staging record, the finish step takes it from there (a record is (2 ncv) doubles on the wire, not kSlotBeta2 + 1 = 1025)
     int packed = 0;
+    // One reduction per step (kFinishLagged, fac.hip lanczos_step_lagged with F.onered; CPU restatement: oracle/onesweep_variant.hpp,
+    // flavour one-reduction): the operator was applied to the UN-normalised residual of this record's pass, u = A f~, and the
+    // partial sums of <f~, u> are reduced by the same kernel (sharded: travel in the same message, behind sum f^2); after the
+    // bookkeeping of the step the tail forms alpha~ = <f~, u> / beta^2 - <f~, v_i> for the step that follows (-> alpha_out) and
+    // takes that step's beta < sqrt(eps) stop (Lanczos.h:107, what k_scale_step / the post-scaled SpMV do otherwise).
+    const double* alpha_parts = nullptr;
+    int64_t alpha_count = 0;
+    double* alpha_out = nullptr;
 };
 
 struct OrthArgs
@@ -117,6 +126,8 @@ struct OrthArgs
     double* vout = nullptr;
     const double* beta_dev = nullptr;
     const int* pending = nullptr;
+    // one reduction per step: src = u = A f~ (un-normalised); the pass forms w = u / beta - beta V[:, ncol - 1] on the fly
+    int onered = 0;
 };
 
 // All launchers enqueue on ctx.stream and return immediately.

@@ -17,6 +17,15 @@ pytestmark = pytest.mark.gpu
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "symeigs_golden.npz"))
 
 
+@pytest.fixture(params=["one-reduction", "two-reductions"], autouse=True)
+def reductions(request, monkeypatch):
+    """Every test of this module runs with both forms of the lagged step: ONE reduction per step (the default since round 5:
+    the product on the un-normalised residual, its <f~, A f~> reduced with the record of the previous pass — include/mispec.h
+    MISPEC_ORTH_ONE_REDUCTION) and the two-reduction form of round 4 (MISPEC_ONE_REDUCTION=0)."""
+    monkeypatch.setenv("MISPEC_ONE_REDUCTION", "1" if request.param == "one-reduction" else "0")
+    return request.param
+
+
 def solve(op, k, m, rule, mode, ctx=None, **kw):
     eigs = sa.SymEigsSolver(op, k, m) if ctx is None else sa.SymEigsSolver(op, k, m, ctx=ctx)
     eigs.set_orth_mode(mode)
@@ -95,6 +104,27 @@ def test_onesweep_on_the_benchmark_matrix(ctx, n):
     # run-to-run reproducibility (fixed-order reductions)
     again, _ = solve(op, k, m, sa.SortRule.LargestMagn, "onesweep", maxit=1000, tol=1e-11)
     assert np.array_equal(again.eigenvalues(), one.eigenvalues()) and again.num_operations() == one.num_operations()
+
+
+def test_the_one_reduction_form_is_the_one_that_runs(ctx, reductions):
+    # plain matrix operator, ncv <= 64: every lagged step but the first of a device run takes the one-reduction form; the flags of
+    # mispec_fac_set_orth_mode override the default either way
+    n, k, m = 200_000, 20, 40
+    op = sa.SparseSymMatProd.synth_band(n, ctx=ctx)
+    default, _ = solve(op, k, m, sa.SortRule.LargestMagn, "onesweep", maxit=1000, tol=1e-11)
+    one, _ = solve(op, k, m, sa.SortRule.LargestMagn, "onesweep-onered", maxit=1000, tol=1e-11)
+    two, _ = solve(op, k, m, sa.SortRule.LargestMagn, "onesweep-twored", maxit=1000, tol=1e-11)
+    di, oi, ti = default.orth_info(), one.orth_info(), two.orth_info()
+    assert oi["one_reduction"] and not ti["one_reduction"] and di["one_reduction"] == (reductions == "one-reduction")
+    assert ti["one_reduction_steps"] == 0 and oi["one_reduction_steps"] >= 0.85 * oi["lagged_steps"] > 0
+    assert di["one_reduction_steps"] == (oi["one_reduction_steps"] if reductions == "one-reduction" else 0)
+    # same solve to rounding: equal counters, eigenvalues to 1e-13
+    assert one.num_operations() == two.num_operations() and one.num_iterations() == two.num_iterations()
+    assert np.abs(one.eigenvalues() - two.eigenvalues()).max() <= 1e-13 * np.abs(two.eigenvalues()).max()
+    assert one.residuals().max() <= 1e-10
+    # wide bases (64 < ncv <= 128) and operators other than the plain product keep two reductions
+    wide, _ = solve(op, 30, 80, sa.SortRule.LargestAlge, "onesweep-onered", maxit=1000, tol=1e-10)
+    assert wide.orth_info()["lagged_steps"] > 0 and wide.orth_info()["one_reduction_steps"] == 0
 
 
 def test_onesweep_is_ignored_where_it_does_not_apply(ctx):

@@ -15,14 +15,16 @@ from spectra_amd import _capi
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["onesweep", "reference"], autouse=True)
+@pytest.fixture(params=["onesweep", "onesweep-two-reductions", "reference"], autouse=True)
 def orth_env(request, monkeypatch):
-    """Every test of this module runs under both defaults of the orthogonalisation scheme (MISPEC_ORTH: the library default
-    `onesweep` and the reference's two-pass control flow); solvers that set a mode themselves are run once."""
+    """Every test of this module runs under the defaults of the orthogonalisation scheme (MISPEC_ORTH: the library default
+    `onesweep` — one all-reduce per lagged step since round 5 —, the same steps with the separate alpha reduction of round 4,
+    MISPEC_ONE_REDUCTION=0, and the reference's two-pass control flow); solvers that set a mode themselves are run once."""
     params = getattr(getattr(request.node, "callspec", None), "params", {})
-    if "orth" in params and request.param == "reference":
+    if "orth" in params and request.param != "onesweep":
         pytest.skip("this test selects its modes itself")
-    monkeypatch.setenv("MISPEC_ORTH", request.param)
+    monkeypatch.setenv("MISPEC_ORTH", "reference" if request.param == "reference" else "onesweep")
+    monkeypatch.setenv("MISPEC_ONE_REDUCTION", "0" if request.param == "onesweep-two-reductions" else "1")
     return request.param
 
 
