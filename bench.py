@@ -179,7 +179,7 @@ def pmc_traffic(n, fmt, post_scaled=False):
     return None, None
 
 
-def live_pmc_traffic(n, fmt, post_scaled, timeout=240):
+def live_pmc_traffic(n, fmt, post_scaled, timeout=240, modes=None):
     """HBM bytes per launch of the fused SpMV measured IN THIS RUN: two rocprofv3 passes (FETCH_SIZE, then WRITE_SIZE — separate
     runs with --kernel-trace only, as MI355X_MICROARCH.md prescribes) of tools/pmc_probe.py (the same matrix, the same
     instantiations, one factorisation sweep + restart per flow) in child processes, FETCH_SIZE calibrated on the probe's k_scale
@@ -201,6 +201,8 @@ def live_pmc_traffic(n, fmt, post_scaled, timeout=240):
         return None, "this run is itself profiled (" + ", ".join(under or ["LD_PRELOAD"]) + "): the live passes are skipped"
     tmp = tempfile.mkdtemp(prefix="mispec_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp", PROBE_N=str(n), PROBE_FORMATS=str(fmt), PROBE_SPMV_REPS="0")
+    if modes:
+        env["PROBE_MODES"] = modes
     files = {}
     t0 = time.time()
     try:
@@ -236,10 +238,12 @@ def live_pmc_traffic(n, fmt, post_scaled, timeout=240):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def spmv_block(op, ms, launches, fused):
-    """Roofline figures of one SpMV instantiation on the bytes it has to move."""
+def spmv_block(op, ms, launches, fused, epi_vectors=2.0):
+    """Roofline figures of one SpMV instantiation on the bytes it has to move.  epi_vectors: vectors the fused Lanczos epilogue reads
+    on top of the product's own x and y — 2 in the reference flow and the two-reduction one-sweep steps (v_prev and v), 1 in the
+    one-reduction steps (only the <f~, A f~> operand: nothing is subtracted in the kernel), a mean over the launches of a solve."""
     fmt = op.spmv_format()
-    moved = op.stored_bytes() + (16.0 * op.local_rows() if fused else 0.0)
+    moved = op.stored_bytes() + (8.0 * epi_vectors * op.local_rows() if fused else 0.0)
     gbps = moved / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     return {"kernel": KERNEL_OF_FORMAT[fmt], "ms_per_launch": ms, "launches": int(launches), "bytes_per_launch": moved,
             "achieved": gbps, "frac": gbps / HBM_PEAK_GBPS,
@@ -284,7 +288,9 @@ def in_loop_block(sa, ctx, rop, nev, ncv, rule, tol, restarts=12):
     blk = {"kernel": KERNEL_OF_FORMAT[rop.spmv_format()], "spmv_format": rop.spmv_format(), "ms_per_launch": ms, "launches": int(n_spmv),
            "bytes_per_launch": alg, "achieved": alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
            "bytes_note": "algorithmic: 12 nnz + 4 (rows + 1) + 8 cols + 8 rows (SURVEY.md 8d)",
-           "frac_with_epilogue_operands": (alg + 16.0 * rop.local_rows()) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if ms > 0 else 0.0,
+           "frac_with_epilogue_operands": (alg + 8.0 * (2.0 - (e.orth_info()["one_reduction_steps"] / max(e.orth_info()["lagged_steps"], 1)
+                                                                if e.orth_info().get("one_reduction") else 0.0)) * rop.local_rows())
+                                          / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if ms > 0 else 0.0,
            "solve": {"seconds": dt, "restarts": restarts, "nconv": int(nconv), "num_operations": int(e.num_operations())}}
     blk["frac"] = blk["achieved"] / HBM_PEAK_GBPS
     del e
@@ -321,7 +327,10 @@ def secondary_configs(args, ctx, op, sa):
                 secs = time.perf_counter() - t0
             p1 = e.get_profile()
             n_spmv = p1["n_spmv"] - p0["n_spmv"]
-            blk = spmv_block(op, (p1["ms_spmv"] - p0["ms_spmv"]) / max(n_spmv, 1), n_spmv, True)
+            oi = e.orth_info()
+            ev_mean = 2.0 - (oi["one_reduction_steps"] / max(oi["lagged_steps"], 1) if oi.get("one_reduction") else 0.0)
+            blk = spmv_block(op, (p1["ms_spmv"] - p0["ms_spmv"]) / max(n_spmv, 1), n_spmv, True, ev_mean)
+            blk["epilogue_vectors_mean"] = ev_mean
             blk["traffic"], blk["traffic_source"] = pmc_traffic(args.n, fmt)
             blk.update({"nconv": int(nconv), "num_operations": int(e.num_operations()), "seconds": secs,
                         "eigenpairs_per_s": nconv / secs, "orth": args.orth})
@@ -381,7 +390,9 @@ def secondary_configs(args, ctx, op, sa):
     ctx.sync()
     dt = time.perf_counter() - t0
     p = e.get_profile()
-    inloop = spmv_block(rop, p["ms_spmv"] / max(p["n_spmv"], 1), p["n_spmv"], True)
+    oi = e.orth_info()
+    ev_mean = 2.0 - (oi["one_reduction_steps"] / max(oi["lagged_steps"], 1) if oi.get("one_reduction") else 0.0)
+    inloop = spmv_block(rop, p["ms_spmv"] / max(p["n_spmv"], 1), p["n_spmv"], True, ev_mean)
     rop.set_spmv_format(0)
     csr_alone = spmv_block(rop, standalone_ms(rop, args.n, 10), 10, False)
     rop.set_spmv_format(-1)
@@ -389,13 +400,13 @@ def secondary_configs(args, ctx, op, sa):
     # epilogue's two vector reads in the loop) whatever format ran, so that they stay comparable across rounds and formats: the
     # staged format (4) moves about 2.2 x those bytes by design — its rate on its own traffic is reported next to it.
     standalone = spmv_block(rop, alone, 20, False)
-    for blk, extra in ((inloop, 16.0 * rop.local_rows()), (standalone, 0.0)):
+    for blk, extra in ((inloop, 8.0 * ev_mean * rop.local_rows()), (standalone, 0.0)):
         alg = rop.algorithmic_bytes() + extra
         ms = blk["ms_per_launch"]
         blk.update({"moved_bytes_per_launch": blk["bytes_per_launch"], "achieved_on_moved_bytes": blk["achieved"], "frac_on_moved_bytes": blk["frac"],
                     "bytes_per_launch": alg, "achieved": alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0})
         blk["frac"] = blk["achieved"] / HBM_PEAK_GBPS
-        blk["bytes_note"] = "algorithmic: 12 nnz + 4 (rows + 1) + 8 cols + 8 rows" + (" + 16 rows (fused epilogue)" if extra else "")
+        blk["bytes_note"] = "algorithmic: 12 nnz + 4 (rows + 1) + 8 cols + 8 rows" + (f" + 8 rows x {ev_mean:.2f} (fused epilogue's operands)" if extra else "")
     out["m_rand"] = {"n": args.n, "nnz": rop.nnz(), "spmv_format": rop.spmv_format(), "reordering": rop.reordering(), "tiles": rop.tiles_info(),
                      "staged": rop.staged_info(),
                      "standalone": standalone, "in_loop": inloop, "standalone_csr_int32_kernel": csr_alone,
@@ -653,7 +664,10 @@ def main():
     evals = eigs.eigenvalues()
     spmv_ms = prof["ms_spmv"] / max(prof["n_spmv"], 1)
     fmt = op.spmv_format()
-    head = spmv_block(op, spmv_ms, prof["n_spmv"], True)
+    oinfo = eigs.orth_info()
+    onered_frac = oinfo["one_reduction_steps"] / max(oinfo["lagged_steps"], 1) if oinfo.get("one_reduction") else 0.0
+    epi_vectors = 2.0 - onered_frac  # one-reduction steps read one epilogue operand (f~ for <f~, A f~>), the others v_prev and v
+    head = spmv_block(op, spmv_ms, prof["n_spmv"], True, epi_vectors)
     alone_ms = standalone_ms(op, args.n if world == 1 else int(sa.lib().mispec_shard_block(args.n, world)) * world, args.spmv_reps)
 
     transport_name = {"gloo-staged": "gloo (host-staged)", "torch": "torch.distributed (RCCL)"}.get(os.environ.get("MISPEC_COMM", "rccl"), "RCCL")
@@ -667,10 +681,15 @@ def main():
     else:
         exchange_desc = f", {transport_name} all-gather of the Krylov vector per SpMV" + (f" ({exchange_note})" if exchange_note else "")
     if rank == 0:
-        traffic, traffic_file = pmc_traffic(args.n, fmt, post_scaled=args.orth.startswith("onesweep")) if world == 1 else (None, None)
+        # the instantiation most launches of a solve use: one-reduction steps run the plain fused kernel (no post-scaling), the
+        # two-reduction one-sweep steps on diagonal storage the post-scaled one
+        post_inst = args.orth.startswith("onesweep") and onered_frac < 0.5
+        traffic, traffic_file = pmc_traffic(args.n, fmt, post_scaled=post_inst) if world == 1 else (None, None)
+        if args.orth.startswith("onesweep") and not post_inst and traffic_file and not traffic_file.startswith("r09"):
+            traffic, traffic_file = None, None  # (summaries of earlier rounds mix this instantiation's reference-flow launches in)
         traffic_committed, live_note = traffic, "not attempted (--no-live-pmc or more than one rank)"
         if world == 1 and not args.no_live_pmc:
-            live, live_note = live_pmc_traffic(args.n, fmt, args.orth.startswith("onesweep"))
+            live, live_note = live_pmc_traffic(args.n, fmt, post_inst, modes=args.orth.replace("-eager", ""))
             if live is not None:
                 traffic, traffic_file = live, None
         out = {
@@ -708,7 +727,10 @@ def main():
                                  "at ~55 GB/s PCIe and is not part of `value`)"),
             },
             "roofline": {
-                "kernel": head["kernel"] + " (SpMV fused with w -= beta*v_prev and the alpha dot" + ("; one-sweep steps: input f, row sums divided by beta" if args.orth.startswith("onesweep") else "") + ")",
+                "kernel": head["kernel"] + (" (one-reduction steps: u = A f~ fused with the partial sums of <f~, u>; w = u/beta - beta*v_prev is formed by the "
+                                            "orthogonalisation pass)" if onered_frac >= 0.5 else
+                                            " (SpMV fused with w -= beta*v_prev and the alpha dot" +
+                                            ("; one-sweep steps: input f, row sums divided by beta" if args.orth.startswith("onesweep") else "") + ")"),
                 "bound": "hbm",
                 "achieved": head["achieved"],
                 "peak": HBM_PEAK_GBPS,
@@ -720,10 +742,12 @@ def main():
                                    if traffic_file or traffic is None else live_note),
                 "traffic_committed": traffic_committed,
                 "bytes_per_launch": head["bytes_per_launch"],
-                "bytes_note": {0: "CSR int32: 12 nnz + 4 (rows+1) + 8 cols + 8 rows (SURVEY.md 8d) + 16 rows for the fused epilogue's v_prev / v reads",
-                               1: "offset-coded CSR: 9 nnz + 4 (rows+1) + 8 cols + 8 rows + 16 rows for the fused epilogue's v_prev / v reads",
-                               2: "diagonal storage: 8 ndia rows + 8 cols + 8 rows + 16 rows for the fused epilogue's v_prev / v reads — "
-                                  "the bytes this kernel has to move, not the CSR figure"}[fmt],
+                "bytes_note": {0: "CSR int32: 12 nnz + 4 (rows+1) + 8 cols + 8 rows (SURVEY.md 8d)",
+                               1: "offset-coded CSR: 9 nnz + 4 (rows+1) + 8 cols + 8 rows",
+                               2: "diagonal storage: 8 ndia rows + 8 cols + 8 rows — the bytes this kernel has to move, not the CSR figure"}[fmt] +
+                              f" + 8 rows x {epi_vectors:.2f} epilogue operands (mean over the launches: one-reduction steps read one vector, "
+                              "the other steps v_prev and v)",
+                "epilogue_vectors_mean": epi_vectors,
                 "index_format": {0: "CSR, int32 column indices",
                                  1: f"CSR, offset codes: 1 byte per entry into {op.offset_codes()} diagonals",
                                  2: f"diagonal storage: {op.offset_codes()} diagonals, no index, no gather"}[fmt],

@@ -32,7 +32,10 @@ for fmt in [int(f) for f in os.environ.get("PROBE_FORMATS", "2,1,0").split(",")]
     ctx.sync()
     # the reference flow (k_scale_step — the calibration kernel —, fused SpMV, RESID_VTF, CORRECT_VTF), then the one-sweep steps
     # (post-scaled SpMV on diagonal storage, k_orth_lagged)
-    for mode in ("reference", "onesweep"):
+    # PROBE_MODES=onesweep: only that flow (the fused SpMV instantiation <EPI, NG, NCW, false> is launched by the reference flow
+    # — with the v_prev operand — AND by the one-reduction steps of the one-sweep flow — without it: one flow per pass keeps
+    # the per-kernel traffic unmixed)
+    for mode in os.environ.get("PROBE_MODES", "reference,onesweep").split(","):
         fac = sa.Factorization(op, 40, True)
         fac.set_orth_mode(mode)
         fac.init_random(0)
