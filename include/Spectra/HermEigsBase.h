@@ -292,6 +292,13 @@ public:
     {
         internal::check(mispec_fac_set_orth_mode(m_fac.handle(), on ? MISPEC_ORTH_ONESWEEP : MISPEC_ORTH_REFERENCE));
     }
+    // ... with ONE global reduction per step (the default; include/mispec.h MISPEC_ORTH_ONE_REDUCTION) or with the separate
+    // reduction of alpha = <v, w> before the pass over V (also: MISPEC_ONE_REDUCTION=0 in the environment).  Call before init().
+    void set_onesweep_orthogonalization(bool on, bool one_reduction)
+    {
+        const int flags = one_reduction ? MISPEC_ORTH_ONE_REDUCTION : MISPEC_ORTH_TWO_REDUCTIONS;
+        internal::check(mispec_fac_set_orth_mode(m_fac.handle(), on ? (MISPEC_ORTH_ONESWEEP | flags) : MISPEC_ORTH_REFERENCE));
+    }
 
 private:
     // The Ritz vectors of H belonging to the converged wanted values, as columns (reference :455-465)
