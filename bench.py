@@ -516,6 +516,11 @@ def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(respawn_as_ranks(args))
+    # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner when a communicator
+    # is created): everything this process and its libraries print goes to stderr, the line itself to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -671,6 +676,8 @@ def main():
     alone_ms = standalone_ms(op, args.n if world == 1 else int(sa.lib().mispec_shard_block(args.n, world)) * world, args.spmv_reps)
 
     transport_name = {"gloo-staged": "gloo (host-staged)", "torch": "torch.distributed (RCCL)"}.get(os.environ.get("MISPEC_COMM", "rccl"), "RCCL")
+    if type(getattr(ctx, "_comm", None)).__name__ == "TorchComm":  # (also the fallback when the library's own communicator failed)
+        transport_name = "torch.distributed (RCCL)"
     if world == 1:
         exchange_desc = ""
     elif halo:
@@ -844,7 +851,8 @@ def main():
                             "csr_kernel_frac above is on SURVEY.md 8d's bytes alone"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, int(eigs.num_operations()), int(total_pairs // args.steps), int(eigs.num_iterations()))
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if using_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -201,9 +201,36 @@ def make_context(device=None, transport=None):
     else:
         ctx = Context(device)
         if world > 1 or force:
-            payload = [Context.rccl_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(payload, src=0)
-            ctx.set_comm_rccl(rank, world, payload[0])
+            # The library's own RCCL communicator (dlopen'd librccl, unique id from rank 0).  It has never met more than one rank
+            # inside a build round (1-GPU leases): should its creation fail on ANY rank — every rank learns it through a MIN
+            # all-reduce on the process group — all ranks fall back to torch.distributed's collectives (TorchComm) instead of
+            # aborting the run.  MISPEC_COMM=rccl-strict keeps the failure fatal.
+            ok = 1
+            err = None
+            try:
+                payload = [Context.rccl_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(payload, src=0)
+                ctx.set_comm_rccl(rank, world, payload[0])
+            except Exception as e:  # noqa: BLE001
+                ok, err = 0, e
+            if transport == "rccl-strict":
+                if err is not None:
+                    raise err
+                return ctx
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                import sys
+
+                if rank == 0:
+                    print("spectra_amd.dist: the library's RCCL communicator could not be created (%r on this rank); "
+                          "falling back to torch.distributed collectives" % (err,), file=sys.stderr)
+                del ctx
+                stream = torch.cuda.Stream(device=device)
+                ctx = Context(device, stream=stream.cuda_stream)
+                comm = TorchComm(stream=stream)
+                ctx.set_comm_callbacks(rank, world, comm._allgather_ptr, comm._allreduce_ptr)
+                ctx._comm = comm
     return ctx
 
 
