@@ -140,14 +140,21 @@ def cpu_baseline(args, gpu_nops, gpu_nconv, gpu_niter):
     return out
 
 
-KERNEL_OF_FORMAT = {0: "k_spmv_csr_win (int32 CSR, x windows in LDS) / k_spmv_csr_stream<EPI, NT, 256, CODES=false> (gathers)", 1: "k_spmv_csr_stream<EPI, NT, 256, CODES=true>", 2: "k_spmv_dia_win / k_spmv_dia",
+KERNEL_OF_FORMAT = {0: "k_spmv_csr_win (int32 CSR, x windows in LDS) / k_spmv_csr_stream<EPI, NT, 256, CODES=false> (gathers)", 1: "k_spmv_csr_stream<EPI, NT, 256, CODES=true>", 2: "k_spmv_dia_win2 (two rows per thread, 16-byte loads) / k_spmv_dia_win / k_spmv_dia",
                     3: "k_spmv_tiles (column-blocked tiles, segment sums in LDS)",
                     4: "k_staged_products + k_staged_rows (two streaming phases, x and y in LDS)"}
 
 
-def fused_spmv_bytes(kernels, fmt, post_scaled):
+def fused_spmv_bytes(kernels, fmt, post_scaled, windows=True):
     """The fused SpMV instantiation of a PMC summary's kernel table (tools/pmc_summarize.py): 0 int32 indices, 1 offset codes,
-    2 diagonal storage; post_scaled: the one-sweep steps' instantiation k_spmv_dia_win<true, NG, NCW, true>."""
+    2 diagonal storage; post_scaled: the one-sweep steps' instantiation k_spmv_dia_win<true, NG, NCW, true>; windows: format 0 runs
+    k_spmv_csr_win<EPI, ITERS, XI, PF, NT> (x windows in LDS, the default since round 5) rather than the gather kernel."""
+    if fmt == 0 and windows:
+        for name, rec in kernels.items():
+            args_ = [a.strip() for a in name.split("<", 1)[1].rstrip(">").split(",")] if "<" in name else []
+            if name.startswith("k_spmv_csr_win<true") and len(args_) == 5 and args_[4] == "false":
+                return float(rec["hbm_bytes"])
+        return None
     for name, rec in kernels.items():
         args_ = [a.strip() for a in name.split("<", 1)[1].rstrip(">").split(",")] if "<" in name else []
         if fmt == 2 and name.startswith("k_spmv_dia") and args_ and args_[0] == "true":
@@ -239,11 +246,14 @@ def live_pmc_traffic(n, fmt, post_scaled, timeout=240, modes=None):
 
 
 def spmv_block(op, ms, launches, fused, epi_vectors=2.0):
-    """Roofline figures of one SpMV instantiation on the bytes it has to move.  epi_vectors: vectors the fused Lanczos epilogue reads
-    on top of the product's own x and y — 2 in the reference flow and the two-reduction one-sweep steps (v_prev and v), 1 in the
-    one-reduction steps (only the <f~, A f~> operand: nothing is subtracted in the kernel), a mean over the launches of a solve."""
+    """Roofline figures of one SpMV instantiation on the bytes it has to move.  epi_vectors: operands of the fused Lanczos epilogue —
+    2 in the reference flow and the two-reduction one-sweep steps (v_prev and v), 1 in the one-reduction steps (only the operand of
+    <f~, A f~>: nothing is subtracted in the kernel), a mean over the launches of a solve.  The operand v IS the product's input
+    vector (already counted as x), so only v_prev adds bytes: 8 rows x (epi_vectors - 1).  (Rounds 1-4 added 16 rows, counting v
+    twice; the PMC traffic of the one-reduction product on diagonal storage is 1.383 GB against 1.36 + 0.007 GB counted this way,
+    profiles/r09v_pmc_traffic.json.)"""
     fmt = op.spmv_format()
-    moved = op.stored_bytes() + (8.0 * epi_vectors * op.local_rows() if fused else 0.0)
+    moved = op.stored_bytes() + (8.0 * max(epi_vectors - 1.0, 0.0) * op.local_rows() if fused else 0.0)
     gbps = moved / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     return {"kernel": KERNEL_OF_FORMAT[fmt], "ms_per_launch": ms, "launches": int(launches), "bytes_per_launch": moved,
             "achieved": gbps, "frac": gbps / HBM_PEAK_GBPS,
@@ -288,7 +298,7 @@ def in_loop_block(sa, ctx, rop, nev, ncv, rule, tol, restarts=12):
     blk = {"kernel": KERNEL_OF_FORMAT[rop.spmv_format()], "spmv_format": rop.spmv_format(), "ms_per_launch": ms, "launches": int(n_spmv),
            "bytes_per_launch": alg, "achieved": alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
            "bytes_note": "algorithmic: 12 nnz + 4 (rows + 1) + 8 cols + 8 rows (SURVEY.md 8d)",
-           "frac_with_epilogue_operands": (alg + 8.0 * (2.0 - (e.orth_info()["one_reduction_steps"] / max(e.orth_info()["lagged_steps"], 1)
+           "frac_with_epilogue_operands": (alg + 8.0 * (1.0 - (e.orth_info()["one_reduction_steps"] / max(e.orth_info()["lagged_steps"], 1)
                                                                 if e.orth_info().get("one_reduction") else 0.0)) * rop.local_rows())
                                           / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if ms > 0 else 0.0,
            "solve": {"seconds": dt, "restarts": restarts, "nconv": int(nconv), "num_operations": int(e.num_operations())}}
@@ -400,13 +410,13 @@ def secondary_configs(args, ctx, op, sa):
     # epilogue's two vector reads in the loop) whatever format ran, so that they stay comparable across rounds and formats: the
     # staged format (4) moves about 2.2 x those bytes by design — its rate on its own traffic is reported next to it.
     standalone = spmv_block(rop, alone, 20, False)
-    for blk, extra in ((inloop, 8.0 * ev_mean * rop.local_rows()), (standalone, 0.0)):
+    for blk, extra in ((inloop, 8.0 * max(ev_mean - 1.0, 0.0) * rop.local_rows()), (standalone, 0.0)):
         alg = rop.algorithmic_bytes() + extra
         ms = blk["ms_per_launch"]
         blk.update({"moved_bytes_per_launch": blk["bytes_per_launch"], "achieved_on_moved_bytes": blk["achieved"], "frac_on_moved_bytes": blk["frac"],
                     "bytes_per_launch": alg, "achieved": alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0})
         blk["frac"] = blk["achieved"] / HBM_PEAK_GBPS
-        blk["bytes_note"] = "algorithmic: 12 nnz + 4 (rows + 1) + 8 cols + 8 rows" + (f" + 8 rows x {ev_mean:.2f} (fused epilogue's operands)" if extra else "")
+        blk["bytes_note"] = "algorithmic: 12 nnz + 4 (rows + 1) + 8 cols + 8 rows" + (f" + 8 rows x {max(ev_mean - 1.0, 0.0):.2f} (v_prev of the two-reduction steps)" if extra else "")
     out["m_rand"] = {"n": args.n, "nnz": rop.nnz(), "spmv_format": rop.spmv_format(), "reordering": rop.reordering(), "tiles": rop.tiles_info(),
                      "staged": rop.staged_info(),
                      "standalone": standalone, "in_loop": inloop, "standalone_csr_int32_kernel": csr_alone,
@@ -752,8 +762,8 @@ def main():
                 "bytes_note": {0: "CSR int32: 12 nnz + 4 (rows+1) + 8 cols + 8 rows (SURVEY.md 8d)",
                                1: "offset-coded CSR: 9 nnz + 4 (rows+1) + 8 cols + 8 rows",
                                2: "diagonal storage: 8 ndia rows + 8 cols + 8 rows — the bytes this kernel has to move, not the CSR figure"}[fmt] +
-                              f" + 8 rows x {epi_vectors:.2f} epilogue operands (mean over the launches: one-reduction steps read one vector, "
-                              "the other steps v_prev and v)",
+                              f" + 8 rows x {max(epi_vectors - 1.0, 0.0):.2f} for v_prev (read by the two-reduction steps only; the epilogue's other "
+                              "operand is the input vector itself, counted as x)",
                 "epilogue_vectors_mean": epi_vectors,
                 "index_format": {0: "CSR, int32 column indices",
                                  1: f"CSR, offset codes: 1 byte per entry into {op.offset_codes()} diagonals",
@@ -847,7 +857,7 @@ def main():
                     "achieved": c32.get("achieved"), "frac": c32.get("frac"), "csr_equivalent_gbps": c32.get("csr_equivalent_gbps"),
                     "traffic": c32.get("traffic"), "eigenpairs_per_s": c32.get("eigenpairs_per_s"),
                     "note": "the int32 CSR kernel (x windows in LDS) forced on the headline matrix (mispec_csr_set_spmv_format 0), "
-                            "HIP events inside a complete solve; bytes = 12 nnz + 4 (rows+1) + 8 cols + 8 rows + 16 rows (fused epilogue); "
+                            "HIP events inside a complete solve; bytes = 12 nnz + 4 (rows+1) + 8 cols + 8 rows + 8 rows per v_prev read; "
                             "csr_kernel_frac above is on SURVEY.md 8d's bytes alone"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, int(eigs.num_operations()), int(total_pairs // args.steps), int(eigs.num_iterations()))

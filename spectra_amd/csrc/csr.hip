@@ -994,6 +994,189 @@ __global__ __launch_bounds__(256) void k_spmv_dia_win(DiaArgs da, mispec_dia_win
         y[row0 + tid] = acc;
 }
 
+// Two rows per thread (round 5): the values of a 256-row block are read with 16-byte loads by 128 threads — half the load
+// instructions per byte (the one-row-per-thread kernel above issues 8-byte loads, which the memory pipeline serves at 0.54-0.70 of
+// the 16-byte rate: it moved 1.38 GB at 5.5 TB/s where the 16-byte kernels of this library reach 5.8-6.3) — rows 2t and 2t + 1,
+// y / v_prev / v as 16-byte accesses too.  Same products in the same order, and the alpha record of the block is formed by the
+// same tree as everywhere else (per-row contributions through LDS, then the four 64-row shuffle trees and (w0 + w1) + (w2 + w3)):
+// bit-identical results and records.  Needs the block layout of the values (dia_row: ld == 0) and 16-byte aligned y / v vectors.
+template <bool EPI, int NG, int NCW = 8, bool POST = false>
+__global__ __launch_bounds__(128) void k_spmv_dia_win2(DiaArgs da, mispec_dia_windows w, const double* __restrict__ x,
+                                                       double* __restrict__ y, int64_t nrows, int nblocks, SpmvEpilogue epi)
+{
+    extern __shared__ double xs[];  // windows, then 256 per-row contributions of the epilogue
+    __shared__ double red[4];
+    const int per = (nblocks + 7) >> 3;
+    const int lmap = (int(blockIdx.x) & 7) * per + (int(blockIdx.x) >> 3);
+    if (lmap >= nblocks)
+        return;
+    const int lb = epi.first_block + lmap;
+    if (EPI && epi.status && *epi.status != 0)
+        return;
+    const int tid = threadIdx.x;
+    double beta = 1.0;
+    if (POST)
+    {
+        StepState* st = static_cast<StepState*>(epi.post_scale_state);
+        beta = st->beta;
+        const bool first = (lmap == 0 && tid == 0);
+        if (beta < epi.post_scale_eps_sqrt)
+        {
+            if (first)
+            {
+                st->status = kStepSmallBeta;
+                st->stop_step = epi.post_scale_step;
+                st->stop_count = 0;
+            }
+            return;
+        }
+        if (first)
+            st->subd[epi.post_scale_step - 1] = beta;
+    }
+    const int64_t row0 = int64_t(lb) * 256;
+    const int nr = int(min(int64_t(256), nrows - row0));
+    const int r0 = 2 * tid;  // rows r0, r0 + 1 of the block (the value array is zero-padded to whole blocks)
+    const double* vrow = da.dia + int64_t(lb) * da.nd * 256 + r0;
+    double2 v[NG * kDiaGroup];
+#pragma unroll
+    for (int k = 0; k < NG * kDiaGroup; k++)
+    {
+        const v2d t2 = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(vrow + int64_t(min(k, da.nd - 1)) * 256));
+        v[k] = make_double2(t2.x, t2.y);
+    }
+    double2 vprev_e = make_double2(0.0, 0.0), vrow_e = make_double2(0.0, 0.0);
+    double hprev_e = 0.0;
+    const bool have0 = r0 < nr, have1 = r0 + 1 < nr;
+    if (EPI && have0)
+    {
+        if (epi.v_prev)
+        {
+            if (have1)
+                vprev_e = *reinterpret_cast<const double2*>(epi.v_prev + row0 + r0);
+            else
+                vprev_e.x = epi.v_prev[row0 + r0];
+            hprev_e = POST ? beta : (epi.h_prev_dev ? *epi.h_prev_dev : epi.h_prev);
+        }
+        if (have1)
+            vrow_e = *reinterpret_cast<const double2*>(epi.v_rows + row0 + r0);
+        else
+            vrow_e.x = epi.v_rows[row0 + r0];
+        if (POST)
+        {
+            vrow_e.x = vrow_e.x / beta;  // Lanczos.h:106
+            vrow_e.y = vrow_e.y / beta;
+        }
+    }
+    const int64_t g0 = da.row_begin + row0;
+    const auto xat = [&](int64_t col) { return x[min(max(col, int64_t(0)), int64_t(da.col_max))]; };
+    // windows -> LDS: entries tid and tid + 128 of every window, the entries past 256 (the spans) two per thread
+    double xw[NCW][2], xtail[2] = {0.0, 0.0};
+    int tail_pos[2] = {-1, -1};
+    const int tails = w.total - 256 * w.nc;
+    {
+        int before = 0;
+#pragma unroll
+        for (int c = 0; c < NCW; c++)
+        {
+            xw[c][0] = xw[c][1] = 0.0;
+            if (c < w.nc)
+            {
+                xw[c][0] = xat(g0 + w.start[c] + tid);
+                xw[c][1] = xat(g0 + w.start[c] + tid + 128);
+                const int span = w.len[c] - 256;
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+                {
+                    const int t = tid + 128 * h;
+                    if (t >= before && t < before + span)
+                    {
+                        tail_pos[h] = w.base[c] + 256 + (t - before);
+                        xtail[h] = xat(g0 + w.start[c] + 256 + (t - before));
+                    }
+                }
+                before += span;
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < NCW; c++)
+        if (c < w.nc)
+        {
+            xs[w.base[c] + tid] = xw[c][0];
+            xs[w.base[c] + tid + 128] = xw[c][1];
+        }
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+        if (tail_pos[h] >= 0)
+            xs[tail_pos[h]] = xtail[h];
+    if (tails > 256)
+    {
+        int before = 0;
+        for (int c = 0; c < w.nc; c++)
+        {
+            const int span = w.len[c] - 256;
+            for (int t = tid + 256; t < before + span; t += 128)
+                if (t >= before)
+                    xs[w.base[c] + 256 + (t - before)] = xat(g0 + w.start[c] + 256 + (t - before));
+            before += span;
+        }
+    }
+    __syncthreads();
+    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NG * kDiaGroup; k++)
+        if (k < da.nd)
+        {
+            acc0 = add_rounded_product(acc0, v[k].x, xs[w.idx[k] + r0]);
+            acc1 = add_rounded_product(acc1, v[k].y, xs[w.idx[k] + r0 + 1]);
+        }
+    if (EPI)
+    {
+        double* cbuf = xs + w.total;  // per-row contributions of the block
+        double c0 = 0.0, c1 = 0.0;
+        double2 yv;
+        yv.x = POST ? acc0 / beta : acc0;
+        yv.y = POST ? acc1 / beta : acc1;
+        if (epi.v_prev)
+        {
+            yv.x -= hprev_e * vprev_e.x;  // Lanczos.h:139
+            yv.y -= hprev_e * vprev_e.y;
+        }
+        if (have1)
+            *reinterpret_cast<double2*>(y + row0 + r0) = yv;
+        else if (have0)
+            y[row0 + r0] = yv.x;
+        if (have0)
+            c0 = vrow_e.x * yv.x;  // Lanczos.h:142 partial <v, w>
+        if (have1)
+            c1 = vrow_e.y * yv.y;
+        cbuf[r0] = c0;
+        cbuf[r0 + 1] = c1;
+        __syncthreads();
+        // the record's tree: wave k of a 256-thread block sums rows 64 k .. 64 k + 63 by shuffles, then (w0 + w1) + (w2 + w3)
+        const int wv = tid >> 6, lane = tid & 63;
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+        {
+            const int k = 2 * wv + h;
+            const double s = wave_reduce_sum(cbuf[64 * k + lane]);
+            if (lane == 0)
+                red[k] = s;
+        }
+        __syncthreads();
+        if (tid == 0)
+            epi.partials[lb] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+    else
+    {
+        if (have1)
+            *reinterpret_cast<double2*>(y + row0 + r0) = make_double2(acc0, acc1);
+        else if (have0)
+            y[row0 + r0] = acc0;
+    }
+}
+
 // ---- reordered matrices: vector permutations and the un-fused epilogue ----------------------------------------------
 __global__ __launch_bounds__(256) void k_perm_gather(int64_t n, const int32_t* __restrict__ perm, const double* __restrict__ src,
                                                      double* __restrict__ dst)
@@ -1714,6 +1897,58 @@ void launch_spmv_raw(const mispec_csr& A, const double* x_dev, double* y_dev, co
     {
         const DiaArgs da{A.dia.p, A.dia_off.p, A.dia_ld, A.ndia, int(A.n_cols - 1), A.row_begin};
         // x staged through LDS windows when the offsets form at most 8 clusters, else direct loads (k_spmv_dia)
+        // two rows per thread with 16-byte loads (k_spmv_dia_win2) when the layout and the alignment allow; MISPEC_DIA2=0: the
+        // one-row-per-thread kernel
+        const char* e_dia2 = getenv("MISPEC_DIA2");
+        const bool dia2 = !(e_dia2 && atoi(e_dia2) == 0) && A.dia_win.nc > 0 && A.dia_ld == 0 && A.ndia <= 2 * kDiaGroup &&
+                          (reinterpret_cast<uintptr_t>(y_dev) & 15) == 0 &&
+                          (!epi || ((reinterpret_cast<uintptr_t>(e.v_rows) & 15) == 0 && (reinterpret_cast<uintptr_t>(e.v_prev) & 15) == 0));
+        if (dia2)
+        {
+            const size_t lds2 = size_t(A.dia_win.total + 256) * sizeof(double);
+            const dim3 block2(128);
+            const int ng = (A.ndia + kDiaGroup - 1) / kDiaGroup;
+            const bool post = epi && e.post_scale_state;
+#define MISPEC_DIA2_LAUNCH(E, G, W, P)                                                                                                  \
+    do                                                                                                                                  \
+    {                                                                                                                                   \
+        if (ev_start && ev_stop)                                                                                                        \
+            hipExtLaunchKernelGGL((k_spmv_dia_win2<E, G, W, P>), grid, block2, lds2, A.ctx->stream, ev_start, ev_stop, 0, da, A.dia_win, \
+                                  x_dev, y_dev, nloc, nblocks, e);                                                                      \
+        else                                                                                                                            \
+            hipLaunchKernelGGL((k_spmv_dia_win2<E, G, W, P>), grid, block2, lds2, A.ctx->stream, da, A.dia_win, x_dev, y_dev, nloc,     \
+                               nblocks, e);                                                                                             \
+    } while (0)
+#define MISPEC_DIA2_W(E, G, P)               \
+    do                                       \
+    {                                        \
+        if (A.dia_win.nc <= 4)               \
+            MISPEC_DIA2_LAUNCH(E, G, 4, P);  \
+        else if (A.dia_win.nc <= 6)          \
+            MISPEC_DIA2_LAUNCH(E, G, 6, P);  \
+        else                                 \
+            MISPEC_DIA2_LAUNCH(E, G, 8, P);  \
+    } while (0)
+#define MISPEC_DIA2_G(E, P)          \
+    do                               \
+    {                                \
+        if (ng == 1)                 \
+            MISPEC_DIA2_W(E, 1, P);  \
+        else                         \
+            MISPEC_DIA2_W(E, 2, P);  \
+    } while (0)
+            if (post)
+                MISPEC_DIA2_G(true, true);
+            else if (epi)
+                MISPEC_DIA2_G(true, false);
+            else
+                MISPEC_DIA2_G(false, false);
+#undef MISPEC_DIA2_G
+#undef MISPEC_DIA2_W
+#undef MISPEC_DIA2_LAUNCH
+            MISPEC_HIP(hipGetLastError());
+            return;
+        }
         if (A.dia_win.nc > 0)
         {
             const size_t lds = size_t(A.dia_win.total) * sizeof(double);
