@@ -1899,8 +1899,8 @@ void launch_spmv_raw(const mispec_csr& A, const double* x_dev, double* y_dev, co
         // x staged through LDS windows when the offsets form at most 8 clusters, else direct loads (k_spmv_dia)
         // two rows per thread with 16-byte loads (k_spmv_dia_win2) when the layout and the alignment allow; MISPEC_DIA2=0: the
         // one-row-per-thread kernel
-        const char* e_dia2 = getenv("MISPEC_DIA2");
-        const bool dia2 = !(e_dia2 && atoi(e_dia2) == 0) && A.dia_win.nc > 0 && A.dia_ld == 0 && A.ndia <= 2 * kDiaGroup &&
+        static const bool dia2_off = getenv("MISPEC_DIA2") && atoi(getenv("MISPEC_DIA2")) == 0;
+        const bool dia2 = !dia2_off && A.dia_win.nc > 0 && A.dia_ld == 0 && A.ndia <= 2 * kDiaGroup &&
                           (reinterpret_cast<uintptr_t>(y_dev) & 15) == 0 &&
                           (!epi || ((reinterpret_cast<uintptr_t>(e.v_rows) & 15) == 0 && (reinterpret_cast<uintptr_t>(e.v_prev) & 15) == 0));
         if (dia2)
@@ -2060,12 +2060,23 @@ void launch_spmv_raw(const mispec_csr& A, const double* x_dev, double* y_dev, co
     if (!coded && A.windows_active() && (reinterpret_cast<uintptr_t>(x_dev) & 15) == 0)
     {
         // MISPEC_CSR_WIN_ITERS = 2 | 4 (chunk of 2032 / 4080 products), MISPEC_CSR_WIN_PF = 0 | 1 (next chunk's loads ahead)
-        const char* e_iters = getenv("MISPEC_CSR_WIN_ITERS");
-        const char* e_pf = getenv("MISPEC_CSR_WIN_PF");
-        const char* e_nt = getenv("MISPEC_CSR_WIN_NT");
-        const int env_iters = e_iters ? atoi(e_iters) : 0;
-        const int env_pf = e_pf ? atoi(e_pf) : -1;
-        const bool nt = e_nt && atoi(e_nt) != 0;
+        // (read once; MISPEC_KERNEL_PROBE=1 — tools/probe_csr_win.py — re-reads them at every launch so that one process can compare)
+        struct Knobs
+        {
+            int iters, pf;
+            bool nt;
+        };
+        const auto read_knobs = [] {
+            const char* e_iters = getenv("MISPEC_CSR_WIN_ITERS");
+            const char* e_pf = getenv("MISPEC_CSR_WIN_PF");
+            const char* e_nt = getenv("MISPEC_CSR_WIN_NT");
+            return Knobs{e_iters ? atoi(e_iters) : 0, e_pf ? atoi(e_pf) : -1, e_nt && atoi(e_nt) != 0};
+        };
+        static const bool probe = getenv("MISPEC_KERNEL_PROBE") != nullptr;
+        static const Knobs cached = read_knobs();
+        const Knobs knobs = probe ? read_knobs() : cached;
+        const int env_iters = knobs.iters, env_pf = knobs.pf;
+        const bool nt = knobs.nt;
         // measured in the solver loop (profiles/r09a, r09b): chunks of 1008 products with the next chunk's loads ahead — the
         // smallest LDS footprint, most resident blocks — for up to 16 entries per row (M-band 0.372 -> 0.369 ms, jittered band
         // 0.412 -> 0.368 ms against the gather kernel on the same box); longer rows take larger chunks (fewer barrier rounds)

@@ -1032,8 +1032,10 @@ void plan_level(int64_t N, int b, int64_t& L, int64_t& P)
         const int64_t pmax = cp.n_dense / std::max(b, 1) + 1;
         if (P > pmax)
         {
-            P = pmax;
-            L = (N + P - 1) / P;
+            // (the retry bias of mispec_symshift_set_shift — "separators moved by one row each attempt" — has to survive the
+            // clamp, or every attempt factors the identical partition: ADVICE r04)
+            L = (N + pmax - 1) / pmax + g_chunk_bias;
+            P = std::max<int64_t>(1, N / L);
         }
     }
     if (P < 2)

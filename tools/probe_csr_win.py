@@ -7,6 +7,7 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["MISPEC_KERNEL_PROBE"] = "1"  # the library re-reads the kernel knobs at every launch (csr.hip launch_spmv_raw)
 import numpy as np
 import scipy.sparse as sp
 import torch
