@@ -452,8 +452,11 @@ def secondary_configs(args, ctx, op, sa):
             blk = in_loop_block(sa, ctx, rop, args.nev, args.ncv, rule, args.tol)
             blk.update({"n": nloc, "nnz": rop.nnz(), "reordering": rop.reordering(), "windows": rop.windows_info(),
                         "standalone_ms_per_launch": standalone_ms(rop, nloc, 20), "host_generation_seconds": t_gen, "ingest_seconds": t_ingest})
-            rop.use_windows(False)
-            blk["gather_kernel_in_loop_ms"] = in_loop_block(sa, ctx, rop, args.nev, args.ncv, rule, args.tol, 6)["ms_per_launch"]
+            auto_windows = rop.nnz() >= 9 * nloc and blk["windows"]["lds_doubles"] > 0  # csr.hpp windows_active()
+            blk["kernel_in_use"] = "k_spmv_csr_win (x windows in LDS)" if auto_windows else "k_spmv_csr_stream (gathers: fewer than 9 entries per row)"
+            rop.use_windows(not auto_windows)
+            blk["other_kernel_in_loop_ms"] = in_loop_block(sa, ctx, rop, args.nev, args.ncv, rule, args.tol, 6)["ms_per_launch"]
+            rop.use_windows(None)
             out[key] = blk
             del rop
         except Exception as e:  # noqa: BLE001

@@ -131,10 +131,12 @@ int mispec_csr_use_offset_codes(mispec_csr* A, int enable);
  * hold its columns; when at least 75 % of the entries are covered the kernel stages those ranges through LDS with coalesced
  * loads instead of gathering x entry by entry (entries outside the windows keep the gather).  The matrix arrays stay the plain
  * int32 CSR; products and summation order are unchanged (bit-identical).  mispec_csr_use_windows switches the kernel per
- * matrix; mispec_csr_windows_info reports blocks with windows, entries served from LDS and the LDS doubles reserved (0: not
- * adopted).  Replaces the x access of MatOp/SparseSymMatProd.h:83-88 / SparseGenMatProd.h:72-77. */
+ * matrix: 1 windows, 0 gathers, -1 automatic (the default: windows when the table was adopted and the rows hold at least 9
+ * entries on average — shorter rows do not pay for them); mispec_csr_windows_info reports blocks with windows, entries served
+ * from LDS and the LDS doubles reserved (0: not adopted).  Replaces the x access of MatOp/SparseSymMatProd.h:83-88 / SparseGenMatProd.h:72-77. */
 int mispec_csr_use_windows(mispec_csr* A, int enable);
 int mispec_csr_windows_info(const mispec_csr* A, int64_t* blocks, int64_t* covered_entries, int64_t* lds_doubles);
+int mispec_csr_windows_in_use(const mispec_csr* A); /* 1: format 0 of this matrix runs k_spmv_csr_win (switch and automatic rule applied) */
 /* The table itself, for tests: 32 ints per 256-row block of this shard — [0] windows | far flag << 8, [1] doubles of LDS, [2] entries
  * served from LDS, [4..11] first column of each window (0x3fffffff: unused), [12..19] LDS position minus first column, [20..27] one
  * past the last column. */

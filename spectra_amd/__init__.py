@@ -286,14 +286,19 @@ class _DeviceMatrix:
         check(lib().mispec_csr_use_offset_codes(self.h, 1 if enable else 0))
 
     def use_windows(self, enable=True):
-        """Per-matrix switch of the int32 CSR kernel: x staged through LDS windows (True) or gathered entry by entry (False)."""
-        check(lib().mispec_csr_use_windows(self.h, 1 if enable else 0))
+        """Per-matrix switch of the int32 CSR kernel: x staged through LDS windows (True) or gathered entry by entry (False);
+        None: automatic (windows when the table was adopted at ingest and the rows hold at least 9 entries on average)."""
+        check(lib().mispec_csr_use_windows(self.h, -1 if enable is None else (1 if enable else 0)))
 
     def windows_info(self):
         """{blocks, covered_entries, lds_doubles} of the x windows of the int32 CSR kernel (lds_doubles = 0: not adopted)."""
         a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         check(lib().mispec_csr_windows_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return {"blocks": a.value, "covered_entries": b.value, "lds_doubles": c.value}
+
+    def windows_in_use(self):
+        """True when format 0 of this matrix runs the kernel with x windows (per-matrix switch and automatic rule applied)."""
+        return bool(lib().mispec_csr_windows_in_use(self.h))
 
     def windows_table(self):
         """The per-block window records (blocks x 32 int32; include/mispec.h mispec_csr_windows_table)."""

@@ -2566,8 +2566,8 @@ extern "C" int mispec_csr_set_spmv_format(mispec_csr* A, int format)
 extern "C" int mispec_csr_use_windows(mispec_csr* A, int enable)
 {
     return guarded([&] {
-        MISPEC_REQUIRE(A, "mispec_csr_use_windows: NULL argument");
-        A->use_windows = enable != 0;
+        MISPEC_REQUIRE(A && enable >= -1 && enable <= 1, "mispec_csr_use_windows: enable must be -1 (automatic), 0 or 1");
+        A->use_windows = enable;
     });
 }
 extern "C" int mispec_csr_windows_info(const mispec_csr* A, int64_t* blocks, int64_t* covered_entries, int64_t* lds_doubles)
@@ -2582,6 +2582,7 @@ extern "C" int mispec_csr_windows_info(const mispec_csr* A, int64_t* blocks, int
             *lds_doubles = A->wtab.p ? A->win_lds_doubles : 0;
     });
 }
+extern "C" int mispec_csr_windows_in_use(const mispec_csr* A) { return A && A->windows_active() ? 1 : 0; }
 extern "C" int mispec_csr_windows_table(const mispec_csr* A, int32_t* records_out, int64_t capacity)
 {
     return guarded([&] {

@@ -50,8 +50,15 @@ struct mispec_csr
     int win_lds_doubles = 0;         // largest window total over the blocks (doubles of LDS the launch reserves)
     int64_t win_covered = 0;         // entries whose x comes from a window
     int64_t win_blocks = 0;          // blocks that have windows
-    bool use_windows = true;         // mispec_csr_use_windows: per-matrix switch (tests compare the two kernels)
-    bool windows_active() const { return use_windows && wtab.p != nullptr && win_lds_doubles > 0; }
+    int use_windows = -1;            // mispec_csr_use_windows: -1 automatic, 0 / 1 per-matrix switch (tests compare the two kernels)
+    // automatic: rows of fewer than 9 entries on average keep the gather kernel — a block then holds too few entries to pay for
+    // its windows (7-point stencil after RCM, in the solver loop: 0.198-0.203 ms with windows, 0.194 ms without, profiles/r09o, r09z)
+    bool windows_active() const
+    {
+        if (wtab.p == nullptr || win_lds_doubles <= 0 || use_windows == 0)
+            return false;
+        return use_windows == 1 || double(nnz) >= 9.0 * double(local_rows());
+    }
     int forced_format = -1;          // mispec_csr_set_spmv_format: -1 automatic, 0 int32 indices, 1 offset codes, 2 diagonals, 3 tiles, 4 staged
     // Column-blocked tiles (fourth format, tiles.hip): built at ingest for matrices whose gathers are scattered over the
     // whole of x and that reordering does not localise; bit-identical products again.

@@ -47,7 +47,7 @@ def both_kernels(op, A, seeds=(0, 1), expect_windows=True):
                 y = device_product(op, x)
                 assert np.array_equal(y, ref), (windows, int(np.count_nonzero(y != ref)), np.nanmax(np.abs(y - ref)))
     finally:
-        op.use_windows(True)
+        op.use_windows(None)
         op.set_spmv_format(-1)
     return info
 
@@ -100,6 +100,30 @@ def test_ragged_local_patterns(ctx, n):
     A = local_random(n, 7, 300, n)
     op = sa.SparseGenMatProd(A, ctx=ctx)
     both_kernels(op, A, expect_windows=n >= 255)  # a handful of entries is not worth a window
+
+
+def test_automatic_rule_short_rows_keep_the_gather_kernel(ctx):
+    # rows of fewer than 9 entries on average do not pay for their windows (7-point stencil after RCM: 0.198-0.203 ms with windows,
+    # 0.194 ms with gathers in the solver loop): the table is adopted, the automatic choice keeps k_spmv_csr_stream, the switch
+    # still selects either kernel, and all three settings give the same bits
+    n = 70001
+    short = local_random(n, 3, 300, 5)   # ~3 entries per row
+    longer = local_random(n, 7, 300, 6)  # ~7: 0 .. 14 entries, 7 on average -> below 9 as well
+    dense = local_random(n, 12, 300, 7)  # ~12
+    for A, auto in ((short, False), (longer, False), (dense, True)):
+        op = sa.SparseGenMatProd(A, ctx=ctx)
+        assert op.windows_info()["lds_doubles"] > 0 and op.windows_in_use() == auto
+        op.use_windows(True)
+        assert op.windows_in_use()
+        op.use_windows(False)
+        assert not op.windows_in_use()
+        op.use_windows(None)
+        assert op.windows_in_use() == auto
+        both_kernels(op, A, seeds=(0,))
+        x = np.random.default_rng(3).standard_normal(n)
+        op.set_spmv_format(0)
+        assert np.array_equal(device_product(op, x), oracle_product(A, x))
+        op.set_spmv_format(-1)
 
 
 def test_odd_column_count_and_windows_at_both_ends(ctx):
@@ -183,7 +207,7 @@ def test_the_solver_loop_is_identical_with_and_without_windows(ctx):
         assert nconv == 6
         out.append((e.eigenvalues(), e.num_operations(), e.eigenvectors()))
         assert e.residuals().max() <= 1e-9
-    op.use_windows(True)
+    op.use_windows(None)
     assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1] and np.array_equal(out[0][2], out[1][2])
 
 
@@ -222,4 +246,4 @@ def test_full_size_irregular_local_matrices_bit_exact(ctx, which):
     for windows in (True, False):
         op.use_windows(windows)
         assert np.array_equal(op.perform_op(x), ref), windows
-    op.use_windows(True)
+    op.use_windows(None)

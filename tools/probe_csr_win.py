@@ -72,6 +72,7 @@ def run(name, op, nev=20, ncv=40, restarts=10):
                           "in_loop_launches": int(p["n_spmv"]), "solve_s": round(dt, 3), "num_operations": int(e.num_operations())}), flush=True)
         del e
     set_variant(op, ("2", "1", "0"))
+    op.use_windows(None)
     for k in ("MISPEC_CSR_WIN_ITERS", "MISPEC_CSR_WIN_PF", "MISPEC_CSR_WIN_NT"):
         os.environ.pop(k, None)
     op.set_spmv_format(-1)
