@@ -366,7 +366,7 @@ enum { MISPEC_ORTH_REFERENCE = 0, MISPEC_ORTH_ONESWEEP = 1,
                                                 with the reference's loop before the sweep is enqueued again (see below) */ };
 int mispec_fac_set_orth_mode(mispec_fac* fac, int mode);
 /* One reduction per one-sweep step (MISPEC_ORTH_ONE_REDUCTION; the library's own operators — sparse and dense matrices, the SVD
- * product, the shift solve —, ncv <= 64; CPU restatement: oracle/
+ * product, the shift solve, the Cholesky mode —, ncv <= 128; CPU restatement: oracle/
  * onesweep_variant.hpp, flavour one-reduction).  The reference's step needs alpha = <v, w> before f = w - alpha v (Lanczos.h:142-145)
  * and beta = |f| before the next product (Lanczos.h:106): two global sums on the critical path, two all-reduces on a sharded run.
  * Here the product of step i + 1 runs on the UN-normalised residual f~ of step i, u = A f~, and its epilogue's partial sums of

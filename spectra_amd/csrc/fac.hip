@@ -516,7 +516,8 @@ void apply_op(mispec_fac& F, const double* x_loc, double* y_loc, bool lanczos_ep
             if (lanczos_epi)
             {
                 launch_lanczos_epilogue(*F.ctx, y_loc, x_loc, v_prev, h_prev, F.nloc, F.alpha_partials.p, h_prev_dev, status);
-                launch_reduce_sum(*F.ctx, F.alpha_partials.p, lanczos_epilogue_records(*F.ctx, F.nloc), alpha_dev);
+                if (!F.skip_alpha_reduce)
+                    launch_reduce_sum(*F.ctx, F.alpha_partials.p, lanczos_epilogue_records(*F.ctx, F.nloc), alpha_dev);
             }
             return;
         }
@@ -1076,7 +1077,7 @@ void lanczos_step_lagged(mispec_fac& F, int i, bool last, bool defer)
         F.skip_alpha_reduce = false;
         FinishArgs fin = F.lag_def.fin;
         fin.alpha_parts = F.alpha_partials.p;
-        fin.alpha_count = F.A ? spmv_num_blocks(F.nloc) : lanczos_epilogue_records(*F.ctx, F.nloc);
+        fin.alpha_count = (F.A && !F.Chol) ? spmv_num_blocks(F.nloc) : lanczos_epilogue_records(*F.ctx, F.nloc);
         fin.alpha_out = F.alpha_slot();
         {
             Timed t(F, FAM_VTF);
@@ -1129,9 +1130,10 @@ void lanczos_step_lagged(mispec_fac& F, int i, bool last, bool defer)
         fin.prev_red = F.red_buf(cur ^ 1);
         // the plain matrix product on bases of one column panel; the last step of a sweep is reduced at once (what follows — the
         // reference's corrections or the restart — needs its record)
-        // (every operator the library applies itself: matrices incl. the SVD product, the banded / dense shift solve, dense
-        // matrices; user operators on device pointers keep receiving the normalised vector, the Cholesky mode its own reduction)
-        const bool defer_record = F.onered && !last && (F.A || F.S || F.D) && !F.Chol && !F.dop && F.m <= kPanelCols;
+        // (every operator the library applies itself: matrices incl. the SVD product and the Cholesky mode of the generalized
+        // problem, the banded / dense shift solve, dense matrices — on bases of up to 128 columns; user operators on device
+        // pointers keep receiving the normalised vector)
+        const bool defer_record = F.onered && !last && (F.A || F.S || F.D) && !F.dop;
         if (defer_record)
         {
             F.lag_def.have = true;

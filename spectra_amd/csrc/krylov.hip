@@ -1400,13 +1400,15 @@ void launch_orth_lagged(const mispec_ctx& ctx, const OrthArgs& a, int grid)
     const dim3 g(static_cast<unsigned>(grid));
     if (a.ncol >= kPanelCols)  // 64..127 finished columns: eight wavefronts of 16 columns
     {
-        MISPEC_REQUIRE(!a.onered, "one-reduction steps: bases of up to 64 columns");
         const dim3 b8(512);
         switch ((a.ncol + 7) / 8)
         {
 #define MISPEC_LAG_CASE8(S)                                                     \
     case S:                                                                     \
-        hipLaunchKernelGGL((k_orth_lagged<S, 1, 8>), g, b8, 0, ctx.stream, a); \
+        if (a.onered)                                                           \
+            hipLaunchKernelGGL((k_orth_lagged<S, 1, 8, true>), g, b8, 0, ctx.stream, a); \
+        else                                                                    \
+            hipLaunchKernelGGL((k_orth_lagged<S, 1, 8>), g, b8, 0, ctx.stream, a); \
         break;
             MISPEC_LAG_CASE8(8)
             MISPEC_LAG_CASE8(9)
@@ -1417,7 +1419,10 @@ void launch_orth_lagged(const mispec_ctx& ctx, const OrthArgs& a, int grid)
             MISPEC_LAG_CASE8(14)
             MISPEC_LAG_CASE8(15)
             default:
-                hipLaunchKernelGGL((k_orth_lagged<16, 1, 8>), g, b8, 0, ctx.stream, a);
+                if (a.onered)
+                    hipLaunchKernelGGL((k_orth_lagged<16, 1, 8, true>), g, b8, 0, ctx.stream, a);
+                else
+                    hipLaunchKernelGGL((k_orth_lagged<16, 1, 8>), g, b8, 0, ctx.stream, a);
                 break;
 #undef MISPEC_LAG_CASE8
         }
