@@ -24,6 +24,11 @@
 //     y[r] = sum_k dia[k][r] * x[r + off_k] in ascending offset order — no index, no gather, no LDS, every load
 //     coalesced, 8 bytes per stored slot.  Same products in the same order as the CSR row sum (absent entries add 0), so
 //     again bit-identical.
+//   * x windows (k_spmv_csr_win, round 5): for matrices whose columns are local but not on fixed offsets the x entries of a
+//     row-block come from LDS windows found at ingest instead of one gather per entry; the arrays stay the plain int32 CSR
+//     (see the comment above k_build_windows).  The default for format 0 when the table is adopted and rows hold >= 9 entries.
+//   * k_spmv_dia_win / k_spmv_dia_win2: diagonal storage with the x windows of a block in LDS; win2 (round 5, the default) handles
+//     two rows per thread with 16-byte loads of the values.
 // Bound: HBM.  Algorithmic bytes per launch: 12*nnz + 4*(rows+1) + 8*cols + 8*rows (CSR with int32
 // indices); the offset-coded variant's compulsory traffic is 9*nnz + ... .
 #include "csr.hpp"
