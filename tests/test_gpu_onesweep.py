@@ -130,6 +130,28 @@ def test_the_one_reduction_form_is_the_one_that_runs(ctx, reductions):
     assert np.abs(wide.eigenvalues() - wide2.eigenvalues()).max() <= 1e-12 * np.abs(wide2.eigenvalues()).max()
 
 
+@pytest.mark.parametrize("rule", ["LargestAlge", "BothEnds", "LargestMagn"])
+def test_device_one_reduction_against_its_cpu_restatement(ctx, rule, reductions):
+    # oracle/onesweep_variant.hpp (flavour one-reduction, gated on the CPU by tests/test_oracle_onesweep.py) states the step the
+    # device runs: same nconv and verdict, eigenvalues to rounding, operation counts within one restart cycle, and the same share
+    # of steps in the one-reduction form (all lagged steps but the first of a sweep / those after the reference's own loop)
+    if reductions != "one-reduction":
+        pytest.skip("the restatement's other flavours are compared through the shared gates above")
+    n, k, m = 1000, 20, 50
+    A, S = sparse_fixture(n, 0.01)
+    dev, nconv = solve(sa.SparseSymMatProd(A, ctx=ctx), k, m, sa.SortRule[rule], "onesweep-onered")
+    o = O.SymEigsSolver(O.Op.csc_sym(n, A.indptr, A.indices, A.data, True), k, m)
+    o.set_onesweep(True, fused=True, one_reduction=True)
+    o.init()
+    nconv_o = o.compute(getattr(O, rule), 1000, 1e-10, O.LargestAlge)
+    assert nconv == nconv_o == k and int(dev.info()) == o.info() == 0
+    assert np.abs(np.sort(dev.eigenvalues()) - np.sort(o.eigenvalues())).max() <= 1e-11
+    assert abs(dev.num_operations() - o.num_operations()) <= m - k and abs(dev.num_iterations() - o.num_iterations()) <= 1
+    di, st = dev.orth_info(), o.onesweep_stats()
+    assert di["lagged_steps"] > 0 and st["lagged_steps"] > 0
+    assert abs(di["one_reduction_steps"] / di["lagged_steps"] - st["one_reduction_steps"] / st["lagged_steps"]) <= 0.1
+
+
 def test_onesweep_is_ignored_where_it_does_not_apply(ctx):
     # ncv > 128 (column panels) keeps the reference's flow
     A, S = sparse_fixture(1000, 0.01)

@@ -17,8 +17,9 @@ RULE = {"LargestMagn": O.LargestMagn, "LargestAlge": O.LargestAlge, "SmallestMag
 
 # flavours of the variant: "eager" applies the last correction of a sweep at once; "fused" lets it ride on the restart (what the
 # device does by default in one-sweep mode: k_vq_fused); "recorrect" additionally forces the loop that follows a failed test
-# "one-reduction": the form DESIGN.md 8 proposes for sharded runs — the product on the un-normalised residual, its <f, Af> reduced
-# together with the previous pass's record (one all-reduce per step instead of two); restated on the CPU only so far
+# "one-reduction": the product on the un-normalised residual, its <f, Af> reduced together with the previous pass's record (one
+# all-reduce per step instead of two) — the device default since round 5 (tests/test_gpu_onesweep.py compares the
+# device with this restatement)
 FLAVOURS = {"eager": {}, "fused": {"fused": True}, "recorrect": {"fused": True, "recorrect": True},
             "one-reduction": {"fused": True, "one_reduction": True}}
 
