@@ -706,10 +706,46 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restri
     for (int t = tid; t < kPartialLd; t += 1024)
         sh[t] = 0.0;
     __syncthreads();
+    __shared__ double sh_a[16];
+    // Small problems (at most 64 records: up to ~16 K rows): every lane holds ONE record of a slot, so all the slots of the
+    // record and the product's partial sums fit one round of loads — one trip to the other XCDs' data instead of three, on the
+    // critical path of every step of a launch-bound solve.  Same sums: a lane's "0 + x", then the shuffle tree.
+    const bool small = nrec <= 64 && ncol + 2 <= 96 && (!fin.alpha_parts || fin.alpha_count <= 1024);
+    if (small)
+    {
+        int sl[6];
+        double xv[6];
+#pragma unroll
+        for (int u = 0; u < 6; u++)
+        {
+            const int s = g + 16 * u;
+            sl[u] = s < ncol ? s : (s == ncol ? kSlotBeta2 : (s == ncol + 1 ? kSlotMaxAbs : -1));
+            xv[u] = (sl[u] >= 0 && lane < nrec) ? partials[int64_t(sl[u]) * pstride + lane] : 0.0;
+        }
+        double av = 0.0;
+        if (fin.alpha_parts && tid < fin.alpha_count)
+            av = fin.alpha_parts[tid];
+#pragma unroll
+        for (int u = 0; u < 6; u++)
+        {
+            if (sl[u] < 0)
+                continue;  // wave-uniform
+            const double acc = (sl[u] == kSlotMaxAbs) ? fmax(0.0, xv[u]) : 0.0 + xv[u];
+            const double r = (sl[u] == kSlotMaxAbs) ? wave_reduce_max(acc) : wave_reduce_sum(acc);
+            if (lane == 0)
+                sh[sl[u]] = r;
+        }
+        if (fin.alpha_parts)
+        {
+            const double v = wave_reduce_sum(0.0 + av);
+            if (lane == 0)
+                sh_a[g] = v;
+        }
+    }
     // column passes of 48 (wave g: c0+g, c0+g+16, c0+g+32); the two scalar slots ride in the last pass when its
     // positions 46/47 are free, otherwise in a pass of their own
-    bool scalars_done = false;
-    for (int c0 = 0; c0 == 0 || c0 < ncol; c0 += 48)
+    bool scalars_done = small;
+    for (int c0 = 0; !small && (c0 == 0 || c0 < ncol); c0 += 48)
     {
         int slot[3];
         slot[0] = (c0 + g < ncol) ? c0 + g : -1;
@@ -731,8 +767,7 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restri
         slot[0] = (g == 0) ? kSlotBeta2 : (g == 1 ? kSlotMaxAbs : -1);
         reduce_slots<1>(partials, pstride, nrec, slot, lane, sh);
     }
-    __shared__ double sh_a[16];
-    if (fin.alpha_parts)
+    if (fin.alpha_parts && !small)
     {
         // k_reduce_sum's order: thread t adds in[t], in[t + 1024], ... ; wave sums; the 16 wave sums one after the other
         constexpr int kBatch = 40;
