@@ -207,12 +207,20 @@ def make_context(device=None, transport=None):
             # aborting the run.  MISPEC_COMM=rccl-strict keeps the failure fatal.
             ok = 1
             err = None
-            try:
-                payload = [Context.rccl_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(payload, src=0)
-                ctx.set_comm_rccl(rank, world, payload[0])
-            except Exception as e:  # noqa: BLE001
-                ok, err = 0, e
+            payload = [None]
+            if rank == 0:
+                try:
+                    payload = [Context.rccl_unique_id()]
+                except Exception as e:  # noqa: BLE001 - every rank still takes part in the broadcast below (no rank may wait alone)
+                    err = e
+            dist.broadcast_object_list(payload, src=0)
+            if payload[0] is None:
+                ok = 0
+            else:
+                try:
+                    ctx.set_comm_rccl(rank, world, payload[0])
+                except Exception as e:  # noqa: BLE001
+                    ok, err = 0, e
             if transport == "rccl-strict":
                 if err is not None:
                     raise err
