@@ -245,6 +245,37 @@ def live_pmc_traffic(n, fmt, post_scaled, timeout=240, modes=None):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def flatten_for_the_driver(out):
+    """The driver's record of a run keeps the SCALARS of the `roofline` block and drops nested objects and unknown top-level keys
+    (BENCH_rNN.json `parsed`): the figures a reader of that record needs — the int32 CSR kernel on the headline matrix, the
+    secondary workloads, the orthogonalisation pass, synchronisations per solve — are copied there as flat scalars (VERDICT r04
+    item 1).  csr_kernel_frac is on SURVEY.md 8d's bytes: (12 nnz + 20 n + 4) / time / 8 TB/s."""
+    sec = out["secondary"] if isinstance(out.get("secondary"), dict) else {}
+    flat = out["roofline"]
+    c32 = sec.get("csr_kernels_same_matrix", {}).get("csr_int32")
+    if c32:
+        flat["csr_kernel_ms"] = c32.get("ms_per_launch")
+        flat["csr_kernel_frac"] = c32.get("frac_8d")
+        flat["csr_kernel_frac_with_epilogue_operands"] = c32.get("frac")
+        flat["csr_kernel_eigenpairs_per_s"] = c32.get("eigenpairs_per_s")
+    for key in ("m_rand", "jitter_band", "stencil_rcm"):
+        blk = sec.get(key, {})
+        blk = blk.get("in_loop", blk) if isinstance(blk, dict) else {}
+        if isinstance(blk, dict) and "frac" in blk:
+            flat[f"secondary_{key}_frac"] = blk["frac"]
+            flat[f"secondary_{key}_ms"] = blk["ms_per_launch"]
+            flat[f"secondary_{key}_format"] = sec[key].get("spmv_format")
+    if isinstance(sec.get("c4"), dict) and "seconds" in sec["c4"]:
+        flat["secondary_c4_seconds"] = sec["c4"]["seconds"]
+    if isinstance(sec.get("c5"), dict) and "seconds" in sec["c5"]:
+        flat["secondary_c5_seconds"] = sec["c5"]["seconds"]
+        flat["secondary_c5_solve_ms"] = sec["c5"].get("solve_ms")
+    if out.get("roofline_orth"):
+        flat["orth_frac"] = out["roofline_orth"].get("frac")
+    if isinstance(out.get("solve"), dict) and "host_syncs_per_solve" in out["solve"]:
+        flat["host_syncs_per_solve"] = out["solve"]["host_syncs_per_solve"]
+
+
 def spmv_block(op, ms, launches, fused, epi_vectors=2.0):
     """Roofline figures of one SpMV instantiation on the bytes it has to move.  epi_vectors: operands of the fused Lanczos epilogue —
     2 in the reference flow and the two-reduction one-sweep steps (v_prev and v), 1 in the one-reduction steps (only the operand of
@@ -832,28 +863,7 @@ def main():
             # north_star names a CSR SpMV: the int32 CSR kernel's in-loop figure on the SAME matrix sits next to the headline
             # kernel's, so that a regression of either is visible in the top-level block
             c32 = out["secondary"].get("csr_kernels_same_matrix", {}).get("csr_int32") if isinstance(out["secondary"], dict) else None
-            sec = out["secondary"] if isinstance(out["secondary"], dict) else {}
-            flat = out["roofline"]
-            if c32:  # flat scalars: the driver's record keeps the scalars of this block
-                flat["csr_kernel_ms"] = c32.get("ms_per_launch")
-                flat["csr_kernel_frac"] = c32.get("frac_8d")  # 12 nnz + 20 n + 4 bytes (1.995 GB at C2) / time / 8 TB/s
-                flat["csr_kernel_frac_with_epilogue_operands"] = c32.get("frac")
-                flat["csr_kernel_eigenpairs_per_s"] = c32.get("eigenpairs_per_s")
-            for key in ("m_rand", "jitter_band", "stencil_rcm"):
-                blk = sec.get(key, {})
-                blk = blk.get("in_loop", blk) if isinstance(blk, dict) else {}
-                if isinstance(blk, dict) and "frac" in blk:
-                    flat[f"secondary_{key}_frac"] = blk["frac"]
-                    flat[f"secondary_{key}_ms"] = blk["ms_per_launch"]
-                    flat[f"secondary_{key}_format"] = sec[key].get("spmv_format")
-            if isinstance(sec.get("c4"), dict) and "seconds" in sec["c4"]:
-                flat["secondary_c4_seconds"] = sec["c4"]["seconds"]
-            if isinstance(sec.get("c5"), dict) and "seconds" in sec["c5"]:
-                flat["secondary_c5_seconds"] = sec["c5"]["seconds"]
-                flat["secondary_c5_solve_ms"] = sec["c5"].get("solve_ms")
-            if out.get("roofline_orth"):
-                flat["orth_frac"] = out["roofline_orth"].get("frac")
-            flat["host_syncs_per_solve"] = out["solve"]["host_syncs_per_solve"]
+            flatten_for_the_driver(out)
             if c32:
                 out["roofline"]["csr_kernel"] = {
                     "kernel": c32.get("kernel"), "ms_per_launch": c32.get("ms_per_launch"), "bytes_per_launch": c32.get("bytes_per_launch"),

@@ -123,3 +123,28 @@ def test_live_pmc_reports_a_failed_pass():
         pytest.skip("a GPU is present: the passes would succeed")
     value, note = bench.live_pmc_traffic(1_000_000, 2, True, timeout=120)
     assert value is None and "pass" in note
+
+
+def test_flat_scalars_the_driver_keeps():
+    # The driver's BENCH_rNN.json keeps only the scalars of the `roofline` block: the int32 CSR kernel's in-loop figure on SURVEY
+    # 8d's bytes and the secondary workloads must be there as flat scalars.  Replayed on the committed final-tree record with the
+    # flat keys stripped: flatten_for_the_driver must put every one of them back, and csr_kernel_frac must be
+    # (12 nnz + 20 n + 4) bytes / time / 8 TB/s.
+    import json
+
+    import bench
+
+    with open(os.path.join(ROOT, "profiles", "r10f_bench_final_tree.json")) as f:
+        rec = json.load(f)
+    want = {k: v for k, v in rec["roofline"].items() if k.startswith(("csr_kernel_", "secondary_")) or k in ("orth_frac", "host_syncs_per_solve")}
+    assert {"csr_kernel_frac", "csr_kernel_ms", "secondary_m_rand_frac", "secondary_jitter_band_frac", "secondary_stencil_rcm_frac",
+            "secondary_jitter_band_format", "secondary_c4_seconds", "secondary_c5_solve_ms", "orth_frac", "host_syncs_per_solve"} <= set(want)
+    stripped = json.loads(json.dumps(rec))
+    for k in want:
+        del stripped["roofline"][k]
+    bench.flatten_for_the_driver(stripped)
+    assert {k: stripped["roofline"][k] for k in want} == want
+    assert all(not isinstance(v, (dict, list)) for k, v in stripped["roofline"].items() if k in want)
+    n, nnz = rec["config"]["n"], rec["config"]["nnz_per_gpu"]
+    frac = (12.0 * nnz + 20.0 * n + 4.0) / (want["csr_kernel_ms"] * 1e-3) / 8e12
+    assert abs(frac - want["csr_kernel_frac"]) <= 1e-9 and want["secondary_jitter_band_format"] == 0 and want["secondary_stencil_rcm_format"] == 0
