@@ -141,6 +141,11 @@ int mispec_csr_windows_in_use(const mispec_csr* A); /* 1: format 0 of this matri
  * served from LDS, [4..11] first column of each window (0x3fffffff: unused), [12..19] LDS position minus first column, [20..27] one
  * past the last column. */
 int mispec_csr_windows_table(const mispec_csr* A, int32_t* records_out, int64_t capacity);
+/* Host-only test hook (no device): the table of local rows [0, n_rows) of a shard that starts at global row row_begin, from host
+ * CSR arrays (rowptr starting at the shard's first entry) — the selection code the device builder runs, on the CPU.  records_out:
+ * 32 ints per 256-row block. */
+int mispec_csr_windows_host(int64_t n_rows, int64_t n_cols, int64_t row_begin, const int32_t* rowptr, const int32_t* colind,
+                            int32_t* records_out);
 /* Storage format the SpMV uses for this shard: 0 = CSR with int32 column indices, 1 = CSR with offset codes, 2 = diagonal
  * storage (values kept diagonal-major, no index and no gather; chosen when the dictionary has <= 32 diagonals that are
  * at least 3/4 full, rows sorted, no duplicate entries), 3 = column-blocked tiles (built at

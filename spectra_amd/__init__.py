@@ -97,6 +97,15 @@ def tiles_spmv_host(mat, x):
     return (y if built.value else None), {"entries": st[0], "padding": st[1], "chunks": st[2]}
 
 
+def windows_host(mat, row_begin=0):
+    """The x-window table of a CSR matrix (scipy, sorted rows) built on the HOST by the code the device builder runs
+    (mispec_csr_windows_host; no device needed): (blocks x 32) int32, see include/mispec.h mispec_csr_windows_table."""
+    rp, ci = _i32(mat.indptr), _i32(mat.indices)
+    out = np.zeros(((mat.shape[0] + 255) // 256, 32), dtype=np.int32)
+    check(lib().mispec_csr_windows_host(mat.shape[0], mat.shape[1], int(row_begin), _ip(rp), _ip(ci), _ip(out)))
+    return out
+
+
 def staged_spmv_host(mat, x):
     """y = A x through the HOST image of the staged format, in the order of its two kernels (mispec_staged_spmv_host; no device
     needed).  mat: scipy CSR with sorted rows.  Returns (y or None when the format does not apply, stats dict)."""

@@ -88,6 +88,7 @@ SIGNATURES = {
     "mispec_csr_windows_info": (C.c_int, [_vp, _lp, _lp, _lp]),
     "mispec_csr_windows_table": (C.c_int, [_vp, _ip, C.c_int64]),
     "mispec_csr_windows_in_use": (C.c_int, [_vp]),
+    "mispec_csr_windows_host": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, _ip, _ip, _ip]),
     "mispec_csr_spmv_format": (C.c_int, [_vp]),
     "mispec_csr_set_spmv_format": (C.c_int, [_vp, C.c_int]),
     "mispec_csr_spmv_bytes": (C.c_double, [_vp, C.c_int]),

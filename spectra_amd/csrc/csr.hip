@@ -297,114 +297,97 @@ constexpr int kWinLines = int((2 * kFarWindow + 512) / 16);  // 128-byte lines o
 constexpr int kWinWords = (kWinLines + 31) / 32;
 constexpr int kWinRuns = 256;          // raw runs of touched lines a block may have before neighbours further apart are joined
 
-__global__ __launch_bounds__(256) void k_build_windows(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind, int64_t nrows,
-                                                       int64_t row_begin, int64_t n_cols, int cap_doubles, int32_t* __restrict__ wtab)
+// ---- the window selection of one 256-row block: plain sequential code shared by the device builder (one thread of the block)
+// and the host hook mispec_csr_windows_host, so that the CPU tests exercise the code the device runs -----------------------------
+__host__ __device__ inline int64_t win_origin(int64_t row_begin, int64_t row0)
 {
-    __shared__ uint32_t bits[kWinWords];
-    __shared__ int s_far, s_n;
-    __shared__ int rs[kWinRuns], re[kWinRuns], cnt[kWinRuns];
-    const int lb = int(blockIdx.x), tid = int(threadIdx.x);
-    const int64_t row0 = int64_t(lb) * 256;
-    const int nr = int(min(int64_t(256), nrows - row0));
-    const int bs = rowptr[row0], be = rowptr[row0 + nr];
-    const int64_t origin = max(int64_t(0), row_begin + row0 - kFarWindow) & ~int64_t(15);
-    for (int w = tid; w < kWinWords; w += 256)
-        bits[w] = 0u;
-    if (tid < kWinRuns)
-        cnt[tid] = 0;
-    if (tid == 0)
-        s_far = 0;
-    __syncthreads();
-    int far = 0;
-    for (int p = bs + tid; p < be; p += 256)
+    const int64_t o = row_begin + row0 - kFarWindow;
+    return (o > 0 ? o : 0) & ~int64_t(15);
+}
+__host__ __device__ inline int win_ctz(uint32_t w)
+{
+    int n = 0;
+    while (!(w & 1u))
     {
-        const int64_t rel = int64_t(colind[p]) - origin;
-        if (rel < 0 || rel >= int64_t(kWinLines) * 16)
-            far++;
-        else
-            atomicOr(&bits[rel >> 9], 1u << ((rel >> 4) & 31));
+        w >>= 1;
+        n++;
     }
-    if (far)
-        atomicAdd(&s_far, far);
-    __syncthreads();
-    if (tid == 0)
+    return n;
+}
+// Runs of touched 128-byte lines of the bitmap; neighbours closer than `gap` lines are one run (the lines in between are loaded
+// too).  The gap grows until the runs fit the table.  Returns the number of runs (0: they do not fit at any gap).
+__host__ __device__ inline int win_find_runs(const uint32_t* bits, int* rs, int* re)
+{
+    int n = 0;
+    bool fits = false;
+    for (int gap = 2; gap <= 2048 && !fits; gap *= 4)
     {
-        // runs of touched 128-byte lines; neighbours closer than `gap` lines are one run (the lines in between are loaded too).
-        // The gap grows until the runs fit the table.
-        int n = 0;
-        bool fits = false;
-        for (int gap = 2; gap <= 2048 && !fits; gap *= 4)
+        n = 0;
+        fits = true;
+        int cs = -1, ce = -1;
+        for (int w = 0; w < kWinWords && fits; w++)
         {
-            n = 0;
-            fits = true;
-            int cs = -1, ce = -1;
-            for (int w = 0; w < kWinWords && fits; w++)
+            uint32_t word = bits[w];
+            while (word)
             {
-                uint32_t word = bits[w];
-                while (word)
+                const int line = w * 32 + win_ctz(word);
+                word &= word - 1;
+                if (cs < 0)
                 {
-                    const int line = w * 32 + __builtin_ctz(word);
-                    word &= word - 1;
-                    if (cs < 0)
-                    {
-                        cs = line;
-                        ce = line + 1;
-                    }
-                    else if (line - ce <= gap)
-                        ce = line + 1;
-                    else
-                    {
-                        if (n == kWinRuns)
-                        {
-                            fits = false;
-                            break;
-                        }
-                        rs[n] = cs;
-                        re[n] = ce;
-                        n++;
-                        cs = line;
-                        ce = line + 1;
-                    }
+                    cs = line;
+                    ce = line + 1;
                 }
-            }
-            if (fits && cs >= 0)
-            {
-                if (n == kWinRuns)
-                    fits = false;
+                else if (line - ce <= gap)
+                    ce = line + 1;
                 else
                 {
+                    if (n == kWinRuns)
+                    {
+                        fits = false;
+                        break;
+                    }
                     rs[n] = cs;
                     re[n] = ce;
                     n++;
+                    cs = line;
+                    ce = line + 1;
                 }
             }
         }
-        s_n = fits ? n : 0;
-    }
-    __syncthreads();
-    // entries per run
-    const int nruns = s_n;
-    if (nruns > 0)
-        for (int p = bs + tid; p < be; p += 256)
+        if (fits && cs >= 0)
         {
-            const int64_t rel = int64_t(colind[p]) - origin;
-            if (rel < 0 || rel >= int64_t(kWinLines) * 16)
-                continue;
-            const int line = int(rel >> 4);
-            int lo = 0, hi = nruns - 1;  // last run with rs <= line
-            while (lo < hi)
+            if (n == kWinRuns)
+                fits = false;
+            else
             {
-                const int mid = (lo + hi + 1) >> 1;
-                if (rs[mid] <= line)
-                    lo = mid;
-                else
-                    hi = mid - 1;
+                rs[n] = cs;
+                re[n] = ce;
+                n++;
             }
-            atomicAdd(&cnt[lo], 1);
         }
-    __syncthreads();
-    if (tid != 0)
-        return;
+    }
+    return fits ? n : 0;
+}
+// index of the run that holds `line` (the last run with rs <= line)
+__host__ __device__ inline int win_run_of(const int* rs, int nruns, int line)
+{
+    int lo = 0, hi = nruns - 1;
+    while (lo < hi)
+    {
+        const int mid = (lo + hi + 1) >> 1;
+        if (rs[mid] <= line)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    return lo;
+}
+// From the runs and their entry counts to the block's record: thin runs are left to the gather, the closest runs are merged or the
+// lightest dropped until at most kWinMax windows within `cap_doubles` of LDS remain.  entries: stored entries of the block; far:
+// entries outside the bitmap's range.
+__host__ __device__ inline void win_select(int nruns, int* rs, int* re, int* cnt, int64_t origin, int64_t n_cols, int cap_doubles, int entries,
+                                           int far, int32_t* rec)
+{
     int n = nruns;
     int dropped = 0;  // entries of runs that are not kept: gathered one by one like the far ones
     const auto remove = [&](int i) {
@@ -427,7 +410,10 @@ __global__ __launch_bounds__(256) void k_build_windows(const int32_t* __restrict
         else
             i++;
     const int64_t col_end = (n_cols + 1) & ~int64_t(1);  // windows hold pairs of doubles
-    const auto length = [&](int i) { return int(min(origin + int64_t(re[i]) * 16, col_end) - (origin + int64_t(rs[i]) * 16)); };
+    const auto length = [&](int i) {
+        const int64_t e = origin + int64_t(re[i]) * 16;
+        return int((e < col_end ? e : col_end) - (origin + int64_t(rs[i]) * 16));
+    };
     int total = 0;
     for (int i = 0; i < n; i++)
         total += length(i);
@@ -473,19 +459,21 @@ __global__ __launch_bounds__(256) void k_build_windows(const int32_t* __restrict
         dropped += cnt[worst];
         remove(worst);
     }
-    int32_t* rec = wtab + size_t(lb) * kWinRec;
-    const int outside = s_far + dropped + (nruns == 0 ? (be - bs) - s_far : 0);
+    const int outside = far + dropped + (nruns == 0 ? entries - far : 0);
     rec[0] = n | ((outside || n == 0 ? 1 : 0) << 8);
     rec[1] = total;
-    rec[2] = (be - bs) - outside;
+    rec[2] = entries - outside;
     rec[3] = 0;
+    for (int i = 28; i < kWinRec; i++)
+        rec[i] = 0;
     int base = 0;
     for (int i = 0; i < kWinMax; i++)
     {
         if (i < n)
         {
             const int64_t start = origin + int64_t(rs[i]) * 16;
-            const int64_t end = min(origin + int64_t(re[i]) * 16, col_end);
+            const int64_t e = origin + int64_t(re[i]) * 16;
+            const int64_t end = e < col_end ? e : col_end;
             rec[4 + i] = int32_t(start);
             rec[4 + kWinMax + i] = int32_t(int64_t(base) - start);
             rec[4 + 2 * kWinMax + i] = int32_t(end);
@@ -497,6 +485,90 @@ __global__ __launch_bounds__(256) void k_build_windows(const int32_t* __restrict
             rec[4 + kWinMax + i] = 0;
             rec[4 + 2 * kWinMax + i] = kWinPad;
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_build_windows(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind, int64_t nrows,
+                                                       int64_t row_begin, int64_t n_cols, int cap_doubles, int32_t* __restrict__ wtab)
+{
+    __shared__ uint32_t bits[kWinWords];
+    __shared__ int s_far, s_n;
+    __shared__ int rs[kWinRuns], re[kWinRuns], cnt[kWinRuns];
+    const int lb = int(blockIdx.x), tid = int(threadIdx.x);
+    const int64_t row0 = int64_t(lb) * 256;
+    const int nr = int(min(int64_t(256), nrows - row0));
+    const int bs = rowptr[row0], be = rowptr[row0 + nr];
+    const int64_t origin = win_origin(row_begin, row0);
+    for (int w = tid; w < kWinWords; w += 256)
+        bits[w] = 0u;
+    if (tid < kWinRuns)
+        cnt[tid] = 0;
+    if (tid == 0)
+        s_far = 0;
+    __syncthreads();
+    int far = 0;
+    for (int p = bs + tid; p < be; p += 256)
+    {
+        const int64_t rel = int64_t(colind[p]) - origin;
+        if (rel < 0 || rel >= int64_t(kWinLines) * 16)
+            far++;
+        else
+            atomicOr(&bits[rel >> 9], 1u << ((rel >> 4) & 31));
+    }
+    if (far)
+        atomicAdd(&s_far, far);
+    __syncthreads();
+    if (tid == 0)
+        s_n = win_find_runs(bits, rs, re);
+    __syncthreads();
+    const int nruns = s_n;  // entries per run
+    if (nruns > 0)
+        for (int p = bs + tid; p < be; p += 256)
+        {
+            const int64_t rel = int64_t(colind[p]) - origin;
+            if (rel < 0 || rel >= int64_t(kWinLines) * 16)
+                continue;
+            atomicAdd(&cnt[win_run_of(rs, nruns, int(rel >> 4))], 1);
+        }
+    __syncthreads();
+    if (tid == 0)
+        win_select(nruns, rs, re, cnt, origin, n_cols, cap_doubles, be - bs, s_far, wtab + size_t(lb) * kWinRec);
+}
+
+// The same table from HOST arrays, one block after the other (mispec_csr_windows_host: the CPU tests run the selection code the
+// device runs, and the GPU tests require the device's table to equal this one).
+void build_windows_host(int64_t nrows, int64_t n_cols, int64_t row_begin, const int32_t* rowptr, const int32_t* colind, int32_t* wtab)
+{
+    const int64_t nblocks = (nrows + 255) / 256;
+    std::vector<uint32_t> bits(static_cast<size_t>(kWinWords));
+    std::vector<int> rs(static_cast<size_t>(kWinRuns)), re(static_cast<size_t>(kWinRuns)), cnt(static_cast<size_t>(kWinRuns));
+    for (int64_t lb = 0; lb < nblocks; lb++)
+    {
+        const int64_t row0 = lb * 256;
+        const int64_t r1 = std::min<int64_t>(nrows, row0 + 256);
+        const int bs = rowptr[row0], be = rowptr[r1];
+        const int64_t origin = win_origin(row_begin, row0);
+        std::fill(bits.begin(), bits.end(), 0u);
+        std::fill(cnt.begin(), cnt.end(), 0);
+        int far = 0;
+        for (int p = bs; p < be; p++)
+        {
+            const int64_t rel = int64_t(colind[p]) - origin;
+            if (rel < 0 || rel >= int64_t(kWinLines) * 16)
+                far++;
+            else
+                bits[size_t(rel >> 9)] |= 1u << ((rel >> 4) & 31);
+        }
+        const int nruns = win_find_runs(bits.data(), rs.data(), re.data());
+        if (nruns > 0)
+            for (int p = bs; p < be; p++)
+            {
+                const int64_t rel = int64_t(colind[p]) - origin;
+                if (rel < 0 || rel >= int64_t(kWinLines) * 16)
+                    continue;
+                cnt[size_t(win_run_of(rs.data(), nruns, int(rel >> 4)))]++;
+            }
+        win_select(nruns, rs.data(), re.data(), cnt.data(), origin, n_cols, kWinCapMax, be - bs, far, wtab + size_t(lb) * kWinRec);
     }
 }
 
@@ -2585,6 +2657,15 @@ extern "C" int mispec_csr_windows_info(const mispec_csr* A, int64_t* blocks, int
             *covered_entries = A->wtab.p ? A->win_covered : 0;
         if (lds_doubles)
             *lds_doubles = A->wtab.p ? A->win_lds_doubles : 0;
+    });
+}
+extern "C" int mispec_csr_windows_host(int64_t n_rows, int64_t n_cols, int64_t row_begin, const int32_t* rowptr, const int32_t* colind,
+                                       int32_t* records_out)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(n_rows >= 0 && n_cols >= 0 && rowptr && records_out && (colind || rowptr[n_rows] == rowptr[0]),
+                       "mispec_csr_windows_host: bad argument");
+        build_windows_host(n_rows, n_cols, row_begin, rowptr, colind, records_out);
     });
 }
 extern "C" int mispec_csr_windows_in_use(const mispec_csr* A) { return A && A->windows_active() ? 1 : 0; }

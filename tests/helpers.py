@@ -69,3 +69,34 @@ def wanted_by_rule(evals_all, rule, k):
         hi = (k + 1) // 2
         return np.sort(np.concatenate([ev[-hi:], ev[:k - hi]]))
     raise ValueError(rule)
+
+
+def check_window_records(T, S, row_begin=0):
+    """Invariants of the x-window records of the int32 CSR kernel (include/mispec.h mispec_csr_windows_table) against the stored
+    matrix S (rows of a shard that starts at global row row_begin; global column indices): windows sorted, disjoint, 128-byte
+    aligned, LDS positions consecutive and even; every entry of a block without the far flag inside a window; the covered count
+    exact.  Returns the number of covered entries."""
+    import numpy as np
+
+    S = S.tocsr()
+    S.sort_indices()
+    n = S.shape[0]
+    covered = 0
+    assert T.shape == ((n + 255) // 256, 32)
+    for b in range(T.shape[0]):
+        rec = T[b]
+        nw, far, total = int(rec[0] & 255), int(rec[0] >> 8), int(rec[1])
+        st, ad, en = rec[4:12].astype(np.int64), rec[12:20].astype(np.int64), rec[20:28].astype(np.int64)
+        cols = S.indices[S.indptr[b * 256]: S.indptr[min(n, (b + 1) * 256)]].astype(np.int64)
+        inside = np.zeros(cols.size, bool)
+        base = 0
+        assert 0 <= nw <= 8 and total <= 6144, (b, rec)
+        for w in range(nw):
+            assert st[w] % 16 == 0 and st[w] + ad[w] == base and en[w] > st[w] and (w == 0 or st[w] >= en[w - 1]), (b, rec)
+            base += en[w] - st[w]
+            inside |= (cols >= st[w]) & (cols < en[w])
+        assert base == total and total % 2 == 0 and np.all(st[nw:] == 0x3FFFFFFF), (b, rec)
+        assert int(inside.sum()) == rec[2] and (far or inside.all()), (b, rec)
+        assert nw > 0 or far, (b, rec)
+        covered += int(inside.sum())
+    return covered

@@ -10,6 +10,7 @@ import scipy.sparse as sp
 import oracle as O
 import spectra_amd as sa
 from spectra_amd import workloads
+from helpers import check_window_records
 
 pytestmark = [pytest.mark.gpu, pytest.mark.operator_only]
 
@@ -53,29 +54,14 @@ def both_kernels(op, A, seeds=(0, 1), expect_windows=True):
 
 
 def check_table(op, S):
-    """Invariants of the window records (include/mispec.h mispec_csr_windows_table) against the stored matrix S: windows sorted,
-    disjoint, 128-byte aligned, LDS positions consecutive; every entry of a block without the far flag inside a window; the
-    covered count exact."""
+    """The device's table: the records' invariants against the stored matrix S, and equality with the table the HOST builds from
+    the same arrays with the same selection code (mispec_csr_windows_host)."""
     T = op.windows_table()
-    S = S.tocsr()
-    S.sort_indices()
-    n = S.shape[0]
-    covered = 0
-    for b in range(T.shape[0]):
-        rec = T[b]
-        nw, far, total = int(rec[0] & 255), int(rec[0] >> 8), int(rec[1])
-        st, ad, en = rec[4:12].astype(np.int64), rec[12:20].astype(np.int64), rec[20:28].astype(np.int64)
-        cols = S.indices[S.indptr[b * 256]: S.indptr[min(n, (b + 1) * 256)]].astype(np.int64)
-        inside = np.zeros(cols.size, bool)
-        base = 0
-        for w in range(nw):
-            assert st[w] % 16 == 0 and st[w] + ad[w] == base and en[w] > st[w] and (w == 0 or st[w] >= en[w - 1]), (b, rec)
-            base += en[w] - st[w]
-            inside |= (cols >= st[w]) & (cols < en[w])
-        assert base == total and total % 2 == 0 and np.all(st[nw:] == 0x3FFFFFFF), (b, rec)
-        assert int(inside.sum()) == rec[2] and (far or inside.all()), (b, rec)
-        covered += int(inside.sum())
+    covered = check_window_records(T, S)
     assert covered == op.windows_info()["covered_entries"]
+    Sc = S.tocsr()
+    Sc.sort_indices()
+    assert np.array_equal(T, sa.windows_host(Sc))
 
 
 def local_random(n, per_row, spread, seed, far=0):
