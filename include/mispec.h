@@ -231,8 +231,12 @@ int mispec_spmv_time(const mispec_csr* A, const double* x_dev, double* y_dev, in
  * half-bandwidth is <= 8 (any n; top level factored on the device) or <= 64 with n > 4096 (longer chunks, levels
  * factored on the host; sigma may lie inside the spectrum: tiny pivots are boosted and set_shift
  * calibrates the iterative-refinement steps each solve then performs, mispec_symshift_refinement_info), a dense
- * LU inverse + GEMV when n <= 4096 (the reference's own test fixtures); other sparsity patterns are rejected
- * by set_shift (MISPEC_EINVAL).  Input: one triangle of a compressed matrix, as for mispec_csr_from_triangle.
+ * LU inverse + GEMV when n <= 4096 (the reference's own test fixtures).  A matrix beyond the dense limit whose band is too
+ * wide AS IT COMES is reordered at construction (reverse Cuthill-McKee on the pattern, as the reference's sparse factorisations
+ * order theirs) and takes the banded path when the reordered half-bandwidth is <= 64 — a banded matrix in a scattering row
+ * order, path- / ladder-like graphs; solves and eigenvectors keep the caller's index order (mispec_symshift_bandwidth reports both
+ * widths; MISPEC_REORDER=none opts out).  Other sparsity patterns are rejected by set_shift (MISPEC_EINVAL).
+ * Input: one triangle of a compressed matrix, as for mispec_csr_from_triangle.
  * ------------------------------------------------------------------------- */
 typedef struct mispec_symshift mispec_symshift;
 int mispec_symshift_create(mispec_ctx* ctx, int64_t n, const int32_t* outer_host, const int32_t* inner_host,
@@ -250,6 +254,8 @@ int mispec_symshift_create_general(mispec_ctx* ctx, int64_t n, const int32_t* ou
                                    const double* val_host, int row_major, mispec_symshift** out);
 int mispec_symshift_destroy(mispec_symshift* S);
 int64_t mispec_symshift_rows(const mispec_symshift* S);
+/* half-bandwidth of the matrix as given, of the matrix as stored (after the ordering, if one was adopted), and whether it is stored reordered */
+int mispec_symshift_bandwidth(const mispec_symshift* S, int64_t* as_given, int64_t* stored, int* reordered);
 /* The levels the banded path plans for an n x n matrix of this half-bandwidth (host arithmetic only): per level rows, half-bandwidth
  * (2b - 1 of the level above), chunk length, chunk count; the last level (one chunk) is the dense one.  Returns the number of
  * levels (arrays hold up to max_levels entries, may be NULL), 0 when the dense path is taken, MISPEC_EINVAL when unsupported. */

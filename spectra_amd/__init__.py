@@ -486,6 +486,13 @@ class SparseSymShiftSolve:
     def set_shift(self, sigma):
         check(lib().mispec_symshift_set_shift(self.h, float(sigma)))
 
+    def bandwidth_info(self):
+        """{as_given, stored, reordered}: half-bandwidth of the matrix as it came and as it is stored (reverse Cuthill-McKee at
+        construction when the band is too wide as given, include/mispec.h mispec_symshift_bandwidth)."""
+        a, b, r = C.c_int64(0), C.c_int64(0), C.c_int(0)
+        check(lib().mispec_symshift_bandwidth(self.h, C.byref(a), C.byref(b), C.byref(r)))
+        return {"as_given": a.value, "stored": b.value, "reordered": bool(r.value)}
+
     def refinement_info(self):
         """Banded path: {refine_steps, boosted_pivots, min_pivot_ratio, probe_backward_error} of the last set_shift()."""
         st, bo, mr, om = C.c_int(0), C.c_int64(0), C.c_double(0.0), C.c_double(0.0)

@@ -102,6 +102,7 @@ SIGNATURES = {
     "mispec_symshift_create": (C.c_int, [_vp, C.c_int64, _ip, _ip, _dp, C.c_char, C.c_int, _vpp]),
     "mispec_symshift_destroy": (C.c_int, [_vp]),
     "mispec_symshift_rows": (C.c_int64, [_vp]),
+    "mispec_symshift_bandwidth": (C.c_int, [_vp, _lp, _lp, C.POINTER(C.c_int)]),
     "mispec_csr_tiles_info": (C.c_int, [_vp, _lp, _lp, _lp, _lp]),
     "mispec_csr_staged_info": (C.c_int, [_vp, _lp, _lp, _lp, _lp]),
     "mispec_csr_reorder": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),

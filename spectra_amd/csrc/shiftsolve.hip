@@ -26,6 +26,7 @@
 //     pivoting of the dense A - sigma I on the host, explicit inverse, and a dense GEMV kernel per step.
 // Anything else (large n with large bandwidth) is rejected: a general sparse LU on the GPU is out of scope.
 #include "shiftsolve.hpp"
+#include "reorder.hpp"
 #include "dense.hpp"
 
 #include <algorithm>
@@ -1811,6 +1812,41 @@ void calibrate_refinement(mispec_symshift& S, const FactorStats& fs)
 
 namespace mispec {
 
+namespace {
+__global__ __launch_bounds__(256) void k_ss_gather(int64_t n, const int32_t* __restrict__ perm, const double* __restrict__ src,
+                                                   double* __restrict__ dst)
+{
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n)
+        dst[i] = src[perm[i]];
+}
+__global__ __launch_bounds__(256) void k_ss_scatter(int64_t n, const int32_t* __restrict__ perm, const double* __restrict__ src,
+                                                    double* __restrict__ dst)
+{
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n)
+        dst[perm[i]] = src[i];
+}
+void to_stored_order(const mispec_symshift& S, const double* src, double* dst)
+{
+    hipLaunchKernelGGL(k_ss_gather, dim3(unsigned((S.n + 255) / 256)), dim3(256), 0, S.ctx->stream, S.n, S.perm_dev.p, src, dst);
+    MISPEC_HIP(hipGetLastError());
+}
+void from_stored_order(const mispec_symshift& S, const double* src, double* dst)
+{
+    hipLaunchKernelGGL(k_ss_scatter, dim3(unsigned((S.n + 255) / 256)), dim3(256), 0, S.ctx->stream, S.n, S.perm_dev.p, src, dst);
+    MISPEC_HIP(hipGetLastError());
+}
+void perm_scratch(const mispec_symshift& S)
+{
+    if (S.perm_x.n < size_t(S.n))
+    {
+        S.perm_x.alloc(size_t(S.n));
+        S.perm_y.alloc(size_t(S.n));
+    }
+}
+}  // namespace
+
 void launch_shiftsolve(const mispec_symshift& S, const double* x_dev, double* y_dev)
 {
     if (!S.factored)
@@ -1819,9 +1855,20 @@ void launch_shiftsolve(const mispec_symshift& S, const double* x_dev, double* y_
         launch_row_gemv(*S.ctx, S.inverse.p, S.n, S.n, S.n, x_dev, y_dev);
     else
     {
-        solve_level(*S.ctx, *S.top, x_dev, y_dev);
+        const double* x = x_dev;
+        double* y = y_dev;
+        if (S.reordered())  // the caller's index order is kept: x -> stored order, solve with P (A - sigma B) P', y back
+        {
+            perm_scratch(S);
+            to_stored_order(S, x_dev, S.perm_x.p);
+            x = S.perm_x.p;
+            y = S.perm_y.p;
+        }
+        solve_level(*S.ctx, *S.top, x, y);
         for (int it = 0; it < S.refine_steps; it++)
-            refine_once(S, x_dev, y_dev);
+            refine_once(S, x, y);
+        if (S.reordered())
+            from_stored_order(S, S.perm_y.p, y_dev);
     }
 }
 
@@ -1832,6 +1879,23 @@ void launch_band_cholesky_solve(const mispec_symshift& S, bool upper, const doub
 {
     if (!S.factored || S.dense || !S.cholesky_ready)
         throw Error(MISPEC_ELOGIC, "SparseCholesky (banded): the factorisation is not available");
+    if (S.reordered())
+    {
+        // G G' = P B P', so B = (P'G)(P'G)': the factor the generalized solver works with is P'G — (P'G)^{-1} x = G^{-1} (P x),
+        // (P'G)^{-T} x = P' (G^{-T} x)
+        perm_scratch(S);
+        if (upper)
+        {
+            chol_backward(*S.ctx, *S.top, x_dev, S.perm_y.p);
+            from_stored_order(S, S.perm_y.p, y_dev);
+        }
+        else
+        {
+            to_stored_order(S, x_dev, S.perm_x.p);
+            chol_forward(*S.ctx, *S.top, S.perm_x.p, y_dev);
+        }
+        return;
+    }
     if (upper)
         chol_backward(*S.ctx, *S.top, x_dev, y_dev);
     else
@@ -1889,17 +1953,87 @@ int symshift_create_impl(mispec_ctx* ctx, int64_t n, const TriangleInput& A, con
                 S->half_bandwidth = std::max<int64_t>(S->half_bandwidth, r - c);
                 countB++;
             });
+        S->half_bandwidth_as_given = S->half_bandwidth;
+        std::vector<int32_t> inv;  // old -> new when the matrix is reordered
+        if (!band_path(n, S->half_bandwidth) && n > kMaxDense && n < (int64_t(1) << 31) &&
+            !(getenv("MISPEC_REORDER") && std::string(getenv("MISPEC_REORDER")) == "none"))
+        {
+            // Too wide for the band kernels as it comes and too large for the dense path: try a bandwidth-reducing ordering
+            // (reverse Cuthill-McKee on the pattern of A (+ B)) before giving up — the reference's SparseLU / SimplicialLDLT
+            // order their matrix too.  Adopted only if the reordered band fits the kernels.
+            std::vector<int32_t> rp(size_t(n) + 1, 0);
+            const auto count = [&](int64_t r, int64_t c, double) {
+                if (r != c)
+                {
+                    rp[size_t(r) + 1]++;
+                    rp[size_t(c) + 1]++;
+                }
+            };
+            for_each_entry(A, n, count);
+            if (B)
+                for_each_entry(*B, n, count);
+            for (int64_t i = 0; i < n; i++)
+                rp[size_t(i) + 1] += rp[size_t(i)];
+            std::vector<int32_t> ci(static_cast<size_t>(rp[size_t(n)]));
+            std::vector<int32_t> fill(rp.begin(), rp.end() - 1);
+            const auto place = [&](int64_t r, int64_t c, double) {
+                if (r != c)
+                {
+                    ci[size_t(fill[size_t(r)]++)] = int32_t(c);
+                    ci[size_t(fill[size_t(c)]++)] = int32_t(r);
+                }
+            };
+            for_each_entry(A, n, place);
+            if (B)
+                for_each_entry(*B, n, place);
+            std::vector<int32_t> perm;
+            ReorderStats st;
+            if (rcm_order(n, rp.data(), ci.data(), true, 0.0, perm, &st) && int64_t(perm.size()) == n)
+            {
+                inv.assign(size_t(n), 0);
+                for (int64_t i = 0; i < n; i++)
+                    inv[size_t(perm[size_t(i)])] = int32_t(i);
+                int64_t hb = 0;
+                const auto width = [&](int64_t r, int64_t c, double) { hb = std::max<int64_t>(hb, std::llabs(int64_t(inv[size_t(r)]) - int64_t(inv[size_t(c)]))); };
+                for_each_entry(A, n, width);
+                if (B)
+                    for_each_entry(*B, n, width);
+                if (band_path(n, hb))
+                {
+                    S->half_bandwidth = hb;
+                    S->perm_host = perm;
+                }
+                else
+                    inv.clear();
+            }
+        }
         if (band_path(n, S->half_bandwidth))
         {
             // ... then, for a band, the band itself (assembled once; every set_shift() starts from it)
             S->band_b = int(std::max<int64_t>(1, std::min<int64_t>(S->half_bandwidth, n - 1)));  // a diagonal matrix: width 1, zeros
             const size_t bw = size_t(S->band_b) + 1;
             S->band0.assign(size_t(n) * bw, 0.0);
-            for_each_entry(A, n, [&](int64_t r, int64_t c, double v) { S->band0[size_t(r) * bw + size_t(r - c)] += v; });
+            // (r >= c in the caller's order; in the stored order the larger index is the row)
+            const auto at = [&](int64_t r, int64_t c) {
+                if (!inv.empty())
+                {
+                    const int64_t R = inv[size_t(r)], C = inv[size_t(c)];
+                    r = std::max(R, C);
+                    c = std::min(R, C);
+                }
+                return size_t(r) * bw + size_t(r - c);
+            };
+            for_each_entry(A, n, [&](int64_t r, int64_t c, double v) { S->band0[at(r, c)] += v; });
             if (B)
             {
                 S->bandB0.assign(size_t(n) * bw, 0.0);
-                for_each_entry(*B, n, [&](int64_t r, int64_t c, double v) { S->bandB0[size_t(r) * bw + size_t(r - c)] += v; });
+                for_each_entry(*B, n, [&](int64_t r, int64_t c, double v) { S->bandB0[at(r, c)] += v; });
+            }
+            if (!S->perm_host.empty())
+            {
+                ctx->make_current();
+                S->perm_dev.alloc(size_t(n));
+                MISPEC_HIP(hipMemcpy(S->perm_dev.p, S->perm_host.data(), size_t(n) * sizeof(int32_t), hipMemcpyHostToDevice));
             }
             if (factored_on_device(n, S->band_b))
             {
@@ -2010,6 +2144,18 @@ extern "C" int mispec_symshift_destroy(mispec_symshift* S)
 }
 
 extern "C" int64_t mispec_symshift_rows(const mispec_symshift* S) { return S ? S->n : 0; }
+extern "C" int mispec_symshift_bandwidth(const mispec_symshift* S, int64_t* as_given, int64_t* stored, int* reordered)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(S, "mispec_symshift_bandwidth: NULL argument");
+        if (as_given)
+            *as_given = S->half_bandwidth_as_given;
+        if (stored)
+            *stored = S->half_bandwidth;
+        if (reordered)
+            *reordered = S->reordered() ? 1 : 0;
+    });
+}
 
 // The levels the banded path plans for an n x n matrix of the given half-bandwidth (no device needed): rows, half-bandwidth,
 // chunk length and chunk count per level, the last level (one chunk) being the dense one.  Returns the number of levels, 0 when
@@ -2167,8 +2313,8 @@ extern "C" int mispec_symshift_set_shift(mispec_symshift* S, double sigma)
         }
         else
             throw Error(MISPEC_EINVAL,
-                        "SparseSymShiftSolve: only banded matrices (half-bandwidth <= 64) or n <= 4096 are supported on the GPU "
-                        "(the reference uses a general sparse LU)");
+                        "SparseSymShiftSolve: only banded matrices (half-bandwidth <= 64 as given or after a reverse Cuthill-McKee "
+                        "ordering) or n <= 4096 are supported on the GPU (the reference uses a general sparse LU)");
         S->factored = true;
     });
 }

@@ -53,6 +53,14 @@ struct mispec_symshift
     long long negative_pivots = 0;
     double probe_backward_error = 0.0;  // of the calibrated solve
     mutable mispec::DevBuf<double> ref_r, ref_dy;
+    // Reordered at construction (round 5): a matrix beyond the dense limit whose band is too wide as it comes, but narrow after a
+    // reverse Cuthill-McKee ordering (a banded matrix in a scattering row order, a path- or ladder-like graph), is stored as
+    // P (A - sigma B) P' with (P x)[i] = x[perm[i]]; the solves keep the caller's index order (gather, solve, scatter).
+    std::vector<int32_t> perm_host;     // new -> old; empty: not reordered
+    mispec::DevBuf<int32_t> perm_dev;
+    mutable mispec::DevBuf<double> perm_x, perm_y;
+    int64_t half_bandwidth_as_given = 0;
+    bool reordered() const { return perm_dev.p != nullptr; }
     ~mispec_symshift();
 };
 

@@ -179,6 +179,25 @@ def test_banded_cholesky_beyond_the_dense_limit(ctx, n, b):
     assert sa.SparseCholesky(sp.tril(notpd).tocsc(), ctx=ctx).info() == sa.CompInfo.NumericalIssue
 
 
+def test_banded_cholesky_of_a_scrambled_matrix(ctx):
+    # round 5: a banded B in a scattering row order is reordered at construction (reverse Cuthill-McKee); the factor the solver
+    # works with is then P'G with G G' = P B P' — (P'G)^{-1} x = G^{-1} P x, (P'G)^{-T} x = P' G^{-T} x: the same identities hold
+    import scipy.sparse.linalg as spla
+
+    n, b = 30_000, 4
+    q = np.random.default_rng(3).permutation(n)
+    B = banded_pd(n, b, seed=5)[q][:, q].tocsc()
+    Bop = sa.SparseCholesky(sp.tril(B).tocsc(), ctx=ctx)
+    assert Bop.info() == sa.CompInfo.Successful
+    x = np.random.default_rng(1).uniform(-1, 1, n)
+    u = Bop.lower_triangular_solve(x)
+    z = Bop.upper_triangular_solve(u)
+    ref = spla.splu(B).solve(x)
+    assert np.abs(z - ref).max() <= 1e-11 * np.abs(ref).max()
+    w = Bop.lower_triangular_solve(B @ Bop.upper_triangular_solve(x))
+    assert np.abs(w - x).max() <= 1e-11 and abs(u @ u - x @ ref) <= 1e-11 * abs(x @ ref)
+
+
 def test_cholesky_mode_on_a_large_banded_pencil(ctx):
     # SymGEigsSolver<SparseSymMatProd, SparseCholesky, GEigsMode::Cholesky> at n = 200 000 (was limited to 4096): against
     # the regular-inverse mode of the same pencil (another algorithm: B^{-1} A with B-inner products) and scipy

@@ -81,6 +81,62 @@ def test_wide_band_with_an_interior_shift(ctx):
     assert np.abs(y - ref).max() <= 1e-8 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.operator_only
+@pytest.mark.parametrize("case", ["scrambled_band", "ladder", "scrambled_wide_band"])
+def test_matrices_that_are_banded_after_reordering(ctx, case):
+    # Round 5: a matrix beyond the dense limit whose band is too wide AS IT COMES is reordered at construction (reverse
+    # Cuthill-McKee, as the reference's sparse factorisations order theirs — MatOp/SparseSymShiftSolve.h:85-109 takes any sparse
+    # matrix) and takes the banded path when that makes its half-bandwidth <= 64; the solves keep the caller's order.
+    rng = np.random.default_rng(11)
+    if case == "ladder":
+        # a 3 x m grid numbered along the SHORT side last: vertex (i, j) -> i * m + j, so vertical neighbours are m apart
+        m = 20_000
+        n = 3 * m
+        idx = np.arange(n).reshape(3, m)
+        r = np.concatenate([idx[:, :-1].ravel(), idx[:-1, :].ravel()])
+        c = np.concatenate([idx[:, 1:].ravel(), idx[1:, :].ravel()])
+        W = sp.coo_matrix((rng.uniform(-0.5, 0.5, r.size), (r, c)), shape=(n, n))
+        A = (W + W.T + sp.diags(rng.uniform(3.0, 4.0, n))).tocsc()
+        wide = m
+    else:
+        n, b = (50_000, 3) if case == "scrambled_band" else (30_000, 20)
+        q = rng.permutation(n)
+        A = banded_spd(n, b, seed=7)[q][:, q].tocsc()
+        wide = 1000
+    op = sa.SparseSymShiftSolve(sp.tril(A).tocsc(), ctx=ctx)
+    info = op.bandwidth_info()
+    assert info["reordered"] and info["as_given"] >= wide and info["stored"] <= 64, info
+    for sigma in (0.0, -1.0):
+        op.set_shift(sigma)
+        M = (A - sigma * sp.identity(n)).tocsc()
+        x = rng.uniform(-1, 1, n)
+        y = op.perform_op(x)
+        assert np.linalg.norm(M @ y - x) <= 1e-12 * np.linalg.norm(x)
+        ref = spla.splu(M).solve(x)
+        assert np.abs(y - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+
+
+def test_shift_invert_solver_on_a_scrambled_banded_matrix(ctx):
+    # the eigenpairs of Q' A Q (a banded matrix in a random row order) through SymEigsShiftSolver: the eigenvalues of A, the
+    # eigenvectors in the caller's (scrambled) order
+    n, b, k, m, sigma = 40_000, 3, 6, 20, 0.0
+    rng = np.random.default_rng(5)
+    A = banded_spd(n, b, seed=2)
+    q = rng.permutation(n)
+    B = A[q][:, q].tocsc()
+    plain = sa.SymEigsShiftSolver(sa.SparseSymShiftSolve(sp.tril(A).tocsc(), ctx=ctx), k, m, sigma)
+    plain.init()
+    assert plain.compute(sa.SortRule.LargestMagn, 1000, 1e-11) == k
+    opq = sa.SparseSymShiftSolve(sp.tril(B).tocsc(), ctx=ctx)
+    assert opq.bandwidth_info()["reordered"]
+    scr = sa.SymEigsShiftSolver(opq, k, m, sigma)
+    scr.init()
+    assert scr.compute(sa.SortRule.LargestMagn, 1000, 1e-11) == k
+    ev, X = scr.eigenvalues(), scr.eigenvectors()
+    assert np.abs(np.sort(ev) - np.sort(plain.eigenvalues())).max() <= 1e-10
+    assert np.abs(B @ X - X * ev).max() <= 1e-9 and np.abs(X.T @ X - np.eye(k)).max() <= 1e-10
+
+
 def test_dense_path_and_failures(ctx):
     A, S = sparse_fixture(100, 0.1)
     op = sa.SparseSymShiftSolve(A, ctx=ctx)            # random pattern: full bandwidth -> dense inverse
