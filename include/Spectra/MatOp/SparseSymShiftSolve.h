@@ -4,7 +4,7 @@
 //
 // The reference factors A - sigma I with Eigen::SparseLU (general sparse, CPU).  Here set_shift() builds a
 // factorisation whose SOLVE runs on the GPU (spectra_amd/csrc/shiftsolve.hip): a recursive partitioned banded
-// LDL' when the half-bandwidth of A is <= 8 (any n) or <= 64 with n > 4096 (csrc/shiftsolve.hpp band_path), or a dense inverse when n <= 4096; other patterns throw
+// LDL' when the half-bandwidth of A — as given, or after the reverse Cuthill-McKee ordering the constructor tries for wider patterns — is <= 8 (any n) or <= 64 with n > 4096 (csrc/shiftsolve.hpp band_path), or a dense inverse when n <= 4096; other patterns throw
 // std::invalid_argument at set_shift().  The solver binds the device operator directly; perform_op() keeps the
 // reference's host-pointer contract for everybody else.
 #ifndef MISPEC_SPECTRA_SPARSE_SYM_SHIFT_SOLVE_H
