@@ -61,6 +61,7 @@ private:
     RealMatrix m_ritz_vec;          // Ritz vectors of H for the nev wanted values (ncv x nev)
     RealVector m_ritz_est;          // last row of the eigenvector matrix of H
     std::vector<char> m_ritz_conv;  // convergence flags of the wanted values
+    bool m_ritz_vec_current = false;  // m_ritz_vec belongs to the current H (it is formed after the last iteration only)
     CompInfo m_info;
 
     // LIMIT of this implementation (not of the reference): the device factorisation holds at most 1024 basis vectors, so a
@@ -75,9 +76,25 @@ private:
     }
 
     // Ritz pairs of H, wanted ones first (reference :205-224)
-    void retrieve_ritzpair(SortRule selection)
+    // with_vectors == false (the iterations of compute()): the Ritz values and the last components of their vectors — all that
+    // the convergence test and the choice of the shifts need; the m x nev matrix of Ritz vectors is formed once, after the last
+    // iteration, from the same H (same values, same order: the eigen-decomposition is deterministic).
+    void retrieve_ritzpair(SortRule selection, bool with_vectors = true)
     {
         RealVector evals;
+        if (!with_vectors)
+        {
+            RealVector last_row;
+            m_fac.ritz_values(evals, last_row);
+            const std::vector<Index> ind = argsort(selection, evals.data(), m_ncv);
+            for (Index i = 0; i < m_ncv; i++)
+            {
+                m_ritz_val[i] = evals[ind[i]];
+                m_ritz_est[i] = last_row[ind[i]];
+            }
+            m_ritz_vec_current = false;
+            return;
+        }
         RealMatrix evecs;
         m_fac.ritz_pairs(evals, evecs);
         const std::vector<Index> ind = argsort(selection, evals.data(), m_ncv);
@@ -89,6 +106,7 @@ private:
         for (Index i = 0; i < m_nev; i++)
             for (Index r = 0; r < m_ncv; r++)
                 m_ritz_vec(r, i) = evecs(r, ind[i]);
+        m_ritz_vec_current = true;
     }
 
     // |last component| * |f| < tol * max(eps^(2/3), |theta|)  (reference :158-175)
@@ -140,7 +158,7 @@ private:
         m_fac.restart_with_shifts(shifts.data(), nshift);
         // back to an ncv-step factorisation
         m_fac.factorize_from(k, m_ncv, m_nmatop);
-        retrieve_ritzpair(selection);
+        retrieve_ritzpair(selection, false);
     }
 
 protected:
@@ -224,7 +242,7 @@ public:
                   SortRule sorting = SortRule::LargestAlge)
     {
         m_fac.factorize_from(1, m_ncv, m_nmatop);
-        retrieve_ritzpair(selection);
+        retrieve_ritzpair(selection, false);
         Index i, nconv = 0;
         for (i = 0; i < maxit; i++)
         {
@@ -233,6 +251,8 @@ public:
                 break;
             restart(nev_adjusted(nconv), selection);
         }
+        if (!m_ritz_vec_current)
+            retrieve_ritzpair(selection, true);  // the Ritz vectors of the final H (what eigenvectors() multiplies V by)
         sort_ritzpair(sorting);
         m_niter += i + 1;
         m_info = (nconv >= m_nev) ? CompInfo::Successful : CompInfo::NotConverging;

@@ -31,6 +31,15 @@ public:
         internal::check(mispec_fac_tridiag_eigen(m_fac.get(), evals.data(), evecs.data()));
     }
 
+    // The Ritz values and the last row of their eigenvector matrix only (the convergence test of an iteration needs no more:
+    // HermEigsBase.h num_converged); bit-identical to what ritz_pairs returns for them.
+    void ritz_values(Vector& evals, Vector& last_row) const
+    {
+        evals.resize(m_m);
+        last_row.resize(m_m);
+        internal::check(mispec_fac_ritz_values(m_fac.get(), evals.data(), last_row.data()));
+    }
+
     // Implicit restart with the given shifts, already in the order they are to be applied
     // (HermEigsBase.h:118-147): per shift QR of H - mu I by Givens rotations, Q <- Q Qi, H <- Qi' H Qi —
     // one LDS-resident kernel — then V <- V Q and the new residual (Arnoldi.h:320-340).

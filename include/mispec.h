@@ -421,6 +421,10 @@ int64_t mispec_fac_local_rows(const mispec_fac* fac);
  * on H(0:ncv,0:ncv) in one workgroup (H and the eigenvector matrix live in LDS).
  * evals_host[ncv], evecs_host[ncv*ncv] col-major (may be NULL). Symmetric factorisations only. */
 int mispec_fac_tridiag_eigen(mispec_fac* fac, double* evals_host, double* evecs_host);
+/* The Ritz values and only the LAST ROW of their eigenvector matrix (m entries each): what the convergence test of an iteration
+ * needs (HermEigsBase.h:158-175); bit-identical to the values and the last row mispec_fac_tridiag_eigen returns — the same
+ * rotations, applied to one row instead of m. */
+int mispec_fac_ritz_values(mispec_fac* fac, double* evals_host, double* last_row_host);
 /* Implicit restart: for each shift mu (already ordered by the caller, HermEigsBase.h:118-121)
  *   TridiagQR::compute(H, mu); Q <- Q*Qi (apply_YQ); H <- Qi' H Qi (matrix_QtHQ)   (HermEigsBase.h:124-147,
  *   UpperHessenbergQR.h:515-598, :383-417, :627-693) — one workgroup, T and Q in LDS —

@@ -160,6 +160,7 @@ SIGNATURES = {
     "mispec_fac_V_dev": (_vp, [_vp, _lp]),
     "mispec_fac_local_rows": (C.c_int64, [_vp]),
     "mispec_fac_tridiag_eigen": (C.c_int, [_vp, _dp, _dp]),
+    "mispec_fac_ritz_values": (C.c_int, [_vp, _dp, _dp]),
     "mispec_fac_restart_sym": (C.c_int, [_vp, _dp, C.c_int]),
     "mispec_fac_compress_V": (C.c_int, [_vp, _dp, _dp, C.c_int]),
     "mispec_fac_restart_gen": (C.c_int, [_vp, C.POINTER(C.c_int), _dp, _dp, C.c_int, C.c_int]),

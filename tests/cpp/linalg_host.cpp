@@ -17,6 +17,7 @@
 #include <complex>
 #include <cstdio>
 #include <random>
+#include <vector>
 
 using namespace Spectra;
 using Matrix = DenseMatrix<double>;
@@ -320,6 +321,31 @@ int main()
         REQUIRE(max_diff(mul(T, X), XD) <= 1e-12);
         REQUIRE(max_diff(mul(X, X, true, false), identity(n)) <= 1e-12);
     }
+    // The eigen-decomposition restricted to ONE row of the eigenvector matrix (mispec_fac_ritz_values: the convergence test of an
+    // iteration needs the last row only): `lanes` names the rows the rotations are applied to, so {m - 1, 1} must give the
+    // eigenvalues and the last row of the full run bit for bit — at the solver's sizes and on a degenerate matrix.
+    for (int m : {1, 2, 3, 20, 40, 64, 100})
+        for (int kind = 0; kind < 2; kind++)
+        {
+            std::vector<double> d0(static_cast<std::size_t>(m)), e0(static_cast<std::size_t>(m), 0.0);
+            for (int i = 0; i < m; i++)
+            {
+                d0[static_cast<std::size_t>(i)] = kind ? double(i % 3) : rnd();
+                e0[static_cast<std::size_t>(i)] = (i + 1 < m) ? (kind ? ((i % 4) ? 1e-3 : 0.0) : rnd()) : 0.0;
+            }
+            std::vector<double> d1 = d0, e1 = e0, d2 = d0, e2 = e0;
+            std::vector<double> Q1(static_cast<std::size_t>(m) * m, 0.0), Q2(static_cast<std::size_t>(m) * m, 0.0);
+            for (int i = 0; i < m; i++)
+                Q1[static_cast<std::size_t>(i) * m + i] = Q2[static_cast<std::size_t>(i) * m + i] = 1.0;
+            const int rc1 = mispec::small::tridiag_eigen(m, d1.data(), e1.data(), Q1.data(), m, mispec::small::Lanes{0, 1});
+            const int rc2 = mispec::small::tridiag_eigen(m, d2.data(), e2.data(), Q2.data(), m, mispec::small::Lanes{m - 1, 1});
+            REQUIRE(rc1 == 0 && rc2 == 0);
+            bool same = true;
+            for (int j = 0; j < m; j++)
+                same = same && d1[static_cast<std::size_t>(j)] == d2[static_cast<std::size_t>(j)] &&
+                       Q1[static_cast<std::size_t>(j) * m + (m - 1)] == Q2[static_cast<std::size_t>(j) * m + (m - 1)];
+            REQUIRE(same);
+        }
     // DoubleShiftQR: Q orthogonal, Q'HQ Hessenberg and similar (DoubleShiftQR.h:400-467)
     {
         const double s = 0.3, t = 0.7;
