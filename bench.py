@@ -274,6 +274,19 @@ def flatten_for_the_driver(out):
         flat["orth_frac"] = out["roofline_orth"].get("frac")
     if isinstance(out.get("solve"), dict) and "host_syncs_per_solve" in out["solve"]:
         flat["host_syncs_per_solve"] = out["solve"]["host_syncs_per_solve"]
+    if isinstance(out.get("solve"), dict) and out["solve"].get("host_turn_us") is not None:
+        flat["host_turn_us"] = out["solve"]["host_turn_us"]
+    sp_ = out.get("shard_proxy")
+    if isinstance(sp_, dict) and "us_per_operation" in sp_:
+        for k in ("rows", "us_per_operation", "idle_frac_est", "reduce_us", "host_turn_us", "host_syncs_per_solve", "speedup_8_compute_only"):
+            flat[f"shard_proxy_{k}"] = sp_.get(k)
+    # the three figures a reader of the headline asks for next, flat and at the top level too
+    for name, val in (("value_reference_api", (out.get("value_with_host_eigenvectors") or {}).get("value")),
+                      ("value_reference_flow", (out.get("other_orth_mode") or {}).get("value")
+                       if (out.get("other_orth_mode") or {}).get("orth") == "reference" else None),
+                      ("value_csr_kernel", flat.get("csr_kernel_eigenpairs_per_s"))):
+        out[name] = val
+        flat[name] = val
 
 
 def spmv_block(op, ms, launches, fused, epi_vectors=2.0):
@@ -336,6 +349,62 @@ def in_loop_block(sa, ctx, rop, nev, ncv, rule, tol, restarts=12):
     blk["frac"] = blk["achieved"] / HBM_PEAK_GBPS
     del e
     return blk
+
+
+def shard_proxy(args, ctx, sa, c2_ms_per_op, parts=8):
+    """What ONE rank of an 8-way row-sharded run computes, on this GPU: the same solve on an M-band matrix of n / 8 rows (the
+    wire is not in it: a 1-GPU box cannot measure it).  Un-instrumented wall time per solve and per operator application, the
+    device-busy share (sum of the kernel families' HIP-event times of one more, instrumented solve), the merged record reduction
+    on its own, the host turn of a restart, and the compute-only speed-up 8 ranks would have if the wire were free:
+    (ms per operation at n) / (ms per operation at n / 8)."""
+    rows = args.n // parts
+    sop = sa.SparseSymMatProd.synth_band(rows, ctx=ctx)
+    e = sa.SymEigsSolver(sop, args.nev, args.ncv)
+    e.set_orth_mode(args.orth)
+    rule = sa.SortRule[args.selection]
+
+    def solve():
+        e.init()
+        nc = e.compute(rule, 1000, args.tol)
+        e.eigenvectors(to_host=False)
+        return nc
+
+    solve()
+    t_before = e.turn_info()
+    p_before = e.get_profile()
+    ctx.sync()
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        nconv = solve()
+    ctx.sync()
+    wall_ms = 1e3 * (time.perf_counter() - t0) / reps
+    t_after = e.turn_info()
+    p_after = e.get_profile()
+    nops = int(e.num_operations())
+    e.profile(1)
+    p0 = e.get_profile()
+    solve()
+    p1 = e.get_profile()
+    e.profile(0)
+    fam = {k[3:]: p1[k] - p0[k] for k in p1 if k.startswith("ms_")}
+    busy_ms = sum(v for k, v in fam.items() if k in ("spmv", "vtf", "gemv", "scale", "compress", "small"))
+    n_red = p1["n_reduce"] - p0["n_reduce"]
+    turns = t_after["turns"] - t_before["turns"]
+    out = {"rows": rows, "nconv": int(nconv), "num_operations": nops, "num_iterations": int(e.num_iterations()),
+           "ms_per_solve": wall_ms, "us_per_operation": 1e3 * wall_ms / nops,
+           "busy_ms_per_solve_instrumented": busy_ms, "idle_frac_est": max(0.0, 1.0 - busy_ms / wall_ms),
+           "reduce_us": 1e3 * fam.get("reduce", 0.0) / n_red if n_red else None,
+           "host_turn_us": 1e6 * (t_after["host_seconds"] - t_before["host_seconds"]) / turns if turns else None,
+           "host_syncs_per_solve": (p_after["n_host_sync"] - p_before["n_host_sync"]) / reps,
+           "speedup_8_compute_only": c2_ms_per_op / (wall_ms / nops) if c2_ms_per_op else None,
+           "max_residual": float(e.residuals().max()),
+           "note": "idle_frac_est = 1 - (sum of the kernel families' event times of an instrumented solve) / (wall of the un-instrumented "
+                   "solves): an estimate — the rocprofv3 gap analysis of the same workload is in profiles/ (trace_gaps_1250000_rows); "
+                   "reduce_us is an event pair around the one-kernel record reduction (includes ~2 us of event overhead); host_turn_us = "
+                   "host time between 'state of the finished sweep seen' and 'restart enqueued' (mispec_symeigs_turn_info)"}
+    del e, sop
+    return out
 
 
 def secondary_configs(args, ctx, op, sa):
@@ -711,6 +780,7 @@ def main():
         del full
     resid = eigs.residuals()
     evals = eigs.eigenvalues()
+    turn1 = eigs.turn_info()
     spmv_ms = prof["ms_spmv"] / max(prof["n_spmv"], 1)
     fmt = op.spmv_format()
     oinfo = eigs.orth_info()
@@ -815,6 +885,8 @@ def main():
                 "num_iterations": int(eigs.num_iterations()), "max_residual": float(resid.max()) if len(resid) else None,
                 "lambda_max": float(evals.max()) if len(evals) else None, "lambda_min": float(evals.min()) if len(evals) else None,
                 "host_syncs_per_solve": prof["n_host_sync"] / args.steps,
+                "host_turn_us": (1e6 * turn1["host_seconds"] / turn1["turns"]) if turn1["turns"] else None,
+                "host_turn_copy_fallbacks": turn1["fallbacks"],
                 "orth_info": eigs.orth_info(),
             },
             "other_orth_mode": other_mode,
@@ -860,6 +932,10 @@ def main():
                 out["secondary"] = secondary_configs(args, ctx, op, sa)
             except Exception as e:  # noqa: BLE001 - the headline line must still be printed
                 out["secondary"] = {"error": repr(e)}
+            try:
+                out["shard_proxy"] = shard_proxy(args, ctx, sa, out["ms_per_step"] / max(out["solve"]["num_operations"], 1))
+            except Exception as e:  # noqa: BLE001
+                out["shard_proxy"] = {"error": repr(e)}
             # north_star names a CSR SpMV: the int32 CSR kernel's in-loop figure on the SAME matrix sits next to the headline
             # kernel's, so that a regression of either is visible in the top-level block
             c32 = out["secondary"].get("csr_kernels_same_matrix", {}).get("csr_int32") if isinstance(out["secondary"], dict) else None

@@ -137,11 +137,11 @@ private:
         if (k >= m_ncv)
             return;
         const int m = static_cast<int>(m_ncv);
-        // Where the ncv x ncv sweeps run: MISPEC_SMALL=device applies the whole shift list in one LDS-resident kernel
+        // Where the ncv x ncv sweeps run: the option small=device (mispec_set_option) applies the whole shift list in one LDS-resident kernel
         // (ncv <= 96, spectra_amd/csrc/small.hip k_hess_restart; H and Q never leave the device between the sweeps and
         // V <- V Q); the default is the host (same arithmetic, internal/SmallDenseGen.h) because one wavefront stepping
         // through a serial chain of reflectors is slower than one host core at these sizes (DESIGN.md 3.4 has the numbers).
-        static const char* where = std::getenv("MISPEC_SMALL");
+        const char* where = mispec_get_option("small");
         if (where && std::string(where) == "device" && m <= 96)
         {
             std::vector<int> kind;

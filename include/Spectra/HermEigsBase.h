@@ -252,7 +252,21 @@ public:
             restart(nev_adjusted(nconv), selection);
         }
         if (!m_ritz_vec_current)
-            retrieve_ritzpair(selection, true);  // the Ritz vectors of the final H (what eigenvectors() multiplies V by)
+        {
+            // The Ritz vectors of the final H (what eigenvectors() multiplies V by): a second decomposition of the SAME host copy
+            // of H the values-only call above read — nothing between num_converged() and this line may change it (f_norm() only
+            // reads beta; accessors that resolve pending device state, get_H / get_f, are not called here).  m_ritz_conv comes
+            // from the first call, the vectors from this one: the order must agree, i.e. the values must be the same bits.
+#ifndef NDEBUG
+            const RealVector before = m_ritz_val;
+#endif
+            retrieve_ritzpair(selection, true);
+#ifndef NDEBUG
+            for (Index j = 0; j < m_nev; j++)
+                if (!(before[j] == m_ritz_val[j]))
+                    throw std::logic_error("HermEigsBase: H changed between the convergence test and the Ritz vectors");
+#endif
+        }
         sort_ritzpair(sorting);
         m_niter += i + 1;
         m_info = (nconv >= m_nev) ? CompInfo::Successful : CompInfo::NotConverging;

@@ -45,6 +45,25 @@ const char* mispec_last_error(void);
 /* "x.y.z (gfx950)" */
 const char* mispec_version(void);
 
+/* Tuning switches and test hooks, by name (value NULL: back to the default).  The library reads no other global state; a name that
+ * has not been set falls back to the environment variable MISPEC_<NAME IN UPPER CASE> — the test-only override the A/B tools
+ * and the parity tests use.  Unknown names: MISPEC_EINVAL.  Names and values:
+ *   orth            onesweep (default) | onesweep-eager | reference      control flow of the Lanczos steps at creation
+ *   one_reduction   1 (default) | 0                                      one reduction per one-sweep step
+ *   orth_kernel     dma (default, >= 65536 rows) | dma2 | dmac | dmap | reg   the one-sweep pass: LDS-DMA ring or registers
+ *   host_turn       fast (default) | copy                                restart's host turn: pinned-memory kernels or hipMemcpy
+ *   small           host (default) | device                              where the ncv x ncv work of a restart runs
+ *   restart_sync    0 (default) | 1                                      synchronising fused restart
+ *   host_steps      0 (default) | 1                                      host-synchronous steps
+ *   spec_corr       corrections enqueued speculatively per step (reference flow)
+ *   overlap, exchange                                                    sharded product: 0 switches the overlap / the neighbour exchange off
+ *   csr_win, csr_win_iters, csr_win_pf, csr_win_nt, dia2, spmv_tiles, spmv_staged, reorder, kernel_probe   SpMV format / kernel choice
+ *   vq              mfma: the f64-MFMA variant of V*Q
+ *   shift           banded shift solve: level plan overrides (tests)
+ * The reference has no counterpart (its only switches are template parameters). */
+int mispec_set_option(const char* name, const char* value);
+const char* mispec_get_option(const char* name);
+
 /* ---------------------------------------------------------------------------
  * Context
  * ------------------------------------------------------------------------- */
@@ -396,6 +415,10 @@ int mispec_fac_orth_info(const mispec_fac* fac, int* mode, int64_t* lagged_steps
  * applies a pending correction first; f_norm() reports sqrt(|f~|^2 - |c|^2) until then.  mispec_fac_restart_info counts the
  * restarts that went the fused way and those that were followed by further corrections. */
 int mispec_fac_restart_info(const mispec_fac* fac, int64_t* fused, int64_t* recorrected);
+/* The host turns of the restarts (HermEigsBase.h:105-155 between two factorize_from calls): how many were timed, the host seconds
+ * between "state of the finished sweep seen" and "restart enqueued" summed over them, and how often the pinned-memory hand-off
+ * fell back to a copy (option host_turn). */
+int mispec_fac_turn_info(const mispec_fac* fac, int64_t* turns, double* host_seconds, int64_t* fallbacks);
 /* How a sharded device matrix moves the Krylov vector before each product: *halo = 1 if only the referenced
  * parts of the other ranks' slices are exchanged point-to-point (recv_doubles of them per product), 0 if the
  * full all-gather is used (or the context is not sharded). */
@@ -453,7 +476,7 @@ int mispec_fac_residuals_complex(mispec_fac* fac, const double* Yre_host, const 
 
 /* Profile of the factorisation so far: counts and accumulated HIP-event time (ms) per kernel family.
  * Timing is only collected between mispec_fac_profile(fac, level) and mispec_fac_profile(fac, 0); level 1 brackets
- * every kernel family with an event pair, level 2 only the operator applications (the SpMV roofline figure) —
+ * every kernel family with an event pair, level 3 the operator applications and the collectives of a sharded run, level 2 only the operator applications (the SpMV roofline figure) —
  * the event records cost a few microseconds each, which matters when the shards are small. */
 typedef struct mispec_profile
 {
@@ -465,6 +488,11 @@ typedef struct mispec_profile
      * compress = V <- V Q and X = V Y; gemv (the correction passes) is not counted — the device decides whether they run.  bytes / ms of the same family = the rate those kernels ran at (the family's event pair
      * also covers its record reduction, ~10 us per launch). */
     double bytes_vtf, bytes_gemv, bytes_compress;
+    /* round 6 (appended): the merged record reduction behind the one-sweep passes timed on its own (level 1; it is also inside
+     * ms_vtf), and — level 3, row-sharded runs — the wire: the exchange of the Krylov vector on its stream, the part of it the
+     * product waits for once the interior row-blocks are done (1 - wait / exchange = the overlap achieved), the all-reduces. */
+    int64_t n_reduce, n_exchange, n_exchange_wait, n_allreduce;
+    double ms_reduce, ms_exchange, ms_exchange_wait, ms_allreduce;
 } mispec_profile;
 int mispec_fac_profile(mispec_fac* fac, int enable);
 int mispec_fac_get_profile(const mispec_fac* fac, mispec_profile* out);
@@ -522,6 +550,7 @@ int mispec_symeigs_set_orth_mode(mispec_symeigs* s, int mode);
 int mispec_symeigs_orth_info(const mispec_symeigs* s, int* mode, int64_t* lagged_steps, int64_t* check_stops,
                              int64_t* state_stops, double* max_rel_c, double* max_chk);
 int mispec_symeigs_restart_info(const mispec_symeigs* s, int64_t* fused, int64_t* recorrected); /* see mispec_fac_restart_info */
+int mispec_symeigs_turn_info(const mispec_symeigs* s, int64_t* turns, double* host_seconds, int64_t* fallbacks); /* see mispec_fac_turn_info */
 int mispec_symeigs_onered_steps(const mispec_symeigs* s, int64_t* steps);                        /* see mispec_fac_onered_steps */
 
 /* ---------------------------------------------------------------------------

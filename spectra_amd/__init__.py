@@ -224,6 +224,16 @@ class Context:
 _default_ctx = None
 
 
+def set_option(name, value=None):
+    """mispec_set_option: a tuning switch / test hook by name (include/mispec.h lists them); value None restores the default."""
+    check(lib().mispec_set_option(name.encode(), None if value is None else str(value).encode()))
+
+
+def get_option(name):
+    v = lib().mispec_get_option(name.encode())
+    return None if v is None else v.decode()
+
+
 def default_context():
     global _default_ctx
     if _default_ctx is None:
@@ -986,6 +996,12 @@ class SymEigsSolver:
                 "state_stops": c.value, "max_rel_c": r.value, "max_chk": k.value, "fused_restarts": fused.value,
                 "fused_recorrected": again.value, "one_reduction_steps": ored.value}
 
+    def turn_info(self):
+        """Host turns of the restarts: count, host seconds between 'sweep state seen' and 'restart enqueued', copy fallbacks."""
+        turns, fb, sec = C.c_int64(0), C.c_int64(0), C.c_double(0.0)
+        check(lib().mispec_symeigs_turn_info(self.h, C.byref(turns), C.byref(sec), C.byref(fb)))
+        return {"turns": turns.value, "host_seconds": sec.value, "fallbacks": fb.value}
+
     def overlap_info(self):
         """(first interior 256-row block, interior blocks, all blocks): what is multiplied while the exchange is in flight."""
         a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
@@ -1537,6 +1553,11 @@ class Factorization:
         fused, again = C.c_int64(0), C.c_int64(0)
         check(lib().mispec_fac_restart_info(self.h, C.byref(fused), C.byref(again)))
         return {"fused_restarts": fused.value, "fused_recorrected": again.value}
+
+    def turn_info(self):
+        turns, fb, sec = C.c_int64(0), C.c_int64(0), C.c_double(0.0)
+        check(lib().mispec_fac_turn_info(self.h, C.byref(turns), C.byref(sec), C.byref(fb)))
+        return {"turns": turns.value, "host_seconds": sec.value, "fallbacks": fb.value}
 
     def compress_V(self, Q, H, new_k):
         Q = np.asfortranarray(Q, dtype=np.float64)

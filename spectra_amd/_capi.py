@@ -45,7 +45,9 @@ class Comm(C.Structure):
 class Profile(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("n_spmv", "n_vtf", "n_gemv", "n_scale", "n_compress", "n_small", "n_host_sync")] + \
                [(n, C.c_double) for n in ("ms_spmv", "ms_vtf", "ms_gemv", "ms_scale", "ms_compress", "ms_small", "spmv_bytes",
-                                             "bytes_vtf", "bytes_gemv", "bytes_compress")]
+                                             "bytes_vtf", "bytes_gemv", "bytes_compress")] + \
+               [(n, C.c_int64) for n in ("n_reduce", "n_exchange", "n_exchange_wait", "n_allreduce")] + \
+               [(n, C.c_double) for n in ("ms_reduce", "ms_exchange", "ms_exchange_wait", "ms_allreduce")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -230,6 +232,10 @@ SIGNATURES = {
     "mispec_fac_set_orth_mode": (C.c_int, [_vp, C.c_int]),
     "mispec_fac_orth_info": (C.c_int, [_vp, C.POINTER(C.c_int), _lp, _lp, _lp, _dp, _dp]),
     "mispec_fac_restart_info": (C.c_int, [_vp, _lp, _lp]),
+    "mispec_fac_turn_info": (C.c_int, [_vp, _lp, _dp, _lp]),
+    "mispec_symeigs_turn_info": (C.c_int, [_vp, _lp, _dp, _lp]),
+    "mispec_set_option": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "mispec_get_option": (C.c_char_p, [C.c_char_p]),
     "mispec_fac_onered_steps": (C.c_int, [_vp, _lp]),
     "mispec_symeigs_onered_steps": (C.c_int, [_vp, _lp]),
     "mispec_symeigs_restart_info": (C.c_int, [_vp, _lp, _lp]),

@@ -137,6 +137,14 @@ struct PinnedBuf
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
+// Tuning switches and test hooks: ONE table, set through mispec_set_option(name, value) (include/mispec.h lists the names).
+// A name that has not been set falls back to the environment variable MISPEC_<NAME IN UPPER CASE> — kept as the test-only
+// override of the A/B tools and the parity tests (VERDICT r05 hygiene item: no getenv() scattered through the kernels' files).
+// Returns nullptr when neither is present.  The pointer stays valid until the option is set again.
+const char* option(const char* name);
+int option_int(const char* name, int dflt);
+bool option_is(const char* name, const char* value);
+
 // malloc for the gigabyte-sized host arrays of the ingest stages (free with std::free).  Throws std::bad_alloc.
 void* big_host_alloc(size_t bytes);
 

@@ -1453,12 +1453,10 @@ void build_dia(mispec_csr& A, const std::vector<int32_t>& dict)
 // the entries get their x from a window; MISPEC_CSR_WIN=0 keeps k_spmv_csr_stream for every matrix.
 void build_windows(mispec_csr& A)
 {
-    static const bool off = [] {
-        const char* e = getenv("MISPEC_CSR_WIN");
-        return e && std::strcmp(e, "0") == 0;
-    }();
+    const bool off = option_is("csr_win", "0");
     const int64_t nloc = A.local_rows();
-    if (off || nloc == 0 || A.nnz == 0 || spmv_rows_per_block() != 256)
+    // (columns at or beyond the start sentinel of unused windows would select a padding window: no table for such a matrix — ADVICE r05)
+    if (off || nloc == 0 || A.nnz == 0 || spmv_rows_per_block() != 256 || A.n_cols > int64_t(kWinPad))
         return;
     const int nblocks = spmv_num_blocks(nloc);
     hipStream_t st = A.ctx->stream;
@@ -1674,9 +1672,9 @@ mispec_csr* upload_rows(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const i
         // at ingest when reverse Cuthill-McKee localises them (reorder.hip)
         // MISPEC_SPMV_TILES = auto (default) | 0 | 1: the column-blocked tile format for scattered patterns that stay
         // scattered (decided below, after the reordering attempt)
-        const char* tmode = getenv("MISPEC_SPMV_TILES");
+        const char* tmode = option("spmv_tiles");
         const bool tiles_off = tmode && std::strcmp(tmode, "0") == 0, tiles_force = tmode && std::strcmp(tmode, "1") == 0;
-        const char* mode = getenv("MISPEC_REORDER");
+        const char* mode = option("reorder");
         const bool off = mode && std::strcmp(mode, "none") == 0;
         const bool force = mode && std::strcmp(mode, "rcm") == 0;
         if (allow_reorder && !off && ctx->world() == 1 && ctx->comm.allgather == nullptr && n_rows == n_cols && p1 > p0)
@@ -1697,7 +1695,7 @@ mispec_csr* upload_rows(mispec_ctx* ctx, int64_t n_rows, int64_t n_cols, const i
             // MISPEC_SPMV_STAGED = auto (default) | 0 | 1: the two-phase format with x and y in LDS (staged.hip).  Since round 4 it is
             // what scattered patterns get (M-rand n = 1e7 in the solver loop: 1.02 ms against 1.45 ms from the tiles); the tiles
             // are then built only on request (MISPEC_SPMV_TILES=1) or when the staged format declines the matrix.
-            const char* smode = getenv("MISPEC_SPMV_STAGED");
+            const char* smode = option("spmv_staged");
             const bool st_off = smode && std::strcmp(smode, "0") == 0, st_force = smode && std::strcmp(smode, "1") == 0;
             const bool scattered = n_cols >= 2 * kFarWindow && far > 0.25;
             bool staged_built = false;
@@ -1976,7 +1974,7 @@ void launch_spmv_raw(const mispec_csr& A, const double* x_dev, double* y_dev, co
         // x staged through LDS windows when the offsets form at most 8 clusters, else direct loads (k_spmv_dia)
         // two rows per thread with 16-byte loads (k_spmv_dia_win2) when the layout and the alignment allow; MISPEC_DIA2=0: the
         // one-row-per-thread kernel
-        static const bool dia2_off = getenv("MISPEC_DIA2") && atoi(getenv("MISPEC_DIA2")) == 0;
+        const bool dia2_off = option_int("dia2", 1) == 0;
         const bool dia2 = !dia2_off && A.dia_win.nc > 0 && A.dia_ld == 0 && A.ndia <= 2 * kDiaGroup &&
                           (reinterpret_cast<uintptr_t>(y_dev) & 15) == 0 &&
                           (!epi || ((reinterpret_cast<uintptr_t>(e.v_rows) & 15) == 0 && (reinterpret_cast<uintptr_t>(e.v_prev) & 15) == 0));
@@ -2144,12 +2142,12 @@ void launch_spmv_raw(const mispec_csr& A, const double* x_dev, double* y_dev, co
             bool nt;
         };
         const auto read_knobs = [] {
-            const char* e_iters = getenv("MISPEC_CSR_WIN_ITERS");
-            const char* e_pf = getenv("MISPEC_CSR_WIN_PF");
-            const char* e_nt = getenv("MISPEC_CSR_WIN_NT");
+            const char* e_iters = option("csr_win_iters");
+            const char* e_pf = option("csr_win_pf");
+            const char* e_nt = option("csr_win_nt");
             return Knobs{e_iters ? atoi(e_iters) : 0, e_pf ? atoi(e_pf) : -1, e_nt && atoi(e_nt) != 0};
         };
-        static const bool probe = getenv("MISPEC_KERNEL_PROBE") != nullptr;
+        const bool probe = option("kernel_probe") != nullptr;
         static const Knobs cached = read_knobs();
         const Knobs knobs = probe ? read_knobs() : cached;
         const int env_iters = knobs.iters, env_pf = knobs.pf;
@@ -2159,7 +2157,8 @@ void launch_spmv_raw(const mispec_csr& A, const double* x_dev, double* y_dev, co
         // 0.412 -> 0.368 ms against the gather kernel on the same box); longer rows take larger chunks (fewer barrier rounds)
         const int auto_iters = double(A.nnz) <= 16.0 * double(nloc) ? 1 : (double(A.nnz) <= 32.0 * double(nloc) ? 2 : 4);
         int iters = env_iters == 1 || env_iters == 2 || env_iters == 4 ? env_iters : auto_iters;
-        while (iters > 1 && size_t(chunk_cap(256) - (4 - iters) * 1024 + 4 + A.win_lds_doubles) * sizeof(double) > 65536)
+        // (64 bytes of margin: the kernel's static `red[4]` shares the 64 KiB with the dynamic allocation — ADVICE r05)
+        while (iters > 1 && size_t(chunk_cap(256) - (4 - iters) * 1024 + 4 + A.win_lds_doubles) * sizeof(double) > 65536 - 64)
             iters >>= 1;  // products + windows within the 64 KiB a launch gets without an attribute
         const bool pf = env_pf >= 0 ? env_pf != 0 : true;
         const int xi = (A.win_lds_doubles + 511) / 512;

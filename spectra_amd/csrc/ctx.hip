@@ -13,6 +13,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <cctype>
 #include <condition_variable>
 #include <exception>
 #include <thread>
@@ -31,6 +32,52 @@ void* big_host_alloc(size_t bytes)
     if (!q)
         throw std::bad_alloc();
     return q;
+}
+
+// ---- options (common.hpp) ----------------------------------------------------------------------------------------------
+namespace {
+struct OptionTable
+{
+    std::mutex mu;
+    std::vector<std::pair<std::string, std::string>> set;  // few entries: a linear scan beats a map
+    // values handed out as const char*: a value that is replaced stays alive (the list only grows by what callers set)
+    std::vector<std::string*> retired;
+};
+OptionTable& option_table()
+{
+    static OptionTable* t = new OptionTable;  // never destroyed: option() may be called from static destructors
+    return *t;
+}
+// every name the library reads (mispec_set_option rejects anything else, so that a typo cannot pass for a measurement)
+const char* const kOptionNames[] = {
+    "csr_win", "spmv_tiles", "reorder", "spmv_staged", "dia2", "csr_win_iters", "csr_win_pf", "csr_win_nt", "kernel_probe",
+    "overlap", "exchange", "small", "spec_corr", "one_reduction", "host_steps", "orth", "restart_sync", "vq", "shift",
+    "reduce", "host_turn", "orth_kernel", "lag_grid", "vq_out_of_place", "shift_fuse", "staged_variant", nullptr};
+}  // namespace
+
+const char* option(const char* name)
+{
+    OptionTable& t = option_table();
+    {
+        std::lock_guard<std::mutex> lock(t.mu);
+        for (auto& kv : t.set)
+            if (kv.first == name)
+                return kv.second.c_str();
+    }
+    std::string env = "MISPEC_";
+    for (const char* c = name; *c; c++)
+        env.push_back(char(std::toupper(static_cast<unsigned char>(*c))));
+    return std::getenv(env.c_str());
+}
+int option_int(const char* name, int dflt)
+{
+    const char* v = option(name);
+    return v ? std::atoi(v) : dflt;
+}
+bool option_is(const char* name, const char* value)
+{
+    const char* v = option(name);
+    return v && std::strcmp(v, value) == 0;
 }
 
 int ingest_threads()
@@ -81,6 +128,30 @@ using namespace mispec;
 
 extern "C" const char* mispec_last_error(void) { return g_last_error.c_str(); }
 extern "C" const char* mispec_version(void) { return "0.1.0 (gfx950)"; }
+
+extern "C" int mispec_set_option(const char* name, const char* value)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(name != nullptr, "mispec_set_option: name is NULL");
+        bool known = false;
+        for (const char* const* k = kOptionNames; *k; k++)
+            known = known || std::strcmp(*k, name) == 0;
+        MISPEC_REQUIRE(known, std::string("mispec_set_option: unknown option '") + name + "'");
+        auto& t = option_table();
+        std::lock_guard<std::mutex> lock(t.mu);
+        for (size_t i = 0; i < t.set.size(); i++)
+            if (t.set[i].first == name)
+            {
+                t.retired.push_back(new std::string(std::move(t.set[i].second)));  // a pointer handed out earlier stays valid
+                t.set.erase(t.set.begin() + long(i));
+                break;
+            }
+        if (value)
+            t.set.emplace_back(name, value);
+    });
+}
+
+extern "C" const char* mispec_get_option(const char* name) { return name ? option(name) : nullptr; }
 
 extern "C" int mispec_ctx_create(int device, void* hip_stream, mispec_ctx** out)
 {

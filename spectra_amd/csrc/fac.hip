@@ -15,6 +15,7 @@
 #include "csr.hpp"
 #include "dense.hpp"
 #include "krylov.hpp"
+#include <chrono>
 #include "cholesky.hpp"
 #include "reginv.hpp"
 #include "shiftsolve.hpp"
@@ -43,6 +44,11 @@ enum Family
     FAM_SCALE,
     FAM_COMPRESS,
     FAM_SMALL,
+    FAM_REDUCE,  // the record reduction behind a one-sweep pass, timed a second time on its own (level 1; also inside FAM_VTF)
+    // profile level 3 ("wire", sharded runs): the exchange on its stream, the part of it the product waits for, the all-reduces
+    FAM_EXCH,
+    FAM_XWAIT,
+    FAM_ALLRED,
     FAM_COUNT
 };
 }  // namespace
@@ -90,6 +96,15 @@ struct mispec_fac
     DevBuf<double> d_H;            // device-driven Arnoldi: the columns of H written by the steps (m x m)
     PinnedBuf<double> h_H;
     PinnedBuf<StepState> h_state;  // its pinned host mirror
+    // Host turn without DMA-engine copies (option host_turn, fetch_state / restart_sym): the sequence word the publishing kernel
+    // writes behind the state, the upload staging of a restart [Q m*m][diag m][subd m], and what the turns cost on the host
+    PinnedBuf<unsigned long long> h_flag;
+    unsigned long long pub_seq = 0;
+    PinnedBuf<double> h_up;
+    int64_t turn_count = 0, turn_fallbacks = 0;
+    double turn_host_s = 0.0;      // host time between "state seen" and "restart enqueued", summed over the restarts
+    std::chrono::steady_clock::time_point turn_t0;
+    bool turn_open = false;
     PinnedBuf<double> h_red, h_small, h_x, h_y;
     PinnedBuf<double> h_stage[2];  // pinned staging of download_columns (allocated on first use)
     hipEvent_t ev_stage[2] = {nullptr, nullptr};
@@ -151,12 +166,12 @@ struct mispec_fac
 
     // profile
     int prof = 0;  // 0 off, 1 every kernel family, 2 only the operator applications
-    int64_t counts[FAM_COUNT] = {0, 0, 0, 0, 0, 0};
+    int64_t counts[FAM_COUNT] = {};
     int64_t n_sync = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[FAM_COUNT];
     std::vector<hipEvent_t> ev_pool;
-    double ms_acc[FAM_COUNT] = {0, 0, 0, 0, 0, 0};
-    double bytes_acc[FAM_COUNT] = {0, 0, 0, 0, 0, 0};  // algorithmic bytes of the n-sized dense kernels (mispec_profile)
+    double ms_acc[FAM_COUNT] = {};
+    double bytes_acc[FAM_COUNT] = {};  // algorithmic bytes of the n-sized dense kernels (mispec_profile)
     void count_bytes(int fam, int vectors) { bytes_acc[fam] += 8.0 * double(nloc) * double(vectors); }
 
     double& Hat(int i, int j) { return H[size_t(j) * m + i]; }
@@ -215,21 +230,24 @@ struct Timed
     mispec_fac& F;
     int fam;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    Timed(mispec_fac& f, int family) : F(f), fam(family)
+    hipStream_t on = nullptr;
+    Timed(mispec_fac& f, int family, hipStream_t other_stream = nullptr) : F(f), fam(family), on(other_stream ? other_stream : f.stream())
     {
         F.counts[fam]++;
-        if (!F.prof || (F.prof == 2 && fam != FAM_SPMV))  // level 2: only the operator applications are timed
+        const bool wire = fam == FAM_EXCH || fam == FAM_XWAIT || fam == FAM_ALLRED;
+        // level 2: only the operator applications are timed; level 3: those and the collectives; level 1: every kernel family
+        if (!F.prof || (F.prof == 2 && fam != FAM_SPMV) || (F.prof == 3 && fam != FAM_SPMV && !wire) || (F.prof != 3 && wire))
             return;
         e0 = take();
         e1 = take();
-        (void) hipEventRecord(e0, F.stream());
+        (void) hipEventRecord(e0, on);
     }
     hipEvent_t take() { return take_event(F); }
     ~Timed()
     {
         if (!F.prof || !e0)
             return;
-        (void) hipEventRecord(e1, F.stream());
+        (void) hipEventRecord(e1, on);
         F.ev[fam].emplace_back(e0, e1);
     }
 };
@@ -255,6 +273,59 @@ void sync_stream(mispec_fac& F)
 {
     MISPEC_HIP(hipStreamSynchronize(F.stream()));
     F.n_sync++;
+}
+
+// option host_turn = fast | copy (default fast): how the state of a finished device-driven sweep reaches the host and how a restart's
+// Q reaches the device.  fast: kernels that write to / read from pinned host memory, the host spins on a sequence word (with
+// the stream's own status as the arbiter: an error or a completed stream without the word falls back to the copy).
+bool fast_host_turn()
+{
+    const char* v = option("host_turn");
+    return !v || std::string(v) != "copy";
+}
+
+// d_state -> *F.h_state, waited for.  One host synchronisation either way (n_sync counts it).
+void fetch_state(mispec_fac& F)
+{
+    StepState& hs = *F.h_state.p;
+    if (!fast_host_turn())
+    {
+        MISPEC_HIP(hipMemcpyAsync(&hs, F.d_state.p, sizeof(StepState), hipMemcpyDeviceToHost, F.stream()));
+        sync_stream(F);
+        F.turn_t0 = std::chrono::steady_clock::now();
+        F.turn_open = true;
+        return;
+    }
+    const unsigned long long want = ++F.pub_seq;
+    launch_publish_state(*F.ctx, F.d_state.p, F.m, F.h_state.p, F.h_flag.p, want);
+    F.n_sync++;
+    volatile unsigned long long* flag = F.h_flag.p;
+    bool seen = false;
+    for (uint64_t spins = 0;; spins++)
+    {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == want)
+        {
+            seen = true;
+            break;
+        }
+        if ((spins & 0x3fff) == 0x3fff)  // every ~16 K polls: is the stream still alive?
+        {
+            const hipError_t q = hipStreamQuery(F.stream());
+            if (q == hipSuccess)
+                break;  // everything enqueued has run: the word must be there now, or this memory is not coherent (fallback)
+            if (q != hipErrorNotReady)
+                MISPEC_HIP(q);
+        }
+        __builtin_ia32_pause();
+    }
+    if (!seen && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != want)
+    {
+        F.turn_fallbacks++;
+        MISPEC_HIP(hipMemcpyAsync(&hs, F.d_state.p, sizeof(StepState), hipMemcpyDeviceToHost, F.stream()));
+        MISPEC_HIP(hipStreamSynchronize(F.stream()));
+    }
+    F.turn_t0 = std::chrono::steady_clock::now();
+    F.turn_open = true;
 }
 
 void comm_check(int rc, const char* what)
@@ -291,7 +362,10 @@ void spmv_of(mispec_fac& F, const mispec_csr& M, const double* x, double* y, con
 void allreduce(mispec_fac& F, double* buf, int64_t count)
 {
     if (F.sharded())
+    {
+        Timed t(F, FAM_ALLRED);
         comm_check(F.ctx->comm.allreduce_sum(F.ctx->comm.user, buf, count, F.stream()), "all-reduce");
+    }
 }
 
 // max over ranks of a device scalar (sum-only communicator: every rank contributes into its own slot)
@@ -320,7 +394,7 @@ void plan_overlap(mispec_fac& F)
     F.interior_first = F.interior_count = 0;
     if (!F.A || !F.sharded() || F.ctx->world() < 2 || F.A2 || F.Bop || F.Chol || F.A->spmv_format() >= 3)  // tiles, staged: no row sub-ranges
         return;
-    const char* e = getenv("MISPEC_OVERLAP");
+    const char* e = option("overlap");
     if (e && atoi(e) == 0)
         return;
     int first = 0, count = 0;
@@ -347,7 +421,7 @@ void plan_exchange(mispec_fac& F)
     const int W = cm.world, me = cm.rank;
     if (!F.A || !F.sharded() || !cm.exchange || W < 2)
         return;
-    const char* e = getenv("MISPEC_EXCHANGE");
+    const char* e = option("exchange");
     if (e && std::string(e) == "allgather")
         return;
     std::vector<int64_t> lo, hi;
@@ -447,7 +521,10 @@ void overlapped_spmv(mispec_fac& F, const mispec_csr& M, const double* x, double
     if (e0)
         MISPEC_HIP(hipEventRecord(e0, F.stream()));
     launch_spmv_raw(M, x, y, epi, nullptr, nullptr, i0, i1 - i0);
-    MISPEC_HIP(hipStreamWaitEvent(F.stream(), F.ev_x_landed, 0));
+    {
+        Timed t(F, FAM_XWAIT);  // (profile level 3: what is left of the exchange once the interior blocks are done)
+        MISPEC_HIP(hipStreamWaitEvent(F.stream(), F.ev_x_landed, 0));
+    }
     launch_spmv_raw(M, x, y, epi, nullptr, nullptr, 0, i0);
     launch_spmv_raw(M, x, y, epi, nullptr, nullptr, i1, nblocks - i1);
     if (e1)
@@ -477,14 +554,17 @@ void apply_op(mispec_fac& F, const double* x_loc, double* y_loc, bool lanczos_ep
                 MISPEC_HIP(hipEventRecord(F.ev_x_ready, F.stream()));
                 MISPEC_HIP(hipStreamWaitEvent(F.comm_stream, F.ev_x_ready, 0));
             }
-            if (F.halo)
-                // the matrix references only parts of the other slices: concurrent point-to-point transfers of exactly those
-                comm_check(F.ctx->comm.exchange(F.ctx->comm.user, F.xfull.p + F.row_begin, F.send_off.data(), F.send_count.data(), F.xfull.p,
-                                                F.recv_off.data(), F.recv_count.data(), xs),
-                           "neighbour exchange");
-            else  // all-gather of the Krylov vector over xGMI, in place: blocks are equal-sized and padded
-                comm_check(F.ctx->comm.allgather(F.ctx->comm.user, F.xfull.p + int64_t(F.ctx->rank()) * F.block, F.xfull.p, F.block, xs),
-                           "all-gather");
+            {
+                Timed t(F, FAM_EXCH, xs);
+                if (F.halo)
+                    // the matrix references only parts of the other slices: concurrent point-to-point transfers of exactly those
+                    comm_check(F.ctx->comm.exchange(F.ctx->comm.user, F.xfull.p + F.row_begin, F.send_off.data(), F.send_count.data(),
+                                                    F.xfull.p, F.recv_off.data(), F.recv_count.data(), xs),
+                               "neighbour exchange");
+                else  // all-gather of the Krylov vector over xGMI, in place: blocks are equal-sized and padded
+                    comm_check(F.ctx->comm.allgather(F.ctx->comm.user, F.xfull.p + int64_t(F.ctx->rank()) * F.block, F.xfull.p, F.block, xs),
+                               "all-gather");
+            }
             if (overlap)
                 MISPEC_HIP(hipEventRecord(F.ev_x_landed, F.comm_stream));
             x = F.xfull.p;
@@ -891,7 +971,7 @@ void lanczos_corrections_host(mispec_fac& F, int i, int count)
 // MISPEC_SMALL=device keeps the m x m work of a restart on the GPU (tested in both settings); the default is the host core.
 bool small_on_device()
 {
-    static const bool on = getenv("MISPEC_SMALL") && std::string(getenv("MISPEC_SMALL")) == "device";
+    const bool on = option_is("small", "device");
     return on;
 }
 
@@ -913,8 +993,8 @@ void resolve_restart(mispec_fac& F)
         return;
     F.restart_unresolved = false;
     StepState& hs = *F.h_state.p;
-    MISPEC_HIP(hipMemcpyAsync(&hs, F.d_state.p, sizeof(StepState), hipMemcpyDeviceToHost, F.stream()));
-    sync_stream(F);
+    fetch_state(F);
+    F.turn_open = false;
     absorb_restart_state(F, hs);
     if (hs.status == kStepRestartCheck)
     {
@@ -999,7 +1079,7 @@ void lanczos_step_host(mispec_fac& F, int i, int64_t* nmatop)
 // launches on one device, but a real all-reduce per step when sharded — so it is left to the host path there.
 int speculative_corrections(const mispec_fac& F)
 {
-    static const int knob = getenv("MISPEC_SPEC_CORR") ? atoi(getenv("MISPEC_SPEC_CORR")) : 0;
+    const int knob = option_int("spec_corr", 0);
     if (knob >= 1 && knob <= 4)
         return knob;
     return (F.sharded() && F.ctx->world() > 1) ? 1 : 2;
@@ -1081,6 +1161,7 @@ void lanczos_step_lagged(mispec_fac& F, int i, bool last, bool defer)
         fin.alpha_out = F.alpha_slot();
         {
             Timed t(F, FAM_VTF);
+            Timed t2(F, FAM_REDUCE);
             reduce_record(F, F.lag_def.nrec, F.lag_def.ncol, F.lag_def.half, fin);
         }
         F.lag_def.have = false;
@@ -1170,7 +1251,7 @@ void lanczos_step_lagged(mispec_fac& F, int i, bool last, bool defer)
 // MISPEC_ORTH_ONE_REDUCTION / MISPEC_ORTH_TWO_REDUCTIONS select it per factorisation)
 bool default_one_reduction()
 {
-    const char* e = getenv("MISPEC_ONE_REDUCTION");
+    const char* e = option("one_reduction");
     return e ? atoi(e) != 0 : true;  // the default since round 5 (C2: 0.986 -> 0.939 s per solve, same counters; profiles/r09l)
 }
 
@@ -1226,8 +1307,7 @@ void factorize_lanczos(mispec_fac& F, int from_k, int to_m, int64_t* nmatop)
             else
                 lanczos_step_device(F, s);
         }
-        MISPEC_HIP(hipMemcpyAsync(&hs, F.d_state.p, sizeof(StepState), hipMemcpyDeviceToHost, F.stream()));
-        sync_stream(F);
+        fetch_state(F);
 
         const int status = hs.status;
         if (from_restart)
@@ -1747,11 +1827,14 @@ int fac_create_impl(mispec_ctx* ctx, const mispec_csr* A, const mispec_symshift*
                 F->h_H.alloc(size_t(ncv) * ncv);
             }
             F->h_state.alloc(1);
-            F->device_steps = !(getenv("MISPEC_HOST_STEPS") && atoi(getenv("MISPEC_HOST_STEPS")) != 0);
+            F->h_flag.alloc(8);
+            F->h_flag.p[0] = 0;
+            F->h_up.alloc(size_t(ncv) * ncv + 2 * size_t(ncv));
+            F->device_steps = option_int("host_steps", 0) == 0;
             {
                 // default since round 4: the one-sweep steps (every gate of tests/test_gpu_onesweep.py and the reference's own test
                 // programs hold in both modes); MISPEC_ORTH=reference restores the reference's two-pass control flow everywhere
-                const char* o = getenv("MISPEC_ORTH");
+                const char* o = option("orth");
                 const std::string mode = o ? o : "onesweep";
                 MISPEC_REQUIRE(mode == "onesweep" || mode == "reference" || mode == "onesweep-eager",
                                "MISPEC_ORTH: expected reference, onesweep or onesweep-eager");
@@ -2009,6 +2092,19 @@ extern "C" int mispec_fac_restart_info(const mispec_fac* fac, int64_t* fused, in
     });
 }
 
+extern "C" int mispec_fac_turn_info(const mispec_fac* fac, int64_t* turns, double* host_seconds, int64_t* fallbacks)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(fac, "mispec_fac_turn_info: NULL argument");
+        if (turns)
+            *turns = fac->turn_count;
+        if (host_seconds)
+            *host_seconds = fac->turn_host_s;
+        if (fallbacks)
+            *fallbacks = fac->turn_fallbacks;
+    });
+}
+
 extern "C" int mispec_fac_exchange_info(const mispec_fac* fac, int* halo, int64_t* recv_doubles)
 {
     return guarded([&] {
@@ -2127,7 +2223,7 @@ extern "C" int mispec_fac_tridiag_eigen(mispec_fac* fac, double* evals_host, dou
         // host for the convergence test, so by default the m x m eigen-decomposition — a serial chain of rotations,
         // ~25 us on a host core against ~0.6 ms on one wavefront — runs where the data is.  MISPEC_SMALL=device
         // keeps it on the GPU (k_tridiag_eigen_w64 / k_tridiag_eigen; same routine, internal/SmallDense.h).
-        static const bool on_device_env = getenv("MISPEC_SMALL") && std::string(getenv("MISPEC_SMALL")) == "device";
+        const bool on_device_env = option_is("small", "device");
         const bool on_device = on_device_env && m <= kMaxSmallDim;
         if (!on_device)
         {
@@ -2172,7 +2268,7 @@ extern "C" int mispec_fac_ritz_values(mispec_fac* fac, double* evals_host, doubl
         mispec_fac& F = *fac;
         MISPEC_REQUIRE(F.symmetric, "mispec_fac_ritz_values: symmetric (Lanczos) factorisations only");
         const int m = F.m;
-        static const bool on_device_env = getenv("MISPEC_SMALL") && std::string(getenv("MISPEC_SMALL")) == "device";
+        const bool on_device_env = option_is("small", "device");
         if (on_device_env && m <= kMaxSmallDim)  // the device kernel forms the whole matrix: take its last row
         {
             std::vector<double> U(size_t(m) * m);
@@ -2273,9 +2369,29 @@ extern "C" int mispec_fac_restart_sym(mispec_fac* fac, const double* shifts_host
             std::vector<double> work(size_t(4) * m);
             for (int sft = 0; sft < nshift; sft++)
                 small::tridiag_shifted_qr(m, hs, hs + m, shifts_host[sft], Q, m, m, work.data(), small::Lanes{0, 1});
-            MISPEC_HIP(hipMemcpyAsync(F.Qdev.p, Q, size_t(m) * m * 8, hipMemcpyHostToDevice, F.stream()));
             const double q_last = Q[size_t(k - 1) * m + (m - 1)], h_sub = hs[m + k - 1];  // Q(m-1, k-1), the new H(k, k-1)
             const bool fused = F.end_pending;
+            // Without a host turn (the default): the record's scalar tail runs on the device (kFinishFusedRestart) and leaves the
+            // start state of the next sweep in d_state — H after compress_H is known here, beta = |f_new| follows from the
+            // record —, so factorize_lanczos enqueues that sweep at once; should the corrected residual fail the reference's
+            // test (Lanczos.h:156), none of its steps runs and the host continues the reference's loop at the sweep's end.
+            const bool no_sync = fused && !option_is("restart_sync", "1") && !F.test_recorrect && F.device_steps && device_operator(F) &&
+                                 !F.bmode();
+            const bool fast = fast_host_turn();
+            if (fast)
+            {
+                // Q and (no_sync) the next sweep's start state through ONE small kernel reading pinned host memory
+                double* up = F.h_up.p;
+                std::memcpy(up, Q, size_t(m) * m * 8);
+                for (int j = 0; j < m; j++)
+                {
+                    up[size_t(m) * m + j] = hs[j];
+                    up[size_t(m) * m + m + j] = (j + 1 < m) ? hs[m + j] : 0.0;
+                }
+                launch_fetch_restart(*F.ctx, up, m, F.Qdev.p, F.d_state.p, no_sync ? 1 : 0);
+            }
+            else
+                MISPEC_HIP(hipMemcpyAsync(F.Qdev.p, Q, size_t(m) * m * 8, hipMemcpyHostToDevice, F.stream()));
             bool test_failed = false;
             if (fused)
             {
@@ -2291,13 +2407,7 @@ extern "C" int mispec_fac_restart_sym(mispec_fac* fac, const double* shifts_host
                 fa.kcol = k;
                 fa.partials = F.partials.p;
                 fa.pstride = F.pstride;
-                // Without a host turn (the default): the record's scalar tail runs on the device (kFinishFusedRestart) and leaves the
-                // start state of the next sweep in d_state — H after compress_H is known here, beta = |f_new| follows from the
-                // record —, so factorize_lanczos enqueues that sweep at once; should the corrected residual fail the reference's
-                // test (Lanczos.h:156), none of its steps runs and the host continues the reference's loop at the sweep's end.
-                static const bool sync_env = getenv("MISPEC_RESTART_SYNC") && std::string(getenv("MISPEC_RESTART_SYNC")) == "1";
-                const bool no_sync = !sync_env && !F.test_recorrect && F.device_steps && device_operator(F) && !F.bmode();
-                if (no_sync)
+                if (no_sync && !fast)
                 {
                     StepState& st0 = *F.h_state.p;
                     std::memset(&st0, 0, sizeof(StepState));
@@ -2323,6 +2433,12 @@ extern "C" int mispec_fac_restart_sym(mispec_fac* fac, const double* shifts_host
                     fin.step = k;
                     fin.eps = F.test_restart_check ? -1.0 : kEps;  // (the hook: max |V'f| > -|f| always holds)
                     reduce_record(F, nrec, m + 1, F.end_rec ^ 1, fin);
+                    if (F.turn_open)
+                    {
+                        F.turn_host_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - F.turn_t0).count();
+                        F.turn_count++;
+                        F.turn_open = false;
+                    }
                     F.fused_restarts++;
                     F.f.swap(F.tmp);
                     F.beta = std::numeric_limits<double>::quiet_NaN();  // unknown on the host until the state comes back
@@ -2559,7 +2675,7 @@ extern "C" int mispec_fac_profile(mispec_fac* fac, int enable)
         fac->ctx->make_current();
         if (!enable && fac->prof)
             drain_profile(*fac);
-        fac->prof = (enable == 2) ? 2 : (enable != 0 ? 1 : 0);
+        fac->prof = (enable == 2 || enable == 3) ? enable : (enable != 0 ? 1 : 0);
     });
 }
 
@@ -2588,5 +2704,13 @@ extern "C" int mispec_fac_get_profile(const mispec_fac* fac_c, mispec_profile* o
         out->bytes_vtf = F.bytes_acc[FAM_VTF];
         out->bytes_gemv = F.bytes_acc[FAM_GEMV];
         out->bytes_compress = F.bytes_acc[FAM_COMPRESS];
+        out->n_reduce = F.counts[FAM_REDUCE];
+        out->n_exchange = F.counts[FAM_EXCH];
+        out->n_exchange_wait = F.counts[FAM_XWAIT];
+        out->n_allreduce = F.counts[FAM_ALLRED];
+        out->ms_reduce = F.ms_acc[FAM_REDUCE];
+        out->ms_exchange = F.ms_acc[FAM_EXCH];
+        out->ms_exchange_wait = F.ms_acc[FAM_XWAIT];
+        out->ms_allreduce = F.ms_acc[FAM_ALLRED];
     });
 }

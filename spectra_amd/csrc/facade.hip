@@ -436,6 +436,11 @@ extern "C" int mispec_symeigs_onered_steps(const mispec_symeigs* s, int64_t* ste
 {
     return s ? mispec_fac_onered_steps(s->fac(), steps) : MISPEC_EINVAL;
 }
+extern "C" int mispec_symeigs_turn_info(const mispec_symeigs* s, int64_t* turns, double* host_seconds, int64_t* fallbacks)
+{
+    return s ? mispec_fac_turn_info(s->fac(), turns, host_seconds, fallbacks) : MISPEC_EINVAL;
+}
+
 extern "C" int mispec_symeigs_restart_info(const mispec_symeigs* s, int64_t* fused, int64_t* recorrected)
 {
     return s ? mispec_fac_restart_info(s->fac(), fused, recorrected) : MISPEC_EINVAL;

@@ -435,100 +435,159 @@ __global__ __launch_bounds__(64 * NW) void k_orth_lagged(OrthArgs a)
     }
 }
 
+// What the scalar tail of a lagged step reads from global memory, loaded in ONE round at the start of the reducing kernel (the
+// loads then overlap the trip to the partial records; read one after the other behind the sums they cost a dependent round trip
+// each — 10 us of a 10.6 us k_finish, profiles/r11d).  Every value is written by earlier kernels only.
+struct LagPre
+{
+    int status, lag_pending;
+    double beta, lag_chk_max, lag_rel_c_max, alpha, cp1, cp2, subd2, diag1;
+    long long lag_steps, onered_steps;
+};
+__device__ __forceinline__ LagPre load_lag_pre(const FinishArgs& fa)
+{
+    const StepState* st = fa.st;
+    const int i = fa.step;
+    LagPre p;
+    p.status = st->status;
+    p.lag_pending = st->lag_pending;
+    p.beta = st->beta;
+    p.lag_chk_max = st->lag_chk_max;
+    p.lag_rel_c_max = st->lag_rel_c_max;
+    p.lag_steps = st->lag_steps;
+    p.onered_steps = st->onered_steps;
+    p.alpha = *fa.alpha_src;
+    p.cp1 = fa.prev_red[i - 1];
+    p.cp2 = i >= 2 ? fa.prev_red[i - 2] : 0.0;
+    p.subd2 = i >= 2 ? st->subd[i - 2] : 0.0;
+    p.diag1 = st->diag[i - 1];
+    return p;
+}
+
+// max |v[j]| and the running sum of v[j]^2 over j < n, in index order; eight loads in flight (one thread walking LDS or global
+// memory pays a full load latency per element otherwise)
+__device__ __forceinline__ void scan_abs_sq(const double* v, int n, double& mx, double& sq)
+{
+    int j = 0;
+    for (; j + 8 <= n; j += 8)
+    {
+        double x[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            x[k] = v[j + k];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+        {
+            mx = fmax(mx, fabs(x[k]));
+            sq += x[k] * x[k];
+        }
+    }
+    for (; j < n; j++)
+    {
+        mx = fmax(mx, fabs(v[j]));
+        sq += v[j] * v[j];
+    }
+}
+
 // Executed by ONE thread after the reduction of an ORTH_LAGGED record (layout above, i = fa.step columns were final).
 // H of step i follows from the Lanczos relation of step i-1; the decisions are the reference's
 // (Lanczos.h:156-168) with "apply the correction now" replaced by "carry it into the next sweep" whenever that is safe.
-__device__ void finish_lagged(double* red, const FinishArgs& fa)
+// `pre`: the state as loaded by load_lag_pre; status / beta: the state this step leaves (what start_next_onered continues from).
+__device__ void finish_lagged(double* red, const FinishArgs& fa, const LagPre& pre, int& status, double& beta)
 {
     StepState* st = fa.st;
     const int i = fa.step;
-    if (st->status != kStepOk)
+    status = pre.status;
+    beta = pre.beta;
+    if (pre.status != kStepOk)
         return;
-    const bool pend = st->lag_pending != 0;
-    const double bprev = st->beta;  // the divisor column i was formed with
+    const bool pend = pre.lag_pending != 0;
+    const double bprev = pre.beta;  // the divisor column i was formed with
     if (pend)
     {
-        double cerr = 0.0;
-        for (int j = 0; j < i; j++)
-            cerr = fmax(cerr, fabs(red[i + 1 + j]));
-        st->lag_chk_max = fmax(st->lag_chk_max, cerr);
+        double cerr = 0.0, unused = 0.0;
+        scan_abs_sq(red + i + 1, i, cerr, unused);
+        st->lag_chk_max = fmax(pre.lag_chk_max, cerr);
         if (cerr > fa.eps)  // Lanczos.h:156 after the first correction, in units of beta
         {
-            st->status = kStepLagCheck;
+            st->status = status = kStepLagCheck;
             st->stop_step = i;
             st->stop_count = 1;
             return;
         }
     }
-    const double* cp = fa.prev_red;  // the accepted V'f of step i-1 (valid when pend)
-    const double alpha = *fa.alpha_src;
+    const double alpha = pre.alpha;
     double d = alpha, sub = bprev;
-    if (pend)
+    if (pend)  // cp = the accepted V'f of step i-1
     {
-        d -= cp[i - 1];
-        sub -= ((i >= 2 ? st->subd[i - 2] * cp[i - 2] : 0.0) + st->diag[i - 1] * cp[i - 1]) / bprev;
+        d -= pre.cp1;
+        sub -= ((i >= 2 ? pre.subd2 * pre.cp2 : 0.0) + pre.diag1 * pre.cp1) / bprev;
     }
     const double gamma2 = red[kSlotBeta2];
     const double gamma = sqrt(gamma2);
     double err = 0.0, c2 = 0.0;
-    for (int j = 0; j <= i; j++)
-    {
-        err = fmax(err, fabs(red[j]));
-        c2 += red[j] * red[j];
-    }
+    scan_abs_sq(red, i + 1, err, c2);
     red[kSlotBeta] = gamma;
     red[kSlotErr] = err;
-    st->diag[i] = d;
-    st->subd[i - 1] = sub;
     st->alpha = alpha;
-    st->beta = gamma;
     st->err = err;
-    st->count = 0;
-    st->lag_pending = 0;
     st->need_corr = 0;
-    st->lag_steps++;
+    st->lag_steps = pre.lag_steps + 1;
+    double d_out = d, sub_out = sub;
+    int count = 0, lag_pending = 0;
+    beta = gamma;
     const int need = err > fa.eps * gamma;  // Lanczos.h:156
     if (need && gamma < fa.beta_thresh)     // Lanczos.h:163
     {
-        st->status = kStepTinyF;
+        status = kStepTinyF;
+        st->status = status;
         st->stop_step = i;
         st->stop_count = 0;
-        return;
     }
-    if (fa.lag_last)  // the CORRECT_VTF launches that follow finish f the reference's way
-    {
+    else if (fa.lag_last)  // the CORRECT_VTF launches that follow finish f the reference's way
         st->need_corr = need;
-        return;
-    }
-    if (!need)
-        return;
-    const double b2 = gamma2 - c2;
-    if (c2 <= fa.lag_limit * gamma2 && b2 > 0.0 && sqrt(b2) >= fa.eps_sqrt)
+    else if (need)
     {
-        st->subd[i - 1] += red[i - 1];  // Lanczos.h:173-175
-        st->diag[i] += red[i];
-        st->beta = sqrt(b2);            // |f - V c| for V'V = I, f'V = c'
-        st->lag_pending = 1;
-        st->count = 1;
-        st->lag_rel_c_max = fmax(st->lag_rel_c_max, sqrt(c2) / gamma);
+        const double b2 = gamma2 - c2;
+        if (c2 <= fa.lag_limit * gamma2 && b2 > 0.0 && sqrt(b2) >= fa.eps_sqrt)
+        {
+            sub_out = sub + red[i - 1];  // Lanczos.h:173-175
+            d_out = d + red[i];
+            beta = sqrt(b2);             // |f - V c| for V'V = I, f'V = c'
+            lag_pending = 1;
+            count = 1;
+            st->lag_rel_c_max = fmax(pre.lag_rel_c_max, sqrt(c2) / gamma);
+        }
+        else  // the reference's loop on the host, from the uncorrected state
+        {
+            status = kStepMoreCorr;
+            st->status = status;
+            st->stop_step = i;
+            st->stop_count = 0;
+        }
     }
-    else  // the reference's loop on the host, from the uncorrected state
-    {
-        st->status = kStepMoreCorr;
-        st->stop_step = i;
-        st->stop_count = 0;
-    }
+    st->diag[i] = d_out;
+    st->subd[i - 1] = sub_out;
+    st->beta = beta;
+    st->count = count;
+    st->lag_pending = lag_pending;
+}
+__device__ void finish_lagged(double* red, const FinishArgs& fa)
+{
+    const LagPre pre = load_lag_pre(fa);
+    int status;
+    double beta;
+    finish_lagged(red, fa, pre, status, beta);
 }
 
 // One reduction per step: after the bookkeeping of step i the same thread starts step i + 1 — its beta < sqrt(eps) stop
 // (Lanczos.h:107; the restart heuristics need a finished f: host) and alpha~ = <f~, A f~> / beta^2 - <f~, v_i> from the sum s1 that
-// travelled with the record (oracle/onesweep_variant.hpp, one_reduction).
-__device__ void start_next_onered(const double* red, const FinishArgs& fa, double s1)
+// travelled with the record (oracle/onesweep_variant.hpp, one_reduction).  status / beta: what finish_lagged left.
+__device__ void start_next_onered(const double* red, const FinishArgs& fa, double s1, int status, double beta, long long onered_steps)
 {
     StepState* st = fa.st;
-    if (st->status != kStepOk)
+    if (status != kStepOk)
         return;
-    const double beta = st->beta;
     if (beta < fa.eps_sqrt)
     {
         st->status = kStepSmallBeta;
@@ -537,7 +596,7 @@ __device__ void start_next_onered(const double* red, const FinishArgs& fa, doubl
         return;
     }
     *fa.alpha_out = s1 / (beta * beta) - red[fa.step];
-    st->onered_steps++;
+    st->onered_steps = onered_steps + 1;
 }
 
 // Executed by ONE thread after the reduction of a k_vq_fused record (krylov.hpp VqFusedArgs): what mispec_fac_restart_sym used to
@@ -693,54 +752,93 @@ __device__ __forceinline__ void reduce_slots(const double* __restrict__ partials
     }
 }
 
+// Every slot of a record of at most 64 * RPL workgroups in ONE round of loads (k_reduce_partials, few records): wave g owns the
+// slots g, g + 16, ..., g + 80 (the two scalar slots ride behind the columns); with `alpha`, thread t also loads the product's
+// partial sums t, t + 1024, ... (at most eight) in the same round — k_reduce_sum's order.
+template <int RPL>
+__device__ __forceinline__ void reduce_one_round(const double* __restrict__ partials, int64_t pstride, int nrec, int ncol,
+                                                 const FinishArgs& fin, bool alpha, double* sh, double* sh_a)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int sl[6];
+    double xv[6][RPL];
+#pragma unroll
+    for (int u = 0; u < 6; u++)
+    {
+        const int s = g + 16 * u;
+        sl[u] = s < ncol ? s : (s == ncol ? kSlotBeta2 : (s == ncol + 1 ? kSlotMaxAbs : -1));
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            const int b = lane + 64 * k;
+            xv[u][k] = (sl[u] >= 0 && b < nrec) ? partials[int64_t(sl[u]) * pstride + b] : 0.0;
+        }
+    }
+    double av[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+    {
+        const int64_t i = tid + int64_t(k) * 1024;
+        av[k] = (alpha && i < fin.alpha_count) ? fin.alpha_parts[i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 6; u++)
+    {
+        if (sl[u] < 0)
+            continue;  // wave-uniform
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+            acc = (sl[u] == kSlotMaxAbs) ? fmax(acc, xv[u][k]) : acc + xv[u][k];
+        const double r = (sl[u] == kSlotMaxAbs) ? wave_reduce_max(acc) : wave_reduce_sum(acc);
+        if (lane == 0)
+            sh[sl[u]] = r;
+    }
+    if (alpha)
+    {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            v += av[k];
+        v = wave_reduce_sum(v);
+        if (lane == 0)
+            sh_a[g] = v;
+    }
+}
+
 __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restrict__ partials, int64_t pstride, int nrec,
                                                            int ncol, double* __restrict__ red, FinishArgs fin)
 {
     __shared__ double sh[kPartialLd];
     // A device-driven run that has stopped: the launches still in the queue are no-ops, and so is this one — the two record
-    // halves must stay what the stopping pass and the one before it left there, the host continues from them.
-    if (fin.st != nullptr && fin.st->status != kStepOk)
-        return;
+    // halves must stay what the stopping pass and the one before it left there, the host continues from them.  The flag is
+    // LOADED here and looked at behind the sums (nothing is written before that): its latency overlaps the trip to the records.
+    const int run_status = (fin.st != nullptr) ? fin.st->status : int(kStepOk);
+    const bool lagged_tail = fin.mode == kFinishLagged && fin.st != nullptr;
+    LagPre pre = {};
+    if (lagged_tail && threadIdx.x == 0)
+        pre = load_lag_pre(fin);
     const int tid = threadIdx.x, lane = tid & 63;
     const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int t = tid; t < kPartialLd; t += 1024)
         sh[t] = 0.0;
     __syncthreads();
     __shared__ double sh_a[16];
-    // Small problems (at most 64 records: up to ~16 K rows): every lane holds ONE record of a slot, so all the slots of the
-    // record and the product's partial sums fit one round of loads — one trip to the other XCDs' data instead of three, on the
-    // critical path of every step of a launch-bound solve.  Same sums: a lane's "0 + x", then the shuffle tree.
-    const bool small = nrec <= 64 && ncol + 2 <= 96 && (!fin.alpha_parts || fin.alpha_count <= 1024);
+    // Few records (at most 256: every run of the LDS-DMA pass, whose grid is one workgroup per CU, and small problems): a lane
+    // holds RPL = 1, 2 or 4 records of each of its wave's six slots, so ALL the slots of the record and (up to 8192 of) the
+    // product's partial sums fit ONE round of loads — one trip to the other XCDs' data instead of three, on the critical path of
+    // every step.  Same sums as the passes below: a lane adds its records l, l + 64, ... in that order, then the shuffle tree.
+    const bool small = nrec <= 256 && ncol + 2 <= 96;
+    const bool alpha_in_round = small && fin.alpha_parts && fin.alpha_count <= 8192;
     if (small)
     {
-        int sl[6];
-        double xv[6];
-#pragma unroll
-        for (int u = 0; u < 6; u++)
-        {
-            const int s = g + 16 * u;
-            sl[u] = s < ncol ? s : (s == ncol ? kSlotBeta2 : (s == ncol + 1 ? kSlotMaxAbs : -1));
-            xv[u] = (sl[u] >= 0 && lane < nrec) ? partials[int64_t(sl[u]) * pstride + lane] : 0.0;
-        }
-        double av = 0.0;
-        if (fin.alpha_parts && tid < fin.alpha_count)
-            av = fin.alpha_parts[tid];
-#pragma unroll
-        for (int u = 0; u < 6; u++)
-        {
-            if (sl[u] < 0)
-                continue;  // wave-uniform
-            const double acc = (sl[u] == kSlotMaxAbs) ? fmax(0.0, xv[u]) : 0.0 + xv[u];
-            const double r = (sl[u] == kSlotMaxAbs) ? wave_reduce_max(acc) : wave_reduce_sum(acc);
-            if (lane == 0)
-                sh[sl[u]] = r;
-        }
-        if (fin.alpha_parts)
-        {
-            const double v = wave_reduce_sum(0.0 + av);
-            if (lane == 0)
-                sh_a[g] = v;
-        }
+        if (nrec <= 64)
+            reduce_one_round<1>(partials, pstride, nrec, ncol, fin, alpha_in_round, sh, sh_a);
+        else if (nrec <= 128)
+            reduce_one_round<2>(partials, pstride, nrec, ncol, fin, alpha_in_round, sh, sh_a);
+        else
+            reduce_one_round<4>(partials, pstride, nrec, ncol, fin, alpha_in_round, sh, sh_a);
     }
     // column passes of 48 (wave g: c0+g, c0+g+16, c0+g+32); the two scalar slots ride in the last pass when its
     // positions 46/47 are free, otherwise in a pass of their own
@@ -767,7 +865,7 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restri
         slot[0] = (g == 0) ? kSlotBeta2 : (g == 1 ? kSlotMaxAbs : -1);
         reduce_slots<1>(partials, pstride, nrec, slot, lane, sh);
     }
-    if (fin.alpha_parts && !small)
+    if (fin.alpha_parts && !alpha_in_round)
     {
         // k_reduce_sum's order: thread t adds in[t], in[t + 1024], ... ; wave sums; the 16 wave sums one after the other
         constexpr int kBatch = 40;
@@ -790,6 +888,8 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restri
             sh_a[g] = v;
     }
     __syncthreads();
+    if (run_status != kStepOk)  // (uniform: every thread loaded the same word)
+        return;
     if (tid == 0)
     {
         double s1 = 0.0;
@@ -802,9 +902,16 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restri
             if (fin.alpha_parts)
                 sh[ncol + 1] = s1;  // sharded: the local sum travels behind sum f^2
         }
-        finish_record(sh, ncol, fin);
-        if (fin.alpha_parts && !fin.packed && fin.mode == kFinishLagged)
-            start_next_onered(sh, fin, s1);
+        if (lagged_tail)
+        {
+            int status;
+            double beta;
+            finish_lagged(sh, fin, pre, status, beta);
+            if (fin.alpha_parts && !fin.packed)
+                start_next_onered(sh, fin, s1, status, beta, pre.onered_steps);
+        }
+        else
+            finish_record(sh, ncol, fin);
     }
     __syncthreads();
     for (int t = tid; t < kPartialLd; t += 1024)
@@ -814,28 +921,114 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restri
 // Sharded runs: the all-reduced record sits in a staging area; it becomes the content of a record half only while the run is live.
 __global__ __launch_bounds__(256) void k_finish(const double* __restrict__ stage, double* __restrict__ red, int ncol, FinishArgs fin)
 {
-    if (fin.st != nullptr && fin.st->status != kStepOk)
-        return;
+    __shared__ double sh[kPartialLd];
+    const int run_status = (fin.st != nullptr) ? fin.st->status : int(kStepOk);
+    const bool lagged_tail = fin.mode == kFinishLagged && fin.st != nullptr;
+    LagPre pre = {};
+    if (lagged_tail && threadIdx.x == 0)
+        pre = load_lag_pre(fin);
+    // the record goes through LDS: the tail's walks over it then cost LDS latencies, and `red` is written once, complete
     for (int t = threadIdx.x; t < kPartialLd; t += 256)
-        red[t] = stage[t];
+        sh[t] = stage[t];
     __syncthreads();
+    if (run_status != kStepOk)
+        return;
     if (threadIdx.x == 0)
     {
         double s1 = 0.0;
         if (fin.packed)
         {
-            red[kSlotBeta2] = stage[ncol];
+            sh[kSlotBeta2] = sh[ncol];
             if (ncol != kSlotBeta2)
-                red[ncol] = 0.0;
+                sh[ncol] = 0.0;
             if (fin.alpha_parts)
             {
-                s1 = stage[ncol + 1];
-                red[ncol + 1] = 0.0;
+                s1 = sh[ncol + 1];
+                sh[ncol + 1] = 0.0;
             }
         }
-        finish_record(red, ncol, fin);
-        if (fin.alpha_parts && fin.mode == kFinishLagged)
-            start_next_onered(red, fin, s1);
+        if (lagged_tail)
+        {
+            int status;
+            double beta;
+            finish_lagged(sh, fin, pre, status, beta);
+            if (fin.alpha_parts)
+                start_next_onered(sh, fin, s1, status, beta, pre.onered_steps);
+        }
+        else
+            finish_record(sh, ncol, fin);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < kPartialLd; t += 256)
+        red[t] = sh[t];
+}
+
+__global__ __launch_bounds__(256) void k_publish_state(const StepState* __restrict__ st, int m, StepState* host_dst,
+                                                        unsigned long long* host_flag, unsigned long long seq)
+{
+    const int tid = threadIdx.x;
+    if (tid == 0)
+    {
+        host_dst->beta = st->beta;
+        host_dst->alpha = st->alpha;
+        host_dst->err = st->err;
+        host_dst->count = st->count;
+        host_dst->need_corr = st->need_corr;
+        host_dst->status = st->status;
+        host_dst->stop_step = st->stop_step;
+        host_dst->stop_count = st->stop_count;
+        host_dst->lag_pending = st->lag_pending;
+        host_dst->lag_rel_c_max = st->lag_rel_c_max;
+        host_dst->lag_chk_max = st->lag_chk_max;
+        host_dst->lag_steps = st->lag_steps;
+        host_dst->rst_err = st->rst_err;
+        host_dst->rst_beta_corr = st->rst_beta_corr;
+        host_dst->onered_steps = st->onered_steps;
+    }
+    for (int j = tid; j < m; j += 256)
+    {
+        host_dst->diag[j] = st->diag[j];
+        host_dst->subd[j] = st->subd[j];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0)
+        __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Start of a restart: Q (m x m) and the start state of the next sweep (diag / subd after compress_H) are read from a pinned
+// host buffer [Q m*m][diag m][subd m] by ONE small kernel in front of the V*Q pass (instead of two hipMemcpyAsync).
+__global__ __launch_bounds__(256) void k_fetch_restart(const double* __restrict__ host_src, int m, double* __restrict__ Qdev,
+                                                        StepState* st, int with_state)
+{
+    const int tid = threadIdx.x + blockIdx.x * 256;
+    const int nq = m * m;
+    for (int i = tid; i < nq; i += 256 * gridDim.x)
+        Qdev[i] = host_src[i];
+    if (!with_state || blockIdx.x != 0)
+        return;
+    for (int j = threadIdx.x; j < m; j += 256)
+    {
+        st->diag[j] = host_src[nq + j];
+        st->subd[j] = host_src[nq + m + j];
+    }
+    if (threadIdx.x == 0)
+    {
+        st->beta = 0.0;
+        st->alpha = 0.0;
+        st->err = 0.0;
+        st->count = 0;
+        st->need_corr = 0;
+        st->status = kStepOk;
+        st->stop_step = 0;
+        st->stop_count = 0;
+        st->lag_pending = 0;
+        st->lag_rel_c_max = 0.0;
+        st->lag_chk_max = 0.0;
+        st->lag_steps = 0;
+        st->rst_err = 0.0;
+        st->rst_beta_corr = 0.0;
+        st->onered_steps = 0;
     }
 }
 
@@ -1510,6 +1703,7 @@ void launch_orth_lagged(const mispec_ctx& ctx, const OrthArgs& a, int grid)
 namespace mispec {
 
 namespace {
+constexpr bool kOrthDmaDefault = true;  // round 6: -3.5 % per C2 solve, -4...7 % per operation at 1.25 M rows (profiles/r11d)
 int orth_tile_rows(int ncol)
 {
     return kTileRows * (((ncol + 3) / 4 <= 10) ? 2 : 1);
@@ -1518,6 +1712,24 @@ int orth_tile_rows(int ncol)
 // one launch over at most kPanelCols columns; grid == 0: choose it from the tile count
 int launch_orth_panel(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a, int grid)
 {
+    // option orth_kernel = dma | dma2 | reg: the LDS-DMA ring version of the one-sweep pass (orth_dma.hip; three or two ring slots)
+    // or the register version below; unset: the LDS-DMA version on vectors of at least 1024 tiles of 128 rows
+    if (mode == ORTH_LAGGED && grid == 0 && orth_lagged_dma_eligible(a))
+    {
+        const char* k = option("orth_kernel");
+        int depth = 0, flags = 0;
+        if (k)
+        {
+            const std::string ks(k);  // dma, dma2 (two slots), dmac (contiguous tile runs), dmap (plain loads), dmacp
+            depth = ks.rfind("dma", 0) == 0 ? (ks == "dma2" ? 2 : 3) : 0;
+            if (depth == 3 && ks.size() > 3)
+                flags = (ks.find('c', 3) != std::string::npos ? 1 : 0) | (ks.find('p', 3) != std::string::npos ? 2 : 0);
+        }
+        else if (kOrthDmaDefault && a.n >= int64_t(1024) * 128)
+            depth = 3;
+        if (depth)
+            return launch_orth_lagged_dma(ctx, a, depth, flags);
+    }
     if (grid == 0)
     {
         const int rows = orth_tile_rows(a.ncol);
@@ -1632,6 +1844,20 @@ void launch_reduce_partials(const mispec_ctx& ctx, const double* partials, int64
     MISPEC_HIP(hipGetLastError());
 }
 
+void launch_publish_state(const mispec_ctx& ctx, const StepState* st, int m, StepState* host_dst, unsigned long long* host_flag,
+                          unsigned long long seq)
+{
+    hipLaunchKernelGGL(k_publish_state, dim3(1), dim3(256), 0, ctx.stream, st, m, host_dst, host_flag, seq);
+    MISPEC_HIP(hipGetLastError());
+}
+
+void launch_fetch_restart(const mispec_ctx& ctx, const double* host_src, int m, double* Qdev, StepState* st, int with_state)
+{
+    hipLaunchKernelGGL(k_fetch_restart, dim3(unsigned((m * m + 1023) / 1024)), dim3(256), 0, ctx.stream, host_src, m, Qdev, st,
+                       with_state);
+    MISPEC_HIP(hipGetLastError());
+}
+
 void launch_finish(const mispec_ctx& ctx, const double* stage, double* red, int ncol, const FinishArgs& fin)
 {
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, ctx.stream, stage, red, ncol, fin);
@@ -1699,8 +1925,7 @@ namespace {
 void launch_vq_panel(const mispec_ctx& ctx, const double* V, int64_t ldv, int m, const double* Q, int ldq, int p, double* X,
                      int64_t ldx, int64_t n, int accumulate)
 {
-    static const char* impl = getenv("MISPEC_VQ");
-    static const bool use_mfma = impl ? std::string(impl) == "mfma" : false;
+    const bool use_mfma = option_is("vq", "mfma");
     if (use_mfma)
     {
         constexpr int NB = 2;

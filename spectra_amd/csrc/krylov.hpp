@@ -130,6 +130,11 @@ struct OrthArgs
     int onered = 0;
 };
 
+// ORTH_LAGGED with the basis streamed through an LDS ring by LDS-DMA (orth_dma.hip): eligible for one column panel on vectors of
+// at least 512 tiles of 128 rows; returns the number of partial records (= workgroups: one per CU).  depth_override 2: two ring slots.
+bool orth_lagged_dma_eligible(const OrthArgs& a);
+int launch_orth_lagged_dma(const mispec_ctx& ctx, const OrthArgs& a, int depth_override, int flags = 0);
+
 // All launchers enqueue on ctx.stream and return immediately.
 int launch_orth(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a);  // returns the number of partial records
 // red[0..kPartialLd): column sums of the records (+ max for kSlotMaxAbs); finish additionally fills kSlotBeta / kSlotErr.
@@ -138,6 +143,11 @@ void launch_reduce_partials(const mispec_ctx& ctx, const double* partials, int64
 // While the device-driven run `fin.st` is live both kernels write `red`; once it has stopped they leave it alone (the host
 // continues from the records of the stopping pass).  launch_finish: red <- stage (an all-reduced record), then the scalar tail.
 void launch_finish(const mispec_ctx& ctx, const double* stage, double* red, int ncol, const FinishArgs& fin);
+// Host turn of a restart without DMA-engine copies (option host_turn): the state of a finished sweep written into pinned host
+// memory by a kernel + a sequence flag the host spins on; Q and the next sweep's start state fetched from pinned host memory.
+void launch_publish_state(const mispec_ctx& ctx, const StepState* st, int m, StepState* host_dst, unsigned long long* host_flag,
+                          unsigned long long seq);
+void launch_fetch_restart(const mispec_ctx& ctx, const double* host_src, int m, double* Qdev, StepState* st, int with_state);
 // out[0] = sum of `count` doubles (SpMV alpha partials), fixed order
 void launch_reduce_sum(const mispec_ctx& ctx, const double* in, int64_t count, double* out);
 // dst = src / divisor over npad elements (v = f / beta, Lanczos.h:106)

@@ -1052,7 +1052,8 @@ void plan_level(int64_t N, int b, int64_t& L, int64_t& P)
 // factor=host (the top level factored on the host).  Not a tuning interface: the defaults are the measured best.
 long long shift_option(const char* key, long long dflt)
 {
-    static const std::string spec = getenv("MISPEC_SHIFT") ? getenv("MISPEC_SHIFT") : "";
+    const char* spec_c = option("shift");
+    const std::string spec = spec_c ? spec_c : "";
     const std::string k = std::string(key) + "=";
     size_t pos = 0;
     while (pos < spec.size())
@@ -1077,7 +1078,7 @@ long long shift_option(const char* key, long long dflt)
 // whether a level of this shape is factored by k_chunk_factor (MISPEC_SHIFT=factor=host keeps everything on the host)
 bool factored_on_device(int64_t N, int b)
 {
-    static const bool host_only = shift_option("factor", 0) != 0;
+    const bool host_only = shift_option("factor", 0) != 0;
     int64_t L, P;
     plan_level(N, b, L, P);
     return P > 1 && b <= 8 && !host_only;
@@ -1088,7 +1089,7 @@ bool factored_on_device(int64_t N, int b)
 // (MISPEC_SHIFT=block_inverse=0 keeps the sweeps; =<MiB> moves the size limit, default 256 MiB per level).
 bool wants_block_inverse(int64_t P, int64_t mmax, int b)
 {
-    static const long long limit_mib = shift_option("block_inverse", 256);
+    const long long limit_mib = shift_option("block_inverse", 256);
     if (limit_mib <= 0 || mmax > 256 || b > 16)
         return false;
     const double bytes = double(P) * double(mmax) * double(mmax) * 8.0;
@@ -1469,7 +1470,7 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
 // rows in flight during the recurrence) measured 0.281 against 0.265 ms (profiles/rounds_1_2/r03b_*) and was removed again.
 int solve_lanes(int64_t P)
 {
-    static const int knob = int(shift_option("lanes", 0));
+    const int knob = int(shift_option("lanes", 0));
     if (knob == 64 || knob == 32 || knob == 16 || knob == 8)
         return knob;
     (void) P;
@@ -1484,8 +1485,8 @@ void launch_chunk_solve(const mispec_ctx& ctx, const BandLevel& lev, dim3 grid_u
     const dim3 grid(unsigned((lev.P - 1 + lanes - 1) / lanes) + 1);  // + the last chunk's own workgroup
     const bool chol = mode != 0 || u_out != nullptr;
     // plain solves of a level whose wavefront segments fit the LDS: the staged kernel (MISPEC_SHIFT=lds=0: always the general one)
-    static const bool lds_off = shift_option("lds", 1) == 0;
-    static const int batch = int(shift_option("batch", 0));
+    const bool lds_off = shift_option("lds", 1) == 0;
+    const int batch = int(shift_option("batch", 0));
     if (!chol && !lds_off && lev.P > 1 && lev.b >= 1 && lev.b <= 8)
     {
         const int U = (batch == 8 || batch == 16 || batch == 32) ? batch : (lev.b <= 4 ? 32 : 16);
@@ -1955,8 +1956,10 @@ int symshift_create_impl(mispec_ctx* ctx, int64_t n, const TriangleInput& A, con
             });
         S->half_bandwidth_as_given = S->half_bandwidth;
         std::vector<int32_t> inv;  // old -> new when the matrix is reordered
+        // (the adjacency below holds every off-diagonal entry of A and of B twice behind int32 row pointers: a pencil with more
+        // entries than that is not reordered — it ends as the clean "unsupported pattern" error instead — ADVICE r05)
         if (!band_path(n, S->half_bandwidth) && n > kMaxDense && n < (int64_t(1) << 31) &&
-            !(getenv("MISPEC_REORDER") && std::string(getenv("MISPEC_REORDER")) == "none"))
+            2 * (countA + countB) < (int64_t(1) << 31) && !option_is("reorder", "none"))
         {
             // Too wide for the band kernels as it comes and too large for the dense path: try a bandwidth-reducing ordering
             // (reverse Cuthill-McKee on the pattern of A (+ B)) before giving up — the reference's SparseLU / SimplicialLDLT

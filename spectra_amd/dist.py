@@ -19,7 +19,7 @@ import os
 
 import numpy as np
 
-from . import Context, shard_range
+from . import Context, MispecError, shard_range
 
 
 def init_process_group(backend=None):
@@ -221,12 +221,19 @@ def make_context(device=None, transport=None):
                     ctx.set_comm_rccl(rank, world, payload[0])
                 except Exception as e:  # noqa: BLE001
                     ok, err = 0, e
+            # every rank learns whether ALL ranks have a communicator before anything is decided (in strict mode a rank
+            # without one must not carry on as a silent single-rank context).  What this cannot recover from: ncclCommInitRank is
+            # itself collective — a rank that fails BEFORE entering it leaves its peers blocked inside it, and the all-reduce below
+            # is never reached; the launcher's timeout ends such a run.
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if transport == "rccl-strict":
                 if err is not None:
                     raise err
+                if int(flag.item()) == 0:
+                    raise MispecError("MISPEC_COMM=rccl-strict: the RCCL communicator could not be created on another rank"
+                                      + (" (rank 0 has no unique id)" if payload[0] is None else ""))
                 return ctx
-            flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 0:
                 import sys
 

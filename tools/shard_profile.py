@@ -54,7 +54,8 @@ def main():
            "seconds_per_solve": dt, "ms_per_operator_application_all_inclusive": 1e3 * dt / nops,
            "kernel_families_ms_per_operation": {k[3:]: (p1[k] - p0[k]) / nops for k in p1 if k.startswith("ms_")},
            "launches_per_operation": {k[2:]: (p1[k] - p0[k]) / nops for k in p1 if k.startswith("n_")},
-           "max_residual": float(eigs.residuals().max()), "orth_info": eigs.orth_info(),
+           "max_residual": float(eigs.residuals().max()), "orth_info": eigs.orth_info(), "turn_info": eigs.turn_info(),
+           "options": {k: sa.get_option(k) for k in ("host_turn", "orth_kernel", "small", "spec_corr")},
            "note": "wall-clock figure from an un-instrumented solve; the family split from one more solve with HIP events; loopback world = 1"}
     print(json.dumps(out), flush=True)
     del eigs, op
