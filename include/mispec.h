@@ -503,6 +503,15 @@ int mispec_fac_get_profile(const mispec_fac* fac, mispec_profile* out);
  * ------------------------------------------------------------------------- */
 int mispec_tridiag_qr(mispec_ctx* ctx, int n, const double* T_host, double shift, double* Q_host, double* QtHQ_host);
 int mispec_tridiag_eigen(mispec_ctx* ctx, int n, const double* T_host, double* evals_host, double* evecs_host);
+/* All nshift shifted QR sweeps of one restart (HermEigsBase.h:124-147: TridiagQR::compute, apply_YQ, matrix_QtHQ per shift;
+ * UpperHessenbergQR.h:515-693) on the tridiagonal (diag_host[n], subd_host[n-1]), by variant — 0: host, the reference's serial
+ * order; 1: host, the skewed pipeline of include/Spectra/internal/SmallDensePipelined.h (what a restart runs); 2: device,
+ * k_restart_pipelined (n <= 64); 3: device, one wavefront.  Variants 0-2 give bit-identical results (variant 3 differs by
+ * rounding: fused multiply-adds, its own hypot).  reps >= 1 calls are timed (host: best of reps; device: HIP events around reps
+ * launches) -> *us_per_call.  diag_out[n], subd_out[n-1], Q_out[n*n] (column-major): Q'TQ and Q = Q_1 ... Q_p; any may be NULL.
+ * ctx may be NULL for the host variants. */
+int mispec_restart_sweeps(mispec_ctx* ctx, int n, const double* diag_host, const double* subd_host, const double* shifts_host,
+                          int nshift, int variant, int reps, double* diag_out, double* subd_out, double* Q_out, double* us_per_call);
 
 /* ---------------------------------------------------------------------------
  * Solver-level facade: Spectra::SymEigsSolver<Spectra::SparseSymMatProd<double>> (include/Spectra/)

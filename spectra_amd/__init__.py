@@ -1607,6 +1607,25 @@ def tridiag_qr(T, shift, ctx=None):
     return Q, D
 
 
+RESTART_SWEEP_VARIANTS = {"host-serial": 0, "host-pipelined": 1, "device-pipelined": 2, "device-wavefront": 3}
+
+
+def restart_sweeps(diag, subd, shifts, variant="host-pipelined", reps=1, ctx=None):
+    """All shifted QR sweeps of one restart on the tridiagonal (diag[n], subd[n-1]) — HermEigsBase.h:124-147 — by variant
+    (RESTART_SWEEP_VARIANTS; mispec_restart_sweeps).  Returns (diag', subd', Q, microseconds per call); the host variants and
+    the pipelined kernel agree bit for bit.  The host variants need no device."""
+    v = RESTART_SWEEP_VARIANTS[variant]
+    d, e, mu = _f64(diag), _f64(subd), _f64(shifts)
+    n = d.size
+    h = None
+    if v >= 2:
+        h = (ctx or default_context()).h
+    do, eo, Q = np.empty(n), np.empty(max(n - 1, 0)), np.empty((n, n), order="F")
+    us = C.c_double(0.0)
+    check(lib().mispec_restart_sweeps(h, n, _dp(d), _dp(e), _dp(mu), mu.size, v, int(reps), _dp(do), _dp(eo), _dp(Q), C.byref(us)))
+    return do, eo, Q, us.value
+
+
 def tridiag_eigen(T, ctx=None):
     """TridiagEigen on the device: returns (eigenvalues, eigenvectors)."""
     ctx = ctx or default_context()

@@ -173,6 +173,7 @@ SIGNATURES = {
     "mispec_fac_get_profile": (C.c_int, [_vp, C.POINTER(Profile)]),
     "mispec_tridiag_qr": (C.c_int, [_vp, C.c_int, _dp, C.c_double, _dp, _dp]),
     "mispec_tridiag_eigen": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
+    "mispec_restart_sweeps": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp]),
     "mispec_symeigs_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vpp]),
     "mispec_symeigs_create_op": (C.c_int, [_vp, op_fn, _vp, C.c_int64, C.c_int64, C.c_int64, _vpp]),
     "mispec_symeigs_create_shift": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_double, _vpp]),

@@ -23,6 +23,7 @@
 
 #include <sys/mman.h>
 #include <Spectra/internal/SmallDense.h>
+#include <Spectra/internal/SmallDensePipelined.h>
 
 #include <cmath>
 #include <memory>
@@ -104,6 +105,9 @@ struct mispec_fac
     int64_t turn_count = 0, turn_fallbacks = 0;
     double turn_host_s = 0.0;      // host time between "state seen" and "restart enqueued", summed over the restarts
     std::chrono::steady_clock::time_point turn_t0;
+    // scratch of the restart's pipelined QR sweeps (restart_sym), kept between restarts
+    std::vector<double> sweep_work, sweep_q;
+    std::vector<small::SweepLane> sweep_lanes;
     bool turn_open = false;
     PinnedBuf<double> h_red, h_small, h_x, h_y;
     PinnedBuf<double> h_stage[2];  // pinned staging of download_columns (allocated on first use)
@@ -2363,12 +2367,32 @@ extern "C" int mispec_fac_restart_sym(mispec_fac* fac, const double* shifts_host
         {
             F.counts[FAM_SMALL]++;
             double* Q = hs + 2 * m;
-            std::fill(Q, Q + size_t(m) * m, 0.0);
-            for (int i = 0; i < m; i++)
-                Q[size_t(i) * m + i] = 1.0;
-            std::vector<double> work(size_t(4) * m);
-            for (int sft = 0; sft < nshift; sft++)
-                small::tridiag_shifted_qr(m, hs, hs + m, shifts_host[sft], Q, m, m, work.data(), small::Lanes{0, 1});
+            // The sweeps as a skewed pipeline (internal/SmallDensePipelined.h): the serial order's T and Q bit for bit (the sweeps in
+            // flight overlap on the out-of-order core, the rows of Q go through SIMD registers) in 40 % of its time — ~20 instead of
+            // ~50 us at m = 40, 18 shifts, on the critical path of every restart.  Option small=host-serial: the reference's order.
+            if (option_is("small", "host-serial"))
+            {
+                std::fill(Q, Q + size_t(m) * m, 0.0);
+                for (int i = 0; i < m; i++)
+                    Q[size_t(i) * m + i] = 1.0;
+                std::vector<double> work(size_t(4) * m);
+                for (int sft = 0; sft < nshift; sft++)
+                    small::tridiag_shifted_qr(m, hs, hs + m, shifts_host[sft], Q, m, m, work.data(), small::Lanes{0, 1});
+            }
+            else
+            {
+                const int ld = (m + 7) / 8 * 8;
+                F.sweep_work.resize(size_t(2 * nshift + 2) * m);
+                F.sweep_q.assign(size_t(ld) * m, 0.0);
+                F.sweep_lanes.resize(size_t(nshift));
+                for (int i = 0; i < m; i++)
+                    F.sweep_q[size_t(i) * ld + i] = 1.0;
+                small::restart_rotations_pipelined(m, hs, hs + m, shifts_host, nshift, F.sweep_work.data(), F.sweep_lanes.data());
+                small::apply_sweeps_to_Q(F.sweep_q.data(), ld, ld, m, F.sweep_work.data(), F.sweep_work.data() + size_t(nshift) * m,
+                                         nshift);
+                for (int c = 0; c < m; c++)
+                    std::memcpy(Q + size_t(c) * m, F.sweep_q.data() + size_t(c) * ld, size_t(m) * sizeof(double));
+            }
             const double q_last = Q[size_t(k - 1) * m + (m - 1)], h_sub = hs[m + k - 1];  // Q(m-1, k-1), the new H(k, k-1)
             const bool fused = F.end_pending;
             // Without a host turn (the default): the record's scalar tail runs on the device (kFinishFusedRestart) and leaves the

@@ -5,9 +5,11 @@
 #include "small.hpp"
 
 #include <Spectra/internal/SmallDense.h>
+#include <Spectra/internal/SmallDensePipelined.h>
 #include <Spectra/internal/SmallDenseGenLanes.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <vector>
 
@@ -391,6 +393,117 @@ __global__ __launch_bounds__(64) void k_restart_sym_w64(int m, double* __restric
         Qout[idx] = Q[idx];
 }
 
+
+// ===================================================================================================
+// The restart's shifted QR sweeps as a skewed pipeline (internal/SmallDensePipelined.h): lane s of
+// wave 0 owns sweep s and runs sweep_tick once per tick (its rotation index trails sweep s - 1 by three), the pair it emits
+// goes to lane s + 1 by __shfl_up; waves 1-3 rotate the columns of Q (LDS, m x m) with the rotations of the tick before —
+// disjoint column pairs, one barrier per tick.  m + 2 + 3 (p - 1) ticks instead of p (m - 1) serial rotations, no fused
+// multiply-add, glibc's hypot restated: T and Q are bit-identical to the host routine (tests/test_gpu_small.py).
+// LDS: rot_c / rot_s [p][m], d0 / e0 / dout / eout [m], Q [m][m].
+// ===================================================================================================
+__global__ __launch_bounds__(256) void k_restart_pipelined(int m, double* __restrict__ diag_io, double* __restrict__ subd_io,
+                                                           ShiftList shifts, int nshift, double* __restrict__ Qout)
+{
+    MISPEC_NO_CONTRACT
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* rot_c = sm;
+    double* rot_s = rot_c + size_t(nshift) * m;
+    double* d0 = rot_s + size_t(nshift) * m;
+    double* e0 = d0 + m;
+    double* dout = e0 + m;
+    double* eout = dout + m;
+    double* Q = eout + m;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = m, n1 = m - 1;
+    for (int i = tid; i < m; i += 256)
+    {
+        const double d = diag_io[i];
+        d0[i] = d;
+        double e = 0.0;
+        if (i < n1)
+        {
+            e = subd_io[i];
+            if (fabs(e) <= small::kEps * (fabs(d) + fabs(diag_io[i + 1])))  // UpperHessenbergQR.h:526-539
+                e = 0.0;
+        }
+        e0[i] = e;
+    }
+    for (int idx = tid; idx < m * m; idx += 256)
+        Q[idx] = (idx / m == idx % m) ? 1.0 : 0.0;
+    __syncthreads();
+    const int last = nshift - 1;
+    const int ticks = (n + 2) + 3 * last;
+    small::SweepLane L = {};
+    if (wave == 0 && lane < nshift)
+        L.mu = shifts.mu[lane];
+    for (int t = 0; t <= ticks; t++)
+    {
+        if (wave == 0)
+        {
+            if (t < ticks)
+            {
+                const int j = t - 3 * lane - 1;
+                double din = __shfl_up(L.out_d, 1, 64);
+                double ein = __shfl_up(L.out_e, 1, 64);
+                if (lane == 0)
+                {
+                    din = (j + 1 <= n1) ? d0[j + 1] : 0.0;
+                    ein = (j >= 0 && j <= n - 2) ? e0[j] : 0.0;
+                }
+                if (lane < nshift && j >= -1 && j <= n)
+                {
+                    if (j == n)
+                        small::sweep_tail(L);
+                    else
+                        small::sweep_tick(L, n, j, din, ein, rot_c + size_t(lane) * m, rot_s + size_t(lane) * m);
+                    if (lane == last)
+                    {
+                        if (j >= 1)
+                            dout[j - 1] = L.out_d;
+                        if (j >= 2)
+                            eout[j - 2] = L.out_e;
+                    }
+                }
+            }
+        }
+        else if (t >= 1)
+        {
+            // the rotations of tick t - 1: sweep s at j = t - 2 - 3 s, 0 <= j <= n - 2
+            const int tp = t - 2;
+            int s_hi = tp / 3;  // j >= 0
+            if (tp < 0)
+                s_hi = -1;
+            if (s_hi > last)
+                s_hi = last;
+            int s_lo = (tp - (n - 2) + 2) / 3;  // j <= n - 2  <=>  s >= (tp - n + 2) / 3
+            if (tp - (n - 2) <= 0)
+                s_lo = 0;
+            const int nact = s_hi - s_lo + 1;
+            for (int item = tid - 64; item < nact * m; item += 192)
+            {
+                const int s = s_lo + item / m, r = item % m;
+                const int j = tp - 3 * s;
+                const double c = rot_c[size_t(s) * m + j], sn = rot_s[size_t(s) * m + j];
+                double* Yi = Q + size_t(j) * m;
+                const double qa = Yi[r], qb = Yi[m + r];
+                Yi[r] = c * qa - sn * qb;  // apply_YQ (:403-416)
+                Yi[m + r] = sn * qa + c * qb;
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < m; i += 256)
+    {
+        diag_io[i] = dout[i];
+        if (i < n1)
+            subd_io[i] = eout[i];
+    }
+    for (int idx = tid; idx < m * m; idx += 256)
+        Qout[idx] = Q[idx];
+}
+
 }  // namespace
 
 namespace mispec {
@@ -432,6 +545,22 @@ void launch_restart_sym(const mispec_ctx& ctx, int m, double* diag, double* subd
     MISPEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_restart_sym), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    int(lds)));
     hipLaunchKernelGGL(k_restart_sym, dim3(1), dim3(64), lds, ctx.stream, m, diag, subd, sl, nshift, Q);
+    MISPEC_HIP(hipGetLastError());
+}
+
+void launch_restart_pipelined(const mispec_ctx& ctx, int m, double* diag, double* subd, const double* shifts_host, int nshift,
+                              double* Q)
+{
+    MISPEC_REQUIRE(m >= 2 && m <= kMaxPipelinedDim, "pipelined restart kernel: dimension out of range");
+    MISPEC_REQUIRE(nshift >= 1 && nshift <= 64 && nshift < m, "pipelined restart kernel: 1 <= shifts <= 64");
+    ShiftList sl;
+    for (int i = 0; i < nshift; i++)
+        sl.mu[i] = shifts_host[i];
+    const size_t lds = (size_t(2) * nshift * m + size_t(4) * m + size_t(m) * m) * sizeof(double);
+    if (lds > 65536)
+        MISPEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_restart_pipelined), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       int(lds)));
+    hipLaunchKernelGGL(k_restart_pipelined, dim3(1), dim3(256), lds, ctx.stream, m, diag, subd, sl, nshift, Q);
     MISPEC_HIP(hipGetLastError());
 }
 
@@ -566,6 +695,99 @@ extern "C" int mispec_tridiag_qr(mispec_ctx* ctx, int n, const double* T_host, d
                 QtHQ_host[size_t(i + 1) * n + i] = e[size_t(i)];
             }
         }
+    });
+}
+
+// All shifts of one restart, by variant (unit tests and latency probe; mispec.h): 0 host, the reference's serial order
+// (tridiag_shifted_qr per shift), 1 host, skewed pipeline + SIMD rows, 2 device, k_restart_pipelined, 3 device, one wavefront.
+extern "C" int mispec_restart_sweeps(mispec_ctx* ctx, int n, const double* diag_host, const double* subd_host, const double* shifts_host,
+                                     int nshift, int variant, int reps, double* diag_out, double* subd_out, double* Q_out,
+                                     double* us_per_call)
+{
+    return guarded([&] {
+        MISPEC_REQUIRE(diag_host && subd_host && shifts_host && n >= 2 && nshift >= 1 && nshift < n && reps >= 1 && variant >= 0 &&
+                           variant <= 3,
+                       "mispec_restart_sweeps: bad argument");
+        MISPEC_REQUIRE(variant < 2 || ctx, "mispec_restart_sweeps: the device variants need a context");
+        std::vector<double> d((size_t) n), e((size_t) n, 0.0), Q(size_t(n) * n);
+        double us = 0.0;
+        if (variant < 2)
+        {
+            const int ld = (n + 7) / 8 * 8;
+            std::vector<double> Qp(size_t(ld) * n), work(size_t(2 * nshift + 2) * n + size_t(4) * n);
+            std::vector<small::SweepLane> lanes((size_t) nshift);
+            double best = 1e300;
+            for (int rep = 0; rep < reps; rep++)
+            {
+                std::copy(diag_host, diag_host + n, d.begin());
+                std::copy(subd_host, subd_host + n - 1, e.begin());
+                e[size_t(n) - 1] = 0.0;
+                const auto t0 = std::chrono::steady_clock::now();
+                if (variant == 0)
+                {
+                    std::fill(Q.begin(), Q.end(), 0.0);
+                    for (int i = 0; i < n; i++)
+                        Q[size_t(i) * n + i] = 1.0;
+                    for (int sft = 0; sft < nshift; sft++)
+                        small::tridiag_shifted_qr(n, d.data(), e.data(), shifts_host[sft], Q.data(), n, n, work.data(), small::Lanes{0, 1});
+                }
+                else
+                {
+                    std::fill(Qp.begin(), Qp.end(), 0.0);
+                    for (int i = 0; i < n; i++)
+                        Qp[size_t(i) * ld + i] = 1.0;
+                    small::restart_rotations_pipelined(n, d.data(), e.data(), shifts_host, nshift, work.data(), lanes.data());
+                    small::apply_sweeps_to_Q(Qp.data(), ld, ld, n, work.data(), work.data() + size_t(nshift) * n, nshift);
+                    for (int c = 0; c < n; c++)
+                        std::copy(Qp.begin() + size_t(c) * ld, Qp.begin() + size_t(c) * ld + n, Q.begin() + size_t(c) * n);
+                }
+                best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+            }
+            us = best;
+        }
+        else
+        {
+            ctx->make_current();
+            SmallBufs b;
+            b.diag.alloc(size_t(n) * size_t(reps));
+            b.subd.alloc(size_t(n) * size_t(reps));
+            b.mat.alloc(size_t(n) * n);
+            std::copy(subd_host, subd_host + n - 1, e.begin());
+            for (int rep = 0; rep < reps; rep++)
+            {
+                MISPEC_HIP(hipMemcpyAsync(b.diag.p + size_t(rep) * n, diag_host, size_t(n) * 8, hipMemcpyHostToDevice, ctx->stream));
+                MISPEC_HIP(hipMemcpyAsync(b.subd.p + size_t(rep) * n, e.data(), size_t(n) * 8, hipMemcpyHostToDevice, ctx->stream));
+            }
+            hipEvent_t e0, e1;
+            MISPEC_HIP(hipEventCreate(&e0));
+            MISPEC_HIP(hipEventCreate(&e1));
+            MISPEC_HIP(hipEventRecord(e0, ctx->stream));
+            for (int rep = 0; rep < reps; rep++)
+            {
+                if (variant == 2)
+                    launch_restart_pipelined(*ctx, n, b.diag.p + size_t(rep) * n, b.subd.p + size_t(rep) * n, shifts_host, nshift, b.mat.p);
+                else
+                    launch_restart_sym(*ctx, n, b.diag.p + size_t(rep) * n, b.subd.p + size_t(rep) * n, shifts_host, nshift, b.mat.p);
+            }
+            MISPEC_HIP(hipEventRecord(e1, ctx->stream));
+            MISPEC_HIP(hipMemcpyAsync(d.data(), b.diag.p, size_t(n) * 8, hipMemcpyDeviceToHost, ctx->stream));
+            MISPEC_HIP(hipMemcpyAsync(e.data(), b.subd.p, size_t(n) * 8, hipMemcpyDeviceToHost, ctx->stream));
+            MISPEC_HIP(hipMemcpyAsync(Q.data(), b.mat.p, size_t(n) * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+            MISPEC_HIP(hipStreamSynchronize(ctx->stream));
+            float ms = 0.f;
+            MISPEC_HIP(hipEventElapsedTime(&ms, e0, e1));
+            MISPEC_HIP(hipEventDestroy(e0));
+            MISPEC_HIP(hipEventDestroy(e1));
+            us = 1e3 * double(ms) / reps;
+        }
+        if (diag_out)
+            std::copy(d.begin(), d.end(), diag_out);
+        if (subd_out)
+            std::copy(e.begin(), e.begin() + n - 1, subd_out);
+        if (Q_out)
+            std::copy(Q.begin(), Q.end(), Q_out);
+        if (us_per_call)
+            *us_per_call = us;
     });
 }
 

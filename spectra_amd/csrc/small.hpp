@@ -18,6 +18,11 @@ void launch_tridiag_eigen(const mispec_ctx& ctx, int n, const double* diag, cons
 void launch_restart_sym(const mispec_ctx& ctx, int m, double* diag, double* subd, const double* shifts_host, int nshift,
                         double* Q);
 
+// The same sweeps as a skewed pipeline over 256 threads (internal/SmallDensePipelined.h): bit-identical to the host routine.
+constexpr int kMaxPipelinedDim = 64;  // LDS: (2 p m + 4 m + m^2) * 8 B <= 100 KiB at m = 64, p = 63
+void launch_restart_pipelined(const mispec_ctx& ctx, int m, double* diag, double* subd, const double* shifts_host, int nshift,
+                              double* Q);
+
 // General (Hessenberg) restart on the device (a19): a list of shifts applied to the m x m Hessenberg H (device, in/out,
 // leading dimension m), accumulating Q (m x m, written).  kind 0: one real shift `a` (UpperHessenbergQR); kind 1: a
 // conjugate pair as the double shift (s, t) = (a, b) (DoubleShiftQR).  One wavefront, H and Q resident in LDS: m <= kMaxGenDim.

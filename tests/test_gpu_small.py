@@ -53,3 +53,39 @@ def test_tridiag_eigen_special_cases(ctx):
     assert np.array_equal(ev, [3.0, -1.0, 2.0]) and np.array_equal(U, np.eye(3))
     with pytest.raises(ValueError):
         sa.tridiag_eigen(np.zeros((129, 129)), ctx=ctx)
+
+
+# ---- the sweeps of a restart as a skewed pipeline on the device (k_restart_pipelined) ------------------------------------------
+@pytest.mark.parametrize("kind", ["dense", "graded", "zeros"])
+@pytest.mark.parametrize("n,p", [(2, 1), (3, 2), (5, 4), (17, 9), (40, 18), (40, 26), (40, 39), (50, 20), (64, 63), (64, 1)])
+def test_pipelined_restart_kernel_equals_the_host_routine_bit_for_bit(ctx, n, p, kind):
+    # lane s of wave 0 = sweep s, waves 1-3 rotate Q: no fused multiply-add, glibc's hypot restated for the device
+    # (SmallDensePipelined.h) — T and Q must be the host's bits, so that either side can run a restart's sweeps
+    from test_host_small_pipelined import _case
+
+    d, e, mu = _case(n, p, 1000 * n + p, kind)
+    d0, e0, Q0, _ = sa.restart_sweeps(d, e, mu, "host-serial")
+    d2, e2, Q2, _ = sa.restart_sweeps(d, e, mu, "device-pipelined", ctx=ctx)
+    assert np.array_equal(d0, d2) and np.array_equal(e0, e2) and np.array_equal(Q0, Q2)
+
+
+def test_pipelined_restart_kernel_many_random_shapes(ctx):
+    from test_host_small_pipelined import _case
+
+    rng = np.random.default_rng(11)
+    for trial in range(120):
+        n = int(rng.integers(2, 65))
+        p = int(rng.integers(1, n))
+        d, e, mu = _case(n, p, 5000 + trial, ["dense", "graded", "zeros"][trial % 3])
+        a = sa.restart_sweeps(d, e, mu, "host-pipelined")
+        b = sa.restart_sweeps(d, e, mu, "device-pipelined", ctx=ctx)
+        assert all(np.array_equal(x, y) for x, y in zip(a[:3], b[:3])), (trial, n, p)
+
+
+def test_one_wavefront_restart_kernel_agrees_to_rounding(ctx):
+    from test_host_small_pipelined import _case
+
+    d, e, mu = _case(40, 18, 3, "dense")
+    d0, e0, Q0, _ = sa.restart_sweeps(d, e, mu, "host-serial")
+    d3, e3, Q3, _ = sa.restart_sweeps(d, e, mu, "device-wavefront", ctx=ctx)
+    assert np.abs(d0 - d3).max() < 1e-12 and np.abs(e0 - e3).max() < 1e-12 and np.abs(Q0 - Q3).max() < 1e-12
