@@ -642,6 +642,14 @@ def main():
     from spectra_amd import dist as sdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    rccl_log = None
+    if world > 1 and os.environ.get("MISPEC_COMM") != "gloo-staged" and "NCCL_DEBUG" not in os.environ:
+        # the first multi-GPU run has to be diagnostic without a second try: RCCL's own account of the
+        # topology and of the algorithm / protocol / channels it picked goes to a per-rank file, rank 0's digest into the line
+        rccl_log = f"/tmp/mispec_rccl_rank{os.environ.get('RANK', '0')}_{os.getpid()}.log"
+        os.environ["NCCL_DEBUG"] = "INFO"
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,ENV")
+        os.environ["NCCL_DEBUG_FILE"] = rccl_log
     if world > 1 or args.gpus > 1 or os.environ.get("MISPEC_FORCE_COMM") == "1":
         # MISPEC_COMM=gloo-staged (tests on a box with fewer GPUs than ranks): gloo process group, collectives staged through
         # host memory, ranks beyond the device count share the last device — exercises this file's N > 1 path end to end
@@ -735,6 +743,44 @@ def main():
             del os.environ["MISPEC_EXCHANGE"]
         else:
             os.environ["MISPEC_EXCHANGE"] = prev
+    # the wire, timed on its own (profile level 3: HIP events around the exchange on its stream, around the part of it a product
+    # waits for, around the all-reduces) in one more solve outside the timed region — flat `wire_*` scalars in the line
+    wire = None
+    if world > 1:
+        we = new_solver(3)
+        solve(we)
+        w0 = we.get_profile()
+        barrier()
+        t0 = time.perf_counter()
+        solve(we)
+        barrier()
+        w_dt = sdist.max_over_ranks(time.perf_counter() - t0)
+        w1 = we.get_profile()
+        wd = {k: w1[k] - w0[k] for k in w1 if k != "spmv_bytes"}
+        nops_w = max(wd["n_spmv"], 1)
+        wire = {"ms_per_solve_instrumented": 1e3 * w_dt, "operations": int(wd["n_spmv"]),
+                "exchange_us": 1e3 * wd["ms_exchange"] / max(wd["n_exchange"], 1), "exchanges": int(wd["n_exchange"]),
+                "exchange_wait_us": 1e3 * wd["ms_exchange_wait"] / max(wd["n_exchange_wait"], 1), "exchange_waits": int(wd["n_exchange_wait"]),
+                "overlap_frac": (1.0 - wd["ms_exchange_wait"] / wd["ms_exchange"]) if wd["ms_exchange"] > 0 else None,
+                "allreduce_us": 1e3 * wd["ms_allreduce"] / max(wd["n_allreduce"], 1), "allreduces": int(wd["n_allreduce"]),
+                "allreduces_per_operation": wd["n_allreduce"] / nops_w,
+                "wire_ms_per_solve": wd["ms_exchange_wait"] + wd["ms_allreduce"],
+                "spmv_ms_per_launch_incl_exchange_wait": wd["ms_spmv"] / nops_w,
+                "note": "rank 0's HIP events (mispec_profile level 3) of ONE extra solve: exchange = the neighbour exchange / all-gather of the Krylov "
+                        "vector on its own stream; exchange_wait = what the product still waits for once the interior row blocks are done "
+                        "(overlap_frac = 1 - wait / exchange); allreduce = the record / alpha all-reduces on the compute stream; "
+                        "wire_ms_per_solve = exchange_wait + allreduce, the wire's share of the critical path"}
+        del we
+    rccl_info = None
+    if rccl_log and rank == 0:
+        try:
+            keys = ("Ring", "Tree", "Channel 00", "nChannels", "comm 0x", "via ", "XGMI", "P2P", "nNodes", "Algo", "Proto", "NCCL_", "RCCL", "HSA_", "topo")
+            with open(rccl_log) as f:
+                hits = [ln.strip()[-220:] for ln in f if any(k in ln for k in keys)]
+            rccl_info = hits[:40]
+            sys.stderr.write("[bench] RCCL (NCCL_DEBUG=INFO, rank 0, first matching lines):\n" + "\n".join(rccl_info[:40]) + "\n")
+        except OSError as ex:
+            rccl_info = [repr(ex)]
     # the other orthogonalisation mode on the same matrix, same number of steps (not part of `value`)
     other_mode = None
     if True:  # always reported, with or without profiling
@@ -927,6 +973,12 @@ def main():
                         "reference flow: alpha, V'f and the correction's V'f check"}
         if allgather_run:
             out["allgather_variant"] = allgather_run
+        if wire:
+            out["wire"] = wire
+            for k in ("exchange_us", "exchange_wait_us", "overlap_frac", "allreduce_us", "allreduces_per_operation", "wire_ms_per_solve"):
+                out["wire_" + k if not k.startswith("wire_") else k] = wire[k]
+        if rccl_info is not None:
+            out["rccl_info"] = rccl_info
         if world == 1 and not args.no_secondary and not args.no_profile:
             try:
                 out["secondary"] = secondary_configs(args, ctx, op, sa)

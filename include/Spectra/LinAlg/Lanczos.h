@@ -1,6 +1,10 @@
 // Symmetric specialisation of the device factorisation: three-term recurrence, always-on V'f check with
 // up to five corrections, tridiagonal H (reference: LinAlg/Lanczos.h:28-217).  Adds the two restart
-// primitives that operate on the tridiagonal H entirely on the GPU.
+// primitives on the tridiagonal H.  Where their m x m arithmetic runs: on a host core by default — serial chains of
+// rotations that a 2.4 GHz lane runs several times slower than a core (measured: profiles/r11g_restart_sweeps_latency.jsonl)
+// — with H coming home through pinned memory and Q going back the same way; option small=device keeps it on the GPU
+// (spectra_amd/csrc/small.hip: k_tridiag_eigen*, k_restart_sym*, k_restart_pipelined).  The n-sized work (V*Q, the residual)
+// is always the device's.
 #ifndef MISPEC_SPECTRA_LANCZOS_H
 #define MISPEC_SPECTRA_LANCZOS_H
 
@@ -22,8 +26,9 @@ public:
 
     Lanczos(const OpType& op, Index m) : Base(op, m, true) {}
 
-    // Eigen-decomposition of the projected tridiagonal H (TridiagEigen, LinAlg/TridiagEigen.h:121-210),
-    // computed by a single-workgroup LDS kernel.  evals has m entries, evecs is m x m.
+    // Eigen-decomposition of the projected tridiagonal H (TridiagEigen, LinAlg/TridiagEigen.h:121-210):
+    // internal/SmallDense.h tridiag_eigen on the host core (default) or as a one-workgroup LDS kernel (small=device).
+    // evals has m entries, evecs is m x m.
     void ritz_pairs(Vector& evals, Matrix& evecs) const
     {
         evals.resize(m_m);
@@ -42,7 +47,9 @@ public:
 
     // Implicit restart with the given shifts, already in the order they are to be applied
     // (HermEigsBase.h:118-147): per shift QR of H - mu I by Givens rotations, Q <- Q Qi, H <- Qi' H Qi —
-    // one LDS-resident kernel — then V <- V Q and the new residual (Arnoldi.h:320-340).
+    // all shifts as one skewed pipeline (internal/SmallDensePipelined.h; bit-identical to the serial order), on the
+    // host core by default — then V <- V Q and the new residual on the device (Arnoldi.h:320-340), with the next
+    // sweep of Lanczos steps enqueued behind it.
     // Afterwards subspace_dim() == m - nshift.
     void restart_with_shifts(const Scalar* shifts, Index nshift)
     {

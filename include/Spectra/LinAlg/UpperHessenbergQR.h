@@ -3,9 +3,10 @@
 //   TridiagQR<double>:         the same for a symmetric tridiagonal T  (:470-711)
 // Same member names as the reference: compute(), matrix_R(), matrix_QtHQ(), apply_QY(), apply_QtY(), apply_YQ(),
 // apply_YQt() (vector and matrix forms, :204-460).  The symmetric solver does
-// NOT use these classes on its fast path — its sweeps run in one LDS-resident kernel (csrc/small.hip,
-// same arithmetic from internal/SmallDense.h); they serve the general solver's restart, user code and
-// the CPU-side unit tests.
+// NOT use these classes on its fast path — all sweeps of a restart run as one skewed pipeline
+// (internal/SmallDensePipelined.h: host core by default, csrc/small.hip kernels with small=device; same
+// arithmetic as internal/SmallDense.h); they serve the general solver's restart, user code and the
+// CPU-side unit tests.
 #ifndef MISPEC_SPECTRA_UPPER_HESSENBERG_QR_H
 #define MISPEC_SPECTRA_UPPER_HESSENBERG_QR_H
 

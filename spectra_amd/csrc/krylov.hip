@@ -997,7 +997,8 @@ __global__ __launch_bounds__(256) void k_publish_state(const StepState* __restri
 }
 
 // Start of a restart: Q (m x m) and the start state of the next sweep (diag / subd after compress_H) are read from a pinned
-// host buffer [Q m*m][diag m][subd m] by ONE small kernel in front of the V*Q pass (instead of two hipMemcpyAsync).
+// host buffer [Q m*m][diag m][subd m] by ONE small kernel in front of the V*Q pass (instead of two hipMemcpyAsync); one element
+// per thread: every read crosses PCIe, so all of them have to be in flight at once (one round trip, not four).
 __global__ __launch_bounds__(256) void k_fetch_restart(const double* __restrict__ host_src, int m, double* __restrict__ Qdev,
                                                         StepState* st, int with_state)
 {
@@ -1853,7 +1854,7 @@ void launch_publish_state(const mispec_ctx& ctx, const StepState* st, int m, Ste
 
 void launch_fetch_restart(const mispec_ctx& ctx, const double* host_src, int m, double* Qdev, StepState* st, int with_state)
 {
-    hipLaunchKernelGGL(k_fetch_restart, dim3(unsigned((m * m + 1023) / 1024)), dim3(256), 0, ctx.stream, host_src, m, Qdev, st,
+    hipLaunchKernelGGL(k_fetch_restart, dim3(unsigned((m * m + 255) / 256)), dim3(256), 0, ctx.stream, host_src, m, Qdev, st,
                        with_state);
     MISPEC_HIP(hipGetLastError());
 }

@@ -527,10 +527,17 @@ void launch_tridiag_eigen(const mispec_ctx& ctx, int n, const double* diag, cons
 }
 
 void launch_restart_sym(const mispec_ctx& ctx, int m, double* diag, double* subd, const double* shifts_host, int nshift,
-                        double* Q)
+                        double* Q, bool allow_pipelined)
 {
     MISPEC_REQUIRE(m >= 2 && m <= kMaxSmallDim, "restart kernel: dimension out of range");
     MISPEC_REQUIRE(nshift >= 0 && nshift <= kMaxShifts, "restart kernel: too many shifts");
+    // the skewed pipeline over four wavefronts where it applies: 110 against 380 us at m = 40, 18 shifts, and the host's bits
+    // (profiles/r11g_restart_sweeps_latency.jsonl)
+    if (allow_pipelined && m <= kMaxPipelinedDim && nshift >= 1 && nshift <= 64 && nshift < m)
+    {
+        launch_restart_pipelined(ctx, m, diag, subd, shifts_host, nshift, Q);
+        return;
+    }
     ShiftList sl;
     for (int i = 0; i < nshift; i++)
         sl.mu[i] = shifts_host[i];
@@ -767,7 +774,7 @@ extern "C" int mispec_restart_sweeps(mispec_ctx* ctx, int n, const double* diag_
                 if (variant == 2)
                     launch_restart_pipelined(*ctx, n, b.diag.p + size_t(rep) * n, b.subd.p + size_t(rep) * n, shifts_host, nshift, b.mat.p);
                 else
-                    launch_restart_sym(*ctx, n, b.diag.p + size_t(rep) * n, b.subd.p + size_t(rep) * n, shifts_host, nshift, b.mat.p);
+                    launch_restart_sym(*ctx, n, b.diag.p + size_t(rep) * n, b.subd.p + size_t(rep) * n, shifts_host, nshift, b.mat.p, false);
             }
             MISPEC_HIP(hipEventRecord(e1, ctx->stream));
             MISPEC_HIP(hipMemcpyAsync(d.data(), b.diag.p, size_t(n) * 8, hipMemcpyDeviceToHost, ctx->stream));

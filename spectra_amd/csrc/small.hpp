@@ -15,8 +15,9 @@ struct ShiftList
 void launch_tridiag_eigen(const mispec_ctx& ctx, int n, const double* diag, const double* subd, double* evals, double* evecs,
                           int* info);
 // nshift x { TridiagQR::compute(T, mu); Q <- Q Qi; T <- Qi' T Qi } ; diag/subd updated in place, Q[m*m] written.
+// allow_pipelined: k_restart_pipelined where it applies (m <= 64), else the one-wavefront kernels.
 void launch_restart_sym(const mispec_ctx& ctx, int m, double* diag, double* subd, const double* shifts_host, int nshift,
-                        double* Q);
+                        double* Q, bool allow_pipelined = true);
 
 // The same sweeps as a skewed pipeline over 256 threads (internal/SmallDensePipelined.h): bit-identical to the host routine.
 constexpr int kMaxPipelinedDim = 64;  // LDS: (2 p m + 4 m + m^2) * 8 B <= 100 KiB at m = 64, p = 63
