@@ -272,6 +272,8 @@ def flatten_for_the_driver(out):
         flat["secondary_c5_solve_ms"] = sec["c5"].get("solve_ms")
     if out.get("roofline_orth"):
         flat["orth_frac"] = out["roofline_orth"].get("frac")
+        if isinstance(out["roofline_orth"].get("pass_only"), dict):
+            flat["orth_pass_frac"] = out["roofline_orth"]["pass_only"].get("frac")
     if isinstance(out.get("solve"), dict) and "host_syncs_per_solve" in out["solve"]:
         flat["host_syncs_per_solve"] = out["solve"]["host_syncs_per_solve"]
     if isinstance(out.get("solve"), dict) and out["solve"].get("host_turn_us") is not None:
@@ -393,14 +395,17 @@ def shard_proxy(args, ctx, sa, c2_ms_per_op, parts=8):
     turns = t_after["turns"] - t_before["turns"]
     out = {"rows": rows, "nconv": int(nconv), "num_operations": nops, "num_iterations": int(e.num_iterations()),
            "ms_per_solve": wall_ms, "us_per_operation": 1e3 * wall_ms / nops,
-           "busy_ms_per_solve_instrumented": busy_ms, "idle_frac_est": max(0.0, 1.0 - busy_ms / wall_ms),
+           "busy_ms_per_solve_instrumented": busy_ms,
+           "idle_frac_est": ((1e3 * (t_after["host_seconds"] - t_before["host_seconds"]) / reps) / wall_ms) if turns else 0.0,
            "reduce_us": 1e3 * fam.get("reduce", 0.0) / n_red if n_red else None,
            "host_turn_us": 1e6 * (t_after["host_seconds"] - t_before["host_seconds"]) / turns if turns else None,
            "host_syncs_per_solve": (p_after["n_host_sync"] - p_before["n_host_sync"]) / reps,
            "speedup_8_compute_only": c2_ms_per_op / (wall_ms / nops) if c2_ms_per_op else None,
            "max_residual": float(e.residuals().max()),
-           "note": "idle_frac_est = 1 - (sum of the kernel families' event times of an instrumented solve) / (wall of the un-instrumented "
-                   "solves): an estimate — the rocprofv3 gap analysis of the same workload is in profiles/ (trace_gaps_1250000_rows); "
+           "note": "idle_frac_est = (host turns of a solve x their host time) / wall: the device has nothing to run while the host forms the "
+                   "Ritz values and the restart's Q — every other gap of the trace is below a microsecond (rocprofv3 gap analysis of the same "
+                   "workload: profiles/*trace_gaps_1250000_rows*); busy_ms_per_solve_instrumented brackets every family with events and is "
+                   "inflated by them (it can exceed the wall time of the un-instrumented solves); "
                    "reduce_us is an event pair around the one-kernel record reduction (includes ~2 us of event overhead); host_turn_us = "
                    "host time between 'state of the finished sweep seen' and 'restart enqueued' (mispec_symeigs_turn_info)"}
     del e, sop
@@ -819,11 +824,19 @@ def main():
         del Xh
     # per-family kernel split: one more solve with every family instrumented, not part of `value`
     split = None
+    pass_only = None
     if not args.no_profile:
         full = new_solver(1)
         solve(full)
         split = full.get_profile()
         del full
+        # ... and one with ONLY the passes over the basis bracketed (level 4): with every family bracketed the event pairs
+        # themselves stretch each 0.5 ms pass by ~10 % (they keep the next launch from being prepared behind the running
+        # kernel); alone they cost ~1 % — the figure that agrees with the rocprofv3 trace of the same kernels
+        po = new_solver(4)
+        solve(po)
+        pass_only = po.get_profile()
+        del po
     resid = eigs.residuals()
     evals = eigs.eigenvalues()
     turn1 = eigs.turn_info()
@@ -947,6 +960,15 @@ def main():
                 "frac": split["bytes_vtf"] / (split["ms_vtf"] * 1e-3) / 1e9 / HBM_PEAK_GBPS if split["ms_vtf"] > 0 else None,
                 "note": "algorithmic bytes (8 n x vectors read + written, summed over the launches of one solve) over the family's HIP-event "
                         "time, which also covers the ~10 us record reduction behind every pass; from the instrumented extra solve",
+                "pass_only": ({"ms_per_solve": pass_only["ms_vtf"], "bytes_per_solve": pass_only["bytes_vtf"],
+                               "passes": int(pass_only["n_vtf"] - pass_only["n_reduce"]),
+                               "ms_per_pass_mean": pass_only["ms_vtf"] / max(pass_only["n_vtf"] - pass_only["n_reduce"], 1),
+                               "achieved": pass_only["bytes_vtf"] / (pass_only["ms_vtf"] * 1e-3) / 1e9,
+                               "frac": pass_only["bytes_vtf"] / (pass_only["ms_vtf"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                               "note": "one more solve with ONLY the passes bracketed by HIP events (mispec_profile level 4, no record "
+                                       "reductions inside): the kernels' own time, agreeing with rocprofv3's AverageNs of k_orth_lagged_dma "
+                                       "(profiles/r11f_c2_only_dia_kernel_stats.csv); `frac` above brackets every family and is ~10 % "
+                                       "pessimistic for it"} if pass_only and pass_only["ms_vtf"] > 0 else None),
                 "compress": {"kernel": ("k_vq_fused (V <- V Q in place with the pending correction of the sweep's last step, its V'f test and the "
                                         "restarted residual on the same tiles), k_vq (X = V Y)" if args.orth == "onesweep"
                                         else "k_vq (V <- V Q in place, X = V Y)"), "achieved": split["bytes_compress"] / (split["ms_compress"] * 1e-3) / 1e9

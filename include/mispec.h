@@ -476,7 +476,8 @@ int mispec_fac_residuals_complex(mispec_fac* fac, const double* Yre_host, const 
 
 /* Profile of the factorisation so far: counts and accumulated HIP-event time (ms) per kernel family.
  * Timing is only collected between mispec_fac_profile(fac, level) and mispec_fac_profile(fac, 0); level 1 brackets
- * every kernel family with an event pair, level 3 the operator applications and the collectives of a sharded run, level 2 only the operator applications (the SpMV roofline figure) —
+ * every kernel family with an event pair, level 3 the operator applications and the collectives of a sharded run, level 2 only the
+ * operator applications (the SpMV roofline figure), level 4 only the passes over the basis (ms_vtf / bytes_vtf without the record reductions) —
  * the event records cost a few microseconds each, which matters when the shards are small. */
 typedef struct mispec_profile
 {

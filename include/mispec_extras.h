@@ -2,8 +2,13 @@
  * mispec_extras.h — C ABI of the components OUTSIDE the hot path of SURVEY.md section 8
  * (BASELINE.json north_star): dense operators, the block Davidson solver, the complex-shift
  * operator / solver and the Buckling / Cayley modes of the generalized shift solver.  They were
- * built in rounds 1-2, are exported by the same libmispec.so and are kept working, but they are
- * not part of the thin shim the hot path needs: include/mispec.h alone is that shim.
+ * built in rounds 1-2 and are kept working, but they are not part of the thin shim the hot path
+ * needs: include/mispec.h alone is that shim.
+ * Where they live (round 6): the Davidson solver and the complex factorisation (mispec_davidson_*,
+ * mispec_zdense_*, mispec_zfac_*: their own kernels, nothing in the hot path calls them) are in a
+ * library of their own, spectra_amd/libmispec_extras.so, built on libmispec.so — link -lmispec_extras
+ * -lmispec.  The dense operators and the shift variants share objects with the hot path (the dense
+ * GEMV applies the last level of the banded shift solve) and stay in libmispec.so.
  * Conventions (handles, error codes, ownership) as in mispec.h.
  * ============================================================================= */
 #ifndef MISPEC_EXTRAS_H

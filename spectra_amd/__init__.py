@@ -517,6 +517,10 @@ class SparseSymShiftSolve:
         check(lib().mispec_symshift_solve_host(self.h, _dp(x), _dp(y)))
         return y
 
+    def solve_device(self, x_ptr, y_ptr):
+        """y = (A - sigma I)^{-1} x on device pointers, enqueued on the context's stream (mispec_symshift_solve)."""
+        check(lib().mispec_symshift_solve(self.h, C.c_void_p(int(x_ptr)), C.c_void_p(int(y_ptr))))
+
     def __del__(self):
         try:
             lib().mispec_symshift_destroy(self.h)

@@ -9,6 +9,8 @@ import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libmispec.so")
+EXTRAS_LIB_PATH = os.path.join(_PKG, "libmispec_extras.so")  # Davidson solver, complex factorisation (mispec_extras.h)
+EXTRAS_PREFIXES = ("mispec_davidson_", "mispec_zdense_", "mispec_zfac_")
 CSRC = os.path.join(_PKG, "csrc")
 
 MISPEC_OK, MISPEC_EINVAL, MISPEC_ELOGIC, MISPEC_ERUNTIME = 0, -1, -2, -3
@@ -281,10 +283,22 @@ def lib():
                 "spectra_amd/libmispec.so is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  This package has no CPU fallback.")
         L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        X = None
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(L, name)  # AttributeError here = header and library out of sync
+            if name.startswith(EXTRAS_PREFIXES):
+                # components outside the hot path: their own library on top of this one (resolved through the handle of the
+                # first, so that Python code keeps saying lib().mispec_davidson_create)
+                if X is None:
+                    if not os.path.exists(EXTRAS_LIB_PATH):
+                        raise ImportError("spectra_amd/libmispec_extras.so is missing — build it with `make -C spectra_amd/csrc`")
+                    X = C.CDLL(EXTRAS_LIB_PATH, mode=C.RTLD_GLOBAL)
+                fn = getattr(X, name)
+                setattr(L, name, fn)
+            else:
+                fn = getattr(L, name)  # AttributeError here = header and library out of sync
             fn.restype = res
             fn.argtypes = args
+        L._extras = X
         _lib = L
     return _lib
 

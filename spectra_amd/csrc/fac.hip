@@ -235,12 +235,18 @@ struct Timed
     int fam;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipStream_t on = nullptr;
-    Timed(mispec_fac& f, int family, hipStream_t other_stream = nullptr) : F(f), fam(family), on(other_stream ? other_stream : f.stream())
+    Timed(mispec_fac& f, int family, hipStream_t other_stream = nullptr, bool is_pass = true)
+        : F(f), fam(family), on(other_stream ? other_stream : f.stream())
     {
         F.counts[fam]++;
         const bool wire = fam == FAM_EXCH || fam == FAM_XWAIT || fam == FAM_ALLRED;
-        // level 2: only the operator applications are timed; level 3: those and the collectives; level 1: every kernel family
-        if (!F.prof || (F.prof == 2 && fam != FAM_SPMV) || (F.prof == 3 && fam != FAM_SPMV && !wire) || (F.prof != 3 && wire))
+        // level 2: only the operator applications are timed; level 3: those and the collectives; level 1: every kernel family;
+        // level 4: only the passes over the basis (FAM_VTF without the record reductions behind them) — an event pair costs a
+        // few microseconds and keeps the next launch from being prepared behind the running kernel, so a family is measured
+        // best when it is the only one bracketed (the one-sweep pass: 467 us per launch in a rocprofv3 trace, 472 at level 4,
+        // 514 at level 1)
+        if (!F.prof || (F.prof == 2 && fam != FAM_SPMV) || (F.prof == 3 && fam != FAM_SPMV && !wire) || (F.prof != 3 && wire) ||
+            (F.prof == 4 && (fam != FAM_VTF || !is_pass)))
             return;
         e0 = take();
         e1 = take();
@@ -1164,7 +1170,7 @@ void lanczos_step_lagged(mispec_fac& F, int i, bool last, bool defer)
         fin.alpha_count = (F.A && !F.Chol) ? spmv_num_blocks(F.nloc) : lanczos_epilogue_records(*F.ctx, F.nloc);
         fin.alpha_out = F.alpha_slot();
         {
-            Timed t(F, FAM_VTF);
+            Timed t(F, FAM_VTF, nullptr, false);
             Timed t2(F, FAM_REDUCE);
             reduce_record(F, F.lag_def.nrec, F.lag_def.ncol, F.lag_def.half, fin);
         }
@@ -2699,7 +2705,7 @@ extern "C" int mispec_fac_profile(mispec_fac* fac, int enable)
         fac->ctx->make_current();
         if (!enable && fac->prof)
             drain_profile(*fac);
-        fac->prof = (enable == 2 || enable == 3) ? enable : (enable != 0 ? 1 : 0);
+        fac->prof = (enable >= 2 && enable <= 4) ? enable : (enable != 0 ? 1 : 0);
     });
 }
 

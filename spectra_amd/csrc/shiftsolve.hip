@@ -30,6 +30,7 @@
 #include "dense.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <complex>
 #include <cstdio>
@@ -961,6 +962,23 @@ struct FactorStats
     bool want_cholesky = false;    // also keep the triangular factor of the last level (G G' = M for SparseCholesky)
 };
 
+// option shift=profile=1: the phases of set_shift with their host wall time, on stderr (tools/bench_configs.py c5 reads them)
+struct PhaseTimer
+{
+    const char* what;
+    int64_t n;
+    int b;
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    PhaseTimer(const char* w, int64_t n_, int b_);
+    ~PhaseTimer()
+    {
+        if (on)
+            std::fprintf(stderr, "[mispec set_shift] %-28s N %9lld b %3d  %9.3f ms\n", what, (long long) n, b,
+                         1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
+
 struct mispec::BandLevel
 {
     int64_t N = 0, L = 0, P = 1;
@@ -1075,6 +1093,14 @@ long long shift_option(const char* key, long long dflt)
     return dflt;
 }
 
+}  // namespace
+PhaseTimer::PhaseTimer(const char* w, int64_t n_, int b_) : what(w), n(n_), b(b_), on(shift_option("profile", 0) != 0)
+{
+    if (on)
+        t0 = std::chrono::steady_clock::now();
+}
+namespace {
+
 // whether a level of this shape is factored by k_chunk_factor (MISPEC_SHIFT=factor=host keeps everything on the host)
 bool factored_on_device(int64_t N, int b)
 {
@@ -1128,12 +1154,8 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
     lev.L = L;
     lev.P = P;
     const int64_t mmax = (P == 1) ? N : std::max<int64_t>(L - b, N - (P - 1) * L);  // longest interior
-    double scale = 0.0;
-    for (int64_t i = 0; i < N; i++)
-        scale = std::max(scale, std::fabs(static_cast<const HostBand&>(M).at(i, 0)));
     // pivots at or below tiny * (largest entry of their matrix row) are boosted to that magnitude: see the header comment
     const double tiny = 1.4901161193847656e-08;  // sqrt(eps)
-    (void) scale;
 
     const bool on_device = factored_on_device(N, b);
     MISPEC_REQUIRE(on_device || !M.view, "internal: a band view is only valid for a level factored on the device");
@@ -1153,10 +1175,14 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
     S.b = (P > 1) ? std::min<int64_t>(2 * b - 1, std::max<int64_t>(nsep - 1, 0)) : 0;
     S.a.assign(size_t(std::max<int64_t>(nsep, 1)) * (S.b + 1), 0.0);
 
+    // per-chunk (2b x 2b) contributions M_SI W to the Schur complement, [P][2b][2b] — written by the device kernel or by the host
+    // threads below, assembled afterwards in chunk order (one order of additions whoever produced the blocks)
+    std::vector<double> Cc;
     // ---- the top level of a large matrix is factored on the device (one lane per chunk, k_chunk_factor); the
-    // ---- Schur complement comes back as per-chunk blocks and is assembled here, in the order of the host loop
+    // ---- Schur complement comes back as per-chunk blocks and is assembled below, in the order of the host loop
     if (on_device)
     {
+        PhaseTimer pt("level: device factor", N, b);
         ctx->make_current();
         const int w2 = 2 * b;
         lev.band.alloc(size_t(N) * (b + 1));
@@ -1195,7 +1221,7 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
             hipLaunchKernelGGL((k_chunk_factor<8>), grid, dim3(kChunkThreads), 0, ctx->stream, N, L, cs, tiny, lev.band.p,
                                lev.Lf.p, lev.Dinv.p, lev.W.p, Cdev.p, dstats.p);
         MISPEC_HIP(hipGetLastError());
-        std::vector<double> Cc(Cdev.n);
+        Cc.resize(Cdev.n);
         unsigned long long hstats[3] = {0ull, 0ull, 0ull};
         MISPEC_HIP(hipMemcpyAsync(Cc.data(), Cdev.p, Cc.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         MISPEC_HIP(hipMemcpyAsync(hstats, dstats.p, sizeof(hstats), hipMemcpyDeviceToHost, ctx->stream));
@@ -1207,39 +1233,13 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
             stats.negative += (long long) hstats[2];
             stats.min_pivot_ratio = std::min(stats.min_pivot_ratio, minpiv);
         }
-        for (int64_t p = 0; p < P; p++)
-            for (int side1 = 0; side1 < 2; side1++)
-            {
-                if ((side1 == 0 && p == 0) || (side1 == 1 && p == P - 1))
-                    continue;
-                for (int c1 = 0; c1 < b; c1++)
-                {
-                    const int64_t s1 = (side1 == 0 ? (p - 1) : p) * b + c1;
-                    for (int side2 = 0; side2 < 2; side2++)
-                    {
-                        if ((side2 == 0 && p == 0) || (side2 == 1 && p == P - 1))
-                            continue;
-                        for (int c2 = 0; c2 < b; c2++)
-                        {
-                            const int64_t s2 = (side2 == 0 ? (p - 1) : p) * b + c2;
-                            if (s2 > s1)
-                                continue;  // lower triangle only
-                            const double acc = Cc[(size_t(p) * w2 + size_t(side1 * b + c1)) * w2 + size_t(side2 * b + c2)];
-                            if (acc != 0.0)
-                            {
-                                MISPEC_REQUIRE(s1 - s2 <= S.b, "internal: Schur complement wider than expected");
-                                S.at(s1, int(s1 - s2)) -= acc;
-                            }
-                        }
-                    }
-                }
-            }
     }
 
     if (P == 1)
     {
         // last level: band LU with partial pivoting (this is where an indefinite matrix needs it most: the Schur
         // complement of all separators), explicit inverse applied as a GEMV
+        PhaseTimer pt("last level: inverse + upload", N, b);
         std::vector<double> inv;
         band_lu_inverse(M, inv);
         ctx->make_current();
@@ -1298,8 +1298,21 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
         M.a.shrink_to_fit();
         return;
     }
-    std::vector<double> D, Lc, rhs, sol;
-    for (int64_t p = 0; p < (on_device ? 0 : P); p++)
+    // ---- host path (half-bandwidth 9...64, and every lower level): the chunks are independent — interior LDL', spikes and the
+    // ---- chunk's Schur block only read M and write their own slices of Lf / Dinv / W / Cc — so they are spread over the host's
+    // ---- cores (parallel_ranges, as the ingest is); the pivot statistics are sums and a minimum, the Schur complement is
+    // ---- assembled from the blocks below: the result does not depend on the number of threads.
+    const int w2h = 2 * b;
+    std::unique_ptr<PhaseTimer> pt_host(on_device ? nullptr : new PhaseTimer("level: host factor (threads)", N, b));
+    if (!on_device)
+        Cc.assign(size_t(P) * w2h * w2h, 0.0);
+    const int parts = on_device ? 1 : int(std::min<int64_t>(std::max<int64_t>(1, (N * int64_t(b + 1) * (b + 1)) / 2000000), ingest_threads()));
+    std::vector<FactorStats> part_stats((size_t) parts);
+    const HostBand& Mc = M;
+    parallel_ranges(on_device ? 0 : P, parts, [&](int part, int64_t p_begin, int64_t p_end) {
+    FactorStats& pst = part_stats[size_t(part)];
+    std::vector<double> D, Lc, rhs;
+    for (int64_t p = p_begin; p < p_end; p++)
     {
         const int64_t row0 = p * L;
         const int64_t m = ((p == P - 1) ? N : (row0 + L - b)) - row0;
@@ -1313,28 +1326,28 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
             for (int d = dk - 1; d >= 0; d--)
             {
                 const int64_t j = k - d - 1;
-                double v = M.at(row0 + k, d + 1);
+                double v = Mc.at(row0 + k, d + 1);
                 // subtract sum_{t<j} L(k,t) D_t L(j,t), t within both bands
                 const int64_t tlo = std::max<int64_t>(std::max<int64_t>(k - b, j - b), 0);
                 for (int64_t t = tlo; t < j; t++)
                     v -= Lc[size_t(k) * b + (k - t - 1)] * D[size_t(t)] * Lc[size_t(j) * b + (j - t - 1)];
                 Lc[size_t(k) * b + d] = v / D[size_t(j)];
             }
-            double dv = M.at(row0 + k, 0);
+            double dv = Mc.at(row0 + k, 0);
             for (int d = 0; d < dk; d++)
                 dv -= Lc[size_t(k) * b + d] * Lc[size_t(k) * b + d] * D[size_t(k - d - 1)];
-            double rowmax = std::fabs(M.at(row0 + k, 0));
+            double rowmax = std::fabs(Mc.at(row0 + k, 0));
             for (int d = 0; d < dk; d++)
-                rowmax = std::max(rowmax, std::fabs(M.at(row0 + k, d + 1)));
+                rowmax = std::max(rowmax, std::fabs(Mc.at(row0 + k, d + 1)));
             const double thr = tiny * rowmax + 1e-300;
-            stats.min_pivot_ratio = std::min(stats.min_pivot_ratio, rowmax > 0.0 ? std::fabs(dv) / rowmax : 0.0);
+            pst.min_pivot_ratio = std::min(pst.min_pivot_ratio, rowmax > 0.0 ? std::fabs(dv) / rowmax : 0.0);
             if (!(std::fabs(dv) > thr))
             {
-                stats.boosts++;
+                pst.boosts++;
                 dv = (dv < 0.0) ? -thr : thr;
             }
             if (dv < 0.0)
-                stats.negative++;
+                pst.negative++;
             D[size_t(k)] = dv;
         }
         for (int64_t k = 0; k < m; k++)
@@ -1375,7 +1388,7 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
                 bool any = false;
                 for (int64_t k = (side == 0 ? 0 : std::max<int64_t>(m - b, 0)); k < (side == 0 ? std::min<int64_t>(b, m) : m); k++)
                 {
-                    const double e = M.get(row0 + k, sr);
+                    const double e = Mc.get(row0 + k, sr);
                     rhs[size_t(k)] = e;
                     any = any || (e != 0.0);
                 }
@@ -1408,7 +1421,41 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
                         double acc = 0.0;
                         for (int64_t k = (side1 == 0 ? 0 : std::max<int64_t>(m - b, 0)); k < (side1 == 0 ? std::min<int64_t>(b, m) : m);
                              k++)
-                            acc += M.get(row0 + k, sr1) * sp[size_t(k)];
+                            acc += Mc.get(row0 + k, sr1) * sp[size_t(k)];
+                        Cc[(size_t(p) * w2h + size_t(side1 * b + c1)) * w2h + size_t(side2 * b + c2)] = acc;
+                    }
+                }
+            }
+        }
+    }
+    });
+    pt_host.reset();
+    for (const FactorStats& pst : part_stats)
+    {
+        stats.boosts += pst.boosts;
+        stats.negative += pst.negative;
+        stats.min_pivot_ratio = std::min(stats.min_pivot_ratio, pst.min_pivot_ratio);
+    }
+    // ---- Schur complement of the separators: S -= (block of chunk p), chunk by chunk, entry by entry in this fixed order
+    if (P > 1)
+    for (int64_t p = 0; p < P; p++)
+        for (int side1 = 0; side1 < 2; side1++)
+        {
+            if ((side1 == 0 && p == 0) || (side1 == 1 && p == P - 1))
+                continue;
+            for (int c1 = 0; c1 < b; c1++)
+            {
+                const int64_t s1 = (side1 == 0 ? (p - 1) : p) * b + c1;
+                for (int side2 = 0; side2 < 2; side2++)
+                {
+                    if ((side2 == 0 && p == 0) || (side2 == 1 && p == P - 1))
+                        continue;
+                    for (int c2 = 0; c2 < b; c2++)
+                    {
+                        const int64_t s2 = (side2 == 0 ? (p - 1) : p) * b + c2;
+                        if (s2 > s1)
+                            continue;  // lower triangle only
+                        const double acc = Cc[(size_t(p) * w2h + size_t(side1 * b + c1)) * w2h + size_t(side2 * b + c2)];
                         if (acc != 0.0)
                         {
                             MISPEC_REQUIRE(s1 - s2 <= S.b, "internal: Schur complement wider than expected");
@@ -1418,7 +1465,6 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
                 }
             }
         }
-    }
     if (P > 1)
     {
         // + M_SS itself (entries inside one separator; different separators are more than b rows apart)
@@ -1451,9 +1497,12 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
         lev.g.alloc(size_t(nsep));
         lev.xs.alloc(size_t(nsep));
     }
-    if (P > 1 && !stats.want_cholesky && wants_block_inverse(P, mmax, b))
-        build_block_inverses(*ctx, lev, mmax);
-    MISPEC_HIP(hipStreamSynchronize(ctx->stream));
+    {
+        PhaseTimer pt("level: uploads + block inverses", N, b);
+        if (P > 1 && !stats.want_cholesky && wants_block_inverse(P, mmax, b))
+            build_block_inverses(*ctx, lev, mmax);
+        MISPEC_HIP(hipStreamSynchronize(ctx->stream));
+    }
     M.a.clear();
     M.a.shrink_to_fit();
     if (P > 1)
@@ -2272,8 +2321,14 @@ extern "C" int mispec_symshift_set_shift(mispec_symshift* S, double sigma)
                     S->top = std::make_unique<BandLevel>();
                     FactorStats fs;
                     fs.want_cholesky = S->want_cholesky;
-                    factor_level(S->ctx, Mt, *S->top, fs);
-                    calibrate_refinement(*S, fs);
+                    {
+                        PhaseTimer pt("factor_level (all levels)", n, int(Mt.b));
+                        factor_level(S->ctx, Mt, *S->top, fs);
+                    }
+                    {
+                        PhaseTimer pt("calibrate_refinement", n, int(S->band_b));
+                        calibrate_refinement(*S, fs);
+                    }
                     S->negative_pivots = fs.negative;
                     S->cholesky_ready = S->want_cholesky && fs.negative == 0 && fs.boosts == 0;
                     g_chunk_bias = 0;

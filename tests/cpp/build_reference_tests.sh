@@ -23,7 +23,7 @@ FLAGS="-std=c++11 -O1 -w -I$ROOT/tests/cpp/eigen_lite -I$ROOT/include -I$REF/tes
 # TEMPLATE_TEST_CASEs over float and double (their Random / isApprox / sparse expressions are the stand-in's).
 SHIM_PROGRAMS=" Givens QR Eigen Arnoldi SparseSymMatProd SparseGenMatProd DenseSymMatProd DenseGenMatProd "
 SHIM_FLAGS="-std=c++17 -O2 -w -I$ROOT/oracle/eigen_shim -I$ROOT/include -I$REF/test"
-LINK="-L$ROOT/spectra_amd -lmispec -Wl,-rpath,\$ORIGIN/../../../spectra_amd"
+LINK="-L$ROOT/spectra_amd -lmispec_extras -lmispec -Wl,-rpath,\$ORIGIN/../../../spectra_amd"
 # Schur, Orthogonalization, Givens, QR and Eigen test host-side classes only and run without a GPU
 LIST="${*:-SymEigs SymEigsShift GenEigs GenEigsRealShift GenEigsComplexShift SymGEigsCholesky SymGEigsRegInv SVD DavidsonSymEigs Example1 Example2 Example3 Example4 Schur Orthogonalization Givens QR Eigen Arnoldi SparseSymMatProd SparseGenMatProd DenseSymMatProd DenseGenMatProd}"
 # Catch2's main(): compiled once
@@ -36,7 +36,7 @@ for name in $LIST; do
     F="$FLAGS"
     STANDIN="$ROOT/tests/cpp/eigen_lite"
     case "$SHIM_PROGRAMS" in *" $name "*) F="$SHIM_FLAGS"; STANDIN="$ROOT/oracle/eigen_shim" ;; esac
-    if [ -f "$OUT/$name.bin" ] && [ -z "$(find "$ROOT/include" "$STANDIN" "$REF/test/$name.cpp" "$ROOT/spectra_amd/libmispec.so" -newer "$OUT/$name.bin" -print -quit)" ]; then
+    if [ -f "$OUT/$name.bin" ] && [ -z "$(find "$ROOT/include" "$STANDIN" "$REF/test/$name.cpp" "$ROOT/spectra_amd/libmispec.so" "$ROOT/spectra_amd/libmispec_extras.so" -newer "$OUT/$name.bin" -print -quit)" ]; then
         echo "up to date $name.bin"
         continue
     fi

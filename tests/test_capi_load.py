@@ -26,8 +26,18 @@ def test_library_exports_every_declared_symbol():
     lib = sa.lib()
     names = header_symbols()
     assert len(names) >= 60
+    # two libraries (round 6): the Davidson solver and the complex factorisation live in libmispec_extras.so, built on
+    # libmispec.so; the hot-path library must not export them, the extras library must export nothing else
+    core_lib = C.CDLL(_capi.LIB_PATH)
+    extras_lib = C.CDLL(_capi.EXTRAS_LIB_PATH)
     for nm in names:
-        assert hasattr(lib, nm), f"{nm} declared in include/mispec.h / mispec_extras.h but not exported by libmispec.so"
+        assert hasattr(lib, nm), f"{nm} declared in include/mispec.h / mispec_extras.h but not exported"
+        in_extras = nm.startswith(_capi.EXTRAS_PREFIXES)
+        assert hasattr(extras_lib if in_extras else core_lib, nm), nm
+        if in_extras:
+            with pytest.raises(AttributeError):
+                getattr(core_lib, nm)
+    assert sum(nm.startswith(_capi.EXTRAS_PREFIXES) for nm in names) >= 28
     assert names == set(_capi.SIGNATURES), names ^ set(_capi.SIGNATURES)
     assert b"gfx950" in lib.mispec_version()
     # the thin shim of the hot path knows nothing of the components outside it

@@ -175,6 +175,8 @@ def test_fused_restart_equals_the_two_pass_sequence(ctx, n, m, k):
     # mispec_fac_restart_sym).  Against the same steps with that correction applied at once and the plain restart
     # ("onesweep-eager"): same H, same basis, same residual up to the order of the sums.  (1000, 64, 30) has a device run that
     # stops in mid-sweep: the records the host continues from must survive the launches queued behind the stop.
+    if os.environ.get("MISPEC_SMALL") == "device":
+        pytest.skip("small=device finishes every sweep eagerly (no fused restart to compare)")
     if n == 1000:
         A, S = sparse_fixture(n, 0.01)
         op = sa.SparseSymMatProd(A, ctx=ctx)

@@ -3,7 +3,10 @@
   C5  SymEigsShiftSolver on a 2M x 2M banded (half-bandwidth 3) definite matrix, sigma = 0, k = 6, ncv = 20
 Prints one JSON object per configuration (eigenpairs/s, per-kernel times, residuals).
 
-    python tools/bench_configs.py [c4] [c5] [g1] [d1]
+    python tools/bench_configs.py [c4] [c5] [g1] [d1] [w5]
+
+  W5  the shift solve on a WIDE band (n = 10^6, half-bandwidth 32, definite): set_shift time (levels factored by the host's
+      cores, chunks in parallel) and the solve — the timing asserts of VERDICT r05 item 4 (set_shift <= 0.5 s)
 
   G1  SymGEigsSolver (regular-inverse mode) on a 2M x 2M pencil: A the M-band pattern, B a tridiagonal mass matrix;
       k = 6, ncv = 20 — not a BASELINE.json config, recorded as the measurement of SURVEY.md 8f row 4
@@ -81,6 +84,39 @@ if "c5" in which:
                       "num_iterations": s.num_iterations(), "max_residual": float(res.max()),
                       "ingest_seconds": t_ingest, "set_shift_seconds": t_factor, "set_shift_seconds_warm": t_factor2, "solve_ms": p["ms_spmv"] / p["n_spmv"],
                       "kernels_ms": {k[3:]: round(v, 2) for k, v in p.items() if k.startswith("ms_")}}))
+
+if "w5" in which:
+    n, b = int(os.environ.get("W5_N", 1_000_000)), int(os.environ.get("W5_B", 32))
+    rng = np.random.default_rng(6)
+    diags = [rng.uniform(-0.5, 0.5, n - d) for d in range(1, b + 1)]
+    A = sp.diags([rng.uniform(-0.5, 0.5, n) + 0.6 * b + 0.5] + diags + diags, [0] + list(range(1, b + 1)) + [-d for d in range(1, b + 1)],
+                 format="csc")
+    op = sa.SparseSymShiftSolve(sp.tril(A).tocsc(), ctx=ctx)
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        op.set_shift(0.1)
+        times.append(time.perf_counter() - t0)
+    f = rng.standard_normal(n)
+    x = op.perform_op(f)
+    r = (A @ x - 0.1 * x) - f
+    import torch
+
+    xd = torch.from_numpy(f).cuda()
+    yd = torch.empty_like(xd)
+    for _ in range(3):
+        op.solve_device(xd.data_ptr(), yd.data_ptr())
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        op.solve_device(xd.data_ptr(), yd.data_ptr())
+    ctx.sync()
+    solve_ms = 1e3 * (time.perf_counter() - t0) / 20
+    out = {"config": f"W5 SparseSymShiftSolve n={n}, half-bandwidth {b}, sigma=0.1", "set_shift_seconds": times,
+           "relative_residual": float(np.linalg.norm(r) / np.linalg.norm(f)), "solve_ms": solve_ms,
+           "solve_bytes_one_touch": (4 * b + 3) * 8.0 * n, "host_threads": os.cpu_count()}
+    out["set_shift_within_half_a_second"] = bool(min(times) <= 0.5)
+    print(json.dumps(out))
 
 if "g1" in which:
     import oracle as O  # only the matrix generator (test infrastructure) is used here, nothing is timed through it
