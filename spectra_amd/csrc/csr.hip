@@ -1,4 +1,4 @@
-// CSR ingest, synthetic matrix generation and the fp64 CSR SpMV kernel for gfx950.
+// CSR ingest, synthetic matrix generation, the format dispatch and the fp64 CSR-stream SpMV kernel for gfx950.
 //
 // SpMV design ("CSR-stream", row-block per workgroup, LDS partial products):
 //   * a workgroup of 256 threads owns 256 consecutive rows, i.e. ONE contiguous run of
@@ -19,6 +19,8 @@
 //     The row of an entry is found through a byte table that the row-owning threads write into LDS
 //     while the streaming loads are in flight (it aliases the product buffer, which is not live yet);
 //     products and summation order are unchanged, so the result is bit-identical to the plain kernel.
+//   (the two variants below live in files of their own since round 6: csr_dia.hip and csr_win.hip; launch_spmv_raw here picks the
+//   format and hands an SpmvLaunch to launch_spmv_dia / launch_spmv_csr_win; shared device helpers: csr_kernels.hpp)
 //   * diagonal variant (k_spmv_dia): when the dictionary has at most 32 diagonals and they are at least 3/4 full,
 //     the values are also kept diagonal-major (dia[k][row], zero where the matrix has no entry) and
 //     y[r] = sum_k dia[k][r] * x[r + off_k] in ascending offset order — no index, no gather, no LDS, every load
@@ -31,8 +33,7 @@
 //     two rows per thread with 16-byte loads of the values.
 // Bound: HBM.  Algorithmic bytes per launch: 12*nnz + 4*(rows+1) + 8*cols + 8*rows (CSR with int32
 // indices); the offset-coded variant's compulsory traffic is 9*nnz + ... .
-#include "csr.hpp"
-#include "krylov.hpp"
+#include "csr_kernels.hpp"
 #include "reorder.hpp"
 
 #include <hip/hip_ext.h>
@@ -48,43 +49,6 @@
 using namespace mispec;
 
 namespace {
-
-typedef double v2d __attribute__((ext_vector_type(2)));
-typedef int v4i __attribute__((ext_vector_type(4)));
-
-// THREADS * 4 entries * 4 load steps = 16 * THREADS >= cap + 3 (k_spmv_csr_stream's ITERS = 4)
-// products per LDS chunk for a THREADS-row workgroup: 256 -> (4080+4)*8 B + 32 B <= 32 KiB -> 5 workgroups / CU
-constexpr int chunk_cap(int threads) { return threads * 16 - 16; }
-// offset-coded variant: 1 KiB of the 32 KiB goes to the dictionary -> (3952+4)*8 + 1024 + 32 B, still 5 workgroups / CU
-constexpr int chunk_cap_codes(int threads) { return threads * 16 - 144; }
-constexpr int kMaxDict = 256;
-
-struct SpmvCodes
-{
-    const uint8_t* codes;
-    const int32_t* dict;
-    int ndict;
-    int col_max;       // n_cols - 1
-    int64_t row_begin; // global index of local row 0
-};
-
-__device__ __forceinline__ double wave_reduce_sum(double v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-        v += __shfl_down(v, off, 64);
-    return v;
-}
-
-// Deterministic 256-thread sum; every thread returns the total.
-__device__ __forceinline__ double block_reduce_sum(double v, double* red)
-{
-    v = wave_reduce_sum(v);
-    if ((threadIdx.x & 63) == 0)
-        red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
-}
 
 // ITERS: 16-byte load groups per thread and chunk (4: chunks of ~4080 entries, 32 KiB of LDS, 5 workgroups per CU; 2: chunks of
 // ~2032 entries, 16 KiB, 8 workgroups per CU — for matrices with few entries per row, whose 256-row blocks would leave half of
@@ -277,983 +241,6 @@ __global__ __launch_bounds__(kThreads) void k_spmv_csr_stream(const int32_t* __r
         y[row0 + tid] = acc;
 }
 
-// ---- int32 CSR with the x entries of a row-block staged through LDS windows ------------------------------------------
-// k_spmv_csr_stream issues one 8-byte gather per stored entry AFTER its column index has arrived: a third dependent round trip
-// per block (row pointers -> val / col_ind -> x), every gather a separate request to the vector L1.  For matrices whose
-// columns are local — banded matrices, stencils, meshes after a bandwidth-reducing ordering, with or without a fixed offset
-// structure — the columns a 256-row block references fall into a few contiguous ranges of x.  Those ranges are found ONCE at
-// ingest (k_build_windows: at most kWinMax windows per block, 128-byte aligned, a 32-int record per block), and the kernel
-//   * loads the windows with coalesced 16-byte loads, TOGETHER with the val / col_ind stream and the epilogue's operands
-//     (one round trip after the row pointers),
-//   * turns every column index into an LDS slot with a chain of compares against the window starts (block-uniform, SGPRs),
-//   * reads x from LDS; entries outside every window ("far" entries of a block, flagged in its record) keep the global gather.
-// The matrix arrays are the plain int32 CSR (12 bytes per entry, SURVEY.md §8d's bytes); products and the summation order are
-// those of k_spmv_csr_stream, so the result is bit-identical to it and to the CPU row-dot.
-constexpr int kWinMax = 8;            // windows per 256-row block
-constexpr int kWinRec = 32;           // int32 per block: [0] nw | far << 8, [1] total doubles, [2] covered entries, [4..] start, [12..] adj, [20..] end
-constexpr int kWinPad = 0x3fffffff;   // start of an unused window (no column reaches it)
-constexpr int kWinCapMax = 6144;      // doubles of LDS a block's windows may take (48 KiB); the launch reserves the matrix's maximum
-constexpr int kWinLines = int((2 * kFarWindow + 512) / 16);  // 128-byte lines of x a block's bitmap covers (row0 - 131072 ... row0 + 256 + 131072)
-constexpr int kWinWords = (kWinLines + 31) / 32;
-constexpr int kWinRuns = 256;          // raw runs of touched lines a block may have before neighbours further apart are joined
-
-// ---- the window selection of one 256-row block: plain sequential code shared by the device builder (one thread of the block)
-// and the host hook mispec_csr_windows_host, so that the CPU tests exercise the code the device runs -----------------------------
-__host__ __device__ inline int64_t win_origin(int64_t row_begin, int64_t row0)
-{
-    const int64_t o = row_begin + row0 - kFarWindow;
-    return (o > 0 ? o : 0) & ~int64_t(15);
-}
-__host__ __device__ inline int win_ctz(uint32_t w)
-{
-    int n = 0;
-    while (!(w & 1u))
-    {
-        w >>= 1;
-        n++;
-    }
-    return n;
-}
-// Runs of touched 128-byte lines of the bitmap; neighbours closer than `gap` lines are one run (the lines in between are loaded
-// too).  The gap grows until the runs fit the table.  Returns the number of runs (0: they do not fit at any gap).
-__host__ __device__ inline int win_find_runs(const uint32_t* bits, int* rs, int* re)
-{
-    int n = 0;
-    bool fits = false;
-    for (int gap = 2; gap <= 2048 && !fits; gap *= 4)
-    {
-        n = 0;
-        fits = true;
-        int cs = -1, ce = -1;
-        for (int w = 0; w < kWinWords && fits; w++)
-        {
-            uint32_t word = bits[w];
-            while (word)
-            {
-                const int line = w * 32 + win_ctz(word);
-                word &= word - 1;
-                if (cs < 0)
-                {
-                    cs = line;
-                    ce = line + 1;
-                }
-                else if (line - ce <= gap)
-                    ce = line + 1;
-                else
-                {
-                    if (n == kWinRuns)
-                    {
-                        fits = false;
-                        break;
-                    }
-                    rs[n] = cs;
-                    re[n] = ce;
-                    n++;
-                    cs = line;
-                    ce = line + 1;
-                }
-            }
-        }
-        if (fits && cs >= 0)
-        {
-            if (n == kWinRuns)
-                fits = false;
-            else
-            {
-                rs[n] = cs;
-                re[n] = ce;
-                n++;
-            }
-        }
-    }
-    return fits ? n : 0;
-}
-// index of the run that holds `line` (the last run with rs <= line)
-__host__ __device__ inline int win_run_of(const int* rs, int nruns, int line)
-{
-    int lo = 0, hi = nruns - 1;
-    while (lo < hi)
-    {
-        const int mid = (lo + hi + 1) >> 1;
-        if (rs[mid] <= line)
-            lo = mid;
-        else
-            hi = mid - 1;
-    }
-    return lo;
-}
-// From the runs and their entry counts to the block's record: thin runs are left to the gather, the closest runs are merged or the
-// lightest dropped until at most kWinMax windows within `cap_doubles` of LDS remain.  entries: stored entries of the block; far:
-// entries outside the bitmap's range.
-__host__ __device__ inline void win_select(int nruns, int* rs, int* re, int* cnt, int64_t origin, int64_t n_cols, int cap_doubles, int entries,
-                                           int far, int32_t* rec)
-{
-    int n = nruns;
-    int dropped = 0;  // entries of runs that are not kept: gathered one by one like the far ones
-    const auto remove = [&](int i) {
-        for (int k = i; k + 1 < n; k++)
-        {
-            rs[k] = rs[k + 1];
-            re[k] = re[k + 1];
-            cnt[k] = cnt[k + 1];
-        }
-        n--;
-    };
-    // a window pays for itself when its entries outnumber its lines (a gather moves a 64-byte sector per entry): runs thinner than
-    // one entry per two lines are dropped, thin AND short ones too
-    for (int i = 0; i < n;)
-        if (2 * cnt[i] < re[i] - rs[i] || cnt[i] < 8)
-        {
-            dropped += cnt[i];
-            remove(i);
-        }
-        else
-            i++;
-    const int64_t col_end = (n_cols + 1) & ~int64_t(1);  // windows hold pairs of doubles
-    const auto length = [&](int i) {
-        const int64_t e = origin + int64_t(re[i]) * 16;
-        return int((e < col_end ? e : col_end) - (origin + int64_t(rs[i]) * 16));
-    };
-    int total = 0;
-    for (int i = 0; i < n; i++)
-        total += length(i);
-    // down to kWinMax windows: merge the closest pair when the lines that adds (128 bytes each) cost less than gathering the
-    // lightest run's entries (a 64-byte sector each) and the LDS budget allows it, else drop the lightest run
-    while (n > kWinMax)
-    {
-        int best = 0, bestgap = 0x7fffffff, light = 0;
-        for (int i = 0; i < n; i++)
-        {
-            if (i + 1 < n && rs[i + 1] - re[i] < bestgap)
-            {
-                bestgap = rs[i + 1] - re[i];
-                best = i;
-            }
-            if (cnt[i] < cnt[light])
-                light = i;
-        }
-        if (2 * bestgap <= cnt[light] && total + 16 * bestgap <= cap_doubles)
-        {
-            total += 16 * bestgap;
-            re[best] = re[best + 1];
-            cnt[best] += cnt[best + 1];
-            remove(best + 1);
-        }
-        else
-        {
-            total -= length(light);
-            dropped += cnt[light];
-            remove(light);
-        }
-    }
-    total = 0;
-    for (int i = 0; i < n; i++)
-        total += length(i);
-    while (n > 0 && total > cap_doubles)  // over the LDS budget: the window with the fewest entries per line goes
-    {
-        int worst = 0;
-        for (int i = 1; i < n; i++)
-            if (int64_t(cnt[i]) * (re[worst] - rs[worst]) < int64_t(cnt[worst]) * (re[i] - rs[i]))
-                worst = i;
-        total -= length(worst);
-        dropped += cnt[worst];
-        remove(worst);
-    }
-    const int outside = far + dropped + (nruns == 0 ? entries - far : 0);
-    rec[0] = n | ((outside || n == 0 ? 1 : 0) << 8);
-    rec[1] = total;
-    rec[2] = entries - outside;
-    rec[3] = 0;
-    for (int i = 28; i < kWinRec; i++)
-        rec[i] = 0;
-    int base = 0;
-    for (int i = 0; i < kWinMax; i++)
-    {
-        if (i < n)
-        {
-            const int64_t start = origin + int64_t(rs[i]) * 16;
-            const int64_t e = origin + int64_t(re[i]) * 16;
-            const int64_t end = e < col_end ? e : col_end;
-            rec[4 + i] = int32_t(start);
-            rec[4 + kWinMax + i] = int32_t(int64_t(base) - start);
-            rec[4 + 2 * kWinMax + i] = int32_t(end);
-            base += int(end - start);
-        }
-        else
-        {
-            rec[4 + i] = kWinPad;
-            rec[4 + kWinMax + i] = 0;
-            rec[4 + 2 * kWinMax + i] = kWinPad;
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void k_build_windows(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind, int64_t nrows,
-                                                       int64_t row_begin, int64_t n_cols, int cap_doubles, int32_t* __restrict__ wtab)
-{
-    __shared__ uint32_t bits[kWinWords];
-    __shared__ int s_far, s_n;
-    __shared__ int rs[kWinRuns], re[kWinRuns], cnt[kWinRuns];
-    const int lb = int(blockIdx.x), tid = int(threadIdx.x);
-    const int64_t row0 = int64_t(lb) * 256;
-    const int nr = int(min(int64_t(256), nrows - row0));
-    const int bs = rowptr[row0], be = rowptr[row0 + nr];
-    const int64_t origin = win_origin(row_begin, row0);
-    for (int w = tid; w < kWinWords; w += 256)
-        bits[w] = 0u;
-    if (tid < kWinRuns)
-        cnt[tid] = 0;
-    if (tid == 0)
-        s_far = 0;
-    __syncthreads();
-    int far = 0;
-    for (int p = bs + tid; p < be; p += 256)
-    {
-        const int64_t rel = int64_t(colind[p]) - origin;
-        if (rel < 0 || rel >= int64_t(kWinLines) * 16)
-            far++;
-        else
-            atomicOr(&bits[rel >> 9], 1u << ((rel >> 4) & 31));
-    }
-    if (far)
-        atomicAdd(&s_far, far);
-    __syncthreads();
-    if (tid == 0)
-        s_n = win_find_runs(bits, rs, re);
-    __syncthreads();
-    const int nruns = s_n;  // entries per run
-    if (nruns > 0)
-        for (int p = bs + tid; p < be; p += 256)
-        {
-            const int64_t rel = int64_t(colind[p]) - origin;
-            if (rel < 0 || rel >= int64_t(kWinLines) * 16)
-                continue;
-            atomicAdd(&cnt[win_run_of(rs, nruns, int(rel >> 4))], 1);
-        }
-    __syncthreads();
-    if (tid == 0)
-        win_select(nruns, rs, re, cnt, origin, n_cols, cap_doubles, be - bs, s_far, wtab + size_t(lb) * kWinRec);
-}
-
-// The same table from HOST arrays, one block after the other (mispec_csr_windows_host: the CPU tests run the selection code the
-// device runs, and the GPU tests require the device's table to equal this one).
-void build_windows_host(int64_t nrows, int64_t n_cols, int64_t row_begin, const int32_t* rowptr, const int32_t* colind, int32_t* wtab)
-{
-    const int64_t nblocks = (nrows + 255) / 256;
-    std::vector<uint32_t> bits(static_cast<size_t>(kWinWords));
-    std::vector<int> rs(static_cast<size_t>(kWinRuns)), re(static_cast<size_t>(kWinRuns)), cnt(static_cast<size_t>(kWinRuns));
-    for (int64_t lb = 0; lb < nblocks; lb++)
-    {
-        const int64_t row0 = lb * 256;
-        const int64_t r1 = std::min<int64_t>(nrows, row0 + 256);
-        const int bs = rowptr[row0], be = rowptr[r1];
-        const int64_t origin = win_origin(row_begin, row0);
-        std::fill(bits.begin(), bits.end(), 0u);
-        std::fill(cnt.begin(), cnt.end(), 0);
-        int far = 0;
-        for (int p = bs; p < be; p++)
-        {
-            const int64_t rel = int64_t(colind[p]) - origin;
-            if (rel < 0 || rel >= int64_t(kWinLines) * 16)
-                far++;
-            else
-                bits[size_t(rel >> 9)] |= 1u << ((rel >> 4) & 31);
-        }
-        const int nruns = win_find_runs(bits.data(), rs.data(), re.data());
-        if (nruns > 0)
-            for (int p = bs; p < be; p++)
-            {
-                const int64_t rel = int64_t(colind[p]) - origin;
-                if (rel < 0 || rel >= int64_t(kWinLines) * 16)
-                    continue;
-                cnt[size_t(win_run_of(rs.data(), nruns, int(rel >> 4)))]++;
-            }
-        win_select(nruns, rs.data(), re.data(), cnt.data(), origin, n_cols, kWinCapMax, be - bs, far, wtab + size_t(lb) * kWinRec);
-    }
-}
-
-// XI: 16-byte window loads per thread (windows of at most 512 * XI doubles); PF: the next chunk's val / col_ind loads are
-// issued before the current chunk's products (two chunks of registers).
-template <bool EPI, int ITERS, int XI, bool PF, bool NT = false>
-__global__ __launch_bounds__(256) void k_spmv_csr_win(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
-                                                      const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y,
-                                                      int64_t nrows, int nblocks, SpmvEpilogue epi, const int32_t* __restrict__ wtab,
-                                                      int col_max)
-{
-    constexpr int kThreads = 256;
-    constexpr int kCap = chunk_cap(kThreads) - (4 - ITERS) * kThreads * 4;
-    extern __shared__ __attribute__((aligned(16))) double smem_win[];
-    double* const prod = smem_win;             // kCap + 4 products
-    double* const xs = smem_win + kCap + 4;    // the block's windows of x
-    __shared__ double red[4];
-
-    const int per = (nblocks + 7) >> 3;
-    const int lmap = (int(blockIdx.x) & 7) * per + (int(blockIdx.x) >> 3);
-    if (lmap >= nblocks)
-        return;
-    const int lb = epi.first_block + lmap;
-    if (EPI && epi.status && *epi.status != 0)
-        return;
-
-    const int tid = threadIdx.x;
-    const int64_t row0 = int64_t(lb) * kThreads;
-    const int nr = int(min(int64_t(kThreads), nrows - row0));
-    const int32_t* __restrict__ rec = wtab + size_t(lb) * kWinRec;
-    const bool far = (rec[0] >> 8) != 0;
-    const int total = rec[1];
-    int st[kWinMax], ad[kWinMax], en[kWinMax];
-#pragma unroll
-    for (int w = 0; w < kWinMax; w++)
-    {
-        st[w] = rec[4 + w];
-        ad[w] = rec[4 + kWinMax + w];
-        en[w] = rec[4 + 2 * kWinMax + w];
-    }
-    const int bs = rowptr[row0];
-    const int be = rowptr[row0 + nr];
-    int rs = 0, re = 0;
-    if (tid < nr)
-    {
-        rs = rowptr[row0 + tid];
-        re = rowptr[row0 + tid + 1];
-    }
-    // the epilogue's operands travel with the matrix stream (as in k_spmv_dia_win)
-    double vprev_early = 0.0, vrow_early = 0.0, hprev_early = 0.0;
-    const bool early = EPI && tid < nr;
-    if (early)
-    {
-        if (epi.v_prev)
-        {
-            vprev_early = epi.v_prev[row0 + tid];
-            hprev_early = epi.h_prev_dev ? *epi.h_prev_dev : epi.h_prev;
-        }
-        vrow_early = epi.v_rows[row0 + tid];
-    }
-
-    struct Chunk
-    {
-        double2 va[ITERS][2];
-        int4 ci[ITERS];
-    };
-    const auto load_chunk = [&](Chunk& C, int cs) {
-        const int a0 = cs & ~3;
-        const int ce = min(be, a0 + kCap);
-        const int last = (ce - 1) & ~3;
-#pragma unroll
-        for (int it = 0; it < ITERS; it++)
-        {
-            const int base = min(a0 + tid * 4 + it * (kThreads * 4), last);
-            if (NT)  // the matrix stream is read once: keep it from evicting the x windows the XCD's blocks share in L2
-            {
-                const v2d a01 = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(val + base));
-                const v2d a23 = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(val + base + 2));
-                const v4i c4 = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(colind + base));
-                C.va[it][0] = make_double2(a01.x, a01.y);
-                C.va[it][1] = make_double2(a23.x, a23.y);
-                C.ci[it] = make_int4(c4.x, c4.y, c4.z, c4.w);
-            }
-            else
-            {
-                C.va[it][0] = *reinterpret_cast<const double2*>(val + base);
-                C.va[it][1] = *reinterpret_cast<const double2*>(val + base + 2);
-                C.ci[it] = *reinterpret_cast<const int4*>(colind + base);
-            }
-        }
-    };
-    Chunk cur, nxt;
-    if (bs < be)
-        load_chunk(cur, bs);
-
-    // windows of x -> LDS: position p of the concatenated windows is column p - adj of its window
-    {
-        double2 xv[XI];
-#pragma unroll
-        for (int k = 0; k < XI; k++)
-        {
-            const int p = 2 * (tid + k * kThreads);
-            xv[k] = make_double2(0.0, 0.0);
-            if (p < total)
-            {
-                int a = ad[0];
-#pragma unroll
-                for (int w = 1; w < kWinMax; w++)
-                    a = p >= st[w] + ad[w] ? ad[w] : a;
-                const int c = p - a;
-                if (c + 1 <= col_max)
-                    xv[k] = *reinterpret_cast<const double2*>(x + c);
-                else
-                    xv[k].x = x[min(c, col_max)];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < XI; k++)
-        {
-            const int p = 2 * (tid + k * kThreads);
-            if (p < total)
-                *reinterpret_cast<double2*>(&xs[p]) = xv[k];
-        }
-    }
-    __syncthreads();
-
-    const unsigned slot_max = unsigned(max(total, 1) - 1);
-    double acc = 0.0;
-    for (int cs = bs; cs < be;)
-    {
-        const int a0 = cs & ~3;
-        const int ce = min(be, a0 + kCap);
-        if (PF && ce < be)
-            load_chunk(nxt, ce);
-        // x of every entry: LDS slot through the window chain; far entries from global memory
-        double xg[ITERS][4];
-        if (!far)
-        {
-#pragma unroll
-            for (int it = 0; it < ITERS; it++)
-            {
-                const int c4[4] = {cur.ci[it].x, cur.ci[it].y, cur.ci[it].z, cur.ci[it].w};
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                {
-                    int a = ad[0];
-#pragma unroll
-                    for (int w = 1; w < kWinMax; w++)
-                        a = c4[j] >= st[w] ? ad[w] : a;
-                    // entries of the alignment lead-in / the padding belong to other blocks: clamp, their products are never summed
-                    xg[it][j] = xs[min(unsigned(c4[j] + a), slot_max)];
-                }
-            }
-        }
-        else
-        {
-#pragma unroll
-            for (int it = 0; it < ITERS; it++)
-            {
-                const int c4[4] = {cur.ci[it].x, cur.ci[it].y, cur.ci[it].z, cur.ci[it].w};
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                {
-                    int a = ad[0], e = en[0];
-#pragma unroll
-                    for (int w = 1; w < kWinMax; w++)
-                    {
-                        const bool ge = c4[j] >= st[w];
-                        a = ge ? ad[w] : a;
-                        e = ge ? en[w] : e;
-                    }
-                    if (c4[j] >= st[0] && c4[j] < e)
-                        xg[it][j] = xs[c4[j] + a];
-                    else
-                        xg[it][j] = x[c4[j]];
-                }
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < ITERS; it++)
-        {
-            const int base = a0 + tid * 4 + it * (kThreads * 4);
-            if (base < ce)
-            {
-                double2 p0, p1;
-                p0.x = cur.va[it][0].x * xg[it][0];
-                p0.y = cur.va[it][0].y * xg[it][1];
-                p1.x = cur.va[it][1].x * xg[it][2];
-                p1.y = cur.va[it][1].y * xg[it][3];
-                *reinterpret_cast<double2*>(&prod[base - a0]) = p0;
-                *reinterpret_cast<double2*>(&prod[base - a0 + 2]) = p1;
-            }
-        }
-        __syncthreads();
-        const int lo = max(rs, cs), hi = min(re, ce);
-        {
-            int k = lo;
-            for (; k + 4 <= hi; k += 4)
-            {
-                const double p0 = prod[k - a0], p1 = prod[k - a0 + 1], p2 = prod[k - a0 + 2], p3 = prod[k - a0 + 3];
-                acc += p0;
-                acc += p1;
-                acc += p2;
-                acc += p3;
-            }
-            for (; k < hi; k++)
-                acc += prod[k - a0];
-        }
-        cs = ce;
-        if (cs < be)
-        {
-            __syncthreads();
-            if (PF)
-                cur = nxt;
-            else
-                load_chunk(cur, cs);
-        }
-    }
-
-    if (EPI)
-    {
-        double contrib = 0.0;
-        if (tid < nr)
-        {
-            const int64_t row = row0 + tid;
-            double yv = acc;
-            if (epi.v_prev)
-                yv -= hprev_early * vprev_early;  // Lanczos.h:139
-            y[row] = yv;
-            contrib = vrow_early * yv;  // Lanczos.h:142 partial <v, w>
-        }
-        const double total_c = block_reduce_sum(contrib, red);
-        if (tid == 0)
-            epi.partials[lb] = total_c;
-    }
-    else if (tid < nr)
-        y[row0 + tid] = acc;
-}
-
-// ---- diagonal storage -----------------------------------------------------------------------------------------------
-constexpr int kMaxDia = 32;      // diagonals of the diagonal format
-constexpr int kDiaGroup = 8;     // loads issued together per thread: 8 values + 8 x entries
-
-// One thread per row: scatter the row's values into the diagonal-major array.  `pos_of_code` maps a dictionary code to the
-// rank of its offset.  Within a row the ranks must increase strictly (columns sorted, no duplicates), else the diagonal
-// sum would not be the CSR row sum bit for bit: such matrices raise *bad and keep the CSR kernels.
-__global__ __launch_bounds__(256) void k_build_dia(const int32_t* __restrict__ rowptr, const uint8_t* __restrict__ codes,
-                                                   const double* __restrict__ val, const int32_t* __restrict__ pos_of_code,
-                                                   int64_t nloc, int64_t ld, double* __restrict__ dia, int* __restrict__ bad, int nd_blocked)
-{
-    const int64_t r = int64_t(blockIdx.x) * 256 + threadIdx.x;
-    if (r >= nloc)
-        return;
-    int last = -1;
-    for (int p = rowptr[r]; p < rowptr[r + 1]; p++)
-    {
-        const int pos = pos_of_code[codes[p]];
-        if (pos <= last)
-            *bad = 1;
-        last = pos;
-        // nd_blocked > 0: the values of a 256-row block are one contiguous [nd][256] piece (one stream per workgroup)
-        if (nd_blocked)
-            dia[(int64_t(blockIdx.x) * nd_blocked + pos) * 256 + threadIdx.x] = val[p];
-        else
-            dia[int64_t(pos) * ld + r] = val[p];
-    }
-}
-
-// acc + a*b with the product rounded before the sum, as the CSR kernels do it (their products pass through LDS)
-__device__ __forceinline__ double add_rounded_product(double acc, double a, double b)
-{
-#pragma clang fp contract(off)
-    const double p = a * b;
-    return acc + p;
-}
-
-struct DiaArgs
-{
-    const double* dia;
-    const int32_t* off;
-    int64_t ld;       // diagonal-major layout: dia[k * ld + r]; 0: block layout dia[(block * nd + k) * 256 + r % 256]
-    int nd;
-    int col_max;
-    int64_t row_begin;
-};
-// start of thread t's column of values in row-block lb and the stride between consecutive diagonals
-__device__ __forceinline__ const double* dia_row(const DiaArgs& da, int lb, int t, int64_t& stride)
-{
-    if (da.ld == 0)
-    {
-        stride = 256;
-        return da.dia + int64_t(lb) * da.nd * 256 + t;
-    }
-    stride = da.ld;
-    return da.dia + int64_t(lb) * 256 + t;
-}
-
-template <bool EPI>
-__global__ __launch_bounds__(256) void k_spmv_dia(DiaArgs da, const double* __restrict__ x, double* __restrict__ y, int64_t nrows,
-                                                  int nblocks, SpmvEpilogue epi)
-{
-    __shared__ int off_s[kMaxDia];
-    __shared__ double red[4];
-    // same XCD-aware row-block map and the same 256-row blocks as k_spmv_csr_stream: the alpha partials of the fused
-    // epilogue are identical records
-    const int per = (nblocks + 7) >> 3;
-    const int lmap = (int(blockIdx.x) & 7) * per + (int(blockIdx.x) >> 3);
-    if (lmap >= nblocks)
-        return;
-    const int lb = epi.first_block + lmap;  // a launch may cover a sub-range of the row-blocks (comm / compute overlap)
-    if (EPI && epi.status && *epi.status != 0)
-        return;
-    const int tid = threadIdx.x;
-    if (tid < da.nd)
-        off_s[tid] = da.off[tid];
-    __syncthreads();
-    const int64_t row0 = int64_t(lb) * 256;
-    const int nr = int(min(int64_t(256), nrows - row0));
-    const int64_t r = row0 + min(tid, nr - 1);  // threads past the last row repeat it (their result is dropped)
-    int64_t vstride;
-    const double* vrow = dia_row(da, lb, min(tid, nr - 1), vstride);
-    const int64_t grow = da.row_begin + r;
-    double acc = 0.0;
-    for (int g = 0; g < da.nd; g += kDiaGroup)
-    {
-        double v[kDiaGroup], xv[kDiaGroup];
-#pragma unroll
-        for (int u = 0; u < kDiaGroup; u++)
-        {
-            const int d = min(g + u, da.nd - 1);
-            v[u] = __builtin_nontemporal_load(vrow + int64_t(d) * vstride);  // read once per SpMV
-            const int64_t c = grow + off_s[d];
-            xv[u] = x[min(max(c, int64_t(0)), int64_t(da.col_max))];  // out of range only where the value is a padding zero
-        }
-#pragma unroll
-        for (int u = 0; u < kDiaGroup; u++)
-            if (g + u < da.nd)
-                acc = add_rounded_product(acc, v[u], xv[u]);  // no FMA: bit-identical to the CSR row sum
-    }
-    if (EPI)
-    {
-        double contrib = 0.0;
-        if (tid < nr)
-        {
-            const int64_t row = row0 + tid;
-            double yv = acc;
-            if (epi.v_prev)
-                yv -= (epi.h_prev_dev ? *epi.h_prev_dev : epi.h_prev) * epi.v_prev[row];  // Lanczos.h:139
-            y[row] = yv;
-            contrib = epi.v_rows[row] * yv;  // Lanczos.h:142 partial <v, w>
-        }
-        const double total = block_reduce_sum(contrib, red);
-        if (tid == 0)
-            epi.partials[lb] = total;
-    }
-    else if (tid < nr)
-        y[row0 + tid] = acc;
-}
-
-// The same product with the x entries of a row-block staged through LDS: the offsets cluster, so a block of 256 rows reads
-// a few contiguous windows of x (coalesced, once) instead of one 8-byte load per row and diagonal through the L1.
-// NG = groups of eight diagonals whose values a thread keeps in registers.
-// POST (one-sweep Lanczos steps only, fac.hip lanczos_step_lagged): the input is the UN-normalised residual f and the division
-// by beta = |f| (read from the step state) is applied to the row sums and to the epilogue's v instead of to every window entry —
-// w = (A f)/beta - beta v_prev, alpha partial = (f/beta) w — together with the step start that k_scale_step otherwise does
-// (H(i,i-1) = beta, the beta < sqrt(eps) stop): no scaling pass and no scaled copy of f, two divisions per row.
-template <bool EPI, int NG, int NCW = 8, bool POST = false>  // NCW: registers for window entries (>= number of windows)
-__global__ __launch_bounds__(256) void k_spmv_dia_win(DiaArgs da, mispec_dia_windows w, const double* __restrict__ x,
-                                                      double* __restrict__ y, int64_t nrows, int nblocks, SpmvEpilogue epi)
-{
-    extern __shared__ double xs[];
-    __shared__ double red[4];
-    const int per = (nblocks + 7) >> 3;
-    const int lmap = (int(blockIdx.x) & 7) * per + (int(blockIdx.x) >> 3);
-    if (lmap >= nblocks)
-        return;
-    const int lb = epi.first_block + lmap;  // a launch may cover a sub-range of the row-blocks (comm / compute overlap)
-    if (EPI && epi.status && *epi.status != 0)
-        return;
-    const int tid = threadIdx.x;
-    double beta = 1.0;
-    if (POST)
-    {
-        // every block takes the same decision from the same beta; one thread records it (Lanczos.h:99-128 without the restart branch)
-        StepState* st = static_cast<StepState*>(epi.post_scale_state);
-        beta = st->beta;
-        const bool first = (lmap == 0 && tid == 0);
-        if (beta < epi.post_scale_eps_sqrt)
-        {
-            if (first)
-            {
-                st->status = kStepSmallBeta;
-                st->stop_step = epi.post_scale_step;
-                st->stop_count = 0;
-            }
-            return;
-        }
-        if (first)
-            st->subd[epi.post_scale_step - 1] = beta;
-    }
-    const int64_t row0 = int64_t(lb) * 256;
-    const int nr = int(min(int64_t(256), nrows - row0));
-    int64_t vstride;
-    const double* vrow = dia_row(da, lb, min(tid, nr - 1), vstride);
-    double v[NG * kDiaGroup];
-#pragma unroll
-    for (int k = 0; k < NG * kDiaGroup; k++)
-        v[k] = __builtin_nontemporal_load(vrow + int64_t(min(k, da.nd - 1)) * vstride);
-    // The epilogue's operands travel with the matrix values: issued here, they are in flight during the window staging and
-    // the barrier instead of costing the block a second round trip to HBM after its row sums (the kernel is bound by the
-    // number of resident blocks, i.e. by latency per block: profiles/rounds_1_2/r02r_*, r03q_*).
-    double vprev_early = 0.0, vrow_early = 0.0, hprev_early = 0.0;
-    const bool early = EPI && tid < nr;
-    if (early)
-    {
-        if (epi.v_prev)
-        {
-            vprev_early = epi.v_prev[row0 + tid];
-            hprev_early = POST ? beta : (epi.h_prev_dev ? *epi.h_prev_dev : epi.h_prev);
-        }
-        vrow_early = epi.v_rows[row0 + tid];
-        if (POST)
-            vrow_early = vrow_early / beta;  // Lanczos.h:106
-    }
-    const int64_t g0 = da.row_begin + row0;
-    // x windows -> LDS.  A window is 256 + span entries: two per thread, ALL loaded before the first LDS write.  (Written as
-    // a loop over windows and pieces, each piece was a load, a wait and a write: ten dependent round trips per block on the
-    // five clusters of M-band, the latency the occupancy experiments of profiles/rounds_1_2/r02r_* were measuring.)
-    const auto xat = [&](int64_t col) { return x[min(max(col, int64_t(0)), int64_t(da.col_max))]; };
-    // entry tid of every window in a register of its own; the entries past 256 (the spans: 10 in all for M-band) one per
-    // thread, thread t taking the t-th of them — 64 VGPRs in total, i.e. eight workgroups per CU as before
-    double xw[NCW], xtail = 0.0;
-    int tail_pos = -1;  // LDS slot of this thread's tail entry
-    const int tails = w.total - 256 * w.nc;
-    {
-        int before = 0;
-#pragma unroll
-        for (int c = 0; c < NCW; c++)
-        {
-            xw[c] = 0.0;
-            if (c < w.nc)
-            {
-                xw[c] = xat(g0 + w.start[c] + tid);
-                const int span = w.len[c] - 256;
-                if (tid >= before && tid < before + span)
-                {
-                    tail_pos = w.base[c] + 256 + (tid - before);
-                    xtail = xat(g0 + w.start[c] + 256 + (tid - before));
-                }
-                before += span;
-            }
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int c = 0; c < NCW; c++)
-        if (c < w.nc)
-            xs[w.base[c] + tid] = xw[c];
-    if (tail_pos >= 0)
-        xs[tail_pos] = xtail;
-    if (tails > 256)  // more tail entries than threads (very wide clusters): the rest the slow way
-    {
-        int before = 0;
-        for (int c = 0; c < w.nc; c++)
-        {
-            const int span = w.len[c] - 256;
-            for (int t = tid + 256; t < before + span; t += 256)
-                if (t >= before)
-                {
-                    const double xv = xat(g0 + w.start[c] + 256 + (t - before));
-                    xs[w.base[c] + 256 + (t - before)] = xv;
-                }
-            before += span;
-        }
-    }
-    __syncthreads();
-    double acc = 0.0;
-#pragma unroll
-    for (int k = 0; k < NG * kDiaGroup; k++)
-        if (k < da.nd)
-            acc = add_rounded_product(acc, v[k], xs[w.idx[k] + tid]);
-    if (EPI)
-    {
-        double contrib = 0.0;
-        if (tid < nr)
-        {
-            const int64_t row = row0 + tid;
-            double yv = POST ? acc / beta : acc;
-            if (epi.v_prev)
-                yv -= (early ? hprev_early : (epi.h_prev_dev ? *epi.h_prev_dev : epi.h_prev)) *
-                      (early ? vprev_early : epi.v_prev[row]);  // Lanczos.h:139
-            y[row] = yv;
-            contrib = (early ? vrow_early : epi.v_rows[row]) * yv;  // Lanczos.h:142 partial <v, w>
-        }
-        const double total = block_reduce_sum(contrib, red);
-        if (tid == 0)
-            epi.partials[lb] = total;
-    }
-    else if (tid < nr)
-        y[row0 + tid] = acc;
-}
-
-// Two rows per thread (round 5): the values of a 256-row block are read with 16-byte loads by 128 threads — half the load
-// instructions per byte (the one-row-per-thread kernel above issues 8-byte loads, which the memory pipeline serves at 0.54-0.70 of
-// the 16-byte rate: it moved 1.38 GB at 5.5 TB/s where the 16-byte kernels of this library reach 5.8-6.3) — rows 2t and 2t + 1,
-// y / v_prev / v as 16-byte accesses too.  Same products in the same order, and the alpha record of the block is formed by the
-// same tree as everywhere else (per-row contributions through LDS, then the four 64-row shuffle trees and (w0 + w1) + (w2 + w3)):
-// bit-identical results and records.  Needs the block layout of the values (dia_row: ld == 0) and 16-byte aligned y / v vectors.
-template <bool EPI, int NG, int NCW = 8, bool POST = false>
-__global__ __launch_bounds__(128) void k_spmv_dia_win2(DiaArgs da, mispec_dia_windows w, const double* __restrict__ x,
-                                                       double* __restrict__ y, int64_t nrows, int nblocks, SpmvEpilogue epi)
-{
-    extern __shared__ double xs[];  // windows, then 256 per-row contributions of the epilogue
-    __shared__ double red[4];
-    const int per = (nblocks + 7) >> 3;
-    const int lmap = (int(blockIdx.x) & 7) * per + (int(blockIdx.x) >> 3);
-    if (lmap >= nblocks)
-        return;
-    const int lb = epi.first_block + lmap;
-    if (EPI && epi.status && *epi.status != 0)
-        return;
-    const int tid = threadIdx.x;
-    double beta = 1.0;
-    if (POST)
-    {
-        StepState* st = static_cast<StepState*>(epi.post_scale_state);
-        beta = st->beta;
-        const bool first = (lmap == 0 && tid == 0);
-        if (beta < epi.post_scale_eps_sqrt)
-        {
-            if (first)
-            {
-                st->status = kStepSmallBeta;
-                st->stop_step = epi.post_scale_step;
-                st->stop_count = 0;
-            }
-            return;
-        }
-        if (first)
-            st->subd[epi.post_scale_step - 1] = beta;
-    }
-    const int64_t row0 = int64_t(lb) * 256;
-    const int nr = int(min(int64_t(256), nrows - row0));
-    const int r0 = 2 * tid;  // rows r0, r0 + 1 of the block (the value array is zero-padded to whole blocks)
-    const double* vrow = da.dia + int64_t(lb) * da.nd * 256 + r0;
-    double2 v[NG * kDiaGroup];
-#pragma unroll
-    for (int k = 0; k < NG * kDiaGroup; k++)
-    {
-        const v2d t2 = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(vrow + int64_t(min(k, da.nd - 1)) * 256));
-        v[k] = make_double2(t2.x, t2.y);
-    }
-    double2 vprev_e = make_double2(0.0, 0.0), vrow_e = make_double2(0.0, 0.0);
-    double hprev_e = 0.0;
-    const bool have0 = r0 < nr, have1 = r0 + 1 < nr;
-    if (EPI && have0)
-    {
-        if (epi.v_prev)
-        {
-            if (have1)
-                vprev_e = *reinterpret_cast<const double2*>(epi.v_prev + row0 + r0);
-            else
-                vprev_e.x = epi.v_prev[row0 + r0];
-            hprev_e = POST ? beta : (epi.h_prev_dev ? *epi.h_prev_dev : epi.h_prev);
-        }
-        if (have1)
-            vrow_e = *reinterpret_cast<const double2*>(epi.v_rows + row0 + r0);
-        else
-            vrow_e.x = epi.v_rows[row0 + r0];
-        if (POST)
-        {
-            vrow_e.x = vrow_e.x / beta;  // Lanczos.h:106
-            vrow_e.y = vrow_e.y / beta;
-        }
-    }
-    const int64_t g0 = da.row_begin + row0;
-    const auto xat = [&](int64_t col) { return x[min(max(col, int64_t(0)), int64_t(da.col_max))]; };
-    // windows -> LDS: entries tid and tid + 128 of every window, the entries past 256 (the spans) two per thread
-    double xw[NCW][2], xtail[2] = {0.0, 0.0};
-    int tail_pos[2] = {-1, -1};
-    const int tails = w.total - 256 * w.nc;
-    {
-        int before = 0;
-#pragma unroll
-        for (int c = 0; c < NCW; c++)
-        {
-            xw[c][0] = xw[c][1] = 0.0;
-            if (c < w.nc)
-            {
-                xw[c][0] = xat(g0 + w.start[c] + tid);
-                xw[c][1] = xat(g0 + w.start[c] + tid + 128);
-                const int span = w.len[c] - 256;
-#pragma unroll
-                for (int h = 0; h < 2; h++)
-                {
-                    const int t = tid + 128 * h;
-                    if (t >= before && t < before + span)
-                    {
-                        tail_pos[h] = w.base[c] + 256 + (t - before);
-                        xtail[h] = xat(g0 + w.start[c] + 256 + (t - before));
-                    }
-                }
-                before += span;
-            }
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int c = 0; c < NCW; c++)
-        if (c < w.nc)
-        {
-            xs[w.base[c] + tid] = xw[c][0];
-            xs[w.base[c] + tid + 128] = xw[c][1];
-        }
-#pragma unroll
-    for (int h = 0; h < 2; h++)
-        if (tail_pos[h] >= 0)
-            xs[tail_pos[h]] = xtail[h];
-    if (tails > 256)
-    {
-        int before = 0;
-        for (int c = 0; c < w.nc; c++)
-        {
-            const int span = w.len[c] - 256;
-            for (int t = tid + 256; t < before + span; t += 128)
-                if (t >= before)
-                    xs[w.base[c] + 256 + (t - before)] = xat(g0 + w.start[c] + 256 + (t - before));
-            before += span;
-        }
-    }
-    __syncthreads();
-    double acc0 = 0.0, acc1 = 0.0;
-#pragma unroll
-    for (int k = 0; k < NG * kDiaGroup; k++)
-        if (k < da.nd)
-        {
-            acc0 = add_rounded_product(acc0, v[k].x, xs[w.idx[k] + r0]);
-            acc1 = add_rounded_product(acc1, v[k].y, xs[w.idx[k] + r0 + 1]);
-        }
-    if (EPI)
-    {
-        double* cbuf = xs + w.total;  // per-row contributions of the block
-        double c0 = 0.0, c1 = 0.0;
-        double2 yv;
-        yv.x = POST ? acc0 / beta : acc0;
-        yv.y = POST ? acc1 / beta : acc1;
-        if (epi.v_prev)
-        {
-            yv.x -= hprev_e * vprev_e.x;  // Lanczos.h:139
-            yv.y -= hprev_e * vprev_e.y;
-        }
-        if (have1)
-            *reinterpret_cast<double2*>(y + row0 + r0) = yv;
-        else if (have0)
-            y[row0 + r0] = yv.x;
-        if (have0)
-            c0 = vrow_e.x * yv.x;  // Lanczos.h:142 partial <v, w>
-        if (have1)
-            c1 = vrow_e.y * yv.y;
-        cbuf[r0] = c0;
-        cbuf[r0 + 1] = c1;
-        __syncthreads();
-        // the record's tree: wave k of a 256-thread block sums rows 64 k .. 64 k + 63 by shuffles, then (w0 + w1) + (w2 + w3)
-        const int wv = tid >> 6, lane = tid & 63;
-#pragma unroll
-        for (int h = 0; h < 2; h++)
-        {
-            const int k = 2 * wv + h;
-            const double s = wave_reduce_sum(cbuf[64 * k + lane]);
-            if (lane == 0)
-                red[k] = s;
-        }
-        __syncthreads();
-        if (tid == 0)
-            epi.partials[lb] = (red[0] + red[1]) + (red[2] + red[3]);
-    }
-    else
-    {
-        if (have1)
-            *reinterpret_cast<double2*>(y + row0 + r0) = make_double2(acc0, acc1);
-        else if (have0)
-            y[row0 + r0] = acc0;
-    }
-}
-
 // ---- reordered matrices: vector permutations and the un-fused epilogue ----------------------------------------------
 __global__ __launch_bounds__(256) void k_perm_gather(int64_t n, const int32_t* __restrict__ perm, const double* __restrict__ src,
                                                      double* __restrict__ dst)
@@ -1377,115 +364,6 @@ void alloc_codes(mispec_csr& A)
     const size_t cap = size_t(round_up(A.nnz, 4) + 8);
     A.codes.alloc(cap);
     MISPEC_HIP(hipMemsetAsync(A.codes.p, 0, cap, A.ctx->stream));
-}
-
-// Diagonal storage from the offset codes (device): only for small, well-filled dictionaries whose rows are sorted and free
-// of duplicates; anything else keeps the CSR kernels (mispec_csr_set_spmv_format selects among the formats a matrix has).
-void build_dia(mispec_csr& A, const std::vector<int32_t>& dict)
-{
-    const int64_t nloc = A.local_rows();
-    const int nd = int(dict.size());
-    if (nd == 0 || nd > kMaxDia || nloc == 0 || double(A.nnz) < 0.75 * double(nd) * double(nloc))
-        return;
-    std::vector<int32_t> order(static_cast<size_t>(nd)), pos(static_cast<size_t>(nd)), offs(static_cast<size_t>(nd));
-    std::iota(order.begin(), order.end(), 0);
-    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return dict[size_t(a)] < dict[size_t(b)]; });
-    for (int k = 0; k < nd; k++)
-    {
-        pos[size_t(order[size_t(k)])] = k;
-        offs[size_t(k)] = dict[size_t(order[size_t(k)])];
-    }
-    // the values of a 256-row block are stored as one contiguous [nd][256] piece, so a workgroup streams ONE 30 KB run instead
-    // of nd runs of 2 KB that are 80 MB apart (the diagonal-major layout dia[k][row] of round 1 measured 1.5 % slower and is gone)
-    constexpr bool blocked = true;
-    const int64_t ld = round_up(nloc, 256);
-    DevBuf<int32_t> d_pos;
-    DevBuf<int> d_bad;
-    d_pos.alloc(size_t(nd));
-    d_bad.alloc(1);
-    A.dia.alloc(size_t(ld) * size_t(nd));
-    A.dia_off.alloc(size_t(nd));
-    hipStream_t st = A.ctx->stream;
-    MISPEC_HIP(hipMemsetAsync(A.dia.p, 0, A.dia.n * sizeof(double), st));
-    MISPEC_HIP(hipMemsetAsync(d_bad.p, 0, sizeof(int), st));
-    MISPEC_HIP(hipMemcpyAsync(d_pos.p, pos.data(), pos.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    MISPEC_HIP(hipMemcpyAsync(A.dia_off.p, offs.data(), offs.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_build_dia, dim3(unsigned((nloc + 255) / 256)), dim3(256), 0, st, A.rowptr.p, A.codes.p, A.val.p, d_pos.p, nloc, ld,
-                       A.dia.p, d_bad.p, blocked ? nd : 0);
-    MISPEC_HIP(hipGetLastError());
-    int bad = 0;
-    MISPEC_HIP(hipMemcpyAsync(&bad, d_bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
-    MISPEC_HIP(hipStreamSynchronize(st));
-    if (bad)
-    {
-        A.dia.release();
-        A.dia_off.release();
-        return;
-    }
-    A.dia_ld = blocked ? 0 : ld;
-    A.ndia = nd;
-    // x windows: consecutive sorted offsets share a window while it stays within 256 + 256 entries
-    mispec_dia_windows w;
-    int first = 0;
-    bool ok = true;
-    for (int k = 0; k <= nd && ok; k++)
-        if (k == nd || int64_t(offs[size_t(k)]) - int64_t(offs[size_t(first)]) > 256)
-        {
-            if (w.nc == 8)
-            {
-                ok = false;
-                break;
-            }
-            const int c = w.nc++;
-            w.start[c] = offs[size_t(first)];
-            w.len[c] = 256 + (offs[size_t(k) - 1] - offs[size_t(first)]);
-            w.base[c] = w.total;
-            for (int d = first; d < k; d++)
-                w.idx[d] = w.total + (offs[size_t(d)] - offs[size_t(first)]);
-            w.total += w.len[c];
-            first = k;
-        }
-    if (ok)
-        A.dia_win = w;
-}
-
-// x windows for the int32 CSR kernel (k_spmv_csr_win), from the device copy of the index arrays.  Adopted when at least 75 % of
-// the entries get their x from a window; MISPEC_CSR_WIN=0 keeps k_spmv_csr_stream for every matrix.
-void build_windows(mispec_csr& A)
-{
-    const bool off = option_is("csr_win", "0");
-    const int64_t nloc = A.local_rows();
-    // (columns at or beyond the start sentinel of unused windows would select a padding window: no table for such a matrix — ADVICE r05)
-    if (off || nloc == 0 || A.nnz == 0 || spmv_rows_per_block() != 256 || A.n_cols > int64_t(kWinPad))
-        return;
-    const int nblocks = spmv_num_blocks(nloc);
-    hipStream_t st = A.ctx->stream;
-    A.wtab.alloc(size_t(nblocks) * kWinRec);
-    hipLaunchKernelGGL(k_build_windows, dim3(unsigned(nblocks)), dim3(256), 0, st, A.rowptr.p, A.colind.p, nloc, A.row_begin, A.n_cols,
-                       kWinCapMax, A.wtab.p);
-    MISPEC_HIP(hipGetLastError());
-    std::vector<int32_t> h(size_t(nblocks) * kWinRec);
-    MISPEC_HIP(hipMemcpyAsync(h.data(), A.wtab.p, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    MISPEC_HIP(hipStreamSynchronize(st));
-    int64_t covered = 0, blocks = 0;
-    int lds = 0;
-    for (int b = 0; b < nblocks; b++)
-    {
-        const int32_t* rec = h.data() + size_t(b) * kWinRec;
-        if ((rec[0] & 255) == 0)
-            continue;
-        blocks++;
-        covered += rec[2];
-        lds = std::max(lds, int(rec[1]));
-    }
-    A.win_covered = covered;
-    A.win_blocks = blocks;
-    A.win_lds_doubles = lds;
-    if (double(covered) < 0.75 * double(A.nnz))
-    {
-        A.wtab.release();
-        A.win_lds_doubles = 0;
-    }
 }
 
 // Host side of the offset-coded format: one byte per entry of rows [b, e) if the shard's entries lie on at most
@@ -1968,152 +846,10 @@ void launch_spmv_raw(const mispec_csr& A, const double* x_dev, double* y_dev, co
         launch_spmv_tiles(A.tiles, A.ctx->stream, x_dev, y_dev, nloc, all_blocks, epi, ev_start, ev_stop);
         return;
     }
+    SpmvLaunch L{grid, block, nloc, nblocks, epi, e, ev_start, ev_stop, x_dev, y_dev};
     if (format == 2)
     {
-        const DiaArgs da{A.dia.p, A.dia_off.p, A.dia_ld, A.ndia, int(A.n_cols - 1), A.row_begin};
-        // x staged through LDS windows when the offsets form at most 8 clusters, else direct loads (k_spmv_dia)
-        // two rows per thread with 16-byte loads (k_spmv_dia_win2) when the layout and the alignment allow; MISPEC_DIA2=0: the
-        // one-row-per-thread kernel
-        const bool dia2_off = option_int("dia2", 1) == 0;
-        const bool dia2 = !dia2_off && A.dia_win.nc > 0 && A.dia_ld == 0 && A.ndia <= 2 * kDiaGroup &&
-                          (reinterpret_cast<uintptr_t>(y_dev) & 15) == 0 &&
-                          (!epi || ((reinterpret_cast<uintptr_t>(e.v_rows) & 15) == 0 && (reinterpret_cast<uintptr_t>(e.v_prev) & 15) == 0));
-        if (dia2)
-        {
-            const size_t lds2 = size_t(A.dia_win.total + 256) * sizeof(double);
-            const dim3 block2(128);
-            const int ng = (A.ndia + kDiaGroup - 1) / kDiaGroup;
-            const bool post = epi && e.post_scale_state;
-#define MISPEC_DIA2_LAUNCH(E, G, W, P)                                                                                                  \
-    do                                                                                                                                  \
-    {                                                                                                                                   \
-        if (ev_start && ev_stop)                                                                                                        \
-            hipExtLaunchKernelGGL((k_spmv_dia_win2<E, G, W, P>), grid, block2, lds2, A.ctx->stream, ev_start, ev_stop, 0, da, A.dia_win, \
-                                  x_dev, y_dev, nloc, nblocks, e);                                                                      \
-        else                                                                                                                            \
-            hipLaunchKernelGGL((k_spmv_dia_win2<E, G, W, P>), grid, block2, lds2, A.ctx->stream, da, A.dia_win, x_dev, y_dev, nloc,     \
-                               nblocks, e);                                                                                             \
-    } while (0)
-#define MISPEC_DIA2_W(E, G, P)               \
-    do                                       \
-    {                                        \
-        if (A.dia_win.nc <= 4)               \
-            MISPEC_DIA2_LAUNCH(E, G, 4, P);  \
-        else if (A.dia_win.nc <= 6)          \
-            MISPEC_DIA2_LAUNCH(E, G, 6, P);  \
-        else                                 \
-            MISPEC_DIA2_LAUNCH(E, G, 8, P);  \
-    } while (0)
-#define MISPEC_DIA2_G(E, P)          \
-    do                               \
-    {                                \
-        if (ng == 1)                 \
-            MISPEC_DIA2_W(E, 1, P);  \
-        else                         \
-            MISPEC_DIA2_W(E, 2, P);  \
-    } while (0)
-            if (post)
-                MISPEC_DIA2_G(true, true);
-            else if (epi)
-                MISPEC_DIA2_G(true, false);
-            else
-                MISPEC_DIA2_G(false, false);
-#undef MISPEC_DIA2_G
-#undef MISPEC_DIA2_W
-#undef MISPEC_DIA2_LAUNCH
-            MISPEC_HIP(hipGetLastError());
-            return;
-        }
-        if (A.dia_win.nc > 0)
-        {
-            const size_t lds = size_t(A.dia_win.total) * sizeof(double);
-            const int ng = (A.ndia + kDiaGroup - 1) / kDiaGroup;
-#define MISPEC_DIA_WIN_W(E, G, W)                                                                                             \
-    do                                                                                                                     \
-    {                                                                                                                      \
-        if (ev_start && ev_stop)                                                                                           \
-            hipExtLaunchKernelGGL((k_spmv_dia_win<E, G, W>), grid, block, lds, A.ctx->stream, ev_start, ev_stop, 0, da, A.dia_win, x_dev, \
-                                  y_dev, nloc, nblocks, e);                                                                \
-        else                                                                                                               \
-            hipLaunchKernelGGL((k_spmv_dia_win<E, G, W>), grid, block, lds, A.ctx->stream, da, A.dia_win, x_dev, y_dev, nloc, nblocks, e); \
-    } while (0)
-#define MISPEC_DIA_WIN(E, G)              \
-    do                                    \
-    {                                     \
-        if (A.dia_win.nc <= 4)            \
-            MISPEC_DIA_WIN_W(E, G, 4);    \
-        else if (A.dia_win.nc <= 6)       \
-            MISPEC_DIA_WIN_W(E, G, 6);    \
-        else                              \
-            MISPEC_DIA_WIN_W(E, G, 8);    \
-    } while (0)
-#define MISPEC_DIA_WIN_G(E)          \
-    do                               \
-    {                                \
-        if (ng == 1)                 \
-            MISPEC_DIA_WIN(E, 1);    \
-        else if (ng == 2)            \
-            MISPEC_DIA_WIN(E, 2);    \
-        else if (ng == 3)            \
-            MISPEC_DIA_WIN(E, 3);    \
-        else                         \
-            MISPEC_DIA_WIN(E, 4);    \
-    } while (0)
-            if (epi && e.post_scale_state)
-            {
-#define MISPEC_DIA_WIN_POST_W(G, W)                                                                                                    \
-    do                                                                                                                                 \
-    {                                                                                                                                  \
-        if (ev_start && ev_stop)                                                                                                       \
-            hipExtLaunchKernelGGL((k_spmv_dia_win<true, G, W, true>), grid, block, lds, A.ctx->stream, ev_start, ev_stop, 0, da, A.dia_win, \
-                                  x_dev, y_dev, nloc, nblocks, e);                                                                     \
-        else                                                                                                                           \
-            hipLaunchKernelGGL((k_spmv_dia_win<true, G, W, true>), grid, block, lds, A.ctx->stream, da, A.dia_win, x_dev, y_dev, nloc, \
-                               nblocks, e);                                                                                            \
-    } while (0)
-#define MISPEC_DIA_WIN_POST(G)               \
-    do                                       \
-    {                                        \
-        if (A.dia_win.nc <= 4)               \
-            MISPEC_DIA_WIN_POST_W(G, 4);     \
-        else if (A.dia_win.nc <= 6)          \
-            MISPEC_DIA_WIN_POST_W(G, 6);     \
-        else                                 \
-            MISPEC_DIA_WIN_POST_W(G, 8);     \
-    } while (0)
-                if (ng == 1)
-                    MISPEC_DIA_WIN_POST(1);
-                else if (ng == 2)
-                    MISPEC_DIA_WIN_POST(2);
-                else if (ng == 3)
-                    MISPEC_DIA_WIN_POST(3);
-                else
-                    MISPEC_DIA_WIN_POST(4);
-#undef MISPEC_DIA_WIN_POST
-#undef MISPEC_DIA_WIN_POST_W
-            }
-            else if (epi)
-                MISPEC_DIA_WIN_G(true);
-            else
-                MISPEC_DIA_WIN_G(false);
-#undef MISPEC_DIA_WIN_G
-#undef MISPEC_DIA_WIN
-#undef MISPEC_DIA_WIN_W
-            MISPEC_HIP(hipGetLastError());
-            return;
-        }
-        if (ev_start && ev_stop)
-        {
-            if (epi)
-                hipExtLaunchKernelGGL(k_spmv_dia<true>, grid, block, 0, A.ctx->stream, ev_start, ev_stop, 0, da, x_dev, y_dev, nloc, nblocks, e);
-            else
-                hipExtLaunchKernelGGL(k_spmv_dia<false>, grid, block, 0, A.ctx->stream, ev_start, ev_stop, 0, da, x_dev, y_dev, nloc, nblocks, e);
-        }
-        else if (epi)
-            hipLaunchKernelGGL(k_spmv_dia<true>, grid, block, 0, A.ctx->stream, da, x_dev, y_dev, nloc, nblocks, e);
-        else
-            hipLaunchKernelGGL(k_spmv_dia<false>, grid, block, 0, A.ctx->stream, da, x_dev, y_dev, nloc, nblocks, e);
-        MISPEC_HIP(hipGetLastError());
+        launch_spmv_dia(A, L);  // csr_dia.hip
         return;
     }
     // With an event pair the launch is timed through the dispatch's own completion signal (start/stop of the
@@ -2134,90 +870,7 @@ void launch_spmv_raw(const mispec_csr& A, const double* x_dev, double* y_dev, co
     const bool small_chunk = !coded && double(A.nnz) <= 16.0 * double(nloc);
     if (!coded && A.windows_active() && (reinterpret_cast<uintptr_t>(x_dev) & 15) == 0)
     {
-        // MISPEC_CSR_WIN_ITERS = 2 | 4 (chunk of 2032 / 4080 products), MISPEC_CSR_WIN_PF = 0 | 1 (next chunk's loads ahead)
-        // (read once; MISPEC_KERNEL_PROBE=1 — tools/probe_csr_win.py — re-reads them at every launch so that one process can compare)
-        struct Knobs
-        {
-            int iters, pf;
-            bool nt;
-        };
-        const auto read_knobs = [] {
-            const char* e_iters = option("csr_win_iters");
-            const char* e_pf = option("csr_win_pf");
-            const char* e_nt = option("csr_win_nt");
-            return Knobs{e_iters ? atoi(e_iters) : 0, e_pf ? atoi(e_pf) : -1, e_nt && atoi(e_nt) != 0};
-        };
-        const bool probe = option("kernel_probe") != nullptr;
-        static const Knobs cached = read_knobs();
-        const Knobs knobs = probe ? read_knobs() : cached;
-        const int env_iters = knobs.iters, env_pf = knobs.pf;
-        const bool nt = knobs.nt;
-        // measured in the solver loop (profiles/r09a, r09b): chunks of 1008 products with the next chunk's loads ahead — the
-        // smallest LDS footprint, most resident blocks — for up to 16 entries per row (M-band 0.372 -> 0.369 ms, jittered band
-        // 0.412 -> 0.368 ms against the gather kernel on the same box); longer rows take larger chunks (fewer barrier rounds)
-        const int auto_iters = double(A.nnz) <= 16.0 * double(nloc) ? 1 : (double(A.nnz) <= 32.0 * double(nloc) ? 2 : 4);
-        int iters = env_iters == 1 || env_iters == 2 || env_iters == 4 ? env_iters : auto_iters;
-        // (64 bytes of margin: the kernel's static `red[4]` shares the 64 KiB with the dynamic allocation — ADVICE r05)
-        while (iters > 1 && size_t(chunk_cap(256) - (4 - iters) * 1024 + 4 + A.win_lds_doubles) * sizeof(double) > 65536 - 64)
-            iters >>= 1;  // products + windows within the 64 KiB a launch gets without an attribute
-        const bool pf = env_pf >= 0 ? env_pf != 0 : true;
-        const int xi = (A.win_lds_doubles + 511) / 512;
-        const int cap = chunk_cap(256) - (4 - iters) * 1024;
-        const size_t lds = size_t(cap + 4 + A.win_lds_doubles) * sizeof(double);
-        const int col_max = int(A.n_cols - 1);
-#define MISPEC_WIN_LAUNCH_NT(E, I, X, P, N)                                                                                           \
-    do                                                                                                                             \
-    {                                                                                                                              \
-        if (ev_start && ev_stop)                                                                                                   \
-            hipExtLaunchKernelGGL((k_spmv_csr_win<E, I, X, P, N>), grid, block, lds, A.ctx->stream, ev_start, ev_stop, 0, A.rowptr.p, \
-                                  A.colind.p, A.val.p, x_dev, y_dev, nloc, nblocks, e, A.wtab.p, col_max);                          \
-        else                                                                                                                       \
-            hipLaunchKernelGGL((k_spmv_csr_win<E, I, X, P, N>), grid, block, lds, A.ctx->stream, A.rowptr.p, A.colind.p, A.val.p,  \
-                               x_dev, y_dev, nloc, nblocks, e, A.wtab.p, col_max);                                                 \
-    } while (0)
-#define MISPEC_WIN_LAUNCH(E, I, X, P)               \
-    do                                              \
-    {                                               \
-        if (nt)                                     \
-            MISPEC_WIN_LAUNCH_NT(E, I, X, P, true); \
-        else                                        \
-            MISPEC_WIN_LAUNCH_NT(E, I, X, P, false); \
-    } while (0)
-#define MISPEC_WIN_X(E, I, P)              \
-    do                                     \
-    {                                      \
-        if (xi <= 3)                       \
-            MISPEC_WIN_LAUNCH(E, I, 3, P); \
-        else if (xi <= 5)                  \
-            MISPEC_WIN_LAUNCH(E, I, 5, P); \
-        else if (xi <= 8)                  \
-            MISPEC_WIN_LAUNCH(E, I, 8, P); \
-        else                               \
-            MISPEC_WIN_LAUNCH(E, I, 12, P); \
-    } while (0)
-#define MISPEC_WIN(E)                     \
-    do                                    \
-    {                                     \
-        if (iters == 2 && pf)             \
-            MISPEC_WIN_X(E, 2, true);     \
-        else if (iters == 2)              \
-            MISPEC_WIN_X(E, 2, false);    \
-        else if (iters == 1 && pf)        \
-            MISPEC_WIN_X(E, 1, true);     \
-        else if (iters == 1)              \
-            MISPEC_WIN_X(E, 1, false);    \
-        else                              \
-            MISPEC_WIN_X(E, 4, false);    \
-    } while (0)
-        if (epi)
-            MISPEC_WIN(true);
-        else
-            MISPEC_WIN(false);
-#undef MISPEC_WIN
-#undef MISPEC_WIN_X
-#undef MISPEC_WIN_LAUNCH
-#undef MISPEC_WIN_LAUNCH_NT
-        MISPEC_HIP(hipGetLastError());
+        launch_spmv_csr_win(A, L);  // csr_win.hip
         return;
     }
 #define MISPEC_SPMV(E)                                                    \
@@ -2656,15 +1309,6 @@ extern "C" int mispec_csr_windows_info(const mispec_csr* A, int64_t* blocks, int
             *covered_entries = A->wtab.p ? A->win_covered : 0;
         if (lds_doubles)
             *lds_doubles = A->wtab.p ? A->win_lds_doubles : 0;
-    });
-}
-extern "C" int mispec_csr_windows_host(int64_t n_rows, int64_t n_cols, int64_t row_begin, const int32_t* rowptr, const int32_t* colind,
-                                       int32_t* records_out)
-{
-    return guarded([&] {
-        MISPEC_REQUIRE(n_rows >= 0 && n_cols >= 0 && rowptr && records_out && (colind || rowptr[n_rows] == rowptr[0]),
-                       "mispec_csr_windows_host: bad argument");
-        build_windows_host(n_rows, n_cols, row_begin, rowptr, colind, records_out);
     });
 }
 extern "C" int mispec_csr_windows_in_use(const mispec_csr* A) { return A && A->windows_active() ? 1 : 0; }

@@ -36,6 +36,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 
 using namespace mispec;
@@ -794,9 +795,12 @@ __global__ __launch_bounds__(kChunkThreads) void k_chunk_factor(int64_t N, int64
 void upload_row_major(const std::vector<double>& inv, int64_t n, DevBuf<double>& dst)
 {
     std::vector<double> rm(inv.size());
-    for (int64_t c = 0; c < n; c++)
-        for (int64_t r = 0; r < n; r++)
-            rm[size_t(r) * n + c] = inv[size_t(c) * n + r];
+    // (by the host's cores: at n = 1825 — C5's last level — the serial transposition was 10 of set_shift's 65 ms)
+    parallel_ranges(n, n >= 512 ? ingest_threads() : 1, [&](int, int64_t r0, int64_t r1) {
+        for (int64_t c = 0; c < n; c++)
+            for (int64_t r = r0; r < r1; r++)
+                rm[size_t(r) * n + c] = inv[size_t(c) * n + r];
+    });
     dst.alloc(rm.size());
     MISPEC_HIP(hipMemcpy(dst.p, rm.data(), rm.size() * sizeof(double), hipMemcpyHostToDevice));
 }
@@ -853,8 +857,12 @@ void band_lu_inverse(const HostBand& M, std::vector<double>& inv)
         }
     }
     inv.assign(size_t(N) * N, 0.0);
+    // the N columns of the inverse are independent solves with the factor above: spread over the host's cores (each column is
+    // computed exactly as before — same operations, same order —, so the inverse does not depend on the number of threads).
+    // C5's last level (N = 1825, b = 9): 50 of set_shift's 65 ms on one core.
+    parallel_ranges(N, N >= 256 ? ingest_threads() : 1, [&](int, int64_t c_begin, int64_t c_end) {
     std::vector<double> e(static_cast<size_t>(N));
-    for (int64_t c = 0; c < N; c++)
+    for (int64_t c = c_begin; c < c_end; c++)
     {
         std::fill(e.begin(), e.end(), 0.0);
         e[size_t(c)] = 1.0;
@@ -876,6 +884,7 @@ void band_lu_inverse(const HostBand& M, std::vector<double>& inv)
         }
         std::copy(e.begin(), e.end(), inv.begin() + size_t(c) * N);
     }
+    });
 }
 
 // ---- iterative refinement on the device ---------------------------------------------------------------------
@@ -1162,12 +1171,29 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
     const ChunkStore cs = make_chunk_store(N, b, L, P);
     lev.cs = cs;
     const size_t lf_size = cs.lf_size(), dinv_size = cs.dinv_size(), w_size = size_t(N) * 2 * std::max(b, 1);
-    std::vector<double> Lf, Dinv, W;  // host images of the factor (host path only)
+    // host images of the factor (host path only).  Hundreds of MB at the top level of a wide band (W: 512 MB at n = 1e6, b = 32):
+    // allocated without initialisation and zeroed — first touched — by the host's cores (one core took 0.15 s for it)
+    struct HostImage
+    {
+        std::unique_ptr<double[]> p;
+        size_t n = 0;
+        void zeros(size_t count)
+        {
+            n = count;
+            p.reset(new double[std::max<size_t>(count, 1)]);
+            double* q = p.get();
+            parallel_ranges(int64_t(count), count >= (size_t(1) << 22) ? ingest_threads() : 1,
+                            [q](int, int64_t b0, int64_t b1) { std::fill(q + b0, q + b1, 0.0); });
+        }
+        double& operator[](size_t i) { return p[i]; }
+    };
+    HostImage Lf, Dinv, W;
     if (!on_device)
     {
-        Lf.assign(lf_size, 0.0);
-        Dinv.assign(dinv_size, 0.0);
-        W.assign(w_size, 0.0);
+        PhaseTimer pt("level: host images zeroed", N, b);
+        Lf.zeros(lf_size);
+        Dinv.zeros(dinv_size);
+        W.zeros(w_size);
     }
     const int64_t nsep = (P - 1) * b;
     HostBand S;  // Schur complement of the separators
@@ -1476,26 +1502,32 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
 
     // ---- upload this level ---------------------------------------------------------------------------
     ctx->make_current();
-    auto up = [&](DevBuf<double>& dst, const std::vector<double>& src) {
-        dst.alloc(std::max<size_t>(src.size(), 1));
-        if (!src.empty())
-            MISPEC_HIP(hipMemcpyAsync(dst.p, src.data(), src.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    auto up = [&](DevBuf<double>& dst, const double* src, size_t count) {
+        dst.alloc(std::max<size_t>(count, 1));
+        if (count)
+            MISPEC_HIP(hipMemcpyAsync(dst.p, src, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     };
+    std::unique_ptr<PhaseTimer> pt_up(on_device ? nullptr : new PhaseTimer("level: factor uploaded", N, b));
     if (!on_device)
     {
-        up(lev.Lf, Lf);
-        up(lev.Dinv, Dinv);
+        up(lev.Lf, Lf.p.get(), Lf.n);
+        up(lev.Dinv, Dinv.p.get(), Dinv.n);
     }
     lev.y.alloc(size_t(N));
     if (P > 1)
     {
         if (!on_device)
         {
-            up(lev.W, W);
-            up(lev.band, M.a);
+            up(lev.W, W.p.get(), W.n);
+            up(lev.band, M.a.data(), M.a.size());
         }
         lev.g.alloc(size_t(nsep));
         lev.xs.alloc(size_t(nsep));
+    }
+    if (pt_up)
+    {
+        MISPEC_HIP(hipStreamSynchronize(ctx->stream));  // (the host images go out of scope at the end of this function anyway)
+        pt_up.reset();
     }
     {
         PhaseTimer pt("level: uploads + block inverses", N, b);
@@ -2289,13 +2321,12 @@ extern "C" int mispec_symshift_set_shift(mispec_symshift* S, double sigma)
             }
             else
             {
-                M.a = S->band0;
+                // levels factored on the host: the shifted band is built per attempt below, from the resident unshifted copy,
+                // by the host's cores (it used to be copied twice and shifted by one core: 0.2 s at n = 1e6, b = 32)
+                M.view = &S->band0;
                 if (S->pencil)
-                    for (size_t e = 0; e < M.a.size(); e++)
-                        M.a[e] -= sigma * S->bandB0[e];
-                else
-                    for (int64_t i = 0; i < n; i++)
-                        M.at(i, 0) -= sigma;
+                    M.viewB = &S->bandB0;
+                M.shift = sigma;
             }
             // Up to four attempts with the separators moved by one row each time: an attempt fails when the calibration
             // of the iterative refinement does not converge (singular chunk interiors of a nonsingular matrix)
@@ -2307,12 +2338,23 @@ extern "C" int mispec_symshift_set_shift(mispec_symshift* S, double sigma)
                 try
                 {
                     HostBand Mt = M;  // factor_level consumes its argument
-                    if (Mt.view && !factored_on_device(n, Mt.b))
+                    if (Mt.view && (!factored_on_device(n, Mt.b) || !Mt.view_dev))
                     {
-                        // the attempt factors this level on the host: it needs the shifted band itself, not the device view
+                        // the attempt factors this level on the host (or there is no device copy of the band): it needs the shifted band itself
+                        PhaseTimer pt("shifted band built (host)", n, int(Mt.b));
                         Mt.a.resize(S->band0.size());
-                        for (size_t e = 0; e < Mt.a.size(); e++)
-                            Mt.a[e] = S->band0[e] - sigma * (S->pencil ? S->bandB0[e] : ((e % size_t(Mt.b + 1)) == 0 ? 1.0 : 0.0));
+                        const int64_t bw = Mt.b + 1;
+                        const double* a0 = S->band0.data();
+                        const double* b0 = S->pencil ? S->bandB0.data() : nullptr;
+                        double* dst = Mt.a.data();
+                        parallel_ranges(n, n * bw >= (int64_t(1) << 22) ? ingest_threads() : 1, [=](int, int64_t r0, int64_t r1) {
+                            for (int64_t i = r0; i < r1; i++)
+                                for (int64_t d = 0; d < bw; d++)
+                                {
+                                    const int64_t e = i * bw + d;
+                                    dst[e] = a0[e] - sigma * (b0 ? b0[e] : (d == 0 ? 1.0 : 0.0));
+                                }
+                        });
                         Mt.view = nullptr;
                         Mt.view_dev = nullptr;
                         Mt.viewB = nullptr;
