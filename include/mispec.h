@@ -52,14 +52,15 @@ const char* mispec_version(void);
  *   one_reduction   1 (default) | 0                                      one reduction per one-sweep step
  *   orth_kernel     dma (default, >= 65536 rows) | dma2 | dmac | dmap | reg   the one-sweep pass: LDS-DMA ring or registers
  *   host_turn       fast (default) | copy                                restart's host turn: pinned-memory kernels or hipMemcpy
- *   small           host (default) | device                              where the ncv x ncv work of a restart runs
+ *   small           host (default) | host-serial | device                where the ncv x ncv work of a restart runs (host: the shifted
+ *                                                                        QR sweeps as a skewed pipeline; host-serial: in the reference's order, same bits)
  *   restart_sync    0 (default) | 1                                      synchronising fused restart
  *   host_steps      0 (default) | 1                                      host-synchronous steps
  *   spec_corr       corrections enqueued speculatively per step (reference flow)
  *   overlap, exchange                                                    sharded product: 0 switches the overlap / the neighbour exchange off
  *   csr_win, csr_win_iters, csr_win_pf, csr_win_nt, dia2, spmv_tiles, spmv_staged, reorder, kernel_probe   SpMV format / kernel choice
  *   vq              mfma: the f64-MFMA variant of V*Q
- *   shift           banded shift solve: level plan overrides (tests)
+ *   shift           banded shift solve: key=value list — kernel variants that must agree (tests) and profile=1 (set_shift's phases on stderr)
  * The reference has no counterpart (its only switches are template parameters). */
 int mispec_set_option(const char* name, const char* value);
 const char* mispec_get_option(const char* name);

@@ -52,7 +52,7 @@ OptionTable& option_table()
 const char* const kOptionNames[] = {
     "csr_win", "spmv_tiles", "reorder", "spmv_staged", "dia2", "csr_win_iters", "csr_win_pf", "csr_win_nt", "kernel_probe",
     "overlap", "exchange", "small", "spec_corr", "one_reduction", "host_steps", "orth", "restart_sync", "vq", "shift",
-    "reduce", "host_turn", "orth_kernel", "lag_grid", "vq_out_of_place", "shift_fuse", "staged_variant", nullptr};
+    "host_turn", "orth_kernel", nullptr};
 }  // namespace
 
 const char* option(const char* name)

@@ -86,27 +86,36 @@ struct ChunkStore
 {
     int64_t P = 1, R0 = 0, Rt = 0, groups = 0;  // groups: full-length groups, = ceil((P - 1) / 64)
     int b = 0;
+    // wide != 0 (round 6, half-bandwidths 9...64 solved by one WAVEFRONT per chunk, k_chunk_solve_wave): plain row-major
+    // storage, chunk p's row k at row p * R0 + k (the last chunk has Rt rows), a row's b entries contiguous
+    int wide = 0;
     __host__ __device__ int64_t row_base(int64_t p) const { return (p == P - 1 ? groups : (p >> 6)) * R0; }  // R0, Rt even
     __host__ __device__ int lane(int64_t p) const { return p == P - 1 ? 0 : int(p & 63); }
     // rows are stored in PAIRS: a lane's entries of rows 2j and 2j + 1 are adjacent, one 16-byte load (see k_chunk_solve_lds)
     __host__ __device__ size_t lf(int64_t p, int64_t k, int d) const
     {
+        if (wide)
+            return (size_t(p) * size_t(R0) + size_t(k)) * size_t(b) + size_t(d);
         return (size_t((row_base(p) + k) >> 1) * b + d) * 128 + size_t(lane(p)) * 2 + size_t(k & 1);
     }
     __host__ __device__ size_t dinv(int64_t p, int64_t k) const
     {
+        if (wide)
+            return size_t(p) * size_t(R0) + size_t(k);
         return size_t((row_base(p) + k) >> 1) * 128 + size_t(lane(p)) * 2 + size_t(k & 1);
     }
-    __host__ __device__ size_t rows() const { return size_t(groups) * R0 + Rt; }
-    __host__ __device__ size_t lf_size() const { return rows() * (b > 0 ? b : 1) * 64; }
-    __host__ __device__ size_t dinv_size() const { return rows() * 64; }
+    __host__ __device__ size_t rows() const { return size_t(wide ? P - 1 : groups) * R0 + Rt; }
+    // (wide: 192 rows of slack behind the last chunk — the wave kernel loads its coefficients two batches ahead without a clamp)
+    __host__ __device__ size_t lf_size() const { return (rows() + (wide ? 192 : 0)) * (b > 0 ? b : 1) * (wide ? 1 : 64); }
+    __host__ __device__ size_t dinv_size() const { return rows() * (wide ? 1 : 64); }
 };
 constexpr int kSweepBatch = 32;  // longest batch of the sweep kernels: the row padding of ChunkStore
-inline ChunkStore make_chunk_store(int64_t N, int b, int64_t L, int64_t P)
+inline ChunkStore make_chunk_store(int64_t N, int b, int64_t L, int64_t P, bool wide = false)
 {
     ChunkStore cs;
     cs.P = P;
     cs.b = b;
+    cs.wide = wide ? 1 : 0;
     cs.groups = (P - 1 + 63) / 64;
     const auto padded = [](int64_t m) { return (m + kSweepBatch - 1) / kSweepBatch * kSweepBatch + 16; };
     cs.R0 = P > 1 ? padded(L - b) : 0;
@@ -220,6 +229,211 @@ __global__ __launch_bounds__(kChunkThreads) void k_chunk_solve(int64_t N, int64_
                 hist[0] = acc;
                 yp[k0 - u] = acc;
             }
+        }
+    }
+}
+
+
+// ---- one WAVEFRONT per chunk: half-bandwidths 9...64 (round 6) --------------------------------------------------------------
+// One lane per chunk (k_chunk_solve above) leaves a level of wide-band chunks — 32 b rows each, P = N / (32 b) of them — with
+// P / 64 wavefronts on the whole device, each walking b products per row in sequence: 26 ms per solve at n = 1e6, b = 32.  Here a
+// wavefront owns ONE chunk and its lane l owns the rows r = l (mod 64).  Both sweeps run in scatter form: as soon as the unknown of
+// row k is final (lane k mod 64 holds it; every lane reads it with one v_readlane), every lane adds its product to the row it is
+// working on — forward: row r = k + d + 1 gets -L(r, d) z_k, backward: row r = k - d - 1 gets -L(k, d) y_k, d = the distance of the
+// lane's row —, and the lane that has just finished takes its next row (64 further on), whose start value it loaded a block ago.
+// A row thus receives its b products in exactly the order of k_chunk_solve's chain (forward: oldest unknown first, backward: the
+// farthest first; the start value f_k resp. z_k D_k^{-1} first, every step one fma): the same bits, and the critical path of a
+// step is readlane -> fma.  Coefficients come from the row-major layout (ChunkStore::wide), one coalesced piece of b doubles per
+// step: the backward sweep reads row k of L, the forward sweep row k of the SHIFTED copy LT(k, d) = L(k + d + 1, d) that
+// k_shift_factor builds on the device once per factorisation (reading L down its anti-diagonals instead — 64 different lines per
+// load — ran the first version into the L1: 0.4 us per step).  Modes as k_chunk_solve (0: solve, + u_out; 2: backward half only).
+constexpr int kWaveChunks = 4;  // chunks (wavefronts) per workgroup
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+// LT(k, d) = L(k + d + 1, d) for the interior rows of every chunk (zero where row k + d + 1 lies beyond the interior): the forward
+// sweep's coefficients, row-contiguous.  One thread per entry.
+__global__ __launch_bounds__(256) void k_shift_factor(int64_t N, int64_t L, ChunkStore cs, const double* __restrict__ Lf, double* __restrict__ LfT)
+{
+    const int64_t P = cs.P;
+    const int b = cs.b;
+    const int64_t p = blockIdx.y;
+    const int64_t m = (p == P - 1) ? N - (P - 1) * L : L - b;
+    const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (e >= m * b)
+        return;
+    const int64_t k = e / b;
+    const int d = int(e - k * b);
+    const int64_t r = k + d + 1;
+    LfT[cs.lf(p, k, d)] = (r < m) ? Lf[cs.lf(p, r, d)] : 0.0;
+}
+__global__ __launch_bounds__(64 * kWaveChunks) void k_chunk_solve_wave(int64_t N, int64_t L, ChunkStore cs, const double* __restrict__ Lf,
+                                                                      const double* __restrict__ LfT, const double* __restrict__ Dinv,
+                                                                      const double* __restrict__ f,
+                                                                      double* __restrict__ y, int mode, double* __restrict__ u_out)
+{
+    // The coefficients of a batch of U = 32 steps are loaded TWO batches ahead of their use into one of three register sets whose
+    // roles rotate (no copies: a copy would wait for the loads it moves): a step is ~50 cycles of readlane -> fma, an uncached
+    // load 1-2 us.  Everything that steers the loops is made wave-uniform explicitly (readfirstlane): with a per-lane `m` the
+    // compiler predicates every step on exec and waits for ALL outstanding loads in each (first version: 0.4 us per step).
+    constexpr int U = 32;
+    const int lane = threadIdx.x & 63;
+    const int64_t P = cs.P;
+    const int64_t p = int64_t(blockIdx.x) * kWaveChunks + __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+    if (p >= P)
+        return;
+    const int b = cs.b;
+    const int m = __builtin_amdgcn_readfirstlane(int(p == P - 1 ? N - (P - 1) * L : L - b));  // interior rows of this chunk
+    if (m <= 0)
+        return;
+    const double* const fp = f + p * L;
+    double* const yp = y + p * L;
+    double* const up = u_out ? u_out + p * L : nullptr;
+    const double* const lf = Lf + cs.lf(p, 0, 0);    // L(k, d) = lf[k * b + d]: what y_k contributes to row k - d - 1 (backward)
+    const double* const lft = LfT + cs.lf(p, 0, 0);  // L(k + d + 1, d) = lft[k * b + d]: what z_k contributes to row k + d + 1 (forward)
+    const double* const dv = Dinv + cs.dinv(p, 0);  // 1 / D_k
+    const int nblk = (m + 63) >> 6;
+    const int nbat = 2 * nblk;  // batches of 32 steps: two per 64-row block
+    double c0[U], c1[U], c2[U];
+
+    if (mode != 2)
+    {
+        // ---- forward: z_k = f_k - sum_d L(k, d) z_{k-d-1}; lane l works on row blk * 64 + l, then on the next block's ----
+        double A = (lane < m) ? fp[lane] : 0.0;
+        double fnext = (64 + lane < m) ? fp[64 + lane] : 0.0;  // start values of the rows of the next block
+        double f2 = 0.0, zbuf = 0.0;
+        // the coefficients of the batch that starts at step kb: what z_k contributes to this lane's row k + d + 1.  Unconditional
+        // loads at 32-bit offsets from one base per batch (rows beyond the chunk are the next chunk's or the slack behind the
+        // last: valid memory, masked to 0) — no branch, no 64-bit multiply per load
+        const auto load_batch = [&](double (&tgt)[U], int kb) {
+            const double* const rowp = lft + int64_t(kb) * b;
+            const int d0 = (lane - kb - 1) & 63;
+#pragma unroll
+            for (int u = 0; u < U; u++)
+            {
+                const int d = (d0 - u) & 63;
+                tgt[u] = rowp[u * b + (d < b ? d : b - 1)];  // raw: masked where it is USED (a select here would wait for the load at once)
+            }
+        };
+        // batch `bat` with the coefficients in `cur`; the loads of batch bat + 2 go to `tgt`
+        const auto batch = [&](int bat, const double (&cur)[U], double (&tgt)[U]) {
+            if (bat >= nbat)
+                return;
+            const int k0 = bat * U;
+            const int blk = bat >> 1;
+            if ((bat & 1) == 0)
+                f2 = (int64_t(blk + 2) * 64 + lane < m) ? fp[(blk + 2) * 64 + lane] : 0.0;  // two blocks ahead
+            load_batch(tgt, k0 + 2 * U);
+            const int kk0 = k0 & 63;  // 0 or 32
+#pragma unroll
+            for (int u = 0; u < U; u++)
+            {
+                // (no branch inside a batch — straight-line code lets the compiler count the loads in flight; a step beyond
+                // the last row is harmless: its rows start from 0 and every coefficient there is 0)
+                const double z = readlane_f64(A, kk0 + u);
+                if (lane == kk0 + u)
+                {
+                    zbuf = z;
+                    A = fnext;  // this lane's next row: k + 64
+                }
+                const int d = (lane - kk0 - u - 1) & 63;
+                const double c = ((k0 + u < m) & (d < b)) ? cur[u] : 0.0;
+                A = fma(-c, z, A);
+            }
+            if (bat & 1)
+            {
+                const int64_t r = int64_t(blk) * 64 + lane;
+                if (r < m)
+                {
+                    yp[r] = zbuf;
+                    if (up)
+                        up[r] = zbuf * sqrt(fabs(dv[r]));
+                }
+                fnext = f2;
+            }
+        };
+        load_batch(c0, 0);
+        load_batch(c1, U);
+        for (int bat = 0; bat < nbat; bat += 3)
+        {
+            batch(bat, c0, c2);
+            batch(bat + 1, c1, c0);
+            batch(bat + 2, c2, c1);
+        }
+    }
+    // ---- diagonal and backward: y_k = z_k / D_k - sum_d L(k+d+1, d) y_{k+d+1}  (mode 2: z_k |D_k|^{-1/2} from f instead) ----
+    {
+        const auto start = [&](int64_t r) -> double {  // start value of row r (the wavefront's own writes above are visible to it)
+            if (r < 0 || r >= m)
+                return 0.0;
+            return (mode == 2) ? __dmul_rn(fp[r], sqrt(fabs(dv[r]))) : __dmul_rn(yp[r], dv[r]);
+        };
+        const int top = nblk - 1;
+        // lanes beyond the last row of the top block start in the block below (they finish no row while the top block is swept)
+        double A = (int64_t(top) * 64 + lane < m) ? start(int64_t(top) * 64 + lane) : start(int64_t(top - 1) * 64 + lane);
+        double snext = start(int64_t(top - 1) * 64 + lane);  // what a lane takes when it finishes its row of the block being swept
+        double s2a = 0.0, s2b = 0.0, ybuf = 0.0;  // raw operands of the start values two blocks down (combined when they are taken)
+        int64_t s2r = -1;
+        // the coefficients of batch bt (steps k = bt * 32 + 31 - u): what y_k contributes to this lane's row k - d - 1
+        const auto load_batch = [&](double (&tgt)[U], int bt) {
+            const int kb = (bt > 0 ? bt : 0) * U;  // (a batch below the first: loads of batch 0, masked)
+            const double* const rowp = lf + int64_t(kb) * b;
+            const int e0 = ((kb + U - 1) & 63) - lane - 1;
+#pragma unroll
+            for (int u = 0; u < U; u++)
+            {
+                const int d = (e0 - u) & 63;
+                tgt[u] = rowp[(U - 1 - u) * b + (d < b ? d : b - 1)];  // raw: masked where it is used
+            }
+        };
+        // batch `bat` (descending from nbat - 1): steps k = bat * 32 + 31 - u
+        const auto batch = [&](int bat, const double (&cur)[U], double (&tgt)[U]) {
+            if (bat < 0)
+                return;
+            const int blk = bat >> 1;
+            if (bat & 1)
+            {
+                // loaded a block ahead of their use, RAW (arithmetic on them here would wait for every load in flight)
+                s2r = int64_t(blk - 2) * 64 + lane;
+                const int64_t rc = (s2r >= 0 && s2r < m) ? s2r : 0;
+                s2a = (mode == 2) ? fp[rc] : yp[rc];
+                s2b = dv[rc];
+            }
+            load_batch(tgt, bat - 2);
+            const int kk1 = (bat * U + U - 1) & 63;  // 63 or 31
+#pragma unroll
+            for (int u = 0; u < U; u++)
+            {
+                // (no branch: see above; a step above the last row must not finish a lane's row — `live` —, its coefficient is 0)
+                const bool live = bat * U + U - 1 - u < m;
+                const double yk = readlane_f64(A, kk1 - u);
+                if ((lane == kk1 - u) & live)
+                {
+                    ybuf = yk;
+                    A = snext;  // this lane's next row: k - 64
+                }
+                const int d = (kk1 - u - lane - 1) & 63;
+                const double c = (live & (d < b)) ? cur[u] : 0.0;
+                A = fma(-c, yk, A);
+            }
+            if ((bat & 1) == 0)
+            {
+                const int64_t r = int64_t(blk) * 64 + lane;
+                if (r < m)
+                    yp[r] = ybuf;
+                snext = (s2r >= 0 && s2r < m) ? ((mode == 2) ? __dmul_rn(s2a, sqrt(fabs(s2b))) : __dmul_rn(s2a, s2b)) : 0.0;
+            }
+        };
+        load_batch(c0, nbat - 1);
+        load_batch(c1, nbat - 2);
+        for (int bat = nbat - 1; bat >= 0; bat -= 3)
+        {
+            batch(bat, c0, c2);
+            batch(bat - 1, c1, c0);
+            batch(bat - 2, c2, c1);
         }
     }
 }
@@ -551,6 +765,7 @@ void launch_sep_rhs(hipStream_t stream, int64_t N, int b, int64_t L, int64_t P, 
 // access is a coalesced line.  (The first version — one thread per row over a row-major W, chunk number by a 64-bit division —
 // ran at 3.6 TB/s.)
 constexpr int kBackThreads = 128;
+constexpr int64_t kBackPiece = 2048;  // rows per workgroup
 __global__ __launch_bounds__(kBackThreads) void k_back_subst(int64_t N, int b, int64_t L, int64_t P, const double* __restrict__ W,
                                                              const double* __restrict__ y, const double* __restrict__ xs,
                                                              double* __restrict__ x)
@@ -561,7 +776,11 @@ __global__ __launch_bounds__(kBackThreads) void k_back_subst(int64_t N, int b, i
     const int64_t sep0 = (p == P - 1) ? N : row0 + L - b;
     const double* const xprev = xs + (p - 1) * b;  // p > 0
     const double* const xnext = xs + p * b;        // p < P - 1
-    for (int64_t r = row0 + threadIdx.x; r < end; r += kBackThreads)
+    // blockIdx.y: pieces of kBackPiece rows of a long chunk (wide bands: up to 31250 rows in at most 32 chunks — one workgroup per
+    // chunk streamed its 2b columns of W through 128 threads: 12 ms at n = 1e6, b = 64)
+    const int64_t piece0 = row0 + int64_t(blockIdx.y) * kBackPiece;
+    const int64_t piece1 = (piece0 + kBackPiece < end) ? piece0 + kBackPiece : end;
+    for (int64_t r = piece0 + threadIdx.x; r < piece1; r += kBackThreads)
     {
         if (r >= sep0)
         {
@@ -569,12 +788,27 @@ __global__ __launch_bounds__(kBackThreads) void k_back_subst(int64_t N, int b, i
             continue;
         }
         double acc = y[r];
+        // eight columns of W in flight per thread (a plain loop over the columns waits for every load in turn: 0.8 ms for the
+        // 512 MB of W at n = 1e6, b = 32); the products enter in column order as before
+        const auto side = [&](const double* Wc, const double* xv) {
+            int c = 0;
+            for (; c + 8 <= b; c += 8)
+            {
+                double w[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    w[i] = Wc[int64_t(c + i) * N];
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    acc -= w[i] * xv[c + i];
+            }
+            for (; c < b; c++)
+                acc -= Wc[int64_t(c) * N] * xv[c];
+        };
         if (p > 0)
-            for (int c = 0; c < b; c++)
-                acc -= W[int64_t(c) * N + r] * xprev[c];
+            side(W + r, xprev);
         if (p < P - 1)
-            for (int c = 0; c < b; c++)
-                acc -= W[int64_t(b + c) * N + r] * xnext[c];
+            side(W + int64_t(b) * N + r, xnext);
         x[r] = acc;
     }
 }
@@ -994,6 +1228,7 @@ struct mispec::BandLevel
     int b = 0;
     ChunkStore cs;  // layout of Lf / Dinv
     DevBuf<double> Lf, Dinv, W, band, y, g, xs;
+    DevBuf<double> LfT;  // wide levels (cs.wide): LT(k, d) = L(k + d + 1, d), the forward sweep's coefficients (k_shift_factor)
     DevBuf<double> inv;  // last level only: explicit inverse (N x N), applied by a dense GEMV
     DevBuf<double> binv;  // partitioned level with few chunks: explicit inverses of the interiors, P blocks of binv_ld x binv_ld
     int64_t binv_ld = 0;
@@ -1168,7 +1403,11 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
 
     const bool on_device = factored_on_device(N, b);
     MISPEC_REQUIRE(on_device || !M.view, "internal: a band view is only valid for a level factored on the device");
-    const ChunkStore cs = make_chunk_store(N, b, L, P);
+    // host-factored levels of half-bandwidth 9...64 whose interiors get no explicit inverse: the row-major layout of the
+    // wave-per-chunk solve (option shift=wave=0: the lane-per-chunk kernels of rounds 4-5 on the interleaved layout)
+    const bool wide = !on_device && b > 8 && P > 1 && shift_option("wave", 1) != 0 &&
+                      !(!stats.want_cholesky && wants_block_inverse(P, mmax, b));
+    const ChunkStore cs = make_chunk_store(N, b, L, P, wide);
     lev.cs = cs;
     const size_t lf_size = cs.lf_size(), dinv_size = cs.dinv_size(), w_size = size_t(N) * 2 * std::max(b, 1);
     // host images of the factor (host path only).  Hundreds of MB at the top level of a wide band (W: 512 MB at n = 1e6, b = 32):
@@ -1512,6 +1751,15 @@ void factor_level(mispec_ctx* ctx, HostBand& M, BandLevel& lev, FactorStats& sta
     {
         up(lev.Lf, Lf.p.get(), Lf.n);
         up(lev.Dinv, Dinv.p.get(), Dinv.n);
+        if (cs.wide)
+        {
+            lev.LfT.alloc(std::max<size_t>(Lf.n, 1));
+            MISPEC_HIP(hipMemsetAsync(lev.LfT.p, 0, lev.LfT.n * sizeof(double), ctx->stream));  // (the padding rows of the layout)
+            const int64_t per_chunk = std::max<int64_t>(L - b, N - (P - 1) * L) * b;
+            hipLaunchKernelGGL(k_shift_factor, dim3(unsigned((per_chunk + 255) / 256), unsigned(P)), dim3(256), 0, ctx->stream, N, L, cs,
+                               lev.Lf.p, lev.LfT.p);
+            MISPEC_HIP(hipGetLastError());
+        }
     }
     lev.y.alloc(size_t(N));
     if (P > 1)
@@ -1562,6 +1810,13 @@ void launch_chunk_solve(const mispec_ctx& ctx, const BandLevel& lev, dim3 grid_u
                         double* u_out = nullptr)
 {
     (void) grid_unused;
+    if (lev.cs.wide)  // half-bandwidth 9...64 on the row-major layout: one wavefront per chunk
+    {
+        hipLaunchKernelGGL(k_chunk_solve_wave, dim3(unsigned((lev.P + kWaveChunks - 1) / kWaveChunks)), dim3(64 * kWaveChunks), 0, ctx.stream,
+                           lev.N, lev.L, lev.cs, lev.Lf.p, lev.LfT.p, lev.Dinv.p, f, y, mode, u_out);
+        MISPEC_HIP(hipGetLastError());
+        return;
+    }
     const int lanes = solve_lanes(lev.P);
     const dim3 grid(unsigned((lev.P - 1 + lanes - 1) / lanes) + 1);  // + the last chunk's own workgroup
     const bool chol = mode != 0 || u_out != nullptr;
@@ -1651,8 +1906,11 @@ void solve_level(const mispec_ctx& ctx, const BandLevel& lev, const double* f, d
     launch_sep_rhs(ctx.stream, lev.N, lev.b, lev.L, lev.P, lev.band.p, f, lev.y.p, lev.g.p);
     MISPEC_HIP(hipGetLastError());
     solve_level(ctx, *lev.next, lev.g.p, lev.xs.p);
-    hipLaunchKernelGGL(k_back_subst, dim3(unsigned(lev.P)), dim3(kBackThreads), 0, ctx.stream, lev.N, lev.b, lev.L, lev.P, lev.W.p, lev.y.p,
-                       lev.xs.p, x);
+    {
+        const int64_t longest = std::max<int64_t>(lev.L, lev.N - (lev.P - 1) * lev.L);
+        hipLaunchKernelGGL(k_back_subst, dim3(unsigned(lev.P), unsigned((longest + kBackPiece - 1) / kBackPiece)), dim3(kBackThreads), 0,
+                           ctx.stream, lev.N, lev.b, lev.L, lev.P, lev.W.p, lev.y.p, lev.xs.p, x);
+    }
     MISPEC_HIP(hipGetLastError());
 }
 
@@ -1705,7 +1963,11 @@ void chol_backward(const mispec_ctx& ctx, const BandLevel& lev, const double* u,
     MISPEC_HIP(hipGetLastError());
     chol_backward(ctx, *lev.next, lev.g.p, lev.xs.p);
     launch_chunk_solve(ctx, lev, dim3(unsigned((lev.P + kChunkThreads - 1) / kChunkThreads)), u, lev.y.p, 2, nullptr);
-    hipLaunchKernelGGL(k_back_subst, dim3(unsigned(lev.P)), dim3(kBackThreads), 0, ctx.stream, lev.N, lev.b, lev.L, lev.P, lev.W.p, lev.y.p, lev.xs.p, x);
+    {
+        const int64_t longest = std::max<int64_t>(lev.L, lev.N - (lev.P - 1) * lev.L);
+        hipLaunchKernelGGL(k_back_subst, dim3(unsigned(lev.P), unsigned((longest + kBackPiece - 1) / kBackPiece)), dim3(kBackThreads), 0,
+                           ctx.stream, lev.N, lev.b, lev.L, lev.P, lev.W.p, lev.y.p, lev.xs.p, x);
+    }
     MISPEC_HIP(hipGetLastError());
 }
 

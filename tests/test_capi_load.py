@@ -88,3 +88,29 @@ def test_python_mirror_enums_match_cpp():
     assert names == [r.name for r in sa.SortRule]
     import oracle
     assert [getattr(oracle, r.name) for r in sa.SortRule] == [int(r) for r in sa.SortRule]
+
+
+def test_options_replace_the_environment_switches():
+    # mispec_set_option / mispec_get_option (round 6): one reader for every switch; an unknown name is refused, so that a typo
+    # cannot pass for a measurement; a name that has not been set falls back to MISPEC_<NAME> (the tests' override)
+    assert sa.get_option("orth_kernel") in (None, os.environ.get("MISPEC_ORTH_KERNEL"))
+    try:
+        sa.set_option("orth_kernel", "reg")
+        assert sa.get_option("orth_kernel") == "reg"
+        sa.set_option("orth_kernel", "dma")
+        assert sa.get_option("orth_kernel") == "dma"
+    finally:
+        sa.set_option("orth_kernel", None)
+    assert sa.get_option("orth_kernel") in (None, os.environ.get("MISPEC_ORTH_KERNEL"))
+    with pytest.raises(ValueError):
+        sa.set_option("orth_kernal", "dma")
+    with pytest.raises(ValueError):
+        sa.set_option("vq_out_of_place", "1")  # (a name registered in round 6's first session and never read: removed)
+    os.environ["MISPEC_SPEC_CORR"] = "3"
+    try:
+        assert sa.get_option("spec_corr") == "3"
+        sa.set_option("spec_corr", "1")
+        assert sa.get_option("spec_corr") == "1"
+    finally:
+        sa.set_option("spec_corr", None)
+        del os.environ["MISPEC_SPEC_CORR"]

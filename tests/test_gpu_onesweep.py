@@ -402,3 +402,27 @@ def test_onesweep_on_wide_bases(ctx, n, k, m, rule):
         assert o.compute(getattr(O, rule), 1000, 1e-11) == k
         assert np.abs(np.sort(o.eigenvalues()) - np.sort(evals)).max() < 1e-9
         assert abs(o.num_operations() - one.num_operations()) <= (m - k)
+
+
+@pytest.mark.parametrize("n,k,m", [(1000, 6, 20), (40_003, 10, 37), (131_075, 20, 40), (200_000, 20, 63)])
+def test_the_lds_dma_pass_equals_the_register_pass(ctx, n, k, m):
+    # Round 6: the one-sweep pass has two kernels — k_orth_lagged (registers) and k_orth_lagged_dma (the basis through an LDS ring
+    # by LDS-DMA loads, csrc/orth_dma.hip; the default from 131072 rows on).  Same expressions per element, partial sums grouped
+    # by 256 instead of 1024 workgroups: the same solve to rounding — equal counters, eigenvalues to 1e-13 — at sizes on both
+    # sides of the switch, ragged tails (n not a multiple of the 128-row tile), 1...63 columns, both ring depths.
+    op = sa.SparseSymMatProd.synth_band(n, ctx=ctx)
+    runs = {}
+    try:
+        for kernel in ("reg", "dma", "dma2"):
+            sa.set_option("orth_kernel", kernel)
+            e, nconv = solve(op, k, m, sa.SortRule.LargestMagn, "onesweep", maxit=1000, tol=1e-11)
+            assert nconv == k and e.residuals().max() <= 1e-10
+            runs[kernel] = (e.eigenvalues(), e.num_operations(), e.num_iterations(), e.orth_info()["lagged_steps"])
+    finally:
+        sa.set_option("orth_kernel", None)
+    ref = runs["reg"]
+    for kernel in ("dma", "dma2"):
+        ev, nops, nit, lagged = runs[kernel]
+        assert (nops, nit) == ref[1:3], (kernel, nops, nit, ref[1:3])
+        assert np.abs(ev - ref[0]).max() <= 1e-13 * np.abs(ref[0]).max()
+        assert lagged == ref[3]

@@ -389,3 +389,17 @@ def test_solve_kernel_variants_agree():
         tol = 1e-10 if case[3] else 1e-12   # interior shift: the matrix is indefinite and worse conditioned
         assert float(res_a) <= tol and float(res_b) <= tol, (case, res_a, res_b)
         assert int(steps_a) <= 3 and int(steps_b) <= 3, (case, steps_a, steps_b)   # calibrated separately (+ one safety step when pivots were boosted)
+
+
+def test_wave_per_chunk_solve_equals_the_lane_per_chunk_solve_bit_for_bit():
+    # Round 6: levels of half-bandwidth 9...64 are solved by one WAVEFRONT per chunk on a row-major factor (k_chunk_solve_wave:
+    # scatter-form sweeps, every row receives its products in the chain order of k_chunk_solve) — against the lane-per-chunk
+    # kernels of rounds 4-5 on the interleaved layout (MISPEC_SHIFT=wave=0): the SAME BITS, whatever the width, the chunk
+    # length (32 b rows, the last chunk longer), definite or with an interior shift (refinement on top of both).
+    cases = [(20_011, 9, 0.0, 0), (60_000, 12, -0.5, 0), (100_003, 17, 0.0, 0), (100_000, 32, 0.0, 0), (70_001, 40, 0.0, 0),
+             (150_000, 64, -1.0, 0), (120_000, 16, 0.3, 1)]
+    wave = _solve_in_subprocess({}, cases)
+    lane = _solve_in_subprocess({"MISPEC_SHIFT": "wave=0"}, cases)
+    assert [w[0] for w in wave] == [l[0] for l in lane], (wave, lane)
+    for (crc, res, steps), case in zip(wave, cases):
+        assert float(res) <= (1e-10 if case[3] else 1e-12), (case, res)

@@ -31,15 +31,18 @@ def main():
     wall = rows[-1][1] - rows[0][0]
     print(f"kernels {len(rows)}  busy {busy / 1e6:.1f} ms  wall {wall / 1e6:.1f} ms  idle {(wall - busy) / 1e6:.1f} ms "
           f"({100.0 * (wall - busy) / wall:.1f} %)")
-    pairs = defaultdict(lambda: [0, 0])
+    pairs = defaultdict(lambda: [0, 0, []])
     for (s0, e0, n0), (s1, e1, n1) in zip(rows, rows[1:]):
         g = max(0, s1 - e0)
         p = pairs[(n0, n1)]
         p[0] += 1
         p[1] += g
-    print(f"{'previous -> next':92s} {'count':>7s} {'mean_us':>9s} {'total_ms':>9s}")
-    for (a, b), (c, t) in sorted(pairs.items(), key=lambda kv: -kv[1][1])[:25]:
-        print(f"{a + ' -> ' + b:92s} {c:7d} {t / c / 1e3:9.2f} {t / 1e6:9.2f}")
+        p[2].append(g)
+    print(f"{'previous -> next':92s} {'count':>7s} {'mean_us':>9s} {'total_ms':>9s} {'median':>8s} {'p90':>8s} {'max_us':>9s}")
+    for (a, b), (c, t, gs) in sorted(pairs.items(), key=lambda kv: -kv[1][1])[:25]:
+        gs.sort()
+        print(f"{a + ' -> ' + b:92s} {c:7d} {t / c / 1e3:9.2f} {t / 1e6:9.2f} {gs[len(gs) // 2] / 1e3:8.2f} {gs[(9 * len(gs)) // 10] / 1e3:8.2f} "
+              f"{gs[-1] / 1e3:9.2f}")
 
 
 if __name__ == "__main__":
