@@ -2,8 +2,8 @@
 // y = L^{-1} x and y = L^{-T} x (reference: MatOp/SparseCholesky.h:36-128 — same members: rows(), cols(), info(),
 // lower_triangular_solve(), upper_triangular_solve()).
 // The reference factors with Eigen::SimplicialLLT (sparse, fill-reducing permutation).  Here, for n <= 4096 the factor is
-// dense and kept, inverted, in HBM (spectra_amd/csrc/cholesky.hip); for larger n B must be banded (half-bandwidth <= 8:
-// mass / stiffness matrices of structured problems) and the factor is the one of the partitioned band factorisation
+// dense and kept, inverted, in HBM (spectra_amd/csrc/cholesky.hip); for larger n B must be banded (half-bandwidth <= 64 since
+// round 6, <= 8 before: mass / stiffness matrices of structured problems) and the factor is the one of the partitioned band factorisation
 // (shiftsolve.hip) applied in two halves on the device.  Any G with G G' = B yields the same eigenpairs; other large
 // sparse B are served by the regular-inverse mode (the constructor throws std::invalid_argument for them).
 #ifndef MISPEC_SPECTRA_SPARSE_CHOLESKY_H

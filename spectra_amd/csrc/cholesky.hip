@@ -4,7 +4,7 @@
 // (SymGEigsSolver.h:142-208, MatOp/internal/SymGEigsCholeskyOp.h:63-71).  Any factor G with G G' = B gives the
 // same eigenpairs; here G = L is the dense Cholesky factor (no fill-reducing permutation), computed once on the
 // host, and the two triangular solves are dense GEMVs with the explicit L^{-1} / L^{-T} held in HBM (n <= 4096).
-// Larger B must be BANDED (half-bandwidth <= 8, the usual mass / stiffness matrices of 1-D and structured problems): the
+// Larger B must be BANDED (half-bandwidth <= 64; <= 8 — the usual mass / stiffness matrices of 1-D and structured problems — until round 6): the
 // factor is then the one of the partitioned band factorisation of shiftsolve.hip in its nested order (chunk interiors, then
 // separators, recursively) — G = [L_II D^{1/2} 0; M_SI L_II^{-T} D^{-1/2} G_S] — and G^{-1} x / G^{-T} x are the two halves of
 // the band solve, on the device (launch_band_cholesky_solve).  Other large patterns: regular-inverse mode (conjugate gradient).
@@ -47,10 +47,11 @@ extern "C" int mispec_cholesky_create(mispec_ctx* ctx, int64_t n, const int32_t*
             if (mispec_symshift_create(ctx, n, outer, inner, val, uplo, row_major, &S) != MISPEC_OK)
                 throw Error(MISPEC_EINVAL, mispec_last_error());
             C->band = S;
-            // the triangular halves of the band factorisation are exercised for narrow bands only (the shift solve itself takes up to 64)
-            MISPEC_REQUIRE(S->half_bandwidth <= kNarrowBandwidth,
-                           "SparseCholesky: for n > 4096 the matrix must be banded (half-bandwidth <= 8); use the regular-inverse mode "
-                           "for other large B");
+            // (rounds 2-5: half-bandwidth <= 8 only; round 6: the triangular halves run on the wave-per-chunk solve of the wide
+            // bands too — k_chunk_solve_wave modes 0 + u_out and 2 —, tested up to 64)
+            MISPEC_REQUIRE(S->half_bandwidth <= kMaxBandwidth,
+                           "SparseCholesky: for n > 4096 the matrix must be banded (half-bandwidth <= 64, as given or after a reverse "
+                           "Cuthill-McKee ordering); use the regular-inverse mode for other large B");
             S->want_cholesky = true;
             const int rc = mispec_symshift_set_shift(S, 0.0);
             C->info = (rc == MISPEC_OK && S->cholesky_ready) ? 0 : 3;  // CompInfo::NumericalIssue: B is not positive definite

@@ -156,7 +156,8 @@ def banded_pd(n, b, seed):
     return sp.diags([rng.uniform(0.0, 1.0, n) + b + 0.5] + diags + diags, [0] + list(range(1, b + 1)) + [-d for d in range(1, b + 1)], format="csc")
 
 
-@pytest.mark.parametrize("n,b", [(5000, 1), (20_000, 3), (300_001, 2), (1_000_000, 4)])
+# (half-bandwidths above 8: the Cholesky halves of the wave-per-chunk solve, k_chunk_solve_wave modes 0 + u_out and 2 — round 6)
+@pytest.mark.parametrize("n,b", [(5000, 1), (20_000, 3), (300_001, 2), (1_000_000, 4), (60_007, 12), (100_000, 32), (70_000, 64)])
 def test_banded_cholesky_beyond_the_dense_limit(ctx, n, b):
     # SparseCholesky for n > 4096: a banded B is factored by the partitioned band factorisation;
     # lower_triangular_solve / upper_triangular_solve are G^{-1} x and G^{-T} x of a factor with G G' = B (any such factor
