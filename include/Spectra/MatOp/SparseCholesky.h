@@ -27,7 +27,6 @@ public:
 
 private:
     static_assert(std::is_same<Scalar_, double>::value, "the MI355X path computes in fp64: Scalar must be double");
-    static_assert(std::is_same<StorageIndex, int>::value, "sparse indices are int32 on the device");
     internal::CtxPtr m_ctx;
     std::shared_ptr<mispec_cholesky> m_chol;
 
@@ -39,8 +38,10 @@ private:
             throw std::invalid_argument(
                 "SparseCholesky: the \"Flags\" template parameter does not match the input matrix (ColMajor/RowMajor)");
         mispec_cholesky* raw = nullptr;
-        internal::check(
-            mispec_cholesky_create(m_ctx.get(), B.rows, B.outer, B.inner, B.values, Uplo == Lower ? 'L' : 'U', B.row_major ? 1 : 0, &raw));
+        const std::size_t nnz = static_cast<std::size_t>(B.outer[B.rows]);
+        const internal::Int32Indices<StorageIndex> outer(B.outer, static_cast<std::size_t>(B.rows) + 1), inner(B.inner, nnz);
+        internal::check(mispec_cholesky_create(m_ctx.get(), B.rows, outer.data(), inner.data(), B.values, Uplo == Lower ? 'L' : 'U',
+                                               B.row_major ? 1 : 0, &raw));
         m_chol = std::shared_ptr<mispec_cholesky>(raw, [](mispec_cholesky* p) { (void) mispec_cholesky_destroy(p); });
     }
 

@@ -22,7 +22,6 @@ public:
 
 private:
     static_assert(internal::is_device_scalar<Scalar_>::value, "Scalar must be double (or float, widened: the MI355X path computes in fp64)");
-    static_assert(std::is_same<StorageIndex, int>::value, "sparse indices are int32 on the device");
     using Matrix = DenseMatrix<Scalar>;
 
     internal::CtxPtr m_ctx;
@@ -34,11 +33,14 @@ private:
             throw std::invalid_argument(
                 "SparseGenMatProd: the \"Flags\" template parameter does not match the input matrix (ColMajor/RowMajor)");
         mispec_csr* raw = nullptr;
-        const internal::WidenedIn<Scalar> values(A.values, static_cast<std::size_t>(A.outer[A.row_major ? A.rows : A.cols]));
+        const std::size_t nouter = static_cast<std::size_t>(A.row_major ? A.rows : A.cols);
+        const std::size_t nnz = static_cast<std::size_t>(A.outer[nouter]);
+        const internal::WidenedIn<Scalar> values(A.values, nnz);
+        const internal::Int32Indices<StorageIndex> outer(A.outer, nouter + 1), inner(A.inner, nnz);  // any StorageIndex (reference: :22)
         if (A.row_major)
-            internal::check(mispec_csr_upload(m_ctx.get(), A.rows, A.cols, A.outer, A.inner, values.data(), &raw));
+            internal::check(mispec_csr_upload(m_ctx.get(), A.rows, A.cols, outer.data(), inner.data(), values.data(), &raw));
         else
-            internal::check(mispec_csr_from_csc(m_ctx.get(), A.rows, A.cols, A.outer, A.inner, values.data(), &raw));
+            internal::check(mispec_csr_from_csc(m_ctx.get(), A.rows, A.cols, outer.data(), inner.data(), values.data(), &raw));
         m_mat = std::shared_ptr<mispec_csr>(raw, [](mispec_csr* p) { (void) mispec_csr_destroy(p); });
     }
 

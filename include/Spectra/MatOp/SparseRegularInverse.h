@@ -28,7 +28,6 @@ public:
 
 private:
     static_assert(std::is_same<Scalar_, double>::value, "the MI355X path computes in fp64: Scalar must be double");
-    static_assert(std::is_same<StorageIndex, int>::value, "sparse indices are int32 on the device");
     internal::CtxPtr m_ctx;
     std::shared_ptr<mispec_reginv> m_B;
     mutable CompInfo m_info = CompInfo::Successful;
@@ -42,7 +41,8 @@ private:
                 "SparseRegularInverse: the \"Flags\" template parameter does not match the input matrix (ColMajor/RowMajor)");
         mispec_reginv* raw = nullptr;
         internal::check(
-            mispec_reginv_create(m_ctx.get(), B.rows, B.outer, B.inner, B.values, Uplo == Lower ? 'L' : 'U', B.row_major ? 1 : 0, &raw));
+            mispec_reginv_create(m_ctx.get(), B.rows, internal::Int32Indices<StorageIndex>(B.outer, static_cast<std::size_t>(B.rows) + 1).data(),
+                                 internal::Int32Indices<StorageIndex>(B.inner, static_cast<std::size_t>(B.outer[B.rows])).data(), B.values, Uplo == Lower ? 'L' : 'U', B.row_major ? 1 : 0, &raw));
         m_B = std::shared_ptr<mispec_reginv>(raw, [](mispec_reginv* p) { (void) mispec_reginv_destroy(p); });
     }
 

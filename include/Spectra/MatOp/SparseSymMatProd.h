@@ -30,7 +30,6 @@ public:
 
 private:
     static_assert(internal::is_device_scalar<Scalar_>::value, "Scalar must be double (or float, widened: the MI355X path computes in fp64)");
-    static_assert(std::is_same<StorageIndex, int>::value, "sparse indices are int32 on the device");
     static_assert(Uplo == Lower || Uplo == Upper, "Uplo must be Lower or Upper");
     using Matrix = DenseMatrix<Scalar>;
 
@@ -45,8 +44,11 @@ private:
             throw std::invalid_argument(
                 "SparseSymMatProd: the \"Flags\" template parameter does not match the input matrix (ColMajor/RowMajor)");
         mispec_csr* raw = nullptr;
-        const internal::WidenedIn<Scalar> values(A.values, static_cast<std::size_t>(A.outer[A.rows]));
-        internal::check(mispec_csr_from_triangle(m_ctx.get(), A.rows, A.outer, A.inner, values.data(), Uplo == Lower ? 'L' : 'U',
+        const std::size_t nnz = static_cast<std::size_t>(A.outer[A.rows]);
+        const internal::WidenedIn<Scalar> values(A.values, nnz);
+        // (any StorageIndex, as the reference's SparseSymMatProd.h:30: narrowed to the device's int32 where it is not int)
+        const internal::Int32Indices<StorageIndex> outer(A.outer, static_cast<std::size_t>(A.rows) + 1), inner(A.inner, nnz);
+        internal::check(mispec_csr_from_triangle(m_ctx.get(), A.rows, outer.data(), inner.data(), values.data(), Uplo == Lower ? 'L' : 'U',
                                                  A.row_major ? 1 : 0, &raw));
         m_mat = std::shared_ptr<mispec_csr>(raw, [](mispec_csr* p) { (void) mispec_csr_destroy(p); });
     }

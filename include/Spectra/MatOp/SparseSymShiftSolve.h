@@ -25,7 +25,6 @@ public:
 
 private:
     static_assert(std::is_same<Scalar_, double>::value, "the MI355X path computes in fp64: Scalar must be double");
-    static_assert(std::is_same<StorageIndex, int>::value, "sparse indices are int32 on the device");
     internal::CtxPtr m_ctx;
     std::shared_ptr<mispec_symshift> m_solver;
 
@@ -37,7 +36,9 @@ private:
             throw std::invalid_argument(
                 "SparseSymShiftSolve: the \"Flags\" template parameter does not match the input matrix (ColMajor/RowMajor)");
         mispec_symshift* raw = nullptr;
-        internal::check(mispec_symshift_create(m_ctx.get(), A.rows, A.outer, A.inner, A.values, Uplo == Lower ? 'L' : 'U',
+        const std::size_t nnz = static_cast<std::size_t>(A.outer[A.rows]);
+        const internal::Int32Indices<StorageIndex> outer(A.outer, static_cast<std::size_t>(A.rows) + 1), inner(A.inner, nnz);
+        internal::check(mispec_symshift_create(m_ctx.get(), A.rows, outer.data(), inner.data(), A.values, Uplo == Lower ? 'L' : 'U',
                                                A.row_major ? 1 : 0, &raw));
         m_solver = std::shared_ptr<mispec_symshift>(raw, [](mispec_symshift* p) { (void) mispec_symshift_destroy(p); });
     }

@@ -9,6 +9,8 @@
 #define MISPEC_SPECTRA_DENSE_H
 
 #include <cstddef>
+#include <type_traits>
+#include <stdexcept>
 #include <vector>
 
 #if !defined(MISPEC_NO_EIGEN) && defined(__has_include)
@@ -121,6 +123,40 @@ class WidenedIn<float>
 public:
     WidenedIn(const float* p, std::size_t count) : m_buf(p, p + (p ? count : 0)) {}
     const double* data() const { return m_buf.data(); }
+};
+
+// The index arrays of a compressed sparse matrix seen as const int32_t* — what the device stores (mispec_csr: int32 indices,
+// n < 2^31).  StorageIndex = int: the caller's arrays themselves; any other integer type (the reference takes any StorageIndex,
+// MatOp/SparseSymMatProd.h:30): a narrowed copy, std::invalid_argument if an index does not fit.
+template <typename I>
+class Int32Indices
+{
+    std::vector<int> m_buf;
+    const int* m_p;
+
+public:
+    Int32Indices(const I* p, std::size_t count) : m_p(nullptr)
+    {
+        static_assert(std::is_integral<I>::value, "StorageIndex must be an integer type");
+        m_buf.resize(p ? count : 0);
+        for (std::size_t i = 0; i < m_buf.size(); i++)
+        {
+            if (p[i] < I(0) || static_cast<unsigned long long>(p[i]) > 2147483647ull)
+                throw std::invalid_argument("sparse matrix: an index does not fit the device's int32 indices");
+            m_buf[i] = static_cast<int>(p[i]);
+        }
+        m_p = m_buf.data();
+    }
+    const int* data() const { return m_p; }
+};
+template <>
+class Int32Indices<int>
+{
+    const int* m_p;
+
+public:
+    Int32Indices(const int* p, std::size_t) : m_p(p) {}
+    const int* data() const { return m_p; }
 };
 
 template <typename T>

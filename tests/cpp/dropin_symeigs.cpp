@@ -143,6 +143,55 @@ static void run_test_sets(const Csc& A, int k, int m)
     }
 }
 
+// A StorageIndex other than int (the reference's operators take any, MatOp/SparseSymMatProd.h:30): the same fixture with 64-bit
+// index arrays through SparseSymMatProd / SparseGenMatProd / SparseSymShiftSolve — narrowed to the device's int32 at ingest; the
+// solve must be the int one's bit for bit.
+static void run_wide_storage_index(const Csc& A, int k, int m)
+{
+    const std::vector<long long> colptr(A.colptr.begin(), A.colptr.end()), rowind(A.rowind.begin(), A.rowind.end());
+    SparseView<double, long long> v;
+    v.rows = v.cols = A.n;
+    v.outer = colptr.data();
+    v.inner = rowind.data();
+    v.values = A.val.data();
+    v.row_major = false;
+    SparseSymMatProd<double, Lower, ColMajor, long long> op64(v);
+    SparseSymMatProd<double> op32(A.view());
+    SymEigsSolver<SparseSymMatProd<double, Lower, ColMajor, long long>> e64(op64, k, m);
+    SymEigsSolver<SparseSymMatProd<double>> e32(op32, k, m);
+    e64.init();
+    e32.init();
+    REQUIRE(e64.compute(SortRule::LargestAlge) == k && e32.compute(SortRule::LargestAlge) == k);
+    const auto a = e64.eigenvalues(), b = e32.eigenvalues();
+    for (int i = 0; i < k; i++)
+        REQUIRE(a[i] == b[i]);
+    REQUIRE(e64.num_operations() == e32.num_operations());
+    SparseGenMatProd<double, ColMajor, long long> g64(v);
+    REQUIRE(g64.rows() == A.n && g64.cols() == A.n);
+    std::vector<double> x(A.n, 1.0), y64(A.n), y32(A.n);
+    g64.perform_op(x.data(), y64.data());
+    SparseGenMatProd<double> g32(A.view());
+    g32.perform_op(x.data(), y32.data());
+    for (int i = 0; i < A.n; i++)
+        REQUIRE(y64[i] == y32[i]);
+    // an index beyond int32 is refused like a bad argument
+    std::vector<long long> bad = rowind;
+    if (!bad.empty())
+        bad[0] = 3000000000LL;
+    v.inner = bad.data();
+    bool threw = false;
+    try
+    {
+        SparseSymMatProd<double, Lower, ColMajor, long long> nope(v);
+    }
+    catch (const std::invalid_argument&)
+    {
+        threw = true;
+    }
+    REQUIRE(threw);
+    std::printf("StorageIndex = long long: n=%d identical to the int solve\n", A.n);
+}
+
 // test/GenEigs.cpp:38-108 on the same fixture read as a general matrix (complex results)
 static void run_gen_sets(const Csc& A, int k, int m)
 {
@@ -709,6 +758,7 @@ int main()
         run_test_sets(gen_sparse_data(100, 0.1), 10, 20);   // :145-155
         run_test_sets(gen_sparse_data(1000, 0.01), 20, 50); // :157-167
 
+        run_wide_storage_index(gen_sparse_data(100, 0.1), 10, 20);  // StorageIndex = long long (round 6)
         run_gen_sets(gen_sparse_data(100, 0.1), 10, 30);    // test/GenEigs.cpp:154-163
         run_gen_sets(gen_sparse_data(1000, 0.01), 20, 50);  // :165-174
         run_shift(gen_sparse_data(100, 0.1), 10, 20, 10.0);     // test/SymEigsShift.cpp:160-171
