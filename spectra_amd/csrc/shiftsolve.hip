@@ -2,14 +2,17 @@
 // (replaces MatOp/SparseSymShiftSolve.h:85-109, which delegates to Eigen::SparseLU).
 //
 // Two factorisations, chosen from the half-bandwidth b of A - sigma I at set_shift():
-//   * banded (b <= 8): a recursive "partition + Schur complement" LDL' — the parallel form of a band
+//   * banded (b <= 8 at any n, b <= 64 beyond n = 4096 — as given or after a reverse Cuthill-McKee ordering): a recursive "partition + Schur complement" LDL' — the parallel form of a band
 //     solve.  The rows are cut into chunks of L rows; the last b rows of every chunk form a separator,
-//     the rest (the interior) of different chunks are decoupled.  Factor (host, once per shift): banded
+//     the rest (the interior) of different chunks are decoupled.  Factor (once per shift; b <= 8: top levels on the device,
+//     k_chunk_factor; wider bands: on the host's cores, chunk-parallel): banded
 //     LDL' of every interior block, the spikes W = M_II^{-1} M_IS, and the Schur complement of the
 //     separators, which is again banded (half-bandwidth 2b-1) and is factored the same way, recursively,
 //     until it fits one chunk.  Solve (device, every Lanczos step), per level three kernels:
 //        k_chunk_solve  one thread per chunk: forward/backward substitution on its interior block
-//                       (factors stored chunk-interleaved => coalesced across the threads of a wave)
+//                       (factors stored chunk-interleaved => coalesced across the threads of a wave);
+//                       k_chunk_solve_lds: the same, LDS-staged, for b <= 8 (the measured path, C5);
+//                       k_chunk_solve_wave (round 6): one WAVEFRONT per chunk for b = 9...64 on a row-major factor
 //        k_sep_rhs      g_S = f_S - M_SI y_I
 //        k_back_subst   x_I = y_I - W x_S   (one thread per row, fully parallel)
 //     The sequential depth per level is L rows instead of n.  No pivoting inside the chunks: exact when A - sigma I

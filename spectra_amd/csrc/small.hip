@@ -1,7 +1,9 @@
-// ncv x ncv kernels of the implicit restart: one workgroup (one wavefront), everything in LDS.
-// They are latency-bound (no roofline): what they buy is that H, the rotations and Q never leave
-// the device between the factorisation and compress_V (Q is consumed by the V*Q kernel straight
-// from HBM, 12.8 KB at ncv = 40), and only 2*ncv doubles cross PCIe per restart.
+// ncv x ncv kernels of the implicit restart: one workgroup, everything in LDS — one wavefront each, except
+// k_restart_pipelined (round 6: the shifted QR sweeps as a skewed pipeline over four wavefronts, the host's bits).
+// They are latency-bound (no roofline) and SLOWER than a host core (serial chains of fp64 divisions and square roots:
+// 110 us pipelined / 380 us on one wavefront against 13 us on the core at ncv = 40, profiles/r11g): the default runs
+// the host routines, option small=device these kernels (H, the rotations and Q then never leave the device between
+// the factorisation and compress_V).
 #include "small.hpp"
 
 #include <Spectra/internal/SmallDense.h>
