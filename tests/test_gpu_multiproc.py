@@ -148,3 +148,30 @@ def test_bench_with_eight_ranks_end_to_end():
     w = d["wire"]
     assert w["exchanges"] >= w["operations"] - 2 and w["allreduces"] >= w["operations"]  # one exchange per product, >= one reduction per step
     assert d["wire_overlap_frac"] is None or d["wire_overlap_frac"] <= 1.0
+
+
+@pytest.mark.parametrize("transport", ["rccl-strict", "torch"])
+def test_one_rank_over_the_real_rccl_transports(ctx, tmp_path, transport):
+    # The transports an 8-GPU run uses — the library's own RCCL communicator (dlopen'd librccl, ncclCommInitRank from a broadcast
+    # unique id; `rccl-strict`: no fallback) and torch.distributed's collectives — cannot meet a second GPU on this box; with
+    # MISPEC_FORCE_COMM=1 they are attached for ONE rank, so that at least the loading of the library, the communicator, and
+    # every collective call of a sharded solve (all-gather / send-recv plan over one rank, the batched all-reduces) run on the
+    # device.  The solve must equal the unsharded one bit for bit (one rank owns every row; sums over one rank are copies).
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    n, offsets, nev, ncv = 40_003, (1, 2, 3, 50, 51, 1500, 1501), 6, 20
+    env = dict(os.environ, MP_OUT=str(tmp_path), MP_TRANSPORT=transport, MP_DEVICE="own", MISPEC_FORCE_COMM="1", MP_N=str(n),
+               MP_OFFSETS=",".join(map(str, offsets)), MP_NEV=str(nev), MP_NCV=str(ncv))
+    env.pop("MISPEC_EXCHANGE", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "mp_worker.py")]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-4000:]
+    d = dict(np.load(os.path.join(str(tmp_path), "rank0.npz")))
+    op = sa.SparseSymMatProd.synth_band(n, offsets=offsets, ctx=ctx)
+    e = sa.SymEigsSolver(op, nev, ncv)
+    e.init()
+    assert e.compute(sa.SortRule.LargestMagn, 1000, 1e-11) == nev == int(d["nconv"])
+    assert np.array_equal(e.eigenvalues(), d["evals"]) and int(e.num_operations()) == int(d["nops"])
+    assert d["res"].max() <= 1e-10
