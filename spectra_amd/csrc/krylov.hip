@@ -1731,6 +1731,10 @@ int launch_orth_panel(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a, i
         if (depth)
             return launch_orth_lagged_dma(ctx, a, depth, flags);
     }
+    // the passes of the reference flow and of the Arnoldi process through the same LDS ring (orth_dma_modes.hip; option
+    // orth_kernel=reg: the register kernels below for every mode)
+    if (mode != ORTH_LAGGED && grid == 0 && kOrthDmaDefault && orth_dma_modes_eligible(mode, a) && !option_is("orth_kernel", "reg"))
+        return launch_orth_dma_mode(ctx, mode, a);
     if (grid == 0)
     {
         const int rows = orth_tile_rows(a.ncol);

@@ -135,6 +135,10 @@ struct OrthArgs
 bool orth_lagged_dma_eligible(const OrthArgs& a);
 int launch_orth_lagged_dma(const mispec_ctx& ctx, const OrthArgs& a, int depth_override, int flags = 0);
 
+// The other modes (reference flow, Arnoldi) the same way (orth_dma_modes.hip): one column panel, vectors of at least 1024 tiles.
+bool orth_dma_modes_eligible(OrthMode mode, const OrthArgs& a);
+int launch_orth_dma_mode(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a);
+
 // All launchers enqueue on ctx.stream and return immediately.
 int launch_orth(const mispec_ctx& ctx, OrthMode mode, const OrthArgs& a);  // returns the number of partial records
 // red[0..kPartialLd): column sums of the records (+ max for kSlotMaxAbs); finish additionally fills kSlotBeta / kSlotErr.

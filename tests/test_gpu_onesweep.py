@@ -426,3 +426,29 @@ def test_the_lds_dma_pass_equals_the_register_pass(ctx, n, k, m):
         assert (nops, nit) == ref[1:3], (kernel, nops, nit, ref[1:3])
         assert np.abs(ev - ref[0]).max() <= 1e-13 * np.abs(ref[0]).max()
         assert lagged == ref[3]
+
+
+@pytest.mark.parametrize("n,k,m", [(131_075, 20, 40), (200_000, 10, 64)])
+def test_the_lds_dma_passes_of_the_reference_flow_equal_the_register_passes(ctx, n, k, m):
+    # ... and the passes of the reference's two-pass control flow (k_orth: RESID_VTF / CORRECT_VTF) and of the Arnoldi process
+    # (VTF / CORRECT_ONLY) through the same LDS ring (csrc/orth_dma_modes.hip), against the register kernels (orth_kernel=reg):
+    # the same solve to rounding — equal counters, eigenvalues to 1e-13.
+    op = sa.SparseSymMatProd.synth_band(n, ctx=ctx)
+    gop = sa.SparseGenMatProd.synth_band(n, ctx=ctx)
+    runs = {}
+    try:
+        for kernel in ("reg", None):
+            sa.set_option("orth_kernel", kernel)
+            e, nconv = solve(op, k, m, sa.SortRule.LargestMagn, "reference", maxit=1000, tol=1e-11)
+            assert nconv == k and e.residuals().max() <= 1e-10
+            g = sa.GenEigsSolver(gop, 6, 24)
+            g.init()
+            gconv = g.compute(sa.SortRule.LargestMagn, 1000, 1e-10)
+            assert gconv == 6 and g.residuals().max() <= 1e-9
+            runs[kernel] = (e.eigenvalues(), e.num_operations(), e.num_iterations(), g.eigenvalues(), g.num_operations())
+    finally:
+        sa.set_option("orth_kernel", None)
+    a, b = runs["reg"], runs[None]
+    assert a[1:3] == b[1:3] and a[4] == b[4]
+    assert np.abs(a[0] - b[0]).max() <= 1e-13 * np.abs(a[0]).max()
+    assert np.abs(np.sort_complex(a[3]) - np.sort_complex(b[3])).max() <= 1e-12 * np.abs(a[3]).max()
