@@ -59,6 +59,7 @@ const char* mispec_version(void);
  *   spec_corr       corrections enqueued speculatively per step (reference flow)
  *   overlap, exchange                                                    sharded product: 0 switches the overlap / the neighbour exchange off
  *   csr_win, csr_win_iters, csr_win_pf, csr_win_nt, dia2, spmv_tiles, spmv_staged, reorder, kernel_probe   SpMV format / kernel choice
+ *   host_threads    upper bound on the host threads of the ingest / the shift solve's host-side factorisation (tests: results do not depend on it)
  *   vq              mfma: the f64-MFMA variant of V*Q
  *   shift           banded shift solve: key=value list — kernel variants that must agree (tests) and profile=1 (set_shift's phases on stderr)
  * The reference has no counterpart (its only switches are template parameters). */

@@ -52,7 +52,7 @@ OptionTable& option_table()
 const char* const kOptionNames[] = {
     "csr_win", "spmv_tiles", "reorder", "spmv_staged", "dia2", "csr_win_iters", "csr_win_pf", "csr_win_nt", "kernel_probe",
     "overlap", "exchange", "small", "spec_corr", "one_reduction", "host_steps", "orth", "restart_sync", "vq", "shift",
-    "host_turn", "orth_kernel", nullptr};
+    "host_turn", "orth_kernel", "host_threads", nullptr};
 }  // namespace
 
 const char* option(const char* name)
@@ -86,7 +86,10 @@ int ingest_threads()
         const unsigned hw = std::thread::hardware_concurrency();
         return int(std::min(64u, std::max(1u, hw)));
     }();
-    return n;
+    // option host_threads (tests): an upper bound on the host threads of the ingest and of the shift solve's host-side
+    // factorisation — their results must not depend on it
+    const int cap = option_int("host_threads", 0);
+    return cap >= 1 ? std::min(n, cap) : n;
 }
 
 void parallel_ranges(int64_t n, int parts, const std::function<void(int, int64_t, int64_t)>& fn)

@@ -403,3 +403,14 @@ def test_wave_per_chunk_solve_equals_the_lane_per_chunk_solve_bit_for_bit():
     assert [w[0] for w in wave] == [l[0] for l in lane], (wave, lane)
     for (crc, res, steps), case in zip(wave, cases):
         assert float(res) <= (1e-10 if case[3] else 1e-12), (case, res)
+
+
+def test_the_host_side_factorisation_does_not_depend_on_the_thread_count():
+    # Levels factored on the host (half-bandwidth > 8, and the last level's explicit inverse of every band) run chunk-parallel /
+    # column-parallel on the host's cores since round 6, with a fixed-order assembly of the Schur complement: one thread and all
+    # of them must give the SAME BITS (option host_threads).
+    cases = [(100_000, 32, 0.0, 0), (60_000, 12, -0.5, 0), (300_001, 5, 0.0, 0), (120_000, 16, 0.3, 1)]
+    many = _solve_in_subprocess({}, cases)
+    one = _solve_in_subprocess({"MISPEC_HOST_THREADS": "1"}, cases)
+    three = _solve_in_subprocess({"MISPEC_HOST_THREADS": "3"}, cases)
+    assert [m[0] for m in many] == [o[0] for o in one] == [t[0] for t in three], (many, one, three)
