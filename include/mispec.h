@@ -50,7 +50,7 @@ const char* mispec_version(void);
  * and the parity tests use.  Unknown names: MISPEC_EINVAL.  Names and values:
  *   orth            onesweep (default) | onesweep-eager | reference      control flow of the Lanczos steps at creation
  *   one_reduction   1 (default) | 0                                      one reduction per one-sweep step
- *   orth_kernel     dma (default, >= 65536 rows) | dma2 | dmac | dmap | reg   the one-sweep pass: LDS-DMA ring or registers
+ *   orth_kernel     dma (default, >= 131072 rows) | dma2 | dmac | dmap | reg   the one-sweep pass: LDS-DMA ring or registers
  *   host_turn       fast (default) | copy                                restart's host turn: pinned-memory kernels or hipMemcpy
  *   small           host (default) | host-serial | device                where the ncv x ncv work of a restart runs (host: the shifted
  *                                                                        QR sweeps as a skewed pipeline; host-serial: in the reference's order, same bits)
